@@ -1,0 +1,2155 @@
+// oracle/cvd_oracle.cpp
+//
+// *** TEST INFRASTRUCTURE ONLY -- never imported, linked or executed by the product path. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library.
+//
+// CPU restatement (double precision, forward-mode dual numbers in passes of 4, Ceres-default
+// Levenberg-Marquardt with an exact Cholesky solve) of the geometric-consistency optimizer of
+// facebookresearch/robust_cvd:
+//     lib/PoseOptimizer.cpp, lib/DepthMapTransform.cpp, lib/ValueTransform.h, lib/Processor.cpp:888-1013
+// Each function cites the reference file:line it follows (paths relative to the reference root).
+//
+// PARITY UNPINNED: the reference cannot be built here (Ceres / Eigen / OpenCV / glog / fmt / boost are
+// neither vendored nor installed) and ships no tests, golden vectors or fixtures for this
+// path.  The arithmetic that lives in Ceres (version unpinned by the reference's CMake:
+// `find_package(Ceres REQUIRED)`, lib/CMakeLists.txt:35) is restated from its published algorithm:
+//   ceres/rotation.h        AngleAxisRotatePoint, RotationMatrixToAngleAxis, AngleAxisToRotationMatrix
+//   ceres/jet.h             Jet<double,4> (oracle/jet.h)
+//   ceres/loss_function.cc  CauchyLoss, ScaledLoss;  ceres/corrector.cc  Corrector
+//   ceres/trust_region_minimizer.cc + levenberg_marquardt_strategy.cc  (default Solver::Options)
+// The oracle is pinned instead by independent cross-checks in tests/ (central finite differences,
+// closed forms, zero-noise ground-truth recovery, scipy least_squares on the same residuals).
+//
+// Build: oracle/Makefile -> oracle/_build/libcvd_oracle.so  (g++ -O2 -ffp-contract=off -fopenmp)
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/cvd_types.h"
+#include "jet.h"
+
+namespace cvdo {
+
+static double nowSeconds() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// =====================================================================================================
+// ceres/rotation.h restatement
+// =====================================================================================================
+
+// ceres::AngleAxisRotatePoint (used at reference lib/PoseOptimizer.cpp:185,211).
+template <typename T>
+void angleAxisRotatePoint(const T aa[3], const T pt[3], T result[3]) {
+  const T theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (scalar(theta2) > std::numeric_limits<double>::epsilon()) {
+    const T theta = tsqrt(theta2);
+    const T costheta = tcos(theta);
+    const T sintheta = tsin(theta);
+    const T theta_inverse = T(1.0) / theta;
+    const T w[3] = {aa[0] * theta_inverse, aa[1] * theta_inverse, aa[2] * theta_inverse};
+    const T w_cross_pt[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2],
+                             w[0] * pt[1] - w[1] * pt[0]};
+    const T tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (T(1.0) - costheta);
+    result[0] = pt[0] * costheta + w_cross_pt[0] * sintheta + w[0] * tmp;
+    result[1] = pt[1] * costheta + w_cross_pt[1] * sintheta + w[1] * tmp;
+    result[2] = pt[2] * costheta + w_cross_pt[2] * sintheta + w[2] * tmp;
+  } else {
+    // Near zero: first-order Taylor R ~ I + [aa]x. Every frame starts exactly here (identity poses).
+    const T w_cross_pt[3] = {aa[1] * pt[2] - aa[2] * pt[1], aa[2] * pt[0] - aa[0] * pt[2],
+                             aa[0] * pt[1] - aa[1] * pt[0]};
+    result[0] = pt[0] + w_cross_pt[0];
+    result[1] = pt[1] + w_cross_pt[1];
+    result[2] = pt[2] + w_cross_pt[2];
+  }
+}
+
+// ceres::RotationMatrixToAngleAxis on a column-major 3x3 (reference lib/PoseOptimizer.cpp:779):
+// RotationMatrixToQuaternion followed by QuaternionToAngleAxis.
+static void rotationMatrixToAngleAxis(const double R[9] /*col-major*/, double aa[3]) {
+  auto M = [&](int r, int c) { return R[r + 3 * c]; };
+  double q[4];
+  const double trace = M(0, 0) + M(1, 1) + M(2, 2);
+  if (trace >= 0.0) {
+    double t = std::sqrt(trace + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (M(2, 1) - M(1, 2)) * t;
+    q[2] = (M(0, 2) - M(2, 0)) * t;
+    q[3] = (M(1, 0) - M(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    const int j = (i + 1) % 3;
+    const int k = (j + 1) % 3;
+    double t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i + 1] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (M(k, j) - M(j, k)) * t;
+    q[j + 1] = (M(j, i) + M(i, j)) * t;
+    q[k + 1] = (M(k, i) + M(i, k)) * t;
+  }
+  const double sin_squared_theta = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (sin_squared_theta > 0.0) {
+    const double sin_theta = std::sqrt(sin_squared_theta);
+    const double cos_theta = q[0];
+    const double two_theta = 2.0 * ((cos_theta < 0.0) ? std::atan2(-sin_theta, -cos_theta)
+                                                       : std::atan2(sin_theta, cos_theta));
+    const double k = two_theta / sin_theta;
+    aa[0] = q[1] * k;
+    aa[1] = q[2] * k;
+    aa[2] = q[3] * k;
+  } else {
+    aa[0] = q[1] * 2.0;
+    aa[1] = q[2] * 2.0;
+    aa[2] = q[3] * 2.0;
+  }
+}
+
+// ceres::AngleAxisToRotationMatrix, column-major output (reference lib/PoseOptimizer.cpp:972).
+static void angleAxisToRotationMatrix(const double aa[3], double R[9] /*col-major*/) {
+  auto M = [&](int r, int c) -> double& { return R[r + 3 * c]; };
+  const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > std::numeric_limits<double>::epsilon()) {
+    const double theta = std::sqrt(theta2);
+    const double wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const double c = std::cos(theta), s = std::sin(theta);
+    M(0, 0) = c + wx * wx * (1.0 - c);
+    M(1, 0) = wz * s + wx * wy * (1.0 - c);
+    M(2, 0) = -wy * s + wx * wz * (1.0 - c);
+    M(0, 1) = wx * wy * (1.0 - c) - wz * s;
+    M(1, 1) = c + wy * wy * (1.0 - c);
+    M(2, 1) = wx * s + wy * wz * (1.0 - c);
+    M(0, 2) = wy * s + wx * wz * (1.0 - c);
+    M(1, 2) = -wx * s + wy * wz * (1.0 - c);
+    M(2, 2) = c + wz * wz * (1.0 - c);
+  } else {
+    M(0, 0) = 1.0;  M(1, 0) = aa[2];  M(2, 0) = -aa[1];
+    M(0, 1) = -aa[2]; M(1, 1) = 1.0;  M(2, 1) = aa[0];
+    M(0, 2) = aa[1]; M(1, 2) = -aa[0]; M(2, 2) = 1.0;
+  }
+}
+
+// Eigen::Quaterniond(Matrix3d) (reference lib/PoseOptimizer.cpp:974); q = (x, y, z, w).
+static void rotationMatrixToEigenQuaternion(const double R[9] /*col-major*/, double q[4]) {
+  auto M = [&](int r, int c) { return R[r + 3 * c]; };
+  double t = M(0, 0) + M(1, 1) + M(2, 2);
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (M(2, 1) - M(1, 2)) * t;
+    q[1] = (M(0, 2) - M(2, 0)) * t;
+    q[2] = (M(1, 0) - M(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    const int j = (i + 1) % 3;
+    const int k = (j + 1) % 3;
+    t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (M(k, j) - M(j, k)) * t;
+    q[j] = (M(j, i) + M(i, j)) * t;
+    q[k] = (M(k, i) + M(i, k)) * t;
+  }
+}
+
+// Eigen quaternion * vector (reference lib/PoseOptimizer.cpp:769-772): v + w*uv + qv x uv, uv = 2 qv x v.
+static void quatRotate(const double q[4] /*x,y,z,w*/, const double v[3], double out[3]) {
+  const double uv[3] = {2.0 * (q[1] * v[2] - q[2] * v[1]), 2.0 * (q[2] * v[0] - q[0] * v[2]),
+                        2.0 * (q[0] * v[1] - q[1] * v[0])};
+  out[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+  out[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+  out[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+// =====================================================================================================
+// Value transform (reference lib/ValueTransform.h:57-94)
+// =====================================================================================================
+static int valueNumParams(int type) {
+  if (type == CVD_VALUE_SCALE) return 1;
+  if (type == CVD_VALUE_SCALE_SHIFT) return 2;
+  throw std::runtime_error("Invalid value transform.");
+}
+template <typename T>
+static T valueXform(int type, const T& src, const T* p) {
+  if (type == CVD_VALUE_SCALE) return src * p[0];
+  return (src * p[0]) + p[1];
+}
+
+// =====================================================================================================
+// Transforms and their per-sample gathers (reference lib/DepthMapTransform.cpp)
+// =====================================================================================================
+
+// cubicSpline, reference lib/DepthMapTransform.cpp:671-678
+static void cubicSpline(std::array<double, 4>& w, const double t) {
+  const double t2 = t * t;
+  const double t3 = t2 * t;
+  w[0] = -0.5 * t3 + t2 - 0.5 * t;
+  w[1] = 1.5 * t3 - 2.5 * t2 + 1.0;
+  w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t;
+  w[3] = 0.5 * t3 - 0.5 * t2;
+}
+
+struct Gather {
+  int n = 0;
+  int idx[16];  // parameter-block index inside the transform (vertex id)
+  double w[16];
+};
+
+struct Xform {
+  cvd_xform_desc desc{};
+  std::vector<double> params;
+  int blockSize = 0;
+  int numBlocks = 0;
+
+  bool isDepth() const { return desc.type == CVD_XFORM_DEPTH; }
+
+  // createDepthXform / createSpatialXform, reference lib/DepthMapTransform.cpp:1435-1491
+  static Xform create(const cvd_xform_desc& d) {
+    Xform x;
+    x.desc = d;
+    if (d.type == CVD_XFORM_DEPTH) {
+      switch (d.depth_type) {
+        case CVD_DEPTH_IDENTITY:
+          x.blockSize = 0;
+          x.numBlocks = 0;
+          break;
+        case CVD_DEPTH_GLOBAL:  // :526-534
+          x.blockSize = valueNumParams(d.value_xform);
+          x.numBlocks = 1;
+          x.params.assign(x.blockSize, 1.0);
+          break;
+        case CVD_DEPTH_GRID: {  // :682-737
+          const int gx = d.grid_size[0], gy = d.grid_size[1], gz = d.grid_size[2];
+          if (gx > 1 || gy > 1) {
+            if (gx < 2 || gy < 2)
+              throw std::runtime_error(
+                  "Spatial grid transforms must have at least two rows and columns, respectively.");
+          }
+          x.blockSize = valueNumParams(d.value_xform);
+          const int np = x.blockSize * gx * gy * gz;
+          if (np <= 1) throw std::runtime_error("Grid transform cannot have an empty grid.");
+          if (gz > 1) {
+            if (d.depth_min_max[0] <= 0.0 || d.depth_min_max[1] <= 0.0)
+              throw std::runtime_error("Depth values must be positive.");
+            if (d.depth_min_max[1] - d.depth_min_max[0] <= 0.0)
+              throw std::runtime_error("Depth range must be positive.");
+          }
+          x.numBlocks = gx * gy * gz;
+          x.params.assign(np, 1.0);
+          break;
+        }
+        default:
+          throw std::runtime_error("Invalid depth transform type.");
+      }
+    } else if (d.type == CVD_XFORM_SPATIAL) {
+      x.blockSize = 2;
+      switch (d.spatial_type) {
+        case CVD_SPATIAL_IDENTITY:
+          x.blockSize = 0;
+          x.numBlocks = 0;
+          break;
+        case CVD_SPATIAL_VERTICAL_LINEAR:  // :1098-1105
+          x.numBlocks = 2;
+          break;
+        case CVD_SPATIAL_CORNERS_BILINEAR:  // :1172-1179
+          x.numBlocks = 4;
+          break;
+        case CVD_SPATIAL_BILINEAR_GRID:
+        case CVD_SPATIAL_BICUBIC_GRID:  // :1346-1363
+          if (d.grid_size[1] < 2 || d.grid_size[0] < 2)
+            throw std::logic_error("Need at least two rows and columns in depth transform grid.");
+          x.numBlocks = d.grid_size[0] * d.grid_size[1];
+          break;
+        default:
+          throw std::runtime_error("Invalid spatial transform type.");
+      }
+      x.params.assign(static_cast<size_t>(x.numBlocks) * x.blockSize, 0.0);
+    } else {
+      throw std::runtime_error("Invalid transform type.");
+    }
+    return x;
+  }
+
+  // Cell coordinates shared by every grid gather, reference lib/DepthMapTransform.cpp:750-764.
+  static void cell(const float loc, const int g, int& i, double& r) {
+    const double maxc = std::nextafter(static_cast<double>(g - 1), 0.0);
+    const double s = std::min(std::max((loc + 1.0) * (g - 1) / 2.0, 0.0), maxc);
+    i = static_cast<int>(s);
+    r = s - i;
+  }
+
+  // GridDepthXform::linearGather, reference lib/DepthMapTransform.cpp:739-851
+  void linearGather(const float srcDepth, const float lx, const float ly, Gather& g) const {
+    const int gx = desc.grid_size[0], gy = desc.grid_size[1], gz = desc.grid_size[2];
+    const bool spatial = gx > 1;
+    const bool depthWise = gz > 1;
+    if (blockSize != 1 && (spatial || depthWise)) {
+      // The reference indexes `&params_[i]` (not i*N) here (:829-832): with ScaleShift the blocks alias
+      // and ceres::Problem aborts on overlapping parameter blocks. Not a defined configuration.
+      throw std::runtime_error(
+          "Linear grid gather is only defined for 1-parameter value transforms (reference :829).");
+    }
+    int ix = 0, iy = 0, iz = 0;
+    double rx = 0, ry = 0, rz = 0;
+    if (spatial) {
+      cell(lx, gx, ix, rx);
+      cell(ly, gy, iy, ry);
+    }
+    if (depthWise) {
+      const double dispMin = 1.0 / desc.depth_min_max[1];
+      const double dispMax = 1.0 / desc.depth_min_max[0];
+      const double interval = (dispMax - dispMin) / (gz - 1);
+      const double maxz = std::nextafter(static_cast<double>(gz - 1), 0.0);
+      const double srcDisparity = 1.0 / static_cast<double>(srcDepth);
+      const double sz = std::min(std::max((srcDisparity - dispMin) / interval, 0.0), maxz);
+      iz = static_cast<int>(sz);
+      rz = sz - iz;
+    }
+    const int ys = gx, zs = gx * gy;
+    if (spatial && depthWise) {
+      g.n = 8;
+      const int i0 = ix + iy * ys + iz * zs;
+      const int ids[8] = {i0, i0 + 1, i0 + ys, i0 + ys + 1, i0 + zs, i0 + zs + 1, i0 + zs + ys,
+                          i0 + zs + ys + 1};
+      const double ws[8] = {(1.0 - rx) * (1.0 - ry) * (1.0 - rz), rx * (1.0 - ry) * (1.0 - rz),
+                            (1.0 - rx) * ry * (1.0 - rz),         rx * ry * (1.0 - rz),
+                            (1.0 - rx) * (1.0 - ry) * rz,         rx * (1.0 - ry) * rz,
+                            (1.0 - rx) * ry * rz,                 rx * ry * rz};
+      for (int k = 0; k < 8; ++k) { g.idx[k] = ids[k]; g.w[k] = ws[k]; }
+    } else if (spatial) {
+      g.n = 4;
+      const int i0 = ix + iy * ys;
+      g.idx[0] = i0;          g.w[0] = (1.0 - rx) * (1.0 - ry);
+      g.idx[1] = i0 + 1;      g.w[1] = rx * (1.0 - ry);
+      g.idx[2] = i0 + ys;     g.w[2] = (1.0 - rx) * ry;
+      g.idx[3] = i0 + ys + 1; g.w[3] = rx * ry;
+    } else if (depthWise) {
+      g.n = 2;
+      g.idx[0] = iz;     g.w[0] = 1.0 - rz;
+      g.idx[1] = iz + 1; g.w[1] = rz;
+    } else {
+      g.n = 0;
+    }
+  }
+
+  // Shared 2-D cubic gather with border folding: GridDepthXform::cubicGather
+  // (reference lib/DepthMapTransform.cpp:853-948, gridSize.z == 1 only: quirk q3 -- wz is never applied
+  // and wx/wy are uninitialised for z-only grids) and bicubicSpatialGridGather (:1288-1343).
+  static void cubicGather2d(const float lx, const float ly, const int gx, const int gy, Gather& g) {
+    int ix, iy;
+    double rx, ry;
+    cell(lx, gx, ix, rx);
+    cell(ly, gy, iy, ry);
+    std::array<double, 4> wx, wy;
+    cubicSpline(wx, rx);
+    cubicSpline(wy, ry);
+    const int x0 = (ix == 0 ? 1 : 0);
+    const int x1 = (ix == gx - 2 ? 3 : 4);
+    const int y0 = (iy == 0 ? 1 : 0);
+    const int y1 = (iy == gy - 2 ? 3 : 4);
+    const int xstride = x1 - x0;
+    const int ystride = y1 - y0;
+    g.n = 0;
+    for (int y = y0; y < y1; ++y) {
+      const int py = iy - 1 + y;
+      for (int x = x0; x < x1; ++x) {
+        const int px = ix - 1 + x;
+        g.idx[g.n] = px + py * gx;
+        g.w[g.n] = 0.0;
+        ++g.n;
+      }
+    }
+    for (int y = 0; y < 4; ++y) {
+      for (int x = 0; x < 4; ++x) {
+        const int cx = std::min(std::max(x - x0, 0), xstride - 1);
+        const int cy = std::min(std::max(y - y0, 0), ystride - 1);
+        g.w[cx + cy * xstride] += wx[x] * wy[y];
+      }
+    }
+  }
+
+  // DepthXform::createFunctor: which blocks / weights a sample at `loc` with `srcDepth` depends on.
+  // reference lib/DepthMapTransform.cpp:483-486 (identity), :536-540 (global), :1016-1027 (grid)
+  void depthGather(const float srcDepth, const float lx, const float ly, Gather& g) const {
+    switch (desc.depth_type) {
+      case CVD_DEPTH_IDENTITY:
+        g.n = 0;
+        break;
+      case CVD_DEPTH_GLOBAL:
+        g.n = 1;
+        g.idx[0] = 0;
+        g.w[0] = 1.0;
+        break;
+      case CVD_DEPTH_GRID:
+        if (desc.cubic_interpolation) {
+          if (desc.grid_size[2] > 1 || desc.grid_size[0] < 2)
+            throw std::runtime_error(
+                "Cubic depth grids are only defined for gridSize.z == 1 (reference quirk q3).");
+          cubicGather2d(lx, ly, desc.grid_size[0], desc.grid_size[1], g);
+        } else {
+          linearGather(srcDepth, lx, ly, g);
+        }
+        break;
+      default:
+        throw std::runtime_error("Invalid depth transform type.");
+    }
+  }
+
+  // SpatialXform::createFunctor, reference lib/DepthMapTransform.cpp:1053-1056, 1107-1114, 1181-1191,
+  // 1253-1286, 1288-1343.
+  void spatialGather(const float lx, const float ly, Gather& g) const {
+    switch (desc.spatial_type) {
+      case CVD_SPATIAL_IDENTITY:
+        g.n = 0;
+        break;
+      case CVD_SPATIAL_VERTICAL_LINEAR: {
+        const double w0 = 0.5 + 0.5 * ly;
+        g.n = 2;
+        g.idx[0] = 0; g.w[0] = w0;
+        g.idx[1] = 1; g.w[1] = 1.0 - w0;
+        break;
+      }
+      case CVD_SPATIAL_CORNERS_BILINEAR: {
+        const double wx = 0.5 + 0.5 * lx;
+        const double wy = 0.5 + 0.5 * ly;
+        g.n = 4;
+        g.idx[0] = 0; g.w[0] = wx * wy;
+        g.idx[1] = 1; g.w[1] = (1.0 - wx) * wy;
+        g.idx[2] = 2; g.w[2] = wx * (1.0 - wy);
+        g.idx[3] = 3; g.w[3] = (1.0 - wx) * (1.0 - wy);
+        break;
+      }
+      case CVD_SPATIAL_BILINEAR_GRID: {
+        const int gx = desc.grid_size[0], gy = desc.grid_size[1];
+        int ix, iy;
+        double rx, ry;
+        cell(lx, gx, ix, rx);
+        cell(ly, gy, iy, ry);
+        g.n = 4;
+        const int i0 = ix + iy * gx;
+        g.idx[0] = i0;          g.w[0] = (1.0 - rx) * (1.0 - ry);
+        g.idx[1] = i0 + 1;      g.w[1] = rx * (1.0 - ry);
+        g.idx[2] = i0 + gx;     g.w[2] = (1.0 - rx) * ry;
+        g.idx[3] = i0 + gx + 1; g.w[3] = rx * ry;
+        break;
+      }
+      case CVD_SPATIAL_BICUBIC_GRID:
+        cubicGather2d(lx, ly, desc.grid_size[0], desc.grid_size[1], g);
+        break;
+      default:
+        throw std::runtime_error("Invalid spatial transform type.");
+    }
+  }
+
+  // numDeformationCostResiduals: reference lib/DepthMapTransform.cpp:996-1002 (depth grid),
+  // :1116-1118, :1193-1195, :1365-1367 (spatial); 0 for everything else (DepthMapTransform.h:165).
+  int numDeformationResiduals() const {
+    if (isDepth()) {
+      if (desc.depth_type != CVD_DEPTH_GRID) return 0;
+      const int X = desc.grid_size[0], Y = desc.grid_size[1], Z = desc.grid_size[2];
+      const int edges = (X - 1) * Y * Z + X * (Y - 1) * Z + X * Y * (Z - 1);
+      return edges * blockSize;
+    }
+    return numBlocks * blockSize;  // paramsToResiduals (:60-70); Identity has 0 blocks
+  }
+
+  // computeDeformationCost: computeGridDeformationCost (reference lib/DepthMapTransform.cpp:631-667) for
+  // depth grids, paramsToResiduals (:60-70) for spatial transforms.
+  template <typename T>
+  void deformationCost(T const* const* p, T* residuals) const {
+    if (!isDepth()) {
+      int count = 0;
+      for (int b = 0; b < numBlocks; ++b)
+        for (int i = 0; i < blockSize; ++i) residuals[count++] = p[b][i];
+      return;
+    }
+    T* out = residuals;
+    const int X = desc.grid_size[0], Y = desc.grid_size[1], Z = desc.grid_size[2];
+    const int yStride = X, zStride = X * Y;
+    for (int z = 0; z < Z; ++z) {
+      for (int y = 0; y < Y; ++y) {
+        for (int x = 0; x < X; ++x) {
+          T const* thisBlock = p[x + y * yStride + z * zStride];
+          auto addResidual = [&](T const* thatBlock) {
+            for (int i = 0; i < blockSize; ++i) {
+              T scale = tmin(tabs(thisBlock[i]), tabs(thatBlock[i]));
+              *(out++) = (thisBlock[i] - thatBlock[i]) / scale;
+            }
+          };
+          if (x > 0) addResidual(p[(x - 1) + y * yStride + z * zStride]);
+          if (y > 0) addResidual(p[x + (y - 1) * yStride + z * zStride]);
+          if (z > 0) addResidual(p[x + y * yStride + (z - 1) * zStride]);
+        }
+      }
+    }
+  }
+};
+
+// =====================================================================================================
+// Observation + cost functors (reference lib/PoseOptimizer.cpp:91-554)
+// =====================================================================================================
+
+// Observation, reference lib/PoseOptimizer.cpp:91-128. Block order: [pose(6), depth blocks, spatial blocks].
+struct Obs {
+  float ndc[2];
+  float sourceDepth;
+  int valueType = 0;
+  int depthType = 0;
+  Gather dg;  // depth functor blocks / weights
+  Gather sg;  // spatial functor blocks / weights
+  int numBlocks() const { return 1 + dg.n + sg.n; }
+};
+
+// GridDepthFunctor::eval / GlobalDepthFunctor / IdentityDepthFunctor,
+// reference lib/DepthMapTransform.cpp:597-606, 504-510, 464-470.
+template <typename T>
+static T depthFunctor(const Obs& o, T const* const* dp) {
+  if (o.depthType == CVD_DEPTH_IDENTITY) return T(static_cast<double>(o.sourceDepth));
+  const T src(static_cast<double>(o.sourceDepth));
+  if (o.depthType == CVD_DEPTH_GLOBAL) return valueXform(o.valueType, src, dp[0]);
+  T res(0.0);
+  for (int i = 0; i < o.dg.n; ++i) res += valueXform(o.valueType, src, dp[i]) * T(o.dg.w[i]);
+  return res;
+}
+
+// GridSpatialFunctor::eval & friends, reference lib/DepthMapTransform.cpp:1225-1233, 1075-1085, 1146-1160.
+template <typename T>
+static void spatialFunctor(const Obs& o, T const* const* sp, T out[2]) {
+  out[0] = T(0.0);
+  out[1] = T(0.0);
+  for (int i = 0; i < o.sg.n; ++i) {
+    out[0] += sp[i][0] * T(o.sg.w[i]);
+    out[1] += sp[i][1] * T(o.sg.w[i]);
+  }
+}
+
+template <typename T>
+struct ObsParams {
+  T const* pose;
+  T const* const* depthXform;
+  T const* const* spatialXform;
+};
+
+// unpack, reference lib/PoseOptimizer.cpp:142-157
+template <typename T>
+static ObsParams<T> unpack(int& offset, T const* const* params, const Obs& obs) {
+  ObsParams<T> p;
+  p.pose = params[offset];
+  offset += 1;
+  p.depthXform = &params[offset];
+  offset += obs.dg.n;
+  p.spatialXform = &params[offset];
+  offset += obs.sg.n;
+  return p;
+}
+
+// obsToCamera, reference lib/PoseOptimizer.cpp:162-171
+template <typename T>
+static void obsToCamera(const Obs& obs, const ObsParams<T>& op, T out[3]) {
+  T depth = depthFunctor(obs, op.depthXform);
+  T warp[2];
+  spatialFunctor(obs, op.spatialXform, warp);
+  out[0] = T(static_cast<double>(obs.ndc[0])) + warp[0];
+  out[1] = T(static_cast<double>(obs.ndc[1])) + warp[1];
+  out[2] = depth;
+}
+
+// cameraToWorld, reference lib/PoseOptimizer.cpp:174-192
+template <typename T>
+static void cameraToWorld(const T pointCam[3], const T focal[2], T const* pose, T out[3]) {
+  T dirCam[3] = {pointCam[0] * focal[0], pointCam[1] * focal[1], T(-1.0)};
+  T dirWorld[3];
+  angleAxisRotatePoint(pose + 3, dirCam, dirWorld);
+  const T& depth = pointCam[2];
+  out[0] = pose[0] + dirWorld[0] * depth;
+  out[1] = pose[1] + dirWorld[1] * depth;
+  out[2] = pose[2] + dirWorld[2] * depth;
+}
+
+// worldToCamera, reference lib/PoseOptimizer.cpp:195-221
+template <typename T>
+static void worldToCamera(const T pointWorld[3], const T focal[2], T const* pose, T out[3]) {
+  T pointRel[3];
+  for (int i = 0; i < 3; ++i) pointRel[i] = pointWorld[i] - pose[i];
+  T rotInv[3];
+  for (int i = 0; i < 3; ++i) rotInv[i] = -pose[i + 3];
+  T pointCam[3];
+  angleAxisRotatePoint(rotInv, pointRel, pointCam);
+  const T depth = -pointCam[2];
+  out[0] = pointCam[0] / depth / focal[0];
+  out[1] = pointCam[1] / depth / focal[1];
+  out[2] = depth;
+}
+
+struct CostFunction {
+  int numResiduals = 0;
+  std::vector<int> blockSizes;
+  virtual ~CostFunction() = default;
+  virtual void evalD(double const* const* p, double* r) const = 0;
+  virtual void evalJ(Jet const* const* p, Jet* r) const = 0;
+};
+
+template <typename F>
+struct AutoDiff : CostFunction {
+  F f;
+  explicit AutoDiff(F&& fn) : f(std::move(fn)) {}
+  void evalD(double const* const* p, double* r) const override { f(p, r); }
+  void evalJ(Jet const* const* p, Jet* r) const override { f(p, r); }
+};
+
+// StaticSceneCost, reference lib/PoseOptimizer.cpp:223-319
+struct StaticSceneCost {
+  Obs obs0, obs1;
+  double fixedVFocal, aspect;
+  int intrOpt, lossType;
+  double spatialWeight, depthWeight;
+
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    int off = 0;
+    ObsParams<T> p0 = unpack(off, params, obs0);
+    ObsParams<T> p1 = unpack(off, params, obs1);
+    T focal0[2], focal1[2];
+    if (intrOpt == CVD_INTR_SHARED) {
+      focal0[1] = focal1[1] = params[off++][0];
+    } else if (intrOpt == CVD_INTR_PER_FRAME) {
+      focal0[1] = params[off++][0];
+      focal1[1] = params[off++][0];
+    } else {
+      focal0[1] = focal1[1] = T(fixedVFocal);
+    }
+    focal0[0] = focal0[1] * aspect;
+    focal1[0] = focal1[1] * aspect;
+
+    T pointCam0[3], pointWorld0[3], pointCam1[3];
+    obsToCamera(obs0, p0, pointCam0);
+    cameraToWorld(pointCam0, focal0, p0.pose, pointWorld0);
+    obsToCamera(obs1, p1, pointCam1);
+
+    if (lossType == CVD_STATIC_EUCLIDEAN) {
+      T pointWorld1[3];
+      cameraToWorld(pointCam1, focal1, p1.pose, pointWorld1);
+      for (int i = 0; i < 3; ++i) residuals[i] = pointWorld1[i] - pointWorld0[i];
+    } else {
+      T c01[3];
+      worldToCamera(pointWorld0, focal1, p1.pose, c01);
+      residuals[0] = (c01[0] - pointCam1[0]) * T(spatialWeight);
+      residuals[1] = (c01[1] - pointCam1[1]) * T(spatialWeight);
+      if (lossType == CVD_STATIC_REPRO_DISPARITY) {
+        constexpr double epsilon = 1e-6;
+        T reproDisp = 1.0 / tmax(c01[2], T(epsilon));
+        T disp1 = 1.0 / tmax(pointCam1[2], T(epsilon));
+        residuals[2] = (reproDisp - disp1) * T(depthWeight);
+      } else {
+        T maxDepth = tmax(c01[2], pointCam1[2]);
+        T minDepth = tmin(c01[2], pointCam1[2]);
+        if (lossType == CVD_STATIC_REPRO_DEPTH_RATIO) {
+          residuals[2] = (maxDepth / minDepth - 1.0) * depthWeight;
+        } else if (lossType == CVD_STATIC_REPRO_LOG_DEPTH) {
+          residuals[2] = tlog(minDepth / maxDepth) * depthWeight;
+        } else {
+          throw std::runtime_error("Invalid loss type.");
+        }
+      }
+    }
+  }
+};
+
+// SceneFlowSmoothnessLoss, reference lib/PoseOptimizer.cpp:321-423
+struct SceneFlowSmoothnessLoss {
+  Obs obs0, obs1, obs2;
+  double fixedVFocal, aspect;
+  int intrOpt, lossType;
+
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    int off = 0;
+    ObsParams<T> p0 = unpack(off, params, obs0);
+    T pc0[3];
+    obsToCamera(obs0, p0, pc0);
+    ObsParams<T> p1 = unpack(off, params, obs1);
+    T pc1[3];
+    obsToCamera(obs1, p1, pc1);
+    ObsParams<T> p2 = unpack(off, params, obs2);
+    T pc2[3];
+    obsToCamera(obs2, p2, pc2);
+
+    T f0[2], f1[2], f2[2];
+    if (intrOpt == CVD_INTR_SHARED) {
+      f0[1] = f1[1] = f2[1] = params[off++][0];
+    } else if (intrOpt == CVD_INTR_PER_FRAME) {
+      f0[1] = params[off++][0];
+      f1[1] = params[off++][0];
+      f2[1] = params[off++][0];
+    } else {
+      f0[1] = f1[1] = f2[1] = T(fixedVFocal);
+    }
+    f0[0] = f0[1] * aspect;
+    f1[0] = f1[1] * aspect;
+    f2[0] = f2[1] * aspect;
+
+    if (lossType == CVD_SMOOTH_EUCLIDEAN_LAPLACIAN) {
+      T w0[3], w1[3], w2[3];
+      cameraToWorld(pc0, f0, p0.pose, w0);
+      cameraToWorld(pc1, f1, p1.pose, w1);
+      cameraToWorld(pc2, f2, p2.pose, w2);
+      for (int i = 0; i < 3; ++i) residuals[i] = w0[i] + w2[i] - 2.0 * w1[i];
+    } else {
+      T w0[3], w2[3], c01[3], c21[3];
+      cameraToWorld(pc0, f0, p0.pose, w0);
+      cameraToWorld(pc2, f2, p2.pose, w2);
+      worldToCamera(w0, f1, p1.pose, c01);
+      worldToCamera(w2, f1, p1.pose, c21);
+      residuals[0] = (c01[0] + c21[0] - pc1[0] * 2.0) / f1[1];
+      residuals[1] = (c01[1] + c21[1] - pc1[1] * 2.0) / f1[1];
+      if (lossType == CVD_SMOOTH_REPRO_DISPARITY_LAPLACIAN) {
+        constexpr double epsilon = 1e-6;
+        T d01 = 1.0 / tmax(c01[2], T(epsilon));
+        T d1 = 1.0 / tmax(pc1[2], T(epsilon));
+        T d21 = 1.0 / tmax(c21[2], T(epsilon));
+        residuals[2] = d01 + d21 - d1 * 2.0;
+      } else {
+        T baseDepth = pc1[2];
+        T otherDepth = c01[2] + c21[2] - pc1[2];
+        T maxDepth = tmax(baseDepth, otherDepth);
+        T minDepth = tmin(baseDepth, otherDepth);
+        if (lossType == CVD_SMOOTH_REPRO_DEPTH_RATIO_CONSISTENCY) {
+          residuals[2] = (maxDepth / minDepth - 1.0);
+        } else if (lossType == CVD_SMOOTH_REPRO_LOG_DEPTH_CONSISTENCY) {
+          residuals[2] = tlog(minDepth / maxDepth);
+        } else {
+          throw std::runtime_error("Invalid loss type.");
+        }
+      }
+    }
+  }
+};
+
+// DisparityDissimilarityCost, reference lib/PoseOptimizer.cpp:425-462 (obs carry only the depth functor)
+struct DisparityDissimilarityCost {
+  Obs obs0, obs1;
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    T const* const* x0 = &params[0];
+    T const* const* x1 = &params[obs0.dg.n];
+    T depth0 = depthFunctor(obs0, x0);
+    T depth1 = depthFunctor(obs1, x1);
+    T epsilon = T(1e-6);
+    T disp0 = 1.0 / tmax(depth0, epsilon);
+    T disp1 = 1.0 / tmax(depth1, epsilon);
+    residuals[0] = disp0 - disp1;
+  }
+};
+
+// ParameterRegularizationCost, reference lib/PoseOptimizer.cpp:464-483
+struct ParameterRegularizationCost {
+  int size;
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    for (int i = 0; i < size; ++i) residuals[i] = params[0][i] - T(2.0) * params[1][i] + params[2][i];
+  }
+};
+
+// TargetDisparityCost, reference lib/PoseOptimizer.cpp:488-517
+struct TargetDisparityCost {
+  Obs obs;
+  double targetDisparity;
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    T depth = depthFunctor(obs, params);
+    T epsilon = T(1e-6);
+    T disparity = 1.0 / tmax(depth, epsilon);
+    residuals[0] = disparity - targetDisparity;
+  }
+};
+
+// TargetFocalCost, reference lib/PoseOptimizer.cpp:520-533
+struct TargetFocalCost {
+  double targetFocal;
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    residuals[0] = params[0][0] - T(targetFocal);
+  }
+};
+
+// DeformationCost, reference lib/PoseOptimizer.cpp:536-554
+struct DeformationCost {
+  const Xform* xform;
+  double baseWeight;
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    xform->deformationCost(params, residuals);
+    const int n = xform->numDeformationResiduals();
+    for (int i = 0; i < n; ++i) residuals[i] *= baseWeight;
+  }
+};
+
+// =====================================================================================================
+// ceres::Problem / evaluator restatement
+// =====================================================================================================
+
+enum LossKind { LOSS_NONE = 0, LOSS_CAUCHY = 1, LOSS_SCALED = 2 };
+
+struct ParamBlock {
+  double* ptr = nullptr;
+  int size = 0;
+  int frame = 0;   // owner frame (for deterministic parallel accumulation + canonical layout)
+  int canon = 0;   // offset in the canonical [F x B] layout
+  bool constant = false;
+  bool hasLower0 = false;
+  double lower0 = 0.0;
+  int offset = -1;  // offset in the reduced (active) parameter vector
+};
+
+struct ResidualBlock {
+  std::unique_ptr<CostFunction> cost;
+  int lossKind = LOSS_NONE;
+  double lossParam = 0.0;
+  std::vector<int> blocks;
+};
+
+struct Problem {
+  std::vector<ParamBlock> blocks;
+  std::map<const double*, int> lookup;
+  std::vector<ResidualBlock> residuals;
+  int numActive = 0;
+
+  int blockId(double* ptr, int size, int frame, int canon) {
+    auto it = lookup.find(ptr);
+    if (it != lookup.end()) return it->second;
+    ParamBlock b;
+    b.ptr = ptr;
+    b.size = size;
+    b.frame = frame;
+    b.canon = canon;
+    blocks.push_back(b);
+    lookup[ptr] = static_cast<int>(blocks.size()) - 1;
+    return static_cast<int>(blocks.size()) - 1;
+  }
+  bool has(const double* ptr) const { return lookup.count(ptr) != 0; }
+  void setConstant(const double* ptr) {
+    auto it = lookup.find(ptr);
+    if (it != lookup.end()) blocks[it->second].constant = true;
+  }
+  void setLowerBound0(const double* ptr, double lb) {
+    auto it = lookup.find(ptr);
+    if (it != lookup.end()) {
+      blocks[it->second].hasLower0 = true;
+      blocks[it->second].lower0 = lb;
+    }
+  }
+  void finalize() {
+    int off = 0;
+    for (auto& b : blocks) {
+      if (b.constant) {
+        b.offset = -1;
+      } else {
+        b.offset = off;
+        off += b.size;
+      }
+    }
+    numActive = off;
+  }
+};
+
+// ceres::CauchyLoss / ScaledLoss(nullptr, a) -> rho[0..2] (ceres/loss_function.cc).
+static void evalLoss(int kind, double p, double s, double rho[3]) {
+  if (kind == LOSS_CAUCHY) {
+    const double b = p * p;
+    const double c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double inv = 1.0 / sum;
+    rho[0] = b * std::log(sum);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c * (inv * inv);
+  } else if (kind == LOSS_SCALED) {
+    rho[0] = p * s;
+    rho[1] = p;
+    rho[2] = 0.0;
+  } else {
+    rho[0] = s;
+    rho[1] = 1.0;
+    rho[2] = 0.0;
+  }
+}
+
+// One residual block: values (+ Jacobian, by dual numbers in passes of kStride exactly like
+// ceres::DynamicAutoDiffCostFunction::Evaluate), then the loss corrector (ceres/corrector.cc).
+// `jac` is laid out [numResiduals x totalParams] row-major over the concatenated parameter blocks.
+static double evaluateResidualBlock(const Problem& pb, const ResidualBlock& rb, double* res, double* jac) {
+  const CostFunction& cf = *rb.cost;
+  const int nb = static_cast<int>(rb.blocks.size());
+  const int nr = cf.numResiduals;
+  int total = 0;
+  for (int b = 0; b < nb; ++b) total += cf.blockSizes[b];
+
+  std::vector<const double*> pd(nb);
+  for (int b = 0; b < nb; ++b) pd[b] = pb.blocks[rb.blocks[b]].ptr;
+
+  if (!jac) {
+    cf.evalD(pd.data(), res);
+  } else {
+    std::vector<Jet> store(total);
+    std::vector<const Jet*> pj(nb);
+    {
+      int k = 0;
+      for (int b = 0; b < nb; ++b) {
+        pj[b] = &store[k];
+        for (int i = 0; i < cf.blockSizes[b]; ++i) store[k++] = Jet(pd[b][i]);
+      }
+    }
+    std::vector<Jet> out(nr);
+    for (int start = 0; start < total; start += kStride) {
+      const int end = std::min(total, start + kStride);
+      for (int k = start; k < end; ++k) store[k].v[k - start] = 1.0;
+      cf.evalJ(pj.data(), out.data());
+      for (int k = start; k < end; ++k) {
+        for (int r = 0; r < nr; ++r) jac[static_cast<size_t>(r) * total + k] = out[r].v[k - start];
+        store[k].v[k - start] = 0.0;
+      }
+      if (start == 0)
+        for (int r = 0; r < nr; ++r) res[r] = out[r].a;
+    }
+    if (total == 0) cf.evalD(pd.data(), res);
+  }
+
+  double sq = 0.0;
+  for (int r = 0; r < nr; ++r) sq += res[r] * res[r];
+  if (rb.lossKind == LOSS_NONE) return 0.5 * sq;
+
+  double rho[3];
+  evalLoss(rb.lossKind, rb.lossParam, sq, rho);
+  // Corrector: rho'' <= 0 for Cauchy and Scaled => plain sqrt(rho') scaling of residuals and Jacobian.
+  const double sqrtRho1 = std::sqrt(rho[1]);
+  double residualScaling, alphaSqNorm;
+  if (sq == 0.0 || rho[2] <= 0.0) {
+    residualScaling = sqrtRho1;
+    alphaSqNorm = 0.0;
+  } else {
+    const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+    const double alpha = 1.0 - std::sqrt(D);
+    residualScaling = sqrtRho1 / (1.0 - alpha);
+    alphaSqNorm = alpha / sq;
+  }
+  if (jac) {
+    if (alphaSqNorm == 0.0) {
+      for (size_t i = 0; i < static_cast<size_t>(nr) * total; ++i) jac[i] *= sqrtRho1;
+    } else {
+      // J = sqrt(rho') * (J - alpha/|r|^2 r r^T J)
+      for (int c = 0; c < total; ++c) {
+        double rtj = 0.0;
+        for (int r = 0; r < nr; ++r) rtj += res[r] * jac[static_cast<size_t>(r) * total + c];
+        for (int r = 0; r < nr; ++r)
+          jac[static_cast<size_t>(r) * total + c] =
+              sqrtRho1 * (jac[static_cast<size_t>(r) * total + c] - alphaSqNorm * res[r] * rtj);
+      }
+    }
+  }
+  for (int r = 0; r < nr; ++r) res[r] *= residualScaling;
+  return 0.5 * rho[0];
+}
+
+struct Evaluation {
+  double cost = 0.0;
+  std::vector<double> g;  // reduced gradient J^T r
+  std::vector<double> H;  // reduced dense J^T J (row-major n x n), full symmetric
+};
+
+// Evaluator::Evaluate: cost (+ gradient + J^T J). Deterministic for any thread count: Jacobians are
+// computed in parallel, accumulation rows are owned by (frame % threads).
+static void evaluateProblem(const Problem& pb, int numThreads, bool wantDerivs, Evaluation& ev) {
+  const int n = pb.numActive;
+  const size_t R = pb.residuals.size();
+  ev.cost = 0.0;
+  if (wantDerivs) {
+    ev.g.assign(n, 0.0);
+    ev.H.assign(static_cast<size_t>(n) * n, 0.0);
+  }
+  int T = std::max(1, numThreads);
+#ifdef _OPENMP
+  T = std::min(T, omp_get_max_threads());
+#else
+  T = 1;
+#endif
+  const size_t kChunk = 8192;
+  std::vector<double> costs(kChunk);
+  std::vector<std::vector<double>> resBuf(kChunk), jacBuf(kChunk);
+  for (size_t c0 = 0; c0 < R; c0 += kChunk) {
+    const size_t c1 = std::min(R, c0 + kChunk);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(T)
+    for (long long i = static_cast<long long>(c0); i < static_cast<long long>(c1); ++i) {
+      const ResidualBlock& rb = pb.residuals[i];
+      const int nr = rb.cost->numResiduals;
+      int total = 0;
+      for (int s : rb.cost->blockSizes) total += s;
+      auto& rbuf = resBuf[i - c0];
+      auto& jbuf = jacBuf[i - c0];
+      rbuf.resize(nr);
+      if (wantDerivs) jbuf.resize(static_cast<size_t>(nr) * total);
+      costs[i - c0] = evaluateResidualBlock(pb, rb, rbuf.data(), wantDerivs ? jbuf.data() : nullptr);
+    }
+    for (size_t i = c0; i < c1; ++i) ev.cost += costs[i - c0];
+    if (!wantDerivs) continue;
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num();
+      const int nt = omp_get_num_threads();
+#else
+      const int tid = 0, nt = 1;
+#endif
+      for (size_t i = c0; i < c1; ++i) {
+        const ResidualBlock& rb = pb.residuals[i];
+        const int nr = rb.cost->numResiduals;
+        const int nb = static_cast<int>(rb.blocks.size());
+        int total = 0;
+        for (int s : rb.cost->blockSizes) total += s;
+        const double* J = jacBuf[i - c0].data();
+        const double* r = resBuf[i - c0].data();
+        int ci = 0;
+        for (int bi = 0; bi < nb; ++bi) {
+          const ParamBlock& Bi = pb.blocks[rb.blocks[bi]];
+          const int si = rb.cost->blockSizes[bi];
+          if (Bi.offset >= 0 && (Bi.frame % nt) == tid) {
+            for (int a = 0; a < si; ++a) {
+              const int row = Bi.offset + a;
+              double gs = 0.0;
+              for (int k = 0; k < nr; ++k) gs += J[static_cast<size_t>(k) * total + ci + a] * r[k];
+              ev.g[row] += gs;
+              int cj = 0;
+              for (int bj = 0; bj < nb; ++bj) {
+                const ParamBlock& Bj = pb.blocks[rb.blocks[bj]];
+                const int sj = rb.cost->blockSizes[bj];
+                if (Bj.offset >= 0) {
+                  double* Hrow = &ev.H[static_cast<size_t>(row) * n + Bj.offset];
+                  for (int b = 0; b < sj; ++b) {
+                    double s = 0.0;
+                    for (int k = 0; k < nr; ++k)
+                      s += J[static_cast<size_t>(k) * total + ci + a] *
+                           J[static_cast<size_t>(k) * total + cj + b];
+                    Hrow[b] += s;
+                  }
+                }
+                cj += sj;
+              }
+            }
+          }
+          ci += si;
+        }
+      }
+    }
+  }
+}
+
+// Dense in-place lower Cholesky A = L L^T (row-major, n x n); returns false if not positive definite.
+static bool choleskyFactor(std::vector<double>& A, int n, int numThreads) {
+  const int NB = 64;
+  (void)numThreads;
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int k1 = std::min(n, k0 + NB);
+    // factor diagonal block
+    for (int j = k0; j < k1; ++j) {
+      double d = A[static_cast<size_t>(j) * n + j];
+      for (int p = k0; p < j; ++p) d -= A[static_cast<size_t>(j) * n + p] * A[static_cast<size_t>(j) * n + p];
+      if (!(d > 0.0) || !std::isfinite(d)) return false;
+      d = std::sqrt(d);
+      A[static_cast<size_t>(j) * n + j] = d;
+      for (int i = j + 1; i < k1; ++i) {
+        double s = A[static_cast<size_t>(i) * n + j];
+        for (int p = k0; p < j; ++p) s -= A[static_cast<size_t>(i) * n + p] * A[static_cast<size_t>(j) * n + p];
+        A[static_cast<size_t>(i) * n + j] = s / d;
+      }
+    }
+    // panel solve: rows below
+#pragma omp parallel for schedule(static) num_threads(std::max(1, numThreads)) if (n - k1 > 256)
+    for (int i = k1; i < n; ++i) {
+      for (int j = k0; j < k1; ++j) {
+        double s = A[static_cast<size_t>(i) * n + j];
+        for (int p = k0; p < j; ++p) s -= A[static_cast<size_t>(i) * n + p] * A[static_cast<size_t>(j) * n + p];
+        A[static_cast<size_t>(i) * n + j] = s / A[static_cast<size_t>(j) * n + j];
+      }
+    }
+    // trailing update (lower part only)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(std::max(1, numThreads)) if (n - k1 > 256)
+    for (int i = k1; i < n; ++i) {
+      const double* Li = &A[static_cast<size_t>(i) * n + k0];
+      for (int j = k1; j <= i; ++j) {
+        const double* Lj = &A[static_cast<size_t>(j) * n + k0];
+        double s = 0.0;
+        for (int p = 0; p < k1 - k0; ++p) s += Li[p] * Lj[p];
+        A[static_cast<size_t>(i) * n + j] -= s;
+      }
+    }
+  }
+  return true;
+}
+
+static void choleskySolve(const std::vector<double>& L, int n, std::vector<double>& b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    const double* Li = &L[static_cast<size_t>(i) * n];
+    for (int p = 0; p < i; ++p) s -= Li[p] * b[p];
+    b[i] = s / Li[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int p = i + 1; p < n; ++p) s -= L[static_cast<size_t>(p) * n + i] * b[p];
+    b[i] = s / L[static_cast<size_t>(i) * n + i];
+  }
+}
+
+// Ceres Solver::Options defaults that matter on this path (the reference only sets linear solver type,
+// max_num_iterations and num_threads: lib/PoseOptimizer.cpp:955-961).
+struct CeresDefaults {
+  static constexpr double initial_trust_region_radius = 1e4;
+  static constexpr double max_trust_region_radius = 1e16;
+  static constexpr double min_trust_region_radius = 1e-32;
+  static constexpr double min_relative_decrease = 1e-3;
+  static constexpr double min_lm_diagonal = 1e-6;
+  static constexpr double max_lm_diagonal = 1e32;
+  static constexpr double function_tolerance = 1e-6;
+  static constexpr double gradient_tolerance = 1e-10;
+  static constexpr double parameter_tolerance = 1e-8;
+  static constexpr int max_num_consecutive_invalid_steps = 5;
+};
+
+static void gatherState(const Problem& pb, std::vector<double>& x) {
+  x.resize(pb.numActive);
+  for (const auto& b : pb.blocks)
+    if (b.offset >= 0)
+      for (int i = 0; i < b.size; ++i) x[b.offset + i] = b.ptr[i];
+}
+static void scatterState(const Problem& pb, const std::vector<double>& x) {
+  for (const auto& b : pb.blocks)
+    if (b.offset >= 0)
+      for (int i = 0; i < b.size; ++i) b.ptr[i] = x[b.offset + i];
+}
+// ParameterBlock::Plus with box projection.
+static void plusProject(const Problem& pb, const std::vector<double>& x, const std::vector<double>& d,
+                        std::vector<double>& out) {
+  out.resize(x.size());
+  for (size_t i = 0; i < x.size(); ++i) out[i] = x[i] + d[i];
+  for (const auto& b : pb.blocks)
+    if (b.offset >= 0 && b.hasLower0) out[b.offset] = std::max(out[b.offset], b.lower0);
+}
+
+// ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT / exact normal-equation Cholesky, jacobi_scaling,
+// monotonic steps (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc restated).
+// Not restated: the projected line search Ceres runs for bound-constrained problems (only normalizeDepth
+// has bounds; they stay inactive at its solution).
+static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_solve_summary* summary,
+                         std::vector<cvd_iteration_record>* records) {
+  using D = CeresDefaults;
+  const double t0 = nowSeconds();
+  double tEval = 0.0, tLin = 0.0;
+  pb.finalize();
+  const int n = pb.numActive;
+  cvd_solve_summary sum{};
+  sum.num_residual_blocks = static_cast<int>(pb.residuals.size());
+  sum.num_parameters = n;
+
+  std::vector<double> x, cand, delta(n), step(n), scale(n, 1.0);
+  gatherState(pb, x);
+  bool constrained = false;
+  for (const auto& b : pb.blocks) constrained |= (b.offset >= 0 && b.hasLower0);
+  if (constrained) {
+    std::vector<double> zero(n, 0.0);
+    plusProject(pb, x, zero, cand);
+    x = cand;
+    scatterState(pb, x);
+  }
+
+  Evaluation ev;
+  double te = nowSeconds();
+  evaluateProblem(pb, numThreads, true, ev);
+  tEval += nowSeconds() - te;
+  double xCost = ev.cost;
+  sum.initial_cost = xCost;
+
+  auto gradMaxNorm = [&](const std::vector<double>& g) {
+    double m = 0.0;
+    if (!constrained) {
+      for (double v : g) m = std::max(m, std::abs(v));
+    } else {
+      std::vector<double> neg(n), proj;
+      for (int i = 0; i < n; ++i) neg[i] = -g[i];
+      plusProject(pb, x, neg, proj);
+      for (int i = 0; i < n; ++i) m = std::max(m, std::abs(x[i] - proj[i]));
+    }
+    return m;
+  };
+
+  // Jacobi scaling from the first Jacobian: 1 / (1 + sqrt(squared column norm)).
+  for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(ev.H[static_cast<size_t>(i) * n + i]));
+
+  double radius = D::initial_trust_region_radius;
+  double decreaseFactor = 2.0;
+  int invalidSteps = 0;
+  int iteration = 0;
+  int termination = 1;
+  double xNorm = 0.0;
+  for (double v : x) xNorm += v * v;
+  xNorm = std::sqrt(xNorm);
+
+  cvd_iteration_record rec0{};
+  rec0.iteration = 0;
+  rec0.cost = xCost;
+  rec0.gradient_max_norm = gradMaxNorm(ev.g);
+  rec0.trust_region_radius = radius;
+  rec0.step_is_successful = 1;
+  if (records) records->push_back(rec0);
+
+  if (n == 0 || rec0.gradient_max_norm <= D::gradient_tolerance) {
+    termination = 0;
+  } else {
+    std::vector<double> A, y(n), gs(n), diag(n);
+    while (true) {
+      if (iteration >= maxIterations) { termination = 1; break; }
+      if (radius < D::min_trust_region_radius) { termination = 0; break; }
+      ++iteration;
+      cvd_iteration_record rec{};
+      rec.iteration = iteration;
+
+      // ---- LevenbergMarquardtStrategy::ComputeStep on the column-scaled system
+      double tl = nowSeconds();
+      A.assign(static_cast<size_t>(n) * n, 0.0);
+      for (int i = 0; i < n; ++i) {
+        const double si = scale[i];
+        const double* Hi = &ev.H[static_cast<size_t>(i) * n];
+        double* Ai = &A[static_cast<size_t>(i) * n];
+        for (int j = 0; j <= i; ++j) Ai[j] = Hi[j] * si * scale[j];
+        diag[i] = std::min(std::max(Ai[i], D::min_lm_diagonal), D::max_lm_diagonal);
+        gs[i] = ev.g[i] * si;
+      }
+      for (int i = 0; i < n; ++i) A[static_cast<size_t>(i) * n + i] += diag[i] / radius;
+      bool ok = choleskyFactor(A, n, numThreads);
+      if (ok) {
+        y = gs;
+        choleskySolve(A, n, y);
+        for (int i = 0; i < n; ++i) {
+          step[i] = -y[i];
+          if (!std::isfinite(step[i])) ok = false;
+        }
+      }
+      tLin += nowSeconds() - tl;
+
+      double modelCostChange = 0.0;
+      if (ok) {
+        // model_cost_change = -(J step)^T (r + J step / 2) = -(step^T gs + step^T Hs step / 2)
+        double sg = 0.0, sHs = 0.0;
+        for (int i = 0; i < n; ++i) {
+          sg += step[i] * gs[i];
+          const double* Hi = &ev.H[static_cast<size_t>(i) * n];
+          double hi = 0.0;
+          for (int j = 0; j < n; ++j) hi += Hi[j] * scale[j] * step[j];
+          sHs += step[i] * scale[i] * hi;
+        }
+        modelCostChange = -(sg + 0.5 * sHs);
+        ok = modelCostChange > 0.0;
+      }
+      if (!ok) {
+        // HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
+        if (++invalidSteps >= D::max_num_consecutive_invalid_steps) { termination = 2; break; }
+        radius = radius / decreaseFactor;
+        decreaseFactor *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        if (records) records->push_back(rec);
+        continue;
+      }
+      invalidSteps = 0;
+      for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
+
+      // ---- candidate point + cost
+      plusProject(pb, x, delta, cand);
+      scatterState(pb, cand);
+      Evaluation evc;
+      te = nowSeconds();
+      evaluateProblem(pb, numThreads, false, evc);
+      tEval += nowSeconds() - te;
+      double candCost = evc.cost;
+      if (!std::isfinite(candCost)) candCost = std::numeric_limits<double>::max();
+
+      double stepNorm = 0.0;
+      for (int i = 0; i < n; ++i) stepNorm += delta[i] * delta[i];
+      stepNorm = std::sqrt(stepNorm);
+      rec.step_norm = stepNorm;
+      rec.cost_change = xCost - candCost;
+      rec.relative_decrease = (xCost - candCost) / modelCostChange;
+
+      // ParameterToleranceReached
+      if (stepNorm <= D::parameter_tolerance * (xNorm + D::parameter_tolerance)) {
+        scatterState(pb, x);
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        if (records) records->push_back(rec);
+        termination = 0;
+        break;
+      }
+      // FunctionToleranceReached
+      if (std::abs(xCost - candCost) <= D::function_tolerance * xCost) {
+        // Ceres keeps the iterate it had unless the step is an improvement recorded earlier; the
+        // candidate is NOT accepted here (minimizer returns before IsStepSuccessful).
+        scatterState(pb, x);
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        if (records) records->push_back(rec);
+        termination = 0;
+        break;
+      }
+
+      if (rec.relative_decrease > D::min_relative_decrease) {
+        // HandleSuccessfulStep
+        x = cand;
+        xNorm = 0.0;
+        for (double v : x) xNorm += v * v;
+        xNorm = std::sqrt(xNorm);
+        xCost = candCost;
+        te = nowSeconds();
+        evaluateProblem(pb, numThreads, true, ev);
+        tEval += nowSeconds() - te;
+        ++sum.num_successful_steps;
+        rec.step_is_successful = 1;
+        // LevenbergMarquardtStrategy::StepAccepted
+        const double q = rec.relative_decrease;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * q - 1.0, 3));
+        radius = std::min(D::max_trust_region_radius, radius);
+        decreaseFactor = 2.0;
+        rec.cost = xCost;
+        rec.gradient_max_norm = gradMaxNorm(ev.g);
+        rec.trust_region_radius = radius;
+        if (records) records->push_back(rec);
+        if (rec.gradient_max_norm <= D::gradient_tolerance) { termination = 0; break; }
+      } else {
+        // StepRejected
+        scatterState(pb, x);
+        radius = radius / decreaseFactor;
+        decreaseFactor *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        if (records) records->push_back(rec);
+      }
+    }
+  }
+  scatterState(pb, x);
+  sum.num_iterations = iteration;
+  sum.termination = termination;
+  sum.final_cost = xCost;
+  sum.total_seconds = nowSeconds() - t0;
+  sum.evaluate_seconds = tEval;
+  sum.linear_solve_seconds = tLin;
+  if (summary) *summary = sum;
+}
+
+// =====================================================================================================
+// The optimizer (reference lib/PoseOptimizer.cpp:748-1549, lib/Processor.cpp:888-1013)
+// =====================================================================================================
+
+struct Oracle {
+  int F = 0, W = 0, Hh = 0;
+  float aspect = 1.f, invAspect = 1.f;
+  std::vector<float> depth;  // F * H * W source depth (already inverted from disparity; invalid -> 0)
+
+  std::vector<int> pairFrames;      // 2 per pair
+  std::vector<int64_t> pairOffsets; // P + 1
+  std::vector<float> pairLoc;       // 4 per constraint: loc0.xy, loc1.xy in [0,1]x[0,invAspect]
+  std::vector<uint8_t> pairStatic;
+
+  std::vector<int> tripletCenters;
+  std::vector<int64_t> tripletOffsets;
+  std::vector<float> tripletLoc;  // 6 per constraint
+  std::vector<uint8_t> tripletStatic;
+
+  std::vector<cvd_frame_pose> poses;
+  std::vector<Xform> depthXforms, spatialXforms;
+  cvd_xform_desc depthDesc{}, spatialDesc{};
+
+  std::vector<std::array<double, 7>> poseParams;  // PoseOptimizer.h:149
+  std::vector<cvd_iteration_record> records;
+  cvd_solve_summary lastSummary{};
+  std::string lastError;
+
+  const float* depthImg(int f) const { return &depth[static_cast<size_t>(f) * W * Hh]; }
+
+  // ---- frame range helpers (FrameRange: ordered set of frame ids) -----------------------------------
+  static std::vector<int> rangeOf(const cvd_opt_params& p, int F) {
+    std::vector<int> r;
+    if (!p.frame_range || p.num_range_frames <= 0) {
+      for (int i = 0; i < F; ++i) r.push_back(i);
+    } else {
+      r.assign(p.frame_range, p.frame_range + p.num_range_frames);
+      std::sort(r.begin(), r.end());
+      r.erase(std::unique(r.begin(), r.end()), r.end());
+    }
+    return r;
+  }
+
+  void init(int numFrames, int w, int h, float asp, float invAsp) {
+    F = numFrames; W = w; Hh = h; aspect = asp; invAspect = invAsp;
+    depth.assign(static_cast<size_t>(F) * W * Hh, 0.f);
+    poses.assign(F, cvd_frame_pose{{0, 0, 0}, {0, 0, 0, 1}, 0.f, 0.f});
+    cvd_xform_desc dd{};
+    dd.type = CVD_XFORM_DEPTH;
+    dd.depth_type = CVD_DEPTH_IDENTITY;
+    cvd_xform_desc sd{};
+    sd.type = CVD_XFORM_SPATIAL;
+    sd.spatial_type = CVD_SPATIAL_IDENTITY;
+    resetDepthXforms(dd);
+    resetSpatialXforms(sd);
+  }
+
+  // DepthStream::resetDepthXforms / resetSpatialXforms (reference lib/DepthStream.cpp:368-383)
+  void resetDepthXforms(const cvd_xform_desc& d) {
+    depthDesc = d;
+    depthXforms.clear();
+    for (int f = 0; f < F; ++f) depthXforms.push_back(Xform::create(d));
+  }
+  void resetSpatialXforms(const cvd_xform_desc& d) {
+    spatialDesc = d;
+    spatialXforms.clear();
+    for (int f = 0; f < F; ++f) spatialXforms.push_back(Xform::create(d));
+  }
+
+  // DepthVideoProcessor::resetPoses, reference lib/Processor.cpp:987-1003
+  void resetPoses(double focalLong) {
+    for (int f = 0; f < F; ++f) {
+      cvd_frame_pose& p = poses[f];
+      p.position[0] = p.position[1] = p.position[2] = 0.f;
+      p.orientation[0] = p.orientation[1] = p.orientation[2] = 0.f;
+      p.orientation[3] = 1.f;
+      const float focal = static_cast<float>(focalLong);
+      if (aspect >= 1.f) {
+        p.hfov = std::atan(focal) * 2.f;
+        p.vfov = std::atan(focal / aspect) * 2.f;
+      } else {
+        p.hfov = std::atan(focal * aspect) * 2.f;
+        p.vfov = std::atan(focal) * 2.f;
+      }
+    }
+  }
+
+  // DepthVideoProcessor::gridXformSplit, reference lib/Processor.cpp:888-985
+  void gridXformSplit(const cvd_xform_desc& nd) {
+    if (nd.depth_type != CVD_DEPTH_GRID) throw std::runtime_error("Transform type must be a grid type.");
+    const cvd_xform_desc prev = depthDesc;
+    if (prev.depth_type != CVD_DEPTH_GLOBAL && prev.depth_type != CVD_DEPTH_GRID)
+      throw std::runtime_error("Can only split global or grid type transforms.");
+    if (nd.value_xform != prev.value_xform)
+      throw std::runtime_error("Old and new transforms must use same value transform.");
+    if (prev.depth_type != CVD_DEPTH_GLOBAL &&
+        (prev.grid_size[0] > nd.grid_size[0] || prev.grid_size[1] > nd.grid_size[1]))
+      throw std::runtime_error(
+          "New transform must have at least the same number of rows and columns as the old transform.");
+    std::vector<Xform> old = depthXforms;
+    resetDepthXforms(nd);
+    const int newCols = nd.grid_size[0], newRows = nd.grid_size[1];
+    for (int f = 0; f < F; ++f) {
+      const Xform& px = old[f];
+      Xform& nx = depthXforms[f];
+      const int N = nx.blockSize;
+      for (int row = 0; row < newRows; ++row) {
+        for (int col = 0; col < newCols; ++col) {
+          const int idx = col + row * newCols;
+          double* dst = &nx.params[static_cast<size_t>(idx) * N];
+          if (prev.depth_type == CVD_DEPTH_GLOBAL) {
+            for (int i = 0; i < N; ++i) dst[i] = px.params[i];
+          } else {
+            const int prevRows = prev.grid_size[1], prevCols = prev.grid_size[0];
+            const double maxx = std::nextafter(static_cast<double>(prevCols - 1), 0.0);
+            const double maxy = std::nextafter(static_cast<double>(prevRows - 1), 0.0);
+            const double sx = std::min(col / double(newCols - 1) * (prevCols - 1), maxx);
+            const double sy = std::min(row / double(newRows - 1) * (prevRows - 1), maxy);
+            const int ix = static_cast<int>(sx), iy = static_cast<int>(sy);
+            const double rx = sx - ix, ry = sy - iy;
+            const double* b0 = &px.params[static_cast<size_t>(ix + iy * prevCols) * N];
+            const double* b1 = &px.params[static_cast<size_t>((ix + 1) + iy * prevCols) * N];
+            const double* b2 = &px.params[static_cast<size_t>(ix + (iy + 1) * prevCols) * N];
+            const double* b3 = &px.params[static_cast<size_t>((ix + 1) + (iy + 1) * prevCols) * N];
+            // The reference mixes 1.f and double here (:965-968): (1.f - rx) is evaluated in double.
+            const double w0 = (1.f - rx) * (1.f - ry);
+            const double w1 = rx * (1.f - ry);
+            const double w2 = (1.f - rx) * ry;
+            const double w3 = rx * ry;
+            for (int i = 0; i < N; ++i) dst[i] = b0[i] * w0 + b1[i] * w1 + b2[i] * w2 + b3[i] * w3;
+          }
+        }
+      }
+    }
+  }
+
+  // DepthVideoPoseOptimizer ctor, reference lib/PoseOptimizer.cpp:748-783
+  void posesToParams() {
+    poseParams.resize(F);
+    for (int f = 0; f < F; ++f) {
+      const cvd_frame_pose& p = poses[f];
+      auto& pose = poseParams[f];
+      pose[0] = p.position[0];
+      pose[1] = p.position[1];
+      pose[2] = p.position[2];
+      const double q[4] = {p.orientation[0], p.orientation[1], p.orientation[2], p.orientation[3]};
+      const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ezn[3] = {0, 0, -1};
+      double right[3], up[3], front[3];
+      quatRotate(q, ex, right);
+      quatRotate(q, ey, up);
+      quatRotate(q, ezn, front);
+      double R[9];
+      for (int i = 0; i < 3; ++i) {
+        R[i + 0] = right[i];
+        R[i + 3] = up[i];
+        R[i + 6] = -front[i];
+      }
+      rotationMatrixToAngleAxis(R, &pose[3]);
+      pose[6] = std::tan(p.vfov / 2.0);
+    }
+  }
+
+  // pose write-back, reference lib/PoseOptimizer.cpp:964-987
+  void paramsToPoses(const cvd_opt_params& params) {
+    for (int f : rangeOf(params, F)) {
+      const auto& pose = poseParams[f];
+      cvd_frame_pose& p = poses[f];
+      p.position[0] = static_cast<float>(pose[0]);
+      p.position[1] = static_cast<float>(pose[1]);
+      p.position[2] = static_cast<float>(pose[2]);
+      double R[9], q[4];
+      angleAxisToRotationMatrix(&pose[3], R);
+      rotationMatrixToEigenQuaternion(R, q);
+      for (int i = 0; i < 4; ++i) p.orientation[i] = static_cast<float>(q[i]);
+      const double fsrc = (params.intr_opt == CVD_INTR_SHARED) ? poseParams[0][6] : pose[6];
+      p.vfov = static_cast<float>(std::atan(fsrc) * 2.f);
+      p.hfov = static_cast<float>(std::atan(fsrc * aspect) * 2.f);
+    }
+  }
+
+  // Observation ctor, reference lib/PoseOptimizer.cpp:104-127 (float arithmetic, truncating fetch: q1)
+  Obs makeObs(int frame, const float loc[2]) const {
+    Obs o;
+    o.ndc[0] = -1.f + 2.f * loc[0];
+    o.ndc[1] = 1.f - 2.f * loc[1] / invAspect;
+    int ix = static_cast<int>(loc[0] * W);
+    int iy = static_cast<int>(loc[1] / invAspect * Hh);
+    // cv::Mat::at is unchecked in the reference; clamp so that the oracle never reads out of bounds.
+    ix = std::min(std::max(ix, 0), W - 1);
+    iy = std::min(std::max(iy, 0), Hh - 1);
+    o.sourceDepth = depthImg(frame)[static_cast<size_t>(iy) * W + ix];
+    const Xform& dx = depthXforms[frame];
+    o.valueType = dx.desc.value_xform;
+    o.depthType = dx.desc.depth_type;
+    dx.depthGather(o.sourceDepth, o.ndc[0], o.ndc[1], o.dg);
+    spatialXforms[frame].spatialGather(o.ndc[0], o.ndc[1], o.sg);
+    return o;
+  }
+
+  int B() const { return 7 + depthXforms[0].numBlocks * depthXforms[0].blockSize +
+                         spatialXforms[0].numBlocks * spatialXforms[0].blockSize; }
+  int canonDepth(int k) const { return 7 + k * depthXforms[0].blockSize; }
+  int canonSpatial(int k) const {
+    return 7 + depthXforms[0].numBlocks * depthXforms[0].blockSize + 2 * k;
+  }
+
+  int poseBlock(Problem& pb, int f) { return pb.blockId(poseParams[f].data(), 6, f, f * B()); }
+  int focalBlock(Problem& pb, int f) { return pb.blockId(&poseParams[f][6], 1, f, f * B() + 6); }
+  int depthBlock(Problem& pb, int f, int k) {
+    Xform& x = depthXforms[f];
+    return pb.blockId(&x.params[static_cast<size_t>(k) * x.blockSize], x.blockSize, f,
+                      f * B() + canonDepth(k));
+  }
+  int spatialBlock(Problem& pb, int f, int k) {
+    Xform& x = spatialXforms[f];
+    return pb.blockId(&x.params[static_cast<size_t>(k) * 2], 2, f, f * B() + canonSpatial(k));
+  }
+
+  void appendObsBlocks(Problem& pb, int f, const Obs& o, std::vector<int>& blocks, std::vector<int>& sizes) {
+    blocks.push_back(poseBlock(pb, f));
+    sizes.push_back(6);
+    for (int i = 0; i < o.dg.n; ++i) {
+      blocks.push_back(depthBlock(pb, f, o.dg.idx[i]));
+      sizes.push_back(depthXforms[f].blockSize);
+    }
+    for (int i = 0; i < o.sg.n; ++i) {
+      blocks.push_back(spatialBlock(pb, f, o.sg.idx[i]));
+      sizes.push_back(2);
+    }
+  }
+
+  double vFocal(const cvd_opt_params& p) const {
+    const double a = aspect;
+    return (a >= 1.f ? p.focal_long / a : p.focal_long);
+  }
+
+  static bool validDepth(float d) { return std::isfinite(d) && d > 0; }
+
+  // Pair order = std::map<std::pair<int,int>> order (reference lib/FlowConstraints.h:149).
+  std::vector<int> sortedPairs() const {
+    const int P = static_cast<int>(pairFrames.size() / 2);
+    std::vector<int> order(P);
+    for (int i = 0; i < P; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
+      return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
+    });
+    return order;
+  }
+
+  // addStaticSceneLoss, reference lib/PoseOptimizer.cpp:1149-1240
+  void addStaticSceneLoss(Problem& pb, const cvd_opt_params& p, const std::vector<char>& inRange) {
+    for (int pi : sortedPairs()) {
+      const int f0 = pairFrames[2 * pi], f1 = pairFrames[2 * pi + 1];
+      if (!inRange[f0] || !inRange[f1]) continue;
+      for (int64_t c = pairOffsets[pi]; c < pairOffsets[pi + 1]; ++c) {
+        if (!pairStatic[c]) continue;
+        Obs o0 = makeObs(f0, &pairLoc[4 * c]);
+        Obs o1 = makeObs(f1, &pairLoc[4 * c + 2]);
+        if (!validDepth(o0.sourceDepth) || !validDepth(o1.sourceDepth)) continue;  // q5
+        ResidualBlock rb;
+        std::vector<int> sizes;
+        appendObsBlocks(pb, f0, o0, rb.blocks, sizes);
+        appendObsBlocks(pb, f1, o1, rb.blocks, sizes);
+        if (p.intr_opt == CVD_INTR_SHARED) {
+          rb.blocks.push_back(focalBlock(pb, 0));  // q7
+          sizes.push_back(1);
+        } else if (p.intr_opt == CVD_INTR_PER_FRAME) {
+          rb.blocks.push_back(focalBlock(pb, f0));
+          sizes.push_back(1);
+          rb.blocks.push_back(focalBlock(pb, f1));
+          sizes.push_back(1);
+        }
+        auto cf = std::make_unique<AutoDiff<StaticSceneCost>>(
+            StaticSceneCost{o0, o1, vFocal(p), static_cast<double>(aspect), p.intr_opt,
+                            p.static_loss_type, p.static_spatial_weight, p.static_depth_weight});
+        cf->numResiduals = 3;
+        cf->blockSizes = sizes;
+        rb.cost = std::move(cf);
+        rb.lossKind = LOSS_CAUCHY;
+        rb.lossParam = p.robustness;
+        pb.residuals.push_back(std::move(rb));
+      }
+    }
+  }
+
+  // addSceneFlowSmoothnessLoss, reference lib/PoseOptimizer.cpp:1242-1339 (loop bound quirk q8)
+  void addSceneFlowSmoothnessLoss(Problem& pb, const cvd_opt_params& p, const std::vector<int>& range,
+                                  const std::vector<char>& inRange) {
+    if (range.empty()) return;
+    std::map<int, int> tripletIndex;
+    for (size_t i = 0; i < tripletCenters.size(); ++i) tripletIndex[tripletCenters[i]] = static_cast<int>(i);
+    for (int frame = range.front(); frame < range.back() - 1; ++frame) {
+      if (!inRange[frame] || !inRange[frame + 1] || !inRange[frame + 2]) continue;
+      auto it = tripletIndex.find(frame + 1);
+      if (it == tripletIndex.end()) throw std::runtime_error("Missing triplet constraints.");
+      const int ti = it->second;
+      for (int64_t c = tripletOffsets[ti]; c < tripletOffsets[ti + 1]; ++c) {
+        Obs o0 = makeObs(frame + 0, &tripletLoc[6 * c]);
+        Obs o1 = makeObs(frame + 1, &tripletLoc[6 * c + 2]);
+        Obs o2 = makeObs(frame + 2, &tripletLoc[6 * c + 4]);
+        if (!validDepth(o0.sourceDepth) || !validDepth(o1.sourceDepth) || !validDepth(o2.sourceDepth))
+          continue;
+        ResidualBlock rb;
+        std::vector<int> sizes;
+        appendObsBlocks(pb, frame + 0, o0, rb.blocks, sizes);
+        appendObsBlocks(pb, frame + 1, o1, rb.blocks, sizes);
+        appendObsBlocks(pb, frame + 2, o2, rb.blocks, sizes);
+        if (p.intr_opt == CVD_INTR_SHARED) {
+          rb.blocks.push_back(focalBlock(pb, 0));
+          sizes.push_back(1);
+        } else if (p.intr_opt == CVD_INTR_PER_FRAME) {
+          for (int k = 0; k < 3; ++k) {
+            rb.blocks.push_back(focalBlock(pb, frame + k));
+            sizes.push_back(1);
+          }
+        }
+        auto cf = std::make_unique<AutoDiff<SceneFlowSmoothnessLoss>>(SceneFlowSmoothnessLoss{
+            o0, o1, o2, vFocal(p), static_cast<double>(aspect), p.intr_opt, p.smooth_loss_type});
+        cf->numResiduals = 3;
+        cf->blockSizes = sizes;
+        rb.cost = std::move(cf);
+        rb.lossKind = LOSS_SCALED;
+        rb.lossParam = tripletStatic[c] ? p.smooth_static_weight : p.smooth_dynamic_weight;
+        pb.residuals.push_back(std::move(rb));
+      }
+    }
+  }
+
+  // addScaleRegularization, reference lib/PoseOptimizer.cpp:1341-1415
+  void addScaleRegularization(Problem& pb, const cvd_opt_params& p, const std::vector<int>& range) {
+    int gridSizeX = p.scale_reg_grid_size;
+    int gridSizeY = static_cast<int>(std::round(static_cast<float>(gridSizeX) * invAspect));
+    if (aspect <= 1.f) std::swap(gridSizeX, gridSizeY);
+    for (int f : range) {
+      std::vector<float> samples(depthImg(f), depthImg(f) + static_cast<size_t>(W) * Hh);
+      std::nth_element(samples.begin(), samples.begin() + samples.size() / 2, samples.end());
+      const double medianDepth = samples[samples.size() / 2];
+      for (int y = 0; y < gridSizeY; ++y) {
+        for (int x = 0; x < gridSizeX; ++x) {
+          const float lx = -1.f + 2.f * x / (gridSizeX - 1);
+          const float ly = -1.f + 2.f * y / (gridSizeY - 1);
+          Obs o;
+          o.ndc[0] = lx;
+          o.ndc[1] = ly;
+          o.sourceDepth = static_cast<float>(medianDepth);
+          o.valueType = depthXforms[f].desc.value_xform;
+          o.depthType = depthXforms[f].desc.depth_type;
+          depthXforms[f].depthGather(o.sourceDepth, lx, ly, o.dg);
+          o.sg.n = 0;
+          ResidualBlock rb;
+          std::vector<int> sizes;
+          for (int i = 0; i < o.dg.n; ++i) {
+            rb.blocks.push_back(depthBlock(pb, f, o.dg.idx[i]));
+            sizes.push_back(depthXforms[f].blockSize);
+          }
+          auto cf = std::make_unique<AutoDiff<TargetDisparityCost>>(TargetDisparityCost{o, 1.0});
+          cf->numResiduals = 1;
+          cf->blockSizes = sizes;
+          rb.cost = std::move(cf);
+          rb.lossKind = LOSS_SCALED;
+          rb.lossParam = p.scale_reg;
+          pb.residuals.push_back(std::move(rb));
+        }
+      }
+    }
+  }
+
+  // addPositionRegularization, reference lib/PoseOptimizer.cpp:1417-1447
+  void addPositionRegularization(Problem& pb, const cvd_opt_params& p, const std::vector<int>& range,
+                                 const std::vector<char>& inRange) {
+    if (range.empty()) return;
+    for (int frame = range.front(); frame < range.back() - 1; ++frame) {
+      if (!inRange[frame] || !inRange[frame + 1] || !inRange[frame + 2]) continue;
+      ResidualBlock rb;
+      for (int k = 0; k < 3; ++k) rb.blocks.push_back(poseBlock(pb, frame + k));
+      auto cf = std::make_unique<AutoDiff<ParameterRegularizationCost>>(ParameterRegularizationCost{3});
+      cf->numResiduals = 3;
+      cf->blockSizes = {6, 6, 6};
+      rb.cost = std::move(cf);
+      rb.lossKind = LOSS_SCALED;
+      rb.lossParam = p.position_reg;
+      pb.residuals.push_back(std::move(rb));
+    }
+  }
+
+  // addDepthDeformRegularization / addSpatialDeformRegularization, reference :1449-1522.
+  // (AdaptiveDeformationCost, :559-656, is off by default and not restated: SURVEY.md 8 a13.)
+  void addDeformRegularization(Problem& pb, const std::vector<int>& range, bool depthKind, double weight) {
+    for (int f : range) {
+      Xform& x = depthKind ? depthXforms[f] : spatialXforms[f];
+      if (x.numDeformationResiduals() <= 0) continue;
+      ResidualBlock rb;
+      std::vector<int> sizes;
+      for (int k = 0; k < x.numBlocks; ++k) {
+        rb.blocks.push_back(depthKind ? depthBlock(pb, f, k) : spatialBlock(pb, f, k));
+        sizes.push_back(x.blockSize);
+      }
+      auto cf = std::make_unique<AutoDiff<DeformationCost>>(DeformationCost{&x, weight});
+      cf->numResiduals = x.numDeformationResiduals();
+      cf->blockSizes = sizes;
+      rb.cost = std::move(cf);
+      rb.lossKind = LOSS_NONE;
+      pb.residuals.push_back(std::move(rb));
+    }
+  }
+
+  // addFocalRegularization, reference lib/PoseOptimizer.cpp:1524-1549
+  void addFocalRegularization(Problem& pb, const cvd_opt_params& p, const std::vector<int>& range) {
+    if (p.intr_opt == CVD_INTR_FIXED) return;
+    for (int f : range) {
+      ResidualBlock rb;
+      rb.blocks.push_back(focalBlock(pb, f));
+      auto cf = std::make_unique<AutoDiff<TargetFocalCost>>(TargetFocalCost{vFocal(p)});
+      cf->numResiduals = 1;
+      cf->blockSizes = {1};
+      rb.cost = std::move(cf);
+      rb.lossKind = LOSS_SCALED;
+      rb.lossParam = p.focal_reg;
+      pb.residuals.push_back(std::move(rb));
+    }
+  }
+
+  // Problem of poseOptimizationStep, reference lib/PoseOptimizer.cpp:890-952
+  void buildPoseProblem(Problem& pb, const cvd_opt_params& p, double depthDeformReg) {
+    if (p.adaptive_deformation_cost > 0.0)
+      throw std::runtime_error("AdaptiveDeformationCost is not restated in the oracle.");
+    const std::vector<int> range = rangeOf(p, F);
+    std::vector<char> inRange(F, 0);
+    for (int f : range) inRange[f] = 1;
+    addStaticSceneLoss(pb, p, inRange);
+    if (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0)
+      addSceneFlowSmoothnessLoss(pb, p, range, inRange);
+    if (p.position_reg > 0.0) addPositionRegularization(pb, p, range, inRange);
+    if (depthDeformReg > 0.0) addDeformRegularization(pb, range, true, depthDeformReg);
+    if (p.spatial_deform_reg > 0.0) addDeformRegularization(pb, range, false, p.spatial_deform_reg);
+    if (p.fix_poses)
+      for (int f : range) pb.setConstant(poseParams[f].data());
+    if (p.fix_depth_xforms) {
+      for (int f : range) {
+        Xform& x = depthXforms[f];
+        for (int k = 0; k < x.numBlocks; ++k) pb.setConstant(&x.params[static_cast<size_t>(k) * x.blockSize]);
+      }
+    } else if (p.scale_reg > 0.0) {
+      addScaleRegularization(pb, p, range);
+    }
+    if (p.fix_spatial_xforms) {
+      for (int f : range) {
+        Xform& x = spatialXforms[f];
+        for (int k = 0; k < x.numBlocks; ++k) pb.setConstant(&x.params[static_cast<size_t>(k) * 2]);
+      }
+    }
+    if (p.focal_reg > 0.0) addFocalRegularization(pb, p, range);
+  }
+
+  // poseOptimizationStep, reference lib/PoseOptimizer.cpp:890-990
+  void poseOptimizationStep(const cvd_opt_params& p, double depthDeformReg) {
+    Problem pb;
+    buildPoseProblem(pb, p, depthDeformReg);
+    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records);
+    paramsToPoses(p);
+  }
+
+  // poseOptimization, reference lib/PoseOptimizer.cpp:788-888
+  void poseOptimization(const cvd_opt_params& p) {
+    posesToParams();
+    records.clear();
+    int ctfRows = p.ctf_long, ctfCols = p.ctf_short;
+    int dsoRows = p.dso_long, dsoCols = p.dso_short;
+    if (aspect >= 1.f) {
+      std::swap(ctfCols, ctfRows);
+      std::swap(dsoCols, dsoRows);
+    }
+    auto gridSize = [&](const cvd_xform_desc& d, int g[3]) {
+      if (d.depth_type == CVD_DEPTH_GRID) {
+        g[0] = d.grid_size[0]; g[1] = d.grid_size[1]; g[2] = d.grid_size[2];
+      } else {
+        g[0] = g[1] = g[2] = 1;
+      }
+    };
+    int initGrid[3];
+    gridSize(depthDesc, initGrid);
+    if (p.deferred_spatial_opt) {
+      cvd_xform_desc sd{};
+      sd.type = CVD_XFORM_SPATIAL;
+      sd.spatial_type = CVD_SPATIAL_IDENTITY;
+      resetSpatialXforms(sd);
+    }
+    for (int step = 0; step < p.num_steps; ++step) {
+      const double stepIter = (p.num_steps > 1 ? step / double(p.num_steps - 1) : 0.0);
+      double depthDeformReg = p.depth_deform_reg_final;
+      if (p.graduate_depth_deform_reg) {
+        const double a = std::log(p.depth_deform_reg_initial);
+        const double b = std::log(p.depth_deform_reg_final);
+        depthDeformReg = std::exp(a + (b - a) * stepIter);
+      }
+      poseOptimizationStep(p, depthDeformReg);
+      if (p.coarse_to_fine && step < p.num_steps - 1) {
+        const double ctfIter = (step + 1) / double(p.num_steps - 1);
+        cvd_xform_desc nd = depthDesc;
+        if (nd.depth_type == CVD_DEPTH_GLOBAL) nd.depth_type = CVD_DEPTH_GRID;
+        nd.grid_size[0] = static_cast<int>(initGrid[0] + (ctfCols - initGrid[0]) * ctfIter + 0.5);
+        nd.grid_size[1] = static_cast<int>(initGrid[1] + (ctfRows - initGrid[1]) * ctfIter + 0.5);
+        nd.grid_size[2] = initGrid[2];
+        gridXformSplit(nd);
+      }
+    }
+    if (p.deferred_spatial_opt) {
+      cvd_xform_desc sd{};
+      sd.type = CVD_XFORM_SPATIAL;
+      sd.spatial_type = CVD_SPATIAL_BICUBIC_GRID;
+      sd.grid_size[1] = dsoRows;
+      sd.grid_size[0] = dsoCols;
+      resetSpatialXforms(sd);
+      poseOptimizationStep(p, p.depth_deform_reg_final);
+    }
+  }
+
+  // normalizeDepth, reference lib/PoseOptimizer.cpp:992-1147
+  void normalizeDepth(const cvd_opt_params& p) {
+    posesToParams();
+    records.clear();
+    const std::vector<int> range = rangeOf(p, F);
+    std::vector<char> inRange(F, 0);
+    for (int f : range) inRange[f] = 1;
+    Problem pb;
+    for (int pi : sortedPairs()) {
+      const int i0 = pairFrames[2 * pi], i1 = pairFrames[2 * pi + 1];
+      if (!inRange[i0] || !inRange[i1]) continue;
+      if (p.normalize_depth_from_first_frame) break;
+      for (int64_t c = pairOffsets[pi]; c < pairOffsets[pi + 1]; ++c) {
+        Obs o0 = makeObs(i0, &pairLoc[4 * c]);
+        Obs o1 = makeObs(i1, &pairLoc[4 * c + 2]);
+        if (!validDepth(o0.sourceDepth) || !validDepth(o1.sourceDepth)) continue;
+        o0.sg.n = 0;
+        o1.sg.n = 0;
+        ResidualBlock rb;
+        std::vector<int> sizes;
+        for (int i = 0; i < o0.dg.n; ++i) {
+          rb.blocks.push_back(depthBlock(pb, i0, o0.dg.idx[i]));
+          sizes.push_back(depthXforms[i0].blockSize);
+        }
+        for (int i = 0; i < o1.dg.n; ++i) {
+          rb.blocks.push_back(depthBlock(pb, i1, o1.dg.idx[i]));
+          sizes.push_back(depthXforms[i1].blockSize);
+        }
+        auto cf = std::make_unique<AutoDiff<DisparityDissimilarityCost>>(DisparityDissimilarityCost{o0, o1});
+        cf->numResiduals = 1;
+        cf->blockSizes = sizes;
+        rb.cost = std::move(cf);
+        rb.lossKind = LOSS_CAUCHY;
+        rb.lossParam = p.robustness;
+        pb.residuals.push_back(std::move(rb));
+      }
+    }
+    if (p.scale_reg > 0.0) addScaleRegularization(pb, p, range);
+    if (p.depth_deform_reg_initial > 0.0) addDeformRegularization(pb, range, true, p.depth_deform_reg_initial);
+    for (int f : range) {
+      Xform& x = depthXforms[f];
+      for (int k = 0; k < x.numBlocks; ++k)
+        pb.setLowerBound0(&x.params[static_cast<size_t>(k) * x.blockSize], 0.0);
+    }
+    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records);
+    if (p.normalize_depth_from_first_frame && !range.empty()) {
+      const int first = range.front();
+      for (int f : range)
+        if (f != first) depthXforms[f].params = depthXforms[first].params;
+    }
+  }
+
+  // Parity hook: evaluate the poseOptimizationStep problem at the current double-precision state and
+  // return cost / gradient / J^T J in the canonical per-frame layout [t(3) w(3) f(1) theta.. phi..].
+  void evaluate(const cvd_opt_params& p, double depthDeformReg, const double* pose7, double* cost,
+                int* numResidualBlocks, double* gradient /*F*B*/, double* hdiag /*F*B*B*/,
+                double* hfull /*(F*B)^2*/) {
+    if (pose7) {
+      poseParams.resize(F);
+      for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 7; ++i) poseParams[f][i] = pose7[f * 7 + i];
+    } else {
+      posesToParams();
+    }
+    Problem pb;
+    buildPoseProblem(pb, p, depthDeformReg);
+    pb.finalize();
+    Evaluation ev;
+    const bool derivs = gradient || hdiag || hfull;
+    evaluateProblem(pb, p.num_threads, derivs, ev);
+    if (cost) *cost = ev.cost;
+    if (numResidualBlocks) *numResidualBlocks = static_cast<int>(pb.residuals.size());
+    const int Bf = B();
+    const size_t NC = static_cast<size_t>(F) * Bf;
+    if (gradient) std::fill(gradient, gradient + NC, 0.0);
+    if (hdiag) std::fill(hdiag, hdiag + NC * Bf, 0.0);
+    if (hfull) std::fill(hfull, hfull + NC * NC, 0.0);
+    if (!derivs) return;
+    const int n = pb.numActive;
+    std::vector<int> canon(n, -1);
+    for (const auto& b : pb.blocks)
+      if (b.offset >= 0)
+        for (int i = 0; i < b.size; ++i) canon[b.offset + i] = b.canon + i;
+    for (int i = 0; i < n; ++i) {
+      const int ci = canon[i];
+      if (gradient) gradient[ci] = ev.g[i];
+      for (int j = 0; j < n; ++j) {
+        const double h = ev.H[static_cast<size_t>(i) * n + j];
+        if (h == 0.0) continue;
+        const int cj = canon[j];
+        if (hfull) hfull[static_cast<size_t>(ci) * NC + cj] = h;
+        if (hdiag && ci / Bf == cj / Bf)
+          hdiag[(static_cast<size_t>(ci / Bf) * Bf + ci % Bf) * Bf + cj % Bf] = h;
+      }
+    }
+  }
+};
+
+}  // namespace cvdo
+
+// =====================================================================================================
+// C ABI (ctypes) -- mirrors include/cvd_hip.h with the prefix cvdo_
+// =====================================================================================================
+using cvdo::Oracle;
+
+#define CVDO_TRY(h, body)                               \
+  try {                                                 \
+    body;                                               \
+    return 0;                                           \
+  } catch (const std::exception& e) {                   \
+    if (h) static_cast<Oracle*>(h)->lastError = e.what(); \
+    return -1;                                          \
+  }
+
+extern "C" {
+
+void* cvdo_create() { return new Oracle(); }
+void cvdo_destroy(void* h) { delete static_cast<Oracle*>(h); }
+const char* cvdo_last_error(void* h) { return static_cast<Oracle*>(h)->lastError.c_str(); }
+
+int cvdo_set_video(void* h, int numFrames, int width, int height, float aspect, float invAspect) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->init(numFrames, width, height, aspect, invAspect));
+}
+int cvdo_set_depth(void* h, int frame, const float* depth) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    if (frame < 0 || frame >= o->F) throw std::runtime_error("frame out of range");
+    std::memcpy(&o->depth[static_cast<size_t>(frame) * o->W * o->Hh], depth,
+                sizeof(float) * o->W * o->Hh);
+  });
+}
+int cvdo_set_pair_constraints(void* h, int numPairs, const int32_t* pairFrames, const int64_t* offsets,
+                              const float* loc4, const uint8_t* isStatic) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    o->pairFrames.assign(pairFrames, pairFrames + 2 * numPairs);
+    o->pairOffsets.assign(offsets, offsets + numPairs + 1);
+    const int64_t C = offsets[numPairs];
+    o->pairLoc.assign(loc4, loc4 + 4 * C);
+    if (isStatic) o->pairStatic.assign(isStatic, isStatic + C);
+    else o->pairStatic.assign(C, 1);
+  });
+}
+int cvdo_set_triplet_constraints(void* h, int numTriplets, const int32_t* centers, const int64_t* offsets,
+                                 const float* loc6, const uint8_t* isStatic) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    o->tripletCenters.assign(centers, centers + numTriplets);
+    o->tripletOffsets.assign(offsets, offsets + numTriplets + 1);
+    const int64_t C = offsets[numTriplets];
+    o->tripletLoc.assign(loc6, loc6 + 6 * C);
+    if (isStatic) o->tripletStatic.assign(isStatic, isStatic + C);
+    else o->tripletStatic.assign(C, 1);
+  });
+}
+int cvdo_set_poses(void* h, const cvd_frame_pose* poses) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, o->poses.assign(poses, poses + o->F));
+}
+int cvdo_get_poses(void* h, cvd_frame_pose* poses) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, std::memcpy(poses, o->poses.data(), sizeof(cvd_frame_pose) * o->F));
+}
+int cvdo_reset_poses(void* h, double focalLong) { CVDO_TRY(h, static_cast<Oracle*>(h)->resetPoses(focalLong)); }
+int cvdo_reset_depth_xforms(void* h, const cvd_xform_desc* d) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->resetDepthXforms(*d));
+}
+int cvdo_reset_spatial_xforms(void* h, const cvd_xform_desc* d) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->resetSpatialXforms(*d));
+}
+int cvdo_grid_xform_split(void* h, const cvd_xform_desc* d) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->gridXformSplit(*d));
+}
+int cvdo_get_xform_desc(void* h, int spatial, cvd_xform_desc* d) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, *d = spatial ? o->spatialDesc : o->depthDesc);
+}
+int cvdo_num_xform_params(void* h, int spatial) {
+  Oracle* o = static_cast<Oracle*>(h);
+  const auto& v = spatial ? o->spatialXforms : o->depthXforms;
+  return v.empty() ? 0 : static_cast<int>(v[0].params.size());
+}
+int cvdo_get_xform_params(void* h, int spatial, double* out /*F x numParams*/) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    const auto& v = spatial ? o->spatialXforms : o->depthXforms;
+    for (int f = 0; f < o->F; ++f) {
+      const size_t np = v[f].params.size();
+      std::memcpy(out + f * np, v[f].params.data(), sizeof(double) * np);
+    }
+  });
+}
+int cvdo_set_xform_params(void* h, int spatial, const double* in) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    auto& v = spatial ? o->spatialXforms : o->depthXforms;
+    for (int f = 0; f < o->F; ++f) {
+      const size_t np = v[f].params.size();
+      std::memcpy(v[f].params.data(), in + f * np, sizeof(double) * np);
+    }
+  });
+}
+int cvdo_normalize_depth(void* h, const cvd_opt_params* p) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->normalizeDepth(*p));
+}
+int cvdo_pose_optimization(void* h, const cvd_opt_params* p) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->poseOptimization(*p));
+}
+int cvdo_pose_optimization_step(void* h, const cvd_opt_params* p, double depthDeformReg, int convertPoses) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    if (convertPoses) o->posesToParams();
+    o->records.clear();
+    o->poseOptimizationStep(*p, depthDeformReg);
+  });
+}
+int cvdo_get_pose_params(void* h, double* pose7) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    if (static_cast<int>(o->poseParams.size()) != o->F) o->posesToParams();
+    for (int f = 0; f < o->F; ++f)
+      for (int i = 0; i < 7; ++i) pose7[f * 7 + i] = o->poseParams[f][i];
+  });
+}
+int cvdo_block_size(void* h) { return static_cast<Oracle*>(h)->B(); }
+int cvdo_evaluate(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, double* cost,
+                  int* numResidualBlocks, double* gradient, double* hdiag, double* hfull) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->evaluate(*p, depthDeformReg, pose7, cost, numResidualBlocks, gradient,
+                                                hdiag, hfull));
+}
+int cvdo_get_summary(void* h, cvd_solve_summary* s) {
+  CVDO_TRY(h, *s = static_cast<Oracle*>(h)->lastSummary);
+}
+int cvdo_num_records(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->records.size()); }
+int cvdo_get_records(void* h, cvd_iteration_record* out) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, std::memcpy(out, o->records.data(), sizeof(cvd_iteration_record) * o->records.size()));
+}
+
+// ---- stand-alone known-answer hooks ----------------------------------------------------------------
+// Depth / spatial gather of one sample: returns the number of blocks, fills idx / w (<= 16).
+int cvdo_gather(const cvd_xform_desc* d, float srcDepth, float lx, float ly, int32_t* idx, double* w) {
+  try {
+    cvdo::Xform x = cvdo::Xform::create(*d);
+    cvdo::Gather g;
+    if (d->type == CVD_XFORM_DEPTH) x.depthGather(srcDepth, lx, ly, g);
+    else x.spatialGather(lx, ly, g);
+    for (int i = 0; i < g.n; ++i) { idx[i] = g.idx[i]; w[i] = g.w[i]; }
+    return g.n;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+void cvdo_angle_axis_rotate_point(const double* aa, const double* pt, double* out) {
+  cvdo::angleAxisRotatePoint(aa, pt, out);
+}
+void cvdo_rotation_matrix_to_angle_axis(const double* Rcm, double* aa) { cvdo::rotationMatrixToAngleAxis(Rcm, aa); }
+void cvdo_angle_axis_to_rotation_matrix(const double* aa, double* Rcm) { cvdo::angleAxisToRotationMatrix(aa, Rcm); }
+void cvdo_rotation_matrix_to_quaternion(const double* Rcm, double* q) { cvdo::rotationMatrixToEigenQuaternion(Rcm, q); }
+// Deformation cost of one transform (double): returns number of residuals.
+int cvdo_deformation_cost(const cvd_xform_desc* d, const double* params, double* residuals) {
+  try {
+    cvdo::Xform x = cvdo::Xform::create(*d);
+    std::vector<const double*> blocks(x.numBlocks);
+    for (int k = 0; k < x.numBlocks; ++k) blocks[k] = params + static_cast<size_t>(k) * x.blockSize;
+    x.deformationCost(blocks.data(), residuals);
+    return x.numDeformationResiduals();
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""ctypes binding of oracle/_build/libcvd_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Same method surface as robust_cvd_amd.api.Solver (both derive from robust_cvd_amd.binding.Binding) so
+that parity tests drive the HIP path and the oracle with identical calls.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from robust_cvd_amd.binding import Binding
+from robust_cvd_amd.ctypes_types import XformDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libcvd_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with g++ (seconds). Building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("cvd_oracle.cpp", "jet.h", "../include/cvd_types.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.cvdo_create.restype = C.c_void_p
+    return _lib
+
+
+class Oracle(Binding):
+    def __init__(self):
+        lib = load()
+        super().__init__(lib, "cvdo_", lib.cvdo_create())
+
+
+# ---- stand-alone known-answer hooks ------------------------------------------------------------------
+def gather(desc: XformDesc, src_depth, lx, ly):
+    lib = load()
+    idx = (C.c_int32 * 16)()
+    w = (C.c_double * 16)()
+    n = lib.cvdo_gather(C.byref(desc), C.c_float(src_depth), C.c_float(lx), C.c_float(ly), idx, w)
+    if n < 0:
+        raise RuntimeError("gather failed")
+    return np.array(idx[:n], dtype=np.int32), np.array(w[:n], dtype=np.float64)
+
+
+def angle_axis_rotate_point(aa, pt):
+    lib = load()
+    a = np.ascontiguousarray(aa, dtype=np.float64)
+    p = np.ascontiguousarray(pt, dtype=np.float64)
+    out = np.zeros(3)
+    lib.cvdo_angle_axis_rotate_point(a.ctypes.data_as(C.POINTER(C.c_double)),
+                                     p.ctypes.data_as(C.POINTER(C.c_double)),
+                                     out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def rotation_matrix_to_angle_axis(R):
+    lib = load()
+    Rcm = np.ascontiguousarray(np.asarray(R, dtype=np.float64).T)  # column-major storage
+    out = np.zeros(3)
+    lib.cvdo_rotation_matrix_to_angle_axis(Rcm.ctypes.data_as(C.POINTER(C.c_double)),
+                                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def angle_axis_to_rotation_matrix(aa):
+    lib = load()
+    a = np.ascontiguousarray(aa, dtype=np.float64)
+    out = np.zeros(9)
+    lib.cvdo_angle_axis_to_rotation_matrix(a.ctypes.data_as(C.POINTER(C.c_double)),
+                                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(3, 3).T.copy()
+
+
+def rotation_matrix_to_quaternion(R):
+    lib = load()
+    Rcm = np.ascontiguousarray(np.asarray(R, dtype=np.float64).T)
+    out = np.zeros(4)
+    lib.cvdo_rotation_matrix_to_quaternion(Rcm.ctypes.data_as(C.POINTER(C.c_double)),
+                                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out  # x, y, z, w
+
+
+def deformation_cost(desc: XformDesc, params):
+    lib = load()
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    out = np.zeros(4 * p.size + 8)
+    n = lib.cvdo_deformation_cost(C.byref(desc), p.ctypes.data_as(C.POINTER(C.c_double)),
+                                  out.ctypes.data_as(C.POINTER(C.c_double)))
+    if n < 0:
+        raise RuntimeError("deformation_cost failed")
+    return out[:n].copy()

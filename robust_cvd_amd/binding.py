@@ -1,0 +1,214 @@
+"""numpy <-> C-ABI marshalling shared by the product binding (robust_cvd_amd.api.Solver, prefix `cvd_`,
+include/cvd_hip.h) and by the test oracle's binding (oracle/oracle.py, prefix `cvdo_`).
+
+Only marshalling lives here: no arithmetic of the optimizer path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .ctypes_types import FramePose, IterationRecord, OptParams, SolveSummary, XformDesc
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Binding:
+    """Thin object wrapper over a handle-based C ABI. `lib` is a ctypes CDLL, `prefix` 'cvd_' or 'cvdo_'."""
+
+    def __init__(self, lib, prefix, handle):
+        self._lib = lib
+        self._p = prefix
+        self._h = C.c_void_p(handle)
+        self.num_frames = 0
+        self.width = 0
+        self.height = 0
+        if not self._h:
+            raise RuntimeError(f"{prefix}create failed")
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _fn(self, name, restype=C.c_int):
+        f = getattr(self._lib, self._p + name)
+        f.restype = restype
+        return f
+
+    def _check(self, rc):
+        if rc != 0:
+            err = self._fn("last_error", C.c_char_p)(self._h)
+            raise RuntimeError((err or b"unknown error").decode())
+
+    def close(self):
+        if self._h:
+            self._fn("destroy", None)(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs ----------------------------------------------------------------------------------
+    def set_video(self, num_frames, width, height, aspect=None, inv_aspect=None):
+        """DepthVideo dims: depth maps are width x height; aspect = video.aspect() (float)."""
+        if aspect is None:
+            aspect = np.float32(width) / np.float32(height)
+        if inv_aspect is None:
+            inv_aspect = np.float32(1.0) / np.float32(aspect)
+        self.num_frames, self.width, self.height = int(num_frames), int(width), int(height)
+        self.aspect, self.inv_aspect = float(np.float32(aspect)), float(np.float32(inv_aspect))
+        self._check(self._fn("set_video")(self._h, C.c_int(num_frames), C.c_int(width), C.c_int(height),
+                                          C.c_float(aspect), C.c_float(inv_aspect)))
+
+    def set_depth(self, frame, depth):
+        d = _f32(depth)
+        assert d.shape == (self.height, self.width), d.shape
+        self._check(self._fn("set_depth")(self._h, C.c_int(frame), _ptr(d, C.c_float)))
+
+    def set_depth_all(self, depth):
+        d = _f32(depth)
+        assert d.shape == (self.num_frames, self.height, self.width), d.shape
+        for f in range(self.num_frames):
+            self.set_depth(f, d[f])
+
+    def set_pair_constraints(self, pair_frames, offsets, loc, is_static=None):
+        pf = np.ascontiguousarray(pair_frames, dtype=np.int32).reshape(-1, 2)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        lc = _f32(loc).reshape(-1, 4)
+        assert off.shape[0] == pf.shape[0] + 1 and off[-1] == lc.shape[0]
+        st = None
+        if is_static is not None:
+            st = np.ascontiguousarray(is_static, dtype=np.uint8)
+            assert st.shape[0] == lc.shape[0]
+        self._check(self._fn("set_pair_constraints")(
+            self._h, C.c_int(pf.shape[0]), _ptr(pf, C.c_int32), _ptr(off, C.c_int64), _ptr(lc, C.c_float),
+            _ptr(st, C.c_uint8) if st is not None else None))
+
+    def set_triplet_constraints(self, centers, offsets, loc, is_static=None):
+        ce = np.ascontiguousarray(centers, dtype=np.int32)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        lc = _f32(loc).reshape(-1, 6)
+        st = None
+        if is_static is not None:
+            st = np.ascontiguousarray(is_static, dtype=np.uint8)
+        self._check(self._fn("set_triplet_constraints")(
+            self._h, C.c_int(ce.shape[0]), _ptr(ce, C.c_int32), _ptr(off, C.c_int64), _ptr(lc, C.c_float),
+            _ptr(st, C.c_uint8) if st is not None else None))
+
+    # -- state -----------------------------------------------------------------------------------
+    def set_poses(self, position, orientation_xyzw, vfov, hfov):
+        n = self.num_frames
+        arr = (FramePose * n)()
+        position = np.asarray(position, dtype=np.float32).reshape(n, 3)
+        orientation_xyzw = np.asarray(orientation_xyzw, dtype=np.float32).reshape(n, 4)
+        vfov = np.broadcast_to(np.asarray(vfov, dtype=np.float32), (n,))
+        hfov = np.broadcast_to(np.asarray(hfov, dtype=np.float32), (n,))
+        for i in range(n):
+            arr[i].position[:] = position[i].tolist()
+            arr[i].orientation[:] = orientation_xyzw[i].tolist()
+            arr[i].vfov = float(vfov[i])
+            arr[i].hfov = float(hfov[i])
+        self._check(self._fn("set_poses")(self._h, arr))
+
+    def get_poses(self):
+        n = self.num_frames
+        arr = (FramePose * n)()
+        self._check(self._fn("get_poses")(self._h, arr))
+        raw = np.frombuffer(arr, dtype=np.float32).reshape(n, 9).copy()
+        return {"position": raw[:, 0:3], "orientation": raw[:, 3:7], "vfov": raw[:, 7], "hfov": raw[:, 8]}
+
+    def reset_poses(self, focal_long=0.3461538376301239):
+        self._check(self._fn("reset_poses")(self._h, C.c_double(focal_long)))
+
+    def reset_depth_xforms(self, desc):
+        self._check(self._fn("reset_depth_xforms")(self._h, C.byref(desc)))
+
+    def reset_spatial_xforms(self, desc):
+        self._check(self._fn("reset_spatial_xforms")(self._h, C.byref(desc)))
+
+    def grid_xform_split(self, desc):
+        self._check(self._fn("grid_xform_split")(self._h, C.byref(desc)))
+
+    def xform_desc(self, spatial=False):
+        d = XformDesc()
+        self._check(self._fn("get_xform_desc")(self._h, C.c_int(int(spatial)), C.byref(d)))
+        return d
+
+    def num_xform_params(self, spatial=False):
+        return int(self._fn("num_xform_params")(self._h, C.c_int(int(spatial))))
+
+    def get_xform_params(self, spatial=False):
+        n = self.num_xform_params(spatial)
+        out = np.zeros((self.num_frames, n), dtype=np.float64)
+        if n:
+            self._check(self._fn("get_xform_params")(self._h, C.c_int(int(spatial)), _ptr(out, C.c_double)))
+        return out
+
+    def set_xform_params(self, values, spatial=False):
+        n = self.num_xform_params(spatial)
+        v = _f64(values).reshape(self.num_frames, n)
+        if n:
+            self._check(self._fn("set_xform_params")(self._h, C.c_int(int(spatial)), _ptr(v, C.c_double)))
+
+    def get_pose_params(self):
+        out = np.zeros((self.num_frames, 7), dtype=np.float64)
+        self._check(self._fn("get_pose_params")(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def block_size(self):
+        return int(self._fn("block_size")(self._h))
+
+    # -- the path --------------------------------------------------------------------------------
+    def normalize_depth(self, params):
+        self._check(self._fn("normalize_depth")(self._h, C.byref(params)))
+
+    def pose_optimization(self, params):
+        self._check(self._fn("pose_optimization")(self._h, C.byref(params)))
+
+    def pose_optimization_step(self, params, depth_deform_reg, convert_poses=True):
+        self._check(self._fn("pose_optimization_step")(self._h, C.byref(params), C.c_double(depth_deform_reg),
+                                                       C.c_int(int(convert_poses))))
+
+    def evaluate(self, params, depth_deform_reg, pose_params=None, want_gradient=True, want_hdiag=False,
+                 want_hfull=False):
+        """Cost / gradient / J^T J of the poseOptimizationStep problem at the current state (parity hook).
+        Layout: per frame [t(3) w(3) f(1) theta(G*N) phi(2S)], B = block_size()."""
+        B = self.block_size()
+        F = self.num_frames
+        cost = C.c_double(0.0)
+        nres = C.c_int(0)
+        g = np.zeros((F, B), dtype=np.float64) if want_gradient else None
+        hd = np.zeros((F, B, B), dtype=np.float64) if want_hdiag else None
+        hf = np.zeros((F * B, F * B), dtype=np.float64) if want_hfull else None
+        pp = _f64(pose_params).reshape(F, 7) if pose_params is not None else None
+        self._check(self._fn("evaluate")(
+            self._h, C.byref(params), C.c_double(depth_deform_reg),
+            _ptr(pp, C.c_double) if pp is not None else None, C.byref(cost), C.byref(nres),
+            _ptr(g, C.c_double) if g is not None else None,
+            _ptr(hd, C.c_double) if hd is not None else None,
+            _ptr(hf, C.c_double) if hf is not None else None))
+        return {"cost": cost.value, "num_residual_blocks": nres.value, "gradient": g, "hdiag": hd, "hfull": hf}
+
+    def summary(self):
+        s = SolveSummary()
+        self._check(self._fn("get_summary")(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def records(self):
+        n = int(self._fn("num_records")(self._h))
+        arr = (IterationRecord * max(n, 1))()
+        if n:
+            self._check(self._fn("get_records")(self._h, arr))
+        return [{k: getattr(arr[i], k) for k, _ in IterationRecord._fields_} for i in range(n)]
+
+
+__all__ = ["Binding", "OptParams", "XformDesc"]
