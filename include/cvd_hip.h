@@ -1,0 +1,117 @@
+/*
+ * cvd_hip.h -- C ABI of the MI355X-native geometric-consistency optimizer (libcvd_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of facebookresearch/robust_cvd: the pose / depth-deformation
+ * optimizer behind DepthVideoProcessor::{normalizeDepth, optimizePoses} (reference lib/Processor.cpp:1015-1025)
+ * i.e. DepthVideoPoseOptimizer (reference lib/PoseOptimizer.h:52-124, lib/PoseOptimizer.cpp), with the
+ * transform model of lib/DepthMapTransform.{h,cpp} and the constraint container of lib/FlowConstraints.h.
+ *
+ * The reference exposes this path through a pybind11 class surface (lib/PythonBindings.cpp:170-555), not a
+ * C ABI.  Each entry point below names the reference interface it replaces; INTEGRATION.md shows the
+ * reference-side stub (C++ and ctypes) a maintainer would add.  Handle-based, plain pointers and sizes,
+ * host buffers in / host buffers out; all device memory, streams and kernels are owned by the handle.
+ * Every function returns 0 on success and -1 on error (message: cvd_last_error), never aborts.
+ */
+#ifndef CVD_HIP_H_
+#define CVD_HIP_H_
+
+#include "cvd_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cvd_handle_t cvd_handle;
+
+/* Inner linear solver / LM knobs that have no counterpart in the reference (Ceres' SPARSE_NORMAL_CHOLESKY
+ * is replaced by a block-Jacobi preconditioned conjugate-gradient solve on the device). */
+typedef struct cvd_solver_options {
+  double pcg_relative_tolerance; /* stop when sqrt(r^T M^-1 r) <= tol * its initial value (default 1e-2) */
+  int32_t pcg_max_iterations;    /* default 300 */
+  int32_t pcg_check_every;       /* host convergence check cadence in CG iterations (default 4) */
+  int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
+  int32_t reserved;
+} cvd_solver_options;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+/* One optimizer per DepthVideo + depth stream (reference: DepthVideoPoseOptimizer ctor,
+ * lib/PoseOptimizer.cpp:748-783). `device` = HIP device ordinal. Fails (NULL) when no GPU is usable. */
+cvd_handle* cvd_create(int32_t device);
+void cvd_destroy(cvd_handle* h);
+const char* cvd_last_error(cvd_handle* h);
+/* sizeof() of the ABI structs as compiled, for binding self-checks: fills 6 ints
+ * {xform_desc, opt_params, frame_pose, iteration_record, solve_summary, solver_options}. */
+void cvd_abi_sizes(int32_t* out6);
+void cvd_opt_params_default(cvd_opt_params* p);       /* reference lib/PoseOptimizer.h:55-103 defaults */
+void cvd_solver_options_default(cvd_solver_options* o);
+int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o);
+
+/* ---- inputs (what the reference reads through DepthVideo / DepthStream / FlowConstraintsCollection) -- */
+/* DepthVideo dims + aspect (reference lib/DepthVideo.h: numFrames(), aspect(), invAspect(); DepthStream w/h). */
+int32_t cvd_set_video(cvd_handle* h, int32_t num_frames, int32_t width, int32_t height, float aspect,
+                      float inv_aspect);
+/* DepthFrame::sourceDepth() of one frame: width*height floats, row-major, depth (not disparity), invalid = 0
+ * (reference lib/DepthStream.cpp:176-216). Copied to HBM; the per-frame median used by the scale
+ * regulariser (lib/PoseOptimizer.cpp:1363-1375) is taken here. */
+int32_t cvd_set_depth(cvd_handle* h, int32_t frame, const float* depth);
+/* FlowConstraintsCollection pair constraints (reference lib/FlowConstraints.h:41-205): pair-major,
+ * pair_frames[2*P], offsets[P+1], loc4[4*C] = (loc0.xy, loc1.xy) in [0,1]x[0,invAspect], is_static[C] or NULL. */
+int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames,
+                                 const int64_t* offsets, const float* loc4, const uint8_t* is_static);
+/* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
+int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers,
+                                    const int64_t* offsets, const float* loc6, const uint8_t* is_static);
+
+/* ---- per-frame state (DepthFrame::{extrinsics,intrinsics,depthXform(),spatialXform()}) --------------- */
+int32_t cvd_set_poses(cvd_handle* h, const cvd_frame_pose* poses /* [F] */);
+int32_t cvd_get_poses(cvd_handle* h, cvd_frame_pose* poses /* [F] */);
+/* DepthVideoProcessor::resetPoses (reference lib/Processor.cpp:987-1003) */
+int32_t cvd_reset_poses(cvd_handle* h, double focal_long);
+/* DepthStream::resetDepthXforms / resetSpatialXforms (reference lib/DepthStream.cpp:368-383) */
+int32_t cvd_reset_depth_xforms(cvd_handle* h, const cvd_xform_desc* desc);
+int32_t cvd_reset_spatial_xforms(cvd_handle* h, const cvd_xform_desc* desc);
+/* DepthVideoProcessor::gridXformSplit (reference lib/Processor.cpp:888-985) */
+int32_t cvd_grid_xform_split(cvd_handle* h, const cvd_xform_desc* desc);
+int32_t cvd_get_xform_desc(cvd_handle* h, int32_t spatial, cvd_xform_desc* desc);
+int32_t cvd_num_xform_params(cvd_handle* h, int32_t spatial);          /* Xform::numParams() */
+int32_t cvd_get_xform_params(cvd_handle* h, int32_t spatial, double* out /* [F x numParams] */);
+int32_t cvd_set_xform_params(cvd_handle* h, int32_t spatial, const double* in /* [F x numParams] */);
+/* Internal 7-tuples (t, angle-axis, tan(vFov/2)) of reference lib/PoseOptimizer.h:149, [F x 7] doubles. */
+int32_t cvd_get_pose_params(cvd_handle* h, double* pose7);
+int32_t cvd_block_size(cvd_handle* h); /* unknowns per frame: 7 + depth params + spatial params */
+
+/* ---- the path --------------------------------------------------------------------------------------- */
+/* DepthVideoPoseOptimizer::normalizeDepth (reference lib/PoseOptimizer.cpp:992-1147) */
+int32_t cvd_normalize_depth(cvd_handle* h, const cvd_opt_params* params);
+/* DepthVideoPoseOptimizer::poseOptimization (reference lib/PoseOptimizer.cpp:788-888) */
+int32_t cvd_pose_optimization(cvd_handle* h, const cvd_opt_params* params);
+/* DepthVideoPoseOptimizer::poseOptimizationStep (reference lib/PoseOptimizer.cpp:890-990).
+ * convert_poses != 0: rebuild the internal 7-tuples from the float poses first (what constructing a new
+ * DepthVideoPoseOptimizer does); 0: continue from the double-precision tuples of the previous step. */
+int32_t cvd_pose_optimization_step(cvd_handle* h, const cvd_opt_params* params, double depth_deform_reg,
+                                   int32_t convert_poses);
+/* Parity hook: cost, gradient (F x B) and per-frame J^T J blocks (F x B x B) of the poseOptimizationStep
+ * problem at the current state (pose7 != NULL overrides the 7-tuples). Any output pointer may be NULL.
+ * hfull ((F*B)^2, small problems only) is produced by F*B device mat-vec products with unit vectors. */
+int32_t cvd_evaluate(cvd_handle* h, const cvd_opt_params* params, double depth_deform_reg,
+                     const double* pose7, double* cost, int32_t* num_residual_blocks, double* gradient,
+                     double* hdiag, double* hfull);
+int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s);
+int32_t cvd_num_records(cvd_handle* h);
+int32_t cvd_get_records(cvd_handle* h, cvd_iteration_record* out);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------------------- */
+/* Average duration (ms) of the dominant kernels over the last solve, measured with HIP events on the
+ * solver's own stream: fills {evaluate_assemble, matvec_pairs, matvec_finish, cg_update, block_inverse,
+ * cost} and their launch counts. */
+int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6);
+/* Enable / disable per-launch event timing (costs a sync per launch; off by default). */
+int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
+/* Number of (valid static) constraints in the compiled table of the last solve. */
+int64_t cvd_num_active_constraints(cvd_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CVD_HIP_H_ */

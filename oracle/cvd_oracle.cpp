@@ -1985,9 +1985,9 @@ struct Oracle {
 // =====================================================================================================
 using cvdo::Oracle;
 
-#define CVDO_TRY(h, body)                               \
+#define CVDO_TRY(h, ...)                                \
   try {                                                 \
-    body;                                               \
+    __VA_ARGS__;                                        \
     return 0;                                           \
   } catch (const std::exception& e) {                   \
     if (h) static_cast<Oracle*>(h)->lastError = e.what(); \

@@ -1,0 +1,92 @@
+"""Python host mirror of the optimizer path over the C ABI of libcvd_hip.so (include/cvd_hip.h).
+
+`Solver` has the method surface of the reference's DepthVideoProcessor / DepthVideoPoseOptimizer calls used by
+`pose_optimization.py` (reference pose_optimization.py:177-240): reset_depth_xforms, reset_spatial_xforms,
+normalize_depth, pose_optimization (= optimizePoses), grid_xform_split.  There is NO fallback: if the HIP
+library is missing, or no GPU is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+from .binding import Binding
+from .ctypes_types import OptParams, SolveSummary, XformDesc  # noqa: F401 (re-exported)
+
+_lib = None
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [
+        ("pcg_relative_tolerance", C.c_double),
+        ("pcg_max_iterations", C.c_int32),
+        ("pcg_check_every", C.c_int32),
+        ("verbose", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+def load_library():
+    """dlopen the in-tree libcvd_hip.so. Raises ImportError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). robust_cvd_amd has no CPU fallback.")
+        lib = C.CDLL(path)
+        lib.cvd_create.restype = C.c_void_p
+        lib.cvd_create.argtypes = [C.c_int32]
+        lib.cvd_last_error.restype = C.c_char_p
+        lib.cvd_last_error.argtypes = [C.c_void_p]
+        lib.cvd_num_active_constraints.restype = C.c_int64
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
+    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_video", "cvd_set_depth",
+    "cvd_set_pair_constraints", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
+    "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
+    "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
+    "cvd_get_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
+    "cvd_pose_optimization_step", "cvd_evaluate", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
+    "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints",
+]
+
+KERNEL_CLASSES = ["evaluate_assemble", "matvec_pairs", "matvec_finish", "cg_update", "block_inverse", "cost"]
+
+
+class Solver(Binding):
+    def __init__(self, device=0):
+        lib = load_library()
+        handle = lib.cvd_create(C.c_int32(device))
+        if not handle:
+            raise RuntimeError("cvd_create failed: " + (lib.cvd_last_error(None) or b"").decode())
+        super().__init__(lib, "cvd_", handle)
+
+    def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None):
+        o = SolverOptions()
+        self._lib.cvd_solver_options_default(C.byref(o))
+        if pcg_relative_tolerance is not None:
+            o.pcg_relative_tolerance = pcg_relative_tolerance
+        if pcg_max_iterations is not None:
+            o.pcg_max_iterations = pcg_max_iterations
+        if pcg_check_every is not None:
+            o.pcg_check_every = pcg_check_every
+        if verbose is not None:
+            o.verbose = int(verbose)
+        self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
+
+    def set_kernel_timing(self, enabled=True):
+        self._check(self._fn("set_kernel_timing")(self._h, C.c_int32(int(enabled))))
+
+    def kernel_times(self):
+        ms = (C.c_double * 6)()
+        n = (C.c_int64 * 6)()
+        self._check(self._fn("get_kernel_times")(self._h, ms, n))
+        return {k: {"avg_ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def num_active_constraints(self):
+        return int(self._lib.cvd_num_active_constraints(self._h))

@@ -1,0 +1,639 @@
+// cvd_device.h -- device-side math of the geometric-consistency optimizer (gfx950 / CDNA4 only).
+//
+// What the reference evaluates per residual block with Ceres dual numbers
+// (reference lib/PoseOptimizer.cpp:142-308, lib/DepthMapTransform.cpp:585-948,1214-1343) is evaluated
+// here in closed form: residual + ANALYTIC Jacobian, so that one constraint costs
+// a few hundred f64 FMAs instead of ceil(P/4) Jet passes.  Rotation data that is constant per frame
+// (R(w) and dR/dw_i of ceres::AngleAxisRotatePoint's two-branch formula) is hoisted into FrameConst.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvd {
+
+// ---------------------------------------------------------------------------------------------------
+// Problem layout, passed by value to every kernel (all fields uniform -> SGPRs).
+// Per-frame unknown block: [t(3) w(3) fy(1) | theta (numDepthBlocks*N) | phi (numSpatialBlocks*2)].
+// ---------------------------------------------------------------------------------------------------
+struct Layout {
+  int F, B;
+  // depth transform
+  int depthType;  // cvd_depth_xform_type
+  int N;          // value-transform params per vertex (0 identity, 1 Scale, 2 ScaleShift)
+  int cubic;
+  int gx, gy;     // grid cols / rows (1 for Global)
+  double maxcx, maxcy;  // nextafter(g-1, 0)
+  int nD;         // depth params per frame
+  // spatial transform
+  int spatialType;  // cvd_spatial_xform_type
+  int sgx, sgy;
+  double smaxcx, smaxcy;
+  int nS;  // spatial params per frame
+  // camera / loss
+  double aspect, vFocal;
+  int intrOpt, lossType;
+  double ws, wd;      // staticSpatialWeight, staticDepthWeight
+  double cauchyB;     // robustness^2
+  double cauchyC;     // 1 / robustness^2
+  // regularisers (already decided by the host: 0 => skipped)
+  double scaleRegSqrt;   // sqrt(scaleReg) (ScaledLoss => sqrt weight on the residual)
+  int sregX, sregY;      // scale-regulariser sample grid
+  double focalRegSqrt;   // sqrt(focalReg)
+  double depthDeformW;   // plain multiplier (no loss function)
+  double spatialDeformW; // plain multiplier
+  int includeStatic;     // 0 for normalizeDepth's default problem
+};
+
+// cvd enums duplicated as plain ints to keep this header free of host headers.
+enum : int { kDepthIdentity = 1, kDepthGlobal = 2, kDepthGrid = 3 };
+enum : int { kSpIdentity = 1, kSpVertical = 2, kSpCorners = 3, kSpBilinear = 4, kSpBicubic = 5 };
+enum : int { kLossEuclid = 0, kLossDisparity = 1, kLossRatio = 2, kLossLog = 3 };
+enum : int { kIntrFixed = 0, kIntrShared = 1, kIntrPerFrame = 2 };
+
+// Per-frame constants of one evaluation point (40 doubles).
+struct FrameConst {
+  double R[9];      // row-major R(w): ceres::AngleAxisRotatePoint as a matrix (I + [w]x below eps)
+  double dR[3][9];  // dR/dw_i, differentiated through the SAME branch
+  double t[3];
+  double fy;        // vertical focal actually used (vFocal when intrinsics are fixed)
+};
+
+__device__ __forceinline__ void frameConstFromParams(const double* __restrict__ x, int intrOpt, double vFocal,
+                                                     const double* __restrict__ x0, FrameConst& fc) {
+  const double wx = x[3], wy = x[4], wz = x[5];
+  fc.t[0] = x[0]; fc.t[1] = x[1]; fc.t[2] = x[2];
+  fc.fy = (intrOpt == kIntrFixed) ? vFocal : (intrOpt == kIntrShared ? x0[6] : x[6]);
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  const double w[3] = {wx, wy, wz};
+  if (th2 > 2.220446049250313e-16) {
+    const double th = sqrt(th2);
+    const double s = sin(th), c = cos(th);
+    const double ti = 1.0 / th;
+    const double k[3] = {wx * ti, wy * ti, wz * ti};
+    const double oc = 1.0 - c;
+    // R = c I + s K + (1-c) k k^T
+    fc.R[0] = c + oc * k[0] * k[0];      fc.R[1] = -s * k[2] + oc * k[0] * k[1]; fc.R[2] = s * k[1] + oc * k[0] * k[2];
+    fc.R[3] = s * k[2] + oc * k[1] * k[0]; fc.R[4] = c + oc * k[1] * k[1];      fc.R[5] = -s * k[0] + oc * k[1] * k[2];
+    fc.R[6] = -s * k[1] + oc * k[2] * k[0]; fc.R[7] = s * k[0] + oc * k[2] * k[1]; fc.R[8] = c + oc * k[2] * k[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      // d theta / d w_i = k_i ; d k / d w_i = (e_i - k k_i) / theta
+      double dk[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dk[j] = ((i == j ? 1.0 : 0.0) - k[j] * k[i]) * ti;
+      const double ki = k[i];
+      double* D = fc.dR[i];
+      // -s k_i I + c k_i K + s dK + s k_i k k^T + (1-c)(dk k^T + k dk^T)
+      const double a = -s * ki, b = c * ki, e = s * ki;
+      const double K[9] = {0.0, -k[2], k[1], k[2], 0.0, -k[0], -k[1], k[0], 0.0};
+      const double dK[9] = {0.0, -dk[2], dk[1], dk[2], 0.0, -dk[0], -dk[1], dk[0], 0.0};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          D[r * 3 + q] = (r == q ? a : 0.0) + b * K[r * 3 + q] + s * dK[r * 3 + q] + e * k[r] * k[q] +
+                         oc * (dk[r] * k[q] + k[r] * dk[q]);
+    }
+  } else {
+    fc.R[0] = 1.0;   fc.R[1] = -w[2]; fc.R[2] = w[1];
+    fc.R[3] = w[2];  fc.R[4] = 1.0;   fc.R[5] = -w[0];
+    fc.R[6] = -w[1]; fc.R[7] = w[0];  fc.R[8] = 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) fc.dR[i][q] = 0.0;
+    // d/dw_0 [w]x = [[0,0,0],[0,0,-1],[0,1,0]] etc.
+    fc.dR[0][5] = -1.0; fc.dR[0][7] = 1.0;
+    fc.dR[1][2] = 1.0;  fc.dR[1][6] = -1.0;
+    fc.dR[2][1] = -1.0; fc.dR[2][3] = 1.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gathers (which vertices a sample depends on, with which weights)
+// reference lib/DepthMapTransform.cpp:739-851 (linear), :853-948 (cubic, border folding),
+// :1107-1114, :1181-1191, :1253-1343 (spatial)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gridCell(float loc, int g, double maxc, int& i, double& r) {
+  double s = (static_cast<double>(loc) + 1.0) * static_cast<double>(g - 1) / 2.0;
+  s = fmin(fmax(s, 0.0), maxc);
+  i = static_cast<int>(s);
+  r = s - static_cast<double>(i);
+}
+
+__device__ __forceinline__ void cubicTaps(double t, double w[4]) {
+  const double t2 = t * t;
+  const double t3 = t2 * t;
+  w[0] = -0.5 * t3 + t2 - 0.5 * t;
+  w[1] = 1.5 * t3 - 2.5 * t2 + 1.0;
+  w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t;
+  w[3] = 0.5 * t3 - 0.5 * t2;
+}
+
+template <int K>
+struct Taps {
+  int n;
+  int idx[K];
+  double w[K];
+};
+
+__device__ __forceinline__ void bilinearTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
+                                             double* w) {
+  int ix, iy;
+  double rx, ry;
+  gridCell(lx, gx, mx, ix, rx);
+  gridCell(ly, gy, my, iy, ry);
+  const int i0 = ix + iy * gx;
+  idx[0] = i0;          w[0] = (1.0 - rx) * (1.0 - ry);
+  idx[1] = i0 + 1;      w[1] = rx * (1.0 - ry);
+  idx[2] = i0 + gx;     w[2] = (1.0 - rx) * ry;
+  idx[3] = i0 + gx + 1; w[3] = rx * ry;
+}
+
+// 2-D Catmull-Rom gather with out-of-range taps folded onto the clamped neighbour.
+__device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
+                                           double* w) {
+  int ix, iy;
+  double rx, ry;
+  gridCell(lx, gx, mx, ix, rx);
+  gridCell(ly, gy, my, iy, ry);
+  double wx[4], wy[4];
+  cubicTaps(rx, wx);
+  cubicTaps(ry, wy);
+  const int x0 = (ix == 0 ? 1 : 0);
+  const int x1 = (ix == gx - 2 ? 3 : 4);
+  const int y0 = (iy == 0 ? 1 : 0);
+  const int y1 = (iy == gy - 2 ? 3 : 4);
+  const int xs = x1 - x0, ys = y1 - y0;
+  // fold the 1-D weights first (the 2-D weights are separable products of the folded 1-D weights)
+  double fx[4] = {0.0, 0.0, 0.0, 0.0}, fy[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int cx = min(max(x - x0, 0), xs - 1);
+    const int cy = min(max(x - y0, 0), ys - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == cx) fx[q] += wx[x];
+      if (q == cy) fy[q] += wy[x];
+    }
+  }
+  int n = 0;
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      if (y < ys && x < xs) {
+        idx[n] = (ix - 1 + x0 + x) + (iy - 1 + y0 + y) * gx;
+        w[n] = fx[x] * fy[y];
+        ++n;
+      }
+    }
+  }
+  return n;
+}
+
+template <int KD>
+__device__ __forceinline__ void depthGather(const Layout& L, float lx, float ly, Taps<KD>& t) {
+  if (L.depthType == kDepthGlobal) {
+    t.n = 1;
+    t.idx[0] = 0;
+    t.w[0] = 1.0;
+  } else if (L.depthType == kDepthGrid) {
+    if constexpr (KD >= 16) {
+      if (L.cubic) {
+        t.n = bicubicTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.idx, t.w);
+        return;
+      }
+    }
+    if constexpr (KD >= 4) {
+      t.n = 4;
+      bilinearTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.idx, t.w);
+    } else {
+      t.n = 0;
+    }
+  } else {
+    t.n = 0;
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void spatialGather(const Layout& L, float lx, float ly, Taps<KS>& t) {
+  if constexpr (KS == 0) {
+    t.n = 0;
+    return;
+  } else {
+    switch (L.spatialType) {
+      case kSpVertical: {
+        const double w0 = 0.5 + 0.5 * static_cast<double>(ly);
+        t.n = 2;
+        t.idx[0] = 0; t.w[0] = w0;
+        t.idx[1] = 1; t.w[1] = 1.0 - w0;
+        break;
+      }
+      case kSpCorners: {
+        const double wx = 0.5 + 0.5 * static_cast<double>(lx);
+        const double wy = 0.5 + 0.5 * static_cast<double>(ly);
+        t.n = 4;
+        t.idx[0] = 0; t.w[0] = wx * wy;
+        t.idx[1] = 1; t.w[1] = (1.0 - wx) * wy;
+        t.idx[2] = 2; t.w[2] = wx * (1.0 - wy);
+        t.idx[3] = 3; t.w[3] = (1.0 - wx) * (1.0 - wy);
+        break;
+      }
+      case kSpBilinear:
+        t.n = 4;
+        bilinearTaps(lx, ly, L.sgx, L.sgy, L.smaxcx, L.smaxcy, t.idx, t.w);
+        break;
+      case kSpBicubic:
+        if constexpr (KS >= 16) {
+          t.n = bicubicTaps(lx, ly, L.sgx, L.sgy, L.smaxcx, L.smaxcy, t.idx, t.w);
+        } else {
+          t.n = 0;
+        }
+        break;
+      default:
+        t.n = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One static constraint: residual, robust weight, and the compact Jacobian of both sides.
+// Columns of one side: 7 pose-like (t, w, fy) | depth taps (value params) | spatial taps (2 each).
+//   d r / d theta_k[0] = JD * w_k * d_src ;  d r / d theta_k[1] = JD * w_k ;  d r / d phi_k[c] = JP[.][c] * u_k
+// ---------------------------------------------------------------------------------------------------
+template <int KD, int KS>
+struct Side {
+  double Jp[3][7];
+  double JD[3];
+  double JP[3][2];
+  Taps<KD> dt;
+  Taps<KS> st;
+  double d;  // source depth (double of the float fetched with truncation)
+};
+
+template <int KD, int KS>
+struct Sample {
+  double r[3];
+  double rho0, rho1;  // rho(s), rho'(s) of CauchyLoss
+  Side<KD, KS> a, b;
+};
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+template <int KD, int KS>
+__device__ __forceinline__ double sideDepth(const Layout& L, const Side<KD, KS>& s, const double* __restrict__ xf) {
+  if (L.depthType == kDepthIdentity) return s.d;
+  double D = 0.0;
+  const double* th = xf + 7;
+  for (int k = 0; k < s.dt.n; ++k) {
+    const double v = (L.N == 2) ? (s.d * th[s.dt.idx[k] * 2] + th[s.dt.idx[k] * 2 + 1]) : (s.d * th[s.dt.idx[k]]);
+    D += v * s.dt.w[k];
+  }
+  return D;
+}
+
+// xa / xb: the two frames' parameter blocks (LDS or global). Returns false when the sample is skipped.
+template <int KD, int KS, bool WANT_JAC>
+__device__ __forceinline__ void evalSample(const Layout& L, const FrameConst& fa, const FrameConst& fb,
+                                           const double* __restrict__ xa, const double* __restrict__ xb,
+                                           const float4 ndc, const float2 dsrc, Sample<KD, KS>& s) {
+  constexpr double eps = 1e-6;
+  s.a.d = static_cast<double>(dsrc.x);
+  s.b.d = static_cast<double>(dsrc.y);
+  depthGather<KD>(L, ndc.x, ndc.y, s.a.dt);
+  depthGather<KD>(L, ndc.z, ndc.w, s.b.dt);
+  spatialGather<KS>(L, ndc.x, ndc.y, s.a.st);
+  spatialGather<KS>(L, ndc.z, ndc.w, s.b.st);
+
+  const double Da = sideDepth(L, s.a, xa);
+  const double Db = sideDepth(L, s.b, xb);
+  double pa[2] = {static_cast<double>(ndc.x), static_cast<double>(ndc.y)};
+  double pb[2] = {static_cast<double>(ndc.z), static_cast<double>(ndc.w)};
+  if constexpr (KS > 0) {
+    const double* pha = xa + 7 + L.nD;
+    const double* phb = xb + 7 + L.nD;
+    for (int k = 0; k < s.a.st.n; ++k) {
+      pa[0] += pha[s.a.st.idx[k] * 2] * s.a.st.w[k];
+      pa[1] += pha[s.a.st.idx[k] * 2 + 1] * s.a.st.w[k];
+    }
+    for (int k = 0; k < s.b.st.n; ++k) {
+      pb[0] += phb[s.b.st.idx[k] * 2] * s.b.st.w[k];
+      pb[1] += phb[s.b.st.idx[k] * 2 + 1] * s.b.st.w[k];
+    }
+  }
+  const double A = L.aspect;
+  const double fya = fa.fy, fxa = fa.fy * A;
+  const double fyb = fb.fy, fxb = fb.fy * A;
+
+  // X = t_a + D_a R_a c_a
+  const double ca[3] = {pa[0] * fxa, pa[1] * fya, -1.0};
+  const double Rca[3] = {dot3(fa.R, ca), dot3(fa.R + 3, ca), dot3(fa.R + 6, ca)};
+  const double X[3] = {fa.t[0] + Rca[0] * Da, fa.t[1] + Rca[1] * Da, fa.t[2] + Rca[2] * Da};
+
+  double G[3][3];   // d r / d X
+  double M[3][3];   // d r / d q (reprojection variants)
+  double v[3] = {0, 0, 0};
+  double u = 0, vv = 0, z = 1;
+  double dr2dDb = 0.0;
+  double Rcb[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+
+  if (L.lossType == kLossEuclid) {
+    cb[0] = pb[0] * fxb; cb[1] = pb[1] * fyb; cb[2] = -1.0;
+    Rcb[0] = dot3(fb.R, cb); Rcb[1] = dot3(fb.R + 3, cb); Rcb[2] = dot3(fb.R + 6, cb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s.r[i] = (fb.t[i] + Rcb[i] * Db) - X[i];
+  } else {
+    v[0] = X[0] - fb.t[0]; v[1] = X[1] - fb.t[1]; v[2] = X[2] - fb.t[2];
+    // q = R_b^T v  (AngleAxisRotatePoint with the negated angle-axis)
+    const double q[3] = {fb.R[0] * v[0] + fb.R[3] * v[1] + fb.R[6] * v[2],
+                         fb.R[1] * v[0] + fb.R[4] * v[1] + fb.R[7] * v[2],
+                         fb.R[2] * v[0] + fb.R[5] * v[1] + fb.R[8] * v[2]};
+    z = -q[2];
+    u = q[0] / z / fxb;
+    vv = q[1] / z / fyb;
+    s.r[0] = (u - pb[0]) * L.ws;
+    s.r[1] = (vv - pb[1]) * L.ws;
+    double dr2dA = 0.0;  // d r2 / d z
+    if (L.lossType == kLossDisparity) {
+      const bool zo = !(z < eps);  // max(z, eps): ties keep z
+      const bool bo = !(Db < eps);
+      const double zz = zo ? z : eps;
+      const double bb = bo ? Db : eps;
+      s.r[2] = (1.0 / zz - 1.0 / bb) * L.wd;
+      dr2dA = zo ? (-L.wd / (zz * zz)) : 0.0;
+      dr2dDb = bo ? (L.wd / (bb * bb)) : 0.0;
+    } else {
+      // maxDepth = max(z, Db) (ties -> z), minDepth = min(z, Db) (ties -> z)
+      const bool zIsMax = !(z < Db);
+      const bool zIsMin = !(Db < z);
+      const double mx = zIsMax ? z : Db;
+      const double mn = zIsMin ? z : Db;
+      if (L.lossType == kLossRatio) {
+        s.r[2] = (mx / mn - 1.0) * L.wd;
+        const double dmx = 1.0 / mn, dmn = -mx / (mn * mn);
+        dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+        dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+      } else {
+        s.r[2] = log(mn / mx) * L.wd;
+        const double dmn = 1.0 / mn, dmx = -1.0 / mx;
+        dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+        dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+      }
+    }
+    if constexpr (WANT_JAC) {
+      const double iz = 1.0 / z;
+      M[0][0] = L.ws * iz / fxb; M[0][1] = 0.0;             M[0][2] = L.ws * u * iz;
+      M[1][0] = 0.0;             M[1][1] = L.ws * iz / fyb; M[1][2] = L.ws * vv * iz;
+      M[2][0] = 0.0;             M[2][1] = 0.0;             M[2][2] = -dr2dA;  // z = -q.z
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          G[r][i] = M[r][0] * fb.R[i * 3 + 0] + M[r][1] * fb.R[i * 3 + 1] + M[r][2] * fb.R[i * 3 + 2];
+    }
+  }
+
+  const double sq = s.r[0] * s.r[0] + s.r[1] * s.r[1] + s.r[2] * s.r[2];
+  const double sum = 1.0 + sq * L.cauchyC;
+  s.rho0 = L.cauchyB * log(sum);
+  s.rho1 = 1.0 / sum;
+
+  if constexpr (WANT_JAC) {
+    // world-point derivatives of side a
+    double dXdw[3][3];  // [i][row]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dXdw[i][0] = Da * dot3(fa.dR[i], ca);
+      dXdw[i][1] = Da * dot3(fa.dR[i] + 3, ca);
+      dXdw[i][2] = Da * dot3(fa.dR[i] + 6, ca);
+    }
+    const double cf[3] = {pa[0] * A, pa[1], 0.0};
+    const double dXdf[3] = {Da * dot3(fa.R, cf), Da * dot3(fa.R + 3, cf), Da * dot3(fa.R + 6, cf)};
+    const double dXdpx[3] = {Da * fxa * fa.R[0], Da * fxa * fa.R[3], Da * fxa * fa.R[6]};
+    const double dXdpy[3] = {Da * fya * fa.R[1], Da * fya * fa.R[4], Da * fya * fa.R[7]};
+
+    if (L.lossType == kLossEuclid) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          s.a.Jp[r][c] = (r == c) ? -1.0 : 0.0;
+          s.b.Jp[r][c] = (r == c) ? 1.0 : 0.0;
+          s.a.Jp[r][3 + c] = -dXdw[c][r];
+        }
+        s.a.Jp[r][6] = -dXdf[r];
+        s.a.JD[r] = -Rca[r];
+        s.a.JP[r][0] = -dXdpx[r];
+        s.a.JP[r][1] = -dXdpy[r];
+        const double* Rr = fb.R + 3 * r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.b.Jp[r][3 + c] = Db * dot3(fb.dR[c] + 3 * r, cb);
+        const double cfb[3] = {pb[0] * A, pb[1], 0.0};
+        s.b.Jp[r][6] = Db * dot3(Rr, cfb);
+        s.b.JD[r] = Rcb[r];
+        s.b.JP[r][0] = Db * fxb * Rr[0];
+        s.b.JP[r][1] = Db * fyb * Rr[1];
+      }
+    } else {
+      // d q / d w_b,i = dR_b,i^T v
+      double dqdw[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double* D = fb.dR[i];
+        dqdw[i][0] = D[0] * v[0] + D[3] * v[1] + D[6] * v[2];
+        dqdw[i][1] = D[1] * v[0] + D[4] * v[1] + D[7] * v[2];
+        dqdw[i][2] = D[2] * v[0] + D[5] * v[1] + D[8] * v[2];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          s.a.Jp[r][c] = G[r][c];
+          s.b.Jp[r][c] = -G[r][c];
+          s.a.Jp[r][3 + c] = dot3(G[r], dXdw[c]);
+          s.b.Jp[r][3 + c] = dot3(M[r], dqdw[c]);
+        }
+        s.a.Jp[r][6] = dot3(G[r], dXdf);
+        s.a.JD[r] = dot3(G[r], Rca);
+        s.a.JP[r][0] = dot3(G[r], dXdpx);
+        s.a.JP[r][1] = dot3(G[r], dXdpy);
+      }
+      s.b.Jp[0][6] = -L.ws * u / fyb;
+      s.b.Jp[1][6] = -L.ws * vv / fyb;
+      s.b.Jp[2][6] = 0.0;
+      s.b.JD[0] = 0.0; s.b.JD[1] = 0.0; s.b.JD[2] = dr2dDb;
+      s.b.JP[0][0] = -L.ws; s.b.JP[0][1] = 0.0;
+      s.b.JP[1][0] = 0.0;   s.b.JP[1][1] = -L.ws;
+      s.b.JP[2][0] = 0.0;   s.b.JP[2][1] = 0.0;
+    }
+  }
+}
+
+// Number of tap columns of one side and accessors: column id inside the frame block + d r/d column.
+template <int KD, int KS>
+__device__ __forceinline__ int sideNumTapCols(const Layout& L, const Side<KD, KS>& s) {
+  return s.dt.n * L.N + s.st.n * 2;
+}
+template <int KD, int KS>
+__device__ __forceinline__ void sideTapCol(const Layout& L, const Side<KD, KS>& s, int t, int& col, double J[3]) {
+  const int nd = s.dt.n * L.N;
+  if (t < nd) {
+    const int k = (L.N == 2) ? (t >> 1) : t;
+    const int n = (L.N == 2) ? (t & 1) : 0;
+    col = 7 + s.dt.idx[k] * L.N + n;
+    const double m = s.dt.w[k] * (n == 0 ? s.d : 1.0);
+    J[0] = s.JD[0] * m; J[1] = s.JD[1] * m; J[2] = s.JD[2] * m;
+  } else {
+    const int tt = t - nd;
+    const int k = tt >> 1, c = tt & 1;
+    col = 7 + L.nD + s.st.idx[k] * 2 + c;
+    const double m = s.st.w[k];
+    J[0] = s.JP[0][c] * m; J[1] = s.JP[1][c] * m; J[2] = s.JP[2][c] * m;
+  }
+}
+
+// (J_side p)(r) for r = 0..2 with p the frame's (masked) direction block.
+template <int KD, int KS>
+__device__ __forceinline__ void sideJp(const Layout& L, const Side<KD, KS>& s, const double* __restrict__ p, double out[3]) {
+  double sD = 0.0, sP0 = 0.0, sP1 = 0.0;
+  const double* th = p + 7;
+  for (int k = 0; k < s.dt.n; ++k) {
+    const double v = (L.N == 2) ? (s.d * th[s.dt.idx[k] * 2] + th[s.dt.idx[k] * 2 + 1])
+                                : (L.N == 1 ? s.d * th[s.dt.idx[k]] : 0.0);
+    sD += v * s.dt.w[k];
+  }
+  if constexpr (KS > 0) {
+    const double* ph = p + 7 + L.nD;
+    for (int k = 0; k < s.st.n; ++k) {
+      sP0 += ph[s.st.idx[k] * 2] * s.st.w[k];
+      sP1 += ph[s.st.idx[k] * 2 + 1] * s.st.w[k];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double a = s.JD[r] * sD + s.JP[r][0] * sP0 + s.JP[r][1] * sP1;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a += s.Jp[r][c] * p[c];
+    out[r] += a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-frame regularisers (reference lib/PoseOptimizer.cpp:1341-1415 scale, :1524-1549 focal,
+// :1449-1522 deformation with lib/DepthMapTransform.cpp:631-667 / :60-70).
+// visit(r, n, cols[], jac[]) is called for every regulariser residual of the frame, residual index
+// `i` strided over the calling threads.  Weights are folded in (sqrt for ScaledLoss, plain for deform).
+// ---------------------------------------------------------------------------------------------------
+template <int KD>
+__device__ __forceinline__ int numRegResiduals(const Layout& L) {
+  int n = 0;
+  if (L.scaleRegSqrt > 0.0) n += L.sregX * L.sregY;
+  if (L.focalRegSqrt > 0.0) n += 1;
+  if (L.depthDeformW > 0.0 && L.depthType == kDepthGrid) n += ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+  if (L.spatialDeformW > 0.0) n += L.nS;
+  return n;
+}
+
+// Evaluates regulariser residual `i` of a frame. cols/jac have room for 2*KD (>= 2) entries.
+template <int KD>
+__device__ __forceinline__ void regResidual(const Layout& L, int i, const double* __restrict__ xf, float median,
+                                            double& r, int& n, int* cols, double* jac) {
+  constexpr double eps = 1e-6;
+  n = 0;
+  r = 0.0;
+  if (L.scaleRegSqrt > 0.0) {
+    const int ns = L.sregX * L.sregY;
+    if (i < ns) {
+      const int y = i / L.sregX, x = i - y * L.sregX;
+      // float arithmetic of reference lib/PoseOptimizer.cpp:1384-1385
+      const float lx = __fadd_rn(-1.f, __fdiv_rn(__fmul_rn(2.f, static_cast<float>(x)), static_cast<float>(L.sregX - 1)));
+      const float ly = __fadd_rn(-1.f, __fdiv_rn(__fmul_rn(2.f, static_cast<float>(y)), static_cast<float>(L.sregY - 1)));
+      Taps<KD> t;
+      depthGather<KD>(L, lx, ly, t);
+      const double d = static_cast<double>(median);
+      double D = (L.depthType == kDepthIdentity) ? d : 0.0;
+      const double* th = xf + 7;
+      for (int k = 0; k < t.n; ++k) {
+        const double v = (L.N == 2) ? (d * th[t.idx[k] * 2] + th[t.idx[k] * 2 + 1]) : (d * th[t.idx[k]]);
+        D += v * t.w[k];
+      }
+      const bool o = !(D < eps);
+      const double dd = o ? D : eps;
+      r = L.scaleRegSqrt * (1.0 / dd - 1.0);
+      const double drdD = o ? (-L.scaleRegSqrt / (dd * dd)) : 0.0;
+      for (int k = 0; k < t.n; ++k) {
+        if (L.N == 2) {
+          cols[n] = 7 + t.idx[k] * 2;     jac[n++] = drdD * t.w[k] * d;
+          cols[n] = 7 + t.idx[k] * 2 + 1; jac[n++] = drdD * t.w[k];
+        } else {
+          cols[n] = 7 + t.idx[k]; jac[n++] = drdD * t.w[k] * d;
+        }
+      }
+      return;
+    }
+    i -= ns;
+  }
+  if (L.focalRegSqrt > 0.0) {
+    if (i == 0) {
+      r = L.focalRegSqrt * (xf[6] - L.vFocal);
+      n = 1;
+      cols[0] = 6;
+      jac[0] = L.focalRegSqrt;
+      return;
+    }
+    i -= 1;
+  }
+  if (L.depthDeformW > 0.0 && L.depthType == kDepthGrid) {
+    const int nEdges = ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+    if (i < nEdges) {
+      // enumerate edges in any order (a sum): first the x-edges, then the y-edges
+      const int dim = i % L.N;
+      int e = i / L.N;
+      int va, vb;
+      const int nxE = (L.gx - 1) * L.gy;
+      if (e < nxE) {
+        const int y = e / (L.gx - 1), x = e - y * (L.gx - 1) + 1;
+        va = x + y * L.gx;
+        vb = va - 1;
+      } else {
+        e -= nxE;
+        const int y = e / L.gx + 1, x = e - (y - 1) * L.gx;
+        va = x + y * L.gx;
+        vb = va - L.gx;
+      }
+      const double a = xf[7 + va * L.N + dim];
+      const double b = xf[7 + vb * L.N + dim];
+      const double aa = fabs(a), ab = fabs(b);
+      const bool pickB = ab < aa;  // min(|a|, |b|): ties keep |a|
+      const double sc = pickB ? ab : aa;
+      const double diff = a - b;
+      r = L.depthDeformW * diff / sc;
+      const double dsda = pickB ? 0.0 : (a < 0.0 ? -1.0 : 1.0);
+      const double dsdb = pickB ? (b < 0.0 ? -1.0 : 1.0) : 0.0;
+      n = 2;
+      cols[0] = 7 + va * L.N + dim;
+      jac[0] = L.depthDeformW * (1.0 / sc - diff / (sc * sc) * dsda);
+      cols[1] = 7 + vb * L.N + dim;
+      jac[1] = L.depthDeformW * (-1.0 / sc - diff / (sc * sc) * dsdb);
+      return;
+    }
+    i -= nEdges;
+  }
+  if (L.spatialDeformW > 0.0 && i < L.nS) {
+    r = L.spatialDeformW * xf[7 + L.nD + i];
+    n = 1;
+    cols[0] = 7 + L.nD + i;
+    jac[0] = L.spatialDeformW;
+  }
+}
+
+// Wave-level sum of a double (64 lanes).
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace cvd

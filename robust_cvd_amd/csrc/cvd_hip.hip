@@ -1,0 +1,1432 @@
+// cvd_hip.hip -- host side of libcvd_hip.so: device memory, the Levenberg-Marquardt driver, the
+// block-Jacobi PCG linear solve, the coarse-to-fine schedule and the C ABI of include/cvd_hip.h.
+//
+// Mirrors (file:line relative to the reference root, facebookresearch/robust_cvd):
+//   DepthVideoPoseOptimizer ctor / pose write-back   lib/PoseOptimizer.cpp:748-783, 964-987
+//   poseOptimization (CTF schedule, deferred spatial) lib/PoseOptimizer.cpp:788-888
+//   poseOptimizationStep (which terms, which blocks constant)  lib/PoseOptimizer.cpp:890-952
+//   normalizeDepth                                      lib/PoseOptimizer.cpp:992-1147
+//   gridXformSplit / resetPoses                         lib/Processor.cpp:888-1003
+//   trust-region loop = Ceres defaults (the reference only sets solver type / max iterations / threads,
+//   lib/PoseOptimizer.cpp:955-961); the sparse Cholesky is replaced by PCG.
+//
+// gfx950 only. There is NO CPU path: every entry point that computes fails if no HIP device is usable.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cvd_hip.h"
+#include "cvd_kernels.h"
+
+namespace cvd {
+
+static std::string fmt(const char* f, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return buf;
+}
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      throw std::runtime_error(fmt("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__,    \
+                                   __LINE__, hipGetErrorString(e_)));                            \
+  } while (0)
+
+static double nowSeconds() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    release();
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+  }
+  void upload(const T* src, size_t count, hipStream_t s) {
+    ensure(count);
+    if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void download(T* dst, size_t count, hipStream_t s) const {
+    if (count) HIP_CHECK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+};
+
+// ---- transform bookkeeping on the host (Xform::params_ layout, reference lib/DepthMapTransform.cpp:526-534,
+// 702-707, 1102, 1176, 1356-1357) ---------------------------------------------------------------------
+static int valueNumParams(int t) {
+  if (t == CVD_VALUE_SCALE) return 1;
+  if (t == CVD_VALUE_SCALE_SHIFT) return 2;
+  throw std::runtime_error("Invalid value transform.");
+}
+static int xformBlockSize(const cvd_xform_desc& d) {
+  if (d.type == CVD_XFORM_DEPTH) return d.depth_type == CVD_DEPTH_IDENTITY ? 0 : valueNumParams(d.value_xform);
+  return d.spatial_type == CVD_SPATIAL_IDENTITY ? 0 : 2;
+}
+static int xformNumBlocks(const cvd_xform_desc& d) {
+  if (d.type == CVD_XFORM_DEPTH) {
+    switch (d.depth_type) {
+      case CVD_DEPTH_IDENTITY: return 0;
+      case CVD_DEPTH_GLOBAL: return 1;
+      case CVD_DEPTH_GRID: {
+        const int gx = d.grid_size[0], gy = d.grid_size[1], gz = d.grid_size[2];
+        if (gx > 1 || gy > 1)
+          if (gx < 2 || gy < 2)
+            throw std::runtime_error(
+                "Spatial grid transforms must have at least two rows and columns, respectively.");
+        if (valueNumParams(d.value_xform) * gx * gy * gz <= 1)
+          throw std::runtime_error("Grid transform cannot have an empty grid.");
+        return gx * gy * gz;
+      }
+      default: throw std::runtime_error("Invalid depth transform type.");
+    }
+  } else if (d.type == CVD_XFORM_SPATIAL) {
+    switch (d.spatial_type) {
+      case CVD_SPATIAL_IDENTITY: return 0;
+      case CVD_SPATIAL_VERTICAL_LINEAR: return 2;
+      case CVD_SPATIAL_CORNERS_BILINEAR: return 4;
+      case CVD_SPATIAL_BILINEAR_GRID:
+      case CVD_SPATIAL_BICUBIC_GRID:
+        if (d.grid_size[1] < 2 || d.grid_size[0] < 2)
+          throw std::logic_error("Need at least two rows and columns in depth transform grid.");
+        return d.grid_size[0] * d.grid_size[1];
+      default: throw std::runtime_error("Invalid spatial transform type.");
+    }
+  }
+  throw std::runtime_error("Invalid transform type.");
+}
+
+// ---- rotation conversions on the host (ceres/rotation.h + Eigen semantics) -------------
+static void quatToMatrix(const double q[4] /*x,y,z,w*/, double R[3][3]) {
+  // columns = q * e_x, q * e_y, q * e_z with Eigen's v + w*uv + qv x uv, uv = 2 qv x v
+  for (int c = 0; c < 3; ++c) {
+    double v[3] = {0, 0, 0};
+    v[c] = 1.0;
+    const double uv[3] = {2.0 * (q[1] * v[2] - q[2] * v[1]), 2.0 * (q[2] * v[0] - q[0] * v[2]),
+                          2.0 * (q[0] * v[1] - q[1] * v[0])};
+    R[0][c] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    R[1][c] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    R[2][c] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+  }
+}
+static void matrixToAngleAxis(const double R[3][3], double aa[3]) {
+  double q0, q1, q2, q3;  // w, x, y, z
+  const double tr = R[0][0] + R[1][1] + R[2][2];
+  if (tr >= 0.0) {
+    double t = std::sqrt(tr + 1.0);
+    q0 = 0.5 * t;
+    t = 0.5 / t;
+    q1 = (R[2][1] - R[1][2]) * t;
+    q2 = (R[0][2] - R[2][0]) * t;
+    q3 = (R[1][0] - R[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    double qq[4];
+    qq[i + 1] = 0.5 * t;
+    t = 0.5 / t;
+    qq[0] = (R[k][j] - R[j][k]) * t;
+    qq[j + 1] = (R[j][i] + R[i][j]) * t;
+    qq[k + 1] = (R[k][i] + R[i][k]) * t;
+    q0 = qq[0]; q1 = qq[1]; q2 = qq[2]; q3 = qq[3];
+  }
+  const double s2 = q1 * q1 + q2 * q2 + q3 * q3;
+  if (s2 > 0.0) {
+    const double s = std::sqrt(s2);
+    const double two = 2.0 * ((q0 < 0.0) ? std::atan2(-s, -q0) : std::atan2(s, q0));
+    const double k = two / s;
+    aa[0] = q1 * k; aa[1] = q2 * k; aa[2] = q3 * k;
+  } else {
+    aa[0] = q1 * 2.0; aa[1] = q2 * 2.0; aa[2] = q3 * 2.0;
+  }
+}
+static void angleAxisToMatrix(const double aa[3], double R[3][3]) {
+  const double th2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (th2 > std::numeric_limits<double>::epsilon()) {
+    const double th = std::sqrt(th2);
+    const double wx = aa[0] / th, wy = aa[1] / th, wz = aa[2] / th;
+    const double c = std::cos(th), s = std::sin(th);
+    R[0][0] = c + wx * wx * (1 - c);       R[1][0] = wz * s + wx * wy * (1 - c);  R[2][0] = -wy * s + wx * wz * (1 - c);
+    R[0][1] = wx * wy * (1 - c) - wz * s;  R[1][1] = c + wy * wy * (1 - c);       R[2][1] = wx * s + wy * wz * (1 - c);
+    R[0][2] = wy * s + wx * wz * (1 - c);  R[1][2] = -wx * s + wy * wz * (1 - c); R[2][2] = c + wz * wz * (1 - c);
+  } else {
+    R[0][0] = 1;      R[1][0] = aa[2];  R[2][0] = -aa[1];
+    R[0][1] = -aa[2]; R[1][1] = 1;      R[2][1] = aa[0];
+    R[0][2] = aa[1];  R[1][2] = -aa[0]; R[2][2] = 1;
+  }
+}
+static void matrixToQuat(const double R[3][3], double q[4] /*x,y,z,w*/) {
+  double t = R[0][0] + R[1][1] + R[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[2][1] - R[1][2]) * t;
+    q[1] = (R[0][2] - R[2][0]) * t;
+    q[2] = (R[1][0] - R[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k][j] - R[j][k]) * t;
+    q[j] = (R[j][i] + R[i][j]) * t;
+    q[k] = (R[k][i] + R[i][k]) * t;
+  }
+}
+
+enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPDATE, KC_INVERSE, KC_COST, KC_COUNT };
+
+struct Ceres {  // ceres::Solver::Options defaults used on this path
+  static constexpr double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
+  static constexpr double min_relative_decrease = 1e-3;
+  static constexpr double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  static constexpr int max_consecutive_invalid = 5;
+};
+
+enum ProblemKind { PK_POSE_STEP = 0, PK_NORMALIZE = 1 };
+
+}  // namespace cvd
+
+using namespace cvd;
+
+struct cvd_handle_t {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  cvd_solver_options opt{};
+
+  // video
+  int F = 0, W = 0, H = 0;
+  float aspect = 1.f, invAspect = 1.f;
+  DevBuf<float> dDepth;
+  std::vector<float> median;
+  DevBuf<float> dMedian;
+  bool medianDirty = true;
+
+  // constraints
+  int P = 0;
+  long long C = 0;
+  std::vector<int> pairA, pairB;
+  std::vector<long long> pairOff;
+  DevBuf<int> dPairA, dPairB, dCPair;
+  DevBuf<long long> dPairOff;
+  DevBuf<float4> dLoc, dNdc;
+  DevBuf<float2> dDsrc;
+  DevBuf<unsigned char> dStatic, dInRange;
+  bool haveTriplets = false;
+
+  // work decomposition
+  std::vector<int> itemPair;
+  std::vector<long long> itemBegin, itemEnd;
+  DevBuf<int> dItemPair, dFiOff, dFiList, dFpOff, dFpList;
+  DevBuf<long long> dItemBegin, dItemEnd;
+  std::vector<unsigned char> tableRange;  // range the table / items were compiled for
+  bool tableValid = false;
+  long long numValid = 0;
+
+  // state
+  std::vector<cvd_frame_pose> poses;
+  cvd_xform_desc ddesc{}, sdesc{};
+  std::vector<double> dparams, sparams;  // F x nD, F x nS
+  std::vector<std::array<double, 7>> poseParams;
+  bool poseParamsValid = false;
+
+  // solver buffers
+  DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dZ, dP0, dP1, dQ, dH, dMinv, dWork, dQPart;
+  DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd;
+  DevBuf<FrameConst> dFc;
+  DevBuf<int> dFail;
+  DevBuf<unsigned long long> dCount;
+  double* hScal = nullptr;  // pinned
+
+  // results
+  cvd_solve_summary summary{};
+  std::vector<cvd_iteration_record> records;
+
+  // kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
+  std::vector<int> evClass;
+  size_t evUsed = 0;
+  double kcMs[KC_COUNT] = {0};
+  long long kcN[KC_COUNT] = {0};
+
+  ~cvd_handle_t() {
+    for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (hScal) (void)hipHostFree(hScal);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int nD() const { return xformNumBlocks(ddesc) * xformBlockSize(ddesc); }
+  int nS() const { return xformNumBlocks(sdesc) * xformBlockSize(sdesc); }
+  int Bsz() const { return 7 + nD() + nS(); }
+
+  // ---- timing helpers --------------------------------------------------------------------------------
+  int tBegin(int kc) {
+    if (!timing) return -1;
+    if (evUsed == evPool.size()) {
+      hipEvent_t a, b;
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+      evPool.emplace_back(a, b);
+      evClass.push_back(kc);
+    }
+    evClass[evUsed] = kc;
+    HIP_CHECK(hipEventRecord(evPool[evUsed].first, stream));
+    return static_cast<int>(evUsed++);
+  }
+  void tEnd(int slot) {
+    if (slot >= 0) HIP_CHECK(hipEventRecord(evPool[slot].second, stream));
+  }
+  void tCollect() {
+    if (!timing || evUsed == 0) return;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < evUsed; ++i) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, evPool[i].first, evPool[i].second));
+      kcMs[evClass[i]] += ms;
+      kcN[evClass[i]] += 1;
+    }
+    evUsed = 0;
+  }
+};
+
+namespace cvd {
+
+static std::vector<int> rangeOf(const cvd_opt_params& p, int F) {
+  std::vector<int> r;
+  if (!p.frame_range || p.num_range_frames <= 0) {
+    for (int i = 0; i < F; ++i) r.push_back(i);
+  } else {
+    r.assign(p.frame_range, p.frame_range + p.num_range_frames);
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    for (int f : r)
+      if (f < 0 || f >= F) throw std::runtime_error("frame range out of bounds");
+  }
+  return r;
+}
+
+// DepthVideoPoseOptimizer ctor, reference lib/PoseOptimizer.cpp:753-782
+static void posesToParams(cvd_handle* h) {
+  h->poseParams.resize(h->F);
+  for (int f = 0; f < h->F; ++f) {
+    const cvd_frame_pose& p = h->poses[f];
+    auto& pose = h->poseParams[f];
+    pose[0] = p.position[0];
+    pose[1] = p.position[1];
+    pose[2] = p.position[2];
+    const double q[4] = {p.orientation[0], p.orientation[1], p.orientation[2], p.orientation[3]};
+    double R[3][3];
+    quatToMatrix(q, R);  // columns right, up, -front == q*ex, q*ey, q*ez
+    matrixToAngleAxis(R, &pose[3]);
+    pose[6] = std::tan(p.vfov / 2.0);
+  }
+  h->poseParamsValid = true;
+}
+
+// pose write-back, reference lib/PoseOptimizer.cpp:964-987
+static void paramsToPoses(cvd_handle* h, const cvd_opt_params& params) {
+  for (int f : rangeOf(params, h->F)) {
+    const auto& pose = h->poseParams[f];
+    cvd_frame_pose& p = h->poses[f];
+    p.position[0] = static_cast<float>(pose[0]);
+    p.position[1] = static_cast<float>(pose[1]);
+    p.position[2] = static_cast<float>(pose[2]);
+    double R[3][3], q[4];
+    angleAxisToMatrix(&pose[3], R);
+    matrixToQuat(R, q);
+    for (int i = 0; i < 4; ++i) p.orientation[i] = static_cast<float>(q[i]);
+    const double fsrc = (params.intr_opt == CVD_INTR_SHARED) ? h->poseParams[0][6] : pose[6];
+    p.vfov = static_cast<float>(std::atan(fsrc) * 2.f);
+    p.hfov = static_cast<float>(std::atan(fsrc * h->aspect) * 2.f);
+  }
+}
+
+static void resetXforms(cvd_handle* h, const cvd_xform_desc& d, bool spatial) {
+  const int nb = xformNumBlocks(d), bs = xformBlockSize(d);
+  if (!spatial) {
+    if (d.type != CVD_XFORM_DEPTH) throw std::runtime_error("Transform has the wrong type.");
+    if (d.depth_type == CVD_DEPTH_GRID && d.grid_size[2] > 1)
+      throw std::runtime_error("Depth-wise (gridSize.z > 1) grids are not implemented on the device path.");
+    if (d.depth_type == CVD_DEPTH_GRID && !d.cubic_interpolation && bs != 1 && d.grid_size[0] > 1)
+      throw std::runtime_error(
+          "Linear grid gather is only defined for 1-parameter value transforms (reference "
+          "lib/DepthMapTransform.cpp:829 aliases the blocks otherwise).");
+    h->ddesc = d;
+    h->dparams.assign(static_cast<size_t>(h->F) * nb * bs, 1.0);
+  } else {
+    if (d.type != CVD_XFORM_SPATIAL) throw std::runtime_error("Transform has the wrong type.");
+    h->sdesc = d;
+    h->sparams.assign(static_cast<size_t>(h->F) * nb * bs, 0.0);
+  }
+}
+
+// DepthVideoProcessor::gridXformSplit, reference lib/Processor.cpp:888-985
+static void gridXformSplit(cvd_handle* h, const cvd_xform_desc& nd) {
+  if (nd.depth_type != CVD_DEPTH_GRID) throw std::runtime_error("Transform type must be a grid type.");
+  const cvd_xform_desc prev = h->ddesc;
+  if (prev.depth_type != CVD_DEPTH_GLOBAL && prev.depth_type != CVD_DEPTH_GRID)
+    throw std::runtime_error("Can only split global or grid type transforms.");
+  if (nd.value_xform != prev.value_xform)
+    throw std::runtime_error("Old and new transforms must use same value transform.");
+  if (prev.depth_type != CVD_DEPTH_GLOBAL &&
+      (prev.grid_size[0] > nd.grid_size[0] || prev.grid_size[1] > nd.grid_size[1]))
+    throw std::runtime_error(
+        "New transform must have at least the same number of rows and columns as the old transform.");
+  const std::vector<double> old = h->dparams;
+  const int oldN = h->nD();
+  resetXforms(h, nd, false);
+  const int N = xformBlockSize(nd);
+  const int newCols = nd.grid_size[0], newRows = nd.grid_size[1];
+  const int newN = h->nD();
+  for (int f = 0; f < h->F; ++f) {
+    const double* po = &old[static_cast<size_t>(f) * oldN];
+    double* pn = &h->dparams[static_cast<size_t>(f) * newN];
+    for (int row = 0; row < newRows; ++row) {
+      for (int col = 0; col < newCols; ++col) {
+        double* dst = pn + static_cast<size_t>(col + row * newCols) * N;
+        if (prev.depth_type == CVD_DEPTH_GLOBAL) {
+          for (int i = 0; i < N; ++i) dst[i] = po[i];
+        } else {
+          const int prevRows = prev.grid_size[1], prevCols = prev.grid_size[0];
+          const double maxx = std::nextafter(static_cast<double>(prevCols - 1), 0.0);
+          const double maxy = std::nextafter(static_cast<double>(prevRows - 1), 0.0);
+          const double sx = std::min(col / double(newCols - 1) * (prevCols - 1), maxx);
+          const double sy = std::min(row / double(newRows - 1) * (prevRows - 1), maxy);
+          const int ix = static_cast<int>(sx), iy = static_cast<int>(sy);
+          const double rx = sx - ix, ry = sy - iy;
+          const double* b0 = po + static_cast<size_t>(ix + iy * prevCols) * N;
+          const double* b1 = po + static_cast<size_t>((ix + 1) + iy * prevCols) * N;
+          const double* b2 = po + static_cast<size_t>(ix + (iy + 1) * prevCols) * N;
+          const double* b3 = po + static_cast<size_t>((ix + 1) + (iy + 1) * prevCols) * N;
+          const double w0 = (1.f - rx) * (1.f - ry), w1 = rx * (1.f - ry), w2 = (1.f - rx) * ry, w3 = rx * ry;
+          for (int i = 0; i < N; ++i) dst[i] = b0[i] * w0 + b1[i] * w1 + b2[i] * w2 + b3[i] * w3;
+        }
+      }
+    }
+  }
+}
+
+// ---- problem -> device layout -------------------------------------------------------------------------
+static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
+  if (p.adaptive_deformation_cost > 0.0)
+    throw std::runtime_error("AdaptiveDeformationCost is not implemented (off by default in the reference).");
+  if (p.intr_opt == CVD_INTR_SHARED && kind == PK_POSE_STEP)
+    throw std::runtime_error("IntrinsicsOptimization::Shared is not implemented on the device path yet.");
+  if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP)
+    throw std::runtime_error("Scene-flow smoothness (triplet) loss is not implemented on the device path yet.");
+  if (p.position_reg > 0.0 && kind == PK_POSE_STEP)
+    throw std::runtime_error("Position regularisation is not implemented on the device path yet.");
+  Layout L{};
+  L.F = h->F;
+  L.B = h->Bsz();
+  L.depthType = h->ddesc.depth_type;
+  L.N = xformBlockSize(h->ddesc);
+  L.cubic = h->ddesc.cubic_interpolation ? 1 : 0;
+  L.gx = h->ddesc.depth_type == CVD_DEPTH_GRID ? h->ddesc.grid_size[0] : 1;
+  L.gy = h->ddesc.depth_type == CVD_DEPTH_GRID ? h->ddesc.grid_size[1] : 1;
+  L.maxcx = std::nextafter(static_cast<double>(L.gx - 1), 0.0);
+  L.maxcy = std::nextafter(static_cast<double>(L.gy - 1), 0.0);
+  L.nD = h->nD();
+  L.spatialType = h->sdesc.spatial_type;
+  L.sgx = h->sdesc.grid_size[0];
+  L.sgy = h->sdesc.grid_size[1];
+  L.smaxcx = std::nextafter(static_cast<double>(L.sgx - 1), 0.0);
+  L.smaxcy = std::nextafter(static_cast<double>(L.sgy - 1), 0.0);
+  L.nS = h->nS();
+  L.aspect = h->aspect;
+  L.vFocal = (h->aspect >= 1.f ? p.focal_long / static_cast<double>(h->aspect) : p.focal_long);
+  L.intrOpt = p.intr_opt;
+  L.lossType = p.static_loss_type;
+  L.ws = p.static_spatial_weight;
+  L.wd = p.static_depth_weight;
+  L.cauchyB = p.robustness * p.robustness;
+  L.cauchyC = 1.0 / L.cauchyB;
+  // scale regulariser sample grid, reference lib/PoseOptimizer.cpp:1347-1351
+  int gX = p.scale_reg_grid_size;
+  int gY = static_cast<int>(std::round(static_cast<float>(gX) * h->invAspect));
+  if (h->aspect <= 1.f) std::swap(gX, gY);
+  L.sregX = gX;
+  L.sregY = gY;
+  if (kind == PK_POSE_STEP) {
+    L.includeStatic = 1;
+    L.scaleRegSqrt = (!p.fix_depth_xforms && p.scale_reg > 0.0) ? std::sqrt(p.scale_reg) : 0.0;
+    L.focalRegSqrt = (p.focal_reg > 0.0 && p.intr_opt != CVD_INTR_FIXED) ? std::sqrt(p.focal_reg) : 0.0;
+    L.depthDeformW = depthDeformReg > 0.0 ? depthDeformReg : 0.0;
+    L.spatialDeformW = p.spatial_deform_reg > 0.0 ? p.spatial_deform_reg : 0.0;
+  } else {
+    if (!p.normalize_depth_from_first_frame)
+      throw std::runtime_error(
+          "normalizeDepth with normalizeDepthFromFirstFrame=false is not implemented on the device path "
+          "(the flag is not reachable from the reference's Python bindings).");
+    L.includeStatic = 0;
+    L.scaleRegSqrt = p.scale_reg > 0.0 ? std::sqrt(p.scale_reg) : 0.0;
+    L.focalRegSqrt = 0.0;
+    L.depthDeformW = p.depth_deform_reg_initial > 0.0 ? p.depth_deform_reg_initial : 0.0;
+    L.spatialDeformW = 0.0;
+  }
+  if (L.scaleRegSqrt > 0.0 && (L.sregX < 2 || L.sregY < 2))
+    throw std::runtime_error("scaleRegGridSize too small for this aspect ratio.");
+  return L;
+}
+
+static void tapCounts(const Layout& L, int& KD, int& KS) {
+  KD = (L.depthType == CVD_DEPTH_GRID) ? (L.cubic ? 16 : 4) : 1;
+  switch (L.spatialType) {
+    case CVD_SPATIAL_IDENTITY: KS = 0; break;
+    case CVD_SPATIAL_BICUBIC_GRID: KS = 16; break;
+    default: KS = 4;
+  }
+}
+
+#define CVD_DISPATCH(KDv, KSv, ...)                                             \
+  do {                                                                          \
+    if (KDv == 1 && KSv == 0) { constexpr int KD = 1, KS = 0; __VA_ARGS__; }     \
+    else if (KDv == 4 && KSv == 0) { constexpr int KD = 4, KS = 0; __VA_ARGS__; } \
+    else if (KDv == 16 && KSv == 0) { constexpr int KD = 16, KS = 0; __VA_ARGS__; } \
+    else if (KDv == 1 && KSv == 4) { constexpr int KD = 1, KS = 4; __VA_ARGS__; } \
+    else if (KDv == 4 && KSv == 4) { constexpr int KD = 4, KS = 4; __VA_ARGS__; } \
+    else if (KDv == 16 && KSv == 4) { constexpr int KD = 16, KS = 4; __VA_ARGS__; } \
+    else if (KDv == 1 && KSv == 16) { constexpr int KD = 1, KS = 16; __VA_ARGS__; } \
+    else if (KDv == 4 && KSv == 16) { constexpr int KD = 4, KS = 16; __VA_ARGS__; } \
+    else { constexpr int KD = 16, KS = 16; __VA_ARGS__; }                        \
+  } while (0)
+
+#define CVD_DISPATCH_KD(KDv, ...)                                  \
+  do {                                                             \
+    if (KDv == 1) { constexpr int KD = 1; __VA_ARGS__; }            \
+    else if (KDv == 4) { constexpr int KD = 4; __VA_ARGS__; }       \
+    else { constexpr int KD = 16; __VA_ARGS__; }                    \
+  } while (0)
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename K>
+static void allowLds(K kernel, size_t bytes) {
+  if (bytes > kMaxLds)
+    throw std::runtime_error(fmt("per-frame block needs %zu B of LDS (> 160 KiB): frame block too large", bytes));
+  if (bytes > 48 * 1024)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(bytes)));
+}
+
+// ---- compile the constraint table + work decomposition for a frame range -------------------------------
+static void compileTable(cvd_handle* h, const std::vector<int>& range) {
+  std::vector<unsigned char> inRange(h->F, 0);
+  for (int f : range) inRange[f] = 1;
+  if (h->tableValid && inRange == h->tableRange) return;
+  hipStream_t s = h->stream;
+  h->dInRange.upload(inRange.data(), inRange.size(), s);
+  h->dNdc.ensure(std::max<long long>(h->C, 1));
+  h->dDsrc.ensure(std::max<long long>(h->C, 1));
+  h->dCount.ensure(1);
+  HIP_CHECK(hipMemsetAsync(h->dCount.p, 0, sizeof(unsigned long long), s));
+  if (h->C > 0) {
+    const int bs = 256;
+    const unsigned grid = static_cast<unsigned>((h->C + bs - 1) / bs);
+    hipLaunchKernelGGL(k_build_table, dim3(grid), dim3(bs), 0, s, h->W, h->H, h->invAspect, h->C, h->dLoc.p,
+                       h->dStatic.p, h->dCPair.p, h->dPairA.p, h->dPairB.p, h->dInRange.p, h->dDepth.p,
+                       h->dNdc.p, h->dDsrc.p, h->dCount.p);
+    HIP_CHECK(hipGetLastError());
+  }
+  unsigned long long nv = 0;
+  HIP_CHECK(hipMemcpyAsync(&nv, h->dCount.p, sizeof(nv), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  h->numValid = static_cast<long long>(nv);
+
+  // work items: balanced chunks of <= 768 constraints of one pair
+  h->itemPair.clear();
+  h->itemBegin.clear();
+  h->itemEnd.clear();
+  std::vector<std::vector<int>> frameItems(h->F), framePairs(h->F);
+  for (int p = 0; p < h->P; ++p) {
+    const int a = h->pairA[p], b = h->pairB[p];
+    if (!inRange[a] || !inRange[b]) continue;
+    const long long n = h->pairOff[p + 1] - h->pairOff[p];
+    if (n <= 0) continue;
+    framePairs[a].push_back(p * 2 + 0);
+    framePairs[b].push_back(p * 2 + 1);
+    const long long nItems = (n + 767) / 768;
+    const long long chunk = (n + nItems - 1) / nItems;
+    for (long long k = 0; k < nItems; ++k) {
+      const long long b0 = h->pairOff[p] + k * chunk;
+      const long long b1 = std::min(h->pairOff[p + 1], b0 + chunk);
+      if (b0 >= b1) continue;
+      const int item = static_cast<int>(h->itemPair.size());
+      h->itemPair.push_back(p);
+      h->itemBegin.push_back(b0);
+      h->itemEnd.push_back(b1);
+      frameItems[a].push_back(item * 2 + 0);
+      frameItems[b].push_back(item * 2 + 1);
+    }
+  }
+  std::vector<int> fiOff(h->F + 1, 0), fiList, fpOff(h->F + 1, 0), fpList;
+  for (int f = 0; f < h->F; ++f) {
+    fiOff[f + 1] = fiOff[f] + static_cast<int>(frameItems[f].size());
+    fiList.insert(fiList.end(), frameItems[f].begin(), frameItems[f].end());
+    fpOff[f + 1] = fpOff[f] + static_cast<int>(framePairs[f].size());
+    fpList.insert(fpList.end(), framePairs[f].begin(), framePairs[f].end());
+  }
+  h->dItemPair.upload(h->itemPair.data(), h->itemPair.size(), s);
+  h->dItemBegin.upload(h->itemBegin.data(), h->itemBegin.size(), s);
+  h->dItemEnd.upload(h->itemEnd.data(), h->itemEnd.size(), s);
+  h->dFiOff.upload(fiOff.data(), fiOff.size(), s);
+  h->dFiList.upload(fiList.data(), fiList.size(), s);
+  h->dFpOff.upload(fpOff.data(), fpOff.size(), s);
+  h->dFpList.upload(fpList.data(), fpList.size(), s);
+  HIP_CHECK(hipStreamSynchronize(s));
+  h->tableRange = inRange;
+  h->tableValid = true;
+}
+
+// ---- solver context (one solve) --------------------------------------------------------------------------
+struct Ctx {
+  cvd_handle* h;
+  Layout L;
+  int KD, KS;
+  Table T;
+  Items it;
+  int nItems;
+  size_t n;  // F * B
+  int boundDepth0 = 0;
+};
+
+static void uploadState(cvd_handle* h, const Layout& L, DevBuf<double>& dst) {
+  std::vector<double> x(static_cast<size_t>(L.F) * L.B);
+  const int nD = L.nD, nS = L.nS;
+  for (int f = 0; f < L.F; ++f) {
+    double* xf = &x[static_cast<size_t>(f) * L.B];
+    for (int i = 0; i < 7; ++i) xf[i] = h->poseParams[f][i];
+    for (int i = 0; i < nD; ++i) xf[7 + i] = h->dparams[static_cast<size_t>(f) * nD + i];
+    for (int i = 0; i < nS; ++i) xf[7 + nD + i] = h->sparams[static_cast<size_t>(f) * nS + i];
+  }
+  dst.upload(x.data(), x.size(), h->stream);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+static void downloadState(cvd_handle* h, const Layout& L, const DevBuf<double>& src) {
+  std::vector<double> x(static_cast<size_t>(L.F) * L.B);
+  src.download(x.data(), x.size(), h->stream);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  const int nD = L.nD, nS = L.nS;
+  for (int f = 0; f < L.F; ++f) {
+    const double* xf = &x[static_cast<size_t>(f) * L.B];
+    for (int i = 0; i < 7; ++i) h->poseParams[f][i] = xf[i];
+    for (int i = 0; i < nD; ++i) h->dparams[static_cast<size_t>(f) * nD + i] = xf[7 + i];
+    for (int i = 0; i < nS; ++i) h->sparams[static_cast<size_t>(f) * nS + i] = xf[7 + nD + i];
+  }
+}
+
+static void buildMask(cvd_handle* h, const Layout& L, const cvd_opt_params& p, ProblemKind kind,
+                      const std::vector<int>& range) {
+  std::vector<double> m(static_cast<size_t>(L.F) * L.B, 0.0);
+  for (int f : range) {
+    double* mf = &m[static_cast<size_t>(f) * L.B];
+    const bool poseFree = (kind == PK_POSE_STEP) && !p.fix_poses;
+    for (int i = 0; i < 6; ++i) mf[i] = poseFree ? 1.0 : 0.0;
+    mf[6] = (kind == PK_POSE_STEP && p.intr_opt != CVD_INTR_FIXED) ? 1.0 : 0.0;
+    const bool depthFree = (kind == PK_NORMALIZE) || !p.fix_depth_xforms;
+    for (int i = 0; i < L.nD; ++i) mf[7 + i] = depthFree ? 1.0 : 0.0;
+    const bool spatialFree = (kind == PK_POSE_STEP) && !p.fix_spatial_xforms;
+    for (int i = 0; i < L.nS; ++i) mf[7 + L.nD + i] = spatialFree ? 1.0 : 0.0;
+  }
+  h->dMask.upload(m.data(), m.size(), h->stream);
+}
+
+static void ensureBuffers(Ctx& c) {
+  cvd_handle* h = c.h;
+  const size_t n = c.n;
+  const size_t B = c.L.B;
+  h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
+  h->dDx.ensure(n); h->dR.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
+  h->dHd.ensure(n);
+  h->dH.ensure(n * B); h->dMinv.ensure(n * B); h->dWork.ensure(n * B);
+  h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(c.nItems) * 2 * B));
+  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
+  h->dCostItem.ensure(std::max(1, c.nItems));
+  h->dCostFrame.ensure(c.L.F);
+  h->dScal.ensure(S_COUNT);
+  h->dFc.ensure(c.L.F);
+  h->dFail.ensure(1);
+  if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
+}
+
+static void launchFrameConsts(Ctx& c, const double* x) {
+  hipLaunchKernelGGL(k_frame_consts, dim3((c.L.F + 63) / 64), dim3(64), 0, c.h->stream, c.L, x, c.h->dFc.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void readScalars(Ctx& c) {
+  HIP_CHECK(hipMemcpyAsync(c.h->hScal, c.h->dScal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
+  HIP_CHECK(hipStreamSynchronize(c.h->stream));
+}
+
+// cost only at x
+static double evalCost(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  launchFrameConsts(c, x);
+  const int slot = h->tBegin(KC_COST);
+  if (c.L.includeStatic && c.nItems > 0) {
+    const size_t lds = (2 * c.L.B) * 8 + 2 * sizeof(FrameConst) + 8 * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_cost_items<KD, KS>, lds);
+      hipLaunchKernelGGL((k_cost_items<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                         h->dCostItem.p);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
+  CVD_DISPATCH_KD(c.KD, {
+    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dInRange.p,
+                       h->dCostFrame.p);
+  });
+  HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
+                     h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
+  HIP_CHECK(hipGetLastError());
+  h->tEnd(slot);
+  readScalars(c);
+  return h->hScal[S_COST];
+}
+
+// cost + gradient + diagonal blocks at x
+static double evalFull(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  launchFrameConsts(c, x);
+  const size_t B = c.L.B;
+  const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
+  const int slot = h->tBegin(KC_ASSEMBLE);
+  CVD_DISPATCH(c.KD, c.KS, {
+    allowLds(k_assemble<KD, KS>, lds);
+    hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+                       h->dMedian.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+  });
+  HIP_CHECK(hipGetLastError());
+  h->tEnd(slot);
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
+  hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
+  HIP_CHECK(hipGetLastError());
+  readScalars(c);
+  return h->hScal[S_COST];
+}
+
+static void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta,
+                         const double* lam, double* q) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const size_t B = c.L.B;
+  if (c.L.includeStatic && c.nItems > 0) {
+    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst);
+    const int slot = h->tBegin(KC_MATVEC_PAIRS);
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_matvec_pairs<KD, KS>, lds);
+      hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    h->tEnd(slot);
+  }
+  {
+    const size_t lds = 3 * B * 8 + 8 * 8;
+    const int slot = h->tBegin(KC_MATVEC_FINISH);
+    CVD_DISPATCH_KD(c.KD, {
+      hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
+                         h->dMedian.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
+                         h->dScal.p, useBeta, q, h->dFdot.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    h->tEnd(slot);
+  }
+}
+
+// PCG on (H + diag(lam)) dx = -g with the block-Jacobi preconditioner; returns iterations used.
+static int runPcg(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const int F = c.L.F;
+  const size_t B = c.L.B;
+  double* fd = h->dFdot.p;
+  const size_t ldsU = (B + 8) * 8;
+  // init: dx = 0, r = -g, z = Minv r, rz0
+  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p, fd,
+                     h->dScal.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
+  hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s, F, 1, fd + F, fd + 2 * F, h->dScal.p);
+  HIP_CHECK(hipGetLastError());
+  readScalars(c);
+  const double rz0 = h->hScal[S_RZ0];
+  if (!(rz0 > 0.0)) return 0;
+  const double target = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance * rz0;
+  double* pOld = h->dP0.p;
+  double* pNew = h->dP1.p;
+  int k = 0;
+  const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
+  const int every = std::max(1, c.h->opt.pcg_check_every);
+  while (k < maxIt) {
+    launchMatvec(c, x, h->dZ.p, pOld, pNew, k > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
+    const int slot = h->tBegin(KC_CG_UPDATE);
+    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, fd,
+                       h->dScal.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s, F, 0, fd + F, fd + 2 * F, h->dScal.p);
+    HIP_CHECK(hipGetLastError());
+    h->tEnd(slot);
+    std::swap(pOld, pNew);
+    ++k;
+    if (k % every == 0 || k == maxIt) {
+      readScalars(c);
+      const double rz = h->hScal[S_RZ];
+      if (!(rz == rz)) throw std::runtime_error("PCG produced NaN");
+      if (rz <= target) break;
+    }
+  }
+  return k;
+}
+
+static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
+  const double t0 = nowSeconds();
+  if (h->F <= 0) throw std::runtime_error("no video set");
+  if (!h->poseParamsValid) posesToParams(h);
+  const std::vector<int> range = rangeOf(p, h->F);
+  Ctx c;
+  c.h = h;
+  c.L = makeLayout(h, p, depthDeformReg, kind);
+  tapCounts(c.L, c.KD, c.KS);
+  compileTable(h, range);
+  if (h->medianDirty) {
+    h->dMedian.upload(h->median.data(), h->median.size(), h->stream);
+    h->medianDirty = false;
+  }
+  c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
+  c.nItems = static_cast<int>(h->itemPair.size());
+  c.it = Items{h->dItemPair.p, h->dItemBegin.p, h->dItemEnd.p, c.nItems};
+  c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
+  ensureBuffers(c);
+  buildMask(h, c.L, p, kind, range);
+  uploadState(h, c.L, h->dX);
+  hipStream_t s = h->stream;
+  HIP_CHECK(hipMemsetAsync(h->dDx.p, 0, c.n * sizeof(double), s));
+  HIP_CHECK(hipMemsetAsync(h->dR.p, 0, c.n * sizeof(double), s));
+  HIP_CHECK(hipMemsetAsync(h->dFail.p, 0, sizeof(int), s));
+
+  cvd_solve_summary sum{};
+  long long regBlocks = 0;
+  {
+    const long long nr = static_cast<long long>(range.size());
+    if (c.L.scaleRegSqrt > 0.0) regBlocks += nr * c.L.sregX * c.L.sregY;
+    if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
+    if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
+    if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+  }
+  sum.num_residual_blocks = static_cast<int>((c.L.includeStatic ? h->numValid : 0) + regBlocks);
+
+  double tEval = 0.0, tLin = 0.0;
+  double te = nowSeconds();
+  double xCost = evalFull(c, h->dX.p);
+  tEval += nowSeconds() - te;
+  sum.initial_cost = xCost;
+
+  auto stats = [&]() {
+    hipLaunchKernelGGL(k_step_stats, dim3(1), dim3(256), 0, s, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
+                       h->dX.p, h->dHd.p, h->dScal.p);
+    HIP_CHECK(hipGetLastError());
+    readScalars(c);
+  };
+  HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+  stats();
+  double gmax = h->hScal[S_GMAX];
+  double xNorm = std::sqrt(h->hScal[S_XX]);
+  {
+    // number of active unknowns
+    std::vector<double> hd(c.n);
+    h->dHd.download(hd.data(), c.n, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    int na = 0;
+    for (double v : hd) na += (v != 0.0);
+    sum.num_parameters = na;
+  }
+
+  double radius = Ceres::initial_radius;
+  double decrease = 2.0;
+  int invalid = 0, iteration = 0, termination = 1;
+  bool scaleDone = false;
+  cvd_iteration_record r0{};
+  r0.cost = xCost;
+  r0.gradient_max_norm = gmax;
+  r0.trust_region_radius = radius;
+  r0.step_is_successful = 1;
+  h->records.push_back(r0);
+  if (h->opt.verbose)
+    printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n"
+           "%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", 0, xCost, 0.0, gmax, 0.0, 0.0, radius, 0);
+
+  if (sum.num_parameters == 0 || gmax <= Ceres::gradient_tolerance) {
+    termination = 0;
+  } else {
+    while (true) {
+      if (iteration >= p.max_iterations) { termination = 1; break; }
+      if (radius < Ceres::min_radius) { termination = 0; break; }
+      ++iteration;
+      cvd_iteration_record rec{};
+      rec.iteration = iteration;
+
+      double tl = nowSeconds();
+      hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dScale.p,
+                         scaleDone ? 0 : 1, radius, h->dLam.p);
+      scaleDone = true;
+      {
+        const size_t B = c.L.B;
+        const size_t lds = (B * (B + 1) / 2) * 8;
+        allowLds(k_block_inverse, lds);
+        const int slot = h->tBegin(KC_INVERSE);
+        hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(256), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
+                           h->dWork.p, h->dFail.p);
+        HIP_CHECK(hipGetLastError());
+        h->tEnd(slot);
+      }
+      const int cgIters = runPcg(c, h->dX.p);
+      stats();
+      tLin += nowSeconds() - tl;
+      rec.linear_iterations = cgIters;
+      sum.total_linear_iterations += cgIters;
+      const double dg = h->hScal[S_DG], dr = h->hScal[S_DR], dld = h->hScal[S_DLD], dd = h->hScal[S_DD];
+      const double modelCostChange = -0.5 * dg + 0.5 * dr + 0.5 * dld;
+      bool ok = std::isfinite(modelCostChange) && modelCostChange > 0.0 && std::isfinite(dd);
+      if (!ok) {
+        if (++invalid >= Ceres::max_consecutive_invalid) { termination = 2; break; }
+        radius /= decrease;
+        decrease *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        continue;
+      }
+      invalid = 0;
+      hipLaunchKernelGGL(k_apply_step, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, c.boundDepth0, h->dX.p,
+                         h->dDx.p, h->dXc.p);
+      HIP_CHECK(hipGetLastError());
+      te = nowSeconds();
+      double candCost = evalCost(c, h->dXc.p);
+      tEval += nowSeconds() - te;
+      if (!std::isfinite(candCost)) candCost = std::numeric_limits<double>::max();
+      const double stepNorm = std::sqrt(dd);
+      rec.step_norm = stepNorm;
+      rec.cost_change = xCost - candCost;
+      rec.relative_decrease = (xCost - candCost) / modelCostChange;
+      bool stop = false;
+      if (stepNorm <= Ceres::parameter_tolerance * (xNorm + Ceres::parameter_tolerance)) stop = true;
+      if (!stop && std::abs(xCost - candCost) <= Ceres::function_tolerance * xCost) stop = true;
+      if (stop) {
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+        termination = 0;
+        break;
+      }
+      if (rec.relative_decrease > Ceres::min_relative_decrease) {
+        std::swap(h->dX.p, h->dXc.p);
+        std::swap(h->dX.n, h->dXc.n);
+        xCost = candCost;
+        te = nowSeconds();
+        const double chk = evalFull(c, h->dX.p);
+        (void)chk;
+        tEval += nowSeconds() - te;
+        HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+        stats();
+        gmax = h->hScal[S_GMAX];
+        xNorm = std::sqrt(h->hScal[S_XX]);
+        ++sum.num_successful_steps;
+        rec.step_is_successful = 1;
+        const double q = rec.relative_decrease;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * q - 1.0, 3));
+        radius = std::min(Ceres::max_radius, radius);
+        decrease = 2.0;
+        rec.cost = xCost;
+        rec.gradient_max_norm = gmax;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+        if (gmax <= Ceres::gradient_tolerance) { termination = 0; break; }
+      } else {
+        radius /= decrease;
+        decrease *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+      }
+    }
+  }
+  downloadState(h, c.L, h->dX);
+  h->tCollect();
+  sum.num_iterations = iteration;
+  sum.termination = termination;
+  sum.final_cost = xCost;
+  sum.total_seconds = nowSeconds() - t0;
+  sum.evaluate_seconds = tEval;
+  sum.linear_solve_seconds = tLin;
+  h->summary = sum;
+}
+
+// poseOptimizationStep, reference lib/PoseOptimizer.cpp:890-990
+static void poseOptimizationStep(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg) {
+  solve(h, p, depthDeformReg, PK_POSE_STEP);
+  paramsToPoses(h, p);
+}
+
+// poseOptimization, reference lib/PoseOptimizer.cpp:788-888
+static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
+  posesToParams(h);
+  h->records.clear();
+  int ctfRows = p.ctf_long, ctfCols = p.ctf_short;
+  int dsoRows = p.dso_long, dsoCols = p.dso_short;
+  if (h->aspect >= 1.f) {
+    std::swap(ctfCols, ctfRows);
+    std::swap(dsoCols, dsoRows);
+  }
+  int initGrid[3] = {1, 1, 1};
+  if (h->ddesc.depth_type == CVD_DEPTH_GRID)
+    for (int i = 0; i < 3; ++i) initGrid[i] = h->ddesc.grid_size[i];
+  if (p.deferred_spatial_opt) {
+    cvd_xform_desc sd{};
+    sd.type = CVD_XFORM_SPATIAL;
+    sd.spatial_type = CVD_SPATIAL_IDENTITY;
+    resetXforms(h, sd, true);
+  }
+  cvd_solve_summary total{};
+  auto accumulate = [&](const cvd_solve_summary& s, bool first) {
+    if (first) total.initial_cost = s.initial_cost;
+    total.num_iterations += s.num_iterations;
+    total.num_successful_steps += s.num_successful_steps;
+    total.total_linear_iterations += s.total_linear_iterations;
+    total.total_seconds += s.total_seconds;
+    total.evaluate_seconds += s.evaluate_seconds;
+    total.linear_solve_seconds += s.linear_solve_seconds;
+    total.final_cost = s.final_cost;
+    total.termination = s.termination;
+    total.num_residual_blocks = s.num_residual_blocks;
+    total.num_parameters = s.num_parameters;
+  };
+  for (int step = 0; step < p.num_steps; ++step) {
+    const double stepIter = (p.num_steps > 1 ? step / double(p.num_steps - 1) : 0.0);
+    double depthDeformReg = p.depth_deform_reg_final;
+    if (p.graduate_depth_deform_reg) {
+      const double a = std::log(p.depth_deform_reg_initial), b = std::log(p.depth_deform_reg_final);
+      depthDeformReg = std::exp(a + (b - a) * stepIter);
+    }
+    poseOptimizationStep(h, p, depthDeformReg);
+    accumulate(h->summary, step == 0);
+    if (p.coarse_to_fine && step < p.num_steps - 1) {
+      const double ctfIter = (step + 1) / double(p.num_steps - 1);
+      cvd_xform_desc nd = h->ddesc;
+      if (nd.depth_type == CVD_DEPTH_GLOBAL) nd.depth_type = CVD_DEPTH_GRID;
+      nd.grid_size[0] = static_cast<int>(initGrid[0] + (ctfCols - initGrid[0]) * ctfIter + 0.5);
+      nd.grid_size[1] = static_cast<int>(initGrid[1] + (ctfRows - initGrid[1]) * ctfIter + 0.5);
+      nd.grid_size[2] = initGrid[2];
+      gridXformSplit(h, nd);
+    }
+  }
+  if (p.deferred_spatial_opt) {
+    cvd_xform_desc sd{};
+    sd.type = CVD_XFORM_SPATIAL;
+    sd.spatial_type = CVD_SPATIAL_BICUBIC_GRID;
+    sd.grid_size[1] = dsoRows;
+    sd.grid_size[0] = dsoCols;
+    resetXforms(h, sd, true);
+    poseOptimizationStep(h, p, p.depth_deform_reg_final);
+    accumulate(h->summary, false);
+  }
+  h->summary = total;
+}
+
+// normalizeDepth, reference lib/PoseOptimizer.cpp:992-1147 (default: from the first frame)
+static void normalizeDepth(cvd_handle* h, const cvd_opt_params& p) {
+  posesToParams(h);
+  h->records.clear();
+  solve(h, p, p.depth_deform_reg_initial, PK_NORMALIZE);
+  const std::vector<int> range = rangeOf(p, h->F);
+  if (p.normalize_depth_from_first_frame && !range.empty()) {
+    const int nD = h->nD();
+    const int first = range.front();
+    for (int f : range)
+      if (f != first)
+        std::copy(h->dparams.begin() + static_cast<size_t>(first) * nD,
+                  h->dparams.begin() + static_cast<size_t>(first + 1) * nD,
+                  h->dparams.begin() + static_cast<size_t>(f) * nD);
+  }
+}
+
+static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, const double* pose7,
+                     double* cost, int32_t* nres, double* gradient, double* hdiag, double* hfull) {
+  if (pose7) {
+    h->poseParams.resize(h->F);
+    for (int f = 0; f < h->F; ++f)
+      for (int i = 0; i < 7; ++i) h->poseParams[f][i] = pose7[f * 7 + i];
+    h->poseParamsValid = true;
+  } else {
+    posesToParams(h);
+  }
+  const std::vector<int> range = rangeOf(p, h->F);
+  Ctx c;
+  c.h = h;
+  c.L = makeLayout(h, p, depthDeformReg, PK_POSE_STEP);
+  tapCounts(c.L, c.KD, c.KS);
+  compileTable(h, range);
+  if (h->medianDirty) {
+    h->dMedian.upload(h->median.data(), h->median.size(), h->stream);
+    h->medianDirty = false;
+  }
+  c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
+  c.nItems = static_cast<int>(h->itemPair.size());
+  c.it = Items{h->dItemPair.p, h->dItemBegin.p, h->dItemEnd.p, c.nItems};
+  c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  ensureBuffers(c);
+  buildMask(h, c.L, p, PK_POSE_STEP, range);
+  uploadState(h, c.L, h->dX);
+  hipStream_t s = h->stream;
+  double cst;
+  if (!gradient && !hdiag && !hfull) {
+    cst = evalCost(c, h->dX.p);
+  } else {
+    cst = evalFull(c, h->dX.p);
+  }
+  if (cost) *cost = cst;
+  if (nres) {
+    long long regBlocks = 0;
+    const long long nr = static_cast<long long>(range.size());
+    if (c.L.scaleRegSqrt > 0.0) regBlocks += nr * c.L.sregX * c.L.sregY;
+    if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
+    if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
+    if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+    *nres = static_cast<int32_t>(h->numValid + regBlocks);
+  }
+  if (gradient) h->dG.download(gradient, c.n, s);
+  if (hdiag) h->dH.download(hdiag, c.n * c.L.B, s);
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (hfull) {
+    // column j of J^T J = matvec with the unit vector e_j (lam = 0)
+    std::vector<double> e(c.n, 0.0), col(c.n);
+    HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    for (size_t j = 0; j < c.n; ++j) {
+      e[j] = 1.0;
+      h->dZ.upload(e.data(), c.n, s);
+      launchMatvec(c, h->dX.p, h->dZ.p, h->dP0.p, h->dP1.p, 0, h->dLam.p, h->dQ.p);
+      h->dQ.download(col.data(), c.n, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (size_t i = 0; i < c.n; ++i) hfull[i * c.n + j] = col[i];
+      e[j] = 0.0;
+    }
+  }
+}
+
+}  // namespace cvd
+
+// =======================================================================================================
+// C ABI
+// =======================================================================================================
+#define CVD_TRY(h, ...)                        \
+  try {                                        \
+    if (!(h)) return -1;                       \
+    HIP_CHECK(hipSetDevice((h)->device));      \
+    __VA_ARGS__;                               \
+    return 0;                                  \
+  } catch (const std::exception& e) {          \
+    (h)->err = e.what();                       \
+    return -1;                                 \
+  }
+
+extern "C" {
+
+static std::string g_createError;
+
+cvd_handle* cvd_create(int32_t device) {
+  try {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      throw std::runtime_error("no HIP device available: the optimizer has no CPU path");
+    if (device < 0 || device >= count) throw std::runtime_error("invalid device ordinal");
+    HIP_CHECK(hipSetDevice(device));
+    auto* h = new cvd_handle_t();
+    h->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    cvd_solver_options_default(&h->opt);
+    return h;
+  } catch (const std::exception& e) {
+    g_createError = e.what();
+    return nullptr;
+  }
+}
+void cvd_destroy(cvd_handle* h) { delete h; }
+const char* cvd_last_error(cvd_handle* h) { return h ? h->err.c_str() : g_createError.c_str(); }
+
+void cvd_abi_sizes(int32_t* out6) {
+  out6[0] = sizeof(cvd_xform_desc);
+  out6[1] = sizeof(cvd_opt_params);
+  out6[2] = sizeof(cvd_frame_pose);
+  out6[3] = sizeof(cvd_iteration_record);
+  out6[4] = sizeof(cvd_solve_summary);
+  out6[5] = sizeof(cvd_solver_options);
+}
+
+void cvd_opt_params_default(cvd_opt_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->max_iterations = 1000;
+  p->num_threads = 12;
+  p->num_steps = 4;
+  p->robustness = 0.5;
+  p->static_loss_type = CVD_STATIC_REPRO_DISPARITY;
+  p->static_spatial_weight = 1.0;
+  p->static_depth_weight = 1.0;
+  p->smooth_loss_type = CVD_SMOOTH_REPRO_DISPARITY_LAPLACIAN;
+  p->scale_reg = 1.0;
+  p->scale_reg_grid_size = 10;
+  p->depth_deform_reg_initial = 1.0;
+  p->depth_deform_reg_final = 0.1;
+  p->spatial_deform_reg = 1.0;
+  p->focal_reg = 1.0;
+  p->coarse_to_fine = 1;
+  p->ctf_long = 17;
+  p->ctf_short = 10;
+  p->dso_long = 4;
+  p->dso_short = 3;
+  p->focal_long = 0.3461538376301239;
+  p->intr_opt = CVD_INTR_PER_FRAME;
+  p->normalize_depth_from_first_frame = 1;
+}
+
+void cvd_solver_options_default(cvd_solver_options* o) {
+  o->pcg_relative_tolerance = 1e-2;
+  o->pcg_max_iterations = 300;
+  o->pcg_check_every = 4;
+  o->verbose = 0;
+  o->reserved = 0;
+}
+int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
+
+int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t height, float aspect, float invAspect) {
+  CVD_TRY(h, {
+    if (numFrames <= 0 || width <= 0 || height <= 0) throw std::runtime_error("invalid video dimensions");
+    h->F = numFrames; h->W = width; h->H = height; h->aspect = aspect; h->invAspect = invAspect;
+    h->dDepth.ensure(static_cast<size_t>(numFrames) * width * height);
+    HIP_CHECK(hipMemsetAsync(h->dDepth.p, 0, static_cast<size_t>(numFrames) * width * height * sizeof(float), h->stream));
+    h->median.assign(numFrames, 0.f);
+    h->medianDirty = true;
+    h->poses.assign(numFrames, cvd_frame_pose{{0, 0, 0}, {0, 0, 0, 1}, 0.f, 0.f});
+    h->poseParamsValid = false;
+    cvd_xform_desc dd{};
+    dd.type = CVD_XFORM_DEPTH;
+    dd.depth_type = CVD_DEPTH_IDENTITY;
+    cvd_xform_desc sd{};
+    sd.type = CVD_XFORM_SPATIAL;
+    sd.spatial_type = CVD_SPATIAL_IDENTITY;
+    resetXforms(h, dd, false);
+    resetXforms(h, sd, true);
+    h->tableValid = false;
+    h->P = 0;
+    h->C = 0;
+  });
+}
+
+int32_t cvd_set_depth(cvd_handle* h, int32_t frame, const float* depth) {
+  CVD_TRY(h, {
+    if (frame < 0 || frame >= h->F) throw std::runtime_error("frame out of range");
+    const size_t n = static_cast<size_t>(h->W) * h->H;
+    HIP_CHECK(hipMemcpyAsync(h->dDepth.p + frame * n, depth, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // median of the source depth, reference lib/PoseOptimizer.cpp:1363-1375 (input preprocessing, cached)
+    std::vector<float> tmp(depth, depth + n);
+    std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+    h->median[frame] = tmp[n / 2];
+    h->medianDirty = true;
+    h->tableValid = false;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames, const int64_t* offsets,
+                                 const float* loc4, const uint8_t* isStatic) {
+  CVD_TRY(h, {
+    // the reference iterates a std::map<std::pair<int,int>> (lib/FlowConstraints.h:149): sort by key
+    std::vector<int> order(numPairs);
+    for (int i = 0; i < numPairs; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
+      return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
+    });
+    const long long C = offsets[numPairs];
+    h->P = numPairs;
+    h->C = C;
+    h->pairA.resize(numPairs);
+    h->pairB.resize(numPairs);
+    h->pairOff.assign(numPairs + 1, 0);
+    std::vector<float> loc(static_cast<size_t>(C) * 4);
+    std::vector<unsigned char> st(C, 1);
+    std::vector<int> cpair(C);
+    long long o = 0;
+    for (int k = 0; k < numPairs; ++k) {
+      const int src = order[k];
+      const int a = pairFrames[2 * src], b = pairFrames[2 * src + 1];
+      if (a < 0 || a >= h->F || b < 0 || b >= h->F) throw std::runtime_error("pair frame out of range");
+      h->pairA[k] = a;
+      h->pairB[k] = b;
+      h->pairOff[k] = o;
+      const long long n = offsets[src + 1] - offsets[src];
+      std::memcpy(&loc[o * 4], loc4 + offsets[src] * 4, sizeof(float) * 4 * n);
+      if (isStatic) std::memcpy(&st[o], isStatic + offsets[src], n);
+      for (long long i = 0; i < n; ++i) cpair[o + i] = k;
+      o += n;
+    }
+    h->pairOff[numPairs] = o;
+    hipStream_t s = h->stream;
+    h->dPairA.upload(h->pairA.data(), numPairs, s);
+    h->dPairB.upload(h->pairB.data(), numPairs, s);
+    h->dPairOff.upload(h->pairOff.data(), numPairs + 1, s);
+    h->dLoc.upload(reinterpret_cast<const float4*>(loc.data()), C, s);
+    h->dStatic.upload(st.data(), C, s);
+    h->dCPair.upload(cpair.data(), C, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->tableValid = false;
+  });
+}
+
+int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t, const int32_t*, const int64_t*, const float*, const uint8_t*) {
+  CVD_TRY(h, h->haveTriplets = true);  // stored for the (not yet implemented) smoothness loss
+}
+
+int32_t cvd_set_poses(cvd_handle* h, const cvd_frame_pose* poses) {
+  CVD_TRY(h, { h->poses.assign(poses, poses + h->F); h->poseParamsValid = false; });
+}
+int32_t cvd_get_poses(cvd_handle* h, cvd_frame_pose* poses) {
+  CVD_TRY(h, std::memcpy(poses, h->poses.data(), sizeof(cvd_frame_pose) * h->F));
+}
+int32_t cvd_reset_poses(cvd_handle* h, double focalLong) {
+  CVD_TRY(h, {
+    for (int f = 0; f < h->F; ++f) {
+      cvd_frame_pose& p = h->poses[f];
+      p.position[0] = p.position[1] = p.position[2] = 0.f;
+      p.orientation[0] = p.orientation[1] = p.orientation[2] = 0.f;
+      p.orientation[3] = 1.f;
+      const float focal = static_cast<float>(focalLong);
+      if (h->aspect >= 1.f) {
+        p.hfov = std::atan(focal) * 2.f;
+        p.vfov = std::atan(focal / h->aspect) * 2.f;
+      } else {
+        p.hfov = std::atan(focal * h->aspect) * 2.f;
+        p.vfov = std::atan(focal) * 2.f;
+      }
+    }
+    h->poseParamsValid = false;
+  });
+}
+int32_t cvd_reset_depth_xforms(cvd_handle* h, const cvd_xform_desc* d) { CVD_TRY(h, resetXforms(h, *d, false)); }
+int32_t cvd_reset_spatial_xforms(cvd_handle* h, const cvd_xform_desc* d) { CVD_TRY(h, resetXforms(h, *d, true)); }
+int32_t cvd_grid_xform_split(cvd_handle* h, const cvd_xform_desc* d) { CVD_TRY(h, gridXformSplit(h, *d)); }
+int32_t cvd_get_xform_desc(cvd_handle* h, int32_t spatial, cvd_xform_desc* d) {
+  CVD_TRY(h, *d = spatial ? h->sdesc : h->ddesc);
+}
+int32_t cvd_num_xform_params(cvd_handle* h, int32_t spatial) {
+  if (!h) return 0;
+  try { return spatial ? h->nS() : h->nD(); } catch (...) { return 0; }
+}
+int32_t cvd_get_xform_params(cvd_handle* h, int32_t spatial, double* out) {
+  CVD_TRY(h, {
+    const auto& v = spatial ? h->sparams : h->dparams;
+    if (!v.empty()) std::memcpy(out, v.data(), sizeof(double) * v.size());
+  });
+}
+int32_t cvd_set_xform_params(cvd_handle* h, int32_t spatial, const double* in) {
+  CVD_TRY(h, {
+    auto& v = spatial ? h->sparams : h->dparams;
+    if (!v.empty()) std::memcpy(v.data(), in, sizeof(double) * v.size());
+  });
+}
+int32_t cvd_get_pose_params(cvd_handle* h, double* pose7) {
+  CVD_TRY(h, {
+    if (!h->poseParamsValid) posesToParams(h);
+    for (int f = 0; f < h->F; ++f)
+      for (int i = 0; i < 7; ++i) pose7[f * 7 + i] = h->poseParams[f][i];
+  });
+}
+int32_t cvd_block_size(cvd_handle* h) {
+  if (!h) return 0;
+  try { return h->Bsz(); } catch (...) { return 0; }
+}
+
+int32_t cvd_normalize_depth(cvd_handle* h, const cvd_opt_params* p) { CVD_TRY(h, normalizeDepth(h, *p)); }
+int32_t cvd_pose_optimization(cvd_handle* h, const cvd_opt_params* p) { CVD_TRY(h, poseOptimization(h, *p)); }
+int32_t cvd_pose_optimization_step(cvd_handle* h, const cvd_opt_params* p, double depthDeformReg, int32_t convert) {
+  CVD_TRY(h, {
+    if (convert || !h->poseParamsValid) posesToParams(h);
+    h->records.clear();
+    poseOptimizationStep(h, *p, depthDeformReg);
+  });
+}
+int32_t cvd_evaluate(cvd_handle* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, double* cost,
+                     int32_t* nres, double* gradient, double* hdiag, double* hfull) {
+  CVD_TRY(h, evaluate(h, *p, depthDeformReg, pose7, cost, nres, gradient, hdiag, hfull));
+}
+int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s) { CVD_TRY(h, *s = h->summary); }
+int32_t cvd_num_records(cvd_handle* h) { return h ? static_cast<int32_t>(h->records.size()) : 0; }
+int32_t cvd_get_records(cvd_handle* h, cvd_iteration_record* out) {
+  CVD_TRY(h, std::memcpy(out, h->records.data(), sizeof(cvd_iteration_record) * h->records.size()));
+}
+int32_t cvd_get_kernel_times(cvd_handle* h, double* avgMs6, int64_t* launches6) {
+  CVD_TRY(h, {
+    for (int k = 0; k < KC_COUNT; ++k) {
+      avgMs6[k] = h->kcN[k] ? h->kcMs[k] / h->kcN[k] : 0.0;
+      launches6[k] = h->kcN[k];
+    }
+  });
+}
+int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
+  CVD_TRY(h, {
+    h->timing = enabled != 0;
+    for (int k = 0; k < KC_COUNT; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }
+  });
+}
+int64_t cvd_num_active_constraints(cvd_handle* h) { return h ? h->numValid : 0; }
+
+}  // extern "C"

@@ -1,0 +1,733 @@
+// cvd_kernels.h -- HIP kernels of the geometric-consistency optimizer (gfx950).
+//
+// Kernel map (DESIGN.md has the roofline of each):
+//   k_frame_consts     per frame   : R(w), dR/dw, t, fy of the evaluation point
+//   k_build_table      per constr. : Observation ctor of the reference (NDC + truncating depth fetch)
+//   k_cost_items       pair-major  : sum of rho(|r|^2) of the static constraints (candidate-point cost)
+//   k_cost_frames      per frame   : regulariser cost
+//   k_assemble         frame-major : gradient J^T r and the frame-diagonal blocks of J^T J (+ cost)
+//   k_lm_diag          per unknown : Jacobi scale, LM damping (Ceres LevenbergMarquardtStrategy)
+//   k_block_inverse    per frame   : (H_ff + damping)^-1 by an LDS Cholesky (block-Jacobi preconditioner)
+//   k_matvec_pairs     pair-major  : partial q = J^T (rho' J p), matrix free            <- the hot kernel
+//   k_matvec_finish    per frame   : reduce partials + regulariser Hessian + damping, p.q partial dots
+//   k_cg_update        per frame   : x += alpha p, r -= alpha q, z = M^-1 r, partial dots
+//   k_cg_scalars       1 block     : alpha/beta bookkeeping on the device (no host round trip)
+#pragma once
+
+#include "cvd_device.h"
+
+namespace cvd {
+
+// Compiled constraint table (the reference rebuilds `Observation`s for every solve,
+// lib/PoseOptimizer.cpp:1185-1193; here it is 24 B per constraint, pair-major, resident in HBM).
+struct Table {
+  const float4* ndc;    // (ndc_a.xy, ndc_b.xy), f32 exactly as the reference computes them
+  const float2* dsrc;   // (d_a, d_b) source depths; d_a <= 0 marks a skipped constraint
+  const int* pairA;     // per pair
+  const int* pairB;
+  const long long* pairOff;  // P + 1
+};
+
+struct Items {  // work items of the pair-major kernels: a contiguous chunk of one pair's constraints
+  const int* pair;
+  const long long* begin;
+  const long long* end;
+  int count;
+};
+
+// scalar slots kept on the device during PCG
+enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5, S_RZ0 = 6, S_COST = 7,
+             S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14, S_COUNT = 16 };
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameConst* __restrict__ fc) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= L.F) return;
+  FrameConst c;
+  frameConstFromParams(x + static_cast<size_t>(f) * L.B, L.intrOpt, L.vFocal, x, c);
+  fc[f] = c;
+}
+
+// Observation ctor, reference lib/PoseOptimizer.cpp:104-116 (float arithmetic, no FMA contraction).
+__global__ void k_build_table(int W, int H, float invAspect, long long C, const float4* __restrict__ loc,
+                              const unsigned char* __restrict__ isStatic, const int* __restrict__ cpair,
+                              const int* __restrict__ pairA, const int* __restrict__ pairB,
+                              const unsigned char* __restrict__ inRange, const float* __restrict__ depth,
+                              float4* __restrict__ ndc, float2* __restrict__ dsrc,
+                              unsigned long long* __restrict__ nValid) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (c < C) {
+    const float4 l = loc[c];
+    const int p = cpair[c];
+    const int fa = pairA[p], fb = pairB[p];
+    float4 n;
+    n.x = __fadd_rn(-1.f, __fmul_rn(2.f, l.x));
+    n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, l.y), invAspect));
+    n.z = __fadd_rn(-1.f, __fmul_rn(2.f, l.z));
+    n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, l.w), invAspect));
+    int ax = static_cast<int>(__fmul_rn(l.x, static_cast<float>(W)));
+    int ay = static_cast<int>(__fmul_rn(__fdiv_rn(l.y, invAspect), static_cast<float>(H)));
+    int bx = static_cast<int>(__fmul_rn(l.z, static_cast<float>(W)));
+    int by = static_cast<int>(__fmul_rn(__fdiv_rn(l.w, invAspect), static_cast<float>(H)));
+    ax = min(max(ax, 0), W - 1); ay = min(max(ay, 0), H - 1);
+    bx = min(max(bx, 0), W - 1); by = min(max(by, 0), H - 1);
+    const size_t fs = static_cast<size_t>(W) * H;
+    float da = depth[fa * fs + static_cast<size_t>(ay) * W + ax];
+    float db = depth[fb * fs + static_cast<size_t>(by) * W + bx];
+    ok = isStatic[c] && inRange[fa] && inRange[fb] && isfinite(da) && da > 0.f && isfinite(db) && db > 0.f;
+    if (!ok) { da = 0.f; db = 0.f; }
+    ndc[c] = n;
+    dsrc[c] = make_float2(da, db);
+  }
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(nValid, static_cast<unsigned long long>(__popcll(b)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// candidate-point cost: pair-major over work items
+// ---------------------------------------------------------------------------------------------------
+template <int KD, int KS>
+__global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                    const FrameConst* __restrict__ fc, double* __restrict__ costItem) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  double* xa = sm;
+  double* xb = sm + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(sm + 2 * B);
+  double* red = reinterpret_cast<double*>(fcs + 2);
+  const int item = blockIdx.x;
+  const int p = it.pair[item];
+  const int fa = T.pairA[p], fb = T.pairB[p];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    xa[i] = x[static_cast<size_t>(fa) * B + i];
+    xb[i] = x[static_cast<size_t>(fb) * B + i];
+  }
+  if (threadIdx.x < 2 * (sizeof(FrameConst) / 8)) {
+    const int which = threadIdx.x / (sizeof(FrameConst) / 8);
+    const int k = threadIdx.x % (sizeof(FrameConst) / 8);
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (long long c = it.begin[item] + threadIdx.x; c < it.end[item]; c += blockDim.x) {
+    const float2 d = T.dsrc[c];
+    if (d.x > 0.f) {
+      Sample<KD, KS> s;
+      evalSample<KD, KS, false>(L, fcs[0], fcs[1], xa, xb, T.ndc[c], d, s);
+      acc += s.rho0;
+    }
+  }
+  acc = waveSum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (blockDim.x >> 6); ++w) t += red[w];
+    costItem[item] = 0.5 * t;
+  }
+}
+
+template <int KD>
+__global__ __launch_bounds__(64) void k_cost_frames(Layout L, const double* __restrict__ x,
+                                                    const float* __restrict__ median,
+                                                    const unsigned char* __restrict__ inRange,
+                                                    double* __restrict__ costFrame) {
+  const int f = blockIdx.x;
+  double acc = 0.0;
+  if (inRange[f]) {
+    const double* xf = x + static_cast<size_t>(f) * L.B;
+    const int nr = numRegResiduals<KD>(L);
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) {
+      double r;
+      int n;
+      int cols[2 * KD + 2];
+      double jac[2 * KD + 2];
+      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      acc += r * r;
+    }
+  }
+  acc = waveSum(acc);
+  if (threadIdx.x == 0) costFrame[f] = 0.5 * acc;
+}
+
+// deterministic final sum: out[slot] = sum(a[0..na)) + sum(b[0..nb))
+__global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int na, const double* __restrict__ b,
+                                              int nb, double* __restrict__ out, int slot) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < na; i += 256) acc += a[i];
+  for (int i = threadIdx.x; i < nb; i += 256) acc += b[i];
+  acc = waveSum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[slot] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Frame-major assembly: one workgroup owns frame f, walks every pair it takes part in (as source or as
+// target), and accumulates g_f = J_f^T r and H_ff = J_f^T J_f in LDS (packed lower triangle), then adds the
+// frame's regularisers.  No global atomics, no partial buffers, output written exactly once.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int packedIdx(int i, int j) {  // i >= j
+  return i * (i + 1) / 2 + j;
+}
+
+template <int KD, int KS>
+__global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const double* __restrict__ x,
+                                                  const FrameConst* __restrict__ fc, const double* __restrict__ mask,
+                                                  const float* __restrict__ median,
+                                                  const unsigned char* __restrict__ inRange,
+                                                  const int* __restrict__ fpOff, const int* __restrict__ fpList,
+                                                  double* __restrict__ gOut, double* __restrict__ hOut,
+                                                  double* __restrict__ costFrame) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  const int npk = B * (B + 1) / 2;
+  double* Hs = sm;             // packed lower triangle
+  double* gs = Hs + npk;       // B
+  double* xf = gs + B;         // B
+  double* xo = xf + B;         // B
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(xo + B);  // [0] = own frame, [1] = other frame
+  double* red = reinterpret_cast<double*>(fcs + 2);          // 4 * 36
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
+  for (int i = tid; i < B; i += 256) {
+    gs[i] = 0.0;
+    xf[i] = x[static_cast<size_t>(f) * B + i];
+  }
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (tid < FCW) reinterpret_cast<double*>(fcs)[tid] = reinterpret_cast<const double*>(fc + f)[tid];
+  __syncthreads();
+
+  // register accumulators of the pose-like 7x7 block + gradient (all lanes hit the same addresses)
+  double PP[28];
+  double gp[7];
+  double cost = 0.0;
+#pragma unroll
+  for (int i = 0; i < 28; ++i) PP[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) gp[i] = 0.0;
+
+  if (L.includeStatic) {
+    for (int e = fpOff[f]; e < fpOff[f + 1]; ++e) {
+      const int code = fpList[e];
+      const int p = code >> 1;
+      const int side = code & 1;  // 0: f is the source (a) of pair p, 1: f is the target (b)
+      const int o = side ? T.pairA[p] : T.pairB[p];
+      __syncthreads();
+      for (int i = tid; i < B; i += 256) xo[i] = x[static_cast<size_t>(o) * B + i];
+      if (tid < FCW) reinterpret_cast<double*>(fcs + 1)[tid] = reinterpret_cast<const double*>(fc + o)[tid];
+      __syncthreads();
+      const FrameConst& fa = side ? fcs[1] : fcs[0];
+      const FrameConst& fb = side ? fcs[0] : fcs[1];
+      const double* xa = side ? xo : xf;
+      const double* xb = side ? xf : xo;
+      for (long long c = T.pairOff[p] + tid; c < T.pairOff[p + 1]; c += 256) {
+        const float2 d = T.dsrc[c];
+        if (!(d.x > 0.f)) continue;
+        Sample<KD, KS> s;
+        evalSample<KD, KS, true>(L, fa, fb, xa, xb, T.ndc[c], d, s);
+        const Side<KD, KS>& me = side ? s.b : s.a;
+        const double w = s.rho1;
+        if (!side) cost += s.rho0;  // count every constraint once
+        // pose-like block
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          gp[i] += w * (me.Jp[0][i] * s.r[0] + me.Jp[1][i] * s.r[1] + me.Jp[2][i] * s.r[2]);
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            PP[q] += w * (me.Jp[0][i] * me.Jp[0][j] + me.Jp[1][i] * me.Jp[1][j] + me.Jp[2][i] * me.Jp[2][j]);
+            ++q;
+          }
+        }
+        // tap columns
+        const int nt = sideNumTapCols(L, me);
+        for (int t = 0; t < nt; ++t) {
+          int ct;
+          double Jt[3];
+          sideTapCol(L, me, t, ct, Jt);
+          const double wj0 = w * Jt[0], wj1 = w * Jt[1], wj2 = w * Jt[2];
+          atomicAdd(&gs[ct], wj0 * s.r[0] + wj1 * s.r[1] + wj2 * s.r[2]);
+          const int rowBase = ct * (ct + 1) / 2;
+#pragma unroll
+          for (int i = 0; i < 7; ++i)
+            atomicAdd(&Hs[rowBase + i], wj0 * me.Jp[0][i] + wj1 * me.Jp[1][i] + wj2 * me.Jp[2][i]);
+          for (int t2 = 0; t2 <= t; ++t2) {
+            int c2;
+            double J2[3];
+            sideTapCol(L, me, t2, c2, J2);
+            const double val = wj0 * J2[0] + wj1 * J2[1] + wj2 * J2[2];
+            // tap columns of one sample are distinct but not sorted (border folding keeps row-major order,
+            // spatial columns follow depth columns) -> order the pair
+            const int hi = ct > c2 ? ct : c2, lo = ct > c2 ? c2 : ct;
+            atomicAdd(&Hs[packedIdx(hi, lo)], val);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // block reduction of the register accumulators
+  {
+#pragma unroll
+    for (int i = 0; i < 28; ++i) PP[i] = waveSum(PP[i]);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gp[i] = waveSum(gp[i]);
+    cost = waveSum(cost);
+    const int wv = tid >> 6;
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < 28; ++i) red[wv * 36 + i] = PP[i];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) red[wv * 36 + 28 + i] = gp[i];
+      red[wv * 36 + 35] = cost;
+    }
+  }
+  __syncthreads();
+  if (tid < 28) {
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= tid) ++i;
+    const int j = tid - i * (i + 1) / 2;
+    Hs[packedIdx(i, j)] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+  } else if (tid < 35) {
+    gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+  }
+  __syncthreads();
+  double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
+  __syncthreads();
+
+  // regularisers of this frame
+  double regCost = 0.0;
+  if (inRange[f]) {
+    const int nr = numRegResiduals<KD>(L);
+    for (int i = tid; i < nr; i += 256) {
+      double r;
+      int n;
+      int cols[2 * KD + 2];
+      double jac[2 * KD + 2];
+      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      regCost += r * r;
+      for (int a = 0; a < n; ++a) {
+        atomicAdd(&gs[cols[a]], jac[a] * r);
+        for (int b = 0; b <= a; ++b) {
+          const int hi = cols[a] > cols[b] ? cols[a] : cols[b];
+          const int lo = cols[a] > cols[b] ? cols[b] : cols[a];
+          atomicAdd(&Hs[packedIdx(hi, lo)], jac[a] * jac[b]);
+        }
+      }
+    }
+  }
+  regCost = waveSum(regCost);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = regCost;
+  __syncthreads();
+  if (tid == 0) costFrame[f] = staticCost + 0.5 * (red[0] + red[1] + red[2] + red[3]);
+
+  // write-out with the constant-parameter mask applied (constant columns drop out of J)
+  const double* mf = mask + static_cast<size_t>(f) * B;
+  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
+  double* hf = hOut + static_cast<size_t>(f) * B * B;
+  for (int idx = tid; idx < B * B; idx += 256) {
+    const int i = idx / B, j = idx - i * B;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LM diagonal (Ceres LevenbergMarquardtStrategy::ComputeStep in the unscaled variables):
+//   scale_j = 1 / (1 + sqrt(h_jj)) from the FIRST Jacobian; lam_j = clamp(scale_j^2 h_jj) / (radius scale_j^2).
+// Unknowns nothing depends on (h_jj == 0: constant or absent parameter blocks) get lam = 1, so that the
+// damped system is the identity on them and their step is exactly 0.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, double* __restrict__ scale,
+                          int computeScale, double radius, double* __restrict__ lam) {
+  const size_t n = static_cast<size_t>(L.F) * L.B;
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t f = i / L.B, c = i - f * L.B;
+  const double h = hdiagBlocks[(f * L.B + c) * L.B + c];
+  if (computeScale) scale[i] = 1.0 / (1.0 + sqrt(h));
+  const double s = scale[i];
+  if (h == 0.0) {
+    lam[i] = 1.0;
+  } else {
+    const double d = fmin(fmax(s * s * h, 1e-6), 1e32);
+    lam[i] = d / (radius * s * s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Block-Jacobi preconditioner: Minv_f = (H_ff + diag(lam_f))^-1.  One workgroup per frame, Cholesky of
+// the packed lower triangle in LDS, L^-1 by column-parallel forward substitution (global scratch,
+// L2-resident), Minv = L^-T L^-1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
+                                                       const double* __restrict__ lam, double* __restrict__ minv,
+                                                       double* __restrict__ work, int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
+  double* A = sm;  // packed lower
+  for (int idx = tid; idx < B * (B + 1) / 2; idx += 256) {
+    int i = static_cast<int>((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+    while (i * (i + 1) / 2 > idx) --i;
+    const int j = idx - i * (i + 1) / 2;
+    double v = hf[static_cast<size_t>(i) * B + j];
+    if (i == j) v += lam[static_cast<size_t>(f) * B + i];
+    A[idx] = v;
+  }
+  __syncthreads();
+  for (int j = 0; j < B; ++j) {
+    const int jj = packedIdx(j, j);
+    if (tid == 0) {
+      double d = A[jj];
+      if (!(d > 0.0)) { d = 1.0; atomicAdd(fail, 1); }
+      A[jj] = sqrt(d);
+    }
+    __syncthreads();
+    const double d = A[jj];
+    for (int i = j + 1 + tid; i < B; i += 256) A[packedIdx(i, j)] /= d;
+    __syncthreads();
+    for (int i = j + 1 + tid; i < B; i += 256) {
+      const double lij = A[packedIdx(i, j)];
+      const int rb = i * (i + 1) / 2;
+      for (int k = j + 1; k <= i; ++k) A[rb + k] -= lij * A[packedIdx(k, j)];
+    }
+    __syncthreads();
+  }
+  // Linv column c (thread per column), stored as W[row * B + c]
+  double* Wk = work + static_cast<size_t>(f) * B * B;
+  for (int c = tid; c < B; c += 256) {
+    for (int i = 0; i < c; ++i) Wk[static_cast<size_t>(i) * B + c] = 0.0;
+    Wk[static_cast<size_t>(c) * B + c] = 1.0 / A[packedIdx(c, c)];
+    for (int i = c + 1; i < B; ++i) {
+      double s = 0.0;
+      const int rb = i * (i + 1) / 2;
+      for (int k = c; k < i; ++k) s += A[rb + k] * Wk[static_cast<size_t>(k) * B + c];
+      Wk[static_cast<size_t>(i) * B + c] = -s / A[rb + i];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  double* Mf = minv + static_cast<size_t>(f) * B * B;
+  for (int idx = tid; idx < B * B; idx += 256) {
+    const int a = idx / B, b = idx - a * B;
+    if (b > a) continue;
+    double s = 0.0;
+    for (int k = a; k < B; ++k) s += Wk[static_cast<size_t>(k) * B + a] * Wk[static_cast<size_t>(k) * B + b];
+    Mf[static_cast<size_t>(a) * B + b] = s;
+    Mf[static_cast<size_t>(b) * B + a] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Matrix-free product, pair-major (THE hot kernel): for the work item's constraints
+//   t = rho' (J_a p_a + J_b p_b),  q_a += J_a^T t,  q_b += J_b^T t
+// with J re-derived analytically from 24 B per constraint.  p is formed on the fly as z + beta p_old
+// (beta lives on the device), masked for constant parameters.  Partials go to a per-item slot; the
+// per-frame reduction (k_matvec_finish) is a gather, so there are no global atomics.
+// ---------------------------------------------------------------------------------------------------
+template <int KD, int KS>
+__global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                      const FrameConst* __restrict__ fc,
+                                                      const double* __restrict__ mask, const double* __restrict__ z,
+                                                      const double* __restrict__ pOld,
+                                                      const double* __restrict__ scal, int useBeta,
+                                                      double* __restrict__ qPart) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  double* xa = sm;
+  double* xb = xa + B;
+  double* pa = xb + B;
+  double* pb = pa + B;
+  double* qa = pb + B;
+  double* qb = qa + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
+  const int item = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int p = it.pair[item];
+  const int fa = T.pairA[p], fb = T.pairB[p];
+  const double beta = useBeta ? scal[S_BETA] : 0.0;
+  for (int i = tid; i < B; i += 256) {
+    const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
+    xa[i] = x[ia];
+    xb[i] = x[ib];
+    pa[i] = (z[ia] + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    qa[i] = 0.0;
+    qb[i] = 0.0;
+  }
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (tid < 2 * FCW) {
+    const int which = tid / FCW, k = tid % FCW;
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  __syncthreads();
+  double qpa[7], qpb[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { qpa[i] = 0.0; qpb[i] = 0.0; }
+  for (long long c = it.begin[item] + tid; c < it.end[item]; c += 256) {
+    const float2 d = T.dsrc[c];
+    if (!(d.x > 0.f)) continue;
+    Sample<KD, KS> s;
+    evalSample<KD, KS, true>(L, fcs[0], fcs[1], xa, xb, T.ndc[c], d, s);
+    double t[3] = {0.0, 0.0, 0.0};
+    sideJp(L, s.a, pa, t);
+    sideJp(L, s.b, pb, t);
+    t[0] *= s.rho1; t[1] *= s.rho1; t[2] *= s.rho1;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      qpa[i] += s.a.Jp[0][i] * t[0] + s.a.Jp[1][i] * t[1] + s.a.Jp[2][i] * t[2];
+      qpb[i] += s.b.Jp[0][i] * t[0] + s.b.Jp[1][i] * t[1] + s.b.Jp[2][i] * t[2];
+    }
+    {
+      const int nt = sideNumTapCols(L, s.a);
+      for (int k = 0; k < nt; ++k) {
+        int col;
+        double J[3];
+        sideTapCol(L, s.a, k, col, J);
+        atomicAdd(&qa[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
+      }
+    }
+    {
+      const int nt = sideNumTapCols(L, s.b);
+      for (int k = 0; k < nt; ++k) {
+        int col;
+        double J[3];
+        sideTapCol(L, s.b, k, col, J);
+        atomicAdd(&qb[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    qpa[i] = waveSum(qpa[i]);
+    qpb[i] = waveSum(qpb[i]);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      atomicAdd(&qa[i], qpa[i]);
+      atomicAdd(&qb[i], qpb[i]);
+    }
+  }
+  __syncthreads();
+  double* out = qPart + static_cast<size_t>(item) * 2 * B;
+  for (int i = tid; i < B; i += 256) {
+    out[i] = qa[i];
+    out[B + i] = qb[i];
+  }
+}
+
+// Per frame: p_f = z + beta p_old (stored for the next iteration), q_f = mask * (sum of partials +
+// regulariser J^T J p) + lam * p_f, and the frame's share of p.q.
+template <int KD>
+__global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
+                                                       const double* __restrict__ mask,
+                                                       const double* __restrict__ lam, const float* __restrict__ median,
+                                                       const unsigned char* __restrict__ inRange,
+                                                       const int* __restrict__ fiOff, const int* __restrict__ fiList,
+                                                       const double* __restrict__ qPart, const double* __restrict__ z,
+                                                       const double* __restrict__ pOld, double* __restrict__ pNew,
+                                                       const double* __restrict__ scal, int useBeta,
+                                                       double* __restrict__ q, double* __restrict__ fdot) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  double* xf = sm;
+  double* pf = xf + B;   // masked direction
+  double* qf = pf + B;
+  double* red = qf + B;
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const double beta = useBeta ? scal[S_BETA] : 0.0;
+  const size_t base = static_cast<size_t>(f) * B;
+  for (int i = tid; i < B; i += 256) {
+    const double pv = z[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
+    pNew[base + i] = pv;
+    xf[i] = x[base + i];
+    pf[i] = pv * mask[base + i];
+    double acc = 0.0;
+    for (int e = fiOff[f]; e < fiOff[f + 1]; ++e) {
+      const int code = fiList[e];
+      acc += qPart[(static_cast<size_t>(code >> 1) * 2 + (code & 1)) * B + i];
+    }
+    qf[i] = acc;
+  }
+  __syncthreads();
+  if (inRange[f]) {
+    const int nr = numRegResiduals<KD>(L);
+    for (int i = tid; i < nr; i += 256) {
+      double r;
+      int n;
+      int cols[2 * KD + 2];
+      double jac[2 * KD + 2];
+      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      double t = 0.0;
+      for (int a = 0; a < n; ++a) t += jac[a] * pf[cols[a]];
+      for (int a = 0; a < n; ++a) atomicAdd(&qf[cols[a]], jac[a] * t);
+    }
+  }
+  __syncthreads();
+  double dot = 0.0;
+  for (int i = tid; i < B; i += 256) {
+    const double pv = pNew[base + i];
+    const double qv = qf[i] * mask[base + i] + lam[base + i] * pv;
+    q[base + i] = qv;
+    dot += pv * qv;
+  }
+  dot = waveSum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Per frame: alpha = rz / sum(p.q); dx += alpha p; r -= alpha q; z = Minv_f r; partial r.z and r.r.
+// init != 0: dx = 0, r = -g (already masked), z = Minv r.
+__global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const double* __restrict__ g,
+                                                   const double* __restrict__ minv, const double* __restrict__ p,
+                                                   const double* __restrict__ q, const double* __restrict__ fdotPQ,
+                                                   double* __restrict__ scal, double* __restrict__ dx,
+                                                   double* __restrict__ r, double* __restrict__ z,
+                                                   double* __restrict__ fdotRZ, double* __restrict__ fdotRR) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  double* rf = sm;
+  double* red = rf + B;
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const size_t base = static_cast<size_t>(f) * B;
+  double alpha = 0.0;
+  if (!init) {
+    // every block recomputes the global p.q from the per-frame partials (F doubles, L2-resident)
+    double acc = 0.0;
+    for (int i = tid; i < L.F; i += 256) acc += fdotPQ[i];
+    acc = waveSum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const double pq = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    alpha = scal[S_RZ] / pq;
+    if (f == 0 && tid == 0) { scal[S_PQ] = pq; scal[S_ALPHA] = alpha; }
+  }
+  for (int i = tid; i < B; i += 256) {
+    double rv;
+    if (init) {
+      dx[base + i] = 0.0;
+      rv = -g[base + i];
+    } else {
+      dx[base + i] += alpha * p[base + i];
+      rv = r[base + i] - alpha * q[base + i];
+    }
+    r[base + i] = rv;
+    rf[i] = rv;
+  }
+  __syncthreads();
+  const double* Mf = minv + static_cast<size_t>(f) * B * B;
+  double rz = 0.0, rr = 0.0;
+  for (int i = tid; i < B; i += 256) {
+    double zv = 0.0;
+    for (int j = 0; j < B; ++j) zv += Mf[static_cast<size_t>(j) * B + i] * rf[j];  // symmetric: column access
+    z[base + i] = zv;
+    rz += rf[i] * zv;
+    rr += rf[i] * rf[i];
+  }
+  rz = waveSum(rz);
+  rr = waveSum(rr);
+  if ((tid & 63) == 0) { red[tid >> 6] = rz; red[4 + (tid >> 6)] = rr; }
+  __syncthreads();
+  if (tid == 0) {
+    fdotRZ[f] = red[0] + red[1] + red[2] + red[3];
+    fdotRR[f] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// One block: rz_old <- rz, rz <- sum, beta = rz / rz_old (or rz0 <- rz at init).
+__global__ __launch_bounds__(256) void k_cg_scalars(int F, int init, const double* __restrict__ fdotRZ,
+                                                    const double* __restrict__ fdotRR, double* __restrict__ scal) {
+  __shared__ double red[8];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < F; i += 256) { a += fdotRZ[i]; b += fdotRR[i]; }
+  a = waveSum(a);
+  b = waveSum(b);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double rz = red[0] + red[1] + red[2] + red[3];
+    const double rr = red[4] + red[5] + red[6] + red[7];
+    if (init) {
+      scal[S_RZ0] = rz;
+      scal[S_RZOLD] = rz;
+      scal[S_BETA] = 0.0;
+    } else {
+      const double old = scal[S_RZ];
+      scal[S_RZOLD] = old;
+      scal[S_BETA] = (old != 0.0) ? rz / old : 0.0;
+    }
+    scal[S_RZ] = rz;
+    scal[S_RR] = rr;
+  }
+}
+
+// Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|.
+__global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ dx,
+                                                    const double* __restrict__ g, const double* __restrict__ r,
+                                                    const double* __restrict__ lam, const double* __restrict__ x,
+                                                    const double* __restrict__ hdiagActive, double* __restrict__ scal) {
+  __shared__ double red[6][4];
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const double d = dx[i];
+    a[0] += d * g[i];
+    a[1] += d * r[i];
+    a[2] += d * lam[i] * d;
+    a[3] += d * d;
+    if (hdiagActive[i] != 0.0) a[4] += x[i] * x[i];
+    a[5] = fmax(a[5], fabs(g[i]));
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) a[k] = waveSum(a[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a[5] = fmax(a[5], __shfl_xor(a[5], off, 64));
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 6] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scal[S_DG] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    scal[S_DR] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    scal[S_DLD] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    scal[S_DD] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+    scal[S_XX] = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+    scal[S_GMAX] = fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
+  }
+}
+
+// xcand = x + dx with the lower bound 0 on theta_k[0] when requested (ParameterBlock::Plus projection).
+__global__ void k_apply_step(Layout L, int boundDepth0, const double* __restrict__ x, const double* __restrict__ dx,
+                             double* __restrict__ xc) {
+  const size_t n = static_cast<size_t>(L.F) * L.B;
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = x[i] + dx[i];
+  if (boundDepth0) {
+    const int c = static_cast<int>(i % L.B);
+    if (c >= 7 && c < 7 + L.nD && ((c - 7) % L.N) == 0) v = fmax(v, 0.0);
+  }
+  xc[i] = v;
+}
+
+__global__ void k_extract_diag(Layout L, const double* __restrict__ hBlocks, double* __restrict__ out) {
+  const size_t n = static_cast<size_t>(L.F) * L.B;
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t f = i / L.B, c = i - f * L.B;
+  out[i] = hBlocks[(f * L.B + c) * L.B + c];
+}
+
+}  // namespace cvd
