@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s of the geometric-consistency optimizer on MI355X (driver contract).
+
+Metric (BASELINE.json): Gauss-Newton / Levenberg-Marquardt iterations per second on a 300-frame 384x224
+synthetic video (configs[2]: hierarchical flow_list, full LM loop).  One "step" = one LM iteration in Ceres'
+counting (Jacobian evaluation + linear solve + candidate-cost evaluation) at the FINAL coarse-to-fine grid
+(17x10 bilinear depth grid, 177 unknowns per frame, 53 100 unknowns, ~1.09 M flow constraints), continuing
+from the state the coarser levels converged to.  The convergence tests are disabled inside the timed region
+(`force_iterations`) so that exactly K iterations with full work are timed.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: every rank optimizes its own 300-frame video (independent videos shard with no data-path exchange),
+so `value` = N x K iterations / max-over-ranks time ("weak" scaling, config.parallelism = "video-per-gpu").
+
+The JSON line also carries
+  roofline     : dominant kernel k_matvec_pairs -- algorithmic HBM bytes per launch / average launch duration
+                 (HIP events on the solver stream, live in this run) vs the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (a port of the reference's Ceres problem: autodiff + exact Cholesky LM)
+                 timed on the host cores on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+FRAMES, WIDTH, HEIGHT = 300, 384, 224
+SEED = 1234 + 3
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def prepare(solver, video, params, final_grid=(17, 10)):
+    """Untimed: everything pose_optimization() does before the final coarse-to-fine level."""
+    from robust_cvd_amd import synth
+    from robust_cvd_amd.ctypes_types import XformDesc
+    synth.load_into(solver, video, params.focal_long)
+    solver.reset_depth_xforms(XformDesc.global_depth())
+    solver.reset_spatial_xforms(XformDesc.spatial())
+    solver.normalize_depth(params)
+    # CTF schedule of reference lib/PoseOptimizer.cpp:858-863 for a landscape video: Global -> 6x4 -> 12x7 -> 17x10
+    first = True
+    for grid in (None, (6, 4), (12, 7)):
+        if grid is not None:
+            solver.grid_xform_split(XformDesc.grid_depth(*grid))
+        solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=first)
+        first = False
+    solver.grid_xform_split(XformDesc.grid_depth(*final_grid))
+
+
+def cpu_baseline(params, full_constraints):
+    """Oracle (kind 'port') on a bounded sample: 16 frames at the same resolution / grid, 3 LM iterations."""
+    from robust_cvd_amd import synth
+    from robust_cvd_amd.ctypes_types import XformDesc
+    from oracle.oracle import Oracle
+    cores = os.cpu_count() or 1
+    threads = min(12, cores)  # reference default numThreads = 12 (lib/PoseOptimizer.h:57)
+    sample_frames = 16
+    video = synth.make_video(sample_frames, WIDTH, HEIGHT, seed=SEED)
+    from robust_cvd_amd.ctypes_types import OptParams
+    p = OptParams.defaults()
+    p.num_threads = threads
+    o = Oracle()
+    synth.load_into(o, video, p.focal_long)
+    o.reset_depth_xforms(XformDesc.global_depth())
+    o.reset_spatial_xforms(XformDesc.spatial())
+    o.normalize_depth(p)
+    o.grid_xform_split(XformDesc.grid_depth(17, 10))
+    p.max_iterations = 3
+    t0 = time.perf_counter()
+    o.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=True)
+    dt = time.perf_counter() - t0
+    s = o.summary()
+    iters = max(1, s["num_iterations"])
+    sample_rate = iters / dt
+    scaled = sample_rate * video.num_constraints / float(full_constraints)
+    return {
+        "value": scaled, "unit": "LM iterations/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle (dual-number autodiff + exact dense Cholesky LM) on {sample_frames} frames {WIDTH}x{HEIGHT}, "
+                   f"{len(video.pairs)} pairs, {video.num_constraints} constraints, 17x10 grid, {iters} LM iterations in "
+                   f"{dt:.2f} s = {sample_rate:.3f} it/s on the sample; scaled linearly in the constraint count to the "
+                   f"{full_constraints}-constraint workload (optimistic for the CPU: its solve grows super-linearly)"),
+        "sample_it_per_s": sample_rate,
+        "evaluate_seconds": s["evaluate_seconds"], "linear_solve_seconds": s["linear_solve_seconds"],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--pcg-tol", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-pairs", action="store_true", help="denser pair set (towards the ~4k pairs of BASELINE.json)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from robust_cvd_amd import api, synth
+    from robust_cvd_amd.ctypes_types import OptParams
+
+    params = OptParams.defaults()
+    video = synth.make_video(args.frames, WIDTH, HEIGHT, seed=SEED + rank, extra_offsets=args.extra_pairs)
+    solver = api.Solver(local_rank)
+    if args.pcg_tol is not None:
+        solver.set_options(pcg_relative_tolerance=args.pcg_tol)
+    t_prep = time.perf_counter()
+    prepare(solver, video, params)
+    t_prep = time.perf_counter() - t_prep
+    prep_summary = solver.summary()
+
+    # warmup: W untimed LM iterations at the final grid
+    solver.set_options(pcg_relative_tolerance=args.pcg_tol, force_iterations=1)
+    first = True
+    if args.warmup > 0:
+        params.max_iterations = args.warmup
+        solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
+        first = False
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    solver.set_kernel_timing(True)
+    params.max_iterations = args.steps
+    barrier()
+    t0 = time.perf_counter()
+    solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    summ = solver.summary()
+    assert summ["num_iterations"] == args.steps, summ
+    ktimes = solver.kernel_times()
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        n_active = solver.num_active_constraints()
+        B = solver.block_size()
+        mv = ktimes["matvec_pairs"]
+        # algorithmic bytes of one k_matvec_pairs launch: the 24 B constraint table entry (ndc 16 B + source
+        # depths 8 B) of every constraint + per work item the two frames' x, z, p_old, mask blocks read and
+        # the two partial q blocks written (B doubles each).  See DESIGN.md "k_matvec_pairs".
+        n_items = -(-n_active // 768) if n_active else 0
+        n_items = max(n_items, len(video.pairs))
+        bytes_launch = 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
+        achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
+        out = {
+            "metric": "GN/LM iterations/sec (and ms/iter) on 300-frame 384x224 video, 1/2/4/8 GPU",
+            "value": world * args.steps / dt,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"configs[2]: {args.frames}-frame {WIDTH}x{HEIGHT} synthetic video, hierarchical2 two-way "
+                             f"flow_list ({len(video.pairs)} directed pairs, {video.num_constraints} flow constraints), "
+                             f"full LM loop; timed = LM iterations at the final CTF level (17x10 bilinear grid, "
+                             f"B={B}, {args.frames * B} unknowns), Cauchy 0.5, PerFrame intrinsics"),
+                "pairs": int(len(video.pairs)), "constraints": int(n_active), "unknowns": int(args.frames * B),
+                "parallelism": "single-gpu" if world == 1 else "video-per-gpu",
+                "linear_solver": "block-Jacobi PCG, matrix-free J^T J",
+                "pcg_iterations_per_lm_iteration": summ["total_linear_iterations"] / max(1, summ["num_iterations"]),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": bytes_launch, "avg_launch_ms": mv["avg_ms"], "launches": mv["launches"],
+                "note": "f64 VALU/latency-bound, not HBM-bound: ~24 B and ~1 kflop per constraint (DESIGN.md)",
+            },
+            "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in ktimes.items()},
+            "kernels_launches": {k: v["launches"] for k, v in ktimes.items()},
+            "timed_solve": {k: summ[k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
+                                                 "initial_cost", "final_cost", "evaluate_seconds", "linear_solve_seconds")},
+            "prepare_seconds": t_prep,
+            "prepare_last_level": {k: prep_summary[k] for k in ("num_iterations", "total_linear_iterations", "final_cost",
+                                                                "total_seconds")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, n_active)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

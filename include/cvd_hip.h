@@ -30,7 +30,7 @@ typedef struct cvd_solver_options {
   int32_t pcg_max_iterations;    /* default 300 */
   int32_t pcg_check_every;       /* host convergence check cadence in CG iterations (default 4) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
-  int32_t reserved;
+  int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

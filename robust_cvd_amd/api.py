@@ -21,7 +21,7 @@ class SolverOptions(C.Structure):
         ("pcg_max_iterations", C.c_int32),
         ("pcg_check_every", C.c_int32),
         ("verbose", C.c_int32),
-        ("reserved", C.c_int32),
+        ("force_iterations", C.c_int32),
     ]
 
 
@@ -66,7 +66,8 @@ class Solver(Binding):
             raise RuntimeError("cvd_create failed: " + (lib.cvd_last_error(None) or b"").decode())
         super().__init__(lib, "cvd_", handle)
 
-    def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None):
+    def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None,
+                    force_iterations=None):
         o = SolverOptions()
         self._lib.cvd_solver_options_default(C.byref(o))
         if pcg_relative_tolerance is not None:
@@ -77,6 +78,8 @@ class Solver(Binding):
             o.pcg_check_every = pcg_check_every
         if verbose is not None:
             o.verbose = int(verbose)
+        if force_iterations is not None:
+            o.force_iterations = int(force_iterations)
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
 
     def set_kernel_timing(self, enabled=True):

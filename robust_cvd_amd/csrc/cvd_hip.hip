@@ -896,7 +896,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n"
            "%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", 0, xCost, 0.0, gmax, 0.0, 0.0, radius, 0);
 
-  if (sum.num_parameters == 0 || gmax <= Ceres::gradient_tolerance) {
+  if (sum.num_parameters == 0 || (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations)) {
     termination = 0;
   } else {
     while (true) {
@@ -952,6 +952,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       bool stop = false;
       if (stepNorm <= Ceres::parameter_tolerance * (xNorm + Ceres::parameter_tolerance)) stop = true;
       if (!stop && std::abs(xCost - candCost) <= Ceres::function_tolerance * xCost) stop = true;
+      if (h->opt.force_iterations) stop = false;
       if (stop) {
         rec.cost = xCost;
         rec.trust_region_radius = radius;
@@ -987,7 +988,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         if (h->opt.verbose)
           printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
                  stepNorm, rec.relative_decrease, radius, cgIters);
-        if (gmax <= Ceres::gradient_tolerance) { termination = 0; break; }
+        if (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) { termination = 0; break; }
       } else {
         radius /= decrease;
         decrease *= 2.0;
@@ -1243,7 +1244,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->pcg_max_iterations = 300;
   o->pcg_check_every = 4;
   o->verbose = 0;
-  o->reserved = 0;
+  o->force_iterations = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
 

@@ -554,9 +554,11 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     xf[i] = x[base + i];
     pf[i] = pv * mask[base + i];
     double acc = 0.0;
-    for (int e = fiOff[f]; e < fiOff[f + 1]; ++e) {
-      const int code = fiList[e];
-      acc += qPart[(static_cast<size_t>(code >> 1) * 2 + (code & 1)) * B + i];
+    if (L.includeStatic) {  // no pair kernel ran otherwise: the partial buffer holds stale data
+      for (int e = fiOff[f]; e < fiOff[f + 1]; ++e) {
+        const int code = fiList[e];
+        acc += qPart[(static_cast<size_t>(code >> 1) * 2 + (code & 1)) * B + i];
+      }
     }
     qf[i] = acc;
   }

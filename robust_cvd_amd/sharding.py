@@ -1,0 +1,40 @@
+"""Pair sharding for the multi-GPU path: directed pairs are split across ranks so that
+(i, j) and (j, i) stay on one rank and constraint counts balance (greedy bin packing); per-frame
+regularisers are owned by rank (frame % world).  After local assembly, gradient / frame-diagonal blocks /
+cost are summed with ONE all-reduce per LM iteration (and one per PCG product for the matrix-free q).
+
+Pure index bookkeeping: no optimizer arithmetic here.
+"""
+import numpy as np
+
+
+def shard_pairs(pairs, offsets, world):
+    """Returns a list (len = world) of index arrays into `pairs`. Deterministic; union = all, disjoint."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    counts = np.diff(np.asarray(offsets))
+    groups = {}
+    for i, (a, b) in enumerate(pairs):
+        groups.setdefault((min(a, b), max(a, b)), []).append(i)
+    order = sorted(groups.items(), key=lambda kv: (-int(counts[kv[1]].sum()), kv[0]))
+    load = np.zeros(world, dtype=np.int64)
+    out = [[] for _ in range(world)]
+    for _, idxs in order:
+        r = int(np.argmin(load))
+        out[r].extend(idxs)
+        load[r] += int(counts[idxs].sum())
+    return [np.array(sorted(o), dtype=np.int64) for o in out]
+
+
+def take_pairs(pairs, offsets, loc, is_static, idx):
+    """Sub-collection (pairs, offsets, loc, is_static) of the pairs in idx (kept in map order)."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    offsets = np.asarray(offsets)
+    new_off = [0]
+    locs, stat = [], []
+    for i in idx:
+        locs.append(loc[offsets[i]:offsets[i + 1]])
+        stat.append(is_static[offsets[i]:offsets[i + 1]])
+        new_off.append(new_off[-1] + int(offsets[i + 1] - offsets[i]))
+    loc_o = np.concatenate(locs) if locs else np.zeros((0, loc.shape[1]), loc.dtype)
+    st_o = np.concatenate(stat) if stat else np.zeros((0,), np.uint8)
+    return pairs[idx], np.asarray(new_off, dtype=np.int64), loc_o, st_o

@@ -1,0 +1,68 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/cvd_hip.h declares, struct sizes agree."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from robust_cvd_amd import api
+from robust_cvd_amd.ctypes_types import FramePose, IterationRecord, OptParams, SolveSummary, XformDesc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cvd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = api.load_library()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cvd_hip.h but not exported"
+    assert sorted(api.EXPORTED_SYMBOLS) == names
+
+
+def test_struct_sizes_match_compiled_library():
+    lib = api.load_library()
+    out = (C.c_int32 * 6)()
+    lib.cvd_abi_sizes(out)
+    assert list(out) == [C.sizeof(XformDesc), C.sizeof(OptParams), C.sizeof(FramePose), C.sizeof(IterationRecord),
+                         C.sizeof(SolveSummary), C.sizeof(api.SolverOptions)]
+
+
+def test_default_params_match_reference_defaults():
+    """reference lib/PoseOptimizer.h:55-103"""
+    lib = api.load_library()
+    p = OptParams()
+    lib.cvd_opt_params_default(C.byref(p))
+    d = OptParams.defaults()
+    for name, _ in OptParams._fields_:
+        if name == "frame_range":
+            continue
+        assert getattr(p, name) == getattr(d, name), name
+    assert p.max_iterations == 1000 and p.num_threads == 12 and p.num_steps == 4 and p.robustness == 0.5
+    assert p.ctf_long == 17 and p.ctf_short == 10 and p.dso_long == 4 and p.dso_short == 3
+    assert p.focal_long == 0.3461538376301239 and p.intr_opt == 2 and p.static_loss_type == 1
+
+
+def test_no_cpu_fallback(have_gpu):
+    """Without a GPU the product path must fail loudly (no CPU fallback, no oracle routing)."""
+    if have_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU path"):
+        api.Solver(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/ (tier rule 3)."""
+    pkg = os.path.join(ROOT, "robust_cvd_amd")
+    bad = re.compile(r"^\s*(from|import)\s+oracle\b|libcvd_oracle|cvdo_[a-z]+\s*\(|dlopen.*oracle", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), f"{f} references the oracle"
