@@ -45,6 +45,8 @@ void cvd_abi_sizes(int32_t* out6);
 void cvd_opt_params_default(cvd_opt_params* p);       /* reference lib/PoseOptimizer.h:55-103 defaults */
 void cvd_solver_options_default(cvd_solver_options* o);
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o);
+/* Test hook: 1 = run the generic all-variants kernels even where a specialised fast kernel exists. */
+int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
 
 /* ---- inputs (what the reference reads through DepthVideo / DepthStream / FlowConstraintsCollection) -- */
 /* DepthVideo dims + aspect (reference lib/DepthVideo.h: numFrames(), aspect(), invAspect(); DepthStream w/h). */

@@ -278,6 +278,8 @@ struct cvd_handle_t {
   cvd_solve_summary summary{};
   std::vector<cvd_iteration_record> records;
 
+  bool forceGeneric = false;  // test hook: route the products through the generic (all-variants) kernel
+
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
@@ -753,13 +755,24 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   hipStream_t s = h->stream;
   const size_t B = c.L.B;
   if (c.L.includeStatic && c.nItems > 0) {
-    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst);
+    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24) * 8;
     const int slot = h->tBegin(KC_MATVEC_PAIRS);
-    CVD_DISPATCH(c.KD, c.KS, {
-      allowLds(k_matvec_pairs<KD, KS>, lds);
-      hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+    if (fast && c.KD == 4) {
+      allowLds(k_matvec_pairs_fast<4>, lds);
+      hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
                          h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
-    });
+    } else if (fast) {
+      allowLds(k_matvec_pairs_fast<1>, lds);
+      hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+    } else {
+      CVD_DISPATCH(c.KD, c.KS, {
+        allowLds(k_matvec_pairs<KD, KS>, lds);
+        hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                           h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+      });
+    }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
   }
@@ -912,7 +925,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       scaleDone = true;
       {
         const size_t B = c.L.B;
-        const size_t lds = (B * (B + 1) / 2) * 8;
+        const size_t lds = (B * (B + 1) / 2 + B) * 8;
         allowLds(k_block_inverse, lds);
         const int slot = h->tBegin(KC_INVERSE);
         hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(256), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
@@ -1247,6 +1260,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->force_iterations = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
+int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled) { CVD_TRY(h, h->forceGeneric = enabled != 0); }
 
 int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t height, float aspect, float invAspect) {
   CVD_TRY(h, {

@@ -368,62 +368,97 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, doub
 __global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
                                                        const double* __restrict__ lam, double* __restrict__ minv,
                                                        double* __restrict__ work, int* __restrict__ fail) {
+  // Everything stays in LDS (packed lower triangle A, B(B+1)/2 doubles + one column buffer):
+  //   1. left-looking Cholesky, thread per row (dot of two packed rows; row j is a broadcast read)
+  //   2. X = L^-1 in place, right-to-left by columns: X[i][j] = -(sum_{k=j+1..i} X[i][k] L[k][j]) / L[j][j]
+  //   3. Minv = X^T X written once to global (dense, symmetric).
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  (void)work;
   const int B = L.B;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
-  double* A = sm;  // packed lower
-  for (int idx = tid; idx < B * (B + 1) / 2; idx += 256) {
-    int i = static_cast<int>((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    while (i * (i + 1) / 2 > idx) --i;
-    const int j = idx - i * (i + 1) / 2;
-    double v = hf[static_cast<size_t>(i) * B + j];
-    if (i == j) v += lam[static_cast<size_t>(f) * B + i];
-    A[idx] = v;
+  const int npk = B * (B + 1) / 2;
+  double* A = sm;         // packed lower, row-major: (i, j) at i(i+1)/2 + j
+  double* col = A + npk;  // B
+  for (int i = tid; i < B; i += 256) {
+    const int rb = i * (i + 1) / 2;
+    for (int j = 0; j <= i; ++j) A[rb + j] = hf[static_cast<size_t>(i) * B + j];
+    A[rb + i] += lam[static_cast<size_t>(f) * B + i];
   }
   __syncthreads();
+  // 1. Cholesky (column j finalised per step)
   for (int j = 0; j < B; ++j) {
-    const int jj = packedIdx(j, j);
-    if (tid == 0) {
-      double d = A[jj];
-      if (!(d > 0.0)) { d = 1.0; atomicAdd(fail, 1); }
-      A[jj] = sqrt(d);
+    const int rj = j * (j + 1) / 2;
+    for (int i = j + tid; i < B; i += 256) {
+      const int ri = i * (i + 1) / 2;
+      double s0 = A[ri + j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {  // independent partial sums: keeps several LDS reads in flight
+        s0 -= A[ri + k] * A[rj + k];
+        s1 -= A[ri + k + 1] * A[rj + k + 1];
+        s2 -= A[ri + k + 2] * A[rj + k + 2];
+        s3 -= A[ri + k + 3] * A[rj + k + 3];
+      }
+      for (; k < j; ++k) s0 -= A[ri + k] * A[rj + k];
+      col[i] = (s0 + s1) + (s2 + s3);  // un-normalised column j (col[j] = pivot^2)
     }
     __syncthreads();
-    const double d = A[jj];
-    for (int i = j + 1 + tid; i < B; i += 256) A[packedIdx(i, j)] /= d;
+    double d = col[j];
+    if (!(d > 0.0)) {
+      if (tid == 0) atomicAdd(fail, 1);
+      d = 1.0;
+    }
+    d = sqrt(d);
+    const double id = 1.0 / d;
+    for (int i = j + tid; i < B; i += 256) A[i * (i + 1) / 2 + j] = (i == j) ? d : col[i] * id;
     __syncthreads();
-    for (int i = j + 1 + tid; i < B; i += 256) {
-      const double lij = A[packedIdx(i, j)];
-      const int rb = i * (i + 1) / 2;
-      for (int k = j + 1; k <= i; ++k) A[rb + k] -= lij * A[packedIdx(k, j)];
+  }
+  // 2. in-place inverse of L
+  for (int j = B - 1; j >= 0; --j) {
+    for (int k = j + tid; k < B; k += 256) col[k] = A[k * (k + 1) / 2 + j];
+    __syncthreads();
+    const double ijj = 1.0 / col[j];
+    for (int i = j + tid; i < B; i += 256) {
+      const int ri = i * (i + 1) / 2;
+      if (i == j) {
+        A[ri + j] = ijj;
+      } else {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = j + 1;
+        for (; k + 3 <= i; k += 4) {
+          s0 += A[ri + k] * col[k];
+          s1 += A[ri + k + 1] * col[k + 1];
+          s2 += A[ri + k + 2] * col[k + 2];
+          s3 += A[ri + k + 3] * col[k + 3];
+        }
+        for (; k <= i; ++k) s0 += A[ri + k] * col[k];
+        A[ri + j] = -((s0 + s1) + (s2 + s3)) * ijj;
+      }
     }
     __syncthreads();
   }
-  // Linv column c (thread per column), stored as W[row * B + c]
-  double* Wk = work + static_cast<size_t>(f) * B * B;
-  for (int c = tid; c < B; c += 256) {
-    for (int i = 0; i < c; ++i) Wk[static_cast<size_t>(i) * B + c] = 0.0;
-    Wk[static_cast<size_t>(c) * B + c] = 1.0 / A[packedIdx(c, c)];
-    for (int i = c + 1; i < B; ++i) {
-      double s = 0.0;
-      const int rb = i * (i + 1) / 2;
-      for (int k = c; k < i; ++k) s += A[rb + k] * Wk[static_cast<size_t>(k) * B + c];
-      Wk[static_cast<size_t>(i) * B + c] = -s / A[rb + i];
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
+  // 3. Minv = X^T X
   double* Mf = minv + static_cast<size_t>(f) * B * B;
-  for (int idx = tid; idx < B * B; idx += 256) {
-    const int a = idx / B, b = idx - a * B;
-    if (b > a) continue;
-    double s = 0.0;
-    for (int k = a; k < B; ++k) s += Wk[static_cast<size_t>(k) * B + a] * Wk[static_cast<size_t>(k) * B + b];
-    Mf[static_cast<size_t>(a) * B + b] = s;
-    Mf[static_cast<size_t>(b) * B + a] = s;
+  for (int idx = tid; idx < npk; idx += 256) {
+    int hi = static_cast<int>((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    while ((hi + 1) * (hi + 2) / 2 <= idx) ++hi;
+    while (hi * (hi + 1) / 2 > idx) --hi;
+    const int lo = idx - hi * (hi + 1) / 2;
+    double s0 = 0.0, s1 = 0.0;
+    int k = hi;
+    for (; k + 1 < B; k += 2) {
+      const int rk = k * (k + 1) / 2, rk1 = rk + k + 1;
+      s0 += A[rk + lo] * A[rk + hi];
+      s1 += A[rk1 + lo] * A[rk1 + hi];
+    }
+    if (k < B) {
+      const int rk = k * (k + 1) / 2;
+      s0 += A[rk + lo] * A[rk + hi];
+    }
+    const double sv = s0 + s1;
+    Mf[static_cast<size_t>(hi) * B + lo] = sv;
+    Mf[static_cast<size_t>(lo) * B + hi] = sv;
   }
 }
 
@@ -730,6 +765,266 @@ __global__ void k_extract_diag(Layout L, const double* __restrict__ hBlocks, dou
   if (i >= n) return;
   const size_t f = i / L.B, c = i - f * L.B;
   out[i] = hBlocks[(f * L.B + c) * L.B + c];
+}
+
+
+// =====================================================================================================
+// Fast path of the hot kernel (identity spatial transform, reprojection losses, Identity / Global / bilinear
+// depth transform = everything the reference's default pipeline uses).
+//
+// Same operator as k_matvec_pairs, restructured so that no 3x7 Jacobian is ever materialised:
+//   forward  : dX = directional derivative of the world point along p_a, dq = R_b^T (dX - p_tb) + E_b^T v,
+//              t = rho' * (d r / d q . dq + direct terms)            with E_f = sum_i p_w,i dR_f,i per frame
+//   backward : y_q = (d r / d q)^T t, y_X = R_b y_q; translations get +-y_X, the rotation / focal / depth
+//              columns are contracted per WORKGROUP from 3x3 outer-product accumulators
+//              O_a = sum D_a y_X c_a^T, O_b = sum v y_q^T  (q_w,i = <dR_i, O>), so dR never enters the loop.
+// Per-lane state: 23 accumulators; taps are fully unrolled (no scratch).
+// =====================================================================================================
+template <int KD>
+struct FastTaps {
+  int idx[KD];
+  double w[KD];
+};
+
+template <int KD>
+__device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, FastTaps<KD>& t) {
+  if constexpr (KD == 4) {
+    bilinearTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.idx, t.w);
+  } else {
+    t.idx[0] = 0;
+    t.w[0] = 1.0;
+  }
+}
+
+template <int KD>
+__global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                           const FrameConst* __restrict__ fc,
+                                                           const double* __restrict__ mask,
+                                                           const double* __restrict__ z, const double* __restrict__ pOld,
+                                                           const double* __restrict__ scal, int useBeta,
+                                                           double* __restrict__ qPart) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr double eps = 1e-6;
+  const int B = L.B;
+  double* xa = sm;
+  double* xb = xa + B;
+  double* pa = xb + B;
+  double* pb = pa + B;
+  double* qa = pb + B;
+  double* qb = qa + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
+  double* E = reinterpret_cast<double*>(fcs + 2);  // E_a[9], E_b[9]
+  double* red = E + 18;                            // 4 waves x 24
+  const int item = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int p = it.pair[item];
+  const int fa = T.pairA[p], fb = T.pairB[p];
+  const double beta = useBeta ? scal[S_BETA] : 0.0;
+  for (int i = tid; i < B; i += 256) {
+    const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
+    xa[i] = x[ia];
+    xb[i] = x[ib];
+    pa[i] = (z[ia] + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    qa[i] = 0.0;
+    qb[i] = 0.0;
+  }
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (tid < 2 * FCW) {
+    const int which = tid / FCW, k = tid % FCW;
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  __syncthreads();
+  if (tid < 18) {
+    const int which = tid / 9, e = tid % 9;
+    const double* pp = which ? pb : pa;
+    const FrameConst& f = fcs[which];
+    E[tid] = pp[3] * f.dR[0][e] + pp[4] * f.dR[1][e] + pp[5] * f.dR[2][e];
+  }
+  __syncthreads();
+
+  const int N = L.N;
+  const double A = L.aspect;
+  const FrameConst& Fa = fcs[0];
+  const FrameConst& Fb = fcs[1];
+  const double fya = Fa.fy, fxa = Fa.fy * A;
+  const double fyb = Fb.fy;
+  const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+
+  double aT[3] = {0, 0, 0};  // sum y_X  (q_ta = +aT, q_tb = -aT)
+  double Oa[9], Ob[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
+  double aFa = 0.0, aFb = 0.0;
+
+  for (long long c = it.begin[item] + tid; c < it.end[item]; c += 256) {
+    const float2 d = T.dsrc[c];
+    if (!(d.x > 0.f)) continue;
+    const float4 nd = T.ndc[c];
+    const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
+    FastTaps<KD> ta, tb;
+    fastGather<KD>(L, nd.x, nd.y, ta);
+    fastGather<KD>(L, nd.z, nd.w, tb);
+    // depths and their directional derivatives
+    double Da, Db, sDa, sDb;
+    if (N == 0) {
+      Da = da; Db = db; sDa = 0.0; sDb = 0.0;
+    } else {
+      Da = 0.0; Db = 0.0; sDa = 0.0; sDb = 0.0;
+#pragma unroll
+      for (int k = 0; k < KD; ++k) {
+        if (N == 2) {
+          Da += (da * xa[7 + ta.idx[k] * 2] + xa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
+          Db += (db * xb[7 + tb.idx[k] * 2] + xb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
+          sDa += (da * pa[7 + ta.idx[k] * 2] + pa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
+          sDb += (db * pb[7 + tb.idx[k] * 2] + pb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
+        } else {
+          Da += da * xa[7 + ta.idx[k]] * ta.w[k];
+          Db += db * xb[7 + tb.idx[k]] * tb.w[k];
+          sDa += da * pa[7 + ta.idx[k]] * ta.w[k];
+          sDb += db * pb[7 + tb.idx[k]] * tb.w[k];
+        }
+      }
+    }
+    const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
+    const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
+    const double ca[3] = {pax * fxa, pay * fya, -1.0};
+    const double Rca[3] = {dot3(Fa.R, ca), dot3(Fa.R + 3, ca), dot3(Fa.R + 6, ca)};
+    const double v[3] = {Fa.t[0] + Rca[0] * Da - Fb.t[0], Fa.t[1] + Rca[1] * Da - Fb.t[1],
+                         Fa.t[2] + Rca[2] * Da - Fb.t[2]};
+    const double q0 = Fb.R[0] * v[0] + Fb.R[3] * v[1] + Fb.R[6] * v[2];
+    const double q1 = Fb.R[1] * v[0] + Fb.R[4] * v[1] + Fb.R[7] * v[2];
+    const double q2 = Fb.R[2] * v[0] + Fb.R[5] * v[1] + Fb.R[8] * v[2];
+    const double zz = -q2;
+    const double iz = 1.0 / zz;
+    const double u = q0 * iz * ifxb;
+    const double vv = q1 * iz * ifyb;
+    const double r0 = (u - pbx) * L.ws;
+    const double r1 = (vv - pby) * L.ws;
+    double r2, dr2dA, dr2dDb;
+    if (L.lossType == kLossDisparity) {
+      const bool zo = !(zz < eps), bo = !(Db < eps);
+      const double zc = zo ? zz : eps, bc = bo ? Db : eps;
+      const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / bc;
+      r2 = (izc - ibc) * L.wd;
+      dr2dA = zo ? (-L.wd * izc * izc) : 0.0;
+      dr2dDb = bo ? (L.wd * ibc * ibc) : 0.0;
+    } else {
+      const bool zIsMax = !(zz < Db), zIsMin = !(Db < zz);
+      const double mx = zIsMax ? zz : Db, mn = zIsMin ? zz : Db;
+      if (L.lossType == kLossRatio) {
+        r2 = (mx / mn - 1.0) * L.wd;
+        const double dmx = 1.0 / mn, dmn = -mx / (mn * mn);
+        dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+        dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+      } else {
+        r2 = log(mn / mx) * L.wd;
+        const double dmn = 1.0 / mn, dmx = -1.0 / mx;
+        dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+        dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+      }
+    }
+    const double rho1 = 1.0 / (1.0 + (r0 * r0 + r1 * r1 + r2 * r2) * L.cauchyC);
+
+    // ---- forward: dX, dq, t
+    const double cf[3] = {pax * A, pay, 0.0};
+    const double Rcf[3] = {Fa.R[0] * cf[0] + Fa.R[1] * cf[1], Fa.R[3] * cf[0] + Fa.R[4] * cf[1],
+                           Fa.R[6] * cf[0] + Fa.R[7] * cf[1]};
+    const double Eca[3] = {dot3(E, ca), dot3(E + 3, ca), dot3(E + 6, ca)};
+    const double pfa = pa[6], pfb = pb[6];
+    double w3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w3[i] = pa[i] + Da * (Eca[i] + pfa * Rcf[i]) + sDa * Rca[i] - pb[i];
+    const double* Eb = E + 9;
+    const double dq0 = Fb.R[0] * w3[0] + Fb.R[3] * w3[1] + Fb.R[6] * w3[2] + Eb[0] * v[0] + Eb[3] * v[1] + Eb[6] * v[2];
+    const double dq1 = Fb.R[1] * w3[0] + Fb.R[4] * w3[1] + Fb.R[7] * w3[2] + Eb[1] * v[0] + Eb[4] * v[1] + Eb[7] * v[2];
+    const double dq2 = Fb.R[2] * w3[0] + Fb.R[5] * w3[1] + Fb.R[8] * w3[2] + Eb[2] * v[0] + Eb[5] * v[1] + Eb[8] * v[2];
+    const double wiz = L.ws * iz;
+    const double m00 = wiz * ifxb, m11 = wiz * ifyb, m02 = wiz * u, m12 = wiz * vv;
+    const double pfr = pfb * ifyb;
+    double t0 = (m00 * dq0 + m02 * dq2 - L.ws * u * pfr) * rho1;
+    double t1 = (m11 * dq1 + m12 * dq2 - L.ws * vv * pfr) * rho1;
+    double t2 = (-dr2dA * dq2 + dr2dDb * sDb) * rho1;
+
+    // ---- backward
+    const double yq0 = m00 * t0, yq1 = m11 * t1, yq2 = m02 * t0 + m12 * t1 - dr2dA * t2;
+    aFb -= (L.ws * u * t0 + L.ws * vv * t1) * ifyb;
+    const double yX[3] = {Fb.R[0] * yq0 + Fb.R[1] * yq1 + Fb.R[2] * yq2, Fb.R[3] * yq0 + Fb.R[4] * yq1 + Fb.R[5] * yq2,
+                          Fb.R[6] * yq0 + Fb.R[7] * yq1 + Fb.R[8] * yq2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      aT[i] += yX[i];
+      const double dy = Da * yX[i];
+      Oa[i * 3 + 0] += dy * ca[0];
+      Oa[i * 3 + 1] += dy * ca[1];
+      Oa[i * 3 + 2] += dy * ca[2];
+      Ob[i * 3 + 0] += v[i] * yq0;
+      Ob[i * 3 + 1] += v[i] * yq1;
+      Ob[i * 3 + 2] += v[i] * yq2;
+    }
+    aFa += Da * (Rcf[0] * yX[0] + Rcf[1] * yX[1] + Rcf[2] * yX[2]);
+    if (N > 0) {
+      const double ga = Rca[0] * yX[0] + Rca[1] * yX[1] + Rca[2] * yX[2];
+      const double gb = dr2dDb * t2;
+#pragma unroll
+      for (int k = 0; k < KD; ++k) {
+        if (N == 2) {
+          atomicAdd(&qa[7 + ta.idx[k] * 2], ga * ta.w[k] * da);
+          atomicAdd(&qa[7 + ta.idx[k] * 2 + 1], ga * ta.w[k]);
+          atomicAdd(&qb[7 + tb.idx[k] * 2], gb * tb.w[k] * db);
+          atomicAdd(&qb[7 + tb.idx[k] * 2 + 1], gb * tb.w[k]);
+        } else {
+          atomicAdd(&qa[7 + ta.idx[k]], ga * ta.w[k] * da);
+          atomicAdd(&qb[7 + tb.idx[k]], gb * tb.w[k] * db);
+        }
+      }
+    }
+  }
+  // ---- workgroup reduction of the 23 accumulators, then contraction with dR
+  {
+    const int wv = tid >> 6;
+    double vals[23];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vals[i] = aT[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { vals[3 + i] = Oa[i]; vals[12 + i] = Ob[i]; }
+    vals[21] = aFa;
+    vals[22] = aFb;
+#pragma unroll
+    for (int i = 0; i < 23; ++i) {
+      const double s = waveSum(vals[i]);
+      if ((tid & 63) == 0) red[wv * 24 + i] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < 23) red[tid] = red[tid] + red[24 + tid] + red[48 + tid] + red[72 + tid];
+  __syncthreads();
+  if (tid < 3) {
+    qa[tid] += red[tid];
+    qb[tid] -= red[tid];
+  } else if (tid < 6) {
+    const int i = tid - 3;  // q_wa,i = <dR_a,i, O_a>  (O_a[r][c] = sum D y_X[r] c_a[c])
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s += Fa.dR[i][e] * red[3 + e];
+    qa[3 + i] += s;
+  } else if (tid < 9) {
+    const int i = tid - 6;  // q_wb,i = <dR_b,i, O_b>  (O_b[r][c] = sum v[r] y_q[c]; dq/dw_i = dR_i^T v)
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s += Fb.dR[i][e] * red[12 + e];
+    qb[3 + i] += s;
+  } else if (tid == 9) {
+    qa[6] += red[21];
+  } else if (tid == 10) {
+    qb[6] += red[22];
+  }
+  __syncthreads();
+  double* out = qPart + static_cast<size_t>(item) * 2 * B;
+  for (int i = tid; i < B; i += 256) {
+    out[i] = qa[i];
+    out[B + i] = qb[i];
+  }
 }
 
 }  // namespace cvd

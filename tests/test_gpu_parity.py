@@ -78,6 +78,34 @@ def test_matrix_free_product_matches_oracle_hessian(Solver):
     assert rel(res["hip"]["gradient"], res["oracle"]["gradient"]) < TOL
 
 
+def test_fast_and_generic_product_kernels_agree(Solver):
+    """k_matvec_pairs_fast (default pipeline) vs the generic all-variants kernel on the same inputs."""
+    for ddesc, loss in ((XformDesc.grid_depth(5, 4), StaticLossType.ReproDisparity),
+                        (XformDesc.global_depth(ValueXformType.ScaleShift), StaticLossType.ReproDepthRatio),
+                        (XformDesc.global_depth(), StaticLossType.ReproLogDepth),
+                        (XformDesc.identity_depth(), StaticLossType.ReproDisparity)):
+        v = synth.make_video(4, 64, 40, seed=37, spacing=9)
+        s = Solver(0)
+        synth.load_into(s, v)
+        s.reset_depth_xforms(ddesc)
+        s.reset_spatial_xforms(XformDesc.spatial())
+        rng = np.random.default_rng(9)
+        F = v.num_frames
+        pose = np.zeros((F, 7))
+        pose[:, :6] = rng.normal(0, 0.05, (F, 6))
+        pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+        dx = s.get_xform_params()
+        if dx.size:
+            dx = 0.15 + rng.uniform(0, 0.05, dx.shape)
+            s.set_xform_params(dx)
+        p = OptParams.defaults()
+        p.static_loss_type = loss
+        fast = s.evaluate(p, 0.1, pose, want_hfull=True)["hfull"]
+        s.set_generic_kernels(True)
+        gen = s.evaluate(p, 0.1, pose, want_hfull=True)["hfull"]
+        assert rel(fast, gen) < 1e-12
+
+
 def test_empty_and_ragged_inputs(Solver):
     """Pairs with zero constraints, frames in no pair, all-dynamic constraints, invalid depth everywhere."""
     v = synth.make_video(6, 64, 40, seed=32, spacing=9)

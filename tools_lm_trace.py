@@ -1,0 +1,17 @@
+"""Development aid: print the LM table (incl. PCG iterations per LM iteration) of the full pipeline."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from robust_cvd_amd import api, synth
+from robust_cvd_amd.ctypes_types import *
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2
+v = synth.make_video(F, 384, 224, seed=1237)
+s = api.Solver(0); synth.load_into(s, v)
+s.set_options(verbose=1, pcg_relative_tolerance=tol)
+s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
+p = OptParams.defaults()
+s.normalize_depth(p)
+t0 = time.time(); s.pose_optimization(p); dt = time.time() - t0
+sm = s.summary()
+print("TOTAL", dt, sm)
