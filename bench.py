@@ -164,8 +164,14 @@ def main():
         # algorithmic bytes of one k_matvec_pairs launch: the 24 B constraint table entry (ndc 16 B + source
         # depths 8 B) of every constraint + per work item the two frames' x, z, p_old, mask blocks read and
         # the two partial q blocks written (B doubles each).  See DESIGN.md "k_matvec_pairs".
-        n_items = -(-n_active // 768) if n_active else 0
-        n_items = max(n_items, len(video.pairs))
+        # work items = undirected frame pairs (both directions share one workgroup), chunked at 768 per direction
+        import numpy as np
+        cnt = np.diff(video.offsets)
+        und = {}
+        for (a, b), n in zip(video.pairs.tolist(), cnt.tolist()):
+            k = (min(a, b), max(a, b))
+            und[k] = max(und.get(k, 0), n)
+        n_items = sum(-(-n // 768) for n in und.values())
         bytes_launch = 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
         out = {

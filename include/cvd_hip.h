@@ -26,7 +26,7 @@ typedef struct cvd_handle_t cvd_handle;
 /* Inner linear solver / LM knobs that have no counterpart in the reference (Ceres' SPARSE_NORMAL_CHOLESKY
  * is replaced by a block-Jacobi preconditioned conjugate-gradient solve on the device). */
 typedef struct cvd_solver_options {
-  double pcg_relative_tolerance; /* stop when sqrt(r^T M^-1 r) <= tol * its initial value (default 1e-2) */
+  double pcg_relative_tolerance; /* stop when sqrt(r^T M^-1 r) <= tol * its initial value (default 1e-1 = Ceres' eta) */
   int32_t pcg_max_iterations;    /* default 300 */
   int32_t pcg_check_every;       /* host convergence check cadence in CG iterations (default 4) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */

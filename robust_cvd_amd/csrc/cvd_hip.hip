@@ -251,10 +251,11 @@ struct cvd_handle_t {
   bool haveTriplets = false;
 
   // work decomposition
-  std::vector<int> itemPair;
-  std::vector<long long> itemBegin, itemEnd;
-  DevBuf<int> dItemPair, dFiOff, dFiList, dFpOff, dFpList;
-  DevBuf<long long> dItemBegin, dItemEnd;
+  std::vector<int> itemFa, itemFb;
+  std::vector<long long> itemRange;  // 4 per item
+  DevBuf<int> dItemFa, dItemFb, dFiOff, dFiList, dFpOff, dFpList;
+  DevBuf<long long> dItemRange;
+  DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
   bool tableValid = false;
   long long numValid = 0;
@@ -267,7 +268,8 @@ struct cvd_handle_t {
   bool poseParamsValid = false;
 
   // solver buffers
-  DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dZ, dP0, dP1, dQ, dH, dMinv, dWork, dQPart;
+  DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dZ, dP0, dP1, dQ, dH, dQPart;
+  DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd;
   DevBuf<FrameConst> dFc;
   DevBuf<int> dFail;
@@ -572,30 +574,40 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
   HIP_CHECK(hipStreamSynchronize(s));
   h->numValid = static_cast<long long>(nv);
 
-  // work items: balanced chunks of <= 768 constraints of one pair
-  h->itemPair.clear();
-  h->itemBegin.clear();
-  h->itemEnd.clear();
+  // work items: one per UNDIRECTED pair {a < b} and chunk; each carries a slice of a->b and of b->a
+  h->itemFa.clear();
+  h->itemFb.clear();
+  h->itemRange.clear();
   std::vector<std::vector<int>> frameItems(h->F), framePairs(h->F);
+  std::map<std::pair<int, int>, std::array<int, 2>> edges;  // (min, max) -> {pair min->max, pair max->min}
   for (int p = 0; p < h->P; ++p) {
     const int a = h->pairA[p], b = h->pairB[p];
-    if (!inRange[a] || !inRange[b]) continue;
+    if (!inRange[a] || !inRange[b] || a == b) continue;
     const long long n = h->pairOff[p + 1] - h->pairOff[p];
     if (n <= 0) continue;
     framePairs[a].push_back(p * 2 + 0);
     framePairs[b].push_back(p * 2 + 1);
-    const long long nItems = (n + 767) / 768;
-    const long long chunk = (n + nItems - 1) / nItems;
+    auto it = edges.find({std::min(a, b), std::max(a, b)});
+    if (it == edges.end()) it = edges.insert({{std::min(a, b), std::max(a, b)}, {-1, -1}}).first;
+    it->second[a < b ? 0 : 1] = p;
+  }
+  for (const auto& e : edges) {
+    const int fa = e.first.first, fb = e.first.second;
+    long long n0 = 0, n1 = 0, o0 = 0, o1 = 0;
+    if (e.second[0] >= 0) { o0 = h->pairOff[e.second[0]]; n0 = h->pairOff[e.second[0] + 1] - o0; }
+    if (e.second[1] >= 0) { o1 = h->pairOff[e.second[1]]; n1 = h->pairOff[e.second[1] + 1] - o1; }
+    const long long nItems = std::max<long long>(1, (std::max(n0, n1) + 767) / 768);
+    const long long c0 = (n0 + nItems - 1) / nItems, c1 = (n1 + nItems - 1) / nItems;
     for (long long k = 0; k < nItems; ++k) {
-      const long long b0 = h->pairOff[p] + k * chunk;
-      const long long b1 = std::min(h->pairOff[p + 1], b0 + chunk);
-      if (b0 >= b1) continue;
-      const int item = static_cast<int>(h->itemPair.size());
-      h->itemPair.push_back(p);
-      h->itemBegin.push_back(b0);
-      h->itemEnd.push_back(b1);
-      frameItems[a].push_back(item * 2 + 0);
-      frameItems[b].push_back(item * 2 + 1);
+      const long long b0 = o0 + std::min(n0, k * c0), e0 = o0 + std::min(n0, (k + 1) * c0);
+      const long long b1 = o1 + std::min(n1, k * c1), e1 = o1 + std::min(n1, (k + 1) * c1);
+      if (b0 >= e0 && b1 >= e1) continue;
+      const int item = static_cast<int>(h->itemFa.size());
+      h->itemFa.push_back(fa);
+      h->itemFb.push_back(fb);
+      h->itemRange.insert(h->itemRange.end(), {b0, e0, b1, e1});
+      frameItems[fa].push_back(item * 2 + 0);
+      frameItems[fb].push_back(item * 2 + 1);
     }
   }
   std::vector<int> fiOff(h->F + 1, 0), fiList, fpOff(h->F + 1, 0), fpList;
@@ -605,9 +617,9 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
     fpOff[f + 1] = fpOff[f] + static_cast<int>(framePairs[f].size());
     fpList.insert(fpList.end(), framePairs[f].begin(), framePairs[f].end());
   }
-  h->dItemPair.upload(h->itemPair.data(), h->itemPair.size(), s);
-  h->dItemBegin.upload(h->itemBegin.data(), h->itemBegin.size(), s);
-  h->dItemEnd.upload(h->itemEnd.data(), h->itemEnd.size(), s);
+  h->dItemFa.upload(h->itemFa.data(), h->itemFa.size(), s);
+  h->dItemFb.upload(h->itemFb.data(), h->itemFb.size(), s);
+  h->dItemRange.upload(h->itemRange.data(), h->itemRange.size(), s);
   h->dFiOff.upload(fiOff.data(), fiOff.size(), s);
   h->dFiList.upload(fiList.data(), fiList.size(), s);
   h->dFpOff.upload(fpOff.data(), fpOff.size(), s);
@@ -678,14 +690,18 @@ static void ensureBuffers(Ctx& c) {
   h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
   h->dDx.ensure(n); h->dR.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
   h->dHd.ensure(n);
-  h->dH.ensure(n * B); h->dMinv.ensure(n * B); h->dWork.ensure(n * B);
+  h->dH.ensure(n * B); h->dMinv.ensure(n * B);
   h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(c.nItems) * 2 * B));
-  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
+  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 5);
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
   h->dScal.ensure(S_COUNT);
   h->dFc.ensure(c.L.F);
   h->dFail.ensure(1);
+  if (!h->dCounters.p) {
+    h->dCounters.ensure(4);
+    HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 4 * sizeof(unsigned int), h->stream));
+  }
   if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
 }
 
@@ -755,7 +771,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   hipStream_t s = h->stream;
   const size_t B = c.L.B;
   if (c.L.includeStatic && c.nItems > 0) {
-    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24) * 8;
+    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8) * 8;
     const int slot = h->tBegin(KC_MATVEC_PAIRS);
     const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
     if (fast && c.KD == 4) {
@@ -777,12 +793,12 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     h->tEnd(slot);
   }
   {
-    const size_t lds = 3 * B * 8 + 8 * 8;
+    const size_t lds = 3 * B * 8 + 8 * 8;  // xf, pf, qf + red[6] + flag
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
-                         h->dScal.p, useBeta, q, h->dFdot.p);
+                         h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p);
     });
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -790,17 +806,18 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
 }
 
 // PCG on (H + diag(lam)) dx = -g with the block-Jacobi preconditioner; returns iterations used.
+// Three launches per iteration (pairs product, per-frame finish, per-frame update).  alpha / beta live on
+// the device: the last workgroup of k_matvec_finish / k_cg_update reduces the per-frame partial dot products
+// (agent-scope release/acquire ticket), so there is neither a scalar kernel nor a host round trip in the loop.
 static int runPcg(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   const int F = c.L.F;
   const size_t B = c.L.B;
   double* fd = h->dFdot.p;
-  const size_t ldsU = (B + 8) * 8;
-  // init: dx = 0, r = -g, z = Minv r, rz0
-  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p, fd,
-                     h->dScal.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
-  hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s, F, 1, fd + F, fd + 2 * F, h->dScal.p);
+  const size_t ldsU = (B + 10) * 8;
+  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
+                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
   HIP_CHECK(hipGetLastError());
   readScalars(c);
   const double rz0 = h->hScal[S_RZ0];
@@ -814,9 +831,8 @@ static int runPcg(Ctx& c, const double* x) {
   while (k < maxIt) {
     launchMatvec(c, x, h->dZ.p, pOld, pNew, k > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, fd,
-                       h->dScal.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s, F, 0, fd + F, fd + 2 * F, h->dScal.p);
+    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
+                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
     std::swap(pOld, pNew);
@@ -846,8 +862,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     h->medianDirty = false;
   }
   c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
-  c.nItems = static_cast<int>(h->itemPair.size());
-  c.it = Items{h->dItemPair.p, h->dItemBegin.p, h->dItemEnd.p, c.nItems};
+  c.nItems = static_cast<int>(h->itemFa.size());
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   ensureBuffers(c);
@@ -929,7 +945,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         allowLds(k_block_inverse, lds);
         const int slot = h->tBegin(KC_INVERSE);
         hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(256), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
-                           h->dWork.p, h->dFail.p);
+                           static_cast<double*>(nullptr), h->dFail.p);
         HIP_CHECK(hipGetLastError());
         h->tEnd(slot);
       }
@@ -1134,8 +1150,8 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
     h->medianDirty = false;
   }
   c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
-  c.nItems = static_cast<int>(h->itemPair.size());
-  c.it = Items{h->dItemPair.p, h->dItemBegin.p, h->dItemEnd.p, c.nItems};
+  c.nItems = static_cast<int>(h->itemFa.size());
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);
@@ -1253,7 +1269,7 @@ void cvd_opt_params_default(cvd_opt_params* p) {
 }
 
 void cvd_solver_options_default(cvd_solver_options* o) {
-  o->pcg_relative_tolerance = 1e-2;
+  o->pcg_relative_tolerance = 1e-1;  // = ceres::Solver::Options::eta default (inexact-step forcing value)
   o->pcg_max_iterations = 300;
   o->pcg_check_every = 4;
   o->verbose = 0;

@@ -28,16 +28,55 @@ struct Table {
   const long long* pairOff;  // P + 1
 };
 
-struct Items {  // work items of the pair-major kernels: a contiguous chunk of one pair's constraints
-  const int* pair;
-  const long long* begin;
-  const long long* end;
+// Work items of the pair-major kernels: one UNDIRECTED frame pair {fa < fb} with a chunk of the constraints
+// of the directed pair fa->fb (range[0..1]) and of fb->fa (range[2..3]); either may be empty.  Both directions
+// share the two frames' parameter blocks, so one workgroup prologue / epilogue serves both.
+struct Items {
+  const int* fa;
+  const int* fb;
+  const long long* range;  // 4 per item
   int count;
 };
 
 // scalar slots kept on the device during PCG
 enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5, S_RZ0 = 6, S_COST = 7,
              S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14, S_COUNT = 16 };
+
+// Sum of a short global array (F per-frame partials, L2-resident) by every workgroup that needs the scalar:
+// cheaper than a separate 1-block reduction kernel + its launch boundary. `red` = 4 doubles of LDS.
+__device__ __forceinline__ double blockSumArray(const double* __restrict__ a, int n, double* red) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += a[i];
+  acc = waveSum(acc);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (blockDim.x >> 6); ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// "Last workgroup finishes the reduction": every workgroup publishes its partials with an agent-scope release,
+// takes a ticket, and the last one acquires and reduces (cdna_hip_programming.md G16: release on the producer,
+// acquire on the consumer; L1 is per CU and the 8 XCD L2s are not coherent with each other).
+// `flag` = one int of LDS. Returns true (for every thread of the block) in the last-arriving workgroup.
+__device__ __forceinline__ bool lastBlockArrives(unsigned int* counter, unsigned int total, int* flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (t == total - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+    }
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
 
 // ---------------------------------------------------------------------------------------------------
 __global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameConst* __restrict__ fc) {
@@ -97,8 +136,7 @@ __global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it,
   FrameConst* fcs = reinterpret_cast<FrameConst*>(sm + 2 * B);
   double* red = reinterpret_cast<double*>(fcs + 2);
   const int item = blockIdx.x;
-  const int p = it.pair[item];
-  const int fa = T.pairA[p], fb = T.pairB[p];
+  const int fa = it.fa[item], fb = it.fb[item];
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     xa[i] = x[static_cast<size_t>(fa) * B + i];
     xb[i] = x[static_cast<size_t>(fb) * B + i];
@@ -110,12 +148,19 @@ __global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it,
   }
   __syncthreads();
   double acc = 0.0;
-  for (long long c = it.begin[item] + threadIdx.x; c < it.end[item]; c += blockDim.x) {
-    const float2 d = T.dsrc[c];
-    if (d.x > 0.f) {
-      Sample<KD, KS> s;
-      evalSample<KD, KS, false>(L, fcs[0], fcs[1], xa, xb, T.ndc[c], d, s);
-      acc += s.rho0;
+  for (int dir = 0; dir < 2; ++dir) {
+    const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+    const FrameConst& Fs = fcs[dir];
+    const FrameConst& Ft = fcs[dir ^ 1];
+    const double* xs = dir ? xb : xa;
+    const double* xt = dir ? xa : xb;
+    for (long long c = cb + threadIdx.x; c < ce; c += blockDim.x) {
+      const float2 d = T.dsrc[c];
+      if (d.x > 0.f) {
+        Sample<KD, KS> s;
+        evalSample<KD, KS, false>(L, Fs, Ft, xs, xt, T.ndc[c], d, s);
+        acc += s.rho0;
+      }
     }
   }
   acc = waveSum(acc);
@@ -366,7 +411,7 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, doub
 // L2-resident), Minv = L^-T L^-1.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
-                                                       const double* __restrict__ lam, double* __restrict__ minv,
+                                                       const double* __restrict__ lam, float* __restrict__ minv,
                                                        double* __restrict__ work, int* __restrict__ fail) {
   // Everything stays in LDS (packed lower triangle A, B(B+1)/2 doubles + one column buffer):
   //   1. left-looking Cholesky, thread per row (dot of two packed rows; row j is a broadcast read)
@@ -439,7 +484,7 @@ __global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* _
     __syncthreads();
   }
   // 3. Minv = X^T X
-  double* Mf = minv + static_cast<size_t>(f) * B * B;
+  float* Mf = minv + static_cast<size_t>(f) * B * B;
   for (int idx = tid; idx < npk; idx += 256) {
     int hi = static_cast<int>((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
     while ((hi + 1) * (hi + 2) / 2 <= idx) ++hi;
@@ -456,7 +501,7 @@ __global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* _
       const int rk = k * (k + 1) / 2;
       s0 += A[rk + lo] * A[rk + hi];
     }
-    const double sv = s0 + s1;
+    const float sv = static_cast<float>(s0 + s1);
     Mf[static_cast<size_t>(hi) * B + lo] = sv;
     Mf[static_cast<size_t>(lo) * B + hi] = sv;
   }
@@ -487,8 +532,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
   FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
-  const int p = it.pair[item];
-  const int fa = T.pairA[p], fb = T.pairB[p];
+  const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   for (int i = tid; i < B; i += 256) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
@@ -505,17 +549,29 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
     reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
   }
   __syncthreads();
+  for (int dir = 0; dir < 2; ++dir) {
+  const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+  if (cb >= ce) continue;
+  // role swap for the reverse pair: source = fb, target = fa
+  const FrameConst& Fs = fcs[dir];
+  const FrameConst& Ft = fcs[dir ^ 1];
+  const double* xs = dir ? xb : xa;
+  const double* xt = dir ? xa : xb;
+  const double* ps = dir ? pb : pa;
+  const double* pt = dir ? pa : pb;
+  double* qs = dir ? qb : qa;
+  double* qt = dir ? qa : qb;
   double qpa[7], qpb[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) { qpa[i] = 0.0; qpb[i] = 0.0; }
-  for (long long c = it.begin[item] + tid; c < it.end[item]; c += 256) {
+  for (long long c = cb + tid; c < ce; c += 256) {
     const float2 d = T.dsrc[c];
     if (!(d.x > 0.f)) continue;
     Sample<KD, KS> s;
-    evalSample<KD, KS, true>(L, fcs[0], fcs[1], xa, xb, T.ndc[c], d, s);
+    evalSample<KD, KS, true>(L, Fs, Ft, xs, xt, T.ndc[c], d, s);
     double t[3] = {0.0, 0.0, 0.0};
-    sideJp(L, s.a, pa, t);
-    sideJp(L, s.b, pb, t);
+    sideJp(L, s.a, ps, t);
+    sideJp(L, s.b, pt, t);
     t[0] *= s.rho1; t[1] *= s.rho1; t[2] *= s.rho1;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -528,7 +584,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
         int col;
         double J[3];
         sideTapCol(L, s.a, k, col, J);
-        atomicAdd(&qa[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
+        atomicAdd(&qs[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
       }
     }
     {
@@ -537,7 +593,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
         int col;
         double J[3];
         sideTapCol(L, s.b, k, col, J);
-        atomicAdd(&qb[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
+        atomicAdd(&qt[col], J[0] * t[0] + J[1] * t[1] + J[2] * t[2]);
       }
     }
   }
@@ -549,10 +605,11 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
   if ((tid & 63) == 0) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      atomicAdd(&qa[i], qpa[i]);
-      atomicAdd(&qb[i], qpb[i]);
+      atomicAdd(&qs[i], qpa[i]);
+      atomicAdd(&qt[i], qpb[i]);
     }
   }
+  }  // dir
   __syncthreads();
   double* out = qPart + static_cast<size_t>(item) * 2 * B;
   for (int i = tid; i < B; i += 256) {
@@ -571,8 +628,8 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const int* __restrict__ fiOff, const int* __restrict__ fiList,
                                                        const double* __restrict__ qPart, const double* __restrict__ z,
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
-                                                       const double* __restrict__ scal, int useBeta,
-                                                       double* __restrict__ q, double* __restrict__ fdot) {
+                                                       double* __restrict__ scal, unsigned int* __restrict__ counter,
+                                                       int useBeta, double* __restrict__ q, double* __restrict__ fdot) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -623,14 +680,22 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
   if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
+  // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
+  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
+    const double pq = blockSumArray(fdot, L.F, red);
+    if (tid == 0) {
+      scal[S_PQ] = pq;
+      scal[S_ALPHA] = scal[S_RZ] / pq;
+    }
+  }
 }
 
 // Per frame: alpha = rz / sum(p.q); dx += alpha p; r -= alpha q; z = Minv_f r; partial r.z and r.r.
 // init != 0: dx = 0, r = -g (already masked), z = Minv r.
 __global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const double* __restrict__ g,
-                                                   const double* __restrict__ minv, const double* __restrict__ p,
-                                                   const double* __restrict__ q, const double* __restrict__ fdotPQ,
-                                                   double* __restrict__ scal, double* __restrict__ dx,
+                                                   const float* __restrict__ minv, const double* __restrict__ p,
+                                                   const double* __restrict__ q, double* __restrict__ scal,
+                                                   unsigned int* __restrict__ counter, double* __restrict__ dx,
                                                    double* __restrict__ r, double* __restrict__ z,
                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -640,19 +705,7 @@ __global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const dou
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
-  double alpha = 0.0;
-  if (!init) {
-    // every block recomputes the global p.q from the per-frame partials (F doubles, L2-resident)
-    double acc = 0.0;
-    for (int i = tid; i < L.F; i += 256) acc += fdotPQ[i];
-    acc = waveSum(acc);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    const double pq = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-    alpha = scal[S_RZ] / pq;
-    if (f == 0 && tid == 0) { scal[S_PQ] = pq; scal[S_ALPHA] = alpha; }
-  }
+  const double alpha = init ? 0.0 : scal[S_ALPHA];
   for (int i = tid; i < B; i += 256) {
     double rv;
     if (init) {
@@ -666,11 +719,19 @@ __global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const dou
     rf[i] = rv;
   }
   __syncthreads();
-  const double* Mf = minv + static_cast<size_t>(f) * B * B;
+  // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
+  // applied with f64 accumulation
+  const float* Mf = minv + static_cast<size_t>(f) * B * B;
   double rz = 0.0, rr = 0.0;
   for (int i = tid; i < B; i += 256) {
-    double zv = 0.0;
-    for (int j = 0; j < B; ++j) zv += Mf[static_cast<size_t>(j) * B + i] * rf[j];  // symmetric: column access
+    double zv0 = 0.0, zv1 = 0.0;
+    int j = 0;
+    for (; j + 1 < B; j += 2) {  // symmetric: column access, coalesced over i
+      zv0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
+      zv1 += static_cast<double>(Mf[static_cast<size_t>(j + 1) * B + i]) * rf[j + 1];
+    }
+    if (j < B) zv0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
+    const double zv = zv0 + zv1;
     z[base + i] = zv;
     rz += rf[i] * zv;
     rr += rf[i] * rf[i];
@@ -682,6 +743,24 @@ __global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const dou
   if (tid == 0) {
     fdotRZ[f] = red[0] + red[1] + red[2] + red[3];
     fdotRR[f] = red[4] + red[5] + red[6] + red[7];
+  }
+  // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
+  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 8))) {
+    const double rz = blockSumArray(fdotRZ, L.F, red);
+    const double rr = blockSumArray(fdotRR, L.F, red);
+    if (tid == 0) {
+      if (init) {
+        scal[S_RZ0] = rz;
+        scal[S_RZOLD] = rz;
+        scal[S_BETA] = 0.0;
+      } else {
+        const double old = scal[S_RZ];
+        scal[S_RZOLD] = old;
+        scal[S_BETA] = (old != 0.0) ? rz / old : 0.0;
+      }
+      scal[S_RZ] = rz;
+      scal[S_RR] = rr;
+    }
   }
 }
 
@@ -817,8 +896,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   double* red = E + 18;                            // 4 waves x 24
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
-  const int p = it.pair[item];
-  const int fa = T.pairA[p], fb = T.pairB[p];
+  const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   for (int i = tid; i < B; i += 256) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
@@ -845,8 +923,20 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
 
   const int N = L.N;
   const double A = L.aspect;
-  const FrameConst& Fa = fcs[0];
-  const FrameConst& Fb = fcs[1];
+  for (int dir = 0; dir < 2; ++dir) {
+  const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+  if (cb >= ce) continue;  // uniform
+  // role swap for the reverse pair (source = fb, target = fa): swap every per-frame pointer
+  const FrameConst& Fa = fcs[dir];
+  const FrameConst& Fb = fcs[dir ^ 1];
+  const double* Esrc = E + 9 * dir;
+  const double* Eb = E + 9 * (dir ^ 1);
+  if (dir) {
+    double* t;
+    t = xa; xa = xb; xb = t;
+    t = pa; pa = pb; pb = t;
+    t = qa; qa = qb; qb = t;
+  }
   const double fya = Fa.fy, fxa = Fa.fy * A;
   const double fyb = Fb.fy;
   const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
@@ -857,7 +947,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
   double aFa = 0.0, aFb = 0.0;
 
-  for (long long c = it.begin[item] + tid; c < it.end[item]; c += 256) {
+  for (long long c = cb + tid; c < ce; c += 256) {
     const float2 d = T.dsrc[c];
     if (!(d.x > 0.f)) continue;
     const float4 nd = T.ndc[c];
@@ -930,12 +1020,11 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     const double cf[3] = {pax * A, pay, 0.0};
     const double Rcf[3] = {Fa.R[0] * cf[0] + Fa.R[1] * cf[1], Fa.R[3] * cf[0] + Fa.R[4] * cf[1],
                            Fa.R[6] * cf[0] + Fa.R[7] * cf[1]};
-    const double Eca[3] = {dot3(E, ca), dot3(E + 3, ca), dot3(E + 6, ca)};
+    const double Eca[3] = {dot3(Esrc, ca), dot3(Esrc + 3, ca), dot3(Esrc + 6, ca)};
     const double pfa = pa[6], pfb = pb[6];
     double w3[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) w3[i] = pa[i] + Da * (Eca[i] + pfa * Rcf[i]) + sDa * Rca[i] - pb[i];
-    const double* Eb = E + 9;
     const double dq0 = Fb.R[0] * w3[0] + Fb.R[3] * w3[1] + Fb.R[6] * w3[2] + Eb[0] * v[0] + Eb[3] * v[1] + Eb[6] * v[2];
     const double dq1 = Fb.R[1] * w3[0] + Fb.R[4] * w3[1] + Fb.R[7] * w3[2] + Eb[1] * v[0] + Eb[4] * v[1] + Eb[7] * v[2];
     const double dq2 = Fb.R[2] * w3[0] + Fb.R[5] * w3[1] + Fb.R[8] * w3[2] + Eb[2] * v[0] + Eb[5] * v[1] + Eb[8] * v[2];
@@ -1020,6 +1109,10 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     qb[6] += red[22];
   }
   __syncthreads();
+  }  // dir
+  if (it.range[item * 4 + 2] < it.range[item * 4 + 3]) {  // undo the role swap
+    double* t = qa; qa = qb; qb = t;
+  }
   double* out = qPart + static_cast<size_t>(item) * 2 * B;
   for (int i = tid; i < B; i += 256) {
     out[i] = qa[i];
