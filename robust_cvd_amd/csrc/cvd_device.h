@@ -115,14 +115,14 @@ __device__ __forceinline__ void frameConstFromParams(const double* __restrict__ 
 // reference lib/DepthMapTransform.cpp:739-851 (linear), :853-948 (cubic, border folding),
 // :1107-1114, :1181-1191, :1253-1343 (spatial)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gridCell(float loc, int g, double maxc, int& i, double& r) {
+__host__ __device__ __forceinline__ void gridCell(float loc, int g, double maxc, int& i, double& r) {
   double s = (static_cast<double>(loc) + 1.0) * static_cast<double>(g - 1) / 2.0;
-  s = fmin(fmax(s, 0.0), maxc);
+  s = s < 0.0 ? 0.0 : (s > maxc ? maxc : s);  // std::clamp(s, 0, maxc)
   i = static_cast<int>(s);
   r = s - static_cast<double>(i);
 }
 
-__device__ __forceinline__ void cubicTaps(double t, double w[4]) {
+__host__ __device__ __forceinline__ void cubicTaps(double t, double w[4]) {
   const double t2 = t * t;
   const double t3 = t2 * t;
   w[0] = -0.5 * t3 + t2 - 0.5 * t;
@@ -138,7 +138,7 @@ struct Taps {
   double w[K];
 };
 
-__device__ __forceinline__ void bilinearTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
+__host__ __device__ __forceinline__ void bilinearTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
                                              double* w) {
   int ix, iy;
   double rx, ry;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void bilinearTaps(float lx, float ly, int gx, int gy,
 }
 
 // 2-D Catmull-Rom gather with out-of-range taps folded onto the clamped neighbour.
-__device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
+__host__ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
                                            double* w) {
   int ix, iy;
   double rx, ry;
@@ -170,8 +170,8 @@ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, d
   double fx[4] = {0.0, 0.0, 0.0, 0.0}, fy[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    const int cx = min(max(x - x0, 0), xs - 1);
-    const int cy = min(max(x - y0, 0), ys - 1);
+    int cx = x - x0; cx = cx < 0 ? 0 : (cx > xs - 1 ? xs - 1 : cx);
+    int cy = x - y0; cy = cy < 0 ? 0 : (cy > ys - 1 ? ys - 1 : cy);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q == cx) fx[q] += wx[x];

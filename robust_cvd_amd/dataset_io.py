@@ -1,0 +1,58 @@
+"""Write a synthetic video as a robust_cvd dataset directory (the on-disk inputs at the drop-in boundary,
+SURVEY.md 8b): frames.txt, depth_<model>/depth/frame_%06d.raw (DISPARITY, f32 raw image), flow_list.json,
+flow_constraints.dat.  Formats: reference lib/Importer.cpp:197-238, lib/core/CvUtil.cpp:25-36 / 98-107,
+flow.py:44-74, lib/FlowConstraints.cpp:191-224.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+CV_32FC1 = 5
+
+
+def write_raw_image(path, img):
+    """int rows, int cols, int cvType, size_t elemSize, then row-major data (reference lib/core/CvUtil.cpp:98-107)."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    assert img.ndim == 2
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiQ", img.shape[0], img.shape[1], CV_32FC1, 4))
+        f.write(img.tobytes())
+
+
+def write_flow_constraints(path, pairs, offsets, loc, match_separation=10, triplet_centers=()):
+    """magic, version 3, matchSeparation, per pair {2 x i32 key, u64 n, n x 4 f32}, per triplet {i32, u64 n (=0)}, magic."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIi", 0xDEADBEEF, 3, match_separation))
+        for p, (a, b) in enumerate(np.asarray(pairs).tolist()):
+            n = int(offsets[p + 1] - offsets[p])
+            f.write(struct.pack("<iiQ", a, b, n))
+            f.write(np.ascontiguousarray(loc[offsets[p]:offsets[p + 1]], dtype=np.float32).tobytes())
+        for t in triplet_centers:
+            f.write(struct.pack("<iQ", int(t), 0))
+        f.write(struct.pack("<I", 0xDEADBEEF))
+
+
+def write_dataset(base_dir, video, model_type="midas2", fps=30.0):
+    os.makedirs(base_dir, exist_ok=True)
+    F, W, H = video.num_frames, video.width, video.height
+    with open(os.path.join(base_dir, "frames.txt"), "w") as f:
+        f.write(f"{F}\n{W}\n{H}\n")
+        for i in range(F):
+            f.write(f"{i / fps:.6f}\n")
+    ddir = os.path.join(base_dir, f"depth_{model_type}", "depth")
+    os.makedirs(ddir, exist_ok=True)
+    for i in range(F):
+        d = video.depth[i]
+        disp = np.where(d > 0, 1.0 / np.maximum(d, 1e-30), 0.0).astype(np.float32)  # streams store disparity
+        write_raw_image(os.path.join(ddir, f"frame_{i:06d}.raw"), disp)
+    # flow_list.json: row 0 is a header (reference flow.py:53, skipped by lib/FlowConstraints.cpp:59)
+    with open(os.path.join(base_dir, "flow_list.json"), "w") as f:
+        json.dump([["src", "dst"]] + np.asarray(video.pairs).tolist(), f)
+    # the reference creates a triplet entry for every interior frame of the range (lib/FlowConstraints.cpp:71-80)
+    write_flow_constraints(os.path.join(base_dir, "flow_constraints.dat"), video.pairs, video.offsets, video.loc,
+                           triplet_centers=range(1, F - 1))
+    for d in ("color_full", "color_down"):
+        os.makedirs(os.path.join(base_dir, d), exist_ok=True)
+    return base_dir

@@ -32,5 +32,6 @@ def _build_native():
     """Both native pieces are built in-tree before any test (seconds when up to date)."""
     from robust_cvd_amd import build as b
     b.build()
+    b.build_lib_python()
     from oracle import oracle as o
     o.build()

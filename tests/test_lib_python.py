@@ -1,0 +1,257 @@
+"""Drop-in `lib_python` module (robust_cvd_amd/csrc/lib_python.cpp): the names / semantics the reference's
+Python callers rely on, the on-disk formats, and -- on the GPU -- the full optimize_poses() sequence."""
+import importlib
+import os
+import struct
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from robust_cvd_amd import build as _b
+from robust_cvd_amd import dataset_io, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    d = os.path.dirname(_b.build_lib_python())
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module("lib_python")
+
+
+@pytest.fixture()
+def dataset(tmp_path):
+    v = synth.make_video(10, 96, 56, seed=51)
+    return v, dataset_io.write_dataset(str(tmp_path / "video"), v)
+
+
+def test_names_imported_by_the_reference_callers_exist(lib):
+    # pose_optimization.py:9-23, params.py:14, process.py:25-30, loaders/video_dataset.py:16
+    for n in ("DepthVideo", "DepthVideoImporter", "DepthVideoPoseOptimizer", "DepthVideoProcessor", "DepthXformType",
+              "FlowConstraintsCollection", "FlowConstraintsParams", "IntrinsicsOptimization", "SmoothLossType",
+              "SpatialXformType", "StaticLossType", "ValueXformType", "XformType", "FrameRange", "initLib", "logToStdout"):
+        assert hasattr(lib, n), n
+    p = lib.DepthVideoPoseOptimizer.Params()   # defaults of reference lib/PoseOptimizer.h:55-103 (params.py mirrors them)
+    assert (p.maxIterations, p.numThreads, p.numSteps, p.robustness) == (1000, 12, 4, 0.5)
+    assert p.staticLossType == lib.StaticLossType.ReproDisparity and p.intrOpt == lib.IntrinsicsOptimization.PerFrame
+    assert (p.ctfLong, p.ctfShort, p.dsoLong, p.dsoShort, p.scaleRegGridSize) == (17, 10, 4, 3, 10)
+    assert p.focalLong == 0.3461538376301239 and p.depthDeformRegFinal == 0.1 and p.coarseToFine
+
+
+def test_frame_range(lib):
+    r = lib.FrameRange()
+    r.fromString("1,3,5-7")
+    assert r.toString() == "1,3,5-7" and r.count() == 5 and r.firstFrame() == 1 and r.lastFrame() == 7
+    assert r.inRange(6) and not r.inRange(4) and not r.isConsecutive()
+    r2 = lib.FrameRange()
+    assert r2.isEmpty()
+    with pytest.raises(RuntimeError):
+        r2.firstFrame()
+    r2.resolve(4)
+    assert r2.toString() == "0-3"
+    r3 = lib.FrameRange()
+    r3.fromString("2-9")
+    r3.resolve(5, True)
+    assert r3.toString() == "2-4"
+    with pytest.raises(RuntimeError):
+        r.resolve(5)
+
+
+def test_xform_descriptor_strings(lib):
+    d = lib.XformDescriptor()
+    assert d.str() == "Identity()"
+    d.depthType = lib.DepthXformType.Global
+    d.valueXform = lib.ValueXformType.Scale
+    assert d.str() == "Global(Scale)"
+    d.depthType = lib.DepthXformType.Grid
+    d.gridSize = [17, 10, 1]
+    assert d.str() == "Grid(Scale, Linear, 17, 10, 1)"
+    e = lib.XformDescriptor()
+    e.parse("Grid(ScaleShift, Cubic, 4, 3, 1)")
+    assert e.cubicInterpolation and list(e.gridSize) == [4, 3, 1] and e.valueXform == lib.ValueXformType.ScaleShift
+    e.parse("BicubicGrid(Scale, 5, 6)")          # legacy 2-D form, reference lib/DepthMapTransform.cpp:197-207
+    assert e.str() == "Grid(Scale, Cubic, 5, 6, 1)"
+    s = lib.XformDescriptor()
+    s.reset(lib.XformType.Spatial)
+    assert s.str() == "Identity"
+    s.parse("BicubicGrid(3, 4)")
+    assert s.spatialType == lib.SpatialXformType.BicubicGrid and s.str() == "BicubicGrid(3, 4)"
+
+
+def test_nested_params_are_references_and_assignment_copies(lib):
+    """pose_optimization.py:190-216 relies on both behaviours (SURVEY.md 8b 'ownership')."""
+    opt = lib.DepthVideoPoseOptimizer.Params()
+    params = lib.DepthVideoProcessor.Params()
+    params.poseOptimizer = opt
+    params.poseOptimizer.frameRange.fromString("0-3")     # mutates in place through the getter
+    assert params.poseOptimizer.frameRange.toString() == "0-3"
+    params.poseOptimizer.fixPoses = True
+    assert opt.fixPoses is False                           # the setter copied
+    params.depthXformDesc.depthType = lib.DepthXformType.Global
+    assert params.depthXformDesc.depthType == lib.DepthXformType.Global
+
+
+def test_import_streams_constraints_and_video_dat(lib, dataset):
+    v, base = dataset
+    from tests.drop_in_caller import build_pose_optimizer
+    dv, fc = build_pose_optimizer(lib, base, "midas2", list(range(v.num_frames)), None)
+    assert dv.numFrames() == 10 and dv.width() == 96 and dv.height() == 56
+    assert abs(dv.aspect() - 96 / 56) < 1e-6 and dv.numDepthStreams() == 1 and dv.hasColorStream("down")
+    ds = dv.depthStream(dv.numDepthStreams() - 1)
+    assert ds.name() == "depth_midas2" and ds.depthXformDesc().str() == "Identity()"
+    src = ds.frame(3).sourceDepth()                       # disparity file -> depth, invalid -> 0
+    assert src.shape == (56, 96) and ds.width() == 96
+    np.testing.assert_allclose(src, v.depth[3], rtol=2e-7)
+    f = ds.frame(0)
+    assert f.extrinsics.right() == [1.0, 0.0, 0.0] and f.extrinsics.backward() == [0.0, 0.0, 1.0]
+    assert f.intrinsics.vFov > 0 and f.intrinsics.hFov > 0   # resolveMissingFov
+    assert fc.numPairs() == len(v.pairs) and fc.numConstraints() == v.num_constraints
+    # video.dat layout: magic, version 13, dp format 3, N, pts ... trailing magic
+    raw = open(os.path.join(base, "video.dat"), "rb").read()
+    magic, ver, dpf, n = struct.unpack_from("<IIIi", raw, 0)
+    assert (magic, ver, dpf, n) == (0xDEADBEEF, 13, 3, 10)
+    assert struct.unpack_from("<I", raw, len(raw) - 4)[0] == 0xDEADBEEF
+    dur, w, h, asp, iasp, magic2 = struct.unpack_from("<fiiffI", raw, len(raw) - 24)
+    assert (w, h, magic2) == (96, 56, 0xDEADBEEF) and abs(asp - 96 / 56) < 1e-6 and abs(iasp - 56 / 96) < 1e-6
+    assert b"Identity()" in raw and b"depth_midas2" in raw
+    # flow_constraints.dat round trip is byte-identical
+    before = open(os.path.join(base, "flow_constraints.dat"), "rb").read()
+    fc.save()
+    assert open(os.path.join(base, "flow_constraints.dat"), "rb").read() == before
+
+
+def test_missing_inputs_raise_runtime_error(lib, tmp_path):
+    dv = lib.DepthVideo()
+    with pytest.raises(RuntimeError, match="frame file"):
+        lib.DepthVideoImporter.importVideo(dv, str(tmp_path), False)
+    v = synth.make_video(4, 48, 28, seed=52, spacing=8)
+    base = dataset_io.write_dataset(str(tmp_path / "v"), v)
+    os.remove(os.path.join(base, "flow_list.json"))
+    lib.DepthVideoImporter.importVideo(dv, base, False)
+    fcp = lib.FlowConstraintsParams()
+    fcp.frameRange.resolve(dv.numFrames(), True)
+    with pytest.raises(RuntimeError, match="Flow list file does not exist"):
+        lib.FlowConstraintsCollection(dv, fcp)
+
+
+def test_param_map_and_warp_match_the_oracle_gathers(lib, dataset):
+    """DepthXform.paramMap / SpatialXform.warp (corner-aligned sampling, reference lib/DepthMapTransform.cpp:950-994,
+    428-449) against the oracle's gather at the same locations."""
+    from oracle import oracle as orc
+    from robust_cvd_amd.ctypes_types import SpatialXformType, XformDesc
+    v, base = dataset
+    dv = lib.DepthVideo()
+    lib.DepthVideoImporter.importVideo(dv, base, False)
+    dv.createDepthStream("depth_midas2", "depth_midas2", [-1, -1])
+    ds = dv.depthStream(0)
+    d = lib.XformDescriptor()
+    d.depthType = lib.DepthXformType.Grid
+    d.valueXform = lib.ValueXformType.Scale
+    d.gridSize = [5, 4, 1]
+    ds.resetDepthXforms(d)
+    rng = np.random.default_rng(0)
+    theta = rng.uniform(0.5, 1.5, 20)
+    ds.frame(2).depthXform().setParams(theta.tolist())
+    pm = np.asarray(ds.frame(2).depthXform().paramMap(ds.frame(2)))
+    assert pm.shape == (56, 96) and pm.dtype == np.float64
+    od = XformDesc.grid_depth(5, 4)
+    for (y, x) in ((0, 0), (55, 95), (17, 40), (30, 3)):
+        lx = np.float32(-1) + np.float32(x) * (np.float32(2) / np.float32(95))
+        ly = np.float32(1) - np.float32(y) * (np.float32(2) / np.float32(55))
+        idx, w = orc.gather(od, 1.0, float(lx), float(ly))
+        assert abs(pm[y, x] - float(theta[idx] @ w)) < 1e-12
+    s = lib.XformDescriptor()
+    s.reset(lib.XformType.Spatial)
+    s.spatialType = lib.SpatialXformType.BicubicGrid
+    s.gridSize = [4, 3, 0]
+    ds.resetSpatialXforms(s)
+    phi = rng.normal(0, 0.01, 24)
+    ds.frame(1).spatialXform().setParams(phi.tolist())
+    wmap = np.asarray(ds.frame(1).spatialXform().warp(56, 96))
+    assert wmap.shape == (56, 96, 2) and wmap.dtype == np.float32
+    osd = XformDesc.spatial(SpatialXformType.BicubicGrid, 4, 3)
+    for (y, x) in ((0, 0), (55, 95), (20, 50)):
+        lx = np.float32(-1) + np.float32(x) * (np.float32(2) / np.float32(95))
+        ly = np.float32(1) - np.float32(y) * (np.float32(2) / np.float32(55))
+        idx, w = orc.gather(osd, 1.0, float(lx), float(ly))
+        exp = (phi.reshape(-1, 2)[idx] * w[:, None]).sum(0)
+        np.testing.assert_allclose(wmap[y, x], exp, atol=1e-7)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not mounted")
+def test_reference_pose_optimizer_constructor_runs_unmodified(lib, dataset, monkeypatch):
+    """The reference's own pose_optimization.PoseOptimizer.__init__ (reference pose_optimization.py:99-175) against
+    this module: only cv2 (two integer constants) is stubbed because OpenCV is not installed here."""
+    v, base = dataset
+    cv2 = types.ModuleType("cv2")
+    cv2.CV_32FC3, cv2.CV_8UC1 = 21, 0
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    monkeypatch.syspath_prepend("/root/reference")
+    sys.modules.pop("pose_optimization", None)
+    try:
+        po = importlib.import_module("pose_optimization")
+    except ImportError as e:
+        pytest.skip(f"reference helper import failed: {e}")
+    opt = types.SimpleNamespace(
+        max_iterations=1000, num_threads=12, num_steps=4, robustness=0.5, static_loss_type="ReproDisparity",
+        static_spatial_weight=1.0, static_depth_weight=1.0, smooth_loss_type="ReproDisparityLaplacian",
+        smooth_static_weight=0.0, smooth_dynamic_weight=0.0, position_regularization=0.0, scale_regularization=1.0,
+        scale_regularization_grid_size=10, deformation_regularization_initial=1.0, deformation_regularization_final=0.1,
+        adaptive_deformation_cost=0.0, spatial_deformation_regularization=1.0, graduate_deformation_regularization=False,
+        focal_regularization=1.0, coarse_to_fine=True, ctf_long=17, ctf_short=10, deferred_spatial_opt=False, dso_long=4,
+        dso_short=3, focal_long=0.3461538376301239, intr_opt="PerFrame", fix_poses=False, fix_depth_transforms=False,
+        fix_spatial_transforms=False, use_global_scale=False, dynamic_constraints="Mask", epipolar_dist_thresh=1.0)
+    p = po.PoseOptimizer(base, "midas2", list(range(v.num_frames)), opt)
+    assert p.depth_video.numFrames() == 10 and p.opt_params.ctfLong == 17
+    assert os.path.exists(os.path.join(base, "video.dat"))
+    sys.modules.pop("pose_optimization", None)
+
+
+@pytest.mark.gpu
+def test_optimize_poses_sequence_on_gpu_matches_direct_c_abi(lib, tmp_path):
+    """The reference's optimize_poses() call sequence through lib_python equals driving the C ABI directly."""
+    from robust_cvd_amd import api
+    from robust_cvd_amd.ctypes_types import OptParams, XformDesc
+    from tests.drop_in_caller import build_pose_optimizer, optimize_poses
+    v = synth.make_video(10, 96, 56, seed=53)
+    base = dataset_io.write_dataset(str(tmp_path / "video"), v)
+    frames = list(range(v.num_frames))
+    opt = lib.DepthVideoPoseOptimizer.Params()
+    opt.ctfLong, opt.ctfShort = 6, 4
+    dv, fc = build_pose_optimizer(lib, base, "midas2", frames, opt)
+    # initial FOV of the reference pipeline: createDepthStream -> resolveMissingFov defaults (no resetPoses call)
+    fov0 = [(dv.depthStream(0).frame(f).intrinsics.vFov, dv.depthStream(0).frame(f).intrinsics.hFov) for f in frames]
+    assert abs(fov0[0][0] - 0.666488587) < 1e-6
+    optimize_poses(lib, dv, fc, frames, opt)
+    ds = dv.depthStream(0)
+    assert ds.depthXformDesc().str() == "Grid(Scale, Linear, 6, 4, 1)"
+    s = api.Solver(0)
+    depth_from_disk = np.stack([np.asarray(ds.frame(f).sourceDepth()) for f in frames])
+    s.set_video(v.num_frames, v.width, v.height, dv.aspect(), dv.invAspect())
+    s.set_depth_all(depth_from_disk)
+    s.set_pair_constraints(v.pairs, v.offsets, v.loc, None)
+    s.set_poses(np.zeros((len(frames), 3)), np.tile([0, 0, 0, 1.0], (len(frames), 1)), [a for a, _ in fov0], [b for _, b in fov0])
+    p = OptParams.defaults()
+    p.ctf_long, p.ctf_short = 6, 4
+    p.set_frame_range(frames)
+    s.reset_depth_xforms(XformDesc.global_depth())
+    s.reset_spatial_xforms(XformDesc.spatial())
+    s.normalize_depth(p)
+    s.pose_optimization(p)
+    poses = s.get_poses()
+    th = s.get_xform_params()
+    for f in frames:
+        fr = ds.frame(f)
+        np.testing.assert_allclose(fr.extrinsics.position, poses["position"][f], atol=2e-6)
+        np.testing.assert_allclose(fr.extrinsics.orientation.coeffs(), poses["orientation"][f], atol=2e-6)
+        assert abs(fr.intrinsics.vFov - poses["vfov"][f]) < 1e-6
+        np.testing.assert_allclose(fr.depthXform().params(), th[f], rtol=1e-5)
+    # what loaders/video_dataset.py:update_poses reads afterwards
+    fr = ds.frame(4)
+    assert len(fr.extrinsics.right()) == 3 and np.asarray(fr.depthXform().paramMap(fr)).shape == (56, 96)
+    assert np.asarray(fr.spatialXform().warp(ds.height(), ds.width())).shape == (56, 96, 2)
+    assert os.path.getsize(os.path.join(base, "video.dat")) > 1000
