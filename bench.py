@@ -11,8 +11,11 @@ from the state the coarser levels converged to.  The convergence tests are disab
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: every rank optimizes its own 300-frame video (independent videos shard with no data-path exchange),
-so `value` = N x K iterations / max-over-ranks time ("weak" scaling, config.parallelism = "video-per-gpu").
+N > 1 (default `--mode shard`): the SAME 300-frame problem, frame pairs sharded across the ranks
+(robust_cvd_amd/sharding.py), regularisers by frame % N; the library all-reduces [g | H_ff | cost] once per
+Jacobian evaluation and q once per PCG product over RCCL.  Total work is fixed => "strong" scaling,
+`value` = K iterations / max-over-ranks time.  `--mode replicas` instead gives every rank its own video
+(no data-path exchange, "weak" scaling, value = N x K / time).
 
 The JSON line also carries
   roofline     : dominant kernel k_matvec_pairs -- algorithmic HBM bytes per launch / average launch duration
@@ -99,6 +102,7 @@ def main():
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-pairs", action="store_true", help="denser pair set (towards the ~4k pairs of BASELINE.json)")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="N > 1: pair-sharded (strong) or one video per GPU (weak)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,8 +123,20 @@ def main():
     from robust_cvd_amd.ctypes_types import OptParams
 
     params = OptParams.defaults()
-    video = synth.make_video(args.frames, WIDTH, HEIGHT, seed=SEED + rank, extra_offsets=args.extra_pairs)
+    shard = world > 1 and args.mode == "shard"
+    video = synth.make_video(args.frames, WIDTH, HEIGHT, seed=SEED + (0 if shard or world == 1 else rank),
+                             extra_offsets=args.extra_pairs)
     solver = api.Solver(local_rank)
+    full_pairs, full_constraints = len(video.pairs), video.num_constraints
+    if shard:
+        # RCCL communicator inside the library: rank 0 mints the id, torch.distributed carries the 128 bytes
+        from robust_cvd_amd import sharding
+        ids = [api.Solver.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        solver.comm_init(rank, world, ids[0])
+        mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
+        video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
+            video.pairs, video.offsets, video.loc, video.is_static, mine)
     if args.pcg_tol is not None:
         solver.set_options(pcg_relative_tolerance=args.pcg_tol)
     t_prep = time.perf_counter()
@@ -176,24 +192,24 @@ def main():
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
         out = {
             "metric": "GN/LM iterations/sec (and ms/iter) on 300-frame 384x224 video, 1/2/4/8 GPU",
-            "value": world * args.steps / dt,
+            "value": (1 if shard else world) * args.steps / dt,
             "unit": "LM iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": (f"configs[2]: {args.frames}-frame {WIDTH}x{HEIGHT} synthetic video, hierarchical2 two-way "
-                             f"flow_list ({len(video.pairs)} directed pairs, {video.num_constraints} flow constraints), "
+                             f"flow_list ({full_pairs} directed pairs, {full_constraints} flow constraints), "
                              f"full LM loop; timed = LM iterations at the final CTF level (17x10 bilinear grid, "
                              f"B={B}, {args.frames * B} unknowns), Cauchy 0.5, PerFrame intrinsics"),
-                "pairs": int(len(video.pairs)), "constraints": int(n_active), "unknowns": int(args.frames * B),
-                "parallelism": "single-gpu" if world == 1 else "video-per-gpu",
+                "pairs": int(full_pairs), "constraints": int(n_active), "unknowns": int(args.frames * B),
+                "parallelism": "single-gpu" if world == 1 else (f"pair-sharded dp{world} + RCCL all-reduce" if shard else "video-per-gpu"),
                 "linear_solver": "block-Jacobi PCG, matrix-free J^T J",
                 "pcg_iterations_per_lm_iteration": summ["total_linear_iterations"] / max(1, summ["num_iterations"]),
             },

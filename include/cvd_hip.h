@@ -48,6 +48,14 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o);
 /* Test hook: 1 = run the generic all-variants kernels even where a specialised fast kernel exists. */
 int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
 
+/* ---- multi-GPU: one process per GPU, frame pairs sharded across ranks ---------------------
+ * Every rank holds all frames (depth, parameters) but only ITS pairs (cvd_set_pair_constraints with the shard);
+ * the regularisers of frame f belong to rank f % world.  The library all-reduces [g | H_ff | cost] once per
+ * Jacobian evaluation and q once per PCG product over RCCL on its own stream.  The reference has no
+ * counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
+void cvd_comm_unique_id(uint8_t* out128);
+int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
+
 /* ---- inputs (what the reference reads through DepthVideo / DepthStream / FlowConstraintsCollection) -- */
 /* DepthVideo dims + aspect (reference lib/DepthVideo.h: numFrames(), aspect(), invAspect(); DepthStream w/h). */
 int32_t cvd_set_video(cvd_handle* h, int32_t num_frames, int32_t width, int32_t height, float aspect,

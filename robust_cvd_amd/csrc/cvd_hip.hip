@@ -13,6 +13,7 @@
 // gfx950 only. There is NO CPU path: every entry point that computes fails if no HIP device is usable.
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <array>
@@ -48,6 +49,13 @@ static std::string fmt(const char* f, ...) {
     if (e_ != hipSuccess)                                                                        \
       throw std::runtime_error(fmt("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__,    \
                                    __LINE__, hipGetErrorString(e_)));                            \
+  } while (0)
+
+#define NCCL_CHECK(expr)                                                                         \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess)                                                                       \
+      throw std::runtime_error(fmt("RCCL error %s at %s:%d", ncclGetErrorString(r_), __FILE__, __LINE__)); \
   } while (0)
 
 static double nowSeconds() {
@@ -247,7 +255,11 @@ struct cvd_handle_t {
   DevBuf<long long> dPairOff;
   DevBuf<float4> dLoc, dNdc;
   DevBuf<float2> dDsrc;
-  DevBuf<unsigned char> dStatic, dInRange;
+  DevBuf<unsigned char> dStatic, dInRange, dRegOwner;
+
+  // multi-GPU (pair-sharded): one RCCL communicator, this rank owns the regularisers of frames f % world == rank
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
   bool haveTriplets = false;
 
   // work decomposition
@@ -292,6 +304,7 @@ struct cvd_handle_t {
 
   ~cvd_handle_t() {
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -557,6 +570,11 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
   if (h->tableValid && inRange == h->tableRange) return;
   hipStream_t s = h->stream;
   h->dInRange.upload(inRange.data(), inRange.size(), s);
+  {
+    std::vector<unsigned char> owner(h->F, 0);
+    for (int f = 0; f < h->F; ++f) owner[f] = inRange[f] && (f % h->world == h->rank);
+    h->dRegOwner.upload(owner.data(), owner.size(), s);
+  }
   h->dNdc.ensure(std::max<long long>(h->C, 1));
   h->dDsrc.ensure(std::max<long long>(h->C, 1));
   h->dCount.ensure(1);
@@ -569,6 +587,7 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
                        h->dNdc.p, h->dDsrc.p, h->dCount.p);
     HIP_CHECK(hipGetLastError());
   }
+  if (h->world > 1) NCCL_CHECK(ncclAllReduce(h->dCount.p, h->dCount.p, 1, ncclUint64, ncclSum, h->comm, s));
   unsigned long long nv = 0;
   HIP_CHECK(hipMemcpyAsync(&nv, h->dCount.p, sizeof(nv), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -731,13 +750,14 @@ static double evalCost(Ctx& c, const double* x) {
     HIP_CHECK(hipGetLastError());
   }
   CVD_DISPATCH_KD(c.KD, {
-    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dInRange.p,
+    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dRegOwner.p,
                        h->dCostFrame.p);
   });
   HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
                      h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
   HIP_CHECK(hipGetLastError());
+  if (h->world > 1) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
   h->tEnd(slot);
   readScalars(c);
   return h->hScal[S_COST];
@@ -754,10 +774,18 @@ static double evalFull(Ctx& c, const double* x) {
   CVD_DISPATCH(c.KD, c.KS, {
     allowLds(k_assemble<KD, KS>, lds);
     hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                       h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
   });
   HIP_CHECK(hipGetLastError());
   h->tEnd(slot);
+  if (h->world > 1) {
+    // the exchange step of the pair-sharded mode: one all-reduce of [g | H_ff | per-frame cost] per Jacobian evaluation
+    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(ncclAllReduce(h->dG.p, h->dG.p, c.n, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclAllReduce(h->dH.p, h->dH.p, c.n * B, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclAllReduce(h->dCostFrame.p, h->dCostFrame.p, c.L.F, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclGroupEnd());
+  }
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
   hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
   HIP_CHECK(hipGetLastError());
@@ -797,10 +825,17 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
-                         h->dMedian.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
-                         h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p);
+                         h->dMedian.p, h->dRegOwner.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
+                         h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
+                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0);
     });
     HIP_CHECK(hipGetLastError());
+    if (h->world > 1) {
+      // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
+      NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
+      hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p);
+      HIP_CHECK(hipGetLastError());
+    }
     h->tEnd(slot);
   }
 }
@@ -1276,6 +1311,24 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->force_iterations = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
+void cvd_comm_unique_id(uint8_t* out128) {
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  (void)ncclGetUniqueId(&id);
+  std::memcpy(out128, &id, sizeof(id));
+}
+int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128) {
+  CVD_TRY(h, {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("invalid rank / world size");
+    if (h->comm) { NCCL_CHECK(ncclCommDestroy(h->comm)); h->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    NCCL_CHECK(ncclCommInitRank(&h->comm, world, id, rank));
+    h->rank = rank;
+    h->world = world;
+    h->tableValid = false;
+  });
+}
 int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled) { CVD_TRY(h, h->forceGeneric = enabled != 0); }
 
 int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t height, float aspect, float invAspect) {

@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ qPart, const double* __restrict__ z,
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
-                                                       int useBeta, double* __restrict__ q, double* __restrict__ fdot) {
+                                                       int useBeta, double* __restrict__ q, double* __restrict__ fdot,
+                                                       int distMode) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -669,6 +670,15 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     }
   }
   __syncthreads();
+  // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; in both cases q is
+  // all-reduced afterwards and p.q / alpha are formed by k_dot_pq on the reduced vector.
+  if (distMode) {
+    for (int i = tid; i < B; i += 256) {
+      const double pv = pNew[base + i];
+      q[base + i] = qf[i] * mask[base + i] + (distMode == 1 ? lam[base + i] * pv : 0.0);
+    }
+    return;
+  }
   double dot = 0.0;
   for (int i = tid; i < B; i += 256) {
     const double pv = pNew[base + i];
@@ -681,6 +691,28 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   __syncthreads();
   if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
   // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
+  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
+    const double pq = blockSumArray(fdot, L.F, red);
+    if (tid == 0) {
+      scal[S_PQ] = pq;
+      scal[S_ALPHA] = scal[S_RZ] / pq;
+    }
+  }
+}
+
+// p.q of the all-reduced product (multi-GPU only) + alpha, same last-workgroup pattern as k_matvec_finish.
+__global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
+                                                double* __restrict__ scal, unsigned int* __restrict__ counter,
+                                                double* __restrict__ fdot) {
+  __shared__ double red[8];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const size_t base = static_cast<size_t>(f) * L.B;
+  double dot = 0.0;
+  for (int i = tid; i < L.B; i += 256) dot += p[base + i] * q[base + i];
+  dot = waveSum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
   if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
     const double pq = blockSumArray(fdot, L.F, red);
     if (tid == 0) {

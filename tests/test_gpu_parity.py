@@ -287,6 +287,31 @@ def test_full_size_zero_noise_recovery(Solver):
     assert rerr < 3e-3 and perr < 0.05, (perr, rerr)
 
 
+def test_rccl_communicator_world_size_one(Solver):
+    """The pair-sharded code path (RCCL all-reduces of g / H_ff / cost / q on the solver stream) with a 1-rank
+    communicator must reproduce the plain single-GPU solve bit for bit.  (N > 1 needs N GPUs: the decomposition itself
+    is covered on CPU by tests/test_sharding_gloo.py.)"""
+    v = synth.make_video(8, 96, 56, seed=38)
+    out = []
+    for use_comm in (False, True):
+        s = Solver(0)
+        if use_comm:
+            s.comm_init(0, 1, Solver.comm_unique_id())
+        synth.load_into(s, v)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        s.normalize_depth(p)
+        ev = s.evaluate(p, 0.1, want_gradient=True)
+        s.pose_optimization(p)
+        out.append((ev, s.get_pose_params(), s.get_xform_params(), s.summary()))
+    assert abs(out[0][0]["cost"] - out[1][0]["cost"]) <= 1e-12 * abs(out[0][0]["cost"])
+    assert rel(out[1][0]["gradient"], out[0][0]["gradient"]) < 1e-12
+    assert abs(out[0][3]["final_cost"] - out[1][3]["final_cost"]) <= 1e-6 * abs(out[0][3]["final_cost"])
+    assert rel(out[1][2], out[0][2]) < 1e-3
+
+
 def test_unsupported_configurations_fail_loudly(Solver):
     v = synth.make_video(4, 64, 40, seed=36, spacing=9)
     s = Solver(0)
