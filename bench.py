@@ -190,6 +190,14 @@ def main():
         n_items = sum(-(-n // 768) for n in und.values())
         bytes_launch = 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
+        # HBM bytes per launch from the committed PMC run (separate rocprofv3 --pmc passes cannot run inside this
+        # process): profiles/pmc_matvec_pairs.json, FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE
+        traffic = None
+        try:
+            with open(os.path.join(_ROOT, "profiles", "pmc_matvec_pairs.json")) as fpm:
+                traffic = json.load(fpm)["traffic_bytes_per_launch"] if world == 1 and args.frames == FRAMES else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "GN/LM iterations/sec (and ms/iter) on 300-frame 384x224 video, 1/2/4/8 GPU",
             "value": (1 if shard else world) * args.steps / dt,
@@ -215,7 +223,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_launch, "avg_launch_ms": mv["avg_ms"], "launches": mv["launches"],
                 "note": "f64 VALU/latency-bound, not HBM-bound: ~24 B and ~1 kflop per constraint (DESIGN.md)",
             },

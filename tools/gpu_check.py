@@ -1,7 +1,7 @@
 """Ad-hoc GPU parity probe (development aid; the real tests live in tests/)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robust_cvd_amd import api, synth
 from robust_cvd_amd.ctypes_types import *
 from oracle.oracle import Oracle

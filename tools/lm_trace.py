@@ -1,6 +1,6 @@
 """Development aid: print the LM table (incl. PCG iterations per LM iteration) of the full pipeline."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from robust_cvd_amd import api, synth
 from robust_cvd_amd.ctypes_types import *
