@@ -280,7 +280,7 @@ struct cvd_handle_t {
   bool poseParamsValid = false;
 
   // solver buffers
-  DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dZ, dP0, dP1, dQ, dH, dQPart;
+  DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dR1, dZ, dP0, dP1, dQ, dH, dQPart;
   DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd;
   DevBuf<FrameConst> dFc;
@@ -707,11 +707,11 @@ static void ensureBuffers(Ctx& c) {
   const size_t n = c.n;
   const size_t B = c.L.B;
   h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
-  h->dDx.ensure(n); h->dR.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
+  h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
   h->dHd.ensure(n);
   h->dH.ensure(n * B); h->dMinv.ensure(n * B);
   h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(c.nItems) * 2 * B));
-  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 5);
+  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
   h->dScal.ensure(S_COUNT);
@@ -771,11 +771,22 @@ static double evalFull(Ctx& c, const double* x) {
   const size_t B = c.L.B;
   const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
   const int slot = h->tBegin(KC_ASSEMBLE);
-  CVD_DISPATCH(c.KD, c.KS, {
-    allowLds(k_assemble<KD, KS>, lds);
-    hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+  const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+  if (fast && c.KD == 4) {
+    allowLds(k_assemble_fast<4>, lds);
+    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                        h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
-  });
+  } else if (fast) {
+    allowLds(k_assemble_fast<1>, lds);
+    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+                       h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+  } else {
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_assemble<KD, KS>, lds);
+      hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+                         h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+    });
+  }
   HIP_CHECK(hipGetLastError());
   h->tEnd(slot);
   if (h->world > 1) {
@@ -849,9 +860,12 @@ static int runPcg(Ctx& c, const double* x) {
   hipStream_t s = h->stream;
   const int F = c.L.F;
   const size_t B = c.L.B;
+  if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_cg_update");
+  const int nChunks = static_cast<int>((B + 63) / 64);
+  const int nThreads = 256 * nChunks;
   double* fd = h->dFdot.p;
-  const size_t ldsU = (B + 10) * 8;
-  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
+  const size_t ldsU = (B + nThreads + 48) * 8;
+  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
   HIP_CHECK(hipGetLastError());
   readScalars(c);
@@ -866,7 +880,7 @@ static int runPcg(Ctx& c, const double* x) {
   while (k < maxIt) {
     launchMatvec(c, x, h->dZ.p, pOld, pNew, k > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(256), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
+    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
                        h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);

@@ -722,76 +722,99 @@ __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restri
   }
 }
 
-// Per frame: alpha = rz / sum(p.q); dx += alpha p; r -= alpha q; z = Minv_f r; partial r.z and r.r.
+// alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
+// partial r.z and r.r.  One workgroup per frame with 256 threads per 64-row chunk (blockDim = 256 * ceil(B/64),
+// B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
 // init != 0: dx = 0, r = -g (already masked), z = Minv r.
-__global__ __launch_bounds__(256) void k_cg_update(Layout L, int init, const double* __restrict__ g,
-                                                   const float* __restrict__ minv, const double* __restrict__ p,
-                                                   const double* __restrict__ q, double* __restrict__ scal,
-                                                   unsigned int* __restrict__ counter, double* __restrict__ dx,
-                                                   double* __restrict__ r, double* __restrict__ z,
-                                                   double* __restrict__ fdotRZ, double* __restrict__ fdotRR) {
+__global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
+                                                    const float* __restrict__ minv, const double* __restrict__ p,
+                                                    const double* __restrict__ q, double* __restrict__ scal,
+                                                    unsigned int* __restrict__ counter, double* __restrict__ dx,
+                                                    double* __restrict__ r, double* __restrict__ z,
+                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
-  double* rf = sm;
-  double* red = rf + B;
+  const int nThreads = blockDim.x;
+  double* rf = sm;                 // B
+  double* part = rf + B;           // nThreads partial row sums
+  double* red = part + nThreads;   // 2 * 16 wave partials + 10
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   const double alpha = init ? 0.0 : scal[S_ALPHA];
-  for (int i = tid; i < B; i += 256) {
+  for (int j = tid; j < B; j += nThreads) {
     double rv;
     if (init) {
-      dx[base + i] = 0.0;
-      rv = -g[base + i];
+      dx[base + j] = 0.0;
+      rv = -g[base + j];
     } else {
-      dx[base + i] += alpha * p[base + i];
-      rv = r[base + i] - alpha * q[base + i];
+      dx[base + j] += alpha * p[base + j];
+      rv = r[base + j] - alpha * q[base + j];
     }
-    r[base + i] = rv;
-    rf[i] = rv;
+    r[base + j] = rv;
+    rf[j] = rv;
   }
   __syncthreads();
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
-  // applied with f64 accumulation
+  // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
   const float* Mf = minv + static_cast<size_t>(f) * B * B;
-  double rz = 0.0, rr = 0.0;
-  for (int i = tid; i < B; i += 256) {
-    double zv0 = 0.0, zv1 = 0.0;
-    int j = 0;
-    for (; j + 1 < B; j += 2) {  // symmetric: column access, coalesced over i
-      zv0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
-      zv1 += static_cast<double>(Mf[static_cast<size_t>(j + 1) * B + i]) * rf[j + 1];
+  const int chunk = tid >> 8, row = tid & 63, seg = (tid >> 6) & 3;
+  const int i = chunk * 64 + row;
+  double acc = 0.0;
+  if (i < B) {
+    double a0 = 0.0, a1 = 0.0;
+    int j = seg;
+    for (; j + 4 < B; j += 8) {
+      a0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
+      a1 += static_cast<double>(Mf[static_cast<size_t>(j + 4) * B + i]) * rf[j + 4];
     }
-    if (j < B) zv0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
-    const double zv = zv0 + zv1;
+    if (j < B) a0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
+    acc = a0 + a1;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  double rz = 0.0, rr = 0.0;
+  if (seg == 0 && i < B) {
+    const int b0 = chunk * 256 + row;
+    const double zv = part[b0] + part[b0 + 64] + part[b0 + 128] + part[b0 + 192];
     z[base + i] = zv;
-    rz += rf[i] * zv;
-    rr += rf[i] * rf[i];
+    rz = rf[i] * zv;
+    rr = rf[i] * rf[i];
   }
   rz = waveSum(rz);
   rr = waveSum(rr);
-  if ((tid & 63) == 0) { red[tid >> 6] = rz; red[4 + (tid >> 6)] = rr; }
+  const int nWaves = nThreads >> 6;
+  if ((tid & 63) == 0) { red[tid >> 6] = rz; red[16 + (tid >> 6)] = rr; }
   __syncthreads();
   if (tid == 0) {
-    fdotRZ[f] = red[0] + red[1] + red[2] + red[3];
-    fdotRR[f] = red[4] + red[5] + red[6] + red[7];
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < nWaves; ++w) { a += red[w]; b += red[16 + w]; }
+    fdotRZ[f] = a;
+    fdotRR[f] = b;
   }
   // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
-  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 8))) {
-    const double rz = blockSumArray(fdotRZ, L.F, red);
-    const double rr = blockSumArray(fdotRR, L.F, red);
+  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 40))) {
+    double a = 0.0, b = 0.0;
+    for (int k = tid; k < L.F; k += nThreads) { a += fdotRZ[k]; b += fdotRR[k]; }
+    a = waveSum(a);
+    b = waveSum(b);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; }
+    __syncthreads();
     if (tid == 0) {
+      double rzs = 0.0, rrs = 0.0;
+      for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; }
       if (init) {
-        scal[S_RZ0] = rz;
-        scal[S_RZOLD] = rz;
+        scal[S_RZ0] = rzs;
+        scal[S_RZOLD] = rzs;
         scal[S_BETA] = 0.0;
       } else {
         const double old = scal[S_RZ];
         scal[S_RZOLD] = old;
-        scal[S_BETA] = (old != 0.0) ? rz / old : 0.0;
+        scal[S_BETA] = (old != 0.0) ? rzs / old : 0.0;
       }
-      scal[S_RZ] = rz;
-      scal[S_RR] = rr;
+      scal[S_RZ] = rzs;
+      scal[S_RR] = rrs;
     }
   }
 }
@@ -1149,6 +1172,306 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   for (int i = tid; i < B; i += 256) {
     out[i] = qa[i];
     out[B + i] = qb[i];
+  }
+}
+
+}  // namespace cvd
+
+namespace cvd {
+
+// =====================================================================================================
+// Fast path of the frame-major assembly (same scope as k_matvec_pairs_fast: identity spatial transform,
+// reprojection losses, Identity / Global / bilinear depth transform).  Only the OWN side's Jacobian is formed
+// (3x7 pose-like columns + the 3-vector d r / d D); taps are unrolled, nothing is indexed dynamically, so the
+// kernel needs neither scratch nor 256 VGPRs.  Accumulation: 7x7 + gradient in registers (wave-reduced at
+// the end), pose x grid and grid x grid through LDS f64 atomics into the packed lower triangle.
+// =====================================================================================================
+template <int KD>
+__global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
+                                                       const FrameConst* __restrict__ fc,
+                                                       const double* __restrict__ mask, const float* __restrict__ median,
+                                                       const unsigned char* __restrict__ regOwner,
+                                                       const int* __restrict__ fpOff, const int* __restrict__ fpList,
+                                                       double* __restrict__ gOut, double* __restrict__ hOut,
+                                                       double* __restrict__ costFrame) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr double eps = 1e-6;
+  const int B = L.B;
+  const int npk = B * (B + 1) / 2;
+  double* Hs = sm;
+  double* gs = Hs + npk;
+  double* xf = gs + B;
+  double* xo = xf + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(xo + B);
+  double* red = reinterpret_cast<double*>(fcs + 2);  // 4 * 36
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
+  for (int i = tid; i < B; i += 256) {
+    gs[i] = 0.0;
+    xf[i] = x[static_cast<size_t>(f) * B + i];
+  }
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (tid < FCW) reinterpret_cast<double*>(fcs)[tid] = reinterpret_cast<const double*>(fc + f)[tid];
+  __syncthreads();
+
+  double PP[28], gp[7];
+  double cost = 0.0;
+#pragma unroll
+  for (int i = 0; i < 28; ++i) PP[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) gp[i] = 0.0;
+  const int N = L.N;
+  const double A = L.aspect;
+
+  if (L.includeStatic) {
+    for (int e = fpOff[f]; e < fpOff[f + 1]; ++e) {
+      const int code = fpList[e];
+      const int p = code >> 1;
+      const int side = code & 1;  // 0: f is the source of pair p, 1: f is the target
+      const int o = side ? T.pairA[p] : T.pairB[p];
+      __syncthreads();
+      for (int i = tid; i < B; i += 256) xo[i] = x[static_cast<size_t>(o) * B + i];
+      if (tid < FCW) reinterpret_cast<double*>(fcs + 1)[tid] = reinterpret_cast<const double*>(fc + o)[tid];
+      __syncthreads();
+      const FrameConst& Fa = side ? fcs[1] : fcs[0];
+      const FrameConst& Fb = side ? fcs[0] : fcs[1];
+      const double* xa = side ? xo : xf;
+      const double* xb = side ? xf : xo;
+      const double fya = Fa.fy, fxa = Fa.fy * A;
+      const double fyb = Fb.fy;
+      const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+      for (long long c = T.pairOff[p] + tid; c < T.pairOff[p + 1]; c += 256) {
+        const float2 d = T.dsrc[c];
+        if (!(d.x > 0.f)) continue;
+        const float4 nd = T.ndc[c];
+        const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
+        FastTaps<KD> ta, tb;
+        fastGather<KD>(L, nd.x, nd.y, ta);
+        fastGather<KD>(L, nd.z, nd.w, tb);
+        double Da, Db;
+        if (N == 0) {
+          Da = da; Db = db;
+        } else {
+          Da = 0.0; Db = 0.0;
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            if (N == 2) {
+              Da += (da * xa[7 + ta.idx[k] * 2] + xa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
+              Db += (db * xb[7 + tb.idx[k] * 2] + xb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
+            } else {
+              Da += da * xa[7 + ta.idx[k]] * ta.w[k];
+              Db += db * xb[7 + tb.idx[k]] * tb.w[k];
+            }
+          }
+        }
+        const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
+        const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
+        const double ca[3] = {pax * fxa, pay * fya, -1.0};
+        const double Rca[3] = {dot3(Fa.R, ca), dot3(Fa.R + 3, ca), dot3(Fa.R + 6, ca)};
+        const double v[3] = {Fa.t[0] + Rca[0] * Da - Fb.t[0], Fa.t[1] + Rca[1] * Da - Fb.t[1],
+                             Fa.t[2] + Rca[2] * Da - Fb.t[2]};
+        const double q0 = Fb.R[0] * v[0] + Fb.R[3] * v[1] + Fb.R[6] * v[2];
+        const double q1 = Fb.R[1] * v[0] + Fb.R[4] * v[1] + Fb.R[7] * v[2];
+        const double q2 = Fb.R[2] * v[0] + Fb.R[5] * v[1] + Fb.R[8] * v[2];
+        const double zz = -q2;
+        const double iz = 1.0 / zz;
+        const double u = q0 * iz * ifxb;
+        const double vv = q1 * iz * ifyb;
+        double r[3];
+        r[0] = (u - pbx) * L.ws;
+        r[1] = (vv - pby) * L.ws;
+        double dr2dA, dr2dDb;
+        if (L.lossType == kLossDisparity) {
+          const bool zo = !(zz < eps), bo = !(Db < eps);
+          const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / (bo ? Db : eps);
+          r[2] = (izc - ibc) * L.wd;
+          dr2dA = zo ? (-L.wd * izc * izc) : 0.0;
+          dr2dDb = bo ? (L.wd * ibc * ibc) : 0.0;
+        } else {
+          const bool zIsMax = !(zz < Db), zIsMin = !(Db < zz);
+          const double mx = zIsMax ? zz : Db, mn = zIsMin ? zz : Db;
+          if (L.lossType == kLossRatio) {
+            r[2] = (mx / mn - 1.0) * L.wd;
+            const double dmx = 1.0 / mn, dmn = -mx / (mn * mn);
+            dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+            dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+          } else {
+            r[2] = log(mn / mx) * L.wd;
+            const double dmn = 1.0 / mn, dmx = -1.0 / mx;
+            dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+            dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+          }
+        }
+        const double sum = 1.0 + (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * L.cauchyC;
+        const double w = 1.0 / sum;  // rho'
+        if (!side) cost += L.cauchyB * log(sum);
+
+        // d r / d q (rows): M0 = (m00, 0, m02), M1 = (0, m11, m12), M2 = (0, 0, m22)
+        const double wiz = L.ws * iz;
+        const double m00 = wiz * ifxb, m11 = wiz * ifyb, m02 = wiz * u, m12 = wiz * vv, m22 = -dr2dA;
+        double Jp[3][7];
+        double JD[3];
+        const FastTaps<KD>& tm = side ? tb : ta;
+        const double dm = side ? db : da;
+        if (!side) {
+          // G = M R_b^T ; columns: t -> G, w_i -> G (D_a dR_a,i c_a), fy -> G (D_a R_a cf), D -> G R c_a
+          double G[3][3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            G[0][i] = m00 * Fb.R[i * 3 + 0] + m02 * Fb.R[i * 3 + 2];
+            G[1][i] = m11 * Fb.R[i * 3 + 1] + m12 * Fb.R[i * 3 + 2];
+            G[2][i] = m22 * Fb.R[i * 3 + 2];
+          }
+          const double cf[3] = {pax * A, pay, 0.0};
+          const double dXdf[3] = {Da * (Fa.R[0] * cf[0] + Fa.R[1] * cf[1]), Da * (Fa.R[3] * cf[0] + Fa.R[4] * cf[1]),
+                                  Da * (Fa.R[6] * cf[0] + Fa.R[7] * cf[1])};
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            Jp[rr][0] = G[rr][0]; Jp[rr][1] = G[rr][1]; Jp[rr][2] = G[rr][2];
+            Jp[rr][6] = dot3(G[rr], dXdf);
+            JD[rr] = dot3(G[rr], Rca);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double dX[3] = {Da * dot3(Fa.dR[i], ca), Da * dot3(Fa.dR[i] + 3, ca), Da * dot3(Fa.dR[i] + 6, ca)};
+            Jp[0][3 + i] = dot3(G[0], dX);
+            Jp[1][3 + i] = dot3(G[1], dX);
+            Jp[2][3 + i] = dot3(G[2], dX);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            Jp[0][i] = -(m00 * Fb.R[i * 3 + 0] + m02 * Fb.R[i * 3 + 2]);
+            Jp[1][i] = -(m11 * Fb.R[i * 3 + 1] + m12 * Fb.R[i * 3 + 2]);
+            Jp[2][i] = -(m22 * Fb.R[i * 3 + 2]);
+            const double* D = Fb.dR[i];  // d q / d w_b,i = dR_b,i^T v
+            const double dq0 = D[0] * v[0] + D[3] * v[1] + D[6] * v[2];
+            const double dq1 = D[1] * v[0] + D[4] * v[1] + D[7] * v[2];
+            const double dq2 = D[2] * v[0] + D[5] * v[1] + D[8] * v[2];
+            Jp[0][3 + i] = m00 * dq0 + m02 * dq2;
+            Jp[1][3 + i] = m11 * dq1 + m12 * dq2;
+            Jp[2][3 + i] = m22 * dq2;
+          }
+          Jp[0][6] = -L.ws * u * ifyb;
+          Jp[1][6] = -L.ws * vv * ifyb;
+          Jp[2][6] = 0.0;
+          JD[0] = 0.0; JD[1] = 0.0; JD[2] = dr2dDb;
+        }
+        // ---- accumulate
+        int qi = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          gp[i] += w * (Jp[0][i] * r[0] + Jp[1][i] * r[1] + Jp[2][i] * r[2]);
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            PP[qi] += w * (Jp[0][i] * Jp[0][j] + Jp[1][i] * Jp[1][j] + Jp[2][i] * Jp[2][j]);
+            ++qi;
+          }
+        }
+        if (N > 0) {
+          double v7[7];
+#pragma unroll
+          for (int i = 0; i < 7; ++i) v7[i] = w * (Jp[0][i] * JD[0] + Jp[1][i] * JD[1] + Jp[2][i] * JD[2]);
+          const double sDD = w * (JD[0] * JD[0] + JD[1] * JD[1] + JD[2] * JD[2]);
+          const double sDr = w * (JD[0] * r[0] + JD[1] * r[1] + JD[2] * r[2]);
+          // tap column factors: value params (d/d theta_k[0] = w_k d, d/d theta_k[1] = w_k)
+          double fac[KD * 2];
+          int col[KD * 2];
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            if (N == 2) {
+              col[2 * k] = 7 + tm.idx[k] * 2;     fac[2 * k] = tm.w[k] * dm;
+              col[2 * k + 1] = col[2 * k] + 1;    fac[2 * k + 1] = tm.w[k];
+            } else {
+              col[k] = 7 + tm.idx[k];             fac[k] = tm.w[k] * dm;
+            }
+          }
+          const int nt = (N == 2) ? 2 * KD : KD;
+#pragma unroll
+          for (int a = 0; a < KD * 2; ++a) {
+            if (a < nt) {
+              const int ct = col[a];
+              const int rowBase = ct * (ct + 1) / 2;
+              atomicAdd(&gs[ct], sDr * fac[a]);
+#pragma unroll
+              for (int i = 0; i < 7; ++i) atomicAdd(&Hs[rowBase + i], v7[i] * fac[a]);
+#pragma unroll
+              for (int b = 0; b < KD * 2; ++b) {
+                if (b <= a) {
+                  const int c2 = col[b];
+                  const int hi = ct > c2 ? ct : c2, lo = ct > c2 ? c2 : ct;
+                  atomicAdd(&Hs[packedIdx(hi, lo)], sDD * fac[a] * fac[b]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+#pragma unroll
+    for (int i = 0; i < 28; ++i) PP[i] = waveSum(PP[i]);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gp[i] = waveSum(gp[i]);
+    cost = waveSum(cost);
+    const int wv = tid >> 6;
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < 28; ++i) red[wv * 36 + i] = PP[i];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) red[wv * 36 + 28 + i] = gp[i];
+      red[wv * 36 + 35] = cost;
+    }
+  }
+  __syncthreads();
+  if (tid < 28) {
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= tid) ++i;
+    const int j = tid - i * (i + 1) / 2;
+    Hs[packedIdx(i, j)] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+  } else if (tid < 35) {
+    gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+  }
+  __syncthreads();
+  const double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
+  __syncthreads();
+
+  double regCost = 0.0;
+  if (regOwner[f]) {
+    const int nr = numRegResiduals<KD>(L);
+    for (int i = tid; i < nr; i += 256) {
+      double r;
+      int n;
+      int cols[2 * KD + 2];
+      double jac[2 * KD + 2];
+      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      regCost += r * r;
+      for (int a = 0; a < n; ++a) {
+        atomicAdd(&gs[cols[a]], jac[a] * r);
+        for (int b = 0; b <= a; ++b) {
+          const int hi = cols[a] > cols[b] ? cols[a] : cols[b];
+          const int lo = cols[a] > cols[b] ? cols[b] : cols[a];
+          atomicAdd(&Hs[packedIdx(hi, lo)], jac[a] * jac[b]);
+        }
+      }
+    }
+  }
+  regCost = waveSum(regCost);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = regCost;
+  __syncthreads();
+  if (tid == 0) costFrame[f] = staticCost + 0.5 * (red[0] + red[1] + red[2] + red[3]);
+
+  const double* mf = mask + static_cast<size_t>(f) * B;
+  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
+  double* hf = hOut + static_cast<size_t>(f) * B * B;
+  for (int idx = tid; idx < B * B; idx += 256) {
+    const int i = idx / B, j = idx - i * B;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
   }
 }
 
