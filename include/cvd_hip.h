@@ -88,6 +88,7 @@ int32_t cvd_get_xform_params(cvd_handle* h, int32_t spatial, double* out /* [F x
 int32_t cvd_set_xform_params(cvd_handle* h, int32_t spatial, const double* in /* [F x numParams] */);
 /* Internal 7-tuples (t, angle-axis, tan(vFov/2)) of reference lib/PoseOptimizer.h:149, [F x 7] doubles. */
 int32_t cvd_get_pose_params(cvd_handle* h, double* pose7);
+int32_t cvd_set_pose_params(cvd_handle* h, const double* pose7); /* continue a solve from saved tuples */
 int32_t cvd_block_size(cvd_handle* h); /* unknowns per frame: 7 + depth params + spatial params */
 
 /* ---- the path --------------------------------------------------------------------------------------- */
@@ -115,7 +116,8 @@ int32_t cvd_get_records(cvd_handle* h, cvd_iteration_record* out);
  * solver's own stream: fills {evaluate_assemble, matvec_pairs, matvec_finish, cg_update, block_inverse,
  * cost} and their launch counts. */
 int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6);
-/* Enable / disable per-launch event timing (costs a sync per launch; off by default). */
+/* Per-launch HIP-event timing: 0 = off (default), 1 = every class, otherwise a bit mask (bit k = class k in the
+ * order of cvd_get_kernel_times). Two event records per timed launch. */
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
 /* Number of (valid static) constraints in the compiled table of the last solve. */
 int64_t cvd_num_active_constraints(cvd_handle* h);

@@ -2104,6 +2104,14 @@ int cvdo_get_pose_params(void* h, double* pose7) {
       for (int i = 0; i < 7; ++i) pose7[f * 7 + i] = o->poseParams[f][i];
   });
 }
+int cvdo_set_pose_params(void* h, const double* pose7) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    o->poseParams.resize(o->F);
+    for (int f = 0; f < o->F; ++f)
+      for (int i = 0; i < 7; ++i) o->poseParams[f][i] = pose7[f * 7 + i];
+  });
+}
 int cvdo_block_size(void* h) { return static_cast<Oracle*>(h)->B(); }
 int cvdo_evaluate(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, double* cost,
                   int* numResidualBlocks, double* gradient, double* hdiag, double* hfull) {

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "cvd_set_pair_constraints", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
-    "cvd_get_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
+    "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
     "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints",
 ]
@@ -95,8 +95,16 @@ class Solver(Binding):
     def set_generic_kernels(self, enabled=True):
         self._check(self._fn("set_generic_kernels")(self._h, C.c_int32(int(enabled))))
 
-    def set_kernel_timing(self, enabled=True):
-        self._check(self._fn("set_kernel_timing")(self._h, C.c_int32(int(enabled))))
+    def set_kernel_timing(self, enabled=True, classes=None):
+        """enabled=True times every kernel class; classes=[names] only those (see KERNEL_CLASSES)."""
+        mask = int(bool(enabled))
+        if classes is not None:
+            mask = 0
+            for c in classes:
+                mask |= 1 << KERNEL_CLASSES.index(c)
+            if mask == 1:
+                mask |= 1 << 6  # keep it a mask (bit 0 alone would read as 'all')
+        self._check(self._fn("set_kernel_timing")(self._h, C.c_int32(mask)))
 
     def kernel_times(self):
         ms = (C.c_double * 6)()

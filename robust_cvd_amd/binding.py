@@ -164,6 +164,10 @@ class Binding:
         self._check(self._fn("get_pose_params")(self._h, _ptr(out, C.c_double)))
         return out
 
+    def set_pose_params(self, pose7):
+        v = _f64(pose7).reshape(self.num_frames, 7)
+        self._check(self._fn("set_pose_params")(self._h, _ptr(v, C.c_double)))
+
     def block_size(self):
         return int(self._fn("block_size")(self._h))
 

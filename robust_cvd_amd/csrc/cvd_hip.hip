@@ -295,7 +295,7 @@ struct cvd_handle_t {
   bool forceGeneric = false;  // test hook: route the products through the generic (all-variants) kernel
 
   // kernel timing
-  bool timing = false;
+  int timing = 0;  // bit mask of KernelClass values to time with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
   std::vector<int> evClass;
   size_t evUsed = 0;
@@ -315,7 +315,7 @@ struct cvd_handle_t {
 
   // ---- timing helpers --------------------------------------------------------------------------------
   int tBegin(int kc) {
-    if (!timing) return -1;
+    if (!(timing & (1 << kc))) return -1;
     if (evUsed == evPool.size()) {
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a));
@@ -558,9 +558,15 @@ template <typename K>
 static void allowLds(K kernel, size_t bytes) {
   if (bytes > kMaxLds)
     throw std::runtime_error(fmt("per-frame block needs %zu B of LDS (> 160 KiB): frame block too large", bytes));
-  if (bytes > 48 * 1024)
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(bytes)));
+  if (bytes > 48 * 1024) {
+    static std::map<const void*, size_t> granted;  // one driver call per kernel and high-water mark, not per launch
+    size_t& g = granted[reinterpret_cast<const void*>(kernel)];
+    if (bytes > g) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(bytes)));
+      g = bytes;
+    }
+  }
 }
 
 // ---- compile the constraint table + work decomposition for a frame range -------------------------------
@@ -993,7 +999,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         const size_t lds = (B * (B + 1) / 2 + B) * 8;
         allowLds(k_block_inverse, lds);
         const int slot = h->tBegin(KC_INVERSE);
-        hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(256), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
+        hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(std::min<int>(1024, ((4 * static_cast<int>(B) + 63) / 64) * 64)), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
                            static_cast<double*>(nullptr), h->dFail.p);
         HIP_CHECK(hipGetLastError());
         h->tEnd(slot);
@@ -1488,6 +1494,14 @@ int32_t cvd_get_pose_params(cvd_handle* h, double* pose7) {
       for (int i = 0; i < 7; ++i) pose7[f * 7 + i] = h->poseParams[f][i];
   });
 }
+int32_t cvd_set_pose_params(cvd_handle* h, const double* pose7) {
+  CVD_TRY(h, {
+    h->poseParams.resize(h->F);
+    for (int f = 0; f < h->F; ++f)
+      for (int i = 0; i < 7; ++i) h->poseParams[f][i] = pose7[f * 7 + i];
+    h->poseParamsValid = true;
+  });
+}
 int32_t cvd_block_size(cvd_handle* h) {
   if (!h) return 0;
   try { return h->Bsz(); } catch (...) { return 0; }
@@ -1521,7 +1535,7 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avgMs6, int64_t* launches6) 
 }
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
   CVD_TRY(h, {
-    h->timing = enabled != 0;
+    h->timing = enabled == 1 ? 0x3f : enabled;  // 1 = all classes, otherwise a bit mask (bit k = class k)
     for (int k = 0; k < KC_COUNT; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }
   });
 }

@@ -410,44 +410,49 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, doub
 // the packed lower triangle in LDS, L^-1 by column-parallel forward substitution (global scratch,
 // L2-resident), Minv = L^-T L^-1.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
-                                                       const double* __restrict__ lam, float* __restrict__ minv,
-                                                       double* __restrict__ work, int* __restrict__ fail) {
+__global__ __launch_bounds__(1024) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
+                                                        const double* __restrict__ lam, float* __restrict__ minv,
+                                                        double* __restrict__ work, int* __restrict__ fail) {
   // Everything stays in LDS (packed lower triangle A, B(B+1)/2 doubles + one column buffer):
-  //   1. left-looking Cholesky, thread per row (dot of two packed rows; row j is a broadcast read)
+  //   1. left-looking Cholesky: 4 lanes per row split the dot of two packed rows (quad shuffle reduce)
   //   2. X = L^-1 in place, right-to-left by columns: X[i][j] = -(sum_{k=j+1..i} X[i][k] L[k][j]) / L[j][j]
-  //   3. Minv = X^T X written once to global (dense, symmetric).
+  //   3. Minv = X^T X written once to global as f32 (dense, symmetric).
+  // blockDim = 4 * B rounded up to a wave multiple (<= 1024).
   extern __shared__ __attribute__((aligned(16))) double sm[];
   (void)work;
   const int B = L.B;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
+  const int nT = blockDim.x;
   const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
   const int npk = B * (B + 1) / 2;
   double* A = sm;         // packed lower, row-major: (i, j) at i(i+1)/2 + j
   double* col = A + npk;  // B
-  for (int i = tid; i < B; i += 256) {
-    const int rb = i * (i + 1) / 2;
-    for (int j = 0; j <= i; ++j) A[rb + j] = hf[static_cast<size_t>(i) * B + j];
-    A[rb + i] += lam[static_cast<size_t>(f) * B + i];
+  for (int idx = tid; idx < B * B; idx += nT) {
+    const int i = idx / B, j = idx - i * B;
+    if (j <= i) A[i * (i + 1) / 2 + j] = hf[idx] + (i == j ? lam[static_cast<size_t>(f) * B + i] : 0.0);
   }
   __syncthreads();
+  const int row = tid >> 2, ln = tid & 3;
   // 1. Cholesky (column j finalised per step)
   for (int j = 0; j < B; ++j) {
     const int rj = j * (j + 1) / 2;
-    for (int i = j + tid; i < B; i += 256) {
+    const int i = j + row;
+    double s = 0.0;
+    if (i < B) {
       const int ri = i * (i + 1) / 2;
-      double s0 = A[ri + j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = 0;
-      for (; k + 4 <= j; k += 4) {  // independent partial sums: keeps several LDS reads in flight
-        s0 -= A[ri + k] * A[rj + k];
-        s1 -= A[ri + k + 1] * A[rj + k + 1];
-        s2 -= A[ri + k + 2] * A[rj + k + 2];
-        s3 -= A[ri + k + 3] * A[rj + k + 3];
+      double s0 = 0.0, s1 = 0.0;
+      int k = ln;
+      for (; k + 4 < j; k += 8) {
+        s0 += A[ri + k] * A[rj + k];
+        s1 += A[ri + k + 4] * A[rj + k + 4];
       }
-      for (; k < j; ++k) s0 -= A[ri + k] * A[rj + k];
-      col[i] = (s0 + s1) + (s2 + s3);  // un-normalised column j (col[j] = pivot^2)
+      if (k < j) s0 += A[ri + k] * A[rj + k];
+      s = s0 + s1;
     }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (i < B && ln == 0) col[i] = A[i * (i + 1) / 2 + j] - s;  // un-normalised column j (col[j] = pivot^2)
     __syncthreads();
     double d = col[j];
     if (!(d > 0.0)) {
@@ -456,36 +461,36 @@ __global__ __launch_bounds__(256) void k_block_inverse(Layout L, const double* _
     }
     d = sqrt(d);
     const double id = 1.0 / d;
-    for (int i = j + tid; i < B; i += 256) A[i * (i + 1) / 2 + j] = (i == j) ? d : col[i] * id;
+    for (int ii = j + tid; ii < B; ii += nT) A[ii * (ii + 1) / 2 + j] = (ii == j) ? d : col[ii] * id;
     __syncthreads();
   }
   // 2. in-place inverse of L
   for (int j = B - 1; j >= 0; --j) {
-    for (int k = j + tid; k < B; k += 256) col[k] = A[k * (k + 1) / 2 + j];
+    for (int k = j + tid; k < B; k += nT) col[k] = A[k * (k + 1) / 2 + j];
     __syncthreads();
     const double ijj = 1.0 / col[j];
-    for (int i = j + tid; i < B; i += 256) {
+    const int i = j + row;
+    double s = 0.0;
+    if (i < B && i > j) {
       const int ri = i * (i + 1) / 2;
-      if (i == j) {
-        A[ri + j] = ijj;
-      } else {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int k = j + 1;
-        for (; k + 3 <= i; k += 4) {
-          s0 += A[ri + k] * col[k];
-          s1 += A[ri + k + 1] * col[k + 1];
-          s2 += A[ri + k + 2] * col[k + 2];
-          s3 += A[ri + k + 3] * col[k + 3];
-        }
-        for (; k <= i; ++k) s0 += A[ri + k] * col[k];
-        A[ri + j] = -((s0 + s1) + (s2 + s3)) * ijj;
+      double s0 = 0.0, s1 = 0.0;
+      int k = j + 1 + ln;
+      for (; k + 4 <= i; k += 8) {
+        s0 += A[ri + k] * col[k];
+        s1 += A[ri + k + 4] * col[k + 4];
       }
+      if (k <= i) s0 += A[ri + k] * col[k];
+      s = s0 + s1;
     }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    __syncthreads();  // every read of column j (through col) and of row entries is done before the overwrite
+    if (i < B && ln == 0) A[i * (i + 1) / 2 + j] = (i == j) ? ijj : -s * ijj;
     __syncthreads();
   }
   // 3. Minv = X^T X
   float* Mf = minv + static_cast<size_t>(f) * B * B;
-  for (int idx = tid; idx < npk; idx += 256) {
+  for (int idx = tid; idx < npk; idx += nT) {
     int hi = static_cast<int>((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
     while ((hi + 1) * (hi + 2) / 2 <= idx) ++hi;
     while (hi * (hi + 1) / 2 > idx) --hi;
