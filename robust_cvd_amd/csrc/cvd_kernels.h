@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
 #pragma unroll
   for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
   double aFa = 0.0, aFb = 0.0;
+  double gDa[2] = {0.0, 0.0}, gDb[2] = {0.0, 0.0};  // KD == 1: every sample hits the one depth block -> registers
 
   for (long long c = cb + tid; c < ce; c += 256) {
     const float2 d = T.dsrc[c];
@@ -1115,6 +1116,10 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     if (N > 0) {
       const double ga = Rca[0] * yX[0] + Rca[1] * yX[1] + Rca[2] * yX[2];
       const double gb = dr2dDb * t2;
+      if constexpr (KD == 1) {
+        gDa[0] += ga * da; gDa[1] += ga;
+        gDb[0] += gb * db; gDb[1] += gb;
+      } else {
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
         if (N == 2) {
@@ -1126,6 +1131,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
           atomicAdd(&qa[7 + ta.idx[k]], ga * ta.w[k] * da);
           atomicAdd(&qb[7 + tb.idx[k]], gb * tb.w[k] * db);
         }
+      }
       }
     }
   }
@@ -1143,6 +1149,18 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     for (int i = 0; i < 23; ++i) {
       const double s = waveSum(vals[i]);
       if ((tid & 63) == 0) red[wv * 24 + i] = s;
+    }
+    if constexpr (KD == 1) {
+      if (N > 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const double sa = waveSum(gDa[n]), sb = waveSum(gDb[n]);
+          if ((tid & 63) == 0 && n < N) {
+            atomicAdd(&qa[7 + n], sa);
+            atomicAdd(&qb[7 + n], sb);
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -1221,6 +1239,11 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   __syncthreads();
 
   double PP[28], gp[7];
+  // KD == 1 (Global / Identity): the single depth block is hit by every sample -> register accumulators
+  // [0..13] pose x theta (7 x N), [14..16] theta x theta (lower), [17..18] gradient
+  double GD[19];
+#pragma unroll
+  for (int i = 0; i < 19; ++i) GD[i] = 0.0;
   double cost = 0.0;
 #pragma unroll
   for (int i = 0; i < 28; ++i) PP[i] = 0.0;
@@ -1393,6 +1416,18 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
             }
           }
           const int nt = (N == 2) ? 2 * KD : KD;
+          if constexpr (KD == 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              if (a < nt) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) GD[a * 7 + i] += v7[i] * fac[a];
+                GD[17 + a] += sDr * fac[a];
+              }
+            }
+            GD[14] += sDD * fac[0] * fac[0];
+            if (N == 2) { GD[15] += sDD * fac[1] * fac[0]; GD[16] += sDD * fac[1] * fac[1]; }
+          } else {
 #pragma unroll
           for (int a = 0; a < KD * 2; ++a) {
             if (a < nt) {
@@ -1411,6 +1446,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
               }
             }
           }
+          }
         }
       }
     }
@@ -1422,6 +1458,21 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
 #pragma unroll
     for (int i = 0; i < 7; ++i) gp[i] = waveSum(gp[i]);
     cost = waveSum(cost);
+    if constexpr (KD == 1) {
+      if (N > 0) {
+#pragma unroll
+        for (int i = 0; i < 19; ++i) GD[i] = waveSum(GD[i]);
+        if ((tid & 63) == 0) {
+          for (int a = 0; a < N; ++a) {
+            const int ct = 7 + a;
+            for (int i = 0; i < 7; ++i) atomicAdd(&Hs[ct * (ct + 1) / 2 + i], GD[a * 7 + i]);
+            atomicAdd(&gs[ct], GD[17 + a]);
+          }
+          atomicAdd(&Hs[packedIdx(7, 7)], GD[14]);
+          if (N == 2) { atomicAdd(&Hs[packedIdx(8, 7)], GD[15]); atomicAdd(&Hs[packedIdx(8, 8)], GD[16]); }
+        }
+      }
+    }
     const int wv = tid >> 6;
     if ((tid & 63) == 0) {
 #pragma unroll
