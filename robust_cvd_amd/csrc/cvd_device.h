@@ -43,6 +43,10 @@ struct Layout {
   double depthDeformW;   // plain multiplier (no loss function)
   double spatialDeformW; // plain multiplier
   int includeStatic;     // 0 for normalizeDepth's default problem
+  // position regulariser t_k - 2 t_{k+1} + t_{k+2} (reference lib/PoseOptimizer.cpp:1417-1447)
+  double positionRegSqrt;  // sqrt(positionReg), 0 => off
+  int firstFrame, lastFrame;
+  int rank, world;         // residual k of a per-frame / per-triple regulariser belongs to rank k % world
 };
 
 // cvd enums duplicated as plain ints to keep this header free of host headers.
@@ -626,6 +630,39 @@ __device__ __forceinline__ void regResidual(const Layout& L, int i, const double
     n = 1;
     cols[0] = 7 + L.nD + i;
     jac[0] = L.spatialDeformW;
+  }
+}
+
+// Position regulariser (reference lib/PoseOptimizer.cpp:464-483, 1417-1447): residual k couples the translations
+// of frames k, k+1, k+2 with coefficients (1, -2, 1) * sqrt(positionReg); it exists for
+// firstFrame <= k < lastFrame - 1 when the three frames are in range (loop bound of :1420-1426).
+__device__ __forceinline__ bool posRegValid(const Layout& L, const unsigned char* __restrict__ inRange, int k) {
+  return L.positionRegSqrt > 0.0 && k >= L.firstFrame && k < L.lastFrame - 1 && k >= 0 && k + 2 < L.F &&
+         inRange[k] && inRange[k + 1] && inRange[k + 2] && (k % L.world) == L.rank;
+}
+// Contribution of every position residual that touches frame g to (cost of residual g, gradient / diagonal /
+// product rows of frame g's translation).  v = per-frame vectors with stride B (x for residuals, p for products).
+// out3 += w * c_o * (v_k - 2 v_{k+1} + v_{k+2}),  diag += w * c_o^2
+__device__ __forceinline__ void posRegFrame(const Layout& L, const unsigned char* __restrict__ inRange, int g,
+                                            const double* __restrict__ v, const double* __restrict__ vmask,
+                                            double out3[3], double& diag, double& costOwn) {
+  const double w = L.positionRegSqrt * L.positionRegSqrt;
+  const double cf[3] = {1.0, -2.0, 1.0};
+  for (int o = 0; o < 3; ++o) {
+    const int k = g - o;
+    if (k < 0 || !posRegValid(L, inRange, k)) continue;
+    double r[3];
+    for (int i = 0; i < 3; ++i) {
+      double a = 0.0;
+      for (int j = 0; j < 3; ++j) {
+        const size_t idx = static_cast<size_t>(k + j) * L.B + i;
+        a += cf[j] * v[idx] * (vmask ? vmask[idx] : 1.0);
+      }
+      r[i] = a;
+      out3[i] += w * cf[o] * a;
+    }
+    diag += w * cf[o] * cf[o];
+    if (o == 0) costOwn += w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   }
 }
 

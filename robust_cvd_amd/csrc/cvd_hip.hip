@@ -468,8 +468,6 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
     throw std::runtime_error("IntrinsicsOptimization::Shared is not implemented on the device path yet.");
   if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP)
     throw std::runtime_error("Scene-flow smoothness (triplet) loss is not implemented on the device path yet.");
-  if (p.position_reg > 0.0 && kind == PK_POSE_STEP)
-    throw std::runtime_error("Position regularisation is not implemented on the device path yet.");
   Layout L{};
   L.F = h->F;
   L.B = h->Bsz();
@@ -517,6 +515,14 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
     L.focalRegSqrt = 0.0;
     L.depthDeformW = p.depth_deform_reg_initial > 0.0 ? p.depth_deform_reg_initial : 0.0;
     L.spatialDeformW = 0.0;
+  }
+  {
+    const std::vector<int> rg = rangeOf(p, h->F);
+    L.firstFrame = rg.empty() ? 0 : rg.front();
+    L.lastFrame = rg.empty() ? 0 : rg.back();
+    L.positionRegSqrt = (kind == PK_POSE_STEP && p.position_reg > 0.0) ? std::sqrt(p.position_reg) : 0.0;
+    L.rank = h->rank;
+    L.world = h->world;
   }
   if (L.scaleRegSqrt > 0.0 && (L.sregX < 2 || L.sregY < 2))
     throw std::runtime_error("scaleRegGridSize too small for this aspect ratio.");
@@ -756,7 +762,7 @@ static double evalCost(Ctx& c, const double* x) {
     HIP_CHECK(hipGetLastError());
   }
   CVD_DISPATCH_KD(c.KD, {
-    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dRegOwner.p,
+    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dRegOwner.p, h->dInRange.p,
                        h->dCostFrame.p);
   });
   HIP_CHECK(hipGetLastError());
@@ -781,16 +787,16 @@ static double evalFull(Ctx& c, const double* x) {
   if (fast && c.KD == 4) {
     allowLds(k_assemble_fast<4>, lds);
     hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
   } else if (fast) {
     allowLds(k_assemble_fast<1>, lds);
     hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
   } else {
     CVD_DISPATCH(c.KD, c.KS, {
       allowLds(k_assemble<KD, KS>, lds);
       hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                         h->dMedian.p, h->dRegOwner.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
     });
   }
   HIP_CHECK(hipGetLastError());
@@ -842,7 +848,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
-                         h->dMedian.p, h->dRegOwner.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
                          h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0);
     });
@@ -937,6 +943,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
     if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
     if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+    if (c.L.positionRegSqrt > 0.0)
+      for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
+        regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
   }
   sum.num_residual_blocks = static_cast<int>((c.L.includeStatic ? h->numValid : 0) + regBlocks);
 
@@ -1226,6 +1235,9 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
     if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
     if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
     if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+    if (c.L.positionRegSqrt > 0.0)
+      for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
+        regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
     *nres = static_cast<int32_t>(h->numValid + regBlocks);
   }
   if (gradient) h->dG.download(gradient, c.n, s);

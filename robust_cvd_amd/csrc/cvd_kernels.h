@@ -177,9 +177,15 @@ template <int KD>
 __global__ __launch_bounds__(64) void k_cost_frames(Layout L, const double* __restrict__ x,
                                                     const float* __restrict__ median,
                                                     const unsigned char* __restrict__ inRange,
+                                                    const unsigned char* __restrict__ rangeFlags,
                                                     double* __restrict__ costFrame) {
   const int f = blockIdx.x;
   double acc = 0.0;
+  if (threadIdx.x == 0 && L.positionRegSqrt > 0.0) {
+    double o3[3] = {0, 0, 0}, dg = 0.0, cst = 0.0;
+    if (posRegValid(L, rangeFlags, f)) posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
+    acc += cst;
+  }
   if (inRange[f]) {
     const double* xf = x + static_cast<size_t>(f) * L.B;
     const int nr = numRegResiduals<KD>(L);
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
                                                   const FrameConst* __restrict__ fc, const double* __restrict__ mask,
                                                   const float* __restrict__ median,
                                                   const unsigned char* __restrict__ inRange,
+                                                  const unsigned char* __restrict__ rangeFlags,
                                                   const int* __restrict__ fpOff, const int* __restrict__ fpList,
                                                   double* __restrict__ gOut, double* __restrict__ hOut,
                                                   double* __restrict__ costFrame) {
@@ -364,6 +371,15 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
         }
       }
     }
+  }
+  if (tid == 0 && L.positionRegSqrt > 0.0) {
+    double o3[3] = {0, 0, 0}, dg = 0.0, cst = 0.0;
+    posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
+    for (int i = 0; i < 3; ++i) {
+      atomicAdd(&gs[i], o3[i]);
+      atomicAdd(&Hs[packedIdx(i, i)], dg);
+    }
+    regCost += cst;
   }
   regCost = waveSum(regCost);
   __syncthreads();
@@ -630,6 +646,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ mask,
                                                        const double* __restrict__ lam, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ inRange,
+                                                       const unsigned char* __restrict__ rangeFlags,
                                                        const int* __restrict__ fiOff, const int* __restrict__ fiList,
                                                        const double* __restrict__ qPart, const double* __restrict__ z,
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
@@ -673,6 +690,23 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
       for (int a = 0; a < n; ++a) t += jac[a] * pf[cols[a]];
       for (int a = 0; a < n; ++a) atomicAdd(&qf[cols[a]], jac[a] * t);
     }
+  }
+  if (L.positionRegSqrt > 0.0 && tid < 3) {
+    // neighbours' directions are re-formed from z / p_old (their pNew rows are being written concurrently)
+    const double w = L.positionRegSqrt * L.positionRegSqrt;
+    const double cf[3] = {1.0, -2.0, 1.0};
+    double acc = 0.0;
+    for (int o = 0; o < 3; ++o) {
+      const int k = f - o;
+      if (k < 0 || !posRegValid(L, rangeFlags, k)) continue;
+      double a = 0.0;
+      for (int j = 0; j < 3; ++j) {
+        const size_t idx = static_cast<size_t>(k + j) * B + tid;
+        a += cf[j] * (z[idx] + (useBeta ? beta * pOld[idx] : 0.0)) * mask[idx];
+      }
+      acc += w * cf[o] * a;
+    }
+    atomicAdd(&qf[tid], acc);
   }
   __syncthreads();
   // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; in both cases q is
@@ -1214,6 +1248,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ regOwner,
+                                                       const unsigned char* __restrict__ rangeFlags,
                                                        const int* __restrict__ fpOff, const int* __restrict__ fpList,
                                                        double* __restrict__ gOut, double* __restrict__ hOut,
                                                        double* __restrict__ costFrame) {
@@ -1514,6 +1549,15 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
         }
       }
     }
+  }
+  if (tid == 0 && L.positionRegSqrt > 0.0) {
+    double o3[3] = {0, 0, 0}, dg = 0.0, cst = 0.0;
+    posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
+    for (int i = 0; i < 3; ++i) {
+      atomicAdd(&gs[i], o3[i]);
+      atomicAdd(&Hs[packedIdx(i, i)], dg);
+    }
+    regCost += cst;
   }
   regCost = waveSum(regCost);
   __syncthreads();

@@ -176,6 +176,50 @@ def test_fixed_blocks(Solver):
         assert rel(res["hip"]["hdiag"], res["oracle"]["hdiag"]) < TOL
 
 
+def test_position_regularisation(Solver):
+    """ParameterRegularizationCost t_f - 2 t_{f+1} + t_{f+2} (reference lib/PoseOptimizer.cpp:464-483, 1417-1447),
+    including a frame range with a gap (triples that straddle the gap do not exist)."""
+    v = synth.make_video(9, 64, 40, seed=39, spacing=9)
+    objs = _pair(Solver, v)
+    rng = np.random.default_rng(11)
+    F = v.num_frames
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.05, (F, 6))
+    pose[:, 6] = 0.2
+    for frames in (None, [0, 1, 2, 3, 5, 6, 7, 8]):
+        p = OptParams.defaults()
+        p.num_threads = 1
+        p.position_reg = 3.0
+        if frames is not None:
+            p.set_frame_range(frames)
+        res = {}
+        for k, s in objs.items():
+            s.reset_depth_xforms(XformDesc.grid_depth(3, 3))
+            s.reset_spatial_xforms(XformDesc.spatial())
+            res[k] = s.evaluate(p, 0.1, pose, want_hdiag=True, want_hfull=True)
+        assert res["hip"]["num_residual_blocks"] == res["oracle"]["num_residual_blocks"]
+        assert abs(res["hip"]["cost"] - res["oracle"]["cost"]) <= TOL * abs(res["oracle"]["cost"])
+        assert rel(res["hip"]["gradient"], res["oracle"]["gradient"]) < TOL
+        assert rel(res["hip"]["hdiag"], res["oracle"]["hdiag"]) < TOL
+        assert rel(res["hip"]["hfull"], res["oracle"]["hfull"]) < TOL
+    # and a converged solve
+    out = {}
+    for k, s in objs.items():
+        p = OptParams.defaults()
+        p.num_threads = 4
+        p.position_reg = 3.0
+        p.coarse_to_fine = 0
+        p.num_steps = 1
+        if k == "hip":
+            s.set_options(pcg_relative_tolerance=1e-3)
+        s.reset_poses()
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[k] = s.summary()["final_cost"]
+    assert abs(out["hip"] - out["oracle"]) <= 1e-4 * abs(out["oracle"])
+
+
 def test_normalize_depth_matches_oracle(Solver):
     v = synth.make_video(6, 96, 56, seed=35)
     objs = _pair(Solver, v)
