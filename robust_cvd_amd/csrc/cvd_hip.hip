@@ -282,7 +282,7 @@ struct cvd_handle_t {
   // solver buffers
   DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dR1, dZ, dP0, dP1, dQ, dH, dQPart;
   DevBuf<float> dMinv;
-  DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd;
+  DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
   DevBuf<FrameConst> dFc;
   DevBuf<int> dFail;
   DevBuf<unsigned long long> dCount;
@@ -464,8 +464,6 @@ static void gridXformSplit(cvd_handle* h, const cvd_xform_desc& nd) {
 static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
   if (p.adaptive_deformation_cost > 0.0)
     throw std::runtime_error("AdaptiveDeformationCost is not implemented (off by default in the reference).");
-  if (p.intr_opt == CVD_INTR_SHARED && kind == PK_POSE_STEP)
-    throw std::runtime_error("IntrinsicsOptimization::Shared is not implemented on the device path yet.");
   if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP)
     throw std::runtime_error("Scene-flow smoothness (triplet) loss is not implemented on the device path yet.");
   Layout L{};
@@ -726,6 +724,7 @@ static void ensureBuffers(Ctx& c) {
   h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
+  h->dFocal.ensure(static_cast<size_t>(c.L.F) * 2);
   h->dScal.ensure(S_COUNT);
   h->dFc.ensure(c.L.F);
   h->dFail.ensure(1);
@@ -787,18 +786,24 @@ static double evalFull(Ctx& c, const double* x) {
   if (fast && c.KD == 4) {
     allowLds(k_assemble_fast<4>, lds);
     hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
+                       h->dFocal.p, h->dFocal.p + c.L.F);
   } else if (fast) {
     allowLds(k_assemble_fast<1>, lds);
     hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
+                       h->dFocal.p, h->dFocal.p + c.L.F);
   } else {
     CVD_DISPATCH(c.KD, c.KS, {
       allowLds(k_assemble<KD, KS>, lds);
       hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p);
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
+                       h->dFocal.p, h->dFocal.p + c.L.F);
     });
   }
+  if (c.L.intrOpt == CVD_INTR_SHARED)
+    hipLaunchKernelGGL(k_shared_focal_fixup, dim3(1), dim3(256), 0, s, c.L, h->dFocal.p, h->dFocal.p + c.L.F, h->dMask.p,
+                       h->dG.p, h->dH.p);
   HIP_CHECK(hipGetLastError());
   h->tEnd(slot);
   if (h->world > 1) {
@@ -850,7 +855,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0);
+                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems);
     });
     HIP_CHECK(hipGetLastError());
     if (h->world > 1) {

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
                                                   const unsigned char* __restrict__ rangeFlags,
                                                   const int* __restrict__ fpOff, const int* __restrict__ fpList,
                                                   double* __restrict__ gOut, double* __restrict__ hOut,
-                                                  double* __restrict__ costFrame) {
+                                                  double* __restrict__ costFrame, double* __restrict__ focalG,
+                                                  double* __restrict__ focalH) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   const int npk = B * (B + 1) / 2;
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
   double PP[28];
   double gp[7];
   double cost = 0.0;
+  double shG = 0.0, shH = 0.0;  // IntrinsicsOptimization::Shared: focal gradient / squared column norm
 #pragma unroll
   for (int i = 0; i < 28; ++i) PP[i] = 0.0;
 #pragma unroll
@@ -281,8 +283,22 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
         if (!(d.x > 0.f)) continue;
         Sample<KD, KS> s;
         evalSample<KD, KS, true>(L, fa, fb, xa, xb, T.ndc[c], d, s);
-        const Side<KD, KS>& me = side ? s.b : s.a;
         const double w = s.rho1;
+        if (L.intrOpt == kIntrShared) {
+          // one focal length: the focal column of this constraint is (d r / d f_a + d r / d f_b); its gradient and
+          // squared norm are taken once per constraint (source visit) for frame 0's slot
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            const double tot = s.a.Jp[rr][6] + s.b.Jp[rr][6];
+            s.a.Jp[rr][6] = tot;
+            s.b.Jp[rr][6] = tot;
+          }
+          if (!side) {
+            shG += w * (s.a.Jp[0][6] * s.r[0] + s.a.Jp[1][6] * s.r[1] + s.a.Jp[2][6] * s.r[2]);
+            shH += w * (s.a.Jp[0][6] * s.a.Jp[0][6] + s.a.Jp[1][6] * s.a.Jp[1][6] + s.a.Jp[2][6] * s.a.Jp[2][6]);
+          }
+        }
+        const Side<KD, KS>& me = side ? s.b : s.a;
         if (!side) cost += s.rho0;  // count every constraint once
         // pose-like block
         int q = 0;
@@ -348,8 +364,28 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
     gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
   }
   __syncthreads();
-  double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
+  const double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
   __syncthreads();
+  if (L.intrOpt == kIntrShared) {
+    // The focal column of every constraint belongs to frame 0's slot: publish this frame's static focal
+    // gradient / diagonal for k_shared_focal_fixup and drop the entries from the frame's own block (for f != 0
+    // they are off-diagonal couplings with frame 0, which the block-Jacobi preconditioner does not hold).
+    shG = waveSum(shG);
+    shH = waveSum(shH);
+    if ((tid & 63) == 0) { red[tid >> 6] = shG; red[4 + (tid >> 6)] = shH; }
+    __syncthreads();
+    if (tid == 0) {
+      focalG[f] = red[0] + red[1] + red[2] + red[3];
+      focalH[f] = red[4] + red[5] + red[6] + red[7];
+      gs[6] = 0.0;
+      Hs[packedIdx(6, 6)] = 0.0;
+    }
+    if (f != 0) {
+      for (int j = tid; j < B; j += 256)
+        if (j != 6) Hs[j > 6 ? packedIdx(j, 6) : packedIdx(6, j)] = 0.0;
+    }
+    __syncthreads();
+  }
 
   // regularisers of this frame
   double regCost = 0.0;
@@ -395,6 +431,25 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
     const int i = idx / B, j = idx - i * B;
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
+  }
+}
+
+// IntrinsicsOptimization::Shared: frame 0's focal slot receives the static focal gradient / diagonal of all frames.
+__global__ __launch_bounds__(256) void k_shared_focal_fixup(Layout L, const double* __restrict__ focalG,
+                                                            const double* __restrict__ focalH,
+                                                            const double* __restrict__ mask, double* __restrict__ g,
+                                                            double* __restrict__ hBlocks) {
+  __shared__ double red[8];
+  double a = 0.0, b = 0.0;
+  for (int f = threadIdx.x; f < L.F; f += 256) { a += focalG[f]; b += focalH[f]; }
+  a = waveSum(a);
+  b = waveSum(b);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double m = mask[6];
+    g[6] += (red[0] + red[1] + red[2] + red[3]) * m;
+    hBlocks[static_cast<size_t>(6) * L.B + 6] += (red[4] + red[5] + red[6] + red[7]) * m * m;
   }
 }
 
@@ -564,6 +619,15 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
+  if (L.intrOpt == kIntrShared) {
+    // every constraint's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1226)
+    __syncthreads();
+    if (tid == 0) {
+      const double p06 = (z[6] + (useBeta ? beta * pOld[6] : 0.0)) * mask[6];
+      pa[6] = p06;
+      pb[6] = p06;
+    }
+  }
   constexpr int FCW = sizeof(FrameConst) / 8;
   if (tid < 2 * FCW) {
     const int which = tid / FCW, k = tid % FCW;
@@ -652,7 +716,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode) {
+                                                       int distMode, int nItems) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -669,7 +733,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     xf[i] = x[base + i];
     pf[i] = pv * mask[base + i];
     double acc = 0.0;
-    if (L.includeStatic) {  // no pair kernel ran otherwise: the partial buffer holds stale data
+    if (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) {  // (stale partial buffer without a pair kernel)
       for (int e = fiOff[f]; e < fiOff[f + 1]; ++e) {
         const int code = fiList[e];
         acc += qPart[(static_cast<size_t>(code >> 1) * 2 + (code & 1)) * B + i];
@@ -678,6 +742,14 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     qf[i] = acc;
   }
   __syncthreads();
+  if (L.intrOpt == kIntrShared && f == 0 && L.includeStatic) {
+    // shared focal: frame 0's slot collects the focal adjoint of EVERY work item (both sides)
+    double a = 0.0;
+    for (int k = tid; k < 2 * nItems; k += 256) a += qPart[static_cast<size_t>(k) * B + 6];
+    a = waveSum(a);
+    if ((tid & 63) == 0) atomicAdd(&qf[6], a);
+    __syncthreads();
+  }
   if (inRange[f]) {
     const int nr = numRegResiduals<KD>(L);
     for (int i = tid; i < nr; i += 256) {
@@ -1001,6 +1073,15 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
+  if (L.intrOpt == kIntrShared) {
+    // every constraint's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1226)
+    __syncthreads();
+    if (tid == 0) {
+      const double p06 = (z[6] + (useBeta ? beta * pOld[6] : 0.0)) * mask[6];
+      pa[6] = p06;
+      pb[6] = p06;
+    }
+  }
   constexpr int FCW = sizeof(FrameConst) / 8;
   if (tid < 2 * FCW) {
     const int which = tid / FCW, k = tid % FCW;
@@ -1251,7 +1332,8 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
                                                        const unsigned char* __restrict__ rangeFlags,
                                                        const int* __restrict__ fpOff, const int* __restrict__ fpList,
                                                        double* __restrict__ gOut, double* __restrict__ hOut,
-                                                       double* __restrict__ costFrame) {
+                                                       double* __restrict__ costFrame, double* __restrict__ focalG,
+                                                       double* __restrict__ focalH) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr double eps = 1e-6;
   const int B = L.B;
@@ -1280,6 +1362,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
 #pragma unroll
   for (int i = 0; i < 19; ++i) GD[i] = 0.0;
   double cost = 0.0;
+  double shG = 0.0, shH = 0.0;  // IntrinsicsOptimization::Shared: focal gradient / squared column norm
 #pragma unroll
   for (int i = 0; i < 28; ++i) PP[i] = 0.0;
 #pragma unroll
@@ -1421,6 +1504,27 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
           Jp[2][6] = 0.0;
           JD[0] = 0.0; JD[1] = 0.0; JD[2] = dr2dDb;
         }
+        if (L.intrOpt == kIntrShared) {
+          // one focal length: column = d r / d f_a + d r / d f_b (the other side's part is added here)
+          if (!side) {
+            Jp[0][6] += -L.ws * u * ifyb;
+            Jp[1][6] += -L.ws * vv * ifyb;
+          } else {
+            const double cf[3] = {pax * A, pay, 0.0};
+            const double dXdf[3] = {Da * (Fa.R[0] * cf[0] + Fa.R[1] * cf[1]), Da * (Fa.R[3] * cf[0] + Fa.R[4] * cf[1]),
+                                    Da * (Fa.R[6] * cf[0] + Fa.R[7] * cf[1])};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              Jp[0][6] += (m00 * Fb.R[i * 3 + 0] + m02 * Fb.R[i * 3 + 2]) * dXdf[i];
+              Jp[1][6] += (m11 * Fb.R[i * 3 + 1] + m12 * Fb.R[i * 3 + 2]) * dXdf[i];
+              Jp[2][6] += (m22 * Fb.R[i * 3 + 2]) * dXdf[i];
+            }
+          }
+          if (!side) {
+            shG += w * (Jp[0][6] * r[0] + Jp[1][6] * r[1] + Jp[2][6] * r[2]);
+            shH += w * (Jp[0][6] * Jp[0][6] + Jp[1][6] * Jp[1][6] + Jp[2][6] * Jp[2][6]);
+          }
+        }
         // ---- accumulate
         int qi = 0;
 #pragma unroll
@@ -1529,6 +1633,26 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   __syncthreads();
   const double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
   __syncthreads();
+  if (L.intrOpt == kIntrShared) {
+    // The focal column of every constraint belongs to frame 0's slot: publish this frame's static focal
+    // gradient / diagonal for k_shared_focal_fixup and drop the entries from the frame's own block (for f != 0
+    // they are off-diagonal couplings with frame 0, which the block-Jacobi preconditioner does not hold).
+    shG = waveSum(shG);
+    shH = waveSum(shH);
+    if ((tid & 63) == 0) { red[tid >> 6] = shG; red[4 + (tid >> 6)] = shH; }
+    __syncthreads();
+    if (tid == 0) {
+      focalG[f] = red[0] + red[1] + red[2] + red[3];
+      focalH[f] = red[4] + red[5] + red[6] + red[7];
+      gs[6] = 0.0;
+      Hs[packedIdx(6, 6)] = 0.0;
+    }
+    if (f != 0) {
+      for (int j = tid; j < B; j += 256)
+        if (j != 6) Hs[j > 6 ? packedIdx(j, 6) : packedIdx(6, j)] = 0.0;
+    }
+    __syncthreads();
+  }
 
   double regCost = 0.0;
   if (regOwner[f]) {

@@ -30,6 +30,8 @@ CASES = {
     "global_fixed_euclidean": (4, 64, 40, 25, ("global", 2), ("corners",), 0, 0, 0.1),
     "grid3x3_ratio": (4, 64, 40, 26, ("grid", 3, 3, 1, False), ("vertical",), 2, 2, 0.3),
     "grid3x3_log": (4, 64, 40, 27, ("grid", 3, 3, 1, False), ("bilinear", 3, 2), 2, 3, 0.3),
+    "grid4x3_shared_intrinsics": (5, 64, 40, 28, ("grid", 4, 3, 1, False), ("identity",), 1, 1, 0.1),
+    "global_shared_intrinsics": (5, 64, 40, 29, ("global", 1), ("identity",), 1, 1, 0.1),
 }
 
 

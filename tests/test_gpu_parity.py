@@ -176,6 +176,47 @@ def test_fixed_blocks(Solver):
         assert rel(res["hip"]["hdiag"], res["oracle"]["hdiag"]) < TOL
 
 
+def test_shared_intrinsics(Solver):
+    """IntrinsicsOptimization::Shared: every constraint's focal column is frame 0's slot (reference
+    lib/PoseOptimizer.cpp:1212-1230, q7); the matrix-free product must equal the oracle's full J^T J, and the solve
+    must reach the oracle's minimum with one focal length for all frames."""
+    v = synth.make_video(8, 96, 56, seed=40)
+    objs = _pair(Solver, v)
+    rng = np.random.default_rng(12)
+    F = v.num_frames
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.03, (F, 6))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+    p = OptParams.defaults()
+    p.num_threads = 2
+    p.intr_opt = IntrinsicsOptimization.Shared
+    res = {}
+    for k, s in objs.items():
+        s.reset_depth_xforms(XformDesc.grid_depth(3, 2))
+        s.reset_spatial_xforms(XformDesc.spatial())
+        res[k] = s.evaluate(p, 0.1, pose, want_hfull=True)
+    assert abs(res["hip"]["cost"] - res["oracle"]["cost"]) <= TOL * abs(res["oracle"]["cost"])
+    assert rel(res["hip"]["gradient"], res["oracle"]["gradient"]) < TOL
+    assert rel(res["hip"]["hfull"], res["oracle"]["hfull"]) < TOL
+    assert abs(res["hip"]["gradient"][0, 6]) > 10 * np.abs(res["hip"]["gradient"][1:, 6]).max()
+    out = {}
+    for k, s in objs.items():
+        if k == "hip":
+            s.set_options(pcg_relative_tolerance=1e-3)
+        s.reset_poses()
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.normalize_depth(p)
+        pp = OptParams.defaults()
+        pp.num_threads = 4
+        pp.intr_opt = IntrinsicsOptimization.Shared
+        pp.ctf_long, pp.ctf_short = 6, 4
+        s.pose_optimization(pp)
+        out[k] = (s.summary()["final_cost"], s.get_poses())
+    assert abs(out["hip"][0] - out["oracle"][0]) <= 1e-4 * abs(out["oracle"][0])
+    assert np.ptp(out["hip"][1]["vfov"]) == 0.0                      # one shared FOV written to every frame
+    assert abs(out["hip"][1]["vfov"][0] - out["oracle"][1]["vfov"][0]) < 1e-3
+
+
 def test_position_regularisation(Solver):
     """ParameterRegularizationCost t_f - 2 t_{f+1} + t_{f+2} (reference lib/PoseOptimizer.cpp:464-483, 1417-1447),
     including a frame range with a gap (triples that straddle the gap do not exist)."""
@@ -363,8 +404,8 @@ def test_unsupported_configurations_fail_loudly(Solver):
     s.reset_depth_xforms(XformDesc.global_depth())
     s.reset_spatial_xforms(XformDesc.spatial())
     p = OptParams.defaults()
-    p.intr_opt = IntrinsicsOptimization.Shared
-    with pytest.raises(RuntimeError, match="Shared"):
+    p.smooth_static_weight = 1.0
+    with pytest.raises(RuntimeError, match="smoothness"):
         s.pose_optimization(p)
     p = OptParams.defaults()
     p.adaptive_deformation_cost = 1.0
