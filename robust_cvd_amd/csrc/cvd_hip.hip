@@ -780,17 +780,18 @@ static double evalFull(Ctx& c, const double* x) {
   hipStream_t s = h->stream;
   launchFrameConsts(c, x);
   const size_t B = c.L.B;
-  const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
   const int slot = h->tBegin(KC_ASSEMBLE);
   const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+  const size_t ldsFast = (B * (B + 1) / 2 + 2 * B + 4 * 36) * 8;
+  const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
   if (fast && c.KD == 4) {
-    allowLds(k_assemble_fast<4>, lds);
-    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+    allowLds(k_assemble_fast<4>, ldsFast);
+    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                        h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
                        h->dFocal.p, h->dFocal.p + c.L.F);
   } else if (fast) {
-    allowLds(k_assemble_fast<1>, lds);
-    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+    allowLds(k_assemble_fast<1>, ldsFast);
+    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                        h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
                        h->dFocal.p, h->dFocal.p + c.L.F);
   } else {

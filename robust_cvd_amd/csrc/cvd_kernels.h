@@ -1338,12 +1338,13 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   constexpr double eps = 1e-6;
   const int B = L.B;
   const int npk = B * (B + 1) / 2;
+  // LDS holds only what is accumulated into: the packed block, the gradient, this frame's parameters and the
+  // reduction scratch ((B(B+1)/2 + 2B + 144) doubles: B = 199, the 16x12 grid, still fits 160 KiB).  The other
+  // frame's parameters and both frames' FrameConst are read through L1/L2 (wave-uniform or 4-tap gathers).
   double* Hs = sm;
   double* gs = Hs + npk;
   double* xf = gs + B;
-  double* xo = xf + B;
-  FrameConst* fcs = reinterpret_cast<FrameConst*>(xo + B);
-  double* red = reinterpret_cast<double*>(fcs + 2);  // 4 * 36
+  double* red = xf + B;  // 4 * 36
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
@@ -1351,8 +1352,6 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
     gs[i] = 0.0;
     xf[i] = x[static_cast<size_t>(f) * B + i];
   }
-  constexpr int FCW = sizeof(FrameConst) / 8;
-  if (tid < FCW) reinterpret_cast<double*>(fcs)[tid] = reinterpret_cast<const double*>(fc + f)[tid];
   __syncthreads();
 
   double PP[28], gp[7];
@@ -1376,12 +1375,9 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
       const int p = code >> 1;
       const int side = code & 1;  // 0: f is the source of pair p, 1: f is the target
       const int o = side ? T.pairA[p] : T.pairB[p];
-      __syncthreads();
-      for (int i = tid; i < B; i += 256) xo[i] = x[static_cast<size_t>(o) * B + i];
-      if (tid < FCW) reinterpret_cast<double*>(fcs + 1)[tid] = reinterpret_cast<const double*>(fc + o)[tid];
-      __syncthreads();
-      const FrameConst& Fa = side ? fcs[1] : fcs[0];
-      const FrameConst& Fb = side ? fcs[0] : fcs[1];
+      const double* __restrict__ xo = x + static_cast<size_t>(o) * B;
+      const FrameConst& Fa = side ? fc[o] : fc[f];
+      const FrameConst& Fb = side ? fc[f] : fc[o];
       const double* xa = side ? xo : xf;
       const double* xb = side ? xf : xo;
       const double fya = Fa.fy, fxa = Fa.fy * A;

@@ -176,6 +176,34 @@ def test_fixed_blocks(Solver):
         assert rel(res["hip"]["hdiag"], res["oracle"]["hdiag"]) < TOL
 
 
+def test_config5_grid_16x12_block_fits_the_lds(Solver):
+    """BASELINE configs[4] uses a 16x12 depth grid: B = 199 unknowns per frame, the largest block of the scope table
+    (packed lower triangle = 159 200 B of the 160 KiB LDS).  Parity at that block size on a few frames."""
+    v = synth.make_video(5, 160, 96, seed=43)
+    objs = _pair(Solver, v)
+    rng = np.random.default_rng(13)
+    F = v.num_frames
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.03, (F, 6))
+    pose[:, 6] = 0.2
+    dx = 0.15 + rng.uniform(0, 0.05, (F, 192))
+    p = OptParams.defaults()
+    p.num_threads = 4
+    res = {}
+    for k, s in objs.items():
+        s.reset_depth_xforms(XformDesc.grid_depth(16, 12))
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.set_xform_params(dx)
+        assert s.block_size() == 199
+        res[k] = s.evaluate(p, 0.1, pose, want_hdiag=True)
+    assert abs(res["hip"]["cost"] - res["oracle"]["cost"]) <= TOL * abs(res["oracle"]["cost"])
+    assert rel(res["hip"]["gradient"], res["oracle"]["gradient"]) < TOL
+    assert rel(res["hip"]["hdiag"], res["oracle"]["hdiag"]) < TOL
+    p.max_iterations = 3
+    objs["hip"].pose_optimization_step(p, 0.1)     # assembly + block inverse + PCG at B = 199
+    assert objs["hip"].summary()["final_cost"] < res["hip"]["cost"]
+
+
 def test_shared_intrinsics(Solver):
     """IntrinsicsOptimization::Shared: every constraint's focal column is frame 0's slot (reference
     lib/PoseOptimizer.cpp:1212-1230, q7); the matrix-free product must equal the oracle's full J^T J, and the solve
