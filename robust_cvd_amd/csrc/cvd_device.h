@@ -666,11 +666,26 @@ __device__ __forceinline__ void posRegFrame(const Layout& L, const unsigned char
   }
 }
 
-// Wave-level sum of a double (64 lanes).
+// Wave-level sum of a double (64 lanes), result in every lane.  Four DPP butterfly steps inside each 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS traffic), then the four row sums are combined
+// through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dppMove(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readLane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double waveSum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dppMove<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dppMove<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dppMove<0x141>(v);  // row_half_mirror
+  v += dppMove<0x140>(v);  // row_mirror
+  return (readLane(v, 0) + readLane(v, 16)) + (readLane(v, 32) + readLane(v, 48));
 }
 
 }  // namespace cvd

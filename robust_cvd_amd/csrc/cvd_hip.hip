@@ -283,6 +283,10 @@ struct cvd_handle_t {
   DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dR1, dZ, dP0, dP1, dQ, dH, dQPart;
   DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
+  DevBuf<double> dRegJac;  // regulariser Jacobian rows of the current linearisation point (RegCache)
+  DevBuf<unsigned short> dRegCol;
+  DevBuf<unsigned char> dRegCnt;
+  RegCache regCache{};
   DevBuf<FrameConst> dFc;
   DevBuf<int> dFail;
   DevBuf<unsigned long long> dCount;
@@ -822,6 +826,29 @@ static double evalFull(Ctx& c, const double* x) {
   return h->hScal[S_COST];
 }
 
+// Fills the regulariser Jacobian cache for the products at linearisation point x (before runPcg / the J^T J hook).
+static void prepareMatvec(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  const Layout& L = c.L;
+  int nr = 0;
+  if (L.scaleRegSqrt > 0.0) nr += L.sregX * L.sregY;
+  if (L.focalRegSqrt > 0.0) nr += 1;
+  if (L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) nr += ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+  if (L.spatialDeformW > 0.0) nr += L.nS;
+  const int stride = std::max(2, c.KD * std::max(1, L.N));
+  const size_t entries = static_cast<size_t>(L.F) * stride * std::max(nr, 1);
+  h->dRegJac.ensure(entries);
+  h->dRegCol.ensure(entries);
+  h->dRegCnt.ensure(static_cast<size_t>(L.F) * std::max(nr, 1));
+  h->regCache = RegCache{h->dRegJac.p, h->dRegCol.p, h->dRegCnt.p, nr, stride};
+  if (nr == 0) return;
+  CVD_DISPATCH_KD(c.KD, {
+    hipLaunchKernelGGL((k_reg_cache<KD>), dim3(L.F), dim3(256), 0, h->stream, L, x, h->dMedian.p, h->dRegOwner.p,
+                       h->regCache);
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
 static void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta,
                          const double* lam, double* q) {
   cvd_handle* h = c.h;
@@ -829,15 +856,16 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   const size_t B = c.L.B;
   if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8) * 8;
+    const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
     const int slot = h->tBegin(KC_MATVEC_PAIRS);
     const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
     if (fast && c.KD == 4) {
-      allowLds(k_matvec_pairs_fast<4>, lds);
-      hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+      allowLds(k_matvec_pairs_fast<4>, ldsFast);
+      hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
                          h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
     } else if (fast) {
-      allowLds(k_matvec_pairs_fast<1>, lds);
-      hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+      allowLds(k_matvec_pairs_fast<1>, ldsFast);
+      hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
                          h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
@@ -856,7 +884,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems);
+                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache);
     });
     HIP_CHECK(hipGetLastError());
     if (h->world > 1) {
@@ -869,6 +897,33 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   }
 }
 
+// M_f^-1 = (H_ff + diag(lam_f))^-1 for every frame (f32 output).  Register-resident sweep for B <= 256 (4x4 tiles,
+// up to 3 per thread at 1024 threads); the LDS Cholesky kernel is kept for comparison (set_generic_kernels).
+static void launchBlockInverse(Ctx& c) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const int B = c.L.B;
+  const int nb = (B + 3) / 4, nTiles = nb * (nb + 1) / 2;
+  const int nT = std::min(1024, ((nTiles + 63) / 64) * 64);
+  const int tpt = (nTiles + nT - 1) / nT;
+  const size_t ldsChol = (static_cast<size_t>(B) * (B + 1) / 2 + B) * 8;
+  // three tiles per thread spill: prefer the LDS Cholesky there while its triangle still fits (B <= 199)
+  if (!h->forceGeneric && (tpt <= 2 || (tpt == 3 && ldsChol > 160 * 1024))) {
+    if (tpt == 1)
+      hipLaunchKernelGGL(k_block_inverse_sweep<1>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+    else if (tpt == 2)
+      hipLaunchKernelGGL(k_block_inverse_sweep<2>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+    else
+      hipLaunchKernelGGL(k_block_inverse_sweep<3>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+  } else {
+    const size_t lds = ldsChol;
+    allowLds(k_block_inverse, lds);
+    hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(std::min<int>(1024, ((4 * B + 63) / 64) * 64)), lds, s, c.L,
+                       h->dH.p, h->dLam.p, h->dMinv.p, static_cast<double*>(nullptr), h->dFail.p);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 // PCG on (H + diag(lam)) dx = -g with the block-Jacobi preconditioner; returns iterations used.
 // Three launches per iteration (pairs product, per-frame finish, per-frame update).  alpha / beta live on
 // the device: the last workgroup of k_matvec_finish / k_cg_update reduces the per-frame partial dot products
@@ -879,6 +934,7 @@ static int runPcg(Ctx& c, const double* x) {
   const int F = c.L.F;
   const size_t B = c.L.B;
   if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_cg_update");
+  prepareMatvec(c, x);
   const int nChunks = static_cast<int>((B + 63) / 64);
   const int nThreads = 256 * nChunks;
   double* fd = h->dFdot.p;
@@ -1010,13 +1066,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
                          scaleDone ? 0 : 1, radius, h->dLam.p);
       scaleDone = true;
       {
-        const size_t B = c.L.B;
-        const size_t lds = (B * (B + 1) / 2 + B) * 8;
-        allowLds(k_block_inverse, lds);
         const int slot = h->tBegin(KC_INVERSE);
-        hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(std::min<int>(1024, ((4 * static_cast<int>(B) + 63) / 64) * 64)), lds, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p,
-                           static_cast<double*>(nullptr), h->dFail.p);
-        HIP_CHECK(hipGetLastError());
+        launchBlockInverse(c);
         h->tEnd(slot);
       }
       const int cgIters = runPcg(c, h->dX.p);
@@ -1253,6 +1304,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
     // column j of J^T J = matvec with the unit vector e_j (lam = 0)
     std::vector<double> e(c.n, 0.0), col(c.n);
     HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    prepareMatvec(c, h->dX.p);
     for (size_t j = 0; j < c.n; ++j) {
       e[j] = 1.0;
       h->dZ.upload(e.data(), c.n, s);

@@ -476,6 +476,125 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, doub
   }
 }
 
+// Block-Jacobi preconditioner, register-resident variant: M_f^-1 = (H_ff + diag(lam_f))^-1 by the symmetric sweep
+// operator (Gauss-Jordan without pivoting, valid for SPD blocks).  Sweeping pivot k maps
+//   G_kk <- -1/G_kk,  G_ik <- G_ik / G_kk,  G_ij <- G_ij - G_ik G_kj / G_kk   (i, j != k)
+// and after all B pivots G = -A^-1.  The lower triangle is cut into 4x4 tiles held in REGISTERS (tile id =
+// tid + t * blockDim, TPT tiles per thread); a step only needs the pivot column, which its owners publish to a
+// double-buffered LDS vector, so one barrier per pivot and ~16 FMAs + 64 B of LDS reads per tile and step.
+// Padding rows/columns (B not a multiple of 4) are identity and never swept.
+template <int TPT>
+__global__ __launch_bounds__(1024) void k_block_inverse_sweep(Layout L, const double* __restrict__ hBlocks,
+                                                              const double* __restrict__ lam,
+                                                              float* __restrict__ minv, int* __restrict__ fail) {
+  __shared__ __attribute__((aligned(16))) double colBuf[2][264];
+  const int B = L.B;
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nT = blockDim.x;
+  const int nb = (B + 3) >> 2;
+  const int nTiles = nb * (nb + 1) / 2;
+  const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
+  const double* lf = lam + static_cast<size_t>(f) * B;
+  double T[TPT][4][4];
+  int tI[TPT], tJ[TPT];
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) {
+    const int id = tid + t * nT;
+    tI[t] = -1;
+    tJ[t] = -1;
+    if (id < nTiles) {
+      int I = static_cast<int>((sqrtf(8.f * static_cast<float>(id) + 1.f) - 1.f) * 0.5f);
+      while ((I + 1) * (I + 2) / 2 <= id) ++I;
+      while (I * (I + 1) / 2 > id) --I;
+      tI[t] = I;
+      tJ[t] = id - I * (I + 1) / 2;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 4 * tI[t] + p, j = 4 * tJ[t] + q;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (tI[t] >= 0 && i < B && j < B) v = hf[static_cast<size_t>(i) * B + j] + (i == j ? lf[i] : 0.0);
+        T[t][p][q] = v;
+      }
+    if (tJ[t] == 0) {  // publish pivot column 0
+#pragma unroll
+      for (int p = 0; p < 4; ++p) colBuf[0][4 * tI[t] + p] = T[t][p][0];
+    }
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nb; ++kt) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int k = 4 * kt + a;
+      if (k >= B) break;  // uniform
+      const double* col = colBuf[k & 1];
+      double* nxt = colBuf[(k + 1) & 1];
+      double d = col[k];
+      if (!(d > 0.0)) {
+        if (tid == 0) atomicAdd(fail, 1);
+        d = 1.0;
+      }
+      const double id = 1.0 / d;
+      const int an = (a + 1) & 3;  // compile-time after unrolling
+      const int ktn = kt + (a == 3 ? 1 : 0);
+#pragma unroll
+      for (int t = 0; t < TPT; ++t) {
+        if (tI[t] < 0) continue;
+        const double2 ci01 = *reinterpret_cast<const double2*>(col + 4 * tI[t]);
+        const double2 ci23 = *reinterpret_cast<const double2*>(col + 4 * tI[t] + 2);
+        const double2 cj01 = *reinterpret_cast<const double2*>(col + 4 * tJ[t]);
+        const double2 cj23 = *reinterpret_cast<const double2*>(col + 4 * tJ[t] + 2);
+        const double ci[4] = {ci01.x * id, ci01.y * id, ci23.x * id, ci23.y * id};  // c_i / d
+        const double cj[4] = {cj01.x, cj01.y, cj23.x, cj23.y};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) T[t][p][q] -= ci[p] * cj[q];
+        if (tI[t] == kt) {  // row k of the tile: G_kj <- c_j / d
+#pragma unroll
+          for (int q = 0; q < 4; ++q) T[t][a][q] = cj[q] * id;
+        }
+        if (tJ[t] == kt) {  // column k of the tile: G_ik <- c_i / d
+#pragma unroll
+          for (int p = 0; p < 4; ++p) T[t][p][a] = ci[p];
+          if (tI[t] == kt) T[t][a][a] = -id;
+        }
+        // publish the next pivot column (row k+1 of the tiles left of / on the diagonal, column k+1 below it)
+        if (k + 1 < B) {
+          if (tI[t] == ktn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[4 * tJ[t] + q] = T[t][an][q];
+          } else if (tJ[t] == ktn) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) nxt[4 * tI[t] + p] = T[t][p][an];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* Mf = minv + static_cast<size_t>(f) * B * B;
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) {
+    if (tI[t] < 0) continue;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 4 * tI[t] + p, j = 4 * tJ[t] + q;
+        if (i < B && j < B) {
+          const float v = static_cast<float>(-T[t][p][q]);
+          Mf[static_cast<size_t>(i) * B + j] = v;
+          if (tI[t] != tJ[t]) Mf[static_cast<size_t>(j) * B + i] = v;
+        }
+      }
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // Block-Jacobi preconditioner: Minv_f = (H_ff + diag(lam_f))^-1.  One workgroup per frame, Cholesky of
 // the packed lower triangle in LDS, L^-1 by column-parallel forward substitution (global scratch,
@@ -705,6 +824,39 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
 
 // Per frame: p_f = z + beta p_old (stored for the next iteration), q_f = mask * (sum of partials +
 // regulariser J^T J p) + lam * p_f, and the frame's share of p.q.
+// Regulariser Jacobian cache: the rows of the per-frame regularisers depend on x only, so they are evaluated once per
+// linearisation point (RegCache, filled by k_reg_cache) instead of once per product.  Entry a of residual i of
+// frame f lives at (f * stride + a) * nr + i (consecutive threads = consecutive residuals).
+struct RegCache {
+  double* jac;
+  unsigned short* col;
+  unsigned char* cnt;
+  int nr;      // residuals per frame
+  int stride;  // entries per residual
+};
+
+template <int KD>
+__global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __restrict__ x,
+                                                   const float* __restrict__ median,
+                                                   const unsigned char* __restrict__ owner, RegCache rc) {
+  const int f = blockIdx.x;
+  if (!owner[f]) return;
+  const double* xf = x + static_cast<size_t>(f) * L.B;
+  for (int i = threadIdx.x; i < rc.nr; i += 256) {
+    double r;
+    int n;
+    int cols[2 * KD + 2];
+    double jac[2 * KD + 2];
+    regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+    rc.cnt[static_cast<size_t>(f) * rc.nr + i] = static_cast<unsigned char>(n);
+    for (int a = 0; a < n; ++a) {
+      const size_t e = (static_cast<size_t>(f) * rc.stride + a) * rc.nr + i;
+      rc.jac[e] = jac[a];
+      rc.col[e] = static_cast<unsigned short>(cols[a]);
+    }
+  }
+}
+
 template <int KD>
 __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
                                                        const double* __restrict__ mask,
@@ -716,7 +868,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nItems) {
+                                                       int distMode, int nItems, RegCache rc) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -751,16 +903,14 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     __syncthreads();
   }
   if (inRange[f]) {
-    const int nr = numRegResiduals<KD>(L);
-    for (int i = tid; i < nr; i += 256) {
-      double r;
-      int n;
-      int cols[2 * KD + 2];
-      double jac[2 * KD + 2];
-      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+    // J_reg^T (J_reg p) from the cached rows (k_reg_cache)
+    for (int i = tid; i < rc.nr; i += 256) {
+      const int n = rc.cnt[static_cast<size_t>(f) * rc.nr + i];
+      const size_t e0 = static_cast<size_t>(f) * rc.stride * rc.nr + i;
       double t = 0.0;
-      for (int a = 0; a < n; ++a) t += jac[a] * pf[cols[a]];
-      for (int a = 0; a < n; ++a) atomicAdd(&qf[cols[a]], jac[a] * t);
+      for (int a = 0; a < n; ++a) t += rc.jac[e0 + static_cast<size_t>(a) * rc.nr] * pf[rc.col[e0 + static_cast<size_t>(a) * rc.nr]];
+      for (int a = 0; a < n; ++a)
+        atomicAdd(&qf[rc.col[e0 + static_cast<size_t>(a) * rc.nr]], rc.jac[e0 + static_cast<size_t>(a) * rc.nr] * t);
     }
   }
   if (L.positionRegSqrt > 0.0 && tid < 3) {
@@ -1041,6 +1191,9 @@ __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, 
   }
 }
 
+constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
+constexpr int kRedStride = 8 * 33 + 1;     // 256 columns in 33-padded segments of 32, +1 to skew the rows
+
 template <int KD>
 __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
@@ -1049,6 +1202,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
                                                            const double* __restrict__ scal, int useBeta,
                                                            double* __restrict__ qPart) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
   constexpr double eps = 1e-6;
   const int B = L.B;
   double* xa = sm;
@@ -1059,7 +1213,8 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   double* qb = qa + B;
   FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
   double* E = reinterpret_cast<double*>(fcs + 2);  // E_a[9], E_b[9]
-  double* red = E + 18;                            // 4 waves x 24
+  double* red = E + 18;                            // 27 reduced accumulators
+  double* W = red + 32;                            // transposed reduction scratch: kRedVals rows x kRedStride
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
@@ -1098,9 +1253,17 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
 
   const int N = L.N;
   const double A = L.aspect;
+  // The pose-level accumulators are kept per ROLE (source / target) and swapped between the two directions, so
+  // that one reduction serves both: O_src of direction 0 and O_tgt of direction 1 both contract with dR of frame
+  // `fa` (q_w,i = <dR_i, O> for either role), the translation adjoint changes sign, the focal sums swap.
+  double aT[3] = {0, 0, 0};  // sum y_X  (q_t,src = +aT, q_t,tgt = -aT)
+  double Oa[9], Ob[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
+  double aFa = 0.0, aFb = 0.0;
+  double gDa[2] = {0.0, 0.0}, gDb[2] = {0.0, 0.0};  // KD == 1: every sample hits the one depth block -> registers
   for (int dir = 0; dir < 2; ++dir) {
   const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
-  if (cb >= ce) continue;  // uniform
   // role swap for the reverse pair (source = fb, target = fa): swap every per-frame pointer
   const FrameConst& Fa = fcs[dir];
   const FrameConst& Fb = fcs[dir ^ 1];
@@ -1111,17 +1274,18 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     t = xa; xa = xb; xb = t;
     t = pa; pa = pb; pb = t;
     t = qa; qa = qb; qb = t;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const double o = Oa[i]; Oa[i] = Ob[i]; Ob[i] = o; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) aT[i] = -aT[i];
+    { const double o = aFa; aFa = aFb; aFb = o; }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const double o = gDa[n]; gDa[n] = gDb[n]; gDb[n] = o; }
   }
   const double fya = Fa.fy, fxa = Fa.fy * A;
   const double fyb = Fb.fy;
   const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
 
-  double aT[3] = {0, 0, 0};  // sum y_X  (q_ta = +aT, q_tb = -aT)
-  double Oa[9], Ob[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
-  double aFa = 0.0, aFb = 0.0;
-  double gDa[2] = {0.0, 0.0}, gDb[2] = {0.0, 0.0};  // KD == 1: every sample hits the one depth block -> registers
 
   for (long long c = cb + tid; c < ce; c += 256) {
     const float2 d = T.dsrc[c];
@@ -1250,48 +1414,55 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
       }
     }
   }
-  // ---- workgroup reduction of the 23 accumulators, then contraction with dR
+  }  // dir
+  // ---- one workgroup reduction of the 27 accumulators (roles of direction 1: source = fb, target = fa).
+  // Every thread stores its values transposed into LDS (row = accumulator, column = thread, 33-padded 32-column
+  // segments), then 8 threads per accumulator sum one segment each: ~60 LDS ops per thread instead of 27 x 6
+  // cross-lane butterfly steps.
+  const FrameConst& Fa = fcs[1];
+  const FrameConst& Fb = fcs[0];
   {
-    const int wv = tid >> 6;
-    double vals[23];
+    double vals[NV];
 #pragma unroll
     for (int i = 0; i < 3; ++i) vals[i] = aT[i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) { vals[3 + i] = Oa[i]; vals[12 + i] = Ob[i]; }
     vals[21] = aFa;
     vals[22] = aFb;
+    if constexpr (KD == 1) { vals[23] = gDa[0]; vals[24] = gDa[1]; vals[25] = gDb[0]; vals[26] = gDb[1]; }
+    const int colw = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
-    for (int i = 0; i < 23; ++i) {
-      const double s = waveSum(vals[i]);
-      if ((tid & 63) == 0) red[wv * 24 + i] = s;
-    }
-    if constexpr (KD == 1) {
-      if (N > 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const double sa = waveSum(gDa[n]), sb = waveSum(gDb[n]);
-          if ((tid & 63) == 0 && n < N) {
-            atomicAdd(&qa[7 + n], sa);
-            atomicAdd(&qb[7 + n], sb);
-          }
-        }
-      }
-    }
+    for (int i = 0; i < NV; ++i) W[i * kRedStride + colw] = vals[i];
   }
   __syncthreads();
-  if (tid < 23) red[tid] = red[tid] + red[24 + tid] + red[48 + tid] + red[72 + tid];
+  if (tid < NV * 8) {
+    const double* row = W + (tid >> 3) * kRedStride + (tid & 7) * 33;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+      s0 += row[k];
+      s1 += row[k + 1];
+      s2 += row[k + 2];
+      s3 += row[k + 3];
+    }
+    double sacc = (s0 + s1) + (s2 + s3);
+    sacc += dppMove<0xB1>(sacc);   // 8 consecutive lanes hold one accumulator's segments
+    sacc += dppMove<0x4E>(sacc);
+    sacc += dppMove<0x141>(sacc);
+    if ((tid & 7) == 0) red[tid >> 3] = sacc;
+  }
   __syncthreads();
   if (tid < 3) {
     qa[tid] += red[tid];
     qb[tid] -= red[tid];
   } else if (tid < 6) {
-    const int i = tid - 3;  // q_wa,i = <dR_a,i, O_a>  (O_a[r][c] = sum D y_X[r] c_a[c])
+    const int i = tid - 3;  // q_w,src,i = <dR_src,i, O_a>  (O_a[r][c] = sum D y_X[r] c_a[c])
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < 9; ++e) s += Fa.dR[i][e] * red[3 + e];
     qa[3 + i] += s;
   } else if (tid < 9) {
-    const int i = tid - 6;  // q_wb,i = <dR_b,i, O_b>  (O_b[r][c] = sum v[r] y_q[c]; dq/dw_i = dR_i^T v)
+    const int i = tid - 6;  // q_w,tgt,i = <dR_tgt,i, O_b>  (O_b[r][c] = sum v[r] y_q[c]; dq/dw_i = dR_i^T v)
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < 9; ++e) s += Fb.dR[i][e] * red[12 + e];
@@ -1300,12 +1471,15 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     qa[6] += red[21];
   } else if (tid == 10) {
     qb[6] += red[22];
+  } else if (KD == 1 && tid < 15) {
+    const int n = (tid - 11) & 1;
+    if (n < N) {
+      if (tid < 13) qa[7 + n] += red[23 + n];
+      else qb[7 + n] += red[25 + n];
+    }
   }
   __syncthreads();
-  }  // dir
-  if (it.range[item * 4 + 2] < it.range[item * 4 + 3]) {  // undo the role swap
-    double* t = qa; qa = qb; qb = t;
-  }
+  { double* t = qa; qa = qb; qb = t; }  // undo the role swap
   double* out = qPart + static_cast<size_t>(item) * 2 * B;
   for (int i = tid; i < B; i += 256) {
     out[i] = qa[i];
