@@ -265,7 +265,7 @@ struct cvd_handle_t {
   // work decomposition
   std::vector<int> itemFa, itemFb;
   std::vector<long long> itemRange;  // 4 per item
-  DevBuf<int> dItemFa, dItemFb, dFiOff, dFiList, dFpOff, dFpList;
+  DevBuf<int> dItemFa, dItemFb, dItemSlot, dFiOff, dFiList, dFpOff, dFpList;
   DevBuf<long long> dItemRange;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
@@ -283,6 +283,7 @@ struct cvd_handle_t {
   DevBuf<double> dX, dXc, dG, dLam, dMask, dScale, dDx, dR, dR1, dZ, dP0, dP1, dQ, dH, dQPart;
   DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
+  DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
   DevBuf<double> dRegJac;  // regulariser Jacobian rows of the current linearisation point (RegCache)
   DevBuf<unsigned short> dRegCol;
   DevBuf<unsigned char> dRegCnt;
@@ -291,6 +292,8 @@ struct cvd_handle_t {
   DevBuf<int> dFail;
   DevBuf<unsigned long long> dCount;
   double* hScal = nullptr;  // pinned
+  double* hPcg = nullptr;   // pinned: [S_DONE, S_TARGET, S_ITERS, -] per in-flight PCG batch
+  hipEvent_t pcgEvent[2] = {nullptr, nullptr};
 
   // results
   cvd_solve_summary summary{};
@@ -302,6 +305,8 @@ struct cvd_handle_t {
   int timing = 0;  // bit mask of KernelClass values to time with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
   std::vector<int> evClass;
+  std::vector<int> evIter;  // PCG iteration the launch belongs to (-1 outside PCG): launches enqueued past
+  int curPcgIter = -1;      // convergence are no-ops and are dropped from the statistics (tDropFrom)
   size_t evUsed = 0;
   double kcMs[KC_COUNT] = {0};
   long long kcN[KC_COUNT] = {0};
@@ -310,6 +315,8 @@ struct cvd_handle_t {
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
+    if (hPcg) (void)hipHostFree(hPcg);
+    for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -326,18 +333,25 @@ struct cvd_handle_t {
       HIP_CHECK(hipEventCreate(&b));
       evPool.emplace_back(a, b);
       evClass.push_back(kc);
+      evIter.push_back(-1);
     }
     evClass[evUsed] = kc;
+    evIter[evUsed] = curPcgIter;
     HIP_CHECK(hipEventRecord(evPool[evUsed].first, stream));
     return static_cast<int>(evUsed++);
   }
   void tEnd(int slot) {
     if (slot >= 0) HIP_CHECK(hipEventRecord(evPool[slot].second, stream));
   }
+  void tDropFrom(size_t firstSlot, int firstDeadIter) {
+    for (size_t i = firstSlot; i < evUsed; ++i)
+      if (evIter[i] >= firstDeadIter) evClass[i] = -1;
+  }
   void tCollect() {
     if (!timing || evUsed == 0) return;
     HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t i = 0; i < evUsed; ++i) {
+      if (evClass[i] < 0) continue;
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, evPool[i].first, evPool[i].second));
       kcMs[evClass[i]] += ms;
@@ -653,6 +667,9 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
   h->dItemFa.upload(h->itemFa.data(), h->itemFa.size(), s);
   h->dItemFb.upload(h->itemFb.data(), h->itemFb.size(), s);
   h->dItemRange.upload(h->itemRange.data(), h->itemRange.size(), s);
+  std::vector<int> itemSlot(fiList.size(), 0);  // [item * 2 + side] -> row of the partial-product buffer
+  for (size_t e = 0; e < fiList.size(); ++e) itemSlot[fiList[e]] = static_cast<int>(e);
+  h->dItemSlot.upload(itemSlot.data(), itemSlot.size(), s);
   h->dFiOff.upload(fiOff.data(), fiOff.size(), s);
   h->dFiList.upload(fiList.data(), fiList.size(), s);
   h->dFpOff.upload(fpOff.data(), fpOff.size(), s);
@@ -737,6 +754,10 @@ static void ensureBuffers(Ctx& c) {
     HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 4 * sizeof(unsigned int), h->stream));
   }
   if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
+  if (!h->hPcg) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hPcg), 8 * sizeof(double)));
+    for (auto& e : h->pcgEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
 }
 
 static void launchFrameConsts(Ctx& c, const double* x) {
@@ -790,12 +811,12 @@ static double evalFull(Ctx& c, const double* x) {
   const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
   if (fast && c.KD == 4) {
     allowLds(k_assemble_fast<4>, ldsFast);
-    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(256), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                        h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
                        h->dFocal.p, h->dFocal.p + c.L.F);
   } else if (fast) {
     allowLds(k_assemble_fast<1>, ldsFast);
-    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(256), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                        h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
                        h->dFocal.p, h->dFocal.p + c.L.F);
   } else {
@@ -841,6 +862,7 @@ static void prepareMatvec(Ctx& c, const double* x) {
   h->dRegCol.ensure(entries);
   h->dRegCnt.ensure(static_cast<size_t>(L.F) * std::max(nr, 1));
   h->regCache = RegCache{h->dRegJac.p, h->dRegCol.p, h->dRegCnt.p, nr, stride};
+  HIP_CHECK(hipMemsetAsync(h->dScal.p + S_DONE, 0, sizeof(double), h->stream));
   if (nr == 0) return;
   CVD_DISPATCH_KD(c.KD, {
     hipLaunchKernelGGL((k_reg_cache<KD>), dim3(L.F), dim3(256), 0, h->stream, L, x, h->dMedian.p, h->dRegOwner.p,
@@ -939,35 +961,50 @@ static int runPcg(Ctx& c, const double* x) {
   const int nThreads = 256 * nChunks;
   double* fd = h->dFdot.p;
   const size_t ldsU = (B + nThreads + 48) * 8;
+  const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
-                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
+                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2);
   HIP_CHECK(hipGetLastError());
-  readScalars(c);
-  const double rz0 = h->hScal[S_RZ0];
-  if (!(rz0 > 0.0)) return 0;
-  const double target = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance * rz0;
   double* pOld = h->dP0.p;
   double* pNew = h->dP1.p;
-  int k = 0;
   const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
   const int every = std::max(1, c.h->opt.pcg_check_every);
-  while (k < maxIt) {
-    launchMatvec(c, x, h->dZ.p, pOld, pNew, k > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
-    const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F);
-    HIP_CHECK(hipGetLastError());
-    h->tEnd(slot);
-    std::swap(pOld, pNew);
-    ++k;
-    if (k % every == 0 || k == maxIt) {
-      readScalars(c);
-      const double rz = h->hScal[S_RZ];
-      if (!(rz == rz)) throw std::runtime_error("PCG produced NaN");
-      if (rz <= target) break;
+  // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
+  // batches of `every` iterations and reads the control scalars of batch b only before enqueuing batch b + 2, so
+  // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
+  constexpr int kSlots = 2;
+  const size_t firstTimerSlot = h->evUsed;
+  int enq = 0, batch = 0;
+  bool stop = false;
+  while (!stop) {
+    if (batch >= kSlots) {
+      const int sl = batch % kSlots;
+      HIP_CHECK(hipEventSynchronize(h->pcgEvent[sl]));
+      if (h->hPcg[sl * 4 + 0] != 0.0) break;
     }
+    if (enq >= maxIt) break;
+    const int n = std::min(every, maxIt - enq);
+    for (int i = 0; i < n; ++i, ++enq) {
+      h->curPcgIter = enq;
+      launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
+      const int slot = h->tBegin(KC_CG_UPDATE);
+      hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
+                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2);
+      HIP_CHECK(hipGetLastError());
+      h->tEnd(slot);
+      std::swap(pOld, pNew);
+    }
+    const int sl = batch % kSlots;
+    HIP_CHECK(hipMemcpyAsync(h->hPcg + sl * 4, h->dScal.p + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(h->pcgEvent[sl], s));
+    ++batch;
   }
-  return k;
+  h->curPcgIter = -1;
+  readScalars(c);  // drains the stream; S_DONE / S_ITERS are final
+  if (h->hScal[S_DONE] == 2.0) throw std::runtime_error("PCG produced NaN");
+  const int iters = static_cast<int>(h->hScal[S_ITERS]);
+  h->tDropFrom(firstTimerSlot, iters);
+  return iters;
 }
 
 static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
@@ -986,7 +1023,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   }
   c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
   c.nItems = static_cast<int>(h->itemFa.size());
-  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, c.nItems};
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   ensureBuffers(c);
@@ -1018,8 +1055,10 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   sum.initial_cost = xCost;
 
   auto stats = [&]() {
-    hipLaunchKernelGGL(k_step_stats, dim3(1), dim3(256), 0, s, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
-                       h->dX.p, h->dHd.p, h->dScal.p);
+    const int G = static_cast<int>(std::min<size_t>(128, (c.n + 511) / 512));
+    h->dStatPart.ensure(6 * 128);
+    hipLaunchKernelGGL(k_step_stats, dim3(G), dim3(256), 0, s, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
+                       h->dX.p, h->dHd.p, h->dScal.p, h->dStatPart.p, h->dCounters.p + 2);
     HIP_CHECK(hipGetLastError());
     readScalars(c);
   };
@@ -1272,7 +1311,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   }
   c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
   c.nItems = static_cast<int>(h->itemFa.size());
-  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, c.nItems};
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);

@@ -35,12 +35,17 @@ struct Items {
   const int* fa;
   const int* fb;
   const long long* range;  // 4 per item
+  const int* slot;         // 2 per item: rows of the partial-product buffer (frame-major, see k_matvec_finish)
   int count;
 };
 
 // scalar slots kept on the device during PCG
 enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5, S_RZ0 = 6, S_COST = 7,
-             S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14, S_COUNT = 16 };
+             S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14,
+             // PCG control, owned by the device: S_DONE 0 running / 1 converged / 2 NaN, S_TARGET = tol^2 rz0,
+             // S_ITERS = iterations applied.  Every kernel of an iteration returns at once when S_DONE is set, so
+             // the host may enqueue iterations ahead of the convergence test without changing the result.
+             S_DONE = 15, S_TARGET = 16, S_ITERS = 17, S_COUNT = 20 };
 
 // Sum of a short global array (F per-frame partials, L2-resident) by every workgroup that needs the scalar:
 // cheaper than a separate 1-block reduction kernel + its launch boundary. `red` = 4 doubles of LDS.
@@ -716,6 +721,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
                                                       const double* __restrict__ pOld,
                                                       const double* __restrict__ scal, int useBeta,
                                                       double* __restrict__ qPart) {
+  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xa = sm;
@@ -815,10 +821,12 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
   }
   }  // dir
   __syncthreads();
-  double* out = qPart + static_cast<size_t>(item) * 2 * B;
+  // rows are grouped by frame (slot = position in the frame's item list) so that k_matvec_finish streams them
+  double* outA = qPart + static_cast<size_t>(it.slot[item * 2]) * B;
+  double* outB = qPart + static_cast<size_t>(it.slot[item * 2 + 1]) * B;
   for (int i = tid; i < B; i += 256) {
-    out[i] = qa[i];
-    out[B + i] = qb[i];
+    outA[i] = qa[i];
+    outB[i] = qb[i];
   }
 }
 
@@ -869,6 +877,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nItems, RegCache rc) {
+  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -886,10 +895,19 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     pf[i] = pv * mask[base + i];
     double acc = 0.0;
     if (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) {  // (stale partial buffer without a pair kernel)
-      for (int e = fiOff[f]; e < fiOff[f + 1]; ++e) {
-        const int code = fiList[e];
-        acc += qPart[(static_cast<size_t>(code >> 1) * 2 + (code & 1)) * B + i];
+      // the frame's partial rows are contiguous: independent streaming loads, four in flight per thread
+      const int e0 = fiOff[f], e1 = fiOff[f + 1];
+      const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int e = e0;
+      for (; e + 3 < e1; e += 4, rowp += 4 * B) {
+        a0 += rowp[0];
+        a1 += rowp[B];
+        a2 += rowp[2 * B];
+        a3 += rowp[3 * B];
       }
+      for (; e < e1; ++e, rowp += B) a0 += rowp[0];
+      acc = (a0 + a1) + (a2 + a3);
     }
     qf[i] = acc;
   }
@@ -965,6 +983,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
 __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                 double* __restrict__ fdot) {
+  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   __shared__ double red[8];
   const int f = blockIdx.x, tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * L.B;
@@ -992,8 +1011,10 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     const double* __restrict__ q, double* __restrict__ scal,
                                                     unsigned int* __restrict__ counter, double* __restrict__ dx,
                                                     double* __restrict__ r, double* __restrict__ z,
-                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR) {
+                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
+                                                    double tol2) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
   const int B = L.B;
   const int nThreads = blockDim.x;
   double* rf = sm;                 // B
@@ -1069,10 +1090,16 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
         scal[S_RZ0] = rzs;
         scal[S_RZOLD] = rzs;
         scal[S_BETA] = 0.0;
+        scal[S_TARGET] = tol2 * rzs;
+        scal[S_ITERS] = 0.0;
+        scal[S_DONE] = (rzs == rzs) ? ((rzs > 0.0) ? 0.0 : 1.0) : 2.0;
       } else {
         const double old = scal[S_RZ];
         scal[S_RZOLD] = old;
         scal[S_BETA] = (old != 0.0) ? rzs / old : 0.0;
+        scal[S_ITERS] += 1.0;
+        if (!(rzs == rzs)) scal[S_DONE] = 2.0;
+        else if (rzs <= scal[S_TARGET]) scal[S_DONE] = 1.0;
       }
       scal[S_RZ] = rzs;
       scal[S_RR] = rrs;
@@ -1080,41 +1107,18 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   }
 }
 
-// One block: rz_old <- rz, rz <- sum, beta = rz / rz_old (or rz0 <- rz at init).
-__global__ __launch_bounds__(256) void k_cg_scalars(int F, int init, const double* __restrict__ fdotRZ,
-                                                    const double* __restrict__ fdotRR, double* __restrict__ scal) {
-  __shared__ double red[8];
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < F; i += 256) { a += fdotRZ[i]; b += fdotRR[i]; }
-  a = waveSum(a);
-  b = waveSum(b);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double rz = red[0] + red[1] + red[2] + red[3];
-    const double rr = red[4] + red[5] + red[6] + red[7];
-    if (init) {
-      scal[S_RZ0] = rz;
-      scal[S_RZOLD] = rz;
-      scal[S_BETA] = 0.0;
-    } else {
-      const double old = scal[S_RZ];
-      scal[S_RZOLD] = old;
-      scal[S_BETA] = (old != 0.0) ? rz / old : 0.0;
-    }
-    scal[S_RZ] = rz;
-    scal[S_RR] = rr;
-  }
-}
-
 // Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|.
 __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ dx,
                                                     const double* __restrict__ g, const double* __restrict__ r,
                                                     const double* __restrict__ lam, const double* __restrict__ x,
-                                                    const double* __restrict__ hdiagActive, double* __restrict__ scal) {
+                                                    const double* __restrict__ hdiagActive, double* __restrict__ scal,
+                                                    double* __restrict__ part, unsigned int* __restrict__ counter) {
+  // gridDim.x workgroups stride over the vector; the last one to arrive folds the per-workgroup partials
   __shared__ double red[6][4];
+  __shared__ int flag;
+  const int G = gridDim.x;
   double a[6] = {0, 0, 0, 0, 0, 0};
-  for (size_t i = threadIdx.x; i < n; i += 256) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(G) * 256) {
     const double d = dx[i];
     a[0] += d * g[i];
     a[1] += d * r[i];
@@ -1129,6 +1133,25 @@ __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __re
   for (int off = 32; off > 0; off >>= 1) a[5] = fmax(a[5], __shfl_xor(a[5], off, 64));
   if ((threadIdx.x & 63) == 0)
     for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 6] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    part[k * G + blockIdx.x] = (k < 5) ? (red[k][0] + red[k][1]) + (red[k][2] + red[k][3])
+                                       : fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
+  }
+  if (!lastBlockArrives(counter, G, &flag)) return;
+  double t[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < G; b += 256) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] += part[k * G + b];
+    t[5] = fmax(t[5], part[5 * G + b]);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) t[k] = waveSum(t[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t[5] = fmax(t[5], __shfl_xor(t[5], off, 64));
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 6] = t[k];
   __syncthreads();
   if (threadIdx.x == 0) {
     scal[S_DG] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -1201,6 +1224,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
                                                            const double* __restrict__ scal, int useBeta,
                                                            double* __restrict__ qPart) {
+  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
   constexpr double eps = 1e-6;
@@ -1480,10 +1504,12 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   }
   __syncthreads();
   { double* t = qa; qa = qb; qb = t; }  // undo the role swap
-  double* out = qPart + static_cast<size_t>(item) * 2 * B;
+  // rows are grouped by frame (slot = position in the frame's item list) so that k_matvec_finish streams them
+  double* outA = qPart + static_cast<size_t>(it.slot[item * 2]) * B;
+  double* outB = qPart + static_cast<size_t>(it.slot[item * 2 + 1]) * B;
   for (int i = tid; i < B; i += 256) {
-    out[i] = qa[i];
-    out[B + i] = qb[i];
+    outA[i] = qa[i];
+    outB[i] = qb[i];
   }
 }
 
@@ -1498,8 +1524,10 @@ namespace cvd {
 // kernel needs neither scratch nor 256 VGPRs.  Accumulation: 7x7 + gradient in registers (wave-reduced at
 // the end), pose x grid and grid x grid through LDS f64 atomics into the packed lower triangle.
 // =====================================================================================================
+constexpr int kAsmThreads = 512;  // 8 waves per frame: two per SIMD at 256 VGPRs
+
 template <int KD>
-__global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
+__global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ regOwner,
@@ -1518,11 +1546,16 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   double* Hs = sm;
   double* gs = Hs + npk;
   double* xf = gs + B;
-  double* red = xf + B;  // 4 * 36
+  double* red = xf + B;  // 36 workgroup sums (LDS atomics, one set per wave) + scratch
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
-  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
-  for (int i = tid; i < B; i += 256) {
+  constexpr int NT = kAsmThreads;
+  // wave-uniform wave index (scalar register: the per-entry frame constants below become scalar loads)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  for (int i = tid; i < npk; i += NT) Hs[i] = 0.0;
+  if (tid < 48) red[tid] = 0.0;
+  for (int i = tid; i < B; i += NT) {
     gs[i] = 0.0;
     xf[i] = x[static_cast<size_t>(f) * B + i];
   }
@@ -1544,7 +1577,9 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   const double A = L.aspect;
 
   if (L.includeStatic) {
-    for (int e = fpOff[f]; e < fpOff[f + 1]; ++e) {
+    // one (pair, side) entry per WAVE at a time: the waves run through their entries independently (no barrier
+    // until the end), 64 lanes over the pair's constraints
+    for (int e = fpOff[f] + wv; e < fpOff[f + 1]; e += NT / 64) {
       const int code = fpList[e];
       const int p = code >> 1;
       const int side = code & 1;  // 0: f is the source of pair p, 1: f is the target
@@ -1557,7 +1592,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
       const double fya = Fa.fy, fxa = Fa.fy * A;
       const double fyb = Fb.fy;
       const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
-      for (long long c = T.pairOff[p] + tid; c < T.pairOff[p + 1]; c += 256) {
+      for (long long c = T.pairOff[p] + lane; c < T.pairOff[p + 1]; c += 64) {
         const float2 d = T.dsrc[c];
         if (!(d.x > 0.f)) continue;
         const float4 nd = T.ndc[c];
@@ -1771,7 +1806,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
       if (N > 0) {
 #pragma unroll
         for (int i = 0; i < 19; ++i) GD[i] = waveSum(GD[i]);
-        if ((tid & 63) == 0) {
+        if (lane == 0) {
           for (int a = 0; a < N; ++a) {
             const int ct = 7 + a;
             for (int i = 0; i < 7; ++i) atomicAdd(&Hs[ct * (ct + 1) / 2 + i], GD[a * 7 + i]);
@@ -1782,13 +1817,12 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
         }
       }
     }
-    const int wv = tid >> 6;
-    if ((tid & 63) == 0) {
+    if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 28; ++i) red[wv * 36 + i] = PP[i];
+      for (int i = 0; i < 28; ++i) atomicAdd(&red[i], PP[i]);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) red[wv * 36 + 28 + i] = gp[i];
-      red[wv * 36 + 35] = cost;
+      for (int i = 0; i < 7; ++i) atomicAdd(&red[28 + i], gp[i]);
+      atomicAdd(&red[35], cost);
     }
   }
   __syncthreads();
@@ -1796,12 +1830,12 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
     int i = 0;
     while ((i + 1) * (i + 2) / 2 <= tid) ++i;
     const int j = tid - i * (i + 1) / 2;
-    Hs[packedIdx(i, j)] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+    Hs[packedIdx(i, j)] += red[tid];
   } else if (tid < 35) {
-    gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+    gs[tid - 28] += red[tid];
   }
   __syncthreads();
-  const double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
+  const double staticCost = 0.5 * red[35];
   __syncthreads();
   if (L.intrOpt == kIntrShared) {
     // The focal column of every constraint belongs to frame 0's slot: publish this frame's static focal
@@ -1809,16 +1843,18 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
     // they are off-diagonal couplings with frame 0, which the block-Jacobi preconditioner does not hold).
     shG = waveSum(shG);
     shH = waveSum(shH);
-    if ((tid & 63) == 0) { red[tid >> 6] = shG; red[4 + (tid >> 6)] = shH; }
+    if (lane == 0) { red[wv] = shG; red[16 + wv] = shH; }
     __syncthreads();
     if (tid == 0) {
-      focalG[f] = red[0] + red[1] + red[2] + red[3];
-      focalH[f] = red[4] + red[5] + red[6] + red[7];
+      double sg = 0.0, sh = 0.0;
+      for (int w = 0; w < NT / 64; ++w) { sg += red[w]; sh += red[16 + w]; }
+      focalG[f] = sg;
+      focalH[f] = sh;
       gs[6] = 0.0;
       Hs[packedIdx(6, 6)] = 0.0;
     }
     if (f != 0) {
-      for (int j = tid; j < B; j += 256)
+      for (int j = tid; j < B; j += NT)
         if (j != 6) Hs[j > 6 ? packedIdx(j, 6) : packedIdx(6, j)] = 0.0;
     }
     __syncthreads();
@@ -1827,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   double regCost = 0.0;
   if (regOwner[f]) {
     const int nr = numRegResiduals<KD>(L);
-    for (int i = tid; i < nr; i += 256) {
+    for (int i = tid; i < nr; i += NT) {
       double r;
       int n;
       int cols[2 * KD + 2];
@@ -1855,14 +1891,18 @@ __global__ __launch_bounds__(256) void k_assemble_fast(Layout L, Table T, const 
   }
   regCost = waveSum(regCost);
   __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = regCost;
+  if (lane == 0) red[wv] = regCost;
   __syncthreads();
-  if (tid == 0) costFrame[f] = staticCost + 0.5 * (red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0) {
+    double rc = 0.0;
+    for (int w = 0; w < NT / 64; ++w) rc += red[w];
+    costFrame[f] = staticCost + 0.5 * rc;
+  }
 
   const double* mf = mask + static_cast<size_t>(f) * B;
-  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
+  for (int i = tid; i < B; i += NT) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
   double* hf = hOut + static_cast<size_t>(f) * B * B;
-  for (int idx = tid; idx < B * B; idx += 256) {
+  for (int idx = tid; idx < B * B; idx += NT) {
     const int i = idx / B, j = idx - i * B;
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
