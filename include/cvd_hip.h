@@ -31,6 +31,9 @@ typedef struct cvd_solver_options {
   int32_t pcg_check_every;       /* host convergence check cadence in CG iterations (default 4) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
+  int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve
+                                    (8 unknowns per frame, up to 512 frames); 0: block-Jacobi only */
+  int32_t reserved;
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -121,6 +124,11 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6)
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
 /* Number of (valid static) constraints in the compiled table of the last solve. */
 int64_t cvd_num_active_constraints(cvd_handle* h);
+/* Test hook for the coarse level of the preconditioner (state of the last LM iteration of the last solve):
+ * n = 8 * frames (0 when the level was off), a_c = Z^T (J^T J + diag(lam)) Z as a dense n x n matrix assembled
+ * from its blocks, a_c_inverse = the inverse the solver applied, failed = pivot failures of the factorisation.
+ * Any output pointer may be NULL. */
+int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 
 #ifdef __cplusplus
 }

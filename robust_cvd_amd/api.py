@@ -22,6 +22,8 @@ class SolverOptions(C.Structure):
         ("pcg_check_every", C.c_int32),
         ("verbose", C.c_int32),
         ("force_iterations", C.c_int32),
+        ("coarse_level", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -52,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints",
+    "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
 ]
 
 KERNEL_CLASSES = ["evaluate_assemble", "matvec_pairs", "matvec_finish", "cg_update", "block_inverse", "cost"]
@@ -67,7 +69,7 @@ class Solver(Binding):
         super().__init__(lib, "cvd_", handle)
 
     def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None,
-                    force_iterations=None):
+                    force_iterations=None, coarse_level=None):
         o = SolverOptions()
         self._lib.cvd_solver_options_default(C.byref(o))
         if pcg_relative_tolerance is not None:
@@ -80,6 +82,8 @@ class Solver(Binding):
             o.verbose = int(verbose)
         if force_iterations is not None:
             o.force_iterations = int(force_iterations)
+        if coarse_level is not None:
+            o.coarse_level = int(coarse_level)
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
 
     @staticmethod
@@ -114,3 +118,17 @@ class Solver(Binding):
 
     def num_active_constraints(self):
         return int(self._lib.cvd_num_active_constraints(self._h))
+
+    def coarse_debug(self):
+        """(A_c, A_c^-1 as applied, pivot failures) of the coarse preconditioner level after the last solve."""
+        import numpy as np
+        n = C.c_int32(0)
+        self._check(self._fn("coarse_debug")(self._h, C.byref(n), None, None, None))
+        if n.value == 0:
+            return None
+        a = np.zeros((n.value, n.value))
+        ai = np.zeros((n.value, n.value))
+        fl = C.c_int32(0)
+        self._check(self._fn("coarse_debug")(self._h, C.byref(n), a.ctypes.data_as(C.POINTER(C.c_double)),
+                                             ai.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fl)))
+        return {"a_c": a, "a_c_inverse": ai, "failed": fl.value}

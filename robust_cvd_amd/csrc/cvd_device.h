@@ -666,6 +666,16 @@ __device__ __forceinline__ void posRegFrame(const Layout& L, const unsigned char
   }
 }
 
+// Coarse level of the two-level preconditioner (cvd_coarse.h): kCB modes per frame, the 7 pose-like unknowns and
+// one "every depth-scale vertex moves together" mode.  coarseAt = (Z c)_i for unknown i of frame f.
+constexpr int kCB = 8;
+__device__ __forceinline__ double coarseAt(const double* __restrict__ cF, const Layout& L, int f, int i) {
+  if (cF == nullptr) return 0.0;
+  if (i < 7) return cF[f * kCB + i];
+  if (L.N >= 1 && L.depthType != kDepthIdentity && i < 7 + L.nD && (L.N == 1 || ((i - 7) % L.N) == 0)) return cF[f * kCB + 7];
+  return 0.0;
+}
+
 // Wave-level sum of a double (64 lanes), result in every lane.  Four DPP butterfly steps inside each 16-lane row
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS traffic), then the four row sums are combined
 // through v_readlane.

@@ -25,12 +25,14 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/cvd_hip.h"
 #include "cvd_kernels.h"
+#include "cvd_coarse.h"
 
 namespace cvd {
 
@@ -284,6 +286,20 @@ struct cvd_handle_t {
   DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
   DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
+
+  // coarse (pose-graph) level of the two-level preconditioner (cvd_coarse.h)
+  struct CoarseHost {
+    bool valid = false;   // plan built for the current table
+    int nEdges = 0, nBlocks = 0, nLevels = 0;
+    std::vector<int> itemEdge;
+    DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr,
+        updA, updB, edgeBlk, edgeFa, edgeFb, posLevel, itemEdgeDev;
+    DevBuf<double> edges, edgesUsed, diag, Lb, Linv, Ainv, rc, part, c;  // edgesUsed: snapshot the factor was built from
+    DevBuf<unsigned char> modeActive;
+    DevBuf<int> fail;
+    CoarsePlan plan{};
+  } coarse;
+  bool coarseOn = false;  // this solve uses the coarse level
   DevBuf<double> dRegJac;  // regulariser Jacobian rows of the current linearisation point (RegCache)
   DevBuf<unsigned short> dRegCol;
   DevBuf<unsigned char> dRegCnt;
@@ -591,6 +607,145 @@ static void allowLds(K kernel, size_t bytes) {
   }
 }
 
+// ---- coarse level: symbolic block-sparse Cholesky of the frame graph (cvd_coarse.h) --------------------------
+// Greedy minimum-degree ordering on the frame graph, column structures with fill, left-looking update lists and
+// the level schedule (level of a column = 1 + the highest level among the columns that update it).
+static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>>& edgeList,
+                            const std::vector<int>& itemEdge) {
+  auto& C = h->coarse;
+  const int F = h->F;
+  hipStream_t s = h->stream;
+  std::vector<std::set<int>> adj(F);
+  for (const auto& e : edgeList) {
+    adj[e.first].insert(e.second);
+    adj[e.second].insert(e.first);
+  }
+  // minimum degree (ties: lowest frame), elimination graph with fill
+  std::vector<int> order, pos(F, -1);
+  std::vector<std::vector<int>> structFrames(F);  // by position: neighbours (frames) alive at elimination
+  {
+    std::vector<std::set<int>> g = adj;
+    std::vector<char> alive(F, 1);
+    for (int step = 0; step < F; ++step) {
+      int best = -1;
+      size_t bestDeg = 0;
+      for (int v = 0; v < F; ++v)
+        if (alive[v] && (best < 0 || g[v].size() < bestDeg)) { best = v; bestDeg = g[v].size(); }
+      const int v = best;
+      pos[v] = step;
+      order.push_back(v);
+      std::vector<int> nb(g[v].begin(), g[v].end());
+      structFrames[step] = nb;
+      for (int a : nb) {
+        g[a].erase(v);
+        for (int b : nb)
+          if (a != b) g[a].insert(b);
+      }
+      alive[v] = 0;
+      g[v].clear();
+    }
+  }
+  // column structures by position (sorted), block ids
+  std::vector<int> colPtr(F + 1, 0), blkCol, blkRow;
+  std::vector<std::vector<int>> colRows(F);
+  for (int j = 0; j < F; ++j) {
+    for (int fr : structFrames[j]) colRows[j].push_back(pos[fr]);
+    std::sort(colRows[j].begin(), colRows[j].end());
+    colPtr[j + 1] = colPtr[j] + static_cast<int>(colRows[j].size());
+  }
+  const int nnz = colPtr[F];
+  const int nBlocks = F + nnz;
+  blkCol.assign(nBlocks, 0);
+  blkRow.assign(nBlocks, 0);
+  std::map<std::pair<int, int>, int> blockOf;  // (row position, column position) -> block id
+  for (int j = 0; j < F; ++j) {
+    blkCol[j] = j;
+    blkRow[j] = j;
+    blockOf[{j, j}] = j;
+    for (size_t e = 0; e < colRows[j].size(); ++e) {
+      const int b = F + colPtr[j] + static_cast<int>(e);
+      blkCol[b] = j;
+      blkRow[b] = colRows[j][e];
+      blockOf[{colRows[j][e], j}] = b;
+    }
+  }
+  // row structures and levels
+  std::vector<std::vector<int>> rowBlks(F);
+  for (int b = F; b < nBlocks; ++b) rowBlks[blkRow[b]].push_back(b);
+  std::vector<int> level(F, 0);
+  for (int j = 0; j < F; ++j)
+    for (int b : rowBlks[j]) level[j] = std::max(level[j], level[blkCol[b]] + 1);
+  const int nLevels = F ? *std::max_element(level.begin(), level.end()) + 1 : 0;
+  std::vector<int> rowPtr(F + 1, 0), rowBlk;
+  for (int j = 0; j < F; ++j) {
+    std::sort(rowBlks[j].begin(), rowBlks[j].end(), [&](int a, int b) { return blkCol[a] < blkCol[b]; });
+    rowPtr[j + 1] = rowPtr[j] + static_cast<int>(rowBlks[j].size());
+    rowBlk.insert(rowBlk.end(), rowBlks[j].begin(), rowBlks[j].end());
+  }
+  // update lists: column k contributes L(i,k) L(j,k)^T to block (i, j) for every i >= j in struct(k)
+  std::vector<std::vector<std::pair<int, int>>> upd(nBlocks);
+  for (int k = 0; k < F; ++k) {
+    const auto& rows = colRows[k];
+    for (size_t a = 0; a < rows.size(); ++a)
+      for (size_t b = a; b < rows.size(); ++b) {
+        const int j = rows[a], i = rows[b];  // i >= j
+        const int target = blockOf.at({i, j});
+        upd[target].push_back({F + colPtr[k] + static_cast<int>(b), F + colPtr[k] + static_cast<int>(a)});
+      }
+  }
+  std::vector<int> updPtr(nBlocks + 1, 0), updA, updB;
+  for (int b = 0; b < nBlocks; ++b) {
+    updPtr[b + 1] = updPtr[b] + static_cast<int>(upd[b].size());
+    for (const auto& u : upd[b]) { updA.push_back(u.first); updB.push_back(u.second); }
+  }
+  std::vector<int> levelPtr(nLevels + 1, 0), levelCols, lvlBlkPtr(nLevels + 1, 0), lvlBlks;
+  for (int lv = 0; lv < nLevels; ++lv) {
+    for (int j = 0; j < F; ++j)
+      if (level[j] == lv) {
+        levelCols.push_back(j);
+        lvlBlks.push_back(j);
+        for (int e = colPtr[j]; e < colPtr[j + 1]; ++e) lvlBlks.push_back(F + e);
+      }
+    levelPtr[lv + 1] = static_cast<int>(levelCols.size());
+    lvlBlkPtr[lv + 1] = static_cast<int>(lvlBlks.size());
+  }
+  std::vector<int> edgeBlk, edgeFa, edgeFb;
+  for (const auto& e : edgeList) {
+    const int pa = pos[e.first], pb = pos[e.second];
+    // stored rows = fa, columns = fb; block (i, j), i > j, has rows = frame of position i
+    const int b = blockOf.at({std::max(pa, pb), std::min(pa, pb)});
+    edgeBlk.push_back((b << 1) | (pa > pb ? 0 : 1));
+    edgeFa.push_back(e.first);
+    edgeFb.push_back(e.second);
+  }
+  C.nEdges = static_cast<int>(edgeList.size());
+  C.nBlocks = nBlocks;
+  C.nLevels = nLevels;
+  C.itemEdge = itemEdge;
+  auto up = [&](DevBuf<int>& d, const std::vector<int>& v) { d.upload(v.data(), v.size(), s); };
+  up(C.order, order); up(C.pos, pos); up(C.levelPtr, levelPtr); up(C.levelCols, levelCols);
+  up(C.lvlBlkPtr, lvlBlkPtr); up(C.lvlBlks, lvlBlks); up(C.blkCol, blkCol); up(C.blkRow, blkRow);
+  up(C.colPtr, colPtr); up(C.rowPtr, rowPtr); up(C.rowBlk, rowBlk); up(C.updPtr, updPtr); up(C.updA, updA);
+  up(C.updB, updB); up(C.edgeBlk, edgeBlk); up(C.edgeFa, edgeFa); up(C.edgeFb, edgeFb); up(C.posLevel, level);
+  up(C.itemEdgeDev, itemEdge);
+  const size_t n = static_cast<size_t>(F) * kCB;
+  C.edges.ensure(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
+  C.diag.ensure(static_cast<size_t>(F) * kCBB);
+  C.Lb.ensure(static_cast<size_t>(nBlocks) * kCBB);
+  C.Linv.ensure(static_cast<size_t>(F) * kCBB);
+  C.Ainv.ensure(n * n);
+  C.rc.ensure(n);
+  C.c.ensure(n);
+  C.part.ensure(n * kCoarseSlabs);
+  C.modeActive.ensure(n);
+  C.fail.ensure(1);
+  HIP_CHECK(hipStreamSynchronize(s));
+  C.plan = CoarsePlan{F, nBlocks, nLevels, C.nEdges, C.order.p, C.pos.p, C.levelPtr.p, C.levelCols.p, C.lvlBlkPtr.p,
+                      C.lvlBlks.p, C.blkCol.p, C.blkRow.p, C.colPtr.p, C.rowPtr.p, C.rowBlk.p, C.updPtr.p, C.updA.p,
+                      C.updB.p, C.edgeBlk.p, C.edgeFa.p, C.edgeFb.p};
+  C.valid = true;
+}
+
 // ---- compile the constraint table + work decomposition for a frame range -------------------------------
 static void compileTable(cvd_handle* h, const std::vector<int>& range) {
   std::vector<unsigned char> inRange(h->F, 0);
@@ -656,6 +811,22 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
       frameItems[fa].push_back(item * 2 + 0);
       frameItems[fb].push_back(item * 2 + 1);
     }
+  }
+  h->coarse.valid = false;
+  if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns && !h->itemFa.empty()) {
+    std::map<std::pair<int, int>, int> edgeId;
+    std::vector<std::pair<int, int>> edgeList;
+    std::vector<int> itemEdge(h->itemFa.size());
+    for (size_t i = 0; i < h->itemFa.size(); ++i) {
+      const std::pair<int, int> key{h->itemFa[i], h->itemFb[i]};
+      auto it = edgeId.find(key);
+      if (it == edgeId.end()) {
+        it = edgeId.insert({key, static_cast<int>(edgeList.size())}).first;
+        edgeList.push_back(key);
+      }
+      itemEdge[i] = it->second;
+    }
+    buildCoarsePlan(h, edgeList, itemEdge);
   }
   std::vector<int> fiOff(h->F + 1, 0), fiList, fpOff(h->F + 1, 0), fpList;
   for (int f = 0; f < h->F; ++f) {
@@ -750,8 +921,8 @@ static void ensureBuffers(Ctx& c) {
   h->dFc.ensure(c.L.F);
   h->dFail.ensure(1);
   if (!h->dCounters.p) {
-    h->dCounters.ensure(4);
-    HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 4 * sizeof(unsigned int), h->stream));
+    h->dCounters.ensure(8);
+    HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 8 * sizeof(unsigned int), h->stream));
   }
   if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
   if (!h->hPcg) {
@@ -832,6 +1003,20 @@ static double evalFull(Ctx& c, const double* x) {
                        h->dG.p, h->dH.p);
   HIP_CHECK(hipGetLastError());
   h->tEnd(slot);
+  if (h->coarseOn) {
+    // off-diagonal blocks of the coarse (pose-graph) matrix at this linearisation point
+    auto& C = h->coarse;
+    HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
+    const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_coarse_edges<KD, KS>, ldsE);
+      hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
+                         C.itemEdgeDev.p, C.edges.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    if (h->world > 1)
+      NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
+  }
   if (h->world > 1) {
     // the exchange step of the pair-sharded mode: one all-reduce of [g | H_ff | per-frame cost] per Jacobian evaluation
     NCCL_CHECK(ncclGroupStart());
@@ -851,6 +1036,8 @@ static double evalFull(Ctx& c, const double* x) {
 static void prepareMatvec(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
   const Layout& L = c.L;
+  // the per-frame constants must be those of x: a rejected LM step leaves the candidate's behind (evalCost)
+  launchFrameConsts(c, x);
   int nr = 0;
   if (L.scaleRegSqrt > 0.0) nr += L.sregX * L.sregY;
   if (L.focalRegSqrt > 0.0) nr += 1;
@@ -872,9 +1059,10 @@ static void prepareMatvec(Ctx& c, const double* x) {
 }
 
 static void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta,
-                         const double* lam, double* q) {
+                         const double* lam, double* q, bool withCoarse = false) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
+  const double* cF = withCoarse ? h->coarse.c.p : nullptr;  // z + Z c: the coarse part of the preconditioned residual
   const size_t B = c.L.B;
   if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8) * 8;
@@ -884,16 +1072,16 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     if (fast && c.KD == 4) {
       allowLds(k_matvec_pairs_fast<4>, ldsFast);
       hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
-                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
     } else if (fast) {
       allowLds(k_matvec_pairs_fast<1>, ldsFast);
       hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
-                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_matvec_pairs<KD, KS>, lds);
         hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
-                           h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p);
+                           h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
       });
     }
     HIP_CHECK(hipGetLastError());
@@ -906,7 +1094,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache);
+                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF);
     });
     HIP_CHECK(hipGetLastError());
     if (h->world > 1) {
@@ -946,6 +1134,23 @@ static void launchBlockInverse(Ctx& c) {
   HIP_CHECK(hipGetLastError());
 }
 
+// Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
+static void launchCoarseSetup(Ctx& c) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  auto& C = h->coarse;
+  HIP_CHECK(hipMemsetAsync(C.fail.p, 0, sizeof(int), s));
+  C.edgesUsed.ensure(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
+  HIP_CHECK(hipMemcpyAsync(C.edgesUsed.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB * sizeof(double),
+                           hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
+                     C.modeActive.p);
+  hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
+                     C.Linv.p, C.fail.p);
+  hipLaunchKernelGGL(k_coarse_inverse, dim3(c.L.F), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, C.posLevel.p, C.Ainv.p);
+  HIP_CHECK(hipGetLastError());
+}
+
 // PCG on (H + diag(lam)) dx = -g with the block-Jacobi preconditioner; returns iterations used.
 // Three launches per iteration (pairs product, per-frame finish, per-frame update).  alpha / beta live on
 // the device: the last workgroup of k_matvec_finish / k_cg_update reduces the per-frame partial dot products
@@ -962,8 +1167,18 @@ static int runPcg(Ctx& c, const double* x) {
   double* fd = h->dFdot.p;
   const size_t ldsU = (B + nThreads + 48) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
+  const bool coarse = h->coarseOn;
+  double* rc = coarse ? h->coarse.rc.p : nullptr;
+  const int nC = F * kCB;
+  auto coarseApply = [&](int init) {
+    // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
+    hipLaunchKernelGGL(k_coarse_apply, dim3((nC + 255) / 256, kCoarseSlabs), dim3(256), 0, s, nC, h->coarse.Ainv.p,
+                       h->coarse.rc.p, h->coarse.part.p, h->coarse.c.p, h->dScal.p, h->dCounters.p + 3,
+                       h->coarse.fail.p, h->coarse.modeActive.p, init, tol2);
+  };
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
-                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2);
+                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc);
+  if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
   double* pNew = h->dP1.p;
@@ -986,13 +1201,19 @@ static int runPcg(Ctx& c, const double* x) {
     const int n = std::min(every, maxIt - enq);
     for (int i = 0; i < n; ++i, ++enq) {
       h->curPcgIter = enq;
-      launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p);
+      launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p, coarse);
       const int slot = h->tBegin(KC_CG_UPDATE);
       hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2);
+                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc);
+      if (coarse) coarseApply(0);
       HIP_CHECK(hipGetLastError());
       h->tEnd(slot);
       std::swap(pOld, pNew);
+      if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
+        readScalars(c);
+        std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq, h->hScal[S_RZ],
+                    h->hScal[S_RZPART], h->hScal[S_ALPHA], h->hScal[S_BETA], h->hScal[S_PQ], h->hScal[S_DONE]);
+      }
     }
     const int sl = batch % kSlots;
     HIP_CHECK(hipMemcpyAsync(h->hPcg + sl * 4, h->dScal.p + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1026,6 +1247,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
+  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && c.nItems > 0 && !h->forceGeneric;
   ensureBuffers(c);
   buildMask(h, c.L, p, kind, range);
   uploadState(h, c.L, h->dX);
@@ -1107,6 +1329,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       {
         const int slot = h->tBegin(KC_INVERSE);
         launchBlockInverse(c);
+        if (h->coarseOn) launchCoarseSetup(c);
         h->tEnd(slot);
       }
       const int cgIters = runPcg(c, h->dX.p);
@@ -1313,6 +1536,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   c.nItems = static_cast<int>(h->itemFa.size());
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  h->coarseOn = false;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);
   uploadState(h, c.L, h->dX);
@@ -1438,6 +1662,8 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->pcg_check_every = 4;
   o->verbose = 0;
   o->force_iterations = 0;
+  o->coarse_level = 1;
+  o->reserved = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
 void cvd_comm_unique_id(uint8_t* out128) {
@@ -1649,5 +1875,46 @@ int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
   });
 }
 int64_t cvd_num_active_constraints(cvd_handle* h) { return h ? h->numValid : 0; }
+
+int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed) {
+  CVD_TRY(h, {
+    auto& C = h->coarse;
+    if (!C.valid || !h->coarseOn) {
+      *num_unknowns = 0;
+    } else {
+      const int F = h->F;
+      const size_t n = static_cast<size_t>(F) * kCB;
+      *num_unknowns = static_cast<int32_t>(n);
+      hipStream_t s = h->stream;
+      int fl = 0;
+      C.fail.download(&fl, 1, s);
+      if (a_c_inverse) C.Ainv.download(a_c_inverse, n * n, s);
+      std::vector<double> diag(static_cast<size_t>(F) * kCBB), edges(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
+      std::vector<unsigned char> act(n);
+      std::vector<int> efa(C.nEdges), efb(C.nEdges);
+      C.diag.download(diag.data(), diag.size(), s);
+      C.edgesUsed.download(edges.data(), static_cast<size_t>(C.nEdges) * kCBB, s);
+      C.modeActive.download(act.data(), n, s);
+      C.edgeFa.download(efa.data(), efa.size(), s);
+      C.edgeFb.download(efb.data(), efb.size(), s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (failed) *failed = fl;
+      if (a_c) {
+        std::fill(a_c, a_c + n * n, 0.0);
+        for (int f = 0; f < F; ++f)
+          for (int i = 0; i < kCB; ++i)
+            for (int j = 0; j < kCB; ++j) a_c[(static_cast<size_t>(f) * kCB + i) * n + f * kCB + j] = diag[static_cast<size_t>(f) * kCBB + i * kCB + j];
+        for (int e = 0; e < C.nEdges; ++e)
+          for (int i = 0; i < kCB; ++i)
+            for (int j = 0; j < kCB; ++j) {
+              double v = edges[static_cast<size_t>(e) * kCBB + i * kCB + j];
+              if (!act[efa[e] * kCB + i] || !act[efb[e] * kCB + j]) v = 0.0;
+              a_c[(static_cast<size_t>(efa[e]) * kCB + i) * n + efb[e] * kCB + j] = v;
+              a_c[(static_cast<size_t>(efb[e]) * kCB + j) * n + efa[e] * kCB + i] = v;
+            }
+      }
+    }
+  });
+}
 
 }  // extern "C"

@@ -45,7 +45,9 @@ enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5,
              // PCG control, owned by the device: S_DONE 0 running / 1 converged / 2 NaN, S_TARGET = tol^2 rz0,
              // S_ITERS = iterations applied.  Every kernel of an iteration returns at once when S_DONE is set, so
              // the host may enqueue iterations ahead of the convergence test without changing the result.
-             S_DONE = 15, S_TARGET = 16, S_ITERS = 17, S_COUNT = 20 };
+             S_DONE = 15, S_TARGET = 16, S_ITERS = 17,
+             S_RZPART = 18,  // block-Jacobi part of r^T z while the coarse level (cvd_coarse.h) is pending
+             S_COUNT = 20 };
 
 // Sum of a short global array (F per-frame partials, L2-resident) by every workgroup that needs the scalar:
 // cheaper than a separate 1-block reduction kernel + its launch boundary. `red` = 4 doubles of LDS.
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
                                                       const double* __restrict__ mask, const double* __restrict__ z,
                                                       const double* __restrict__ pOld,
                                                       const double* __restrict__ scal, int useBeta,
-                                                      double* __restrict__ qPart) {
+                                                      double* __restrict__ qPart, const double* __restrict__ cF) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -739,8 +741,8 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
     xa[i] = x[ia];
     xb[i] = x[ib];
-    pa[i] = (z[ia] + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    pa[i] = (z[ia] + coarseAt(cF, L, fa, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + coarseAt(cF, L, fb, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nItems, RegCache rc) {
+                                                       int distMode, int nItems, RegCache rc,
+                                                       const double* __restrict__ cF) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -889,7 +892,8 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   const size_t base = static_cast<size_t>(f) * B;
   for (int i = tid; i < B; i += 256) {
-    const double pv = z[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
+    // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
+    const double pv = z[base + i] + coarseAt(cF, L, f, i) * mask[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
     pNew[base + i] = pv;
     xf[i] = x[base + i];
     pf[i] = pv * mask[base + i];
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
       double a = 0.0;
       for (int j = 0; j < 3; ++j) {
         const size_t idx = static_cast<size_t>(k + j) * B + tid;
-        a += cf[j] * (z[idx] + (useBeta ? beta * pOld[idx] : 0.0)) * mask[idx];
+        a += cf[j] * (z[idx] + coarseAt(cF, L, k + j, tid) + (useBeta ? beta * pOld[idx] : 0.0)) * mask[idx];
       }
       acc += w * cf[o] * a;
     }
@@ -1002,6 +1006,27 @@ __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restri
   }
 }
 
+// PCG scalars after the preconditioner has been applied (shared by k_cg_update and, with the coarse level, k_coarse_apply).
+__device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int init, double rzs, double rrs, double tol2) {
+  if (init) {
+    scal[S_RZ0] = rzs;
+    scal[S_RZOLD] = rzs;
+    scal[S_BETA] = 0.0;
+    scal[S_TARGET] = tol2 * rzs;
+    scal[S_ITERS] = 0.0;
+    scal[S_DONE] = (rzs == rzs) ? ((rzs > 0.0) ? 0.0 : 1.0) : 2.0;
+  } else {
+    const double old = scal[S_RZ];
+    scal[S_RZOLD] = old;
+    scal[S_BETA] = (old != 0.0) ? rzs / old : 0.0;
+    scal[S_ITERS] += 1.0;
+    if (!(rzs == rzs)) scal[S_DONE] = 2.0;
+    else if (rzs <= scal[S_TARGET]) scal[S_DONE] = 1.0;
+  }
+  scal[S_RZ] = rzs;
+  scal[S_RR] = rrs;
+}
+
 // alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
 // partial r.z and r.r.  One workgroup per frame with 256 threads per 64-row chunk (blockDim = 256 * ceil(B/64),
 // B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
@@ -1012,7 +1037,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     unsigned int* __restrict__ counter, double* __restrict__ dx,
                                                     double* __restrict__ r, double* __restrict__ z,
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
-                                                    double tol2) {
+                                                    double tol2, double* __restrict__ rc) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
   const int B = L.B;
@@ -1037,6 +1062,17 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
     rf[j] = rv;
   }
   __syncthreads();
+  if (rc != nullptr) {
+    // restriction to the coarse level: Z_f^T r_f (the 7 pose-like entries and the sum over the depth-scale vertices)
+    if (tid < 7) rc[f * kCB + tid] = rf[tid];
+    if (tid >= 64 && tid < 128) {
+      const int nV = (L.N >= 1 && L.depthType != kDepthIdentity) ? L.nD / L.N : 0;
+      double a = 0.0;
+      for (int v = tid - 64; v < nV; v += 64) a += rf[7 + v * L.N];
+      a = waveSum(a);
+      if (tid == 64) rc[f * kCB + 7] = a;
+    }
+  }
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
   // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
   const float* Mf = minv + static_cast<size_t>(f) * B * B;
@@ -1086,23 +1122,12 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
     if (tid == 0) {
       double rzs = 0.0, rrs = 0.0;
       for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; }
-      if (init) {
-        scal[S_RZ0] = rzs;
-        scal[S_RZOLD] = rzs;
-        scal[S_BETA] = 0.0;
-        scal[S_TARGET] = tol2 * rzs;
-        scal[S_ITERS] = 0.0;
-        scal[S_DONE] = (rzs == rzs) ? ((rzs > 0.0) ? 0.0 : 1.0) : 2.0;
+      if (rc != nullptr) {  // the coarse level adds its part of r^T z and finishes the scalars (k_coarse_apply)
+        scal[S_RZPART] = rzs;
+        scal[S_RR] = rrs;
       } else {
-        const double old = scal[S_RZ];
-        scal[S_RZOLD] = old;
-        scal[S_BETA] = (old != 0.0) ? rzs / old : 0.0;
-        scal[S_ITERS] += 1.0;
-        if (!(rzs == rzs)) scal[S_DONE] = 2.0;
-        else if (rzs <= scal[S_TARGET]) scal[S_DONE] = 1.0;
+        pcgFinishScalars(scal, init, rzs, rrs, tol2);
       }
-      scal[S_RZ] = rzs;
-      scal[S_RR] = rrs;
     }
   }
 }
@@ -1223,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
                                                            const double* __restrict__ scal, int useBeta,
-                                                           double* __restrict__ qPart) {
+                                                           double* __restrict__ qPart, const double* __restrict__ cF) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
@@ -1247,8 +1272,8 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
     xa[i] = x[ia];
     xb[i] = x[ib];
-    pa[i] = (z[ia] + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    pa[i] = (z[ia] + coarseAt(cF, L, fa, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + coarseAt(cF, L, fb, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
