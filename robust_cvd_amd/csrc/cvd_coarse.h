@@ -10,9 +10,11 @@
 // A_c = Z^T A Z is block-sparse on the frame graph (8x8 blocks, one per frame and per undirected frame pair):
 //   * off-diagonal blocks  sum_c rho' (J_a Z_a)^T (J_b Z_b)           k_coarse_edges   (once per linearisation)
 //   * diagonal blocks      Z_f^T (H_ff + diag(lam_f)) Z_f             k_coarse_diag    (once per LM iteration)
-//   * block-sparse Cholesky on a host-computed elimination plan       k_coarse_factor  (one workgroup)
-//   * explicit dense inverse, 8 columns per workgroup                 k_coarse_inverse (F workgroups)
-//   * c = A_c^-1 (Z^T r) per PCG iteration: one dense symmetric product k_coarse_apply
+//   * block-sparse Cholesky A_c = L L^T on a host-computed plan        k_coarse_factor  (one workgroup)
+//   * W = L^-1, block-sparse: W_ij != 0 only if i is an ancestor of j in the elimination tree; its columns are
+//     independent chains, one wave each                                k_coarse_winv
+//   * per PCG iteration c = W^T (W Z^T r): two block-sparse products without level dependencies
+//                                                                      k_coarse_apply_w, k_coarse_apply_wt
 // The regularisers enter through H_ff only (their inter-frame part, the position regulariser, is left to
 // the fine level), so A_c stays SPD.  Everything is deterministic (no atomics in the solves) so that the ranks
 // of the pair-sharded multi-GPU mode stay bit-identical.
@@ -22,7 +24,7 @@
 
 namespace cvd {
 
-constexpr size_t kCoarseMaxUnknowns = 4096;  // dense inverse of A_c: n^2 doubles (128 MiB at the cap)
+constexpr size_t kCoarseMaxUnknowns = 65536;  // 8192 frames (the plan is built on the host in O(F^2))
 constexpr int kCBB = kCB * kCB;   // doubles per coarse block (kCB = 8 coarse unknowns per frame, cvd_device.h)
 
 // LDS hand-off between the lanes of ONE wave (LDS operations of a wave complete in order; the fences only pin
@@ -55,6 +57,13 @@ struct CoarsePlan {
   const int* edgeBlk;    // nEdges: (block id << 1) | transposed   (edge block is stored rows = fa, cols = fb)
   const int* edgeFa;     // nEdges
   const int* edgeFb;     // nEdges
+  // W = L^-1: column j holds blocks at rows path(j) = j, parent(j), parent(parent(j)), ... (W block id = wPtr[j] + t)
+  const int* wPtr;       // F + 1
+  const int* wRow;       // row position of every W block
+  const int* wtPtr;      // F + 1: W blocks of ROW i (transpose structure), ordered by column
+  const int* wtBlk;      //   W block id
+  const int* wtCol;      //   column position
+  int nW;                // number of W blocks
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
                                                         const unsigned char* __restrict__ modeActive,
                                                         double* __restrict__ Lb, double* __restrict__ Linv,
                                                         int* __restrict__ fail) {
-  __shared__ double scratch[16][kCBB];
+  __shared__ double scratch[16][2 * kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
   const int nW = blockDim.x >> 6;
@@ -221,17 +230,31 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
   }
   __syncthreads();
   for (int lv = 0; lv < P.nLevels; ++lv) {
-    // ---- A: gather updates
+    // ---- A: gather updates (operand blocks staged through LDS, the next pair prefetched into registers)
     for (int q = P.lvlBlkPtr[lv] + wv; q < P.lvlBlkPtr[lv + 1]; q += nW) {
       const int b = P.lvlBlks[q];
       double acc = Lb[static_cast<size_t>(b) * kCBB + lane];
-      for (int uidx = P.updPtr[b]; uidx < P.updPtr[b + 1]; ++uidx) {
-        const double* A = Lb + static_cast<size_t>(P.updA[uidx]) * kCBB + r * kCB;
-        const double* Bm = Lb + static_cast<size_t>(P.updB[uidx]) * kCBB + c * kCB;
+      const int u0 = P.updPtr[b], u1 = P.updPtr[b + 1];
+      double* sA = scratch[wv];
+      double* sB = scratch[wv] + kCBB;
+      double na = 0.0, nb = 0.0;
+      if (u0 < u1) {
+        na = Lb[static_cast<size_t>(P.updA[u0]) * kCBB + lane];
+        nb = Lb[static_cast<size_t>(P.updB[u0]) * kCBB + lane];
+      }
+      for (int uidx = u0; uidx < u1; ++uidx) {
+        sA[lane] = na;
+        sB[lane] = nb;
+        CVD_WAVE_SYNC();
+        if (uidx + 1 < u1) {
+          na = Lb[static_cast<size_t>(P.updA[uidx + 1]) * kCBB + lane];
+          nb = Lb[static_cast<size_t>(P.updB[uidx + 1]) * kCBB + lane];
+        }
         double s = 0.0;
 #pragma unroll
-        for (int m = 0; m < kCB; ++m) s += A[m] * Bm[m];
+        for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
         acc -= s;
+        CVD_WAVE_SYNC();
       }
       Lb[static_cast<size_t>(b) * kCBB + lane] = acc;
     }
@@ -296,125 +319,126 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Explicit inverse.  Workgroup jb solves L L^T X = E_jb (the 8 unit columns of position jb) with the level
-// schedule, in place in its 8 rows of the dense inverse (row = coarse index of the right-hand side, column =
-// coarse index of the solution entry; coarse index = frame * 8 + mode).  Gather form only: deterministic.
-//   forward : Y_j = Linv_jj ( E_j - sum_{k in row(j)} L_jk Y_k )
-//   backward: X_j = Linv_jj^T ( Y_j - sum_{i in col(j)} L_ij^T X_i )
-// lane = (r, c): r = mode of the solution entry, c = right-hand side column.
+// W = L^-1.  Column j of W is the solution of L w = E_j; it is non-zero only on the path from j to the root of
+// the elimination tree, and the columns do not depend on each other: one wave per column walks up its path,
+//   W_jj = Linv_jj,    W_ij = -Linv_ii sum_{k on the path below i, L_ik != 0} L_ik W_kj.
+// lane = (r, c) of the 8x8 block.  mark[] (LDS, per wave) maps a position to its index on the path.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coarse_inverse(CoarsePlan P, const double* __restrict__ Lb,
-                                                        const double* __restrict__ Linv, const int* __restrict__ posLevel,
-                                                        double* __restrict__ Ainv) {
-  __shared__ double scratch[4][kCBB];
-  const int jb = blockIdx.x;
+__global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double* __restrict__ Lb,
+                                                     const double* __restrict__ Linv, double* __restrict__ Wb) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
-  const size_t n = static_cast<size_t>(P.F) * kCB;
-  double* rows = Ainv + static_cast<size_t>(P.order[jb]) * kCB * n;  // 8 rows of n
-  auto at = [&](int posIdx, int rr, int cc) -> double& { return rows[static_cast<size_t>(cc) * n + P.order[posIdx] * kCB + rr]; };
-  for (size_t i = tid; i < kCB * n; i += 256) rows[i] = 0.0;
-  __syncthreads();
-  const int lv0 = posLevel[jb];
-  for (int lv = lv0; lv < P.nLevels; ++lv) {
-    for (int q = P.levelPtr[lv] + wv; q < P.levelPtr[lv + 1]; q += 4) {
-      const int j = P.levelCols[q];
-      double acc = (j == jb && r == c) ? 1.0 : 0.0;
-      for (int e = P.rowPtr[j]; e < P.rowPtr[j + 1]; ++e) {
-        const int b = P.rowBlk[e];
-        const int k = P.blkCol[b];
-        const double* Lr = Lb + static_cast<size_t>(b) * kCBB + r * kCB;
-        double s = 0.0;
+  double* scratch = sm + wv * kCBB;                                      // 4 x 64 doubles
+  short* mark = reinterpret_cast<short*>(sm + 4 * kCBB) + wv * P.F;      // 4 x F shorts
+  const int j = blockIdx.x * 4 + wv;
+  if (j >= P.F) return;
+  for (int i = lane; i < P.F; i += 64) mark[i] = -1;
+  CVD_WAVE_SYNC();
+  const int w0 = P.wPtr[j], len = P.wPtr[j + 1] - w0;
+  for (int t = lane; t < len; t += 64) mark[P.wRow[w0 + t]] = static_cast<short>(t);
+  CVD_WAVE_SYNC();
+  Wb[static_cast<size_t>(w0) * kCBB + lane] = Linv[static_cast<size_t>(j) * kCBB + lane];
+  for (int t = 1; t < len; ++t) {
+    const int i = P.wRow[w0 + t];
+    double acc = 0.0;
+    for (int e = P.rowPtr[i]; e < P.rowPtr[i + 1]; ++e) {
+      const int b = P.rowBlk[e];
+      const int idx = mark[P.blkCol[b]];
+      if (idx < 0) continue;  // wave-uniform
+      const double* Lr = Lb + static_cast<size_t>(b) * kCBB + r * kCB;
+      const double* Wk = Wb + static_cast<size_t>(w0 + idx) * kCBB + c;
+      double s2 = 0.0;
 #pragma unroll
-        for (int m = 0; m < kCB; ++m) s += Lr[m] * at(k, m, c);
-        acc -= s;
-      }
-      scratch[wv][lane] = acc;
-      CVD_WAVE_SYNC();
-      const double* Iv = Linv + static_cast<size_t>(j) * kCBB + r * kCB;
-      double y = 0.0;
-#pragma unroll
-      for (int m = 0; m < kCB; ++m) y += Iv[m] * scratch[wv][m * kCB + c];
-      CVD_WAVE_SYNC();
-      at(j, r, c) = y;
+      for (int m = 0; m < kCB; ++m) s2 += Lr[m] * Wk[m * kCB];
+      acc += s2;
     }
-    __syncthreads();
-  }
-  for (int lv = P.nLevels - 1; lv >= 0; --lv) {
-    for (int q = P.levelPtr[lv] + wv; q < P.levelPtr[lv + 1]; q += 4) {
-      const int j = P.levelCols[q];
-      double acc = at(j, r, c);
-      for (int e = P.colPtr[j]; e < P.colPtr[j + 1]; ++e) {
-        const int b = P.F + e;
-        const int i = P.blkRow[b];
-        const double* Lc = Lb + static_cast<size_t>(b) * kCBB + r;  // column r of L_ij: L[m][r]
-        double s = 0.0;
+    scratch[lane] = acc;
+    CVD_WAVE_SYNC();
+    const double* Iv = Linv + static_cast<size_t>(i) * kCBB + r * kCB;
+    double v = 0.0;
 #pragma unroll
-        for (int m = 0; m < kCB; ++m) s += Lc[m * kCB] * at(i, m, c);
-        acc -= s;
-      }
-      scratch[wv][lane] = acc;
-      CVD_WAVE_SYNC();
-      const double* Iv = Linv + static_cast<size_t>(j) * kCBB + r;  // column r of Linv: Linv[m][r]
-      double xv = 0.0;
-#pragma unroll
-      for (int m = 0; m < kCB; ++m) xv += Iv[m * kCB] * scratch[wv][m * kCB + c];
-      CVD_WAVE_SYNC();
-      at(j, r, c) = xv;
-    }
-    __syncthreads();
+    for (int m = 0; m < kCB; ++m) v += Iv[m] * scratch[m * kCB + c];
+    CVD_WAVE_SYNC();
+    Wb[static_cast<size_t>(w0 + t) * kCBB + lane] = -v;
+    // the next step reads this block through global memory from the same wave: make it visible
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 }
 
+// PCG scalars: see pcgFinishScalars (cvd_kernels.h).
 // ---------------------------------------------------------------------------------------------------------
-// c = A_c^-1 rc (dense, symmetric: column access = coalesced), grid (row chunks of 256) x (kCoarseSlabs column
-// slabs).  The last workgroup to arrive folds the slab partials in a fixed order, adds rc . c to r^T z and
-// finishes the PCG scalars that k_cg_update left open (S_RZPART holds the block-Jacobi part of r^T z).
+// y = W (Z^T r): row i gathers W_ij rc_j over the columns j of its subtree (fixed order).  One workgroup per
+// row, the four waves take interleaved quarters of the list; coarse indices are frame * 8 + mode.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kCoarseSlabs = 16;
+__global__ __launch_bounds__(256) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
+                                                        const double* __restrict__ rc, double* __restrict__ y,
+                                                        const double* __restrict__ scal, int init) {
+  __shared__ double part[4][kCB];
+  if (!init && scal[S_DONE] != 0.0) return;
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane >> 3, c = lane & 7;
+  double acc = 0.0;
+  for (int e = P.wtPtr[i] + wv; e < P.wtPtr[i + 1]; e += 4) {
+    const int fj = P.order[P.wtCol[e]];
+    acc += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[fj * kCB + c];
+  }
+  acc += dppMove<0xB1>(acc);
+  acc += dppMove<0x4E>(acc);
+  acc += dppMove<0x141>(acc);
+  if (c == 0) part[wv][r] = acc;
+  __syncthreads();
+  if (tid < kCB) y[i * kCB + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+}
 
-__global__ __launch_bounds__(256) void k_coarse_apply(int n, const double* __restrict__ Ainv,
-                                                      const double* __restrict__ rc, double* __restrict__ part,
-                                                      double* __restrict__ cOut, double* __restrict__ scal,
-                                                      unsigned int* __restrict__ counter, const int* __restrict__ fail,
-                                                      const unsigned char* __restrict__ modeActive, int init, double tol2) {
-  __shared__ double rs[512];
+// ---------------------------------------------------------------------------------------------------------
+// c = W^T y: column j sums W_ij^T y_i over its path (one wave per column), written at the frame's coarse index.
+// The last workgroup adds rc . c to r^T z and finishes the PCG scalars that k_cg_update left open (S_RZPART
+// holds the block-Jacobi part of r^T z).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarsePlan P, const double* __restrict__ Wb,
+                                                         const double* __restrict__ y, const double* __restrict__ rc,
+                                                         double* __restrict__ cOut, double* __restrict__ dotPart,
+                                                         double* __restrict__ scal, unsigned int* __restrict__ counter,
+                                                         const int* __restrict__ fail,
+                                                         const unsigned char* __restrict__ modeActive, int init,
+                                                         double tol2) {
   __shared__ double red[4];
   __shared__ int flag;
   if (!init && scal[S_DONE] != 0.0) return;
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
-  const int slab = blockIdx.y;
-  const int per = (n + kCoarseSlabs - 1) / kCoarseSlabs;
-  const int j0 = slab * per, j1 = min(n, j0 + per);
-  for (int j = j0 + tid; j < j1; j += 256) rs[j - j0] = rc[j];
-  __syncthreads();
-  if (i < n) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int j = j0;
-    const double* col = Ainv + static_cast<size_t>(j0) * n + i;
-    for (; j + 3 < j1; j += 4, col += 4 * static_cast<size_t>(n)) {
-      a0 += col[0] * rs[j - j0];
-      a1 += col[n] * rs[j + 1 - j0];
-      a2 += col[2 * static_cast<size_t>(n)] * rs[j + 2 - j0];
-      a3 += col[3 * static_cast<size_t>(n)] * rs[j + 3 - j0];
-    }
-    for (; j < j1; ++j, col += n) a0 += col[0] * rs[j - j0];
-    part[static_cast<size_t>(slab) * n + i] = (a0 + a1) + (a2 + a3);
-  }
-  if (!lastBlockArrives(counter, gridDim.x * gridDim.y, &flag)) return;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane >> 3, c = lane & 7;
+  const int j = blockIdx.x * 4 + wv;
   const bool ok = (*fail == 0);
   double dot = 0.0;
-  for (int k = tid; k < n; k += 256) {
-    double s = 0.0;
-    for (int sl = 0; sl < kCoarseSlabs; ++sl) s += part[static_cast<size_t>(sl) * n + k];
-    // inactive modes (identity rows of A_c) take no correction; a broken-down factorisation switches the level off
-    if (!ok || !modeActive[k]) s = 0.0;
-    cOut[k] = s;
-    dot += s * rc[k];
+  if (j < P.F) {
+    const int w0 = P.wPtr[j], len = P.wPtr[j + 1] - w0;
+    double acc = 0.0;  // lane (r, c): W[r][c] y_i[r], summed over r below -> c_j[c]
+    for (int t = 0; t < len; ++t)
+      acc += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
+    // sum over r: lanes with equal c are 8 apart
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < kCB) {
+      const int k = P.order[j] * kCB + lane;
+      // inactive modes (identity rows of A_c) take no correction; a broken-down factorisation switches the level off
+      const double v = (ok && modeActive[k]) ? acc : 0.0;
+      cOut[k] = v;
+      dot = v * rc[k];
+    }
   }
   dot = waveSum(dot);
-  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  if (lane == 0) red[wv] = dot;
+  __syncthreads();
+  if (tid == 0) dotPart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (!lastBlockArrives(counter, gridDim.x, &flag)) return;
+  double t = 0.0;
+  for (int b = tid; b < static_cast<int>(gridDim.x); b += 256) t += dotPart[b];
+  t = waveSum(t);
+  if (lane == 0) red[wv] = t;
   __syncthreads();
   if (tid == 0) pcgFinishScalars(scal, init, scal[S_RZPART] + ((red[0] + red[1]) + (red[2] + red[3])), scal[S_RR], tol2);
 }

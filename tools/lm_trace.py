@@ -8,7 +8,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2
 v = synth.make_video(F, 384, 224, seed=1237)
 s = api.Solver(0); synth.load_into(s, v)
-s.set_options(verbose=1, pcg_relative_tolerance=tol)
+s.set_options(verbose=1, pcg_relative_tolerance=tol, coarse_level=int(os.environ.get('CVD_COARSE', '1')))
 s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
 p = OptParams.defaults()
 s.normalize_depth(p)
