@@ -32,7 +32,8 @@ typedef struct cvd_solver_options {
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
   int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve
-                                    (8 unknowns per frame, up to 512 frames); 0: block-Jacobi only */
+                                    (8 unknowns per frame), coarse factor rebuilt on demand; 2: rebuilt every LM
+                                    iteration; 0: block-Jacobi only */
   int32_t reserved;
 } cvd_solver_options;
 

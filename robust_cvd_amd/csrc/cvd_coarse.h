@@ -63,6 +63,10 @@ struct CoarsePlan {
   const int* wtPtr;      // F + 1: W blocks of ROW i (transpose structure), ordered by column
   const int* wtBlk;      //   W block id
   const int* wtCol;      //   column position
+  const int* wtFrame;    //   frame of that column (order[wtCol])
+  const int* wuPtr;      // nW + 1: gather list of W block (i, j): pairs L(i,k) W(k,j), k on the path below i
+  const int* wuL;        //   block id of L(i, k)
+  const int* wuW;        //   W block id of W(k, j)
   int nW;                // number of W blocks
 };
 
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
                                                         double* __restrict__ Lb, double* __restrict__ Linv,
                                                         int* __restrict__ fail) {
   __shared__ double scratch[16][2 * kCBB];
+  __shared__ double fold[16][kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
   const int nW = blockDim.x >> 6;
@@ -230,33 +235,50 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
   }
   __syncthreads();
   for (int lv = 0; lv < P.nLevels; ++lv) {
-    // ---- A: gather updates (operand blocks staged through LDS, the next pair prefetched into registers)
-    for (int q = P.lvlBlkPtr[lv] + wv; q < P.lvlBlkPtr[lv + 1]; q += nW) {
+    // ---- A: gather updates (operand blocks staged through LDS, the next pair prefetched into registers).
+    // Wide levels: one wave per block.  Narrow levels (the top of the tree: few blocks, long update lists): all
+    // waves split the list of one block and their partial sums are folded in wave order.
+    const int q0 = P.lvlBlkPtr[lv], q1 = P.lvlBlkPtr[lv + 1];
+    const bool coop = (q1 - q0) < nW;
+    for (int q = coop ? q0 : q0 + wv; q < q1; q += coop ? 1 : nW) {
       const int b = P.lvlBlks[q];
-      double acc = Lb[static_cast<size_t>(b) * kCBB + lane];
       const int u0 = P.updPtr[b], u1 = P.updPtr[b + 1];
+      const int ustep = coop ? nW : 1;
+      double acc = 0.0;
       double* sA = scratch[wv];
       double* sB = scratch[wv] + kCBB;
       double na = 0.0, nb = 0.0;
-      if (u0 < u1) {
-        na = Lb[static_cast<size_t>(P.updA[u0]) * kCBB + lane];
-        nb = Lb[static_cast<size_t>(P.updB[u0]) * kCBB + lane];
+      int uidx = coop ? u0 + wv : u0;
+      if (uidx < u1) {
+        na = Lb[static_cast<size_t>(P.updA[uidx]) * kCBB + lane];
+        nb = Lb[static_cast<size_t>(P.updB[uidx]) * kCBB + lane];
       }
-      for (int uidx = u0; uidx < u1; ++uidx) {
+      for (; uidx < u1; uidx += ustep) {
         sA[lane] = na;
         sB[lane] = nb;
         CVD_WAVE_SYNC();
-        if (uidx + 1 < u1) {
-          na = Lb[static_cast<size_t>(P.updA[uidx + 1]) * kCBB + lane];
-          nb = Lb[static_cast<size_t>(P.updB[uidx + 1]) * kCBB + lane];
+        if (uidx + ustep < u1) {
+          na = Lb[static_cast<size_t>(P.updA[uidx + ustep]) * kCBB + lane];
+          nb = Lb[static_cast<size_t>(P.updB[uidx + ustep]) * kCBB + lane];
         }
         double s = 0.0;
 #pragma unroll
         for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
-        acc -= s;
+        acc += s;
         CVD_WAVE_SYNC();
       }
-      Lb[static_cast<size_t>(b) * kCBB + lane] = acc;
+      if (!coop) {
+        Lb[static_cast<size_t>(b) * kCBB + lane] -= acc;
+      } else {
+        fold[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0) {
+          double t = 0.0;
+          for (int w = 0; w < nW; ++w) t += fold[w][lane];
+          Lb[static_cast<size_t>(b) * kCBB + lane] -= t;
+        }
+        __syncthreads();
+      }
     }
     __syncthreads();
     // ---- B: diagonal blocks of the level
@@ -322,46 +344,56 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
 // W = L^-1.  Column j of W is the solution of L w = E_j; it is non-zero only on the path from j to the root of
 // the elimination tree, and the columns do not depend on each other: one wave per column walks up its path,
 //   W_jj = Linv_jj,    W_ij = -Linv_ii sum_{k on the path below i, L_ik != 0} L_ik W_kj.
-// lane = (r, c) of the 8x8 block.  mark[] (LDS, per wave) maps a position to its index on the path.
+// lane = (r, c) of the 8x8 block.  The (L_ik, W_kj) gather list of every W block is built on the host.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double* __restrict__ Lb,
                                                      const double* __restrict__ Linv, double* __restrict__ Wb) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double scratch[4][3 * kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
-  double* scratch = sm + wv * kCBB;                                      // 4 x 64 doubles
-  short* mark = reinterpret_cast<short*>(sm + 4 * kCBB) + wv * P.F;      // 4 x F shorts
   const int j = blockIdx.x * 4 + wv;
   if (j >= P.F) return;
-  for (int i = lane; i < P.F; i += 64) mark[i] = -1;
-  CVD_WAVE_SYNC();
+  double* sA = scratch[wv];
+  double* sB = sA + kCBB;
+  double* sC = sB + kCBB;
   const int w0 = P.wPtr[j], len = P.wPtr[j + 1] - w0;
-  for (int t = lane; t < len; t += 64) mark[P.wRow[w0 + t]] = static_cast<short>(t);
-  CVD_WAVE_SYNC();
   Wb[static_cast<size_t>(w0) * kCBB + lane] = Linv[static_cast<size_t>(j) * kCBB + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   for (int t = 1; t < len; ++t) {
-    const int i = P.wRow[w0 + t];
-    double acc = 0.0;
-    for (int e = P.rowPtr[i]; e < P.rowPtr[i + 1]; ++e) {
-      const int b = P.rowBlk[e];
-      const int idx = mark[P.blkCol[b]];
-      if (idx < 0) continue;  // wave-uniform
-      const double* Lr = Lb + static_cast<size_t>(b) * kCBB + r * kCB;
-      const double* Wk = Wb + static_cast<size_t>(w0 + idx) * kCBB + c;
+    const int wb = w0 + t;
+    const int i = P.wRow[wb];
+    const double ivr = Linv[static_cast<size_t>(i) * kCBB + lane];  // staged below: Linv_ii
+    // gather list of this block (host-built): pairs (L_ik, W_kj) with k on the path below i
+    const int u0 = P.wuPtr[wb], u1 = P.wuPtr[wb + 1];
+    double acc = 0.0, na = 0.0, nb = 0.0;
+    if (u0 < u1) {
+      na = Lb[static_cast<size_t>(P.wuL[u0]) * kCBB + lane];
+      nb = Wb[static_cast<size_t>(P.wuW[u0]) * kCBB + lane];
+    }
+    for (int u = u0; u < u1; ++u) {
+      sA[lane] = na;
+      sB[lane] = nb;
+      CVD_WAVE_SYNC();
+      if (u + 1 < u1) {
+        na = Lb[static_cast<size_t>(P.wuL[u + 1]) * kCBB + lane];
+        nb = Wb[static_cast<size_t>(P.wuW[u + 1]) * kCBB + lane];
+      }
       double s2 = 0.0;
 #pragma unroll
-      for (int m = 0; m < kCB; ++m) s2 += Lr[m] * Wk[m * kCB];
+      for (int m = 0; m < kCB; ++m) s2 += sA[r * kCB + m] * sB[m * kCB + c];
       acc += s2;
+      CVD_WAVE_SYNC();
     }
-    scratch[lane] = acc;
+    sC[lane] = acc;
+    sA[lane] = ivr;
     CVD_WAVE_SYNC();
-    const double* Iv = Linv + static_cast<size_t>(i) * kCBB + r * kCB;
     double v = 0.0;
 #pragma unroll
-    for (int m = 0; m < kCB; ++m) v += Iv[m] * scratch[m * kCB + c];
+    for (int m = 0; m < kCB; ++m) v += sA[r * kCB + m] * sC[m * kCB + c];
     CVD_WAVE_SYNC();
-    Wb[static_cast<size_t>(w0 + t) * kCBB + lane] = -v;
-    // the next step reads this block through global memory from the same wave: make it visible
+    Wb[static_cast<size_t>(wb) * kCBB + lane] = -v;
+    // later steps of this wave read the block back through global memory: make it visible
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
@@ -372,25 +404,35 @@ __global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double*
 // y = W (Z^T r): row i gathers W_ij rc_j over the columns j of its subtree (fixed order).  One workgroup per
 // row, the four waves take interleaved quarters of the list; coarse indices are frame * 8 + mode.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
-                                                        const double* __restrict__ rc, double* __restrict__ y,
-                                                        const double* __restrict__ scal, int init) {
-  __shared__ double part[4][kCB];
+__global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
+                                                         const double* __restrict__ rc, double* __restrict__ y,
+                                                         const double* __restrict__ scal, int init) {
+  __shared__ double part[16][kCB];
   if (!init && scal[S_DONE] != 0.0) return;
   const int i = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
-  double acc = 0.0;
-  for (int e = P.wtPtr[i] + wv; e < P.wtPtr[i + 1]; e += 4) {
-    const int fj = P.order[P.wtCol[e]];
-    acc += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[fj * kCB + c];
+  // the rows near the root of the elimination tree gather from hundreds of columns: 16 waves share the list
+  double a0 = 0.0, a1 = 0.0;
+  const int e1 = P.wtPtr[i + 1];
+  int e = P.wtPtr[i] + wv;
+  for (; e + 16 < e1; e += 32) {
+    a0 += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[P.wtFrame[e] * kCB + c];
+    a1 += Wb[static_cast<size_t>(P.wtBlk[e + 16]) * kCBB + lane] * rc[P.wtFrame[e + 16] * kCB + c];
   }
+  if (e < e1) a0 += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[P.wtFrame[e] * kCB + c];
+  double acc = a0 + a1;
   acc += dppMove<0xB1>(acc);
   acc += dppMove<0x4E>(acc);
   acc += dppMove<0x141>(acc);
   if (c == 0) part[wv][r] = acc;
   __syncthreads();
-  if (tid < kCB) y[i * kCB + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  if (tid < kCB) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][tid];
+    y[i * kCB + tid] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -415,9 +457,17 @@ __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarsePlan P, const dou
   double dot = 0.0;
   if (j < P.F) {
     const int w0 = P.wPtr[j], len = P.wPtr[j + 1] - w0;
-    double acc = 0.0;  // lane (r, c): W[r][c] y_i[r], summed over r below -> c_j[c]
-    for (int t = 0; t < len; ++t)
-      acc += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
+    // lane (r, c): W[r][c] y_i[r], summed over r below -> c_j[c]; four independent chains keep loads in flight
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = 0;
+    for (; t + 3 < len; t += 4) {
+      a0 += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
+      a1 += Wb[static_cast<size_t>(w0 + t + 1) * kCBB + lane] * y[P.wRow[w0 + t + 1] * kCB + r];
+      a2 += Wb[static_cast<size_t>(w0 + t + 2) * kCBB + lane] * y[P.wRow[w0 + t + 2] * kCB + r];
+      a3 += Wb[static_cast<size_t>(w0 + t + 3) * kCBB + lane] * y[P.wRow[w0 + t + 3] * kCB + r];
+    }
+    for (; t < len; ++t) a0 += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
+    double acc = (a0 + a1) + (a2 + a3);
     // sum over r: lanes with equal c are 8 apart
     acc += __shfl_xor(acc, 8, 64);
     acc += __shfl_xor(acc, 16, 64);

@@ -293,7 +293,7 @@ struct cvd_handle_t {
     int nEdges = 0, nBlocks = 0, nLevels = 0;
     std::vector<int> itemEdge;
     DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr,
-        updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, itemEdgeDev;
+        updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev;
     DevBuf<double> edges, edgesUsed, diag, Lb, Linv, Wb, rc, y, c, dotPart;  // edgesUsed: snapshot the factor was built from
     int nW = 0;
     DevBuf<unsigned char> modeActive;
@@ -738,10 +738,27 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   std::vector<std::vector<std::pair<int, int>>> wt(F);  // row -> (column, W block id), columns ascending
   for (int j = 0; j < F; ++j)
     for (int t = wPtr[j]; t < wPtr[j + 1]; ++t) wt[wRow[t]].push_back({j, t});
-  std::vector<int> wtPtr(F + 1, 0), wtBlk, wtCol;
+  std::vector<int> wtPtr(F + 1, 0), wtBlk, wtCol, wtFrame;
   for (int i = 0; i < F; ++i) {
     wtPtr[i + 1] = wtPtr[i] + static_cast<int>(wt[i].size());
-    for (const auto& e : wt[i]) { wtCol.push_back(e.first); wtBlk.push_back(e.second); }
+    for (const auto& e : wt[i]) { wtCol.push_back(e.first); wtBlk.push_back(e.second); wtFrame.push_back(order[e.first]); }
+  }
+  std::vector<int> wuPtr(nW + 1, 0), wuL, wuW;
+  {
+    std::vector<int> mark(F, -1);
+    for (int j = 0; j < F; ++j) {
+      for (int t = wPtr[j]; t < wPtr[j + 1]; ++t) mark[wRow[t]] = t;
+      for (int t = wPtr[j]; t < wPtr[j + 1]; ++t) {
+        const int i = wRow[t];
+        if (t > wPtr[j])
+          for (int b : rowBlks[i]) {
+            const int wk = mark[blkCol[b]];
+            if (wk >= 0 && wk < t) { wuL.push_back(b); wuW.push_back(wk); }
+          }
+        wuPtr[t + 1] = static_cast<int>(wuL.size());
+      }
+      for (int t = wPtr[j]; t < wPtr[j + 1]; ++t) mark[wRow[t]] = -1;
+    }
   }
   std::vector<int> edgeBlk, edgeFa, edgeFb;
   for (const auto& e : edgeList) {
@@ -761,7 +778,8 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   up(C.lvlBlkPtr, lvlBlkPtr); up(C.lvlBlks, lvlBlks); up(C.blkCol, blkCol); up(C.blkRow, blkRow);
   up(C.colPtr, colPtr); up(C.rowPtr, rowPtr); up(C.rowBlk, rowBlk); up(C.updPtr, updPtr); up(C.updA, updA);
   up(C.updB, updB); up(C.edgeBlk, edgeBlk); up(C.edgeFa, edgeFa); up(C.edgeFb, edgeFb);
-  up(C.wPtr, wPtr); up(C.wRow, wRow); up(C.wtPtr, wtPtr); up(C.wtBlk, wtBlk); up(C.wtCol, wtCol);
+  up(C.wPtr, wPtr); up(C.wRow, wRow); up(C.wtPtr, wtPtr); up(C.wtBlk, wtBlk); up(C.wtCol, wtCol); up(C.wtFrame, wtFrame);
+  up(C.wuPtr, wuPtr); up(C.wuL, wuL); up(C.wuW, wuW);
   C.nW = nW;
   up(C.itemEdgeDev, itemEdge);
   const size_t n = static_cast<size_t>(F) * kCB;
@@ -779,8 +797,8 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   HIP_CHECK(hipStreamSynchronize(s));
   C.plan = CoarsePlan{F, nBlocks, nLevels, C.nEdges, C.order.p, C.pos.p, C.levelPtr.p, C.levelCols.p, C.lvlBlkPtr.p,
                       C.lvlBlks.p, C.blkCol.p, C.blkRow.p, C.colPtr.p, C.rowPtr.p, C.rowBlk.p, C.updPtr.p, C.updA.p,
-                      C.updB.p, C.edgeBlk.p, C.edgeFa.p, C.edgeFb.p, C.wPtr.p, C.wRow.p, C.wtPtr.p, C.wtBlk.p, C.wtCol.p,
-                      nW};
+                      C.updB.p, C.edgeBlk.p, C.edgeFa.p, C.edgeFb.p, C.wPtr.p, C.wRow.p, C.wtPtr.p, C.wtBlk.p, C.wtCol.p, C.wtFrame.p,
+                      C.wuPtr.p, C.wuL.p, C.wuW.p, nW};
   C.valid = true;
 }
 
@@ -1185,8 +1203,7 @@ static void launchCoarseSetup(Ctx& c) {
                      C.modeActive.p);
   hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
                      C.Linv.p, C.fail.p);
-  const size_t ldsW = 4 * kCBB * sizeof(double) + 4 * static_cast<size_t>(c.L.F) * sizeof(short);
-  hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), ldsW, s, C.plan, C.Lb.p, C.Linv.p, C.Wb.p);
+  hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, C.Wb.p);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1210,7 +1227,7 @@ static int runPcg(Ctx& c, const double* x) {
   double* rc = coarse ? h->coarse.rc.p : nullptr;
   auto coarseApply = [&](int init) {
     // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
-    hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(256), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
+    hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
                        h->coarse.y.p, h->dScal.p, init);
     hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, h->coarse.plan, h->coarse.Wb.p,
                        h->coarse.y.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p, h->dScal.p,
@@ -1341,7 +1358,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
   int invalid = 0, iteration = 0, termination = 1;
-  int coarseAge = -1, cgAfterRefresh = 0, lastCg = 0;  // coarse level: LM iterations since the last rebuild
+  int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
+  constexpr int kCoarseRebuildIters = 16;
   bool scaleDone = false;
   cvd_iteration_record r0{};
   r0.cost = xCost;
@@ -1373,20 +1391,22 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         h->tEnd(slot);
       }
       if (h->coarseOn) {
-        // The coarse inverse is only a preconditioner: any SPD approximation of Z^T A Z serves, so it is kept
-        // across LM iterations (lagged lam and linearisation point) and rebuilt when the previous solve needed
-        // clearly more PCG iterations than the solve that followed the last rebuild.
-        const bool refresh = h->opt.coarse_level != 2 || coarseAge < 0 || lastCg > std::max(8, 2 * cgAfterRefresh);
+        // The coarse factor is only a preconditioner: any SPD approximation of Z^T A Z serves, so it is kept
+        // across LM iterations (lagged lam and linearisation point).  A rebuild costs about as much as
+        // kCoarseRebuildIters PCG iterations; it is done once the iterations spent beyond the count observed
+        // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
+        const bool refresh = h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
         if (refresh) {
           launchCoarseSetup(c);
           coarseAge = 0;
+          cgExcess = 0;
         } else {
           ++coarseAge;
         }
       }
       const int cgIters = runPcg(c, h->dX.p);
       if (coarseAge == 0) cgAfterRefresh = cgIters;
-      lastCg = cgIters;
+      else cgExcess += std::max(0, cgIters - cgAfterRefresh);
       stats();
       tLin += nowSeconds() - tl;
       rec.linear_iterations = cgIters;
@@ -1953,7 +1973,7 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
         for (size_t k = 0; k < n; ++k) {
           unit[k] = 1.0;
           C.rc.upload(unit.data(), n, s);
-          hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(256), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, scalTmp.p, 1);
+          hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, scalTmp.p, 1);
           hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, C.plan, C.Wb.p, C.y.p, C.rc.p, C.c.p,
                              C.dotPart.p, scalTmp.p, h->dCounters.p + 3, C.fail.p, C.modeActive.p, 1, 0.0);
           C.c.download(a_c_inverse + k * n, n, s);
