@@ -341,6 +341,153 @@ __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Multi-workgroup variant of the factorisation.  A column's work (gather for its blocks, diagonal Cholesky,
+// scaling of its off-diagonal blocks) depends only on columns of LOWER levels, so a workgroup takes whole columns
+// and the workgroups meet once per level at a grid barrier (all kCoarseFactorGroups workgroups are co-resident:
+// far fewer than CUs).  Inside a column the 16 waves split every update list and fold their partial sums in wave
+// order (deterministic).  Lb must be zeroed and *barrier set to 0 by the host before the launch.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kCoarseFactorGroups = 32;
+
+__device__ __forceinline__ void coarseGridBarrier(unsigned int* counter, unsigned int target, int* fail) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) {  // never hang the device: give up and report (the level is switched off)
+        atomicAdd(fail, 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const double* __restrict__ diag,
+                                                           const double* __restrict__ edges,
+                                                           const unsigned char* __restrict__ modeActive,
+                                                           double* __restrict__ Lb, double* __restrict__ Linv,
+                                                           int* __restrict__ fail, unsigned int* __restrict__ barrier) {
+  __shared__ double scratch[16][2 * kCBB];
+  __shared__ double fold[16][kCBB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane >> 3, c = lane & 7;
+  const int nG = gridDim.x, g = blockIdx.x;
+  unsigned int phase = 0;
+  // load: diagonal blocks by position, edge blocks (masked by the mode flags, transposed if needed)
+  for (int j = g * 16 + wv; j < P.F; j += nG * 16) Lb[static_cast<size_t>(j) * kCBB + lane] = diag[static_cast<size_t>(P.order[j]) * kCBB + lane];
+  for (int e = g * 16 + wv; e < P.nEdges; e += nG * 16) {
+    const int code = P.edgeBlk[e];
+    const int b = code >> 1, tr = code & 1;
+    const int fa = P.edgeFa[e], fb = P.edgeFb[e];
+    const int ra = tr ? c : r, cb2 = tr ? r : c;
+    double v = edges[static_cast<size_t>(e) * kCBB + ra * kCB + cb2];
+    if (!modeActive[fa * kCB + ra] || !modeActive[fb * kCB + cb2]) v = 0.0;
+    Lb[static_cast<size_t>(b) * kCBB + lane] = v;
+  }
+  coarseGridBarrier(barrier, ++phase * nG, fail);
+  double* sA = scratch[wv];
+  double* sB = scratch[wv] + kCBB;
+  for (int lv = 0; lv < P.nLevels; ++lv) {
+    for (int q = P.levelPtr[lv] + g; q < P.levelPtr[lv + 1]; q += nG) {
+      const int j = P.levelCols[q];
+      const int nOff = P.colPtr[j + 1] - P.colPtr[j];
+      // ---- gather: block k = 0 is the diagonal, k >= 1 the off-diagonal blocks of the column
+      for (int k = 0; k <= nOff; ++k) {
+        const int b = (k == 0) ? j : P.F + P.colPtr[j] + k - 1;
+        const int u0 = P.updPtr[b], u1 = P.updPtr[b + 1];
+        if (u0 == u1) continue;  // uniform
+        double acc = 0.0, na = 0.0, nb = 0.0;
+        int uidx = u0 + wv;
+        if (uidx < u1) {
+          na = Lb[static_cast<size_t>(P.updA[uidx]) * kCBB + lane];
+          nb = Lb[static_cast<size_t>(P.updB[uidx]) * kCBB + lane];
+        }
+        for (; uidx < u1; uidx += 16) {
+          sA[lane] = na;
+          sB[lane] = nb;
+          CVD_WAVE_SYNC();
+          if (uidx + 16 < u1) {
+            na = Lb[static_cast<size_t>(P.updA[uidx + 16]) * kCBB + lane];
+            nb = Lb[static_cast<size_t>(P.updB[uidx + 16]) * kCBB + lane];
+          }
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
+          acc += s;
+          CVD_WAVE_SYNC();
+        }
+        fold[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0) {
+          double t = 0.0;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) t += fold[w][lane];
+          Lb[static_cast<size_t>(b) * kCBB + lane] -= t;
+        }
+        __syncthreads();
+      }
+      // ---- diagonal block: dense 8x8 Cholesky and the inverse of its factor (wave 0)
+      if (wv == 0) {
+        double* S = scratch[0];
+        S[lane] = Lb[static_cast<size_t>(j) * kCBB + lane];
+        for (int k = 0; k < kCB; ++k) {
+          CVD_WAVE_SYNC();
+          double d = S[k * kCB + k];
+          if (!(d > 0.0)) {
+            if (lane == 0) atomicAdd(fail, 1);
+            d = 1.0;
+          }
+          const double sd = sqrt(d);
+          const double lrk = S[r * kCB + k] / sd, lck = S[c * kCB + k] / sd;
+          CVD_WAVE_SYNC();
+          if (c == k && r >= k) S[lane] = (r == k) ? sd : lrk;
+          else if (r > k && c > k && c <= r) S[lane] -= lrk * lck;
+        }
+        CVD_WAVE_SYNC();
+        if (c > r) S[lane] = 0.0;
+        CVD_WAVE_SYNC();
+        Lb[static_cast<size_t>(j) * kCBB + lane] = S[lane];
+        double* Iv = Linv + static_cast<size_t>(j) * kCBB;
+        if (lane < kCB) {
+          double col[kCB];
+#pragma unroll
+          for (int i = 0; i < kCB; ++i) {
+            double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < kCB; ++m)
+              if (m < i) v -= S[i * kCB + m] * col[m];
+            col[i] = v / S[i * kCB + i];
+          }
+#pragma unroll
+          for (int i = 0; i < kCB; ++i) Iv[i * kCB + lane] = col[i];
+        }
+      }
+      __syncthreads();
+      // ---- off-diagonal blocks: L_ij = G Linv_jj^T
+      for (int k = wv; k < nOff; k += 16) {
+        const int b = P.F + P.colPtr[j] + k;
+        sA[lane] = Lb[static_cast<size_t>(b) * kCBB + lane];
+        sB[lane] = Linv[static_cast<size_t>(j) * kCBB + lane];
+        CVD_WAVE_SYNC();
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
+        Lb[static_cast<size_t>(b) * kCBB + lane] = s;
+        CVD_WAVE_SYNC();
+      }
+      __syncthreads();
+    }
+    coarseGridBarrier(barrier, ++phase * nG, fail);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // W = L^-1.  Column j of W is the solution of L w = E_j; it is non-zero only on the path from j to the root of
 // the elimination tree, and the columns do not depend on each other: one wave per column walks up its path,
 //   W_jj = Linv_jj,    W_ij = -Linv_ii sum_{k on the path below i, L_ik != 0} L_ik W_kj.

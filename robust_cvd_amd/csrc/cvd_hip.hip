@@ -22,7 +22,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <set>
@@ -298,6 +300,7 @@ struct cvd_handle_t {
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
+    DevBuf<unsigned int> barrier;  // grid barrier of k_coarse_factor_mw
     CoarsePlan plan{};
   } coarse;
   bool coarseOn = false;  // this solve uses the coarse level
@@ -992,13 +995,25 @@ static void launchFrameConsts(Ctx& c, const double* x) {
   HIP_CHECK(hipGetLastError());
 }
 
+// The LM loop is latency-bound on its read-backs (a handful of scalars per decision): poll instead of the
+// interrupt-driven hipStreamSynchronize / hipEventSynchronize, whose wake-up costs tens of microseconds.
+static void spinStream(hipStream_t s) {
+  hipError_t e;
+  while ((e = hipStreamQuery(s)) == hipErrorNotReady) {}
+  HIP_CHECK(e);
+}
+static void spinEvent(hipEvent_t ev) {
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
+  HIP_CHECK(e);
+}
 static void readScalars(Ctx& c) {
   HIP_CHECK(hipMemcpyAsync(c.h->hScal, c.h->dScal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
-  HIP_CHECK(hipStreamSynchronize(c.h->stream));
+  spinStream(c.h->stream);
 }
 
-// cost only at x
-static double evalCost(Ctx& c, const double* x) {
+// cost only at x: enqueueCost leaves it in S_COST on the device, evalCost also reads it back
+static void enqueueCost(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   launchFrameConsts(c, x);
@@ -1022,12 +1037,25 @@ static double evalCost(Ctx& c, const double* x) {
   HIP_CHECK(hipGetLastError());
   if (h->world > 1) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
   h->tEnd(slot);
+}
+static double evalCost(Ctx& c, const double* x) {
+  enqueueCost(c, x);
   readScalars(c);
-  return h->hScal[S_COST];
+  return c.h->hScal[S_COST];
+}
+
+// step statistics (k_step_stats) into the device scalars; the caller reads them back
+static void enqueueStats(Ctx& c) {
+  cvd_handle* h = c.h;
+  const int G = static_cast<int>(std::min<size_t>(128, (c.n + 511) / 512));
+  h->dStatPart.ensure(6 * 128);
+  hipLaunchKernelGGL(k_step_stats, dim3(G), dim3(256), 0, h->stream, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
+                     h->dX.p, h->dHd.p, h->dScal.p, h->dStatPart.p, h->dCounters.p + 2);
+  HIP_CHECK(hipGetLastError());
 }
 
 // cost + gradient + diagonal blocks at x
-static double evalFull(Ctx& c, const double* x) {
+static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   launchFrameConsts(c, x);
@@ -1084,6 +1112,10 @@ static double evalFull(Ctx& c, const double* x) {
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
   hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
   HIP_CHECK(hipGetLastError());
+  if (withStats) {  // |g|_max and |x| of the new point in the same read-back (lam = 0: only those two are used)
+    HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    enqueueStats(c);
+  }
   readScalars(c);
   return h->hScal[S_COST];
 }
@@ -1201,8 +1233,17 @@ static void launchCoarseSetup(Ctx& c) {
                            hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
                      C.modeActive.p);
-  hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
-                     C.Linv.p, C.fail.p);
+  static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
+  if (singleWg) {
+    hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
+                       C.Linv.p, C.fail.p);
+  } else {
+    C.barrier.ensure(1);
+    HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, sizeof(unsigned int), s));
+    HIP_CHECK(hipMemsetAsync(C.Lb.p, 0, static_cast<size_t>(C.nBlocks) * kCBB * sizeof(double), s));
+    hipLaunchKernelGGL(k_coarse_factor_mw, dim3(kCoarseFactorGroups), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p,
+                       C.modeActive.p, C.Lb.p, C.Linv.p, C.fail.p, C.barrier.p);
+  }
   hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, C.Wb.p);
   HIP_CHECK(hipGetLastError());
 }
@@ -1211,7 +1252,7 @@ static void launchCoarseSetup(Ctx& c) {
 // Three launches per iteration (pairs product, per-frame finish, per-frame update).  alpha / beta live on
 // the device: the last workgroup of k_matvec_finish / k_cg_update reduces the per-frame partial dot products
 // (agent-scope release/acquire ticket), so there is neither a scalar kernel nor a host round trip in the loop.
-static int runPcg(Ctx& c, const double* x) {
+static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = nullptr) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   const int F = c.L.F;
@@ -1251,7 +1292,7 @@ static int runPcg(Ctx& c, const double* x) {
   while (!stop) {
     if (batch >= kSlots) {
       const int sl = batch % kSlots;
-      HIP_CHECK(hipEventSynchronize(h->pcgEvent[sl]));
+      spinEvent(h->pcgEvent[sl]);
       if (h->hPcg[sl * 4 + 0] != 0.0) break;
     }
     if (enq >= maxIt) break;
@@ -1278,7 +1319,8 @@ static int runPcg(Ctx& c, const double* x) {
     ++batch;
   }
   h->curPcgIter = -1;
-  readScalars(c);  // drains the stream; S_DONE / S_ITERS are final
+  if (tail) tail();  // follow-up work that does not need the host's decision rides on the same read-back
+  readScalars(c);    // drains the stream; S_DONE / S_ITERS are final
   if (h->hScal[S_DONE] == 2.0) throw std::runtime_error("PCG produced NaN");
   const int iters = static_cast<int>(h->hScal[S_ITERS]);
   h->tDropFrom(firstTimerSlot, iters);
@@ -1334,11 +1376,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   sum.initial_cost = xCost;
 
   auto stats = [&]() {
-    const int G = static_cast<int>(std::min<size_t>(128, (c.n + 511) / 512));
-    h->dStatPart.ensure(6 * 128);
-    hipLaunchKernelGGL(k_step_stats, dim3(G), dim3(256), 0, s, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
-                       h->dX.p, h->dHd.p, h->dScal.p, h->dStatPart.p, h->dCounters.p + 2);
-    HIP_CHECK(hipGetLastError());
+    enqueueStats(c);
     readScalars(c);
   };
   HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
@@ -1358,8 +1396,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
   int invalid = 0, iteration = 0, termination = 1;
-  int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
   constexpr int kCoarseRebuildIters = 16;
+  int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
   bool scaleDone = false;
   cvd_iteration_record r0{};
   r0.cost = xCost;
@@ -1385,7 +1423,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dScale.p,
                          scaleDone ? 0 : 1, radius, h->dLam.p);
       scaleDone = true;
-      {
+      static const bool lagBJ = std::getenv("CVD_LAG_BJ") != nullptr;  // experiment
+      const bool willRefresh = !h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
+      if (!lagBJ || willRefresh) {
         const int slot = h->tBegin(KC_INVERSE);
         launchBlockInverse(c);
         h->tEnd(slot);
@@ -1404,10 +1444,17 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
           ++coarseAge;
         }
       }
-      const int cgIters = runPcg(c, h->dX.p);
+      // one read-back for the PCG result, the step statistics and the cost of the candidate point (the
+      // candidate is formed speculatively; it is simply not used when the model decrease is invalid)
+      const int cgIters = runPcg(c, h->dX.p, [&]() {
+        enqueueStats(c);
+        hipLaunchKernelGGL(k_apply_step, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, c.boundDepth0, h->dX.p,
+                           h->dDx.p, h->dXc.p);
+        HIP_CHECK(hipGetLastError());
+        enqueueCost(c, h->dXc.p);
+      });
       if (coarseAge == 0) cgAfterRefresh = cgIters;
       else cgExcess += std::max(0, cgIters - cgAfterRefresh);
-      stats();
       tLin += nowSeconds() - tl;
       rec.linear_iterations = cgIters;
       sum.total_linear_iterations += cgIters;
@@ -1424,12 +1471,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         continue;
       }
       invalid = 0;
-      hipLaunchKernelGGL(k_apply_step, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, c.boundDepth0, h->dX.p,
-                         h->dDx.p, h->dXc.p);
-      HIP_CHECK(hipGetLastError());
-      te = nowSeconds();
-      double candCost = evalCost(c, h->dXc.p);
-      tEval += nowSeconds() - te;
+      double candCost = h->hScal[S_COST];
       if (!std::isfinite(candCost)) candCost = std::numeric_limits<double>::max();
       const double stepNorm = std::sqrt(dd);
       rec.step_norm = stepNorm;
@@ -1454,11 +1496,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         std::swap(h->dX.n, h->dXc.n);
         xCost = candCost;
         te = nowSeconds();
-        const double chk = evalFull(c, h->dX.p);
+        const double chk = evalFull(c, h->dX.p, true);
         (void)chk;
         tEval += nowSeconds() - te;
-        HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
-        stats();
         gmax = h->hScal[S_GMAX];
         xNorm = std::sqrt(h->hScal[S_XX]);
         ++sum.num_successful_steps;
@@ -1522,6 +1562,24 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
     sd.type = CVD_XFORM_SPATIAL;
     sd.spatial_type = CVD_SPATIAL_IDENTITY;
     resetXforms(h, sd, true);
+  }
+  {
+    // Reserve the device buffers for the largest block of the schedule up front: growing them level by level
+    // costs a hipFree + hipMalloc (milliseconds, with a device synchronisation) per buffer and level.
+    const int N = (h->ddesc.depth_type == CVD_DEPTH_IDENTITY) ? 0 : valueNumParams(h->ddesc.value_xform);
+    size_t nDmax = static_cast<size_t>(h->nD());
+    if (p.coarse_to_fine && h->ddesc.depth_type != CVD_DEPTH_IDENTITY)
+      nDmax = std::max(nDmax, static_cast<size_t>(ctfCols) * ctfRows * initGrid[2] * N);
+    size_t nSmax = static_cast<size_t>(h->nS());
+    if (p.deferred_spatial_opt) nSmax = std::max(nSmax, static_cast<size_t>(dsoRows) * dsoCols * 2);
+    const size_t Bmax = 7 + nDmax + nSmax;
+    const size_t n = static_cast<size_t>(h->F) * Bmax;
+    h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
+    h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);
+    h->dQ.ensure(n); h->dHd.ensure(n); h->dMask.ensure(n);
+    h->dH.ensure(n * Bmax); h->dMinv.ensure(n * Bmax);
+    // one undirected work item per ~768 constraints and pair: bounded by pairs + constraints / 768
+    h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / 768) + 1) * 2 * Bmax);
   }
   cvd_solve_summary total{};
   auto accumulate = [&](const cvd_solve_summary& s, bool first) {

@@ -8,10 +8,16 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2
 v = synth.make_video(F, 384, 224, seed=1237)
 s = api.Solver(0); synth.load_into(s, v)
-s.set_options(verbose=1, pcg_relative_tolerance=tol, coarse_level=int(os.environ.get('CVD_COARSE', '1')))
+s.set_options(verbose=int(os.environ.get('CVD_VERBOSE', '1')), pcg_relative_tolerance=tol, coarse_level=int(os.environ.get('CVD_COARSE', '1')))
 s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
 p = OptParams.defaults()
 s.normalize_depth(p)
 t0 = time.time(); s.pose_optimization(p); dt = time.time() - t0
 sm = s.summary()
 print("TOTAL", dt, sm)
+if os.environ.get("CVD_TWICE"):
+    synth.load_into(s, v)
+    s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
+    s.normalize_depth(p)
+    t0 = time.time(); s.pose_optimization(p); dt = time.time() - t0
+    print("SECOND", dt, s.summary()["final_cost"])
