@@ -233,7 +233,7 @@ def main():
                              f"B={B}, {args.frames * B} unknowns), Cauchy 0.5, PerFrame intrinsics"),
                 "pairs": int(full_pairs), "constraints": int(n_active), "unknowns": int(args.frames * B),
                 "parallelism": "single-gpu" if world == 1 else (f"pair-sharded dp{world} + RCCL all-reduce" if shard else "video-per-gpu"),
-                "linear_solver": "block-Jacobi PCG, matrix-free J^T J",
+                "linear_solver": "PCG on matrix-free J^T J, two-level preconditioner (per-frame block-Jacobi + pose-graph coarse level)",
                 "pcg_iterations_per_lm_iteration": total_cg / max(1, done),
                 "solves_in_timed_region": n_solves,
             },

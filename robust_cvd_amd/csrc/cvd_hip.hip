@@ -312,6 +312,8 @@ struct cvd_handle_t {
   DevBuf<int> dFail;
   DevBuf<unsigned long long> dCount;
   double* hScal = nullptr;  // pinned
+  double* hStage[2] = {nullptr, nullptr};  // pinned staging for the per-solve state / mask transfers
+  size_t hStageN[2] = {0, 0};
   double* hPcg = nullptr;   // pinned: [S_DONE, S_TARGET, S_ITERS, -] per in-flight PCG batch
   hipEvent_t pcgEvent[2] = {nullptr, nullptr};
 
@@ -335,6 +337,7 @@ struct cvd_handle_t {
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
+    for (auto& p : hStage) if (p) (void)hipHostFree(p);
     if (hPcg) (void)hipHostFree(hPcg);
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -921,8 +924,20 @@ struct Ctx {
   int boundDepth0 = 0;
 };
 
+// Pinned staging buffer `which` with room for n doubles (pageable transfers of the F x B vectors cost ~1 ms each).
+static double* pinnedStage(cvd_handle* h, int which, size_t n) {
+  if (h->hStageN[which] < n) {
+    if (h->hStage[which]) HIP_CHECK(hipHostFree(h->hStage[which]));
+    h->hStage[which] = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hStage[which]), std::max<size_t>(n, 1) * sizeof(double)));
+    h->hStageN[which] = n;
+  }
+  return h->hStage[which];
+}
+
 static void uploadState(cvd_handle* h, const Layout& L, DevBuf<double>& dst) {
-  std::vector<double> x(static_cast<size_t>(L.F) * L.B);
+  const size_t nAll = static_cast<size_t>(L.F) * L.B;
+  double* x = pinnedStage(h, 1, nAll);
   const int nD = L.nD, nS = L.nS;
   for (int f = 0; f < L.F; ++f) {
     double* xf = &x[static_cast<size_t>(f) * L.B];
@@ -930,13 +945,14 @@ static void uploadState(cvd_handle* h, const Layout& L, DevBuf<double>& dst) {
     for (int i = 0; i < nD; ++i) xf[7 + i] = h->dparams[static_cast<size_t>(f) * nD + i];
     for (int i = 0; i < nS; ++i) xf[7 + nD + i] = h->sparams[static_cast<size_t>(f) * nS + i];
   }
-  dst.upload(x.data(), x.size(), h->stream);
+  dst.upload(x, nAll, h->stream);
   HIP_CHECK(hipStreamSynchronize(h->stream));
 }
 
 static void downloadState(cvd_handle* h, const Layout& L, const DevBuf<double>& src) {
-  std::vector<double> x(static_cast<size_t>(L.F) * L.B);
-  src.download(x.data(), x.size(), h->stream);
+  const size_t nAll = static_cast<size_t>(L.F) * L.B;
+  double* x = pinnedStage(h, 0, nAll);
+  src.download(x, nAll, h->stream);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   const int nD = L.nD, nS = L.nS;
   for (int f = 0; f < L.F; ++f) {
@@ -949,7 +965,10 @@ static void downloadState(cvd_handle* h, const Layout& L, const DevBuf<double>& 
 
 static void buildMask(cvd_handle* h, const Layout& L, const cvd_opt_params& p, ProblemKind kind,
                       const std::vector<int>& range) {
-  std::vector<double> m(static_cast<size_t>(L.F) * L.B, 0.0);
+  const size_t nAll = static_cast<size_t>(L.F) * L.B;
+  HIP_CHECK(hipStreamSynchronize(h->stream));  // an earlier transfer may still read the staging buffer
+  double* m = pinnedStage(h, 0, nAll);
+  std::fill(m, m + nAll, 0.0);
   for (int f : range) {
     double* mf = &m[static_cast<size_t>(f) * L.B];
     const bool poseFree = (kind == PK_POSE_STEP) && !p.fix_poses;
@@ -960,7 +979,7 @@ static void buildMask(cvd_handle* h, const Layout& L, const cvd_opt_params& p, P
     const bool spatialFree = (kind == PK_POSE_STEP) && !p.fix_spatial_xforms;
     for (int i = 0; i < L.nS; ++i) mf[7 + L.nD + i] = spatialFree ? 1.0 : 0.0;
   }
-  h->dMask.upload(m.data(), m.size(), h->stream);
+  h->dMask.upload(m, nAll, h->stream);
 }
 
 static void ensureBuffers(Ctx& c) {
@@ -1437,7 +1456,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
         const bool refresh = h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
         if (refresh) {
+          const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
           launchCoarseSetup(c);
+          h->tEnd(slot);
           coarseAge = 0;
           cgExcess = 0;
         } else {
