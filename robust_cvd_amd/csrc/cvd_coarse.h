@@ -13,8 +13,8 @@
 //   * block-sparse Cholesky A_c = L L^T on a host-computed plan        k_coarse_factor  (one workgroup)
 //   * W = L^-1, block-sparse: W_ij != 0 only if i is an ancestor of j in the elimination tree; its columns are
 //     independent chains, one wave each                                k_coarse_winv
-//   * per PCG iteration c = W^T (W Z^T r): two block-sparse products without level dependencies
-//                                                                      k_coarse_apply_w, k_coarse_apply_wt
+//   * per PCG iteration y = W Z^T r (k_coarse_apply_w, which also closes the PCG scalars: r^T Z c = |y|^2); the
+//     consumers form c_f = sum_t W_tf^T y_t for the frames they touch (coarseFrameCorrection, cvd_device.h)
 // The regularisers enter through H_ff only (their inter-frame part, the position regulariser, is left to
 // the fine level), so A_c stays SPD.  Everything is deterministic (no atomics in the solves) so that the ranks
 // of the pair-sharded multi-GPU mode stay bit-identical.
@@ -553,8 +553,12 @@ __global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double*
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
                                                          const double* __restrict__ rc, double* __restrict__ y,
-                                                         const double* __restrict__ scal, int init) {
+                                                         double* __restrict__ dotPart, double* __restrict__ scal,
+                                                         unsigned int* __restrict__ counter,
+                                                         const int* __restrict__ fail, int init, double tol2) {
   __shared__ double part[16][kCB];
+  __shared__ double red[16];
+  __shared__ int flag;
   if (!init && scal[S_DONE] != 0.0) return;
   const int i = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -579,65 +583,47 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += part[w][tid];
     y[i * kCB + tid] = t;
+    part[0][tid] = t * t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCB; ++k) t += part[0][k];
+    dotPart[i] = t;
+  }
+  // r^T Z A_c^-1 Z^T r = |W Z^T r|^2 = |y|^2: the last workgroup adds it to the block-Jacobi part of r^T z
+  // (S_RZPART, left by k_cg_update) and finishes the PCG scalars of this iteration
+  if (!lastBlockArrives(counter, gridDim.x, &flag)) return;
+  double t = 0.0;
+  for (int b = tid; b < static_cast<int>(gridDim.x); b += 1024) t += dotPart[b];
+  t = waveSum(t);
+  if (lane == 0) red[wv] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double dot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) dot += red[w];
+    if (*fail != 0) dot = 0.0;  // a broken-down factorisation switches the level off (the consumers use c = 0)
+    pcgFinishScalars(scal, init, scal[S_RZPART] + dot, scal[S_RR], tol2);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// c = W^T y: column j sums W_ij^T y_i over its path (one wave per column), written at the frame's coarse index.
-// The last workgroup adds rc . c to r^T z and finishes the PCG scalars that k_cg_update left open (S_RZPART
-// holds the block-Jacobi part of r^T z).
+// c = W^T y for ALL frames into global memory.  The PCG kernels form the c_f they need themselves
+// (coarseFrameCorrection); this kernel only runs with the position regulariser (whose rows read the neighbours'
+// directions) and for the test hook.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarsePlan P, const double* __restrict__ Wb,
-                                                         const double* __restrict__ y, const double* __restrict__ rc,
-                                                         double* __restrict__ cOut, double* __restrict__ dotPart,
-                                                         double* __restrict__ scal, unsigned int* __restrict__ counter,
-                                                         const int* __restrict__ fail,
-                                                         const unsigned char* __restrict__ modeActive, int init,
-                                                         double tol2) {
-  __shared__ double red[4];
-  __shared__ int flag;
+__global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, double* __restrict__ cOut,
+                                                         const double* __restrict__ scal, int init) {
+  __shared__ double cl[4][kCB];
   if (!init && scal[S_DONE] != 0.0) return;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int r = lane >> 3, c = lane & 7;
-  const int j = blockIdx.x * 4 + wv;
-  const bool ok = (*fail == 0);
-  double dot = 0.0;
-  if (j < P.F) {
-    const int w0 = P.wPtr[j], len = P.wPtr[j + 1] - w0;
-    // lane (r, c): W[r][c] y_i[r], summed over r below -> c_j[c]; four independent chains keep loads in flight
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int t = 0;
-    for (; t + 3 < len; t += 4) {
-      a0 += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
-      a1 += Wb[static_cast<size_t>(w0 + t + 1) * kCBB + lane] * y[P.wRow[w0 + t + 1] * kCB + r];
-      a2 += Wb[static_cast<size_t>(w0 + t + 2) * kCBB + lane] * y[P.wRow[w0 + t + 2] * kCB + r];
-      a3 += Wb[static_cast<size_t>(w0 + t + 3) * kCBB + lane] * y[P.wRow[w0 + t + 3] * kCB + r];
-    }
-    for (; t < len; ++t) a0 += Wb[static_cast<size_t>(w0 + t) * kCBB + lane] * y[P.wRow[w0 + t] * kCB + r];
-    double acc = (a0 + a1) + (a2 + a3);
-    // sum over r: lanes with equal c are 8 apart
-    acc += __shfl_xor(acc, 8, 64);
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    if (lane < kCB) {
-      const int k = P.order[j] * kCB + lane;
-      // inactive modes (identity rows of A_c) take no correction; a broken-down factorisation switches the level off
-      const double v = (ok && modeActive[k]) ? acc : 0.0;
-      cOut[k] = v;
-      dot = v * rc[k];
-    }
-  }
-  dot = waveSum(dot);
-  if (lane == 0) red[wv] = dot;
-  __syncthreads();
-  if (tid == 0) dotPart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-  if (!lastBlockArrives(counter, gridDim.x, &flag)) return;
-  double t = 0.0;
-  for (int b = tid; b < static_cast<int>(gridDim.x); b += 256) t += dotPart[b];
-  t = waveSum(t);
-  if (lane == 0) red[wv] = t;
-  __syncthreads();
-  if (tid == 0) pcgFinishScalars(scal, init, scal[S_RZPART] + ((red[0] + red[1]) + (red[2] + red[3])), scal[S_RR], tol2);
+  const int f = blockIdx.x * 4 + wv;
+  if (f >= F) return;
+  coarseFrameCorrection(V, f, lane, cl[wv]);
+  CVD_WAVE_SYNC();
+  if (lane < kCB) cOut[f * kCB + lane] = cl[wv][lane];
 }
 
 }  // namespace cvd

@@ -675,6 +675,47 @@ __device__ __forceinline__ double coarseAt(const double* __restrict__ cF, const 
   if (L.N >= 1 && L.depthType != kDepthIdentity && i < 7 + L.nD && (L.N == 1 || ((i - 7) % L.N) == 0)) return cF[f * kCB + 7];
   return 0.0;
 }
+// What the consumers of the preconditioned residual need from the coarse level: y = W Z^T r (k_coarse_apply_w) and
+// the W blocks of the frame's elimination-tree path; c_f = sum_t W_tf^T y_t is formed where it is used, which
+// saves a launch per PCG iteration -- or, Wb == nullptr and cF != nullptr, c of all frames was written by
+// k_coarse_apply_wt (the default: the path walk in every consumer prologue costs more than the launch).
+// Both null: level off.
+struct CoarseView {
+  const int* pos;    // frame -> elimination position
+  const int* wPtr;   // W blocks of column j: [wPtr[j], wPtr[j+1]), rows wRow[.]
+  const int* wRow;
+  const double* Wb;
+  const double* y;
+  const unsigned char* modeActive;
+  const int* fail;
+  const double* cF;
+};
+// One wave: out[0..7] = c_f (zero for inactive modes / a failed factorisation).  lane = (r, c) of the 8x8 block.
+__device__ __forceinline__ void coarseFrameCorrection(const CoarseView& V, int f, int lane, double* __restrict__ out) {
+  const int r = lane >> 3;
+  const int j = V.pos[f];
+  const int w0 = V.wPtr[j], len = V.wPtr[j + 1] - w0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int t = 0;
+  for (; t + 3 < len; t += 4) {
+    a0 += V.Wb[static_cast<size_t>(w0 + t) * 64 + lane] * V.y[V.wRow[w0 + t] * kCB + r];
+    a1 += V.Wb[static_cast<size_t>(w0 + t + 1) * 64 + lane] * V.y[V.wRow[w0 + t + 1] * kCB + r];
+    a2 += V.Wb[static_cast<size_t>(w0 + t + 2) * 64 + lane] * V.y[V.wRow[w0 + t + 2] * kCB + r];
+    a3 += V.Wb[static_cast<size_t>(w0 + t + 3) * 64 + lane] * V.y[V.wRow[w0 + t + 3] * kCB + r];
+  }
+  for (; t < len; ++t) a0 += V.Wb[static_cast<size_t>(w0 + t) * 64 + lane] * V.y[V.wRow[w0 + t] * kCB + r];
+  double acc = (a0 + a1) + (a2 + a3);
+  acc += __shfl_xor(acc, 8, 64);   // sum over r: lanes with equal c are 8 apart
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < kCB) out[lane] = (*V.fail == 0 && V.modeActive[f * kCB + lane]) ? acc : 0.0;
+}
+// (Z c_f)_i from the 8 values of coarseFrameCorrection
+__device__ __forceinline__ double coarseAtLds(const double* __restrict__ cl, const Layout& L, int i) {
+  if (i < 7) return cl[i];
+  if (L.N >= 1 && L.depthType != kDepthIdentity && i < 7 + L.nD && (L.N == 1 || ((i - 7) % L.N) == 0)) return cl[7];
+  return 0.0;
+}
 
 // Wave-level sum of a double (64 lanes), result in every lane.  Four DPP butterfly steps inside each 16-lane row
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS traffic), then the four row sums are combined

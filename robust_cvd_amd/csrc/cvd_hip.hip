@@ -797,7 +797,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.rc.ensure(n);
   C.y.ensure(n);
   C.c.ensure(n);
-  C.dotPart.ensure(static_cast<size_t>((F + 3) / 4));
+  C.dotPart.ensure(static_cast<size_t>(F));
   C.modeActive.ensure(n);
   C.fail.ensure(1);
   HIP_CHECK(hipStreamSynchronize(s));
@@ -1139,6 +1139,16 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   return h->hScal[S_COST];
 }
 
+static bool coarseFusedConsumers() {
+  static const bool v = std::getenv("CVD_COARSE_FUSED") != nullptr;  // experiment: c_f formed inside the consumers
+  return v;
+}
+static CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
+  if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  auto& C = h->coarse;
+  return CoarseView{C.pos.p, C.wPtr.p, C.wRow.p, walk ? C.Wb.p : nullptr, C.y.p, C.modeActive.p, C.fail.p, C.c.p};
+}
+
 // Fills the regulariser Jacobian cache for the products at linearisation point x (before runPcg / the J^T J hook).
 static void prepareMatvec(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
@@ -1169,10 +1179,10 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
                          const double* lam, double* q, bool withCoarse = false) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
-  const double* cF = withCoarse ? h->coarse.c.p : nullptr;  // z + Z c: the coarse part of the preconditioned residual
+  const CoarseView cF = coarseView(h, withCoarse, coarseFusedConsumers());  // z + Z c: the coarse part of the preconditioned residual
   const size_t B = c.L.B;
   if (c.L.includeStatic && c.nItems > 0) {
-    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8) * 8;
+    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
     const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
     const int slot = h->tBegin(KC_MATVEC_PAIRS);
     const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
@@ -1195,7 +1205,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     h->tEnd(slot);
   }
   {
-    const size_t lds = 3 * B * 8 + 8 * 8;  // xf, pf, qf + red[6] + flag
+    const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
@@ -1288,13 +1298,14 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   auto coarseApply = [&](int init) {
     // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
     hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
-                       h->coarse.y.p, h->dScal.p, init);
-    hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, h->coarse.plan, h->coarse.Wb.p,
-                       h->coarse.y.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p, h->dScal.p,
-                       h->dCounters.p + 3, h->coarse.fail.p, h->coarse.modeActive.p, init, tol2);
+                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2);
+    if (c.L.positionRegSqrt > 0.0 || !coarseFusedConsumers())
+      hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
+                         h->dScal.p, init);
   };
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
-                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc);
+                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
+                     h->coarse.modeActive.p);
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -1321,7 +1332,8 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
       launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p, coarse);
       const int slot = h->tBegin(KC_CG_UPDATE);
       hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc);
+                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
+                     h->coarse.modeActive.p);
       if (coarse) coarseApply(0);
       HIP_CHECK(hipGetLastError());
       h->tEnd(slot);
@@ -1442,9 +1454,11 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dScale.p,
                          scaleDone ? 0 : 1, radius, h->dLam.p);
       scaleDone = true;
-      static const bool lagBJ = std::getenv("CVD_LAG_BJ") != nullptr;  // experiment
+      // The block-Jacobi level follows lam every LM iteration; the coarse level is rebuilt on demand (below).
+      // (Lagging the block inverse as well is ~4% faster on the benchmark but makes the converged parameters
+      // visibly sensitive to rounding noise along the weak gauge directions.)
       const bool willRefresh = !h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
-      if (!lagBJ || willRefresh) {
+      {
         const int slot = h->tBegin(KC_INVERSE);
         launchBlockInverse(c);
         h->tEnd(slot);
@@ -1454,8 +1468,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         // across LM iterations (lagged lam and linearisation point).  A rebuild costs about as much as
         // kCoarseRebuildIters PCG iterations; it is done once the iterations spent beyond the count observed
         // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
-        const bool refresh = h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
-        if (refresh) {
+        if (willRefresh) {
           const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
           launchCoarseSetup(c);
           h->tEnd(slot);
@@ -2052,9 +2065,10 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
         for (size_t k = 0; k < n; ++k) {
           unit[k] = 1.0;
           C.rc.upload(unit.data(), n, s);
-          hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, scalTmp.p, 1);
-          hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, C.plan, C.Wb.p, C.y.p, C.rc.p, C.c.p,
-                             C.dotPart.p, scalTmp.p, h->dCounters.p + 3, C.fail.p, C.modeActive.p, 1, 0.0);
+          hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, C.dotPart.p,
+                             scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0);
+          hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
+                             scalTmp.p, 1);
           C.c.download(a_c_inverse + k * n, n, s);
           HIP_CHECK(hipStreamSynchronize(s));
           unit[k] = 0.0;

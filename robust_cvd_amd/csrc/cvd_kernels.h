@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
                                                       const double* __restrict__ mask, const double* __restrict__ z,
                                                       const double* __restrict__ pOld,
                                                       const double* __restrict__ scal, int useBeta,
-                                                      double* __restrict__ qPart, const double* __restrict__ cF) {
+                                                      double* __restrict__ qPart, CoarseView V) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -733,16 +733,25 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
   double* qa = pb + B;
   double* qb = qa + B;
   FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
+  double* cl = reinterpret_cast<double*>(fcs + 2) + 18 + 4 * 24 + 8;  // 2 x kCB coarse corrections
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
+  // coarse part of the preconditioned residual of the two frames (one wave each), see CoarseView
+  if (V.Wb != nullptr) {
+    if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
+    else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
+  } else if (tid < 2 * kCB) {
+    cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
+  }
+  __syncthreads();
   for (int i = tid; i < B; i += 256) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
     xa[i] = x[ia];
     xb[i] = x[ib];
-    pa[i] = (z[ia] + coarseAt(cF, L, fa, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + coarseAt(cF, L, fb, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    pa[i] = (z[ia] + coarseAtLds(cl, L, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
@@ -878,8 +887,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nItems, RegCache rc,
-                                                       const double* __restrict__ cF) {
+                                                       int distMode, int nItems, RegCache rc, CoarseView V) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -887,13 +895,20 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   double* pf = xf + B;   // masked direction
   double* qf = pf + B;
   double* red = qf + B;
+  double* cl = red + 8;  // kCB coarse corrections of this frame
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   const size_t base = static_cast<size_t>(f) * B;
+  if (V.Wb != nullptr) {
+    if (tid < 64) coarseFrameCorrection(V, f, tid, cl);
+  } else if (tid < kCB) {
+    cl[tid] = (V.cF != nullptr) ? V.cF[f * kCB + tid] : 0.0;
+  }
+  __syncthreads();
   for (int i = tid; i < B; i += 256) {
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
-    const double pv = z[base + i] + coarseAt(cF, L, f, i) * mask[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
+    const double pv = z[base + i] + coarseAtLds(cl, L, i) * mask[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
     pNew[base + i] = pv;
     xf[i] = x[base + i];
     pf[i] = pv * mask[base + i];
@@ -946,7 +961,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
       double a = 0.0;
       for (int j = 0; j < 3; ++j) {
         const size_t idx = static_cast<size_t>(k + j) * B + tid;
-        a += cf[j] * (z[idx] + coarseAt(cF, L, k + j, tid) + (useBeta ? beta * pOld[idx] : 0.0)) * mask[idx];
+        a += cf[j] * (z[idx] + coarseAt(V.cF, L, k + j, tid) + (useBeta ? beta * pOld[idx] : 0.0)) * mask[idx];
       }
       acc += w * cf[o] * a;
     }
@@ -1037,7 +1052,8 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     unsigned int* __restrict__ counter, double* __restrict__ dx,
                                                     double* __restrict__ r, double* __restrict__ z,
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
-                                                    double tol2, double* __restrict__ rc) {
+                                                    double tol2, double* __restrict__ rc,
+                                                    const unsigned char* __restrict__ modeActive) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
   const int B = L.B;
@@ -1064,13 +1080,14 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   __syncthreads();
   if (rc != nullptr) {
     // restriction to the coarse level: Z_f^T r_f (the 7 pose-like entries and the sum over the depth-scale vertices)
-    if (tid < 7) rc[f * kCB + tid] = rf[tid];
+    // (inactive modes are identity rows of the coarse matrix: they must not feed the coarse solve)
+    if (tid < 7) rc[f * kCB + tid] = modeActive[f * kCB + tid] ? rf[tid] : 0.0;
     if (tid >= 64 && tid < 128) {
       const int nV = (L.N >= 1 && L.depthType != kDepthIdentity) ? L.nD / L.N : 0;
       double a = 0.0;
       for (int v = tid - 64; v < nV; v += 64) a += rf[7 + v * L.N];
       a = waveSum(a);
-      if (tid == 64) rc[f * kCB + 7] = a;
+      if (tid == 64) rc[f * kCB + 7] = modeActive[f * kCB + 7] ? a : 0.0;
     }
   }
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
@@ -1248,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
                                                            const double* __restrict__ scal, int useBeta,
-                                                           double* __restrict__ qPart, const double* __restrict__ cF) {
+                                                           double* __restrict__ qPart, CoarseView V) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
@@ -1264,16 +1281,25 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   double* E = reinterpret_cast<double*>(fcs + 2);  // E_a[9], E_b[9]
   double* red = E + 18;                            // 27 reduced accumulators
   double* W = red + 32;                            // transposed reduction scratch: kRedVals rows x kRedStride
+  double* cl = W;                                  // prologue only: 2 x kCB coarse corrections
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
+  // coarse part of the preconditioned residual of the two frames (one wave each), see CoarseView
+  if (V.Wb != nullptr) {
+    if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
+    else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
+  } else if (tid < 2 * kCB) {
+    cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
+  }
+  __syncthreads();
   for (int i = tid; i < B; i += 256) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
     xa[i] = x[ia];
     xb[i] = x[ib];
-    pa[i] = (z[ia] + coarseAt(cF, L, fa, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + coarseAt(cF, L, fb, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    pa[i] = (z[ia] + coarseAtLds(cl, L, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
     qa[i] = 0.0;
     qb[i] = 0.0;
   }
