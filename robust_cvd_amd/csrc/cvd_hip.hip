@@ -13,6 +13,7 @@
 // gfx950 only. There is NO CPU path: every entry point that computes fails if no HIP device is usable.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -35,6 +36,7 @@
 #include "../../include/cvd_hip.h"
 #include "cvd_kernels.h"
 #include "cvd_coarse.h"
+#include "cvd_triplets.h"
 
 namespace cvd {
 
@@ -265,6 +267,20 @@ struct cvd_handle_t {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   bool haveTriplets = false;
+  // scene-flow smoothness triplets (cvd_triplets.h): groups keyed by the centre frame
+  std::vector<int> tripCenter;
+  std::vector<long long> tripOff;
+  long long tripC = 0;
+  DevBuf<float> dTLoc, dTDsrc;
+  DevBuf<float2> dTNdc;
+  DevBuf<unsigned char> dTStatic;
+  DevBuf<int> dTGroupOfC, dTCenterAll, dTCenter, dTSlot, dFtOff, dFtList;
+  DevBuf<long long> dTOff;
+  DevBuf<double> dCostTrip;
+  std::vector<int> tripActive;      // groups this rank evaluates for the compiled range
+  bool tableWithTriplets = false;   // the compiled work decomposition includes the triplet rows
+  long long numValidTrip = 0;
+  int qRows = 0;                    // rows of the partial-product buffer (2 per pair item + 3 per triplet group)
 
   // work decomposition
   std::vector<int> itemFa, itemFb;
@@ -296,7 +312,7 @@ struct cvd_handle_t {
     std::vector<int> itemEdge;
     DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr,
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev;
-    DevBuf<double> edges, edgesUsed, diag, Lb, Linv, Wb, rc, y, c, dotPart;  // edgesUsed: snapshot the factor was built from
+    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, y, c, dotPart;
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
@@ -365,6 +381,26 @@ struct cvd_handle_t {
   }
   void tEnd(int slot) {
     if (slot >= 0) HIP_CHECK(hipEventRecord(evPool[slot].second, stream));
+  }
+  // Event pair for hipExtLaunchKernelGGL(start, stop): the events take the kernel's own begin / end time stamps
+  // (what rocprofv3 --kernel-trace reports), without the dispatch gap a record-before / record-after pair includes.
+  int tReserve(int kc, hipEvent_t& start, hipEvent_t& stop) {
+    start = nullptr;
+    stop = nullptr;
+    if (!(timing & (1 << kc))) return -1;
+    if (evUsed == evPool.size()) {
+      hipEvent_t a, b;
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+      evPool.emplace_back(a, b);
+      evClass.push_back(kc);
+      evIter.push_back(-1);
+    }
+    evClass[evUsed] = kc;
+    evIter[evUsed] = curPcgIter;
+    start = evPool[evUsed].first;
+    stop = evPool[evUsed].second;
+    return static_cast<int>(evUsed++);
   }
   void tDropFrom(size_t firstSlot, int firstDeadIter) {
     for (size_t i = firstSlot; i < evUsed; ++i)
@@ -505,8 +541,15 @@ static void gridXformSplit(cvd_handle* h, const cvd_xform_desc& nd) {
 static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
   if (p.adaptive_deformation_cost > 0.0)
     throw std::runtime_error("AdaptiveDeformationCost is not implemented (off by default in the reference).");
-  if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP)
-    throw std::runtime_error("Scene-flow smoothness (triplet) loss is not implemented on the device path yet.");
+  if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP) {
+    if (p.smooth_loss_type != CVD_SMOOTH_EUCLIDEAN_LAPLACIAN && p.smooth_loss_type != CVD_SMOOTH_REPRO_DISPARITY_LAPLACIAN)
+      throw std::runtime_error("Scene-flow smoothness: only EuclideanLaplacian and ReproDisparityLaplacian are implemented "
+                               "on the device path.");
+    if (p.intr_opt == CVD_INTR_SHARED)
+      throw std::runtime_error("Scene-flow smoothness with IntrinsicsOptimization::Shared is not implemented on the "
+                               "device path.");
+    if (!h->haveTriplets) throw std::runtime_error("Missing triplet constraints.");
+  }
   Layout L{};
   L.F = h->F;
   L.B = h->Bsz();
@@ -809,10 +852,10 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
 }
 
 // ---- compile the constraint table + work decomposition for a frame range -------------------------------
-static void compileTable(cvd_handle* h, const std::vector<int>& range) {
+static void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplets = false) {
   std::vector<unsigned char> inRange(h->F, 0);
   for (int f : range) inRange[f] = 1;
-  if (h->tableValid && inRange == h->tableRange) return;
+  if (h->tableValid && inRange == h->tableRange && withTriplets == h->tableWithTriplets) return;
   hipStream_t s = h->stream;
   h->dInRange.upload(inRange.data(), inRange.size(), s);
   {
@@ -874,6 +917,53 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
       frameItems[fb].push_back(item * 2 + 1);
     }
   }
+  // ---- scene-flow smoothness triplets: table, active groups (all three frames in range; groups are sharded
+  // over the ranks like the per-frame regularisers), per-frame (group, role) lists and their partial-product rows
+  h->tripActive.clear();
+  h->numValidTrip = 0;
+  std::vector<std::vector<int>> frameTrips(h->F);
+  if (withTriplets) {
+    std::map<int, int> groupOf;
+    for (size_t g = 0; g < h->tripCenter.size(); ++g) groupOf[h->tripCenter[g]] = static_cast<int>(g);
+    if (!range.empty()) {
+      // reference lib/PoseOptimizer.cpp:1255-1262: every in-range consecutive triple needs its constraints
+      for (int fr = range.front(); fr < range.back() - 1; ++fr) {
+        if (!inRange[fr] || !inRange[fr + 1] || !inRange[fr + 2]) continue;
+        auto itg = groupOf.find(fr + 1);
+        if (itg == groupOf.end()) throw std::runtime_error("Missing triplet constraints.");
+        const int g = itg->second;
+        h->tripActive.push_back(g);
+      }
+    }
+    h->dTNdc.ensure(static_cast<size_t>(std::max<long long>(h->tripC, 1)) * 3);
+    h->dTDsrc.ensure(static_cast<size_t>(std::max<long long>(h->tripC, 1)) * 3);
+    HIP_CHECK(hipMemsetAsync(h->dCount.p, 0, sizeof(unsigned long long), s));
+    if (h->tripC > 0) {
+      const unsigned grid = static_cast<unsigned>((h->tripC + 255) / 256);
+      hipLaunchKernelGGL(k_build_triplet_table, dim3(grid), dim3(256), 0, s, h->W, h->H, h->invAspect, h->tripC,
+                         h->dTLoc.p, h->dTGroupOfC.p, h->dTCenterAll.p, h->F, h->dInRange.p, h->dDepth.p, h->dTNdc.p,
+                         h->dTDsrc.p, h->dCount.p);
+      HIP_CHECK(hipGetLastError());
+    }
+    unsigned long long nvt = 0;
+    HIP_CHECK(hipMemcpyAsync(&nvt, h->dCount.p, sizeof(nvt), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->numValidTrip = static_cast<long long>(nvt);
+    // this rank's share of the groups
+    std::vector<int> mine;
+    for (size_t k = 0; k < h->tripActive.size(); ++k)
+      if (static_cast<int>(k) % h->world == h->rank) mine.push_back(h->tripActive[k]);
+    h->tripActive.swap(mine);
+    const int pairCodes = static_cast<int>(h->itemFa.size()) * 2;
+    for (size_t k = 0; k < h->tripActive.size(); ++k) {
+      const int f1 = h->tripCenter[h->tripActive[k]];
+      for (int role = 0; role < 3; ++role) {
+        frameItems[f1 - 1 + role].push_back(pairCodes + static_cast<int>(k) * 3 + role);
+        frameTrips[f1 - 1 + role].push_back((static_cast<int>(k) << 2) | role);
+      }
+    }
+  }
+  h->tableWithTriplets = withTriplets;
   h->coarse.valid = false;
   if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns && !h->itemFa.empty()) {
     std::map<std::pair<int, int>, int> edgeId;
@@ -900,9 +990,35 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range) {
   h->dItemFa.upload(h->itemFa.data(), h->itemFa.size(), s);
   h->dItemFb.upload(h->itemFb.data(), h->itemFb.size(), s);
   h->dItemRange.upload(h->itemRange.data(), h->itemRange.size(), s);
-  std::vector<int> itemSlot(fiList.size(), 0);  // [item * 2 + side] -> row of the partial-product buffer
+  std::vector<int> itemSlot(fiList.size(), 0);  // [item * 2 + side | pairs * 2 + group * 3 + role] -> row
   for (size_t e = 0; e < fiList.size(); ++e) itemSlot[fiList[e]] = static_cast<int>(e);
+  h->qRows = static_cast<int>(fiList.size());
   h->dItemSlot.upload(itemSlot.data(), itemSlot.size(), s);
+  if (withTriplets) {
+    // compact per-rank group arrays in tripActive order: offsets / centre / rows; per-frame (group, role) lists
+    const size_t nG = h->tripActive.size();
+    std::vector<long long> tOff(2 * std::max<size_t>(nG, 1), 0);
+    std::vector<int> tCen(std::max<size_t>(nG, 1), 0), tSlot(3 * std::max<size_t>(nG, 1), 0);
+    const int pairCodes = static_cast<int>(h->itemFa.size()) * 2;
+    for (size_t k = 0; k < nG; ++k) {
+      const int g = h->tripActive[k];
+      tOff[2 * k] = h->tripOff[g];
+      tOff[2 * k + 1] = h->tripOff[g + 1];
+      tCen[k] = h->tripCenter[g];
+      for (int role = 0; role < 3; ++role) tSlot[3 * k + role] = itemSlot[pairCodes + static_cast<int>(k) * 3 + role];
+    }
+    std::vector<int> ftOff(h->F + 1, 0), ftList;
+    for (int f = 0; f < h->F; ++f) {
+      ftOff[f + 1] = ftOff[f] + static_cast<int>(frameTrips[f].size());
+      ftList.insert(ftList.end(), frameTrips[f].begin(), frameTrips[f].end());
+    }
+    h->dTOff.upload(tOff.data(), tOff.size(), s);
+    h->dTCenter.upload(tCen.data(), tCen.size(), s);
+    h->dTSlot.upload(tSlot.data(), tSlot.size(), s);
+    h->dFtOff.upload(ftOff.data(), ftOff.size(), s);
+    h->dFtList.upload(ftList.data(), ftList.size(), s);
+    h->dCostTrip.ensure(std::max<size_t>(nG, 1));
+  }
   h->dFiOff.upload(fiOff.data(), fiOff.size(), s);
   h->dFiList.upload(fiList.data(), fiList.size(), s);
   h->dFpOff.upload(fpOff.data(), fpOff.size(), s);
@@ -922,6 +1038,8 @@ struct Ctx {
   int nItems;
   size_t n;  // F * B
   int boundDepth0 = 0;
+  bool trip = false;  // scene-flow smoothness triplets are part of this problem
+  TripletTable TT{};
 };
 
 // Pinned staging buffer `which` with room for n doubles (pageable transfers of the F x B vectors cost ~1 ms each).
@@ -990,7 +1108,7 @@ static void ensureBuffers(Ctx& c) {
   h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
   h->dHd.ensure(n);
   h->dH.ensure(n * B); h->dMinv.ensure(n * B);
-  h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(c.nItems) * 2 * B));
+  h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(std::max(h->qRows, c.nItems * 2)) * B));
   h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
@@ -1051,6 +1169,14 @@ static void enqueueCost(Ctx& c, const double* x) {
                        h->dCostFrame.p);
   });
   HIP_CHECK(hipGetLastError());
+  if (c.trip && c.TT.nGroups > 0) {
+    // scene-flow smoothness: group costs are added to the centre frames' entries
+    CVD_DISPATCH(c.KD, c.KS, {
+      hipLaunchKernelGGL((k_cost_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), 0, s, c.L, c.TT, x, h->dFc.p,
+                         h->dCostFrame.p);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
                      h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
   HIP_CHECK(hipGetLastError());
@@ -1105,21 +1231,19 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
     hipLaunchKernelGGL(k_shared_focal_fixup, dim3(1), dim3(256), 0, s, c.L, h->dFocal.p, h->dFocal.p + c.L.F, h->dMask.p,
                        h->dG.p, h->dH.p);
   HIP_CHECK(hipGetLastError());
-  h->tEnd(slot);
-  if (h->coarseOn) {
-    // off-diagonal blocks of the coarse (pose-graph) matrix at this linearisation point
-    auto& C = h->coarse;
-    HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
-    const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
+  if (c.trip && c.TT.nGroups > 0) {
+    // scene-flow smoothness: its share of g / H_ff is added to the pair assembly's output, its cost to the frame sums
+    const size_t ldsT = (B * (B + 1) / 2 + B) * 8;
     CVD_DISPATCH(c.KD, c.KS, {
-      allowLds(k_coarse_edges<KD, KS>, ldsE);
-      hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
-                         C.itemEdgeDev.p, C.edges.p);
+      allowLds(k_assemble_triplets<KD, KS>, ldsT);
+      hipLaunchKernelGGL((k_assemble_triplets<KD, KS>), dim3(c.L.F), dim3(256), ldsT, s, c.L, c.TT, x, h->dFc.p,
+                         h->dMask.p, h->dFtOff.p, h->dFtList.p, h->dG.p, h->dH.p);
+      hipLaunchKernelGGL((k_cost_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), 0, s, c.L, c.TT, x, h->dFc.p,
+                         h->dCostFrame.p);
     });
     HIP_CHECK(hipGetLastError());
-    if (h->world > 1)
-      NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
   }
+  h->tEnd(slot);
   if (h->world > 1) {
     // the exchange step of the pair-sharded mode: one all-reduce of [g | H_ff | per-frame cost] per Jacobian evaluation
     NCCL_CHECK(ncclGroupStart());
@@ -1184,25 +1308,37 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
     const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
-    const int slot = h->tBegin(KC_MATVEC_PAIRS);
+    hipEvent_t evStart, evStop;
+    (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
     const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
     if (fast && c.KD == 4) {
       allowLds(k_matvec_pairs_fast<4>, ldsFast);
-      hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
-                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+      hipExtLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L, c.T,
+                            c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p), z,
+                            pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
     } else if (fast) {
       allowLds(k_matvec_pairs_fast<1>, ldsFast);
-      hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, h->dFc.p,
-                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+      hipExtLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L, c.T,
+                            c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p), z,
+                            pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_matvec_pairs<KD, KS>, lds);
-        hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
-                           h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+        hipExtLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, evStart, evStop, 0, c.L, c.T,
+                              c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p),
+                              z, pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
       });
     }
     HIP_CHECK(hipGetLastError());
-    h->tEnd(slot);
+  }
+  if (c.trip && c.TT.nGroups > 0) {
+    const size_t ldsT = (9 * B + 3 * kCB) * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_matvec_triplets<KD, KS>, ldsT);
+      hipLaunchKernelGGL((k_matvec_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), ldsT, s, c.L, c.TT, x, h->dFc.p,
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    });
+    HIP_CHECK(hipGetLastError());
   }
   {
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
@@ -1252,14 +1388,27 @@ static void launchBlockInverse(Ctx& c) {
 }
 
 // Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
-static void launchCoarseSetup(Ctx& c) {
+static void launchCoarseSetup(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   auto& C = h->coarse;
+  const size_t B = c.L.B;
   HIP_CHECK(hipMemsetAsync(C.fail.p, 0, sizeof(int), s));
-  C.edgesUsed.ensure(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
-  HIP_CHECK(hipMemcpyAsync(C.edgesUsed.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB * sizeof(double),
-                           hipMemcpyDeviceToDevice, s));
+  {
+    // off-diagonal blocks of the coarse (pose-graph) matrix at the current linearisation point x (only here: the
+    // factor is rebuilt on demand, not at every accepted step)
+    launchFrameConsts(c, x);
+    HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
+    const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_coarse_edges<KD, KS>, ldsE);
+      hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
+                         C.itemEdgeDev.p, C.edges.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    if (h->world > 1)
+      NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
+  }
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
                      C.modeActive.p);
   static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
@@ -1299,7 +1448,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
     hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
                        h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2);
-    if (c.L.positionRegSqrt > 0.0 || !coarseFusedConsumers())
+    if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
@@ -1315,6 +1464,9 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
   // batches of `every` iterations and reads the control scalars of batch b only before enqueuing batch b + 2, so
   // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
+  // (profiling aid: CVD_PCG_LOCKSTEP=1 checks after every iteration and never runs ahead, so that per-launch
+  // counter averages contain no early-exit launches)
+  static const bool lockstep = std::getenv("CVD_PCG_LOCKSTEP") != nullptr;
   constexpr int kSlots = 2;
   const size_t firstTimerSlot = h->evUsed;
   int enq = 0, batch = 0;
@@ -1326,7 +1478,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
       if (h->hPcg[sl * 4 + 0] != 0.0) break;
     }
     if (enq >= maxIt) break;
-    const int n = std::min(every, maxIt - enq);
+    const int n = lockstep ? 1 : std::min(every, maxIt - enq);
     for (int i = 0; i < n; ++i, ++enq) {
       h->curPcgIter = enq;
       launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p, coarse);
@@ -1348,6 +1500,10 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     HIP_CHECK(hipMemcpyAsync(h->hPcg + sl * 4, h->dScal.p + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipEventRecord(h->pcgEvent[sl], s));
     ++batch;
+    if (lockstep) {
+      spinEvent(h->pcgEvent[sl]);
+      if (h->hPcg[sl * 4 + 0] != 0.0) break;
+    }
   }
   h->curPcgIter = -1;
   if (tail) tail();  // follow-up work that does not need the host's decision rides on the same read-back
@@ -1356,6 +1512,20 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   const int iters = static_cast<int>(h->hScal[S_ITERS]);
   h->tDropFrom(firstTimerSlot, iters);
   return iters;
+}
+
+// Scene-flow smoothness triplets of this problem (reference lib/PoseOptimizer.cpp:899): on when a weight is > 0.
+static bool wantsTriplets(const cvd_opt_params& p, ProblemKind kind) {
+  return kind == PK_POSE_STEP && (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0);
+}
+static void bindTriplets(Ctx& c, const cvd_opt_params& p, ProblemKind kind) {
+  cvd_handle* h = c.h;
+  c.trip = wantsTriplets(p, kind) && c.L.includeStatic;
+  if (!c.trip) return;
+  c.TT = TripletTable{h->dTNdc.p, h->dTDsrc.p, h->dTStatic.p, h->dTOff.p, h->dTCenter.p, h->dTSlot.p,
+                      static_cast<int>(h->tripActive.size()),
+                      p.smooth_loss_type == CVD_SMOOTH_EUCLIDEAN_LAPLACIAN ? kSmoothEuclidLaplacian : kSmoothDisparityLaplacian,
+                      std::sqrt(std::max(0.0, p.smooth_static_weight)), std::sqrt(std::max(0.0, p.smooth_dynamic_weight))};
 }
 
 static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
@@ -1367,7 +1537,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, kind);
   tapCounts(c.L, c.KD, c.KS);
-  compileTable(h, range);
+  compileTable(h, range, wantsTriplets(p, kind));
   if (h->medianDirty) {
     h->dMedian.upload(h->median.data(), h->median.size(), h->stream);
     h->medianDirty = false;
@@ -1377,6 +1547,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
+  bindTriplets(c, p, kind);
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && c.nItems > 0 && !h->forceGeneric;
   ensureBuffers(c);
   buildMask(h, c.L, p, kind, range);
@@ -1398,7 +1569,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
         regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
   }
-  sum.num_residual_blocks = static_cast<int>((c.L.includeStatic ? h->numValid : 0) + regBlocks);
+  sum.num_residual_blocks = static_cast<int>((c.L.includeStatic ? h->numValid : 0) + (c.trip ? h->numValidTrip : 0) + regBlocks);
 
   double tEval = 0.0, tLin = 0.0;
   double te = nowSeconds();
@@ -1470,7 +1641,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
         if (willRefresh) {
           const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
-          launchCoarseSetup(c);
+          launchCoarseSetup(c, h->dX.p);
           h->tEnd(slot);
           coarseAge = 0;
           cgExcess = 0;
@@ -1693,7 +1864,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, PK_POSE_STEP);
   tapCounts(c.L, c.KD, c.KS);
-  compileTable(h, range);
+  compileTable(h, range, wantsTriplets(p, PK_POSE_STEP));
   if (h->medianDirty) {
     h->dMedian.upload(h->median.data(), h->median.size(), h->stream);
     h->medianDirty = false;
@@ -1702,6 +1873,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   c.nItems = static_cast<int>(h->itemFa.size());
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  bindTriplets(c, p, PK_POSE_STEP);
   h->coarseOn = false;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);
@@ -1724,7 +1896,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
     if (c.L.positionRegSqrt > 0.0)
       for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
         regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
-    *nres = static_cast<int32_t>(h->numValid + regBlocks);
+    *nres = static_cast<int32_t>(h->numValid + (c.trip ? h->numValidTrip : 0) + regBlocks);
   }
   if (gradient) h->dG.download(gradient, c.n, s);
   if (hdiag) h->dH.download(hdiag, c.n * c.L.B, s);
@@ -1937,8 +2109,29 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
   });
 }
 
-int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t, const int32_t*, const int64_t*, const float*, const uint8_t*) {
-  CVD_TRY(h, h->haveTriplets = true);  // stored for the (not yet implemented) smoothness loss
+int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t numTriplets, const int32_t* centers, const int64_t* offsets,
+                                    const float* loc6, const uint8_t* isStatic) {
+  CVD_TRY(h, {
+    const long long C = numTriplets > 0 ? offsets[numTriplets] : 0;
+    h->tripCenter.assign(centers, centers + numTriplets);
+    h->tripOff.assign(offsets, offsets + numTriplets + 1);
+    h->tripC = C;
+    for (int c : h->tripCenter)
+      if (c < 1 || c + 1 >= h->F) throw std::runtime_error("triplet centre frame out of range");
+    std::vector<int> groupOfC(static_cast<size_t>(std::max<long long>(C, 1)), 0);
+    for (int g = 0; g < numTriplets; ++g)
+      for (long long c = offsets[g]; c < offsets[g + 1]; ++c) groupOfC[c] = g;
+    std::vector<unsigned char> st(static_cast<size_t>(std::max<long long>(C, 1)), 1);
+    if (isStatic && C > 0) std::memcpy(st.data(), isStatic, C);
+    hipStream_t s = h->stream;
+    h->dTLoc.upload(loc6, static_cast<size_t>(C) * 6, s);
+    h->dTStatic.upload(st.data(), st.size(), s);
+    h->dTGroupOfC.upload(groupOfC.data(), groupOfC.size(), s);
+    h->dTCenterAll.upload(h->tripCenter.data(), h->tripCenter.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->haveTriplets = true;
+    h->tableValid = false;
+  });
 }
 
 int32_t cvd_set_poses(cvd_handle* h, const cvd_frame_pose* poses) {
@@ -2080,7 +2273,7 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
       std::vector<unsigned char> act(n);
       std::vector<int> efa(C.nEdges), efb(C.nEdges);
       C.diag.download(diag.data(), diag.size(), s);
-      C.edgesUsed.download(edges.data(), static_cast<size_t>(C.nEdges) * kCBB, s);
+      C.edges.download(edges.data(), static_cast<size_t>(C.nEdges) * kCBB, s);
       C.modeActive.download(act.data(), n, s);
       C.edgeFa.download(efa.data(), efa.size(), s);
       C.edgeFb.download(efb.data(), efb.size(), s);

@@ -246,6 +246,60 @@ def make_video(num_frames, width, height, seed=1234, pairs=None, spacing=12.5, f
               "field_amp": field_amp})
 
 
+def make_triplets(video: SyntheticVideo, spacing=25.0, seed=77, flow_noise_px=0.25, dynamic_fraction=0.25):
+    """Triplet constraints of the scene-flow smoothness loss (reference lib/FlowConstraints.h:116-205, keyed by the
+    centre frame): points sampled in frame c, projected with the true geometry into c-1 and c+1 (+ flow noise).
+    Returns (centers [T] int32, offsets [T+1] int64, loc6 [C, 6] float32 = loc(c-1), loc(c), loc(c+1), is_static [C])."""
+    rng = np.random.default_rng(seed)
+    F, W, H = video.num_frames, video.width, video.height
+    A = float(video.aspect)
+    fy = video.true_fy
+    fx = fy * A
+    R = rodrigues(video.true_w)
+    t = video.true_t
+    scale_x = np.float32(1.0) / np.float32(W)
+    scale_y = np.float32(video.inv_aspect) / np.float32(H)
+    row_h = spacing * np.sqrt(3.0) / 2.0
+    rows = int(np.floor(H / row_h)) + 2
+    cols = int(np.floor(W / spacing)) + 2
+    jj, ii = np.meshgrid(np.arange(cols), np.arange(rows))
+    base = np.stack([((jj + 0.5 * (ii % 2)) * spacing).ravel(), (ii * row_h).ravel()], axis=-1)
+    centers, off, chunks, flags = [], [0], [], []
+    for c in range(1, F - 1):
+        pix = base + rng.uniform(-spacing, 0.0, size=(1, 2)) + rng.uniform(-0.9, 0.9, size=base.shape)
+        ix, iy = np.rint(pix[:, 0]), np.rint(pix[:, 1])
+        ok = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+        nx = -1.0 + 2.0 * ix / W
+        ny = 1.0 - 2.0 * iy / H
+        D = scene_depth(t[c], R[c], fx, fy, nx, ny)
+        cam = np.stack([nx * fx, ny * fy, -np.ones_like(nx)], axis=-1)
+        X = t[c] + D[:, None] * (cam @ R[c].T)
+        l = np.empty((base.shape[0], 6), dtype=np.float32)
+        l[:, 2] = ix.astype(np.float32) * scale_x
+        l[:, 3] = iy.astype(np.float32) * scale_y
+        for k, o in ((0, c - 1), (4, c + 1)):
+            q = (X - t[o]) @ R[o]  # R_o^T (X - t_o)
+            z = -q[:, 2]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = q[:, 0] / z / fx
+                v = q[:, 1] / z / fy
+            x1 = ((u + 1.0) * 0.5 * W + rng.normal(0.0, flow_noise_px, size=u.shape)).astype(np.float32)
+            y1 = ((1.0 - v) * 0.5 * H + rng.normal(0.0, flow_noise_px, size=v.shape)).astype(np.float32)
+            ok &= (z > 1e-3) & np.isfinite(x1) & np.isfinite(y1)
+            ok &= (np.floor(x1 + np.float32(0.5)) >= 0) & (np.floor(x1 + np.float32(0.5)) < W)
+            ok &= (np.floor(y1 + np.float32(0.5)) >= 0) & (np.floor(y1 + np.float32(0.5)) < H)
+            l[:, k] = x1 * scale_x
+            l[:, k + 1] = y1 * scale_y
+        l = l[ok]
+        centers.append(c)
+        chunks.append(l)
+        flags.append((rng.uniform(size=l.shape[0]) >= dynamic_fraction).astype(np.uint8))
+        off.append(off[-1] + l.shape[0])
+    loc6 = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 6), np.float32)
+    st = np.concatenate(flags) if flags else np.zeros((0,), np.uint8)
+    return np.asarray(centers, np.int32), np.asarray(off, np.int64), loc6, st
+
+
 def load_into(binding, video: SyntheticVideo, focal_long=0.3461538376301239):
     """Upload a SyntheticVideo through the common C-ABI surface (product Solver or test Oracle)."""
     binding.set_video(video.num_frames, video.width, video.height, video.aspect, video.inv_aspect)
