@@ -32,6 +32,9 @@ CASES = {
     "grid3x3_log": (4, 64, 40, 27, ("grid", 3, 3, 1, False), ("bilinear", 3, 2), 2, 3, 0.3),
     "grid4x3_shared_intrinsics": (5, 64, 40, 28, ("grid", 4, 3, 1, False), ("identity",), 1, 1, 0.1),
     "global_shared_intrinsics": (5, 64, 40, 29, ("global", 1), ("identity",), 1, 1, 0.1),
+    # scene-flow smoothness triplets (a9): name -> same tuple + (smooth loss type, static weight, dynamic weight)
+    "grid4x3_triplets_disparity_laplacian": (6, 64, 40, 30, ("grid", 4, 3, 1, False), ("identity",), 2, 1, 0.1, (1, 2.0, 0.5)),
+    "global_triplets_euclidean_laplacian": (6, 64, 40, 31, ("global", 1), ("bilinear", 3, 2), 2, 1, 0.1, (0, 1.5, 1.0)),
 }
 
 
@@ -48,7 +51,8 @@ def make_descs(dargs, sargs):
 
 
 def case_inputs(name):
-    F, W, H, seed, dargs, sargs, intr, loss, reg = CASES[name]
+    F, W, H, seed, dargs, sargs, intr, loss, reg = CASES[name][:9]
+    smooth = CASES[name][9] if len(CASES[name]) > 9 else None
     v = synth.make_video(F, W, H, seed=seed, spacing=9)
     rng = np.random.default_rng(seed)
     dd, sd = make_descs(dargs, sargs)
@@ -70,11 +74,12 @@ def case_inputs(name):
     is_static = (rng.uniform(size=v.num_constraints) > 0.1).astype(np.uint8)  # some dynamic constraints
     depth = v.depth.copy()
     depth[:, ::7, ::5] = 0.0   # invalid depth pixels (quirk q5: such constraints are skipped)
-    return v, depth, is_static, pose, dx, sx, dd, sd, intr, loss, reg
+    trip = synth.make_triplets(v, spacing=9.0, seed=seed + 100) if smooth else None
+    return v, depth, is_static, pose, dx, sx, dd, sd, intr, loss, reg, smooth, trip
 
 
 def run_oracle(name):
-    v, depth, is_static, pose, dx, sx, dd, sd, intr, loss, reg = case_inputs(name)
+    v, depth, is_static, pose, dx, sx, dd, sd, intr, loss, reg, smooth, trip = case_inputs(name)
     o = Oracle()
     o.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
     o.set_depth_all(depth)
@@ -87,8 +92,14 @@ def run_oracle(name):
     p.num_threads = 1
     p.intr_opt = intr
     p.static_loss_type = loss
+    extra = {}
+    if smooth:
+        o.set_triplet_constraints(*trip)
+        p.smooth_loss_type, p.smooth_static_weight, p.smooth_dynamic_weight = smooth
+        extra = dict(smooth=np.asarray(smooth, dtype=np.float64), trip_centers=trip[0], trip_offsets=trip[1],
+                     trip_loc=trip[2], trip_static=trip[3])
     ev = o.evaluate(p, reg, pose, want_gradient=True, want_hdiag=True)
-    return dict(frames=v.num_frames, width=v.width, height=v.height, aspect=np.float32(v.aspect),
+    return dict(**extra, frames=v.num_frames, width=v.width, height=v.height, aspect=np.float32(v.aspect),
                 inv_aspect=np.float32(v.inv_aspect), depth=depth, pairs=v.pairs, offsets=v.offsets, loc=v.loc,
                 is_static=is_static, pose=pose, depth_params=dx, spatial_params=sx,
                 depth_desc=np.frombuffer(bytes(dd), dtype=np.uint8), spatial_desc=np.frombuffer(bytes(sd), dtype=np.uint8),

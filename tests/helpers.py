@@ -36,6 +36,11 @@ def evaluate_golden(binding, g, **kw):
     p.num_threads = 1
     p.intr_opt = int(g["intr_opt"])
     p.static_loss_type = int(g["loss"])
+    if "smooth" in g:  # scene-flow smoothness triplets
+        binding.set_triplet_constraints(g["trip_centers"], g["trip_offsets"], g["trip_loc"], g["trip_static"])
+        p.smooth_loss_type = int(g["smooth"][0])
+        p.smooth_static_weight = float(g["smooth"][1])
+        p.smooth_dynamic_weight = float(g["smooth"][2])
     return binding.evaluate(p, float(g["depth_deform_reg"]), g["pose"], want_gradient=True, want_hdiag=True, **kw)
 
 

@@ -20,3 +20,4 @@ def test_golden_cases_cover_the_scope_table():
     names = golden_cases()
     assert len(names) >= 7
     assert any("cubic" in n for n in names) and any("17x10" in n for n in names)
+    assert sum("triplets" in n for n in names) >= 2   # scene-flow smoothness, both implemented Laplacians

@@ -432,8 +432,8 @@ def test_unsupported_configurations_fail_loudly(Solver):
     s.reset_depth_xforms(XformDesc.global_depth())
     s.reset_spatial_xforms(XformDesc.spatial())
     p = OptParams.defaults()
-    p.smooth_static_weight = 1.0
-    with pytest.raises(RuntimeError, match="smoothness"):
+    p.smooth_static_weight = 1.0   # smoothness on but no triplet constraints given: the reference's error text
+    with pytest.raises(RuntimeError, match="Missing triplet constraints"):
         s.pose_optimization(p)
     p = OptParams.defaults()
     p.adaptive_deformation_cost = 1.0
