@@ -38,11 +38,13 @@ SEED = 1234 + 3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def prepare(solver, video, params, final_grid=(17, 10)):
+def prepare(solver, video, params, final_grid=(17, 10), pair_graph=None):
     """Untimed: everything pose_optimization() does before the final coarse-to-fine level."""
     from robust_cvd_amd import synth
     from robust_cvd_amd.ctypes_types import XformDesc
     synth.load_into(solver, video, params.focal_long)
+    if pair_graph is not None:  # pair-sharded mode: the whole problem's frame graph for the coarse preconditioner level
+        solver.set_pair_graph(pair_graph)
     solver.reset_depth_xforms(XformDesc.global_depth())
     solver.reset_spatial_xforms(XformDesc.spatial())
     solver.normalize_depth(params)
@@ -135,13 +137,14 @@ def main():
         ids = [api.Solver.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         solver.comm_init(rank, world, ids[0])
+        all_pairs = video.pairs.copy()
         mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
         video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
             video.pairs, video.offsets, video.loc, video.is_static, mine)
     if args.pcg_tol is not None:
         solver.set_options(pcg_relative_tolerance=args.pcg_tol)
     t_prep = time.perf_counter()
-    prepare(solver, video, params)
+    prepare(solver, video, params, pair_graph=all_pairs if shard else None)
     t_prep = time.perf_counter() - t_prep
     prep_summary = solver.summary()
 

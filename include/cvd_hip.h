@@ -59,6 +59,10 @@ int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
  * counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
 void cvd_comm_unique_id(uint8_t* out128);
 int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
+/* Pair-sharded mode only: the frame pairs of the WHOLE problem (2 * num_pairs frame indices, direction and order
+ * irrelevant), identical on every rank.  The coarse level of the preconditioner is built on this graph; without it
+ * a multi-rank solve falls back to the block-Jacobi level alone.  Call after cvd_set_video. */
+int32_t cvd_set_pair_graph(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames);
 
 /* ---- inputs (what the reference reads through DepthVideo / DepthStream / FlowConstraintsCollection) -- */
 /* DepthVideo dims + aspect (reference lib/DepthVideo.h: numFrames(), aspect(), invAspect(); DepthStream w/h). */

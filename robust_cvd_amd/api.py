@@ -48,7 +48,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
-    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_set_video", "cvd_set_depth",
+    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth",
     "cvd_set_pair_constraints", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
@@ -95,6 +95,12 @@ class Solver(Binding):
     def comm_init(self, rank, world, unique_id: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._fn("comm_init")(self._h, C.c_int32(rank), C.c_int32(world), buf))
+
+    def set_pair_graph(self, pair_frames):
+        """Frame pairs of the whole problem (pair-sharded multi-GPU mode): same array on every rank."""
+        import numpy as np
+        pf = np.ascontiguousarray(pair_frames, dtype=np.int32).reshape(-1, 2)
+        self._check(self._fn("set_pair_graph")(self._h, C.c_int32(pf.shape[0]), pf.ctypes.data_as(C.POINTER(C.c_int32))))
 
     def set_generic_kernels(self, enabled=True):
         self._check(self._fn("set_generic_kernels")(self._h, C.c_int32(int(enabled))))

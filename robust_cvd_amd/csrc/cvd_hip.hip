@@ -320,6 +320,10 @@ struct cvd_handle_t {
     CoarsePlan plan{};
   } coarse;
   bool coarseOn = false;  // this solve uses the coarse level
+  // frame-pair graph of the WHOLE problem (cvd_set_pair_graph): in the pair-sharded multi-GPU mode every rank must
+  // build the same elimination plan although it only holds its own pairs
+  std::vector<std::pair<int, int>> globalEdges;
+  bool haveGlobalEdges = false;
   DevBuf<double> dRegJac;  // regulariser Jacobian rows of the current linearisation point (RegCache)
   DevBuf<unsigned short> dRegCol;
   DevBuf<unsigned char> dRegCnt;
@@ -965,14 +969,25 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
   }
   h->tableWithTriplets = withTriplets;
   h->coarse.valid = false;
-  if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns && !h->itemFa.empty()) {
+  // The coarse level needs the frame graph of the whole problem.  One rank: the local items are the whole problem.
+  // Several ranks: only with cvd_set_pair_graph (identical on all ranks); otherwise the level stays off.
+  if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns && !h->itemFa.empty() &&
+      (h->world == 1 || h->haveGlobalEdges)) {
     std::map<std::pair<int, int>, int> edgeId;
     std::vector<std::pair<int, int>> edgeList;
+    if (h->haveGlobalEdges) {
+      for (const auto& e : h->globalEdges) {
+        if (!inRange[e.first] || !inRange[e.second]) continue;
+        edgeId.insert({e, static_cast<int>(edgeList.size())});
+        edgeList.push_back(e);
+      }
+    }
     std::vector<int> itemEdge(h->itemFa.size());
     for (size_t i = 0; i < h->itemFa.size(); ++i) {
       const std::pair<int, int> key{h->itemFa[i], h->itemFb[i]};
       auto it = edgeId.find(key);
       if (it == edgeId.end()) {
+        if (h->haveGlobalEdges) throw std::runtime_error("cvd_set_pair_graph: a frame pair with constraints is missing from the graph");
         it = edgeId.insert({key, static_cast<int>(edgeList.size())}).first;
         edgeList.push_back(key);
       }
@@ -2234,6 +2249,20 @@ int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
   });
 }
 int64_t cvd_num_active_constraints(cvd_handle* h) { return h ? h->numValid : 0; }
+
+int32_t cvd_set_pair_graph(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames) {
+  CVD_TRY(h, {
+    std::set<std::pair<int, int>> uniq;
+    for (int i = 0; i < numPairs; ++i) {
+      const int a = pairFrames[2 * i], b = pairFrames[2 * i + 1];
+      if (a < 0 || a >= h->F || b < 0 || b >= h->F) throw std::runtime_error("pair graph frame out of range");
+      if (a != b) uniq.insert({std::min(a, b), std::max(a, b)});
+    }
+    h->globalEdges.assign(uniq.begin(), uniq.end());
+    h->haveGlobalEdges = numPairs > 0;
+    h->tableValid = false;
+  });
+}
 
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed) {
   CVD_TRY(h, {

@@ -1040,6 +1040,26 @@ struct DepthVideoProcessor {
       off.push_back(static_cast<int64_t>(st.size()));
     }
     s.check(cvd_set_pair_constraints(s.h, static_cast<int>(pf.size() / 2), pf.data(), off.data(), loc.data(), st.data()));
+    if (!fc.triplets_.empty()) {
+      // scene-flow smoothness triplets, keyed by the centre frame (reference lib/FlowConstraints.h:156-167); groups at
+      // the sequence ends cannot form a triple and are not handed over
+      std::vector<int32_t> centers;
+      std::vector<int64_t> toff{0};
+      std::vector<float> tloc;
+      std::vector<uint8_t> tst;
+      for (auto& kv : fc.triplets_) {
+        if (kv.first < 1 || kv.first + 1 >= F) continue;
+        centers.push_back(kv.first);
+        for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+          tloc.insert(tloc.end(), kv.second.loc[i].begin(), kv.second.loc[i].end());
+          tst.push_back(kv.second.isStatic[i]);
+        }
+        toff.push_back(static_cast<int64_t>(tst.size()));
+      }
+      if (!centers.empty())
+        s.check(cvd_set_triplet_constraints(s.h, static_cast<int>(centers.size()), centers.data(), toff.data(), tloc.data(),
+                                            tst.data()));
+    }
     const cvd_xform_desc dd = ds.depthXformDesc_.toC(), sd = ds.spatialXformDesc_.toC();
     s.check(cvd_reset_depth_xforms(s.h, &dd));
     s.check(cvd_reset_spatial_xforms(s.h, &sd));

@@ -411,6 +411,9 @@ def test_rccl_communicator_world_size_one(Solver):
         if use_comm:
             s.comm_init(0, 1, Solver.comm_unique_id())
         synth.load_into(s, v)
+        if use_comm:
+            # the whole problem's frame graph, as the sharded mode hands it to every rank (coarse preconditioner level)
+            s.set_pair_graph(v.pairs)
         s.reset_depth_xforms(XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())
         p = OptParams.defaults()
@@ -423,6 +426,17 @@ def test_rccl_communicator_world_size_one(Solver):
     assert rel(out[1][0]["gradient"], out[0][0]["gradient"]) < 1e-12
     assert abs(out[0][3]["final_cost"] - out[1][3]["final_cost"]) <= 1e-6 * abs(out[0][3]["final_cost"])
     assert rel(out[1][2], out[0][2]) < 1e-3
+    # the coarse level was on in both runs (same PCG work, far below block-Jacobi alone)
+    assert abs(out[0][3]["total_linear_iterations"] - out[1][3]["total_linear_iterations"]) <= \
+        0.2 * out[0][3]["total_linear_iterations"] + 5
+    s = Solver(0)
+    synth.load_into(s, v)
+    with pytest.raises(RuntimeError, match="missing from the graph"):
+        s.set_pair_graph(v.pairs[: len(v.pairs) // 2])
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(OptParams.defaults())
+        s.pose_optimization_step(OptParams.defaults(), 0.1)
 
 
 def test_unsupported_configurations_fail_loudly(Solver):
