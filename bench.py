@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-pairs", action="store_true", help="denser pair set (towards the ~4k pairs of BASELINE.json)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every kernel class (slower)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="development: no HIP-event timing of the hot kernel (roofline fields are then empty)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="N > 1: pair-sharded (strong) or one video per GPU (weak)")
     args = ap.parse_args()
 
@@ -177,7 +178,8 @@ def main():
 
     # HIP-event timing of the dominant kernel only (two event records per timed launch): the other classes are
     # timed in the profiles/ runs, not inside the measured region
-    solver.set_kernel_timing(True, classes=None if args.time_all_kernels else ["matvec_pairs"])
+    if not args.no_kernel_timing:
+        solver.set_kernel_timing(True, classes=None if args.time_all_kernels else ["matvec_pairs"])
     barrier()
     t0 = time.perf_counter()
     done, total_cg, n_solves, summ = run_iterations(args.steps)

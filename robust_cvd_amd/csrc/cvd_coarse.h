@@ -564,15 +564,17 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
   // the rows near the root of the elimination tree gather from hundreds of columns: 16 waves share the list
-  double a0 = 0.0, a1 = 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int e1 = P.wtPtr[i + 1];
   int e = P.wtPtr[i] + wv;
-  for (; e + 16 < e1; e += 32) {
+  for (; e + 48 < e1; e += 64) {  // four independent gathers in flight per wave
     a0 += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[P.wtFrame[e] * kCB + c];
     a1 += Wb[static_cast<size_t>(P.wtBlk[e + 16]) * kCBB + lane] * rc[P.wtFrame[e + 16] * kCB + c];
+    a2 += Wb[static_cast<size_t>(P.wtBlk[e + 32]) * kCBB + lane] * rc[P.wtFrame[e + 32] * kCB + c];
+    a3 += Wb[static_cast<size_t>(P.wtBlk[e + 48]) * kCBB + lane] * rc[P.wtFrame[e + 48] * kCB + c];
   }
-  if (e < e1) a0 += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[P.wtFrame[e] * kCB + c];
-  double acc = a0 + a1;
+  for (; e < e1; e += 16) a0 += Wb[static_cast<size_t>(P.wtBlk[e]) * kCBB + lane] * rc[P.wtFrame[e] * kCB + c];
+  double acc = (a0 + a1) + (a2 + a3);
   acc += dppMove<0xB1>(acc);
   acc += dppMove<0x4E>(acc);
   acc += dppMove<0x141>(acc);

@@ -971,8 +971,8 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
   h->coarse.valid = false;
   // The coarse level needs the frame graph of the whole problem.  One rank: the local items are the whole problem.
   // Several ranks: only with cvd_set_pair_graph (identical on all ranks); otherwise the level stays off.
-  if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns && !h->itemFa.empty() &&
-      (h->world == 1 || h->haveGlobalEdges)) {
+  if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns &&
+      (h->world == 1 ? !h->itemFa.empty() : h->haveGlobalEdges)) {  // (rank-independent decision when sharded)
     std::map<std::pair<int, int>, int> edgeId;
     std::vector<std::pair<int, int>> edgeList;
     if (h->haveGlobalEdges) {
@@ -1326,22 +1326,35 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
     const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+    // (plain launches unless the launch is timed: hipExtLaunchKernelGGL is not used inside a graph capture)
+    const FrameConst* fcp = h->dFc.p;
+    const double* maskp = h->dMask.p;
+    const double* scalp = h->dScal.p;
     if (fast && c.KD == 4) {
       allowLds(k_matvec_pairs_fast<4>, ldsFast);
-      hipExtLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L, c.T,
-                            c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p), z,
-                            pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
+      if (evStart)
+        hipExtLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
+                              c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+      else
+        hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp, maskp,
+                           z, pOld, scalp, useBeta, h->dQPart.p, cF);
     } else if (fast) {
       allowLds(k_matvec_pairs_fast<1>, ldsFast);
-      hipExtLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L, c.T,
-                            c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p), z,
-                            pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
+      if (evStart)
+        hipExtLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
+                              c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+      else
+        hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp, maskp,
+                           z, pOld, scalp, useBeta, h->dQPart.p, cF);
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_matvec_pairs<KD, KS>, lds);
-        hipExtLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, evStart, evStop, 0, c.L, c.T,
-                              c.it, x, static_cast<const FrameConst*>(h->dFc.p), static_cast<const double*>(h->dMask.p),
-                              z, pOld, static_cast<const double*>(h->dScal.p), useBeta, h->dQPart.p, cF);
+        if (evStart)
+          hipExtLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, evStart, evStop, 0, c.L, c.T,
+                                c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+        else
+          hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, fcp, maskp, z,
+                             pOld, scalp, useBeta, h->dQPart.p, cF);
       });
     }
     HIP_CHECK(hipGetLastError());
@@ -1415,11 +1428,13 @@ static void launchCoarseSetup(Ctx& c, const double* x) {
     launchFrameConsts(c, x);
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
-    CVD_DISPATCH(c.KD, c.KS, {
-      allowLds(k_coarse_edges<KD, KS>, ldsE);
-      hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
-                         C.itemEdgeDev.p, C.edges.p);
-    });
+    if (c.nItems > 0) {
+      CVD_DISPATCH(c.KD, c.KS, {
+        allowLds(k_coarse_edges<KD, KS>, ldsE);
+        hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
+                           C.itemEdgeDev.p, C.edges.p);
+      });
+    }
     HIP_CHECK(hipGetLastError());
     if (h->world > 1)
       NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
@@ -1486,6 +1501,20 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   const size_t firstTimerSlot = h->evUsed;
   int enq = 0, batch = 0;
   bool stop = false;
+  auto enqueueIteration = [&](int it, int useBeta) {
+    h->curPcgIter = it;
+    launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
+    const int slot = h->tBegin(KC_CG_UPDATE);
+    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
+                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
+                       h->coarse.modeActive.p);
+    if (coarse) coarseApply(0);
+    HIP_CHECK(hipGetLastError());
+    h->tEnd(slot);
+    std::swap(pOld, pNew);
+  };
+  // (Replaying the batch as a hipGraph was tried: the ~6 us between the five dependent launches of an iteration are
+  // device-side dependency resolution, not host launch latency -- no gain, removed.)
   while (!stop) {
     if (batch >= kSlots) {
       const int sl = batch % kSlots;
@@ -1495,16 +1524,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     if (enq >= maxIt) break;
     const int n = lockstep ? 1 : std::min(every, maxIt - enq);
     for (int i = 0; i < n; ++i, ++enq) {
-      h->curPcgIter = enq;
-      launchMatvec(c, x, h->dZ.p, pOld, pNew, enq > 0 ? 1 : 0, h->dLam.p, h->dQ.p, coarse);
-      const int slot = h->tBegin(KC_CG_UPDATE);
-      hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                         h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p);
-      if (coarse) coarseApply(0);
-      HIP_CHECK(hipGetLastError());
-      h->tEnd(slot);
-      std::swap(pOld, pNew);
+      enqueueIteration(enq, enq > 0 ? 1 : 0);
       if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
         readScalars(c);
         std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq, h->hScal[S_RZ],
@@ -1563,7 +1583,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   bindTriplets(c, p, kind);
-  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && c.nItems > 0 && !h->forceGeneric;
+  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric;
   ensureBuffers(c);
   buildMask(h, c.L, p, kind, range);
   uploadState(h, c.L, h->dX);
