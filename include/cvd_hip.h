@@ -28,7 +28,7 @@ typedef struct cvd_handle_t cvd_handle;
 typedef struct cvd_solver_options {
   double pcg_relative_tolerance; /* stop when sqrt(r^T M^-1 r) <= tol * its initial value (default 1e-1 = Ceres' eta) */
   int32_t pcg_max_iterations;    /* default 300 */
-  int32_t pcg_check_every;       /* host convergence check cadence in CG iterations (default 4) */
+  int32_t pcg_check_every;       /* unused since the device mirrors its progress to the host (kept for layout) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
   int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve

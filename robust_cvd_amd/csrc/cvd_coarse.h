@@ -555,7 +555,8 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
                                                          const double* __restrict__ rc, double* __restrict__ y,
                                                          double* __restrict__ dotPart, double* __restrict__ scal,
                                                          unsigned int* __restrict__ counter,
-                                                         const int* __restrict__ fail, int init, double tol2) {
+                                                         const int* __restrict__ fail, int init, double tol2,
+                                                         double* __restrict__ hostMirror) {
   __shared__ double part[16][kCB];
   __shared__ double red[16];
   __shared__ int flag;
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
 #pragma unroll
     for (int w = 0; w < 16; ++w) dot += red[w];
     if (*fail != 0) dot = 0.0;  // a broken-down factorisation switches the level off (the consumers use c = 0)
-    pcgFinishScalars(scal, init, scal[S_RZPART] + dot, scal[S_RR], tol2);
+    pcgFinishScalars(scal, init, scal[S_RZPART] + dot, scal[S_RR], tol2, hostMirror);
   }
 }
 

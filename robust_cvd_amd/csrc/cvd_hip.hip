@@ -334,7 +334,7 @@ struct cvd_handle_t {
   double* hScal = nullptr;  // pinned
   double* hStage[2] = {nullptr, nullptr};  // pinned staging for the per-solve state / mask transfers
   size_t hStageN[2] = {0, 0};
-  double* hPcg = nullptr;   // pinned: [S_DONE, S_TARGET, S_ITERS, -] per in-flight PCG batch
+  double* hPcg = nullptr;   // pinned, device-written PCG progress mirror: [0] iterations + 1, [1..8] done-flag ring
   hipEvent_t pcgEvent[2] = {nullptr, nullptr};
 
   // results
@@ -1137,7 +1137,7 @@ static void ensureBuffers(Ctx& c) {
   }
   if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
   if (!h->hPcg) {
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hPcg), 8 * sizeof(double)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hPcg), 16 * sizeof(double)));
     for (auto& e : h->pcgEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
 }
@@ -1472,19 +1472,21 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   double* fd = h->dFdot.p;
   const size_t ldsU = (B + nThreads + 48) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
+  for (int i = 0; i < 9; ++i) h->hPcg[i] = 0.0;  // device progress mirror (pcgFinishScalars): nothing applied yet
   const bool coarse = h->coarseOn;
   double* rc = coarse ? h->coarse.rc.p : nullptr;
   auto coarseApply = [&](int init) {
     // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
     hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
-                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2);
+                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2,
+                       h->hPcg);
     if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p);
+                     h->coarse.modeActive.p, h->hPcg);
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -1497,17 +1499,15 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   // (profiling aid: CVD_PCG_LOCKSTEP=1 checks after every iteration and never runs ahead, so that per-launch
   // counter averages contain no early-exit launches)
   static const bool lockstep = std::getenv("CVD_PCG_LOCKSTEP") != nullptr;
-  constexpr int kSlots = 2;
   const size_t firstTimerSlot = h->evUsed;
-  int enq = 0, batch = 0;
-  bool stop = false;
+  int enq = 0;
   auto enqueueIteration = [&](int it, int useBeta) {
     h->curPcgIter = it;
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
     const int slot = h->tBegin(KC_CG_UPDATE);
     hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
                        h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                       h->coarse.modeActive.p);
+                       h->coarse.modeActive.p, h->hPcg);
     if (coarse) coarseApply(0);
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -1515,29 +1515,25 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   };
   // (Replaying the batch as a hipGraph was tried: the ~6 us between the five dependent launches of an iteration are
   // device-side dependency resolution, not host launch latency -- no gain, removed.)
-  while (!stop) {
-    if (batch >= kSlots) {
-      const int sl = batch % kSlots;
-      spinEvent(h->pcgEvent[sl]);
-      if (h->hPcg[sl * 4 + 0] != 0.0) break;
+  // Convergence is decided on the device (S_DONE); the last workgroup of every iteration also mirrors its progress
+  // into pinned host memory (pcgFinishScalars).  Iteration k is enqueued once the done flag after exactly
+  // k - kRunAhead + 1 iterations is known to be clear: nothing but the PCG kernels is in the stream, the device is
+  // never starved (kRunAhead iterations are queued ahead) and kRunAhead - 1 early-exit iterations are wasted per
+  // solve.  The rule is a function of iteration counts only, hence identical on all ranks of a sharded run.
+  const int kRunAhead = lockstep ? 1 : 2;
+  volatile double* prog = h->hPcg;
+  while (enq < maxIt) {
+    if (enq >= kRunAhead - 1) {
+      const int need = enq - kRunAhead + 1;
+      while (static_cast<int>(prog[0]) - 1 < need) {}
+      if (prog[1 + (need & 7)] != 0.0) break;
     }
-    if (enq >= maxIt) break;
-    const int n = lockstep ? 1 : std::min(every, maxIt - enq);
-    for (int i = 0; i < n; ++i, ++enq) {
-      enqueueIteration(enq, enq > 0 ? 1 : 0);
-      if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
-        readScalars(c);
-        std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq, h->hScal[S_RZ],
-                    h->hScal[S_RZPART], h->hScal[S_ALPHA], h->hScal[S_BETA], h->hScal[S_PQ], h->hScal[S_DONE]);
-      }
-    }
-    const int sl = batch % kSlots;
-    HIP_CHECK(hipMemcpyAsync(h->hPcg + sl * 4, h->dScal.p + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipEventRecord(h->pcgEvent[sl], s));
-    ++batch;
-    if (lockstep) {
-      spinEvent(h->pcgEvent[sl]);
-      if (h->hPcg[sl * 4 + 0] != 0.0) break;
+    enqueueIteration(enq, enq > 0 ? 1 : 0);
+    ++enq;
+    if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
+      readScalars(c);
+      std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq - 1, h->hScal[S_RZ],
+                  h->hScal[S_RZPART], h->hScal[S_ALPHA], h->hScal[S_BETA], h->hScal[S_PQ], h->hScal[S_DONE]);
     }
   }
   h->curPcgIter = -1;
@@ -2308,7 +2304,7 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
           unit[k] = 1.0;
           C.rc.upload(unit.data(), n, s);
           hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, C.dotPart.p,
-                             scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0);
+                             scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0, static_cast<double*>(nullptr));
           hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
                              scalTmp.p, 1);
           C.c.download(a_c_inverse + k * n, n, s);

@@ -1022,24 +1022,37 @@ __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restri
 }
 
 // PCG scalars after the preconditioner has been applied (shared by k_cg_update and, with the coarse level, k_coarse_apply).
-__device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int init, double rzs, double rrs, double tol2) {
+__device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int init, double rzs, double rrs, double tol2,
+                                                 double* __restrict__ hostMirror) {
+  double done, iters;
   if (init) {
     scal[S_RZ0] = rzs;
     scal[S_RZOLD] = rzs;
     scal[S_BETA] = 0.0;
     scal[S_TARGET] = tol2 * rzs;
-    scal[S_ITERS] = 0.0;
-    scal[S_DONE] = (rzs == rzs) ? ((rzs > 0.0) ? 0.0 : 1.0) : 2.0;
+    iters = 0.0;
+    done = (rzs == rzs) ? ((rzs > 0.0) ? 0.0 : 1.0) : 2.0;
   } else {
     const double old = scal[S_RZ];
     scal[S_RZOLD] = old;
     scal[S_BETA] = (old != 0.0) ? rzs / old : 0.0;
-    scal[S_ITERS] += 1.0;
-    if (!(rzs == rzs)) scal[S_DONE] = 2.0;
-    else if (rzs <= scal[S_TARGET]) scal[S_DONE] = 1.0;
+    iters = scal[S_ITERS] + 1.0;
+    done = scal[S_DONE];
+    if (!(rzs == rzs)) done = 2.0;
+    else if (rzs <= scal[S_TARGET]) done = 1.0;
   }
+  scal[S_ITERS] = iters;
+  scal[S_DONE] = done;
   scal[S_RZ] = rzs;
   scal[S_RR] = rrs;
+  // Progress for the host in pinned, coherent memory, so that it can bound its run-ahead without any copy or event
+  // in the stream: [0] = iterations applied + 1 (0 = nothing yet), [1 + (iterations applied & 7)] = the done flag
+  // after exactly that many iterations (a ring: the host's decisions depend on the iteration count only, never on
+  // timing, which keeps the ranks of a multi-GPU run enqueuing the same collectives).
+  if (hostMirror != nullptr) {
+    __hip_atomic_store(hostMirror + 1 + (static_cast<int>(iters) & 7), done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hostMirror, iters + 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
@@ -1053,7 +1066,8 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     double* __restrict__ r, double* __restrict__ z,
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
                                                     double tol2, double* __restrict__ rc,
-                                                    const unsigned char* __restrict__ modeActive) {
+                                                    const unsigned char* __restrict__ modeActive,
+                                                    double* __restrict__ hostMirror) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
   const int B = L.B;
@@ -1143,7 +1157,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
         scal[S_RZPART] = rzs;
         scal[S_RR] = rrs;
       } else {
-        pcgFinishScalars(scal, init, rzs, rrs, tol2);
+        pcgFinishScalars(scal, init, rzs, rrs, tol2, hostMirror);
       }
     }
   }
