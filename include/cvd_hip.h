@@ -119,6 +119,19 @@ int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s);
 int32_t cvd_num_records(cvd_handle* h);
 int32_t cvd_get_records(cvd_handle* h, cvd_iteration_record* out);
 
+/* ---- dense consumers of the result: what loaders/video_dataset.py reads after every optimisation --
+ * All frames [first_frame, first_frame + num_frames) in one launch, current transform parameters of the handle, host
+ * buffer out (may be NULL: compute only).  kernel_ms (may be NULL) receives the kernel time (HIP events).
+ * Pixel-centre convention loc = (-1 + x 2/(w-1), 1 - y 2/(h-1)) of the reference. */
+/* DepthXform::apply (reference lib/DepthMapTransform.cpp:394-415): out [n][H][W] f32 transformed depth. */
+int32_t cvd_apply_depth_xforms(cvd_handle* h, int32_t first_frame, int32_t num_frames, float* out, double* kernel_ms);
+/* GridDepthXform::paramMap (reference lib/DepthMapTransform.cpp:950-994): out [n][H][W][N] f64; Grid transforms only
+ * ("Parameter map not implemented for this transform type." otherwise, :422-425). */
+int32_t cvd_depth_param_maps(cvd_handle* h, int32_t first_frame, int32_t num_frames, double* out, double* kernel_ms);
+/* SpatialXform::warp(h, w) (reference lib/DepthMapTransform.cpp:428-449): out [n][height][width][2] f32. */
+int32_t cvd_spatial_warp_maps(cvd_handle* h, int32_t first_frame, int32_t num_frames, int32_t height, int32_t width,
+                              float* out, double* kernel_ms);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------------- */
 /* Average duration (ms) of the dominant kernels over the last solve, measured with HIP events on the
  * solver's own stream: fills {evaluate_assemble, matvec_pairs, matvec_finish, cg_update, block_inverse,

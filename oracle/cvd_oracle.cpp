@@ -2127,6 +2127,84 @@ int cvdo_get_records(void* h, cvd_iteration_record* out) {
   CVDO_TRY(h, std::memcpy(out, o->records.data(), sizeof(cvd_iteration_record) * o->records.size()));
 }
 
+// ---- dense consumers of the result: same signatures as include/cvd_hip.h -----------------------
+// Pixel-centre convention of the reference: loc = (-1 + x * 2/(w-1), 1 - y * 2/(h-1)) in f32.
+static void pixelLoc(int x, int y, int w, int h, float& lx, float& ly) {
+  const float xScale = 2.f / (w - 1.f), yScale = 2.f / (h - 1.f);
+  lx = -1.f + x * xScale;
+  ly = 1.f - y * yScale;
+}
+// DepthXform::apply, reference lib/DepthMapTransform.cpp:394-415
+int cvdo_apply_depth_xforms(void* h, int firstFrame, int numFrames, float* out, double* /*kernelMs*/) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    for (int k = 0; k < numFrames; ++k) {
+      const int f = firstFrame + k;
+      const cvdo::Xform& X = o->depthXforms[f];
+      const int N = X.blockSize;
+      for (int y = 0; y < o->Hh; ++y)
+        for (int x = 0; x < o->W; ++x) {
+          const double d = o->depthImg(f)[static_cast<size_t>(y) * o->W + x];
+          float lx, ly;
+          pixelLoc(x, y, o->W, o->Hh, lx, ly);
+          double D = d;
+          if (X.desc.depth_type != CVD_DEPTH_IDENTITY && N > 0) {
+            cvdo::Gather g;
+            X.depthGather(static_cast<float>(d), lx, ly, g);
+            D = 0.0;
+            for (int i = 0; i < g.n; ++i)
+              D += ((N == 2) ? (d * X.params[g.idx[i] * 2] + X.params[g.idx[i] * 2 + 1]) : d * X.params[g.idx[i]]) * g.w[i];
+          }
+          out[(static_cast<size_t>(k) * o->Hh + y) * o->W + x] = static_cast<float>(D);
+        }
+    }
+  });
+}
+// GridDepthXform::paramMap, reference lib/DepthMapTransform.cpp:950-994 (:422-425 for the other transform types)
+int cvdo_depth_param_maps(void* h, int firstFrame, int numFrames, double* out, double* /*kernelMs*/) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    for (int k = 0; k < numFrames; ++k) {
+      const int f = firstFrame + k;
+      const cvdo::Xform& X = o->depthXforms[f];
+      if (X.desc.depth_type != CVD_DEPTH_GRID) throw std::runtime_error("Parameter map not implemented for this transform type.");
+      const int N = X.blockSize;
+      for (int y = 0; y < o->Hh; ++y)
+        for (int x = 0; x < o->W; ++x) {
+          float lx, ly;
+          pixelLoc(x, y, o->W, o->Hh, lx, ly);
+          cvdo::Gather g;
+          X.depthGather(o->depthImg(f)[static_cast<size_t>(y) * o->W + x], lx, ly, g);
+          double* dst = out + ((static_cast<size_t>(k) * o->Hh + y) * o->W + x) * N;
+          for (int d = 0; d < N; ++d) dst[d] = 0.0;
+          for (int i = 0; i < g.n; ++i)
+            for (int d = 0; d < N; ++d) dst[d] += X.params[g.idx[i] * N + d] * g.w[i];
+        }
+    }
+  });
+}
+// SpatialXform::warp(h, w), reference lib/DepthMapTransform.cpp:428-449
+int cvdo_spatial_warp_maps(void* h, int firstFrame, int numFrames, int height, int width, float* out, double* /*kernelMs*/) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    for (int k = 0; k < numFrames; ++k) {
+      const cvdo::Xform& X = o->spatialXforms[firstFrame + k];
+      for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+          float lx, ly;
+          pixelLoc(x, y, width, height, lx, ly);
+          cvdo::Gather g;
+          X.spatialGather(lx, ly, g);
+          double wx = 0.0, wy = 0.0;
+          for (int i = 0; i < g.n; ++i) { wx += X.params[g.idx[i] * 2] * g.w[i]; wy += X.params[g.idx[i] * 2 + 1] * g.w[i]; }
+          float* dst = out + ((static_cast<size_t>(k) * height + y) * width + x) * 2;
+          dst[0] = static_cast<float>(wx);
+          dst[1] = static_cast<float>(wy);
+        }
+    }
+  });
+}
+
 // ---- stand-alone known-answer hooks ----------------------------------------------------------------
 // Depth / spatial gather of one sample: returns the number of blocks, fills idx / w (<= 16).
 int cvdo_gather(const cvd_xform_desc* d, float srcDepth, float lx, float ly, int32_t* idx, double* w) {

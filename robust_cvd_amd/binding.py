@@ -202,6 +202,44 @@ class Binding:
             _ptr(hf, C.c_double) if hf is not None else None))
         return {"cost": cost.value, "num_residual_blocks": nres.value, "gradient": g, "hdiag": hd, "hfull": hf}
 
+    # -- dense consumers of the result ------------------------------------------------
+    def apply_depth_xforms(self, first=0, count=None, timing=False):
+        """DepthXform::apply for frames [first, first+count): [n, H, W] float32."""
+        count = self.num_frames - first if count is None else count
+        out = np.zeros((count, self.height, self.width), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._fn("apply_depth_xforms")(self._h, C.c_int(first), C.c_int(count), _ptr(out, C.c_float),
+                                                   C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
+    def depth_param_maps(self, first=0, count=None, timing=False):
+        """GridDepthXform::paramMap: [n, H, W] (one value parameter) or [n, H, W, N] float64."""
+        count = self.num_frames - first if count is None else count
+        n = max(1, self.num_xform_params(False) // max(1, self._grid_vertices()))
+        out = np.zeros((count, self.height, self.width, n), dtype=np.float64)
+        ms = C.c_double(0.0)
+        self._check(self._fn("depth_param_maps")(self._h, C.c_int(first), C.c_int(count), _ptr(out, C.c_double),
+                                                 C.byref(ms) if timing else None))
+        out = out[..., 0] if n == 1 else out
+        return (out, ms.value) if timing else out
+
+    def spatial_warp_maps(self, height=None, width=None, first=0, count=None, timing=False):
+        """SpatialXform::warp(h, w): [n, h, w, 2] float32."""
+        count = self.num_frames - first if count is None else count
+        height = self.height if height is None else height
+        width = self.width if width is None else width
+        out = np.zeros((count, height, width, 2), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._fn("spatial_warp_maps")(self._h, C.c_int(first), C.c_int(count), C.c_int(height),
+                                                  C.c_int(width), _ptr(out, C.c_float), C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
+    def _grid_vertices(self):
+        d = self.xform_desc(False)
+        if int(d.depth_type) == 3:  # Grid
+            return max(1, d.grid_size[0] * d.grid_size[1] * max(1, d.grid_size[2]))
+        return 1
+
     def summary(self):
         s = SolveSummary()
         self._check(self._fn("get_summary")(self._h, C.byref(s)))

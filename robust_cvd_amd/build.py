@@ -4,8 +4,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "cvd_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "cvd_kernels.h"), os.path.join(_HERE, "csrc", "cvd_device.h"),
-        os.path.join(_HERE, "..", "include", "cvd_hip.h"), os.path.join(_HERE, "..", "include", "cvd_types.h")]
+DEPS = [SRC] + sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h")) + \
+       [os.path.join(_HERE, "..", "include", "cvd_hip.h"), os.path.join(_HERE, "..", "include", "cvd_types.h")]
 LIB = os.path.join(_HERE, "lib", "libcvd_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics"]
 

@@ -37,6 +37,7 @@
 #include "cvd_kernels.h"
 #include "cvd_coarse.h"
 #include "cvd_triplets.h"
+#include "cvd_dense.h"
 
 namespace cvd {
 
@@ -304,6 +305,7 @@ struct cvd_handle_t {
   DevBuf<float> dMinv;
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
   DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
+  DevBuf<double> dDense;     // output of the dense consumer kernels (cvd_dense.h)
 
   // coarse (pose-graph) level of the two-level preconditioner (cvd_coarse.h)
   struct CoarseHost {
@@ -1949,6 +1951,59 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   }
 }
 
+// ---- dense consumers of the result (cvd_dense.h) ----------------------------------------------
+// kind 0: DepthXform::apply -> f32 [n][H][W]; 1: GridDepthXform::paramMap -> f64 [n][H][W][N];
+// 2: SpatialXform::warp -> f32 [n][h][w][2] for the raster (w, h).  Host buffer out; the device buffer is kept for
+// the next call.  Returns the kernel time in ms through *kernelMs when asked (HIP events on the solver stream).
+static void denseMaps(cvd_handle* h, int kind, int first, int count, int w, int hh, void* out, double* kernelMs) {
+  if (h->F <= 0) throw std::runtime_error("no video set");
+  if (first < 0 || count < 0 || first + count > h->F) throw std::runtime_error("frame range out of bounds");
+  if (!h->poseParamsValid) posesToParams(h);
+  cvd_opt_params p;
+  cvd_opt_params_default(&p);
+  Layout L = makeLayout(h, p, 0.0, PK_POSE_STEP);
+  int KD, KS;
+  tapCounts(L, KD, KS);
+  if (kind == 1 && L.depthType != CVD_DEPTH_GRID)
+    throw std::runtime_error("Parameter map not implemented for this transform type.");  // reference :422-425
+  if (kind != 2) { w = h->W; hh = h->H; }
+  if (w < 2 || hh < 2) throw std::runtime_error("raster too small");
+  uploadState(h, L, h->dX);
+  hipStream_t s = h->stream;
+  const size_t pixels = static_cast<size_t>(count) * hh * w;
+  const size_t bytes = pixels * (kind == 0 ? sizeof(float) : kind == 1 ? sizeof(double) * std::max(L.N, 1) : sizeof(float2));
+  h->dDense.ensure((bytes + 7) / 8);
+  if (count == 0) return;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernelMs) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventRecord(e0, s)); }
+  const dim3 grid((w * hh + 255) / 256, 1, count), block(256);
+  if (kind == 0) {
+    CVD_DISPATCH_KD(KD, {
+      hipLaunchKernelGGL((k_apply_depth<KD>), grid, block, 0, s, L, w, hh, first, h->dDepth.p, h->dX.p,
+                         reinterpret_cast<float*>(h->dDense.p));
+    });
+  } else if (kind == 1) {
+    CVD_DISPATCH_KD(KD, {
+      hipLaunchKernelGGL((k_param_map<KD>), grid, block, 0, s, L, w, hh, first, h->dX.p, h->dDense.p);
+    });
+  } else {
+    if (KS == 0) hipLaunchKernelGGL((k_warp_map<0>), grid, block, 0, s, L, w, hh, first, h->dX.p, reinterpret_cast<float2*>(h->dDense.p));
+    else if (KS == 4) hipLaunchKernelGGL((k_warp_map<4>), grid, block, 0, s, L, w, hh, first, h->dX.p, reinterpret_cast<float2*>(h->dDense.p));
+    else hipLaunchKernelGGL((k_warp_map<16>), grid, block, 0, s, L, w, hh, first, h->dX.p, reinterpret_cast<float2*>(h->dDense.p));
+  }
+  HIP_CHECK(hipGetLastError());
+  if (kernelMs) HIP_CHECK(hipEventRecord(e1, s));
+  if (out) HIP_CHECK(hipMemcpyAsync(out, h->dDense.p, bytes, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (kernelMs) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *kernelMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
 }  // namespace cvd
 
 // =======================================================================================================
@@ -2244,6 +2299,16 @@ int32_t cvd_pose_optimization_step(cvd_handle* h, const cvd_opt_params* p, doubl
 int32_t cvd_evaluate(cvd_handle* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, double* cost,
                      int32_t* nres, double* gradient, double* hdiag, double* hfull) {
   CVD_TRY(h, evaluate(h, *p, depthDeformReg, pose7, cost, nres, gradient, hdiag, hfull));
+}
+int32_t cvd_apply_depth_xforms(cvd_handle* h, int32_t firstFrame, int32_t numFrames, float* out, double* kernelMs) {
+  CVD_TRY(h, denseMaps(h, 0, firstFrame, numFrames, 0, 0, out, kernelMs));
+}
+int32_t cvd_depth_param_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrames, double* out, double* kernelMs) {
+  CVD_TRY(h, denseMaps(h, 1, firstFrame, numFrames, 0, 0, out, kernelMs));
+}
+int32_t cvd_spatial_warp_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrames, int32_t height, int32_t width,
+                              float* out, double* kernelMs) {
+  CVD_TRY(h, denseMaps(h, 2, firstFrame, numFrames, width, height, out, kernelMs));
 }
 int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s) { CVD_TRY(h, *s = h->summary); }
 int32_t cvd_num_records(cvd_handle* h) { return h ? static_cast<int32_t>(h->records.size()) : 0; }
