@@ -119,6 +119,20 @@ int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s);
 int32_t cvd_num_records(cvd_handle* h);
 int32_t cvd_get_records(cvd_handle* h, cvd_iteration_record* out);
 
+/* ---- constraint sampling: FlowConstraintsCollection::compute(PairKey), reference
+ * lib/FlowConstraints.cpp:296-465.  Images have the size given to cvd_set_video.  Inputs (host): corner[F][H][W] =
+ * cornerMinEigenVal response of every frame's colour image (computed by the caller), flow[P][H][W][2] and mask[P][H][W]
+ * of every directed pair (pair_frames[2P]), optionally dyn_dist[F][dyn_h][dyn_w] = distance transform of the dynamic
+ * mask (NULL: no dynamic-mask stream).  offsets[P + 1] receives the constraint counts as a prefix sum; the constraints
+ * (rank order per pair, loc0.xy loc1.xy scaled to [0,1]x[0,invAspect]) stay on the device until
+ * cvd_get_sampled_constraints copies them out (loc4 holds offsets[P] x 4 floats).  Ties in the corner response resolve
+ * by ascending pixel index (unspecified in the reference: std::sort). */
+int32_t cvd_sample_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* corner,
+                                    const float* flow, const uint8_t* mask, const float* dyn_dist, int32_t dyn_w,
+                                    int32_t dyn_h, int32_t match_separation, float min_dynamic_distance,
+                                    int64_t* offsets);
+int32_t cvd_get_sampled_constraints(cvd_handle* h, float* loc4);
+
 /* ---- dense consumers of the result: what loaders/video_dataset.py reads after every optimisation --
  * All frames [first_frame, first_frame + num_frames) in one launch, current transform parameters of the handle, host
  * buffer out (may be NULL: compute only).  kernel_ms (may be NULL) receives the kernel time (HIP events).

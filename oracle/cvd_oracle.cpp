@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1376,6 +1377,7 @@ struct Oracle {
   std::vector<float> pairLoc;       // 4 per constraint: loc0.xy, loc1.xy in [0,1]x[0,invAspect]
   std::vector<uint8_t> pairStatic;
 
+  std::vector<float> sampledLoc;  // result of cvdo_sample_pair_constraints
   std::vector<int> tripletCenters;
   std::vector<int64_t> tripletOffsets;
   std::vector<float> tripletLoc;  // 6 per constraint
@@ -2125,6 +2127,72 @@ int cvdo_num_records(void* h) { return static_cast<int>(static_cast<Oracle*>(h)-
 int cvdo_get_records(void* h, cvd_iteration_record* out) {
   Oracle* o = static_cast<Oracle*>(h);
   CVDO_TRY(h, std::memcpy(out, o->records.data(), sizeof(cvd_iteration_record) * o->records.size()));
+}
+
+// ---- constraint sampling: same signatures as include/cvd_hip.h -------------------------------------
+// FlowConstraintsCollection::compute(PairKey), reference lib/FlowConstraints.cpp:400-465, and sampleConstraints,
+// :352-397 (Pixel ordering :304-315, buildDiskMask :317-332, scaleConstraint :334-339).  Deviation: ties in the corner
+// response keep pixel order (std::stable_sort); the reference's std::sort leaves their order unspecified.
+int cvdo_sample_pair_constraints(void* h, int numPairs, const int32_t* pairFrames, const float* corner,
+                                 const float* flow, const uint8_t* mask, const float* dynDist, int dynW, int dynH,
+                                 int matchSeparation, float minDynamicDistance, int64_t* offsets) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    const int w = o->W, hh = o->Hh;
+    const size_t npx = static_cast<size_t>(w) * hh;
+    o->sampledLoc.clear();
+    offsets[0] = 0;
+    const int dw = dynDist ? dynW : w, dh = dynDist ? dynH : hh;
+    const float scaleX = dw / float(w), scaleY = dh / float(hh);  // dynamicMaskScale, :411-413
+    struct Pixel { float cornerStrength; int ix0, iy0; float fx1, fy1; };
+    for (int p = 0; p < numPairs; ++p) {
+      const int fa = pairFrames[2 * p], fb = pairFrames[2 * p + 1];
+      const float* cornerPtr = corner + fa * npx;
+      const float* fl = flow + static_cast<size_t>(p) * npx * 2;
+      const uint8_t* mk = mask + static_cast<size_t>(p) * npx;
+      std::vector<Pixel> pixels;
+      for (int iy0 = 0; iy0 < hh; ++iy0) {
+        // (cv::Mat access is unchecked in the reference; a half-resolution mask can be indexed one past its end: clamp)
+        const int iy0s = std::min(static_cast<int>(iy0 * scaleY + 0.5f), dh - 1);
+        for (int ix0 = 0; ix0 < w; ++ix0) {
+          const int ix0s = std::min(static_cast<int>(ix0 * scaleX + 0.5f), dw - 1);
+          const float d0 = dynDist ? dynDist[static_cast<size_t>(fa) * dw * dh + static_cast<size_t>(iy0s) * dw + ix0s] : FLT_MAX;
+          if (mk[iy0 * w + ix0] && d0 > minDynamicDistance) {
+            const float fx1 = ix0 + fl[(static_cast<size_t>(iy0) * w + ix0) * 2];
+            const float fy1 = iy0 + fl[(static_cast<size_t>(iy0) * w + ix0) * 2 + 1];
+            const int ix1 = fx1 + 0.5f;
+            const int iy1 = fy1 + 0.5f;
+            if (ix1 >= 0 && ix1 < w && iy1 >= 0 && iy1 < hh) {
+              const int ix1s = std::min(std::max(static_cast<int>(fx1 * scaleX + 0.5f), 0), dw - 1);
+              const int iy1s = std::min(std::max(static_cast<int>(fy1 * scaleY + 0.5f), 0), dh - 1);
+              const float d1 = dynDist ? dynDist[static_cast<size_t>(fb) * dw * dh + static_cast<size_t>(iy1s) * dw + ix1s] : FLT_MAX;
+              if (d1 > minDynamicDistance) pixels.push_back({cornerPtr[iy0 * w + ix0], ix0, iy0, fx1, fy1});
+            }
+          }
+        }
+      }
+      std::stable_sort(pixels.begin(), pixels.end(),
+                       [](const Pixel& a, const Pixel& b) { return a.cornerStrength > b.cornerStrength; });
+      std::vector<uint8_t> invalid(npx, 0);
+      const int r = matchSeparation;
+      const float sx = 1.f / w, sy = o->invAspect / hh;
+      for (const Pixel& px : pixels) {
+        if (invalid[static_cast<size_t>(px.iy0) * w + px.ix0]) continue;
+        const float l[4] = {px.ix0 * sx, px.iy0 * sy, px.fx1 * sx, px.fy1 * sy};
+        o->sampledLoc.insert(o->sampledLoc.end(), l, l + 4);
+        for (int my = std::max(0, px.iy0 - r); my <= std::min(hh - 1, px.iy0 + r); ++my)
+          for (int mx = std::max(0, px.ix0 - r); mx <= std::min(w - 1, px.ix0 + r); ++mx) {
+            const int rx = mx - px.ix0, ry = my - px.iy0;
+            if (rx * rx + ry * ry <= r * r) invalid[static_cast<size_t>(my) * w + mx] = 255;
+          }
+      }
+      offsets[p + 1] = static_cast<int64_t>(o->sampledLoc.size() / 4);
+    }
+  });
+}
+int cvdo_get_sampled_constraints(void* h, float* loc4) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, std::memcpy(loc4, o->sampledLoc.data(), sizeof(float) * o->sampledLoc.size()));
 }
 
 // ---- dense consumers of the result: same signatures as include/cvd_hip.h -----------------------

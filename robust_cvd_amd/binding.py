@@ -202,6 +202,30 @@ class Binding:
             _ptr(hf, C.c_double) if hf is not None else None))
         return {"cost": cost.value, "num_residual_blocks": nres.value, "gradient": g, "hdiag": hd, "hfull": hf}
 
+    # -- constraint sampling ----------------------------------------------------------
+    def sample_pair_constraints(self, pair_frames, corner, flow, mask, match_separation, dyn_dist=None,
+                                min_dynamic_distance=0.0):
+        """FlowConstraintsCollection::compute for directed pairs: returns (offsets [P+1] int64, loc [C, 4] float32)."""
+        pf = np.ascontiguousarray(pair_frames, dtype=np.int32).reshape(-1, 2)
+        P = pf.shape[0]
+        co = _f32(corner); fl = _f32(flow); mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert co.shape == (self.num_frames, self.height, self.width), co.shape
+        assert fl.shape == (P, self.height, self.width, 2) and mk.shape == (P, self.height, self.width)
+        dd, dw, dh = None, 0, 0
+        if dyn_dist is not None:
+            dd = _f32(dyn_dist)
+            assert dd.ndim == 3 and dd.shape[0] == self.num_frames
+            dh, dw = dd.shape[1], dd.shape[2]
+        off = np.zeros(P + 1, dtype=np.int64)
+        self._check(self._fn("sample_pair_constraints")(
+            self._h, C.c_int(P), _ptr(pf, C.c_int32), _ptr(co, C.c_float), _ptr(fl, C.c_float), _ptr(mk, C.c_uint8),
+            _ptr(dd, C.c_float) if dd is not None else None, C.c_int(dw), C.c_int(dh), C.c_int(match_separation),
+            C.c_float(min_dynamic_distance), _ptr(off, C.c_int64)))
+        loc = np.zeros((int(off[-1]), 4), dtype=np.float32)
+        if loc.size:
+            self._check(self._fn("get_sampled_constraints")(self._h, _ptr(loc, C.c_float)))
+        return off, loc
+
     # -- dense consumers of the result (SURVEY.md 8 f3) ------------------------------------------------
     def apply_depth_xforms(self, first=0, count=None, timing=False):
         """DepthXform::apply for frames [first, first+count): [n, H, W] float32."""

@@ -38,6 +38,9 @@
 #include "cvd_coarse.h"
 #include "cvd_triplets.h"
 #include "cvd_dense.h"
+#include "cvd_sampling.h"
+
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 namespace cvd {
 
@@ -306,6 +309,9 @@ struct cvd_handle_t {
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
   DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
   DevBuf<double> dDense;     // output of the dense consumer kernels (cvd_dense.h)
+  // constraint sampling (cvd_sampling.h): result of the last cvd_sample_pair_constraints
+  DevBuf<float4> dSampledLoc;
+  std::vector<long long> sampledOff;
 
   // coarse (pose-graph) level of the two-level preconditioner (cvd_coarse.h)
   struct CoarseHost {
@@ -1951,6 +1957,95 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   }
 }
 
+// ---- constraint sampling (cvd_sampling.h) -----------------------------------------------------------
+static void samplePairConstraints(cvd_handle* h, int numPairs, const int32_t* pairFrames, const float* corner,
+                                  const float* flow, const uint8_t* mask, const float* dyn, int dw, int dh,
+                                  int matchSeparation, float minDynamicDistance, int64_t* offsets) {
+  if (h->F <= 0) throw std::runtime_error("no video set");
+  if (matchSeparation < 0) throw std::runtime_error("matchSeparation must be >= 0");
+  const int W = h->W, H = h->H;
+  const size_t npx = static_cast<size_t>(W) * H;
+  if ((npx + 31) / 32 * 4 > kMaxLds) throw std::runtime_error("image too large for the LDS-resident sampling mask");
+  for (int i = 0; i < 2 * numPairs; ++i)
+    if (pairFrames[i] < 0 || pairFrames[i] >= h->F) throw std::runtime_error("pair frame out of range");
+  hipStream_t s = h->stream;
+  DevBuf<float> dCorner, dDyn;
+  DevBuf<float2> dFlow;
+  DevBuf<unsigned char> dMaskS;
+  DevBuf<int> dPairs;
+  DevBuf<unsigned long long> dKeys, dKeysOut;
+  DevBuf<unsigned int> dNValid, dCount, dSeg;
+  DevBuf<float4> dSlab;
+  DevBuf<long long> dOff;
+  dCorner.upload(corner, static_cast<size_t>(h->F) * npx, s);
+  if (dyn) dDyn.upload(dyn, static_cast<size_t>(h->F) * dw * dh, s);
+  dPairs.upload(pairFrames, static_cast<size_t>(numPairs) * 2, s);
+  dFlow.upload(reinterpret_cast<const float2*>(flow), static_cast<size_t>(numPairs) * npx, s);
+  dMaskS.upload(mask, static_cast<size_t>(numPairs) * npx, s);
+  SamplingArgs A{W, H, h->invAspect, matchSeparation, minDynamicDistance, dCorner.p, dyn ? dDyn.p : nullptr,
+                 dyn ? dw : W, dyn ? dh : H};
+  // batches of pairs: keys (2 x 8 B) and the output slab (16 B) per pixel, ~1 GiB at a time
+  const int PB = static_cast<int>(std::max<size_t>(1, std::min<size_t>(numPairs, (size_t(1) << 30) / (npx * 32))));
+  dKeys.ensure(static_cast<size_t>(PB) * npx);
+  dKeysOut.ensure(static_cast<size_t>(PB) * npx);
+  dSlab.ensure(static_cast<size_t>(PB) * npx);
+  dNValid.ensure(PB);
+  dCount.ensure(PB);
+  std::vector<unsigned int> seg(PB + 1);
+  for (int i = 0; i <= PB; ++i) seg[i] = static_cast<unsigned int>(static_cast<size_t>(i) * npx);
+  if (static_cast<size_t>(PB) * npx > 0xFFFFFFFFull) throw std::runtime_error("sampling batch too large");
+  dSeg.upload(seg.data(), seg.size(), s);
+  size_t tmpBytes = 0;
+  HIP_CHECK(rocprim::segmented_radix_sort_keys_desc(nullptr, tmpBytes, dKeys.p, dKeysOut.p,
+                                                    static_cast<unsigned int>(static_cast<size_t>(PB) * npx),
+                                                    static_cast<unsigned int>(PB), dSeg.p, dSeg.p + 1, 0, 64, s));
+  DevBuf<unsigned char> dTmp;
+  dTmp.ensure(tmpBytes);
+  // pass 1: per batch candidates -> sort -> greedy; counts to the host; the slabs are compacted in pass 2 of the
+  // same batch once the running offset is known
+  std::vector<long long> off(numPairs + 1, 0);
+  std::vector<unsigned int> cnt(PB);
+  h->dSampledLoc.ensure(1);
+  std::vector<float4> hostLoc;
+  for (int p0 = 0; p0 < numPairs; p0 += PB) {
+    const int nb = std::min(PB, numPairs - p0);
+    HIP_CHECK(hipMemsetAsync(dNValid.p, 0, sizeof(unsigned int) * nb, s));
+    hipLaunchKernelGGL(k_fc_candidates, dim3(static_cast<unsigned>((npx + 255) / 256), nb), dim3(256), 0, s, A, p0,
+                       dPairs.p, dFlow.p, dMaskS.p, dKeys.p, dNValid.p);
+    HIP_CHECK(hipGetLastError());
+    size_t tb = tmpBytes;
+    HIP_CHECK(rocprim::segmented_radix_sort_keys_desc(dTmp.p, tb, dKeys.p, dKeysOut.p,
+                                                      static_cast<unsigned int>(static_cast<size_t>(nb) * npx),
+                                                      static_cast<unsigned int>(nb), dSeg.p, dSeg.p + 1, 0, 64, s));
+    const size_t ldsBytes = (npx + 31) / 32 * 4;
+    allowLds(k_fc_greedy, ldsBytes);
+    hipLaunchKernelGGL(k_fc_greedy, dim3(nb), dim3(64), ldsBytes, s, A, p0, dKeysOut.p, dNValid.p, dFlow.p, dSlab.p,
+                       dCount.p);
+    HIP_CHECK(hipGetLastError());
+    dCount.download(cnt.data(), nb, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < nb; ++i) off[p0 + i + 1] = off[p0 + i] + cnt[i];
+    // grow the result buffer and compact this batch into it
+    const size_t total = static_cast<size_t>(off[p0 + nb]);
+    if (total > h->dSampledLoc.n) {
+      DevBuf<float4> bigger;
+      bigger.ensure(std::max<size_t>(total, h->dSampledLoc.n * 2));
+      if (off[p0] > 0)
+        HIP_CHECK(hipMemcpyAsync(bigger.p, h->dSampledLoc.p, sizeof(float4) * off[p0], hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      std::swap(bigger.p, h->dSampledLoc.p);
+      std::swap(bigger.n, h->dSampledLoc.n);
+    }
+    dOff.upload(off.data(), off.size(), s);
+    hipLaunchKernelGGL(k_fc_compact, dim3(16, nb), dim3(256), 0, s, static_cast<int>(npx), p0, dOff.p, dSlab.p,
+                       h->dSampledLoc.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  h->sampledOff = off;
+  for (int i = 0; i <= numPairs; ++i) offsets[i] = off[i];
+}
+
 // ---- dense consumers of the result (cvd_dense.h) ----------------------------------------------
 // kind 0: DepthXform::apply -> f32 [n][H][W]; 1: GridDepthXform::paramMap -> f64 [n][H][W][N];
 // 2: SpatialXform::warp -> f32 [n][h][w][2] for the raster (w, h).  Host buffer out; the device buffer is kept for
@@ -2299,6 +2394,21 @@ int32_t cvd_pose_optimization_step(cvd_handle* h, const cvd_opt_params* p, doubl
 int32_t cvd_evaluate(cvd_handle* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, double* cost,
                      int32_t* nres, double* gradient, double* hdiag, double* hfull) {
   CVD_TRY(h, evaluate(h, *p, depthDeformReg, pose7, cost, nres, gradient, hdiag, hfull));
+}
+int32_t cvd_sample_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames, const float* corner,
+                                    const float* flow, const uint8_t* mask, const float* dynDist, int32_t dynW,
+                                    int32_t dynH, int32_t matchSeparation, float minDynamicDistance, int64_t* offsets) {
+  CVD_TRY(h, samplePairConstraints(h, numPairs, pairFrames, corner, flow, mask, dynDist, dynW, dynH, matchSeparation,
+                                   minDynamicDistance, offsets));
+}
+int32_t cvd_get_sampled_constraints(cvd_handle* h, float* loc4) {
+  CVD_TRY(h, {
+    const size_t n = h->sampledOff.empty() ? 0 : static_cast<size_t>(h->sampledOff.back());
+    if (n) {
+      HIP_CHECK(hipMemcpyAsync(loc4, h->dSampledLoc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+  });
 }
 int32_t cvd_apply_depth_xforms(cvd_handle* h, int32_t firstFrame, int32_t numFrames, float* out, double* kernelMs) {
   CVD_TRY(h, denseMaps(h, 0, firstFrame, numFrames, 0, 0, out, kernelMs));

@@ -1,0 +1,78 @@
+"""GPU parity of the flow-constraint sampling (robust_cvd_amd/csrc/cvd_sampling.h) against the oracle's
+sequential restatement of FlowConstraintsCollection::compute(PairKey) / sampleConstraints
+(reference lib/FlowConstraints.cpp:296-465).  Integer / index work and float products: bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Solver():
+    from robust_cvd_amd import api
+    return api.Solver
+
+
+def _inputs(F, W, H, P, seed, ties=False, dyn=None):
+    rng = np.random.default_rng(seed)
+    pairs = np.stack([rng.integers(0, F, P), rng.integers(0, F, P)], axis=1).astype(np.int32)
+    corner = rng.uniform(0, 1, (F, H, W)).astype(np.float32)
+    if ties:
+        corner = np.round(corner * 8) / 8          # heavy ties: exercises the documented tie-break (pixel order)
+    flow = rng.normal(0, 3.0, (P, H, W, 2)).astype(np.float32)
+    flow[:, :3] -= 5.0                              # push some targets out of the image / across zero (truncation)
+    mask = (rng.uniform(size=(P, H, W)) > 0.2).astype(np.uint8) * 255
+    dd = None
+    if dyn is not None:
+        dh, dw = dyn
+        dd = rng.uniform(0, 20, (F, dh, dw)).astype(np.float32)
+    return pairs, corner, flow, mask, dd
+
+
+@pytest.mark.parametrize("case", [
+    dict(W=64, H=40, sep=10, ties=False, dyn=None),
+    dict(W=64, H=40, sep=3, ties=True, dyn=None),
+    dict(W=96, H=56, sep=0, ties=False, dyn=None),          # dense mode: every valid pixel is a constraint
+    dict(W=96, H=56, sep=6, ties=False, dyn=(56, 96)),      # dynamic mask at image resolution
+    dict(W=96, H=56, sep=6, ties=True, dyn=(28, 48)),       # dynamic mask at half resolution
+])
+def test_sampling_matches_oracle(Solver, case):
+    F, P = 4, 7
+    W, H = case["W"], case["H"]
+    pairs, corner, flow, mask, dd = _inputs(F, W, H, P, seed=W + case["sep"], ties=case["ties"], dyn=case["dyn"])
+    out = {}
+    for k, s in (("hip", Solver(0)), ("oracle", Oracle())):
+        s.set_video(F, W, H)
+        out[k] = s.sample_pair_constraints(pairs, corner, flow, mask, case["sep"], dyn_dist=dd, min_dynamic_distance=4.0)
+    (oa, la), (ob, lb) = out["hip"], out["oracle"]
+    assert np.array_equal(oa, ob)
+    assert la.shape == lb.shape and la.shape[0] == oa[-1] > 0
+    assert np.array_equal(la, lb)                  # same constraints, same (rank) order, same float bits
+    if case["sep"] == 0 and dd is None:
+        # dense mode sanity: one constraint per valid candidate
+        assert oa[-1] <= int((mask > 0).sum())
+
+
+def test_sampling_minimum_distance_property_at_full_size(Solver):
+    """BASELINE-size image (384 x 224), matchSeparation 10: accepted reference pixels of a pair are pairwise farther
+    apart than the disk radius, every rejected candidate is covered, ~590 constraints per pair."""
+    F, P, W, H, sep = 3, 6, 384, 224, 10
+    pairs, corner, flow, mask, _ = _inputs(F, W, H, P, seed=5)
+    flow *= 0.3
+    s = Solver(0)
+    s.set_video(F, W, H)
+    off, loc = s.sample_pair_constraints(pairs, corner, flow, mask, sep)
+    inv_aspect = np.float32(1.0) / (np.float32(W) / np.float32(H))
+    for p in range(P):
+        l = loc[off[p]:off[p + 1]]
+        x = np.rint(l[:, 0] * W).astype(int)
+        y = np.rint(l[:, 1] / inv_aspect * H).astype(int)
+        d2 = (x[:, None] - x[None, :]) ** 2 + (y[:, None] - y[None, :]) ** 2
+        np.fill_diagonal(d2, 10 ** 9)
+        assert d2.min() > sep * sep
+        assert 400 < len(l) < 900
+        # rank order: corner strengths of the accepted pixels are non-increasing
+        cs = corner[pairs[p, 0], y, x]
+        assert np.all(np.diff(cs) <= 0)
