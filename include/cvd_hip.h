@@ -132,6 +132,16 @@ int32_t cvd_sample_pair_constraints(cvd_handle* h, int32_t num_pairs, const int3
                                     int32_t dyn_h, int32_t match_separation, float min_dynamic_distance,
                                     int64_t* offsets);
 int32_t cvd_get_sampled_constraints(cvd_handle* h, float* loc4);
+/* FlowConstraintsCollection::compute(TripletKey), reference lib/FlowConstraints.cpp:467-550: centres[T] (frames c with
+ * c-1 and c+1 inside the video), flow10 / mask10 = c -> c-1 and flow12 / mask12 = c -> c+1, each [T][H][W](x2).  Result:
+ * offsets[T + 1] and, through cvd_get_sampled_triplet_constraints, loc6 = (loc(c-1), loc(c), loc(c+1)) per constraint.
+ * The reference's two index slips are reproduced (corner response read at the column of the c-1 target; third
+ * dynamic-distance test on frame c's map). */
+int32_t cvd_sample_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers, const float* corner,
+                                       const float* flow10, const uint8_t* mask10, const float* flow12,
+                                       const uint8_t* mask12, const float* dyn_dist, int32_t dyn_w, int32_t dyn_h,
+                                       int32_t match_separation, float min_dynamic_distance, int64_t* offsets);
+int32_t cvd_get_sampled_triplet_constraints(cvd_handle* h, float* loc6);
 
 /* ---- dense consumers of the result: what loaders/video_dataset.py reads after every optimisation --
  * All frames [first_frame, first_frame + num_frames) in one launch, current transform parameters of the handle, host

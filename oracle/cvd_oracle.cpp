@@ -1377,7 +1377,7 @@ struct Oracle {
   std::vector<float> pairLoc;       // 4 per constraint: loc0.xy, loc1.xy in [0,1]x[0,invAspect]
   std::vector<uint8_t> pairStatic;
 
-  std::vector<float> sampledLoc;  // result of cvdo_sample_pair_constraints
+  std::vector<float> sampledLoc, sampledTrip;  // results of cvdo_sample_pair / _triplet_constraints
   std::vector<int> tripletCenters;
   std::vector<int64_t> tripletOffsets;
   std::vector<float> tripletLoc;  // 6 per constraint
@@ -2189,6 +2189,77 @@ int cvdo_sample_pair_constraints(void* h, int numPairs, const int32_t* pairFrame
       offsets[p + 1] = static_cast<int64_t>(o->sampledLoc.size() / 4);
     }
   });
+}
+// FlowConstraintsCollection::compute(TripletKey), reference lib/FlowConstraints.cpp:467-550, including its two index
+// slips: corner response read at cornerPtr[ix0] (:533) and the third dynamic-distance test on
+// dynamicDistance1 (:527).  Unchecked Mat accesses are clamped like in the pair version.
+int cvdo_sample_triplet_constraints(void* h, int numTriplets, const int32_t* centers, const float* corner,
+                                    const float* flow10, const uint8_t* mask10, const float* flow12,
+                                    const uint8_t* mask12, const float* dynDist, int dynW, int dynH, int matchSeparation,
+                                    float minDynamicDistance, int64_t* offsets) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    const int w = o->W, hh = o->Hh;
+    const size_t npx = static_cast<size_t>(w) * hh;
+    o->sampledTrip.clear();
+    offsets[0] = 0;
+    const int dw = dynDist ? dynW : w, dh = dynDist ? dynH : hh;
+    const float scaleX = dw / float(w), scaleY = dh / float(hh);
+    auto sc = [](float v, float s, int hi) { return std::min(std::max(static_cast<int>(v * s + 0.5f), 0), hi); };
+    auto dist = [&](int f, int y, int x) {
+      return dynDist ? dynDist[static_cast<size_t>(f) * dw * dh + static_cast<size_t>(y) * dw + x] : FLT_MAX;
+    };
+    struct Pixel { float cornerStrength; int ix1, iy1; float fx0, fy0, fx2, fy2; };
+    for (int g = 0; g < numTriplets; ++g) {
+      const int fc = centers[g];
+      const float* cornerImg = corner + fc * npx;
+      const float* f10 = flow10 + static_cast<size_t>(g) * npx * 2;
+      const float* f12 = flow12 + static_cast<size_t>(g) * npx * 2;
+      const uint8_t* m10 = mask10 + static_cast<size_t>(g) * npx;
+      const uint8_t* m12 = mask12 + static_cast<size_t>(g) * npx;
+      std::vector<Pixel> pixels;
+      for (int iy1 = 0; iy1 < hh; ++iy1) {
+        const float* cornerPtr = cornerImg + static_cast<size_t>(iy1) * w;
+        const int iy1s = sc(iy1, scaleY, dh - 1);
+        for (int ix1 = 0; ix1 < w; ++ix1) {
+          const int ix1s = sc(ix1, scaleX, dw - 1);
+          const size_t pi = static_cast<size_t>(iy1) * w + ix1;
+          if (m10[pi] && m12[pi] && dist(fc, iy1s, ix1s) > minDynamicDistance) {
+            const float fx0 = ix1 + f10[pi * 2], fy0 = iy1 + f10[pi * 2 + 1];
+            const int ix0 = fx0 + 0.5f, iy0 = fy0 + 0.5f;
+            const float fx2 = ix1 + f12[pi * 2], fy2 = iy1 + f12[pi * 2 + 1];
+            const int ix2 = fx2 + 0.5f, iy2 = fy2 + 0.5f;
+            if (ix0 >= 0 && ix0 < w && iy0 >= 0 && iy0 < hh && ix2 >= 0 && ix2 < w && iy2 >= 0 && iy2 < hh) {
+              const int ix0s = sc(fx0, scaleX, dw - 1), iy0s = sc(fy0, scaleY, dh - 1);
+              const int ix2s = sc(fx2, scaleX, dw - 1), iy2s = sc(fy2, scaleY, dh - 1);
+              if (dist(fc - 1, iy0s, ix0s) > minDynamicDistance && dist(fc, iy2s, ix2s) > minDynamicDistance)
+                pixels.push_back({cornerPtr[ix0], ix1, iy1, fx0, fy0, fx2, fy2});
+            }
+          }
+        }
+      }
+      std::stable_sort(pixels.begin(), pixels.end(),
+                       [](const Pixel& a, const Pixel& b) { return a.cornerStrength > b.cornerStrength; });
+      std::vector<uint8_t> invalid(npx, 0);
+      const int r = matchSeparation;
+      const float sx = 1.f / w, sy = o->invAspect / hh;
+      for (const Pixel& px : pixels) {
+        if (invalid[static_cast<size_t>(px.iy1) * w + px.ix1]) continue;  // referencePixel = c[1] (:345-347)
+        const float l[6] = {px.fx0 * sx, px.fy0 * sy, px.ix1 * sx, px.iy1 * sy, px.fx2 * sx, px.fy2 * sy};
+        o->sampledTrip.insert(o->sampledTrip.end(), l, l + 6);
+        for (int my = std::max(0, px.iy1 - r); my <= std::min(hh - 1, px.iy1 + r); ++my)
+          for (int mx = std::max(0, px.ix1 - r); mx <= std::min(w - 1, px.ix1 + r); ++mx) {
+            const int rx = mx - px.ix1, ry = my - px.iy1;
+            if (rx * rx + ry * ry <= r * r) invalid[static_cast<size_t>(my) * w + mx] = 255;
+          }
+      }
+      offsets[g + 1] = static_cast<int64_t>(o->sampledTrip.size() / 6);
+    }
+  });
+}
+int cvdo_get_sampled_triplet_constraints(void* h, float* loc6) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, std::memcpy(loc6, o->sampledTrip.data(), sizeof(float) * o->sampledTrip.size()));
 }
 int cvdo_get_sampled_constraints(void* h, float* loc4) {
   Oracle* o = static_cast<Oracle*>(h);

@@ -226,6 +226,30 @@ class Binding:
             self._check(self._fn("get_sampled_constraints")(self._h, _ptr(loc, C.c_float)))
         return off, loc
 
+    def sample_triplet_constraints(self, centers, corner, flow10, mask10, flow12, mask12, match_separation,
+                                   dyn_dist=None, min_dynamic_distance=0.0):
+        """FlowConstraintsCollection::compute(TripletKey): returns (offsets [T+1] int64, loc [C, 6] float32)."""
+        ce = np.ascontiguousarray(centers, dtype=np.int32)
+        T = ce.shape[0]
+        co = _f32(corner)
+        f10, f12 = _f32(flow10), _f32(flow12)
+        m10, m12 = np.ascontiguousarray(mask10, dtype=np.uint8), np.ascontiguousarray(mask12, dtype=np.uint8)
+        assert f10.shape == (T, self.height, self.width, 2) and f12.shape == f10.shape
+        assert m10.shape == (T, self.height, self.width) and m12.shape == m10.shape
+        dd, dw, dh = None, 0, 0
+        if dyn_dist is not None:
+            dd = _f32(dyn_dist)
+            dh, dw = dd.shape[1], dd.shape[2]
+        off = np.zeros(T + 1, dtype=np.int64)
+        self._check(self._fn("sample_triplet_constraints")(
+            self._h, C.c_int(T), _ptr(ce, C.c_int32), _ptr(co, C.c_float), _ptr(f10, C.c_float), _ptr(m10, C.c_uint8),
+            _ptr(f12, C.c_float), _ptr(m12, C.c_uint8), _ptr(dd, C.c_float) if dd is not None else None, C.c_int(dw),
+            C.c_int(dh), C.c_int(match_separation), C.c_float(min_dynamic_distance), _ptr(off, C.c_int64)))
+        loc = np.zeros((int(off[-1]), 6), dtype=np.float32)
+        if loc.size:
+            self._check(self._fn("get_sampled_triplet_constraints")(self._h, _ptr(loc, C.c_float)))
+        return off, loc
+
     # -- dense consumers of the result (SURVEY.md 8 f3) ------------------------------------------------
     def apply_depth_xforms(self, first=0, count=None, timing=False):
         """DepthXform::apply for frames [first, first+count): [n, H, W] float32."""

@@ -310,8 +310,8 @@ struct cvd_handle_t {
   DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
   DevBuf<double> dDense;     // output of the dense consumer kernels (cvd_dense.h)
   // constraint sampling (cvd_sampling.h): result of the last cvd_sample_pair_constraints
-  DevBuf<float4> dSampledLoc;
-  std::vector<long long> sampledOff;
+  DevBuf<float2> dSampledLoc, dSampledTrip;  // 2 resp. 3 float2 per constraint
+  std::vector<long long> sampledOff, sampledTripOff;
 
   // coarse (pose-graph) level of the two-level preconditioner (cvd_coarse.h)
   struct CoarseHost {
@@ -1958,92 +1958,108 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
 }
 
 // ---- constraint sampling (cvd_sampling.h) -----------------------------------------------------------
-static void samplePairConstraints(cvd_handle* h, int numPairs, const int32_t* pairFrames, const float* corner,
-                                  const float* flow, const uint8_t* mask, const float* dyn, int dw, int dh,
-                                  int matchSeparation, float minDynamicDistance, int64_t* offsets) {
+// triplet == false: keyFrames = 2 x n frames (a, b) of the directed pairs, flow / mask = a -> b.
+// triplet == true : keyFrames = n centre frames c, flow / mask = c -> c-1, flow2 / mask2 = c -> c+1.
+static void sampleConstraints(cvd_handle* h, bool triplet, int num, const int32_t* keyFrames, const float* corner,
+                              const float* flow, const uint8_t* mask, const float* flow2, const uint8_t* mask2,
+                              const float* dyn, int dw, int dh, int matchSeparation, float minDynamicDistance,
+                              int64_t* offsets) {
   if (h->F <= 0) throw std::runtime_error("no video set");
   if (matchSeparation < 0) throw std::runtime_error("matchSeparation must be >= 0");
   const int W = h->W, H = h->H;
   const size_t npx = static_cast<size_t>(W) * H;
+  const int width = triplet ? 3 : 2;  // float2 per constraint
   if ((npx + 31) / 32 * 4 > kMaxLds) throw std::runtime_error("image too large for the LDS-resident sampling mask");
-  for (int i = 0; i < 2 * numPairs; ++i)
-    if (pairFrames[i] < 0 || pairFrames[i] >= h->F) throw std::runtime_error("pair frame out of range");
+  for (int i = 0; i < (triplet ? 1 : 2) * num; ++i) {
+    const int f = keyFrames[i];
+    if (f < 0 || f >= h->F || (triplet && (f < 1 || f + 1 >= h->F))) throw std::runtime_error("sampling frame out of range");
+  }
   hipStream_t s = h->stream;
   DevBuf<float> dCorner, dDyn;
-  DevBuf<float2> dFlow;
-  DevBuf<unsigned char> dMaskS;
-  DevBuf<int> dPairs;
+  DevBuf<float2> dFlow, dFlow2, dSlab;
+  DevBuf<unsigned char> dMaskS, dMaskS2, dTmp;
+  DevBuf<int> dKeysF;
   DevBuf<unsigned long long> dKeys, dKeysOut;
   DevBuf<unsigned int> dNValid, dCount, dSeg;
-  DevBuf<float4> dSlab;
   DevBuf<long long> dOff;
   dCorner.upload(corner, static_cast<size_t>(h->F) * npx, s);
   if (dyn) dDyn.upload(dyn, static_cast<size_t>(h->F) * dw * dh, s);
-  dPairs.upload(pairFrames, static_cast<size_t>(numPairs) * 2, s);
-  dFlow.upload(reinterpret_cast<const float2*>(flow), static_cast<size_t>(numPairs) * npx, s);
-  dMaskS.upload(mask, static_cast<size_t>(numPairs) * npx, s);
+  dKeysF.upload(keyFrames, static_cast<size_t>(num) * (triplet ? 1 : 2), s);
+  dFlow.upload(reinterpret_cast<const float2*>(flow), static_cast<size_t>(num) * npx, s);
+  dMaskS.upload(mask, static_cast<size_t>(num) * npx, s);
+  if (triplet) {
+    dFlow2.upload(reinterpret_cast<const float2*>(flow2), static_cast<size_t>(num) * npx, s);
+    dMaskS2.upload(mask2, static_cast<size_t>(num) * npx, s);
+  }
   SamplingArgs A{W, H, h->invAspect, matchSeparation, minDynamicDistance, dCorner.p, dyn ? dDyn.p : nullptr,
                  dyn ? dw : W, dyn ? dh : H};
-  // batches of pairs: keys (2 x 8 B) and the output slab (16 B) per pixel, ~1 GiB at a time
-  const int PB = static_cast<int>(std::max<size_t>(1, std::min<size_t>(numPairs, (size_t(1) << 30) / (npx * 32))));
+  // batches: keys (2 x 8 B) and the output slab (8 B x width) per pixel, ~1 GiB at a time
+  const int PB = static_cast<int>(std::max<size_t>(1, std::min<size_t>(num, (size_t(1) << 30) / (npx * (16 + 8 * width)))));
+  if (static_cast<size_t>(PB) * npx > 0xFFFFFFFFull) throw std::runtime_error("sampling batch too large");
   dKeys.ensure(static_cast<size_t>(PB) * npx);
   dKeysOut.ensure(static_cast<size_t>(PB) * npx);
-  dSlab.ensure(static_cast<size_t>(PB) * npx);
+  dSlab.ensure(static_cast<size_t>(PB) * npx * width);
   dNValid.ensure(PB);
   dCount.ensure(PB);
   std::vector<unsigned int> seg(PB + 1);
   for (int i = 0; i <= PB; ++i) seg[i] = static_cast<unsigned int>(static_cast<size_t>(i) * npx);
-  if (static_cast<size_t>(PB) * npx > 0xFFFFFFFFull) throw std::runtime_error("sampling batch too large");
   dSeg.upload(seg.data(), seg.size(), s);
   size_t tmpBytes = 0;
   HIP_CHECK(rocprim::segmented_radix_sort_keys_desc(nullptr, tmpBytes, dKeys.p, dKeysOut.p,
                                                     static_cast<unsigned int>(static_cast<size_t>(PB) * npx),
                                                     static_cast<unsigned int>(PB), dSeg.p, dSeg.p + 1, 0, 64, s));
-  DevBuf<unsigned char> dTmp;
   dTmp.ensure(tmpBytes);
-  // pass 1: per batch candidates -> sort -> greedy; counts to the host; the slabs are compacted in pass 2 of the
-  // same batch once the running offset is known
-  std::vector<long long> off(numPairs + 1, 0);
+  DevBuf<float2>& result = triplet ? h->dSampledTrip : h->dSampledLoc;
+  std::vector<long long> off(num + 1, 0);
   std::vector<unsigned int> cnt(PB);
-  h->dSampledLoc.ensure(1);
-  std::vector<float4> hostLoc;
-  for (int p0 = 0; p0 < numPairs; p0 += PB) {
-    const int nb = std::min(PB, numPairs - p0);
+  result.ensure(1);
+  for (int p0 = 0; p0 < num; p0 += PB) {
+    const int nb = std::min(PB, num - p0);
     HIP_CHECK(hipMemsetAsync(dNValid.p, 0, sizeof(unsigned int) * nb, s));
-    hipLaunchKernelGGL(k_fc_candidates, dim3(static_cast<unsigned>((npx + 255) / 256), nb), dim3(256), 0, s, A, p0,
-                       dPairs.p, dFlow.p, dMaskS.p, dKeys.p, dNValid.p);
+    const dim3 gridC(static_cast<unsigned>((npx + 255) / 256), nb);
+    if (triplet)
+      hipLaunchKernelGGL(k_fc_triplet_candidates, gridC, dim3(256), 0, s, A, p0, dKeysF.p, dFlow.p, dMaskS.p, dFlow2.p,
+                         dMaskS2.p, dKeys.p, dNValid.p);
+    else
+      hipLaunchKernelGGL(k_fc_candidates, gridC, dim3(256), 0, s, A, p0, dKeysF.p, dFlow.p, dMaskS.p, dKeys.p, dNValid.p);
     HIP_CHECK(hipGetLastError());
     size_t tb = tmpBytes;
     HIP_CHECK(rocprim::segmented_radix_sort_keys_desc(dTmp.p, tb, dKeys.p, dKeysOut.p,
                                                       static_cast<unsigned int>(static_cast<size_t>(nb) * npx),
                                                       static_cast<unsigned int>(nb), dSeg.p, dSeg.p + 1, 0, 64, s));
     const size_t ldsBytes = (npx + 31) / 32 * 4;
-    allowLds(k_fc_greedy, ldsBytes);
-    hipLaunchKernelGGL(k_fc_greedy, dim3(nb), dim3(64), ldsBytes, s, A, p0, dKeysOut.p, dNValid.p, dFlow.p, dSlab.p,
-                       dCount.p);
+    if (triplet) {
+      allowLds(k_fc_greedy<true>, ldsBytes);
+      hipLaunchKernelGGL(k_fc_greedy<true>, dim3(nb), dim3(64), ldsBytes, s, A, p0, dKeysOut.p, dNValid.p, dFlow.p,
+                         dFlow2.p, dSlab.p, dCount.p);
+    } else {
+      allowLds(k_fc_greedy<false>, ldsBytes);
+      hipLaunchKernelGGL(k_fc_greedy<false>, dim3(nb), dim3(64), ldsBytes, s, A, p0, dKeysOut.p, dNValid.p, dFlow.p,
+                         static_cast<const float2*>(nullptr), dSlab.p, dCount.p);
+    }
     HIP_CHECK(hipGetLastError());
     dCount.download(cnt.data(), nb, s);
     HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i < nb; ++i) off[p0 + i + 1] = off[p0 + i] + cnt[i];
     // grow the result buffer and compact this batch into it
-    const size_t total = static_cast<size_t>(off[p0 + nb]);
-    if (total > h->dSampledLoc.n) {
-      DevBuf<float4> bigger;
-      bigger.ensure(std::max<size_t>(total, h->dSampledLoc.n * 2));
+    const size_t total = static_cast<size_t>(off[p0 + nb]) * width;
+    if (total > result.n) {
+      DevBuf<float2> bigger;
+      bigger.ensure(std::max<size_t>(total, result.n * 2));
       if (off[p0] > 0)
-        HIP_CHECK(hipMemcpyAsync(bigger.p, h->dSampledLoc.p, sizeof(float4) * off[p0], hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(bigger.p, result.p, sizeof(float2) * off[p0] * width, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      std::swap(bigger.p, h->dSampledLoc.p);
-      std::swap(bigger.n, h->dSampledLoc.n);
+      std::swap(bigger.p, result.p);
+      std::swap(bigger.n, result.n);
     }
     dOff.upload(off.data(), off.size(), s);
-    hipLaunchKernelGGL(k_fc_compact, dim3(16, nb), dim3(256), 0, s, static_cast<int>(npx), p0, dOff.p, dSlab.p,
-                       h->dSampledLoc.p);
+    hipLaunchKernelGGL(k_fc_compact, dim3(16, nb), dim3(256), 0, s, static_cast<int>(npx), width, p0, dOff.p, dSlab.p,
+                       result.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(s));
   }
-  h->sampledOff = off;
-  for (int i = 0; i <= numPairs; ++i) offsets[i] = off[i];
+  (triplet ? h->sampledTripOff : h->sampledOff) = off;
+  for (int i = 0; i <= num; ++i) offsets[i] = off[i];
 }
 
 // ---- dense consumers of the result (cvd_dense.h) ----------------------------------------------
@@ -2398,14 +2414,30 @@ int32_t cvd_evaluate(cvd_handle* h, const cvd_opt_params* p, double depthDeformR
 int32_t cvd_sample_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames, const float* corner,
                                     const float* flow, const uint8_t* mask, const float* dynDist, int32_t dynW,
                                     int32_t dynH, int32_t matchSeparation, float minDynamicDistance, int64_t* offsets) {
-  CVD_TRY(h, samplePairConstraints(h, numPairs, pairFrames, corner, flow, mask, dynDist, dynW, dynH, matchSeparation,
-                                   minDynamicDistance, offsets));
+  CVD_TRY(h, sampleConstraints(h, false, numPairs, pairFrames, corner, flow, mask, nullptr, nullptr, dynDist, dynW, dynH,
+                               matchSeparation, minDynamicDistance, offsets));
 }
 int32_t cvd_get_sampled_constraints(cvd_handle* h, float* loc4) {
   CVD_TRY(h, {
     const size_t n = h->sampledOff.empty() ? 0 : static_cast<size_t>(h->sampledOff.back());
     if (n) {
-      HIP_CHECK(hipMemcpyAsync(loc4, h->dSampledLoc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+      HIP_CHECK(hipMemcpyAsync(loc4, h->dSampledLoc.p, n * 2 * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+  });
+}
+int32_t cvd_sample_triplet_constraints(cvd_handle* h, int32_t numTriplets, const int32_t* centers, const float* corner,
+                                       const float* flow10, const uint8_t* mask10, const float* flow12,
+                                       const uint8_t* mask12, const float* dynDist, int32_t dynW, int32_t dynH,
+                                       int32_t matchSeparation, float minDynamicDistance, int64_t* offsets) {
+  CVD_TRY(h, sampleConstraints(h, true, numTriplets, centers, corner, flow10, mask10, flow12, mask12, dynDist, dynW, dynH,
+                               matchSeparation, minDynamicDistance, offsets));
+}
+int32_t cvd_get_sampled_triplet_constraints(cvd_handle* h, float* loc6) {
+  CVD_TRY(h, {
+    const size_t n = h->sampledTripOff.empty() ? 0 : static_cast<size_t>(h->sampledTripOff.back());
+    if (n) {
+      HIP_CHECK(hipMemcpyAsync(loc6, h->dSampledTrip.p, n * 3 * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
       HIP_CHECK(hipStreamSynchronize(h->stream));
     }
   });

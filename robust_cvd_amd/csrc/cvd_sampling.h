@@ -87,12 +87,78 @@ __global__ __launch_bounds__(256) void k_fc_candidates(SamplingArgs A, int pair0
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(&nValid[pb], static_cast<unsigned int>(__popcll(b)));
 }
 
+// Triplet candidates, reference lib/FlowConstraints.cpp:467-545: centre pixel (ix1, iy1) of frame c with the flows
+// c -> c-1 and c -> c+1.  Two index slips of the reference are kept: the corner response is read
+// at column ix0 (the flow target in frame c-1) of row iy1, and the third dynamic-distance test reads frame c's map.
+__device__ __forceinline__ bool fcTripletCandidate(const SamplingArgs& A, int fc, int ix1, int iy1, float2 f10, float2 f12,
+                                                   unsigned char m10, unsigned char m12, float& fx0, float& fy0,
+                                                   float& fx2, float& fy2, int& ix0) {
+  const size_t dpl = static_cast<size_t>(A.dw) * A.dh;
+  const float sx = __fdiv_rn(static_cast<float>(A.dw), static_cast<float>(A.W));
+  const float sy = __fdiv_rn(static_cast<float>(A.dh), static_cast<float>(A.H));
+  auto scaled = [&](float v, float sc, int hi) {
+    float t = v * sc;
+    asm volatile("" : "+v"(t));
+    return min(max(static_cast<int>(t + 0.5f), 0), hi);
+  };
+  if (!(m10 && m12)) return false;
+  if (A.dyn != nullptr) {
+    const int iy1s = scaled(static_cast<float>(iy1), sy, A.dh - 1), ix1s = scaled(static_cast<float>(ix1), sx, A.dw - 1);
+    if (!(A.dyn[fc * dpl + static_cast<size_t>(iy1s) * A.dw + ix1s] > A.minDynamicDistance)) return false;
+  }
+  fx0 = __fadd_rn(static_cast<float>(ix1), f10.x);
+  fy0 = __fadd_rn(static_cast<float>(iy1), f10.y);
+  ix0 = static_cast<int>(__fadd_rn(fx0, 0.5f));
+  const int iy0 = static_cast<int>(__fadd_rn(fy0, 0.5f));
+  fx2 = __fadd_rn(static_cast<float>(ix1), f12.x);
+  fy2 = __fadd_rn(static_cast<float>(iy1), f12.y);
+  const int ix2 = static_cast<int>(__fadd_rn(fx2, 0.5f));
+  const int iy2 = static_cast<int>(__fadd_rn(fy2, 0.5f));
+  if (!(ix0 >= 0 && ix0 < A.W && iy0 >= 0 && iy0 < A.H && ix2 >= 0 && ix2 < A.W && iy2 >= 0 && iy2 < A.H)) return false;
+  if (A.dyn != nullptr) {
+    const int ix0s = scaled(fx0, sx, A.dw - 1), iy0s = scaled(fy0, sy, A.dh - 1);
+    const int ix2s = scaled(fx2, sx, A.dw - 1), iy2s = scaled(fy2, sy, A.dh - 1);
+    if (!(A.dyn[(fc - 1) * dpl + static_cast<size_t>(iy0s) * A.dw + ix0s] > A.minDynamicDistance)) return false;
+    if (!(A.dyn[fc * dpl + static_cast<size_t>(iy2s) * A.dw + ix2s] > A.minDynamicDistance)) return false;  // (sic: frame c)
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_fc_triplet_candidates(SamplingArgs A, int g0, const int* __restrict__ centers,
+                                                               const float2* __restrict__ flow10,
+                                                               const unsigned char* __restrict__ mask10,
+                                                               const float2* __restrict__ flow12,
+                                                               const unsigned char* __restrict__ mask12,
+                                                               unsigned long long* __restrict__ keys,
+                                                               unsigned int* __restrict__ nValid) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gb = blockIdx.y;
+  const int g = g0 + gb;
+  const int npx = A.W * A.H;
+  bool ok = false;
+  if (pix < npx) {
+    const int iy1 = pix / A.W, ix1 = pix - iy1 * A.W;
+    const int fc = centers[g];
+    const size_t gi = static_cast<size_t>(g) * npx + pix;
+    float fx0, fy0, fx2, fy2;
+    int ix0 = 0;
+    ok = fcTripletCandidate(A, fc, ix1, iy1, flow10[gi], flow12[gi], mask10[gi], mask12[gi], fx0, fy0, fx2, fy2, ix0);
+    const unsigned int hi = ok ? orderedBits(A.corner[static_cast<size_t>(fc) * npx + static_cast<size_t>(iy1) * A.W + ix0]) : 0u;
+    keys[static_cast<size_t>(gb) * npx + pix] =
+        (static_cast<unsigned long long>(hi) << 32) | static_cast<unsigned int>(~static_cast<unsigned int>(pix));
+  }
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&nValid[gb], static_cast<unsigned int>(__popcll(b)));
+}
+
 // One wave per pair: greedy disk suppression over the rank-ordered candidates.
 // slab: [pairs in batch][W*H][4] accepted constraints in rank order; count[pb] = how many.
+// TRIPLET: flow = c -> c-1, flow2 = c -> c+1 and the slab holds 6 floats per constraint (3 x float2).
+template <bool TRIPLET>
 __global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, const unsigned long long* __restrict__ sortedKeys,
                                                   const unsigned int* __restrict__ nValid,
-                                                  const float2* __restrict__ flow, float4* __restrict__ slab,
-                                                  unsigned int* __restrict__ count) {
+                                                  const float2* __restrict__ flow, const float2* __restrict__ flow2,
+                                                  float2* __restrict__ slab, unsigned int* __restrict__ count) {
   extern __shared__ unsigned int invalid[];  // W*H bits
   const int pb = blockIdx.x, lane = threadIdx.x;
   const int p = pair0 + pb;
@@ -125,10 +191,21 @@ __global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, con
       const int cy = static_cast<int>(cp) / A.W, cx = static_cast<int>(cp) - cy * A.W;
       if (lane == 0) {
         const float2 ff = flow[static_cast<size_t>(p) * npx + cp];
-        const float fx1 = __fadd_rn(static_cast<float>(cx), ff.x), fy1 = __fadd_rn(static_cast<float>(cy), ff.y);
-        slab[static_cast<size_t>(pb) * npx + nOut] =
-            make_float4(__fmul_rn(static_cast<float>(cx), sxo), __fmul_rn(static_cast<float>(cy), syo),
-                        __fmul_rn(fx1, sxo), __fmul_rn(fy1, syo));
+        const float fxa = __fadd_rn(static_cast<float>(cx), ff.x), fya = __fadd_rn(static_cast<float>(cy), ff.y);
+        const float2 here = make_float2(__fmul_rn(static_cast<float>(cx), sxo), __fmul_rn(static_cast<float>(cy), syo));
+        const float2 there = make_float2(__fmul_rn(fxa, sxo), __fmul_rn(fya, syo));
+        if constexpr (TRIPLET) {
+          const float2 f2 = flow2[static_cast<size_t>(p) * npx + cp];
+          const float fxb = __fadd_rn(static_cast<float>(cx), f2.x), fyb = __fadd_rn(static_cast<float>(cy), f2.y);
+          float2* o = slab + (static_cast<size_t>(pb) * npx + nOut) * 3;
+          o[0] = there;  // frame c-1
+          o[1] = here;   // frame c (the reference pixel)
+          o[2] = make_float2(__fmul_rn(fxb, sxo), __fmul_rn(fyb, syo));
+        } else {
+          float2* o = slab + (static_cast<size_t>(pb) * npx + nOut) * 2;
+          o[0] = here;
+          o[1] = there;
+        }
       }
       ++nOut;
       // stamp the disk (reference buildDiskMask: dx^2 + dy^2 <= r^2), clipped to the image
@@ -147,12 +224,12 @@ __global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, con
 }
 
 // compaction of one batch: slab rows -> the pair's slice of the output
-__global__ __launch_bounds__(256) void k_fc_compact(int npx, int pair0, const long long* __restrict__ offsets,
-                                                    const float4* __restrict__ slab, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_fc_compact(int npx, int width, int pair0, const long long* __restrict__ offsets,
+                                                    const float2* __restrict__ slab, float2* __restrict__ out) {
   const int pb = blockIdx.y;
-  const long long o0 = offsets[pair0 + pb], n = offsets[pair0 + pb + 1] - o0;
+  const long long o0 = offsets[pair0 + pb] * width, n = (offsets[pair0 + pb + 1] - offsets[pair0 + pb]) * width;
   for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256)
-    out[o0 + i] = slab[static_cast<size_t>(pb) * npx + i];
+    out[o0 + i] = slab[static_cast<size_t>(pb) * npx * width + i];
 }
 
 }  // namespace cvd

@@ -76,3 +76,30 @@ def test_sampling_minimum_distance_property_at_full_size(Solver):
         # rank order: corner strengths of the accepted pixels are non-increasing
         cs = corner[pairs[p, 0], y, x]
         assert np.all(np.diff(cs) <= 0)
+
+
+@pytest.mark.parametrize("dyn", [None, (56, 96), (29, 49)])
+def test_triplet_sampling_matches_oracle(Solver, dyn):
+    """compute(TripletKey), reference lib/FlowConstraints.cpp:467-550, quirks included."""
+    F, W, H, sep = 6, 96, 56, 5
+    rng = np.random.default_rng(17)
+    centers = np.array([1, 2, 4], dtype=np.int32)
+    T = len(centers)
+    corner = (np.round(rng.uniform(0, 1, (F, H, W)) * 64) / 64).astype(np.float32)
+    f10 = rng.normal(0, 2.5, (T, H, W, 2)).astype(np.float32)
+    f12 = rng.normal(0, 2.5, (T, H, W, 2)).astype(np.float32)
+    m10 = (rng.uniform(size=(T, H, W)) > 0.15).astype(np.uint8)
+    m12 = (rng.uniform(size=(T, H, W)) > 0.15).astype(np.uint8)
+    dd = rng.uniform(0, 20, (F,) + dyn).astype(np.float32) if dyn else None
+    out = {}
+    for k, s in (("hip", Solver(0)), ("oracle", Oracle())):
+        s.set_video(F, W, H)
+        out[k] = s.sample_triplet_constraints(centers, corner, f10, m10, f12, m12, sep, dyn_dist=dd, min_dynamic_distance=3.0)
+    (oa, la), (ob, lb) = out["hip"], out["oracle"]
+    assert np.array_equal(oa, ob) and oa[-1] > 0
+    assert la.shape == lb.shape == (oa[-1], 6)
+    assert np.array_equal(la, lb)
+    # the centre observation is an integer pixel, the outer two carry the sub-pixel flow
+    inv_aspect = np.float32(1.0) / (np.float32(W) / np.float32(H))
+    assert np.allclose(la[:, 2] * W, np.rint(la[:, 2] * W), atol=1e-4)
+    assert np.allclose(la[:, 3] / inv_aspect * H, np.rint(la[:, 3] / inv_aspect * H), atol=1e-4)
