@@ -675,6 +675,25 @@ __device__ __forceinline__ double coarseAt(const double* __restrict__ cF, const 
   if (L.N >= 1 && L.depthType != kDepthIdentity && i < 7 + L.nD && (L.N == 1 || ((i - 7) % L.N) == 0)) return cF[f * kCB + 7];
   return 0.0;
 }
+// Coarse-level pieces fused into the per-frame PCG kernels (Wb == nullptr: off).  With y = W Z^T r maintained by
+// recursion, y <- y - alpha W (Z^T q), k_cg_update updates the frame's row of y itself (W rows gather from the
+// restricted product qc = Z^T q that k_matvec_finish left behind), so the steady-state iteration needs no separate
+// "y = W Z^T r" launch.
+struct CoarseStep {
+  const int* wtPtr;     // W blocks of ROW i: [wtPtr[i], wtPtr[i+1])
+  const int* wtBlk;     //   W block id
+  const int* wtFrame;   //   frame of the block's column
+  const double* Wb;
+  const double* qc;     // Z^T q, [F][kCB]
+  double* y;            // [F][kCB] by elimination position
+  double* fdotY;        // [F] |y_i|^2
+  const int* fail;
+};
+// masked restriction Z_f^T v_f of one frame's vector (LDS or global) by the calling workgroup: threads 0..6 the
+// pose-like entries, wave 1 the sum over the depth-scale vertices
+__device__ __forceinline__ void coarseRestrict(const Layout& L, const double* __restrict__ vf, int f, int tid,
+                                               const unsigned char* __restrict__ modeActive, double* __restrict__ out);
+
 // What the consumers of the preconditioned residual need from the coarse level: y = W Z^T r (k_coarse_apply_w) and
 // the W blocks of the frame's elimination-tree path; c_f = sum_t W_tf^T y_t is formed where it is used, which
 // saves a launch per PCG iteration -- or, Wb == nullptr and cF != nullptr, c of all frames was written by
@@ -737,6 +756,19 @@ __device__ __forceinline__ double waveSum(double v) {
   v += dppMove<0x141>(v);  // row_half_mirror
   v += dppMove<0x140>(v);  // row_mirror
   return (readLane(v, 0) + readLane(v, 16)) + (readLane(v, 32) + readLane(v, 48));
+}
+
+__device__ __forceinline__ void coarseRestrict(const Layout& L, const double* __restrict__ vf, int f, int tid,
+                                               const unsigned char* __restrict__ modeActive, double* __restrict__ out) {
+  // (inactive modes are identity rows of the coarse matrix: they must not feed the coarse solve)
+  if (tid < 7) out[f * kCB + tid] = modeActive[f * kCB + tid] ? vf[tid] : 0.0;
+  if (tid >= 64 && tid < 128) {
+    const int nV = (L.N >= 1 && L.depthType != kDepthIdentity) ? L.nD / L.N : 0;
+    double a = 0.0;
+    for (int v = tid - 64; v < nV; v += 64) a += vf[7 + v * L.N];
+    a = waveSum(a);
+    if (tid == 64) out[f * kCB + 7] = modeActive[f * kCB + 7] ? a : 0.0;
+  }
 }
 
 }  // namespace cvd

@@ -320,7 +320,7 @@ struct cvd_handle_t {
     std::vector<int> itemEdge;
     DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr,
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev;
-    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, y, c, dotPart;
+    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY;
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
@@ -850,6 +850,8 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.Linv.ensure(static_cast<size_t>(F) * kCBB);
   C.Wb.ensure(static_cast<size_t>(nW) * kCBB);
   C.rc.ensure(n);
+  C.qc.ensure(n);
+  C.fdotY.ensure(F);
   C.y.ensure(n);
   C.c.ensure(n);
   C.dotPart.ensure(static_cast<size_t>(F));
@@ -1383,13 +1385,15 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF);
+                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF,
+                         (withCoarse && h->world == 1) ? h->coarse.qc.p : nullptr);
     });
     HIP_CHECK(hipGetLastError());
     if (h->world > 1) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
       NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
-      hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p);
+      hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
+                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p);
       HIP_CHECK(hipGetLastError());
     }
     h->tEnd(slot);
@@ -1478,23 +1482,33 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   const int nChunks = static_cast<int>((B + 63) / 64);
   const int nThreads = 256 * nChunks;
   double* fd = h->dFdot.p;
-  const size_t ldsU = (B + nThreads + 48) * 8;
+  const size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
   for (int i = 0; i < 9; ++i) h->hPcg[i] = 0.0;  // device progress mirror (pcgFinishScalars): nothing applied yet
   const bool coarse = h->coarseOn;
   double* rc = coarse ? h->coarse.rc.p : nullptr;
-  auto coarseApply = [&](int init) {
-    // second level of the preconditioner: c = A_c^-1 Z^T r; also closes the PCG scalars of this iteration
-    hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
-                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2,
-                       h->hPcg);
+  // Coarse level per iteration: y = W Z^T r is kept up to date inside k_cg_update (CoarseStep: y <- y - alpha W Z^T q,
+  // |y|^2 closes r^T z), so only c = W^T y remains as a launch; the first residual goes through k_coarse_apply_w.
+  static const bool unfusedY = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
+  auto coarseC = [&](int init) {
     if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
+  auto coarseApply = [&](int init) {
+    hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
+                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2,
+                       h->hPcg);
+    coarseC(init);
+  };
+  const CoarseStep csOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const CoarseStep csOn = (coarse && !unfusedY)
+                              ? CoarseStep{h->coarse.wtPtr.p, h->coarse.wtBlk.p, h->coarse.wtFrame.p, h->coarse.Wb.p,
+                                           h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p}
+                              : csOff;
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p, h->hPcg);
+                     h->coarse.modeActive.p, h->hPcg, csOff);
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -1514,9 +1528,9 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
     const int slot = h->tBegin(KC_CG_UPDATE);
     hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                       h->coarse.modeActive.p, h->hPcg);
-    if (coarse) coarseApply(0);
+                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
+                       (coarse && unfusedY) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn);
+    if (coarse) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
     std::swap(pOld, pNew);

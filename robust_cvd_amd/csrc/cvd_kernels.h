@@ -887,7 +887,8 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nItems, RegCache rc, CoarseView V) {
+                                                       int distMode, int nItems, RegCache rc, CoarseView V,
+                                                       double* __restrict__ qc) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -982,12 +983,14 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     const double pv = pNew[base + i];
     const double qv = qf[i] * mask[base + i] + lam[base + i] * pv;
     q[base + i] = qv;
+    qf[i] = qv;
     dot += pv * qv;
   }
   dot = waveSum(dot);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
   if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
+  if (qc != nullptr) coarseRestrict(L, qf, f, tid, V.modeActive, qc);  // Z^T q for the fused y update (CoarseStep)
   // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
   if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
     const double pq = blockSumArray(fdot, L.F, red);
@@ -1001,11 +1004,13 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
 // p.q of the all-reduced product (multi-GPU only) + alpha, same last-workgroup pattern as k_matvec_finish.
 __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
-                                                double* __restrict__ fdot) {
+                                                double* __restrict__ fdot, double* __restrict__ qc,
+                                                const unsigned char* __restrict__ modeActive) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   __shared__ double red[8];
   const int f = blockIdx.x, tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * L.B;
+  if (qc != nullptr) coarseRestrict(L, q + base, f, tid, modeActive, qc);  // on the all-reduced q
   double dot = 0.0;
   for (int i = tid; i < L.B; i += 256) dot += p[base + i] * q[base + i];
   dot = waveSum(dot);
@@ -1067,7 +1072,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
                                                     double tol2, double* __restrict__ rc,
                                                     const unsigned char* __restrict__ modeActive,
-                                                    double* __restrict__ hostMirror) {
+                                                    double* __restrict__ hostMirror, CoarseStep cs) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
   const int B = L.B;
@@ -1075,6 +1080,8 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   double* rf = sm;                 // B
   double* part = rf + B;           // nThreads partial row sums
   double* red = part + nThreads;   // 2 * 16 wave partials + 10
+  double* ypart = red + 48;        // 16 waves x kCB partial sums of the fused y update + kCB squares
+  const bool fusedY = !init && cs.Wb != nullptr;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
@@ -1092,17 +1099,23 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
     rf[j] = rv;
   }
   __syncthreads();
-  if (rc != nullptr) {
-    // restriction to the coarse level: Z_f^T r_f (the 7 pose-like entries and the sum over the depth-scale vertices)
-    // (inactive modes are identity rows of the coarse matrix: they must not feed the coarse solve)
-    if (tid < 7) rc[f * kCB + tid] = modeActive[f * kCB + tid] ? rf[tid] : 0.0;
-    if (tid >= 64 && tid < 128) {
-      const int nV = (L.N >= 1 && L.depthType != kDepthIdentity) ? L.nD / L.N : 0;
-      double a = 0.0;
-      for (int v = tid - 64; v < nV; v += 64) a += rf[7 + v * L.N];
-      a = waveSum(a);
-      if (tid == 64) rc[f * kCB + 7] = modeActive[f * kCB + 7] ? a : 0.0;
+  if (rc != nullptr) coarseRestrict(L, rf, f, tid, modeActive, rc);  // Z_f^T r_f (first residual: k_coarse_apply_w)
+  if (fusedY) {
+    // row f of W (Z^T q): gathered from the columns of the frame's subtree, the waves share the list
+    const int wv = tid >> 6, lane = tid & 63, c8 = lane & 7, nWv = nThreads >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    const int e1 = cs.wtPtr[f + 1];
+    int e = cs.wtPtr[f] + wv;
+    for (; e + nWv < e1; e += 2 * nWv) {
+      a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
+      a1 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + nWv] * kCB + c8];
     }
+    if (e < e1) a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
+    double ya = a0 + a1;
+    ya += dppMove<0xB1>(ya);
+    ya += dppMove<0x4E>(ya);
+    ya += dppMove<0x141>(ya);
+    if (c8 == 0) ypart[wv * kCB + (lane >> 3)] = ya;
   }
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
   // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
@@ -1141,19 +1154,44 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
     fdotRZ[f] = a;
     fdotRR[f] = b;
   }
-  // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
-  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 40))) {
-    double a = 0.0, b = 0.0;
-    for (int k = tid; k < L.F; k += nThreads) { a += fdotRZ[k]; b += fdotRR[k]; }
-    a = waveSum(a);
-    b = waveSum(b);
-    __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; }
+  if (fusedY) {
+    // y_f <- y_f - alpha (W Z^T q)_f (ypart is complete: two barriers since it was written); |y_f|^2 is this
+    // frame's share of the coarse part of r^T z = |W Z^T r|^2
+    if (tid < kCB) {
+      double sy = 0.0;
+      for (int w = 0; w < nWaves; ++w) sy += ypart[w * kCB + tid];
+      const double yn = cs.y[f * kCB + tid] - alpha * sy;
+      cs.y[f * kCB + tid] = yn;
+      ypart[16 * kCB + tid] = yn * yn;
+    }
     __syncthreads();
     if (tid == 0) {
-      double rzs = 0.0, rrs = 0.0;
-      for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; }
-      if (rc != nullptr) {  // the coarse level adds its part of r^T z and finishes the scalars (k_coarse_apply)
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kCB; ++k) t += ypart[16 * kCB + k];
+      cs.fdotY[f] = t;
+    }
+  }
+  // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
+  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 40))) {
+    double a = 0.0, b = 0.0, cY = 0.0;
+    for (int k = tid; k < L.F; k += nThreads) {
+      a += fdotRZ[k];
+      b += fdotRR[k];
+      if (fusedY) cY += cs.fdotY[k];
+    }
+    a = waveSum(a);
+    b = waveSum(b);
+    cY = waveSum(cY);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; ypart[tid >> 6] = cY; }
+    __syncthreads();
+    if (tid == 0) {
+      double rzs = 0.0, rrs = 0.0, ys = 0.0;
+      for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; ys += ypart[w]; }
+      if (fusedY) {  // two-level r^T z; a broken-down coarse factorisation switches the level off (consumers use c = 0)
+        pcgFinishScalars(scal, 0, rzs + (*cs.fail == 0 ? ys : 0.0), rrs, tol2, hostMirror);
+      } else if (rc != nullptr) {  // first residual: k_coarse_apply_w adds its part of r^T z and finishes the scalars
         scal[S_RZPART] = rzs;
         scal[S_RR] = rrs;
       } else {
