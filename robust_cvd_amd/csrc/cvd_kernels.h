@@ -1103,15 +1103,17 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   if (fusedY) {
     // row f of W (Z^T q): gathered from the columns of the frame's subtree, the waves share the list
     const int wv = tid >> 6, lane = tid & 63, c8 = lane & 7, nWv = nThreads >> 6;
-    double a0 = 0.0, a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const int e1 = cs.wtPtr[f + 1];
     int e = cs.wtPtr[f] + wv;
-    for (; e + nWv < e1; e += 2 * nWv) {
+    for (; e + 3 * nWv < e1; e += 4 * nWv) {  // four independent gathers in flight per wave
       a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
       a1 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + nWv] * kCB + c8];
+      a2 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + 2 * nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + 2 * nWv] * kCB + c8];
+      a3 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + 3 * nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + 3 * nWv] * kCB + c8];
     }
-    if (e < e1) a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
-    double ya = a0 + a1;
+    for (; e < e1; e += nWv) a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
+    double ya = (a0 + a1) + (a2 + a3);
     ya += dppMove<0xB1>(ya);
     ya += dppMove<0x4E>(ya);
     ya += dppMove<0x141>(ya);
