@@ -1547,7 +1547,17 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   while (enq < maxIt) {
     if (enq >= kRunAhead - 1) {
       const int need = enq - kRunAhead + 1;
-      while (static_cast<int>(prog[0]) - 1 < need) {}
+      for (unsigned long long spins = 0; static_cast<int>(prog[0]) - 1 < need; ++spins) {
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+          // never spin forever on a mirror that cannot advance: a faulted stream reports here, and an idle stream
+          // whose iterations did not publish progress is a logic error
+          const hipError_t e = hipStreamQuery(s);
+          if (e != hipErrorNotReady) {
+            HIP_CHECK(e);
+            if (static_cast<int>(prog[0]) - 1 < need) throw std::runtime_error("PCG progress mirror stalled");
+          }
+        }
+      }
       if (prog[1 + (need & 7)] != 0.0) break;
     }
     enqueueIteration(enq, enq > 0 ? 1 : 0);
