@@ -270,6 +270,8 @@ struct cvd_handle_t {
   // multi-GPU (pair-sharded): one RCCL communicator, this rank owns the regularisers of frames f % world == rank
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  bool distForced = false;  // test hook (CVD_FORCE_DIST with a 1-rank communicator): run the multi-rank code path
+  bool dist() const { return world > 1 || distForced; }
   bool haveTriplets = false;
   // scene-flow smoothness triplets (cvd_triplets.h): groups keyed by the centre frame
   std::vector<int> tripCenter;
@@ -889,7 +891,7 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
                        h->dNdc.p, h->dDsrc.p, h->dCount.p);
     HIP_CHECK(hipGetLastError());
   }
-  if (h->world > 1) NCCL_CHECK(ncclAllReduce(h->dCount.p, h->dCount.p, 1, ncclUint64, ncclSum, h->comm, s));
+  if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dCount.p, h->dCount.p, 1, ncclUint64, ncclSum, h->comm, s));
   unsigned long long nv = 0;
   HIP_CHECK(hipMemcpyAsync(&nv, h->dCount.p, sizeof(nv), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -982,7 +984,7 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
   // The coarse level needs the frame graph of the whole problem.  One rank: the local items are the whole problem.
   // Several ranks: only with cvd_set_pair_graph (identical on all ranks); otherwise the level stays off.
   if (static_cast<size_t>(h->F) * kCB <= kCoarseMaxUnknowns &&
-      (h->world == 1 ? !h->itemFa.empty() : h->haveGlobalEdges)) {  // (rank-independent decision when sharded)
+      (!h->dist() ? !h->itemFa.empty() : h->haveGlobalEdges)) {  // (rank-independent decision when sharded)
     std::map<std::pair<int, int>, int> edgeId;
     std::vector<std::pair<int, int>> edgeList;
     if (h->haveGlobalEdges) {
@@ -1205,7 +1207,7 @@ static void enqueueCost(Ctx& c, const double* x) {
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
                      h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
   HIP_CHECK(hipGetLastError());
-  if (h->world > 1) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
+  if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
   h->tEnd(slot);
 }
 static double evalCost(Ctx& c, const double* x) {
@@ -1269,7 +1271,7 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
     HIP_CHECK(hipGetLastError());
   }
   h->tEnd(slot);
-  if (h->world > 1) {
+  if (h->dist()) {
     // the exchange step of the pair-sharded mode: one all-reduce of [g | H_ff | per-frame cost] per Jacobian evaluation
     NCCL_CHECK(ncclGroupStart());
     NCCL_CHECK(ncclAllReduce(h->dG.p, h->dG.p, c.n, ncclDouble, ncclSum, h->comm, s));
@@ -1385,11 +1387,11 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->world > 1 ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF,
-                         (withCoarse && h->world == 1) ? h->coarse.qc.p : nullptr);
+                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF,
+                         (withCoarse && !h->dist()) ? h->coarse.qc.p : nullptr);
     });
     HIP_CHECK(hipGetLastError());
-    if (h->world > 1) {
+    if (h->dist()) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
       NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
       hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
@@ -1448,7 +1450,7 @@ static void launchCoarseSetup(Ctx& c, const double* x) {
       });
     }
     HIP_CHECK(hipGetLastError());
-    if (h->world > 1)
+    if (h->dist())
       NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
   }
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
@@ -2240,6 +2242,8 @@ int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t*
     NCCL_CHECK(ncclCommInitRank(&h->comm, world, id, rank));
     h->rank = rank;
     h->world = world;
+    // test hook: with one rank the collectives are no-ops, but the sharded-mode kernels and call sequence still run
+    h->distForced = world == 1 && std::getenv("CVD_FORCE_DIST") != nullptr;
     h->tableValid = false;
   });
 }

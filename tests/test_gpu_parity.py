@@ -439,6 +439,40 @@ def test_rccl_communicator_world_size_one(Solver):
         s.pose_optimization_step(OptParams.defaults(), 0.1)
 
 
+def test_sharded_code_path_on_one_rank(Solver, monkeypatch):
+    """CVD_FORCE_DIST: a 1-rank communicator runs the pair-sharded mode's kernels and call sequence for real (partial q +
+    RCCL all-reduce + k_dot_pq, restriction from the reduced product, all-reduced coarse edge blocks, cost reduction);
+    the result must match the plain single-GPU solve."""
+    v = synth.make_video(8, 96, 56, seed=38)
+    trip = synth.make_triplets(v, spacing=20.0)
+    out = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("CVD_FORCE_DIST", "1")
+        s = Solver(0)
+        s.comm_init(0, 1, Solver.comm_unique_id())
+        synth.load_into(s, v)
+        s.set_triplet_constraints(*trip)
+        s.set_pair_graph(v.pairs)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        p.smooth_static_weight, p.smooth_dynamic_weight = 0.5, 0.25
+        s.normalize_depth(p)
+        ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+        s.pose_optimization(p)
+        out.append((ev, s.get_xform_params(), s.summary()))
+    monkeypatch.delenv("CVD_FORCE_DIST", raising=False)
+    a, b = out
+    assert abs(a[0]["cost"] - b[0]["cost"]) <= 1e-12 * abs(a[0]["cost"])
+    assert rel(b[0]["gradient"], a[0]["gradient"]) < 1e-12
+    assert rel(b[0]["hdiag"], a[0]["hdiag"]) < 1e-12
+    assert abs(a[2]["final_cost"] - b[2]["final_cost"]) <= 1e-6 * abs(a[2]["final_cost"])
+    assert rel(b[1], a[1]) < 1e-3
+    assert abs(a[2]["total_linear_iterations"] - b[2]["total_linear_iterations"]) <= 0.2 * a[2]["total_linear_iterations"] + 5
+
+
 def test_unsupported_configurations_fail_loudly(Solver):
     v = synth.make_video(4, 64, 40, seed=36, spacing=9)
     s = Solver(0)
