@@ -155,9 +155,15 @@ __host__ __device__ __forceinline__ void bilinearTaps(float lx, float ly, int gx
   idx[3] = i0 + gx + 1; w[3] = rx * ry;
 }
 
-// 2-D Catmull-Rom gather with out-of-range taps folded onto the clamped neighbour.
-__host__ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
-                                           double* w) {
+// 2-D Catmull-Rom gather with out-of-range taps folded onto the clamped neighbour, in separable form: the
+// tap (x, y), x < xs, y < ys, reads control point base + x + y * gx with weight fx[x] * fy[y].
+struct CubicSep {
+  int base, xs, ys;
+  double fx[4], fy[4];
+};
+
+__host__ __device__ __forceinline__ void bicubicSeparable(float lx, float ly, int gx, int gy, double mx, double my,
+                                                          CubicSep& s) {
   int ix, iy;
   double rx, ry;
   gridCell(lx, gx, mx, ix, rx);
@@ -169,27 +175,36 @@ __host__ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, 
   const int x1 = (ix == gx - 2 ? 3 : 4);
   const int y0 = (iy == 0 ? 1 : 0);
   const int y1 = (iy == gy - 2 ? 3 : 4);
-  const int xs = x1 - x0, ys = y1 - y0;
+  s.xs = x1 - x0;
+  s.ys = y1 - y0;
+  s.base = (ix - 1 + x0) + (iy - 1 + y0) * gx;
   // fold the 1-D weights first (the 2-D weights are separable products of the folded 1-D weights)
-  double fx[4] = {0.0, 0.0, 0.0, 0.0}, fy[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { s.fx[q] = 0.0; s.fy[q] = 0.0; }
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    int cx = x - x0; cx = cx < 0 ? 0 : (cx > xs - 1 ? xs - 1 : cx);
-    int cy = x - y0; cy = cy < 0 ? 0 : (cy > ys - 1 ? ys - 1 : cy);
+    int cx = x - x0; cx = cx < 0 ? 0 : (cx > s.xs - 1 ? s.xs - 1 : cx);
+    int cy = x - y0; cy = cy < 0 ? 0 : (cy > s.ys - 1 ? s.ys - 1 : cy);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q == cx) fx[q] += wx[x];
-      if (q == cy) fy[q] += wy[x];
+      if (q == cx) s.fx[q] += wx[x];
+      if (q == cy) s.fy[q] += wy[x];
     }
   }
+}
+
+__host__ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, int gy, double mx, double my, int* idx,
+                                           double* w) {
+  CubicSep s;
+  bicubicSeparable(lx, ly, gx, gy, mx, my, s);
   int n = 0;
 #pragma unroll
   for (int y = 0; y < 4; ++y) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      if (y < ys && x < xs) {
-        idx[n] = (ix - 1 + x0 + x) + (iy - 1 + y0 + y) * gx;
-        w[n] = fx[x] * fy[y];
+      if (y < s.ys && x < s.xs) {
+        idx[n] = s.base + x + y * gx;
+        w[n] = s.fx[x] * s.fy[y];
         ++n;
       }
     }

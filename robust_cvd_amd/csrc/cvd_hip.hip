@@ -292,6 +292,13 @@ struct cvd_handle_t {
   std::vector<int> itemFa, itemFb;
   std::vector<long long> itemRange;  // 4 per item
   DevBuf<int> dItemFa, dItemFb, dItemSlot, dFiOff, dFiList, dFpOff, dFpList;
+  // k_assemble_fast work list (AsmWork): parts sorted longest first, units, partial-block slots of split frames
+  DevBuf<AsmPart> dAsmParts;
+  DevBuf<int2> dAsmUnits;
+  DevBuf<double> dAsmScratch;
+  DevBuf<unsigned int> dAsmCount;
+  int nAsmParts = 0, nAsmSlots = 0;
+  int numCU = 256;
   DevBuf<long long> dItemRange;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
@@ -1046,6 +1053,53 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     h->dFtList.upload(ftList.data(), ftList.size(), s);
     h->dCostTrip.ensure(std::max<size_t>(nG, 1));
   }
+  {
+    // k_assemble_fast work list: units of <= kAsmUnit constraints, parts of <= capU units.  capU = the mean units
+    // per frame (or per CU when there are fewer frames than CUs), so a frame of average size stays whole and
+    // only the long-range hub frames of the hierarchical flow list are split.
+    std::vector<int2> units;
+    std::vector<int> fuOff(h->F + 1, 0);
+    for (int f = 0; f < h->F; ++f) {
+      for (const int code : framePairs[f]) {
+        const long long n = h->pairOff[(code >> 1) + 1] - h->pairOff[code >> 1];
+        for (long long o = 0; o < n; o += kAsmUnit) units.push_back(make_int2(code, static_cast<int>(o)));
+      }
+      fuOff[f + 1] = static_cast<int>(units.size());
+    }
+    int activeFrames = 0;
+    for (int f = 0; f < h->F; ++f) activeFrames += inRange[f] ? 1 : 0;
+    const long long denom = std::max<long long>(1, std::max(activeFrames, h->numCU));
+    const int capU = static_cast<int>(std::max<long long>(kAsmThreads / 64, (static_cast<long long>(units.size()) + denom - 1) / denom));
+    std::vector<AsmPart> parts;
+    int slots = 0;
+    for (int f = 0; f < h->F; ++f) {
+      // (frames outside the range have no entries: their part writes the zero block / gradient / cost)
+      const int nu = fuOff[f + 1] - fuOff[f];
+      const int np = std::max(1, (nu + capU - 1) / capU);
+      const int per = (nu + np - 1) / np;
+      for (int q = 0; q < np; ++q) {
+        AsmPart a;
+        a.frame = f;
+        a.u0 = fuOff[f] + std::min(nu, q * per);
+        a.u1 = fuOff[f] + std::min(nu, (q + 1) * per);
+        a.part = q;
+        a.nParts = np;
+        a.slot0 = np > 1 ? slots : 0;
+        parts.push_back(a);
+      }
+      if (np > 1) slots += np;
+    }
+    std::stable_sort(parts.begin(), parts.end(),
+                     [](const AsmPart& a, const AsmPart& b) { return a.u1 - a.u0 > b.u1 - b.u0; });
+    h->nAsmParts = static_cast<int>(parts.size());
+    h->nAsmSlots = slots;
+    h->dAsmParts.upload(parts.data(), parts.size(), s);
+    h->dAsmUnits.upload(units.data(), units.size(), s);
+    if (h->dAsmCount.n < static_cast<size_t>(h->F)) {
+      h->dAsmCount.ensure(h->F);
+      HIP_CHECK(hipMemsetAsync(h->dAsmCount.p, 0, sizeof(unsigned int) * h->F, s));
+    }
+  }
   h->dFiOff.upload(fiOff.data(), fiOff.size(), s);
   h->dFiList.upload(fiList.data(), fiList.size(), s);
   h->dFpOff.upload(fpOff.data(), fpOff.size(), s);
@@ -1233,19 +1287,18 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   launchFrameConsts(c, x);
   const size_t B = c.L.B;
   const int slot = h->tBegin(KC_ASSEMBLE);
-  const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+  const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;
   const size_t ldsFast = (B * (B + 1) / 2 + 2 * B + 4 * 36) * 8;
   const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
-  if (fast && c.KD == 4) {
-    allowLds(k_assemble_fast<4>, ldsFast);
-    hipLaunchKernelGGL((k_assemble_fast<4>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
-                       h->dFocal.p, h->dFocal.p + c.L.F);
-  } else if (fast) {
-    allowLds(k_assemble_fast<1>, ldsFast);
-    hipLaunchKernelGGL((k_assemble_fast<1>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
-                       h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
-                       h->dFocal.p, h->dFocal.p + c.L.F);
+  if (fast) {
+    h->dAsmScratch.ensure(static_cast<size_t>(h->nAsmSlots) * (B * (B + 1) / 2 + B + 4));
+    const AsmWork work{h->dAsmParts.p, h->dAsmUnits.p, h->dAsmScratch.p, h->dAsmCount.p};
+    CVD_DISPATCH_KD(c.KD, {
+      allowLds(k_assemble_fast<KD>, ldsFast);
+      hipLaunchKernelGGL((k_assemble_fast<KD>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                         h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
+                         h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+    });
   } else {
     CVD_DISPATCH(c.KD, c.KS, {
       allowLds(k_assemble<KD, KS>, lds);
@@ -1337,27 +1390,21 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
-    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN && (c.KD == 1 || c.KD == 4);
+    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;
     // (plain launches unless the launch is timed: hipExtLaunchKernelGGL is not used inside a graph capture)
     const FrameConst* fcp = h->dFc.p;
     const double* maskp = h->dMask.p;
     const double* scalp = h->dScal.p;
-    if (fast && c.KD == 4) {
-      allowLds(k_matvec_pairs_fast<4>, ldsFast);
-      if (evStart)
-        hipExtLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
-                              c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-      else
-        hipLaunchKernelGGL((k_matvec_pairs_fast<4>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp, maskp,
-                           z, pOld, scalp, useBeta, h->dQPart.p, cF);
-    } else if (fast) {
-      allowLds(k_matvec_pairs_fast<1>, ldsFast);
-      if (evStart)
-        hipExtLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
-                              c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-      else
-        hipLaunchKernelGGL((k_matvec_pairs_fast<1>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp, maskp,
-                           z, pOld, scalp, useBeta, h->dQPart.p, cF);
+    if (fast) {
+      CVD_DISPATCH_KD(c.KD, {
+        allowLds(k_matvec_pairs_fast<KD>, ldsFast);
+        if (evStart)
+          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
+                                c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+        else
+          hipLaunchKernelGGL((k_matvec_pairs_fast<KD>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp,
+                             maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+      });
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_matvec_pairs<KD, KS>, lds);
@@ -2171,6 +2218,7 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipSetDevice(device));
     auto* h = new cvd_handle_t();
     h->device = device;
+    HIP_CHECK(hipDeviceGetAttribute(&h->numCU, hipDeviceAttributeMultiprocessorCount, device));
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     cvd_solver_options_default(&h->opt);
     return h;
@@ -2247,6 +2295,12 @@ int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t*
     h->tableValid = false;
   });
 }
+#ifdef CVD_ASM_PROFILE
+int32_t cvd_debug_asm_profile(unsigned long long* out) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cvd::g_asmProf), sizeof(unsigned long long) * 2048 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled) { CVD_TRY(h, h->forceGeneric = enabled != 0); }
 
 int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t height, float aspect, float invAspect) {

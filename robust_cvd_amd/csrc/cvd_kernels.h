@@ -39,6 +39,25 @@ struct Items {
   int count;
 };
 
+// Work list of k_assemble_fast: a frame's (pair, side) entries are cut into units of at most kAsmUnit constraints
+// and the units into parts (one workgroup each) of bounded size, so that frames with many pairs (the long-range
+// levels of the hierarchical flow list) do not set the kernel's duration.  Parts of a split frame publish their
+// packed partial blocks and the last one to arrive folds them (lastBlockArrives on a per-frame counter).
+constexpr int kAsmUnit = 128;
+struct AsmPart {
+  int frame;
+  int u0, u1;   // unit range
+  int part;     // index within the frame
+  int nParts;   // 1: the frame is not split
+  int slot0;    // first partial-block slot of the frame (split frames only)
+};
+struct AsmWork {
+  const AsmPart* parts;      // sorted by descending size (longest first)
+  const int2* units;         // {pair * 2 + side, first constraint relative to the pair's offset}
+  double* scratch;           // partial blocks: slots x (B(B+1)/2 + B + 2) doubles
+  unsigned int* counters;    // one per frame, zero between launches
+};
+
 // scalar slots kept on the device during PCG
 enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5, S_RZ0 = 6, S_COST = 7,
              S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14,
@@ -1298,11 +1317,28 @@ template <int KD>
 struct FastTaps {
   int idx[KD];
   double w[KD];
+  __device__ __forceinline__ bool ok(int) const { return true; }
+  __device__ __forceinline__ int I(int k) const { return idx[k]; }
+  __device__ __forceinline__ double Wt(int k) const { return w[k]; }
+};
+
+// bicubic: the 16 taps stay in separable form (8 weights + 3 ints instead of 16 + 16 registers); tap k = (k & 3, k >> 2)
+// exists when it lies inside the folded xs x ys footprint, in the same row-major order as bicubicTaps enumerates.
+template <>
+struct FastTaps<16> {
+  CubicSep s;
+  int gx;
+  __device__ __forceinline__ bool ok(int k) const { return (k & 3) < s.xs && (k >> 2) < s.ys; }
+  __device__ __forceinline__ int I(int k) const { return s.base + (k & 3) + (k >> 2) * gx; }
+  __device__ __forceinline__ double Wt(int k) const { return s.fx[k & 3] * s.fy[k >> 2]; }
 };
 
 template <int KD>
 __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, FastTaps<KD>& t) {
-  if constexpr (KD == 4) {
+  if constexpr (KD == 16) {
+    bicubicSeparable(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.s);
+    t.gx = L.gx;
+  } else if constexpr (KD == 4) {
     bilinearTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.idx, t.w);
   } else {
     t.idx[0] = 0;
@@ -1432,16 +1468,27 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
       Da = 0.0; Db = 0.0; sDa = 0.0; sDb = 0.0;
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
-        if (N == 2) {
-          Da += (da * xa[7 + ta.idx[k] * 2] + xa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
-          Db += (db * xb[7 + tb.idx[k] * 2] + xb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
-          sDa += (da * pa[7 + ta.idx[k] * 2] + pa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
-          sDb += (db * pb[7 + tb.idx[k] * 2] + pb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
-        } else {
-          Da += da * xa[7 + ta.idx[k]] * ta.w[k];
-          Db += db * xb[7 + tb.idx[k]] * tb.w[k];
-          sDa += da * pa[7 + ta.idx[k]] * ta.w[k];
-          sDb += db * pb[7 + tb.idx[k]] * tb.w[k];
+        if (ta.ok(k)) {
+          const int ia = ta.I(k);
+          const double wa = ta.Wt(k);
+          if (N == 2) {
+            Da += (da * xa[7 + ia * 2] + xa[7 + ia * 2 + 1]) * wa;
+            sDa += (da * pa[7 + ia * 2] + pa[7 + ia * 2 + 1]) * wa;
+          } else {
+            Da += da * xa[7 + ia] * wa;
+            sDa += da * pa[7 + ia] * wa;
+          }
+        }
+        if (tb.ok(k)) {
+          const int ib = tb.I(k);
+          const double wb = tb.Wt(k);
+          if (N == 2) {
+            Db += (db * xb[7 + ib * 2] + xb[7 + ib * 2 + 1]) * wb;
+            sDb += (db * pb[7 + ib * 2] + pb[7 + ib * 2 + 1]) * wb;
+          } else {
+            Db += db * xb[7 + ib] * wb;
+            sDb += db * pb[7 + ib] * wb;
+          }
         }
       }
     }
@@ -1530,14 +1577,25 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
       } else {
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
-        if (N == 2) {
-          atomicAdd(&qa[7 + ta.idx[k] * 2], ga * ta.w[k] * da);
-          atomicAdd(&qa[7 + ta.idx[k] * 2 + 1], ga * ta.w[k]);
-          atomicAdd(&qb[7 + tb.idx[k] * 2], gb * tb.w[k] * db);
-          atomicAdd(&qb[7 + tb.idx[k] * 2 + 1], gb * tb.w[k]);
-        } else {
-          atomicAdd(&qa[7 + ta.idx[k]], ga * ta.w[k] * da);
-          atomicAdd(&qb[7 + tb.idx[k]], gb * tb.w[k] * db);
+        if (ta.ok(k)) {
+          const int ia = ta.I(k);
+          const double wa = ta.Wt(k);
+          if (N == 2) {
+            atomicAdd(&qa[7 + ia * 2], ga * wa * da);
+            atomicAdd(&qa[7 + ia * 2 + 1], ga * wa);
+          } else {
+            atomicAdd(&qa[7 + ia], ga * wa * da);
+          }
+        }
+        if (tb.ok(k)) {
+          const int ib = tb.I(k);
+          const double wb = tb.Wt(k);
+          if (N == 2) {
+            atomicAdd(&qb[7 + ib * 2], gb * wb * db);
+            atomicAdd(&qb[7 + ib * 2 + 1], gb * wb);
+          } else {
+            atomicAdd(&qb[7 + ib], gb * wb * db);
+          }
         }
       }
       }
@@ -1631,13 +1689,19 @@ namespace cvd {
 // =====================================================================================================
 constexpr int kAsmThreads = 512;  // 8 waves per frame: two per SIMD at 256 VGPRs
 
+#ifdef CVD_ASM_PROFILE
+__device__ unsigned long long g_asmProf[2048 * 16];
+#define ASM_STAMP(slot) do { if (lane == 0) g_asmProf[(blockIdx.x & 2047) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define ASM_STAMP(slot) do {} while (0)
+#endif
 template <int KD>
 __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ regOwner,
                                                        const unsigned char* __restrict__ rangeFlags,
-                                                       const int* __restrict__ fpOff, const int* __restrict__ fpList,
+                                                       AsmWork work,
                                                        double* __restrict__ gOut, double* __restrict__ hOut,
                                                        double* __restrict__ costFrame, double* __restrict__ focalG,
                                                        double* __restrict__ focalH) {
@@ -1652,12 +1716,14 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
   double* gs = Hs + npk;
   double* xf = gs + B;
   double* red = xf + B;  // 36 workgroup sums (LDS atomics, one set per wave) + scratch
-  const int f = blockIdx.x;
+  const AsmPart me = work.parts[blockIdx.x];
+  const int f = me.frame;
   const int tid = threadIdx.x;
   constexpr int NT = kAsmThreads;
   // wave-uniform wave index (scalar register: the per-entry frame constants below become scalar loads)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+  if (tid == 0) ASM_STAMP(0);
   for (int i = tid; i < npk; i += NT) Hs[i] = 0.0;
   if (tid < 48) red[tid] = 0.0;
   for (int i = tid; i < B; i += NT) {
@@ -1665,6 +1731,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
     xf[i] = x[static_cast<size_t>(f) * B + i];
   }
   __syncthreads();
+  if (tid == 0) ASM_STAMP(1);
 
   double PP[28], gp[7];
   // KD == 1 (Global / Identity): the single depth block is hit by every sample -> register accumulators
@@ -1682,10 +1749,11 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
   const double A = L.aspect;
 
   if (L.includeStatic) {
-    // one (pair, side) entry per WAVE at a time: the waves run through their entries independently (no barrier
-    // until the end), 64 lanes over the pair's constraints
-    for (int e = fpOff[f] + wv; e < fpOff[f + 1]; e += NT / 64) {
-      const int code = fpList[e];
+    // one unit (slice of a (pair, side) entry) per WAVE at a time: the waves run through their units independently
+    // (no barrier until the end), 64 lanes over the slice's constraints
+    for (int u = me.u0 + wv; u < me.u1; u += NT / 64) {
+      const int2 unit = work.units[u];
+      const int code = __builtin_amdgcn_readfirstlane(unit.x);
       const int p = code >> 1;
       const int side = code & 1;  // 0: f is the source of pair p, 1: f is the target
       const int o = side ? T.pairA[p] : T.pairB[p];
@@ -1697,7 +1765,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
       const double fya = Fa.fy, fxa = Fa.fy * A;
       const double fyb = Fb.fy;
       const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
-      for (long long c = T.pairOff[p] + lane; c < T.pairOff[p + 1]; c += 64) {
+      const long long cBegin = T.pairOff[p] + __builtin_amdgcn_readfirstlane(unit.y);
+      const long long cEnd = cBegin + kAsmUnit < T.pairOff[p + 1] ? cBegin + kAsmUnit : T.pairOff[p + 1];
+      for (long long c = cBegin + lane; c < cEnd; c += 64) {
         const float2 d = T.dsrc[c];
         if (!(d.x > 0.f)) continue;
         const float4 nd = T.ndc[c];
@@ -1712,12 +1782,15 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
           Da = 0.0; Db = 0.0;
 #pragma unroll
           for (int k = 0; k < KD; ++k) {
-            if (N == 2) {
-              Da += (da * xa[7 + ta.idx[k] * 2] + xa[7 + ta.idx[k] * 2 + 1]) * ta.w[k];
-              Db += (db * xb[7 + tb.idx[k] * 2] + xb[7 + tb.idx[k] * 2 + 1]) * tb.w[k];
-            } else {
-              Da += da * xa[7 + ta.idx[k]] * ta.w[k];
-              Db += db * xb[7 + tb.idx[k]] * tb.w[k];
+            if (ta.ok(k)) {
+              const int ia = ta.I(k);
+              if (N == 2) Da += (da * xa[7 + ia * 2] + xa[7 + ia * 2 + 1]) * ta.Wt(k);
+              else Da += da * xa[7 + ia] * ta.Wt(k);
+            }
+            if (tb.ok(k)) {
+              const int ib = tb.I(k);
+              if (N == 2) Db += (db * xb[7 + ib * 2] + xb[7 + ib * 2 + 1]) * tb.Wt(k);
+              else Db += db * xb[7 + ib] * tb.Wt(k);
             }
           }
         }
@@ -1852,16 +1925,49 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
           for (int i = 0; i < 7; ++i) v7[i] = w * (Jp[0][i] * JD[0] + Jp[1][i] * JD[1] + Jp[2][i] * JD[2]);
           const double sDD = w * (JD[0] * JD[0] + JD[1] * JD[1] + JD[2] * JD[2]);
           const double sDr = w * (JD[0] * r[0] + JD[1] * r[1] + JD[2] * r[2]);
+          if constexpr (KD == 16) {
+            // bicubic: column factors come straight from the separable weights, taps outside the folded
+            // footprint are skipped (d/d theta_k[0] = w_k d, d/d theta_k[1] = w_k)
+#pragma unroll
+            for (int ka = 0; ka < 16; ++ka) {
+              if (!tm.ok(ka)) continue;
+              const double wa = tm.Wt(ka);
+              const int ia = tm.I(ka);
+#pragma unroll
+              for (int na = 0; na < 2; ++na) {
+                if (na >= N) continue;
+                const int ct = 7 + ia * N + na;
+                const double fa = (N == 2 && na == 1) ? wa : wa * dm;
+                const int rowBase = ct * (ct + 1) / 2;
+                atomicAdd(&gs[ct], sDr * fa);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) atomicAdd(&Hs[rowBase + i], v7[i] * fa);
+#pragma unroll
+                for (int kb = 0; kb <= ka; ++kb) {
+                  if (!tm.ok(kb)) continue;
+                  const double wb = tm.Wt(kb);
+                  const int ib = tm.I(kb);
+#pragma unroll
+                  for (int nb = 0; nb < 2; ++nb) {
+                    if (nb >= N || (kb == ka && nb > na)) continue;
+                    const int c2 = 7 + ib * N + nb;
+                    const double fb = (N == 2 && nb == 1) ? wb : wb * dm;
+                    atomicAdd(&Hs[rowBase + c2], sDD * fa * fb);  // tap order is index order: c2 <= ct
+                  }
+                }
+              }
+            }
+          } else {
           // tap column factors: value params (d/d theta_k[0] = w_k d, d/d theta_k[1] = w_k)
           double fac[KD * 2];
           int col[KD * 2];
 #pragma unroll
           for (int k = 0; k < KD; ++k) {
             if (N == 2) {
-              col[2 * k] = 7 + tm.idx[k] * 2;     fac[2 * k] = tm.w[k] * dm;
-              col[2 * k + 1] = col[2 * k] + 1;    fac[2 * k + 1] = tm.w[k];
+              col[2 * k] = 7 + tm.I(k) * 2;       fac[2 * k] = tm.Wt(k) * dm;
+              col[2 * k + 1] = col[2 * k] + 1;    fac[2 * k + 1] = tm.Wt(k);
             } else {
-              col[k] = 7 + tm.idx[k];             fac[k] = tm.w[k] * dm;
+              col[k] = 7 + tm.I(k);               fac[k] = tm.Wt(k) * dm;
             }
           }
           const int nt = (N == 2) ? 2 * KD : KD;
@@ -1896,11 +2002,14 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
             }
           }
           }
+          }
         }
       }
     }
   }
+  ASM_STAMP(4 + wv);  // each wave's end of the constraint loop
   __syncthreads();
+  if (tid == 0) ASM_STAMP(2);
   {
 #pragma unroll
     for (int i = 0; i < 28; ++i) PP[i] = waveSum(PP[i]);
@@ -1942,6 +2051,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
   __syncthreads();
   const double staticCost = 0.5 * red[35];
   __syncthreads();
+  if (tid == 0) ASM_STAMP(13);
   if (L.intrOpt == kIntrShared) {
     // The focal column of every constraint belongs to frame 0's slot: publish this frame's static focal
     // gradient / diagonal for k_shared_focal_fixup and drop the entries from the frame's own block (for f != 0
@@ -1953,8 +2063,10 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
     if (tid == 0) {
       double sg = 0.0, sh = 0.0;
       for (int w = 0; w < NT / 64; ++w) { sg += red[w]; sh += red[16 + w]; }
-      focalG[f] = sg;
+      focalG[f] = sg;  // (a split frame: overwritten with the sum over the parts below)
       focalH[f] = sh;
+      red[42] = sg;
+      red[43] = sh;
       gs[6] = 0.0;
       Hs[packedIdx(6, 6)] = 0.0;
     }
@@ -1965,8 +2077,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
     __syncthreads();
   }
 
+  if (tid == 0) ASM_STAMP(14);
   double regCost = 0.0;
-  if (regOwner[f]) {
+  if (regOwner[f] && me.part == 0) {
     const int nr = numRegResiduals<KD>(L);
     for (int i = tid; i < nr; i += NT) {
       double r;
@@ -1985,7 +2098,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
       }
     }
   }
-  if (tid == 0 && L.positionRegSqrt > 0.0) {
+  if (tid == 0 && L.positionRegSqrt > 0.0 && me.part == 0) {
     double o3[3] = {0, 0, 0}, dg = 0.0, cst = 0.0;
     posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
     for (int i = 0; i < 3; ++i) {
@@ -1996,14 +2109,45 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
   }
   regCost = waveSum(regCost);
   __syncthreads();
+  if (tid == 0) ASM_STAMP(15);
   if (lane == 0) red[wv] = regCost;
   __syncthreads();
   if (tid == 0) {
     double rc = 0.0;
     for (int w = 0; w < NT / 64; ++w) rc += red[w];
-    costFrame[f] = staticCost + 0.5 * rc;
+    if (me.nParts == 1) costFrame[f] = staticCost + 0.5 * rc;
+    red[40] = staticCost + 0.5 * rc;
+  }
+  if (me.nParts > 1) {
+    // split frame: publish this part's packed block / gradient / cost; the last part to arrive folds the others in
+    __syncthreads();
+    const size_t stride = static_cast<size_t>(npk) + B + 4;
+    double* mine = work.scratch + static_cast<size_t>(me.slot0 + me.part) * stride;
+    for (int i = tid; i < npk; i += NT) mine[i] = Hs[i];
+    for (int i = tid; i < B; i += NT) mine[npk + i] = gs[i];
+    if (tid == 0) {
+      mine[npk + B] = red[40];
+      if (L.intrOpt == kIntrShared) { mine[npk + B + 1] = red[42]; mine[npk + B + 2] = red[43]; }
+    }
+    if (!lastBlockArrives(work.counters + f, static_cast<unsigned int>(me.nParts), reinterpret_cast<int*>(red + 41))) return;
+    double costSum = red[40];
+    double sgSum = red[42], shSum = red[43];
+    for (int q = 0; q < me.nParts; ++q) {
+      if (q == me.part) continue;
+      const double* other = work.scratch + static_cast<size_t>(me.slot0 + q) * stride;
+      for (int i = tid; i < npk; i += NT) Hs[i] += other[i];
+      for (int i = tid; i < B; i += NT) gs[i] += other[npk + i];
+      costSum += other[npk + B];
+      if (L.intrOpt == kIntrShared) { sgSum += other[npk + B + 1]; shSum += other[npk + B + 2]; }
+    }
+    if (tid == 0) {
+      costFrame[f] = costSum;
+      if (L.intrOpt == kIntrShared) { focalG[f] = sgSum; focalH[f] = shSum; }
+    }
+    __syncthreads();
   }
 
+  if (tid == 0) ASM_STAMP(3);
   const double* mf = mask + static_cast<size_t>(f) * B;
   for (int i = tid; i < B; i += NT) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
   double* hf = hOut + static_cast<size_t>(f) * B * B;
@@ -2012,6 +2156,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
   }
+  if (tid == 0) ASM_STAMP(12);
 }
 
 }  // namespace cvd

@@ -81,6 +81,9 @@ def test_matrix_free_product_matches_oracle_hessian(Solver):
 def test_fast_and_generic_product_kernels_agree(Solver):
     """k_matvec_pairs_fast (default pipeline) vs the generic all-variants kernel on the same inputs."""
     for ddesc, loss in ((XformDesc.grid_depth(5, 4), StaticLossType.ReproDisparity),
+                        (XformDesc.grid_depth(4, 4, cubic=True), StaticLossType.ReproDisparity),
+                        (XformDesc.grid_depth(6, 5, ValueXformType.ScaleShift, cubic=True), StaticLossType.ReproDepthRatio),
+                        (XformDesc.grid_depth(3, 2, cubic=True), StaticLossType.ReproLogDepth),
                         (XformDesc.global_depth(ValueXformType.ScaleShift), StaticLossType.ReproDepthRatio),
                         (XformDesc.global_depth(), StaticLossType.ReproLogDepth),
                         (XformDesc.identity_depth(), StaticLossType.ReproDisparity)):
@@ -100,10 +103,14 @@ def test_fast_and_generic_product_kernels_agree(Solver):
             s.set_xform_params(dx)
         p = OptParams.defaults()
         p.static_loss_type = loss
-        fast = s.evaluate(p, 0.1, pose, want_hfull=True)["hfull"]
+        fast = s.evaluate(p, 0.1, pose, want_hdiag=True, want_hfull=True)
         s.set_generic_kernels(True)
-        gen = s.evaluate(p, 0.1, pose, want_hfull=True)["hfull"]
-        assert rel(fast, gen) < 1e-12
+        gen = s.evaluate(p, 0.1, pose, want_hdiag=True, want_hfull=True)
+        assert rel(fast["hfull"], gen["hfull"]) < 1e-12
+        # k_assemble_fast vs k_assemble: cost, gradient and the diagonal blocks
+        assert abs(fast["cost"] - gen["cost"]) <= 1e-12 * abs(gen["cost"])
+        assert rel(fast["gradient"], gen["gradient"]) < 1e-12
+        assert rel(fast["hdiag"], gen["hdiag"]) < 1e-12
 
 
 def test_empty_and_ragged_inputs(Solver):
