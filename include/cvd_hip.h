@@ -143,6 +143,19 @@ int32_t cvd_sample_triplet_constraints(cvd_handle* h, int32_t num_triplets, cons
                                        int32_t match_separation, float min_dynamic_distance, int64_t* offsets);
 int32_t cvd_get_sampled_triplet_constraints(cvd_handle* h, float* loc6);
 
+/* ---- image operators in front of the sampler: the two OpenCV calls of
+ * FlowConstraintsCollection::compute.  Batches of num_images images of height x width, host buffers in and out
+ * (out may be NULL: compute only), kernel_ms (may be NULL) = kernel time from HIP events. */
+/* cvtColor(BGR2GRAY) + cornerMinEigenVal(gray, blockSize 3, Sobel aperture 3, BORDER_DEFAULT) of float BGR images
+ * (reference lib/FlowConstraints.cpp:417-423): bgr [n][H][W][3] -> out [n][H][W], the `corner` input of the samplers. */
+int32_t cvd_corner_min_eigenval(cvd_handle* h, int32_t num_images, int32_t height, int32_t width, const float* bgr,
+                                float* out, double* kernel_ms);
+/* FlowConstraintsCollection::dynamicDistance (reference lib/FlowConstraints.cpp:257-286): binarise the dynamic mask
+ * (< 127 -> 0) and distanceTransform(DIST_L2, DIST_MASK_5) = 5x5 chamfer distance to the nearest zero pixel:
+ * mask [n][H][W] u8 -> out [n][H][W] f32, the `dyn_dist` input of the samplers. */
+int32_t cvd_dynamic_distance(cvd_handle* h, int32_t num_images, int32_t height, int32_t width, const uint8_t* mask,
+                             float* out, double* kernel_ms);
+
 /* ---- dense consumers of the result: what loaders/video_dataset.py reads after every optimisation --
  * All frames [first_frame, first_frame + num_frames) in one launch, current transform parameters of the handle, host
  * buffer out (may be NULL: compute only).  kernel_ms (may be NULL) receives the kernel time (HIP events).

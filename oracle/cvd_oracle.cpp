@@ -2377,4 +2377,122 @@ int cvdo_deformation_cost(const cvd_xform_desc* d, const double* params, double*
   }
 }
 
+// ---- image operators in front of the sampler -------------------------------------------------
+// The reference calls OpenCV here (lib/FlowConstraints.cpp:417-423 cvtColor + cornerMinEigenVal, :257-286
+// distanceTransform).  OpenCV is not part of /root/reference and not installed: the functions below restate its
+// published algorithms (imgproc corner.cpp: Sobel with the 1/(2^(aperture-1) blockSize) scale on the smoothing taps,
+// cov = (dx^2, dx dy, dy^2), unnormalised box filter, calcMinEigenVal; distransform.cpp: two-pass 5x5 chamfer in 16-bit
+// fixed point with weights 1, 1.4, 2.1969), BORDER_REFLECT_101.  Parity with an OpenCV build is unpinned.
+static int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+int cvdo_corner_min_eigenval(void* h, int numImages, int height, int width, const float* bgr, float* out,
+                             double* /*kernelMs*/) {
+  CVDO_TRY(h, {
+    const int w = width, hh = height;
+    const size_t px = static_cast<size_t>(w) * hh;
+    const float k0 = static_cast<float>(1.0 / 12.0), k1 = static_cast<float>(2.0 / 12.0);
+    std::vector<float> gray(px), rowDiff(px), rowSmooth(px), cov(px * 3), rowSum(px * 3);
+    for (int n = 0; n < numImages; ++n) {
+      const float* im = bgr + static_cast<size_t>(n) * px * 3;
+      for (size_t i = 0; i < px; ++i) gray[i] = (im[i * 3] * 0.114f + im[i * 3 + 1] * 0.587f) + im[i * 3 + 2] * 0.299f;
+      // separable Sobel: row pass (difference / scaled smoothing), then column pass
+      for (int y = 0; y < hh; ++y)
+        for (int x = 0; x < w; ++x) {
+          const float l = gray[static_cast<size_t>(y) * w + reflect101(x - 1, w)];
+          const float r = gray[static_cast<size_t>(y) * w + reflect101(x + 1, w)];
+          const float c = gray[static_cast<size_t>(y) * w + x];
+          rowDiff[static_cast<size_t>(y) * w + x] = r - l;
+          rowSmooth[static_cast<size_t>(y) * w + x] = c * k1 + (l + r) * k0;
+        }
+      for (int y = 0; y < hh; ++y)
+        for (int x = 0; x < w; ++x) {
+          const size_t up = static_cast<size_t>(reflect101(y - 1, hh)) * w + x;
+          const size_t dn = static_cast<size_t>(reflect101(y + 1, hh)) * w + x;
+          const size_t at = static_cast<size_t>(y) * w + x;
+          const float dx = rowDiff[at] * k1 + (rowDiff[up] + rowDiff[dn]) * k0;
+          const float dy = rowSmooth[dn] - rowSmooth[up];
+          cov[at * 3] = dx * dx;
+          cov[at * 3 + 1] = dx * dy;
+          cov[at * 3 + 2] = dy * dy;
+        }
+      // boxFilter 3x3, normalize = false: row sums, then column sums
+      for (int y = 0; y < hh; ++y)
+        for (int x = 0; x < w; ++x)
+          for (int k = 0; k < 3; ++k) {
+            const float* row = cov.data() + static_cast<size_t>(y) * w * 3;
+            rowSum[(static_cast<size_t>(y) * w + x) * 3 + k] =
+                (row[reflect101(x - 1, w) * 3 + k] + row[x * 3 + k]) + row[reflect101(x + 1, w) * 3 + k];
+          }
+      for (int y = 0; y < hh; ++y)
+        for (int x = 0; x < w; ++x) {
+          float sum[3];
+          for (int k = 0; k < 3; ++k)
+            sum[k] = (rowSum[(static_cast<size_t>(reflect101(y - 1, hh)) * w + x) * 3 + k] +
+                      rowSum[(static_cast<size_t>(y) * w + x) * 3 + k]) +
+                     rowSum[(static_cast<size_t>(reflect101(y + 1, hh)) * w + x) * 3 + k];
+          const float a = sum[0] * 0.5f, b = sum[1], c = sum[2] * 0.5f;
+          const float d = a - c;
+          out[static_cast<size_t>(n) * px + static_cast<size_t>(y) * w + x] = (a + c) - std::sqrt(d * d + b * b);
+        }
+    }
+  });
+}
+int cvdo_dynamic_distance(void* h, int numImages, int height, int width, const uint8_t* mask, float* out,
+                          double* /*kernelMs*/) {
+  CVDO_TRY(h, {
+    const int w = width, hh = height;
+    const unsigned int DIST_MAX = 0x7fffffffu >> 2;
+    const unsigned int HV = static_cast<unsigned int>(std::lround(1.0f * 65536.0));
+    const unsigned int DIAG = static_cast<unsigned int>(std::lround(static_cast<double>(1.4f) * 65536.0));
+    const unsigned int LONG = static_cast<unsigned int>(std::lround(static_cast<double>(2.1969f) * 65536.0));
+    const float scale = 1.f / 65536.f;
+    const int step = w + 4;
+    std::vector<unsigned int> temp(static_cast<size_t>(step) * (hh + 4));
+    for (int n = 0; n < numImages; ++n) {
+      const uint8_t* src = mask + static_cast<size_t>(n) * w * hh;
+      float* dst = out + static_cast<size_t>(n) * w * hh;
+      std::fill(temp.begin(), temp.end(), DIST_MAX);
+      for (int i = 0; i < hh; ++i) {  // forward pass
+        unsigned int* tmp = temp.data() + static_cast<size_t>(i + 2) * step + 2;
+        for (int j = 0; j < w; ++j) {
+          if (src[static_cast<size_t>(i) * w + j] < 127) {  // reference binarisation (:271): < 127 -> 0
+            tmp[j] = 0;
+          } else {
+            unsigned int t0 = tmp[j - step * 2 - 1] + LONG;
+            unsigned int t = tmp[j - step * 2 + 1] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j - step - 2] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j - step - 1] + DIAG; if (t0 > t) t0 = t;
+            t = tmp[j - step] + HV; if (t0 > t) t0 = t;
+            t = tmp[j - step + 1] + DIAG; if (t0 > t) t0 = t;
+            t = tmp[j - step + 2] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j - 1] + HV; if (t0 > t) t0 = t;
+            tmp[j] = t0;
+          }
+        }
+      }
+      for (int i = hh - 1; i >= 0; --i) {  // backward pass
+        unsigned int* tmp = temp.data() + static_cast<size_t>(i + 2) * step + 2;
+        for (int j = w - 1; j >= 0; --j) {
+          unsigned int t0 = tmp[j];
+          if (t0 > HV) {
+            unsigned int t = tmp[j + step * 2 + 1] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j + step * 2 - 1] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j + step + 2] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j + step + 1] + DIAG; if (t0 > t) t0 = t;
+            t = tmp[j + step] + HV; if (t0 > t) t0 = t;
+            t = tmp[j + step - 1] + DIAG; if (t0 > t) t0 = t;
+            t = tmp[j + step - 2] + LONG; if (t0 > t) t0 = t;
+            t = tmp[j + 1] + HV; if (t0 > t) t0 = t;
+            tmp[j] = t0;
+          }
+          dst[static_cast<size_t>(i) * w + j] = static_cast<float>(t0) * scale;
+        }
+      }
+    }
+  });
+}
+
 }  // extern "C"

@@ -250,6 +250,29 @@ class Binding:
             self._check(self._fn("get_sampled_triplet_constraints")(self._h, _ptr(loc, C.c_float)))
         return off, loc
 
+    # -- image operators in front of the sampler ---------------------------------------
+    def corner_min_eigenval(self, bgr, timing=False):
+        """cvtColor(BGR2GRAY) + cornerMinEigenVal(blockSize 3) of float BGR images [n, H, W, 3] -> [n, H, W] float32."""
+        im = _f32(bgr)
+        assert im.ndim == 4 and im.shape[3] == 3, im.shape
+        n, hh, w = im.shape[:3]
+        out = np.zeros((n, hh, w), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._fn("corner_min_eigenval")(self._h, C.c_int(n), C.c_int(hh), C.c_int(w), _ptr(im, C.c_float),
+                                                    _ptr(out, C.c_float), C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
+    def dynamic_distance(self, mask, timing=False):
+        """FlowConstraintsCollection::dynamicDistance: u8 masks [n, H, W] -> chamfer distance [n, H, W] float32."""
+        mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mk.ndim == 3, mk.shape
+        n, hh, w = mk.shape
+        out = np.zeros((n, hh, w), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._fn("dynamic_distance")(self._h, C.c_int(n), C.c_int(hh), C.c_int(w), _ptr(mk, C.c_uint8),
+                                                 _ptr(out, C.c_float), C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
     # -- dense consumers of the result (SURVEY.md 8 f3) ------------------------------------------------
     def apply_depth_xforms(self, first=0, count=None, timing=False):
         """DepthXform::apply for frames [first, first+count): [n, H, W] float32."""

@@ -39,6 +39,7 @@
 #include "cvd_triplets.h"
 #include "cvd_dense.h"
 #include "cvd_sampling.h"
+#include "cvd_imageops.h"
 
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -318,6 +319,9 @@ struct cvd_handle_t {
   DevBuf<double> dFdot, dCostItem, dCostFrame, dScal, dHd, dFocal;
   DevBuf<double> dStatPart;  // per-workgroup partials of k_step_stats
   DevBuf<double> dDense;     // output of the dense consumer kernels (cvd_dense.h)
+  DevBuf<float> dImgIn, dImgGray, dImgCov, dImgOut;  // cvd_imageops.h staging
+  DevBuf<unsigned char> dImgMask;
+  DevBuf<unsigned int> dImgTmp;
   // constraint sampling (cvd_sampling.h): result of the last cvd_sample_pair_constraints
   DevBuf<float2> dSampledLoc, dSampledTrip;  // 2 resp. 3 float2 per constraint
   std::vector<long long> sampledOff, sampledTripOff;
@@ -2188,6 +2192,52 @@ static void denseMaps(cvd_handle* h, int kind, int first, int count, int w, int 
   }
 }
 
+// cornerMinEigenVal of n BGR float images (kind 0) / chamfer distance transform of n 8-bit masks (kind 1)
+static void imageOps(cvd_handle* h, int kind, int n, int w, int hh, const void* in, float* out, double* kernelMs) {
+  if (n < 0 || w < 1 || hh < 1) throw std::runtime_error("invalid image batch");
+  if (n == 0) return;
+  if (!in) throw std::runtime_error("null image input");
+  hipStream_t s = h->stream;
+  const size_t px = static_cast<size_t>(w) * hh, pixels = px * n;
+  if (pixels > (1ull << 31)) throw std::runtime_error("image batch too large for one call");
+  h->dImgOut.ensure(pixels);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernelMs) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+  if (kind == 0) {
+    h->dImgIn.ensure(pixels * 3);
+    h->dImgGray.ensure(pixels);
+    h->dImgCov.ensure(pixels * 3);
+    HIP_CHECK(hipMemcpyAsync(h->dImgIn.p, in, pixels * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    if (kernelMs) HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_bgr_to_gray, dim3(static_cast<unsigned>((pixels + 255) / 256)), dim3(256), 0, s, h->dImgIn.p, pixels,
+                       h->dImgGray.p);
+    const dim3 grid(static_cast<unsigned>((px + 255) / 256), 1, n);
+    hipLaunchKernelGGL(k_sobel_cov, grid, dim3(256), 0, s, h->dImgGray.p, w, hh, h->dImgCov.p);
+    hipLaunchKernelGGL(k_box_min_eigenval, grid, dim3(256), 0, s, h->dImgCov.p, w, hh, h->dImgOut.p);
+  } else {
+    const size_t tmpPer = static_cast<size_t>(w + 4) * (hh + 4);
+    h->dImgMask.ensure(pixels);
+    h->dImgTmp.ensure(tmpPer * n);
+    HIP_CHECK(hipMemcpyAsync(h->dImgMask.p, in, pixels, hipMemcpyHostToDevice, s));
+    if (kernelMs) HIP_CHECK(hipEventRecord(e0, s));
+    const size_t lds = kChamferThreads * sizeof(long long) + static_cast<size_t>(w) * sizeof(unsigned int);
+    if (lds > 64 * 1024) throw std::runtime_error("mask too wide for the distance transform kernel");
+    hipLaunchKernelGGL(k_chamfer_5x5, dim3(n), dim3(kChamferThreads), lds, s, h->dImgMask.p, w, hh, h->dImgTmp.p,
+                       h->dImgOut.p);
+  }
+  HIP_CHECK(hipGetLastError());
+  if (kernelMs) HIP_CHECK(hipEventRecord(e1, s));
+  if (out) HIP_CHECK(hipMemcpyAsync(out, h->dImgOut.p, pixels * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (kernelMs) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *kernelMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
 }  // namespace cvd
 
 // =======================================================================================================
@@ -2533,6 +2583,14 @@ int32_t cvd_depth_param_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrame
 int32_t cvd_spatial_warp_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrames, int32_t height, int32_t width,
                               float* out, double* kernelMs) {
   CVD_TRY(h, denseMaps(h, 2, firstFrame, numFrames, width, height, out, kernelMs));
+}
+int32_t cvd_corner_min_eigenval(cvd_handle* h, int32_t numImages, int32_t height, int32_t width, const float* bgr,
+                                float* out, double* kernelMs) {
+  CVD_TRY(h, imageOps(h, 0, numImages, width, height, bgr, out, kernelMs));
+}
+int32_t cvd_dynamic_distance(cvd_handle* h, int32_t numImages, int32_t height, int32_t width, const uint8_t* mask,
+                             float* out, double* kernelMs) {
+  CVD_TRY(h, imageOps(h, 1, numImages, width, height, mask, out, kernelMs));
 }
 int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s) { CVD_TRY(h, *s = h->summary); }
 int32_t cvd_num_records(cvd_handle* h) { return h ? static_cast<int32_t>(h->records.size()) : 0; }
