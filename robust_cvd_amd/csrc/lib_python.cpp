@@ -13,7 +13,7 @@
 // normalizeDepth / optimizePoses run on the MI355X through the C ABI of libcvd_hip.so (include/cvd_hip.h).
 // The same Python names, argument meaning and error behaviour (std::runtime_error -> RuntimeError) as the
 // reference, so that the reference's pose_optimization.py / params.py / loaders/video_dataset.py import it
-// unchanged.  Out-of-scope pieces (COLMAP import, tracks, filters, constraint sampling from flow images) raise.
+// unchanged.  Out-of-scope pieces (COLMAP import, tracks, filters) raise; constraint sampling from the flow images runs on the device.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -834,11 +835,185 @@ struct FlowConstraintsCollection {
       if (!params.frameRange.inRange(t - 1) || !params.frameRange.inRange(t) || !params.frameRange.inRange(t + 1)) continue;
       triplets_.emplace(t, TripletConstraints());
     }
-    if (params.doNotUseCache || !load())
-      throw std::runtime_error(
-          "flow_constraints.dat is missing or stale: sampling constraints from flow images "
-          "(FlowConstraintsCollection::compute, reference lib/FlowConstraints.cpp:257-550) is outside this "
-          "build (needs OpenCV cornerMinEigenVal / PNG decoding). Provide the cache file.");
+    if (params.doNotUseCache) {
+      compute();
+    } else if (!load()) {
+      compute();
+      save();
+    }
+  }
+
+  // ---- image files of the dataset (reference lib/core/CvUtil.cpp:25-36 raw header; PNG through Pillow: no OpenCV) ----
+  static std::vector<float> readRawFloat(const std::string& fn, int channels, int& rows, int& cols) {
+    std::ifstream is(fn, std::ios::binary);
+    if (!is) throw std::runtime_error("Could not open '" + fn + "'.");
+    rows = rd<int32_t>(is);
+    cols = rd<int32_t>(is);
+    const int type = rd<int32_t>(is);
+    const size_t elem = rd<size_t>(is);
+    // CV_32FC(n) = 5 + 8 (n - 1)
+    if (type != 5 + 8 * (channels - 1) || elem != static_cast<size_t>(4 * channels) || rows <= 0 || cols <= 0)
+      throw std::runtime_error("Unexpected image type in '" + fn + "'.");
+    std::vector<float> v(static_cast<size_t>(rows) * cols * channels);
+    is.read(reinterpret_cast<char*>(v.data()), v.size() * 4);
+    if (!is) throw std::runtime_error("Truncated image file '" + fn + "'.");
+    return v;
+  }
+  static std::vector<uint8_t> readPngGray(const std::string& fn, int& rows, int& cols) {  // imread(IMREAD_GRAYSCALE)
+    py::gil_scoped_acquire gil;
+    py::object im = py::module_::import("PIL.Image").attr("open")(fn).attr("convert")("L");
+    cols = im.attr("width").cast<int>();
+    rows = im.attr("height").cast<int>();
+    const std::string bytes = im.attr("tobytes")().cast<std::string>();
+    if (bytes.size() != static_cast<size_t>(rows) * cols) throw std::runtime_error("Unexpected PNG payload in '" + fn + "'.");
+    return std::vector<uint8_t>(bytes.begin(), bytes.end());
+  }
+  struct Device {
+    cvd_handle* h = nullptr;
+    explicit Device(int dev) : h(cvd_create(dev)) {
+      if (!h) throw std::runtime_error(std::string("cvd_create: ") + cvd_last_error(nullptr));
+    }
+    ~Device() { if (h) cvd_destroy(h); }
+    void check(int rc) const { if (rc != 0) throw std::runtime_error(cvd_last_error(h)); }
+  };
+  int device_ = 0;  // extension: HIP device used by compute() / setStaticFlagFromDynamicMask()
+
+  // dynamicDistance of every frame in `frames` (reference :257-286); false when there is no dynamic_mask stream
+  bool dynamicDistances(Device& dev, const std::vector<int>& frames, int numFrames, std::vector<float>& dist, int& dw,
+                        int& dh) const {
+    if (!video_->hasColorStream("dynamic_mask")) return false;
+    const ColorStream& ms = *video_->colorStreams_.at(video_->colorStreamIndex("dynamic_mask"));
+    std::vector<uint8_t> masks;
+    dw = dh = 0;
+    for (size_t k = 0; k < frames.size(); ++k) {
+      int r, c;
+      const std::string fn = ms.path_ + "/frame_" + fmtInt6(frames[k]) + ms.extension_;
+      if (!fileExists(fn)) throw std::runtime_error("Dynamic mask stream is missing a frame.");
+      std::vector<uint8_t> m = readPngGray(fn, r, c);
+      if (k == 0) { dw = c; dh = r; masks.resize(static_cast<size_t>(frames.size()) * dw * dh); }
+      if (c != dw || r != dh) throw std::runtime_error("Dynamic masks have inconsistent sizes.");
+      std::copy(m.begin(), m.end(), masks.begin() + k * static_cast<size_t>(dw) * dh);
+    }
+    std::vector<float> packed(masks.size());
+    dev.check(cvd_dynamic_distance(dev.h, static_cast<int>(frames.size()), dh, dw, masks.data(), packed.data(), nullptr));
+    // the samplers index the maps by frame number
+    dist.assign(static_cast<size_t>(numFrames) * dw * dh, 0.f);
+    for (size_t k = 0; k < frames.size(); ++k)
+      std::copy(packed.begin() + k * static_cast<size_t>(dw) * dh, packed.begin() + (k + 1) * static_cast<size_t>(dw) * dh,
+                dist.begin() + static_cast<size_t>(frames[k]) * dw * dh);
+    return true;
+  }
+
+  // FlowConstraintsCollection::compute (reference :288-550): corner response of every frame, then the greedy disk
+  // sampling of every pair / triplet, all on the device (cvd_corner_min_eigenval, cvd_dynamic_distance,
+  // cvd_sample_pair_constraints, cvd_sample_triplet_constraints); this function only moves files to buffers.
+  void compute() {
+    const ColorStream& cs = *video_->colorStreams_.at(video_->colorStreamIndex("down"));
+    const int F = video_->numFrames();
+    std::vector<int> frames;  // frames that appear in a key
+    {
+      std::vector<char> used(F, 0);
+      for (auto& kv : pairs_) { used.at(kv.first.first) = 1; used.at(kv.first.second) = 1; }
+      for (auto& kv : triplets_) { used.at(kv.first - 1) = 1; used.at(kv.first) = 1; used.at(kv.first + 1) = 1; }
+      for (int f = 0; f < F; ++f) if (used[f]) frames.push_back(f);
+    }
+    if (frames.empty()) return;
+    Device dev(device_);
+    int w = 0, h = 0;
+    std::vector<float> corner;
+    {
+      std::vector<float> bgr;
+      for (size_t k = 0; k < frames.size(); ++k) {
+        int r, c;
+        std::vector<float> im = readRawFloat(cs.path_ + "/frame_" + fmtInt6(frames[k]) + cs.extension_, 3, r, c);
+        if (k == 0) { w = c; h = r; bgr.resize(frames.size() * static_cast<size_t>(w) * h * 3); }
+        if (c != w || r != h) throw std::runtime_error("Color frames have inconsistent sizes.");
+        std::copy(im.begin(), im.end(), bgr.begin() + k * static_cast<size_t>(w) * h * 3);
+      }
+      std::vector<float> packed(frames.size() * static_cast<size_t>(w) * h);
+      dev.check(cvd_corner_min_eigenval(dev.h, static_cast<int>(frames.size()), h, w, bgr.data(), packed.data(), nullptr));
+      corner.assign(static_cast<size_t>(F) * w * h, 0.f);
+      for (size_t k = 0; k < frames.size(); ++k)
+        std::copy(packed.begin() + k * static_cast<size_t>(w) * h, packed.begin() + (k + 1) * static_cast<size_t>(w) * h,
+                  corner.begin() + static_cast<size_t>(frames[k]) * w * h);
+    }
+    dev.check(cvd_set_video(dev.h, F, w, h, video_->aspect_, video_->invAspect_));
+    std::vector<float> dyn;
+    int dw = 0, dh = 0;
+    const bool haveDyn = dynamicDistances(dev, frames, F, dyn, dw, dh);
+    auto loadFlowAndMask = [&](int a, int b, float* flow, uint8_t* mask) {  // reference :226-255
+      const std::string ff = path_ + "/flow/flow_" + fmtInt6(a) + "_" + fmtInt6(b) + ".raw";
+      if (!fileExists(ff)) throw std::runtime_error("Flow file does not exist.");
+      int r, c;
+      std::vector<float> fl = readRawFloat(ff, 2, r, c);
+      if (c != w || r != h) throw std::runtime_error("Flow has the wrong size.");
+      std::copy(fl.begin(), fl.end(), flow);
+      const std::string mf = path_ + "/flow_mask/mask_" + fmtInt6(a) + "_" + fmtInt6(b) + ".png";
+      if (!fileExists(mf)) throw std::runtime_error("Mask file does not exist.");
+      std::vector<uint8_t> m = readPngGray(mf, r, c);
+      if (c != w || r != h) throw std::runtime_error("Mask has the wrong size.");
+      std::copy(m.begin(), m.end(), mask);
+    };
+    const size_t px = static_cast<size_t>(w) * h;
+    const size_t batch = std::max<size_t>(1, (512ull << 20) / (px * 18));  // ~512 MiB of flow + mask per call
+    {  // pairs
+      std::vector<std::pair<int, int>> keys;
+      for (auto& kv : pairs_) keys.push_back(kv.first);
+      for (size_t k0 = 0; k0 < keys.size(); k0 += batch) {
+        const size_t n = std::min(batch, keys.size() - k0);
+        std::vector<int32_t> pf(2 * n);
+        std::vector<float> flow(n * px * 2);
+        std::vector<uint8_t> mask(n * px);
+        for (size_t k = 0; k < n; ++k) {
+          pf[2 * k] = keys[k0 + k].first;
+          pf[2 * k + 1] = keys[k0 + k].second;
+          loadFlowAndMask(pf[2 * k], pf[2 * k + 1], flow.data() + k * px * 2, mask.data() + k * px);
+        }
+        std::vector<int64_t> off(n + 1, 0);
+        dev.check(cvd_sample_pair_constraints(dev.h, static_cast<int>(n), pf.data(), corner.data(), flow.data(), mask.data(),
+                                              haveDyn ? dyn.data() : nullptr, dw, dh, params_.matchSeparation,
+                                              static_cast<float>(params_.minDynamicDistance), off.data()));
+        std::vector<float> loc(static_cast<size_t>(off[n]) * 4);
+        if (!loc.empty()) dev.check(cvd_get_sampled_constraints(dev.h, loc.data()));
+        for (size_t k = 0; k < n; ++k) {
+          PairConstraints& pc = pairs_.at(keys[k0 + k]);
+          const size_t cnt = static_cast<size_t>(off[k + 1] - off[k]);
+          pc.loc.resize(cnt);
+          std::memcpy(pc.loc.data(), loc.data() + static_cast<size_t>(off[k]) * 4, cnt * 16);
+          pc.isStatic.assign(cnt, 1);
+        }
+      }
+    }
+    {  // triplets (reference :467-550): flows centre -> previous and centre -> next
+      std::vector<int> keys;
+      for (auto& kv : triplets_) keys.push_back(kv.first);
+      const size_t tb = std::max<size_t>(1, batch / 2);
+      for (size_t k0 = 0; k0 < keys.size(); k0 += tb) {
+        const size_t n = std::min(tb, keys.size() - k0);
+        std::vector<int32_t> ce(n);
+        std::vector<float> f10(n * px * 2), f12(n * px * 2);
+        std::vector<uint8_t> m10(n * px), m12(n * px);
+        for (size_t k = 0; k < n; ++k) {
+          ce[k] = keys[k0 + k];
+          loadFlowAndMask(ce[k], ce[k] - 1, f10.data() + k * px * 2, m10.data() + k * px);
+          loadFlowAndMask(ce[k], ce[k] + 1, f12.data() + k * px * 2, m12.data() + k * px);
+        }
+        std::vector<int64_t> off(n + 1, 0);
+        dev.check(cvd_sample_triplet_constraints(dev.h, static_cast<int>(n), ce.data(), corner.data(), f10.data(), m10.data(),
+                                                 f12.data(), m12.data(), haveDyn ? dyn.data() : nullptr, dw, dh,
+                                                 params_.matchSeparation, static_cast<float>(params_.minDynamicDistance),
+                                                 off.data()));
+        std::vector<float> loc(static_cast<size_t>(off[n]) * 6);
+        if (!loc.empty()) dev.check(cvd_get_sampled_triplet_constraints(dev.h, loc.data()));
+        for (size_t k = 0; k < n; ++k) {
+          TripletConstraints& tc = triplets_.at(keys[k0 + k]);
+          const size_t cnt = static_cast<size_t>(off[k + 1] - off[k]);
+          tc.loc.resize(cnt);
+          std::memcpy(tc.loc.data(), loc.data() + static_cast<size_t>(off[k]) * 6, cnt * 24);
+          tc.isStatic.assign(cnt, 1);
+        }
+      }
+    }
   }
 
   bool load() {  // reference :116-189
@@ -889,11 +1064,38 @@ struct FlowConstraintsCollection {
     for (auto& kv : pairs_) std::fill(kv.second.isStatic.begin(), kv.second.isStatic.end(), 1);
     for (auto& kv : triplets_) std::fill(kv.second.isStatic.begin(), kv.second.isStatic.end(), 1);
   }
-  void setStaticFlagFromDynamicMask(int /*distance*/) {  // reference :573-660
+  void setStaticFlagFromDynamicMask(int distance) {  // reference :573-660
     if (!video_->hasColorStream("dynamic_mask")) { resetStaticFlag(); return; }
-    throw std::runtime_error(
-        "setStaticFlagFromDynamicMask with a dynamic_mask stream needs PNG decoding + distanceTransform "
-        "(OpenCV), which this build does not have; use setStaticFlags(pair_index, flags) instead.");
+    const int F = video_->numFrames();
+    std::vector<int> frames;
+    {
+      std::vector<char> used(F, 0);
+      for (auto& kv : pairs_) { used.at(kv.first.first) = 1; used.at(kv.first.second) = 1; }
+      for (auto& kv : triplets_) { used.at(kv.first - 1) = 1; used.at(kv.first) = 1; used.at(kv.first + 1) = 1; }
+      for (int f = 0; f < F; ++f) if (used[f]) frames.push_back(f);
+    }
+    if (frames.empty()) return;
+    Device dev(device_);
+    std::vector<float> dd;
+    int w = 0, h = 0;
+    dynamicDistances(dev, frames, F, dd, w, h);
+    // static <=> every end point is farther than `distance` from the dynamic region; pixel = int(loc * w) for both
+    // coordinates (loc.y is scaled by invAspect, so `* w` lands on the row: reference :616-619)
+    auto isFar = [&](int frame, float lx, float ly) {
+      const int ix = static_cast<int>(lx * w), iy = static_cast<int>(ly * w);
+      if (ix < 0 || ix >= w || iy < 0 || iy >= h) throw std::runtime_error("constraint outside the dynamic mask");
+      return dd[(static_cast<size_t>(frame) * h + iy) * w + ix] > static_cast<float>(distance);
+    };
+    for (auto& kv : pairs_)
+      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+        const auto& c = kv.second.loc[i];
+        kv.second.isStatic[i] = isFar(kv.first.first, c[0], c[1]) && isFar(kv.first.second, c[2], c[3]);
+      }
+    for (auto& kv : triplets_)
+      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+        const auto& c = kv.second.loc[i];
+        kv.second.isStatic[i] = isFar(kv.first - 1, c[0], c[1]) && isFar(kv.first, c[2], c[3]) && isFar(kv.first + 1, c[4], c[5]);
+      }
   }
   void pruneStaticFlag(int) { throw std::runtime_error("pruneStaticFlag is outside the optimizer path of this build."); }
   // extension: explicit flags (what setStaticFlagFromDynamicMask would compute), per pair in map order
@@ -1323,7 +1525,9 @@ PYBIND11_MODULE(lib_python, m) {
       .def("pruneStaticFlag", &FlowConstraintsCollection::pruneStaticFlag)
       .def("setStaticFlags", &FlowConstraintsCollection::setStaticFlags)
       .def("numPairs", &FlowConstraintsCollection::numPairs)
-      .def("numConstraints", &FlowConstraintsCollection::numConstraints);
+      .def("numConstraints", &FlowConstraintsCollection::numConstraints)
+      .def("compute", &FlowConstraintsCollection::compute, py::call_guard<py::gil_scoped_release>())
+      .def_readwrite("device", &FlowConstraintsCollection::device_);
 
   py::class_<DepthVideoImporter>(m, "DepthVideoImporter")
       .def_static("importVideo", &DepthVideoImporter::importVideo)

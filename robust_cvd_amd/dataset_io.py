@@ -13,12 +13,50 @@ CV_32FC1 = 5
 
 
 def write_raw_image(path, img):
-    """int rows, int cols, int cvType, size_t elemSize, then row-major data (reference lib/core/CvUtil.cpp:98-107)."""
+    """int rows, int cols, int cvType, size_t elemSize, then row-major data (reference lib/core/CvUtil.cpp:98-107).
+    [H, W] -> CV_32FC1, [H, W, C] -> CV_32FC(C)."""
     img = np.ascontiguousarray(img, dtype=np.float32)
-    assert img.ndim == 2
+    assert img.ndim in (2, 3)
+    ch = 1 if img.ndim == 2 else img.shape[2]
     with open(path, "wb") as f:
-        f.write(struct.pack("<iiiQ", img.shape[0], img.shape[1], CV_32FC1, 4))
+        f.write(struct.pack("<iiiQ", img.shape[0], img.shape[1], CV_32FC1 + 8 * (ch - 1), 4 * ch))
         f.write(img.tobytes())
+
+
+def write_flow_inputs(base_dir, pairs, flows, masks, colors, dynamic_masks=None):
+    """The image inputs of FlowConstraintsCollection::compute (reference lib/FlowConstraints.cpp:226-286, 401-420):
+    flow/flow_%06d_%06d.raw (2 x f32, pixels), flow_mask/mask_%06d_%06d.png, color_down/frame_%06d.raw (BGR f32),
+    optionally dynamic_mask/frame_%06d.png.  PNGs are written with Pillow."""
+    from PIL import Image
+    for d in ("flow", "flow_mask", "color_down"):
+        os.makedirs(os.path.join(base_dir, d), exist_ok=True)
+    for (a, b), fl, mk in zip(np.asarray(pairs).tolist(), flows, masks):
+        write_raw_image(os.path.join(base_dir, "flow", f"flow_{a:06d}_{b:06d}.raw"), fl)
+        Image.fromarray(np.ascontiguousarray(mk, dtype=np.uint8), "L").save(
+            os.path.join(base_dir, "flow_mask", f"mask_{a:06d}_{b:06d}.png"))
+    for i, c in enumerate(colors):
+        write_raw_image(os.path.join(base_dir, "color_down", f"frame_{i:06d}.raw"), c)
+    if dynamic_masks is not None:
+        os.makedirs(os.path.join(base_dir, "dynamic_mask"), exist_ok=True)
+        for i, m in enumerate(dynamic_masks):
+            Image.fromarray(np.ascontiguousarray(m, dtype=np.uint8), "L").save(
+                os.path.join(base_dir, "dynamic_mask", f"frame_{i:06d}.png"))
+
+
+def read_flow_constraints(path, num_pairs, num_triplets):
+    """Inverse of write_flow_constraints: (match_separation, {(a, b): [n, 4] f32}, {centre: [n, 6] f32})."""
+    with open(path, "rb") as f:
+        magic, version, sep = struct.unpack("<IIi", f.read(12))
+        assert magic == 0xDEADBEEF and version == 3
+        pairs, trips = {}, {}
+        for _ in range(num_pairs):
+            a, b, n = struct.unpack("<iiQ", f.read(16))
+            pairs[(a, b)] = np.frombuffer(f.read(16 * n), dtype=np.float32).reshape(n, 4)
+        for _ in range(num_triplets):
+            t, n = struct.unpack("<iQ", f.read(12))
+            trips[t] = np.frombuffer(f.read(24 * n), dtype=np.float32).reshape(n, 6)
+        assert struct.unpack("<I", f.read(4))[0] == 0xDEADBEEF
+    return sep, pairs, trips
 
 
 def write_flow_constraints(path, pairs, offsets, loc, match_separation=10, triplet_centers=()):

@@ -255,3 +255,56 @@ def test_optimize_poses_sequence_on_gpu_matches_direct_c_abi(lib, tmp_path):
     assert len(fr.extrinsics.right()) == 3 and np.asarray(fr.depthXform().paramMap(fr)).shape == (56, 96)
     assert np.asarray(fr.spatialXform().warp(ds.height(), ds.width())).shape == (56, 96, 2)
     assert os.path.getsize(os.path.join(base, "video.dat")) > 1000
+
+
+@pytest.mark.gpu
+def test_constraints_are_sampled_from_the_flow_images_on_the_gpu(lib, tmp_path):
+    """FlowConstraintsCollection(video, params) without a cache file: compute() + save() (reference
+    lib/FlowConstraints.cpp:84-93, 288-550) through the device kernels; the cache it writes must hold exactly what the
+    oracle's chain (corner response -> dynamic distance -> greedy sampling) gives on the same images."""
+    from oracle.oracle import Oracle
+    F, W, H, sep = 4, 64, 40, 6
+    v = synth.make_video(F, W, H, seed=53, spacing=8)
+    base = dataset_io.write_dataset(str(tmp_path / "v"), v)
+    os.remove(os.path.join(base, "flow_constraints.dat"))
+    rng = np.random.default_rng(11)
+    pairs = np.array([[0, 1], [1, 0], [1, 2], [2, 1], [2, 3], [3, 2]], np.int32)
+    flows = rng.normal(0, 1.5, (len(pairs), H, W, 2)).astype(np.float32)
+    masks = np.where(rng.uniform(size=(len(pairs), H, W)) < 0.9, 255, 0).astype(np.uint8)
+    colors = rng.uniform(0, 1, (F, H, W, 3)).astype(np.float32)
+    dyn = np.full((F, H // 2, W // 2), 255, np.uint8)
+    dyn[:, 4:8, 6:14] = 0
+    with open(os.path.join(base, "flow_list.json"), "w") as f:
+        import json
+        json.dump([["src", "dst"]] + pairs.tolist(), f)
+    dataset_io.write_flow_inputs(base, pairs, flows, masks, colors, dyn)
+    dv = lib.DepthVideo()
+    lib.DepthVideoImporter.importVideo(dv, base, True)
+    assert dv.hasColorStream("down") and dv.hasColorStream("dynamic_mask")
+    fcp = lib.FlowConstraintsParams()
+    fcp.frameRange.resolve(dv.numFrames(), True)
+    fcp.matchSeparation = sep
+    fcp.minDynamicDistance = 2
+    fc = lib.FlowConstraintsCollection(dv, fcp)          # no cache: compute + save
+    assert os.path.exists(os.path.join(base, "flow_constraints.dat")) and fc.numConstraints() > 40
+    got_sep, got_pairs, got_trips = dataset_io.read_flow_constraints(os.path.join(base, "flow_constraints.dat"), len(pairs), F - 2)
+    assert got_sep == sep
+    o = Oracle()
+    synth.load_into(o, v)
+    corner = o.corner_min_eigenval(colors)
+    dd = o.dynamic_distance(dyn)
+    off, loc = o.sample_pair_constraints(pairs, corner, flows, masks, sep, dyn_dist=dd, min_dynamic_distance=2.0)
+    for k, (a, b) in enumerate(pairs.tolist()):
+        assert np.array_equal(got_pairs[(a, b)], loc[off[k]:off[k + 1]])
+    idx = {tuple(p): k for k, p in enumerate(pairs.tolist())}
+    centers = np.array([1, 2], np.int32)
+    f10 = np.stack([flows[idx[(c, c - 1)]] for c in centers]); m10 = np.stack([masks[idx[(c, c - 1)]] for c in centers])
+    f12 = np.stack([flows[idx[(c, c + 1)]] for c in centers]); m12 = np.stack([masks[idx[(c, c + 1)]] for c in centers])
+    toff, tloc = o.sample_triplet_constraints(centers, corner, f10, m10, f12, m12, sep, dyn_dist=dd, min_dynamic_distance=2.0)
+    for k, c in enumerate(centers.tolist()):
+        assert np.array_equal(got_trips[c], tloc[toff[k]:toff[k + 1]])
+    # a second construction finds the cache (same counts), and the dynamic-mask flags follow the distance map
+    fc2 = lib.FlowConstraintsCollection(dv, fcp)
+    assert fc2.numConstraints() == fc.numConstraints()
+    fc2.setStaticFlagFromDynamicMask(3)
+    fc2.resetStaticFlag()
