@@ -169,6 +169,24 @@ int32_t cvd_depth_param_maps(cvd_handle* h, int32_t first_frame, int32_t num_fra
 int32_t cvd_spatial_warp_maps(cvd_handle* h, int32_t first_frame, int32_t num_frames, int32_t height, int32_t width,
                               float* out, double* kernel_ms);
 
+/* DepthVideoProcessor::flowGuidedFilter (reference lib/Processor.cpp:315-590; Op::FlowGuidedFilter, the --post_filter of
+ * the pipeline) with DepthVideo::project (reference lib/DepthVideo.cpp:637-681).  The batch holds num_frames CONSECUTIVE
+ * frames: batch frame 0 must be video frame max(0, firstFrame - frame_radius) and the last batch frame the last frame
+ * of the range (the reference's temporal window is [max(0, frame - radius), min(lastFrame, frame + radius)]); outputs
+ * are produced for batch frames [first_output, first_output + num_outputs).
+ *   depth    [n][depth_height][depth_width]  DepthFrame::depth() of the source stream (transformed depth)
+ *   cameras  [n][9]  position xyz, orientation quaternion x y z w, hFov, vFov
+ *   flow_fwd [n-1][height][width][2], mask_fwd [n-1][height][width]: flow / mask of (k -> k+1), pixels
+ *   flow_bwd, mask_bwd: entry k = (k+1 -> k)
+ *   out      [num_outputs][height][width] filtered depth (weighted mean, or weighted median if median != 0)
+ * farConnections is not supported (the caller must reject it); the median holds at most 256 samples per pixel.
+ * f32 in the reference's operation order; expf is the device function (float tolerance, not bit-exact). */
+int32_t cvd_flow_guided_filter(cvd_handle* h, int32_t num_frames, int32_t first_output, int32_t num_outputs,
+                               int32_t height, int32_t width, int32_t depth_height, int32_t depth_width, float inv_aspect,
+                               const float* depth, const float* cameras, const float* flow_fwd, const uint8_t* mask_fwd,
+                               const float* flow_bwd, const uint8_t* mask_bwd, int32_t frame_radius,
+                               int32_t spatial_radius, int32_t median, float* out, double* kernel_ms);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------------- */
 /* Average duration (ms) of the dominant kernels over the last solve, measured with HIP events on the
  * solver's own stream: fills {evaluate_assemble, matvec_pairs, matvec_finish, cg_update, block_inverse,

@@ -2495,4 +2495,115 @@ int cvdo_dynamic_distance(void* h, int numImages, int height, int width, const u
   });
 }
 
+// ---- DepthVideoProcessor::flowGuidedFilter, reference lib/Processor.cpp:315-590 (+ DepthVideo::project,
+// lib/DepthVideo.cpp:637-681).  Batch layout as in include/cvd_hip.h (cvd_flow_guided_filter).  float arithmetic in the
+// reference's order; samples are collected in a vector and std::sort-ed for the median exactly like the reference.
+static void quatRotate(const float* q, const float* v, float* out) {  // Eigen: uv = 2 q.vec x v; v + w uv + q.vec x uv
+  float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  for (int i = 0; i < 3; ++i) uv[i] += uv[i];
+  const float c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int i = 0; i < 3; ++i) out[i] = v[i] + q[3] * uv[i] + c[i];
+}
+int cvdo_flow_guided_filter(void* h, int numFrames, int firstOutput, int numOutputs, int height, int width, int depthHeight,
+                            int depthWidth, float invAspect, const float* depth, const float* cameras,
+                            const float* flowFwd, const uint8_t* maskFwd, const float* flowBwd, const uint8_t* maskBwd,
+                            int frameRadius, int spatialRadius, int median, float* out, double* /*kernelMs*/) {
+  CVDO_TRY(h, {
+    const int w = width, hh = height, n = numFrames;
+    const size_t px = static_cast<size_t>(w) * hh;
+    struct Cam { float pos[3], right[3], up[3], front[3], tanH, tanV; };
+    std::vector<Cam> cams(n);
+    for (int k = 0; k < n; ++k) {
+      const float* c = cameras + static_cast<size_t>(k) * 9;
+      const float ex[3] = {1.f, 0.f, 0.f}, ey[3] = {0.f, 1.f, 0.f}, ez[3] = {0.f, 0.f, -1.f};
+      for (int i = 0; i < 3; ++i) cams[k].pos[i] = c[i];
+      quatRotate(c + 3, ex, cams[k].right);
+      quatRotate(c + 3, ey, cams[k].up);
+      quatRotate(c + 3, ez, cams[k].front);
+      cams[k].tanH = std::tan(c[7] / 2.f);   // project(): tan(intr.hFov / 2.f)
+      cams[k].tanV = std::tan(c[8] / 2.f);
+    }
+    struct SampleInfo { float depth, weight; };
+    std::vector<SampleInfo> samples;
+    for (int o = 0; o < numOutputs; ++o) {
+      const int frame = firstOutput + o;
+      const Cam& ref = cams[frame];
+      const int f0 = std::max(0, frame - frameRadius);
+      const int f1 = std::min(n - 1, frame + frameRadius);
+      auto addSample = [&](float lx, float ly, int fi) {  // reference :437-446 + project :656-681, :637-654
+        const float nx = lx / w, ny = ly / hh * invAspect;
+        int x = std::min(depthWidth - 1, int(nx * depthWidth + 0.5f));
+        int y = std::min(depthHeight - 1, int(ny / invAspect * depthHeight + 0.5f));
+        x = std::max(x, 0);
+        y = std::max(y, 0);
+        const float d = depth[(static_cast<size_t>(fi) * depthHeight + y) * depthWidth + x];
+        const Cam& c = cams[fi];
+        const float rx = -1.f + 2.f * nx;
+        const float ry = 1.f - 2.f * ny / invAspect;
+        const float a = rx * c.tanH, b = ry * c.tanV;
+        float pos[3];
+        for (int i = 0; i < 3; ++i) {
+          const float ray = (c.front[i] + c.right[i] * a) + c.up[i] * b;
+          pos[i] = c.pos[i] + ray * d;
+        }
+        const float dd = ((pos[0] - ref.pos[0]) * ref.front[0] + (pos[1] - ref.pos[1]) * ref.front[1]) +
+                         (pos[2] - ref.pos[2]) * ref.front[2];
+        samples.push_back({dd, 0.f});
+      };
+      for (int y = 0; y < hh; ++y) {
+        const int y0 = std::max(0, y - spatialRadius), y1 = std::min(hh - 1, y + spatialRadius);
+        for (int x = 0; x < w; ++x) {
+          const int x0 = std::max(0, x - spatialRadius), x1 = std::min(w - 1, x + spatialRadius);
+          samples.clear();
+          float referenceDepth = FLT_MAX;
+          for (int wy = y0; wy <= y1; ++wy)
+            for (int wx = x0; wx <= x1; ++wx) {
+              addSample(static_cast<float>(wx), static_cast<float>(wy), frame);
+              if (wx == x && wy == y) referenceDepth = samples.back().depth;
+              for (int dir = 0; dir < 2; ++dir) {
+                float lx = static_cast<float>(wx), ly = static_cast<float>(wy);
+                for (int fi = frame + (dir ? -1 : 1); dir ? fi >= f0 : fi <= f1; fi += dir ? -1 : 1) {
+                  // forward: flow (fi-1 -> fi); backward: flow (fi+1 -> fi)
+                  const size_t e = static_cast<size_t>(dir ? fi : fi - 1) * px;
+                  const float* flow = (dir ? flowBwd : flowFwd) + e * 2;
+                  const uint8_t* mask = (dir ? maskBwd : maskFwd) + e;
+                  int ix = std::min(int(lx + 0.5f), w - 1);
+                  int iy = std::min(int(ly + 0.5f), hh - 1);
+                  if (!mask[static_cast<size_t>(iy) * w + ix]) break;
+                  lx += flow[(static_cast<size_t>(iy) * w + ix) * 2];
+                  ly += flow[(static_cast<size_t>(iy) * w + ix) * 2 + 1];
+                  ix = static_cast<int>(lx + 0.5f);
+                  iy = static_cast<int>(ly + 0.5f);
+                  if (ix < 0 || ix >= w || iy < 0 || iy >= hh) break;
+                  addSample(lx, ly, fi);
+                }
+              }
+            }
+          float depthSum = 0.f, weightSum = 0.f;
+          for (SampleInfo& sm : samples) {
+            const float value = std::max(sm.depth, referenceDepth) / std::min(sm.depth, referenceDepth);
+            sm.weight = expf(-value * 3.f);
+            depthSum += sm.depth * sm.weight;
+            weightSum += sm.weight;
+          }
+          float result = 0.f;
+          if (median) {
+            const float halfWeight = weightSum / 2.f;
+            std::sort(samples.begin(), samples.end(),
+                      [](const SampleInfo& l, const SampleInfo& r) { return l.depth < r.depth; });
+            float cum = 0.f;
+            for (const SampleInfo& sm : samples) {
+              cum += sm.weight;
+              if (cum >= halfWeight) { result = sm.depth; break; }
+            }
+          } else {
+            result = weightSum > 0.f ? depthSum / weightSum : 0.f;
+          }
+          out[(static_cast<size_t>(o) * hh + y) * w + x] = result;
+        }
+      }
+    }
+  });
+}
+
 }  // extern "C"

@@ -305,6 +305,27 @@ class Binding:
                                                   C.c_int(width), _ptr(out, C.c_float), C.byref(ms) if timing else None))
         return (out, ms.value) if timing else out
 
+    def flow_guided_filter(self, depth, cameras, flow_fwd, mask_fwd, flow_bwd, mask_bwd, inv_aspect, frame_radius,
+                           spatial_radius=0, median=False, first=0, count=None, timing=False):
+        """DepthVideoProcessor::flowGuidedFilter on a batch of consecutive frames (see include/cvd_hip.h)."""
+        d = _f32(depth)
+        n, dh, dw = d.shape
+        cam = _f32(cameras).reshape(n, 9)
+        ff, fb = _f32(flow_fwd), _f32(flow_bwd)
+        mf = np.ascontiguousarray(mask_fwd, dtype=np.uint8)
+        mb = np.ascontiguousarray(mask_bwd, dtype=np.uint8)
+        assert ff.shape[0] == n - 1 and ff.shape == fb.shape and mf.shape == ff.shape[:3] == mb.shape, (ff.shape, mf.shape)
+        hh, w = (ff.shape[1], ff.shape[2]) if n > 1 else (dh, dw)
+        count = n - first if count is None else count
+        out = np.zeros((count, hh, w), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._fn("flow_guided_filter")(
+            self._h, C.c_int(n), C.c_int(first), C.c_int(count), C.c_int(hh), C.c_int(w), C.c_int(dh), C.c_int(dw),
+            C.c_float(inv_aspect), _ptr(d, C.c_float), _ptr(cam, C.c_float), _ptr(ff, C.c_float), _ptr(mf, C.c_uint8),
+            _ptr(fb, C.c_float), _ptr(mb, C.c_uint8), C.c_int(frame_radius), C.c_int(spatial_radius), C.c_int(int(median)),
+            _ptr(out, C.c_float), C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
     def _grid_vertices(self):
         d = self.xform_desc(False)
         if int(d.depth_type) == 3:  # Grid

@@ -40,6 +40,7 @@
 #include "cvd_dense.h"
 #include "cvd_sampling.h"
 #include "cvd_imageops.h"
+#include "cvd_filter.h"
 
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -322,6 +323,9 @@ struct cvd_handle_t {
   DevBuf<float> dImgIn, dImgGray, dImgCov, dImgOut;  // cvd_imageops.h staging
   DevBuf<unsigned char> dImgMask;
   DevBuf<unsigned int> dImgTmp;
+  DevBuf<float> dFltDepth, dFltOut, dFltFlowF, dFltFlowB;  // cvd_filter.h staging
+  DevBuf<unsigned char> dFltMaskF, dFltMaskB;
+  DevBuf<FilterCam> dFltCams;
   // constraint sampling (cvd_sampling.h): result of the last cvd_sample_pair_constraints
   DevBuf<float2> dSampledLoc, dSampledTrip;  // 2 resp. 3 float2 per constraint
   std::vector<long long> sampledOff, sampledTripOff;
@@ -2238,6 +2242,75 @@ static void imageOps(cvd_handle* h, int kind, int n, int w, int hh, const void* 
   }
 }
 
+// Quaternion (x, y, z, w) times vector, the way Eigen evaluates it in float (uv = 2 q.vec x v; v + w uv + q.vec x uv)
+static void quatRotate(const float* q, const float* v, float* out) {
+  float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  for (int i = 0; i < 3; ++i) uv[i] += uv[i];
+  const float c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int i = 0; i < 3; ++i) out[i] = v[i] + q[3] * uv[i] + c[i];
+}
+
+static void flowGuidedFilter(cvd_handle* h, int n, int first, int count, int w, int hh, int dw, int dh, float invAspect,
+                             const float* depth, const float* cameras, const float* flowF, const uint8_t* maskF,
+                             const float* flowB, const uint8_t* maskB, int frameRadius, int spatialRadius, int median,
+                             float* out, double* kernelMs) {
+  if (n < 1 || first < 0 || count < 0 || first + count > n) throw std::runtime_error("invalid frame batch");
+  if (w < 1 || hh < 1 || dw < 1 || dh < 1 || !(invAspect > 0.f)) throw std::runtime_error("invalid raster");
+  if (frameRadius < 0 || spatialRadius < 0) throw std::runtime_error("negative filter radius");
+  if (!depth || !cameras || (n > 1 && frameRadius > 0 && (!flowF || !maskF || !flowB || !maskB)))
+    throw std::runtime_error("null filter input");
+  if (count == 0) return;
+  const long long side = 2ll * spatialRadius + 1, maxSamples = side * side * (2ll * frameRadius + 1);
+  if (median && maxSamples > 256)
+    throw std::runtime_error("flow guided median filter: (2 spatialRadius + 1)^2 (2 frameRadius + 1) > 256 samples per pixel");
+  hipStream_t s = h->stream;
+  const size_t px = static_cast<size_t>(w) * hh, dpx = static_cast<size_t>(dw) * dh;
+  std::vector<FilterCam> cams(n);
+  for (int k = 0; k < n; ++k) {
+    const float* c = cameras + static_cast<size_t>(k) * 9;
+    const float ex[3] = {1.f, 0.f, 0.f}, ey[3] = {0.f, 1.f, 0.f}, ez[3] = {0.f, 0.f, -1.f};
+    for (int i = 0; i < 3; ++i) cams[k].pos[i] = c[i];
+    quatRotate(c + 3, ex, cams[k].right);
+    quatRotate(c + 3, ey, cams[k].up);
+    quatRotate(c + 3, ez, cams[k].front);
+    cams[k].tanH = std::tan(c[7] / 2.f);
+    cams[k].tanV = std::tan(c[8] / 2.f);
+  }
+  h->dFltCams.upload(cams.data(), n, s);
+  h->dFltDepth.upload(depth, dpx * n, s);
+  const size_t links = n > 1 && frameRadius > 0 ? static_cast<size_t>(n - 1) : 0;
+  h->dFltFlowF.upload(flowF, links * px * 2, s);
+  h->dFltFlowB.upload(flowB, links * px * 2, s);
+  h->dFltMaskF.upload(maskF, links * px, s);
+  h->dFltMaskB.upload(maskB, links * px, s);
+  h->dFltOut.ensure(px * count);
+  FilterArgs A;
+  A.n = n; A.first = first; A.count = count; A.w = w; A.h = hh; A.dw = dw; A.dh = dh; A.invAspect = invAspect;
+  A.frameRadius = links ? frameRadius : 0; A.spatialRadius = spatialRadius; A.median = median;
+  A.depth = h->dFltDepth.p; A.cams = h->dFltCams.p;
+  A.flowFwd = reinterpret_cast<const float2*>(h->dFltFlowF.p); A.maskFwd = h->dFltMaskF.p;
+  A.flowBwd = reinterpret_cast<const float2*>(h->dFltFlowB.p); A.maskBwd = h->dFltMaskB.p;
+  A.out = h->dFltOut.p;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernelMs) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventRecord(e0, s)); }
+  const dim3 grid(static_cast<unsigned>((px + 255) / 256), 1, count), block(256);
+  if (!median) hipLaunchKernelGGL((k_flow_guided_filter<0>), grid, block, 0, s, A);
+  else if (maxSamples <= 16) hipLaunchKernelGGL((k_flow_guided_filter<16>), grid, block, 0, s, A);
+  else if (maxSamples <= 64) hipLaunchKernelGGL((k_flow_guided_filter<64>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((k_flow_guided_filter<256>), grid, block, 0, s, A);
+  HIP_CHECK(hipGetLastError());
+  if (kernelMs) HIP_CHECK(hipEventRecord(e1, s));
+  if (out) HIP_CHECK(hipMemcpyAsync(out, h->dFltOut.p, px * count * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (kernelMs) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *kernelMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
 }  // namespace cvd
 
 // =======================================================================================================
@@ -2591,6 +2664,14 @@ int32_t cvd_corner_min_eigenval(cvd_handle* h, int32_t numImages, int32_t height
 int32_t cvd_dynamic_distance(cvd_handle* h, int32_t numImages, int32_t height, int32_t width, const uint8_t* mask,
                              float* out, double* kernelMs) {
   CVD_TRY(h, imageOps(h, 1, numImages, width, height, mask, out, kernelMs));
+}
+int32_t cvd_flow_guided_filter(cvd_handle* h, int32_t numFrames, int32_t firstOutput, int32_t numOutputs, int32_t height,
+                               int32_t width, int32_t depthHeight, int32_t depthWidth, float invAspect, const float* depth,
+                               const float* cameras, const float* flowFwd, const uint8_t* maskFwd, const float* flowBwd,
+                               const uint8_t* maskBwd, int32_t frameRadius, int32_t spatialRadius, int32_t median,
+                               float* out, double* kernelMs) {
+  CVD_TRY(h, flowGuidedFilter(h, numFrames, firstOutput, numOutputs, width, height, depthWidth, depthHeight, invAspect, depth,
+                              cameras, flowFwd, maskFwd, flowBwd, maskBwd, frameRadius, spatialRadius, median, out, kernelMs));
 }
 int32_t cvd_get_summary(cvd_handle* h, cvd_solve_summary* s) { CVD_TRY(h, *s = h->summary); }
 int32_t cvd_num_records(cvd_handle* h) { return h ? static_cast<int32_t>(h->records.size()) : 0; }
