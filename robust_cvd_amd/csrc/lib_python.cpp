@@ -1359,10 +1359,97 @@ struct DepthVideoProcessor {
       logInfo(b);
     }
   }
+  // Op::Copy, reference lib/Processor.cpp:152-181
+  void copy(const DvpParams& p) {
+    if (p.sourceDepthStream < 0 || p.sourceDepthStream >= video_->numDepthStreams())
+      throw std::runtime_error("Source depth stream out of range.");
+    if (p.sourceDepthStream == p.depthStream)
+      throw std::runtime_error("Source and destination depth stream cannot be identical.");
+    DepthStream& src = *video_->depthStreams_.at(p.sourceDepthStream);
+    DepthStream& dst = *video_->depthStreams_.at(p.depthStream);
+    for (int f : p.frameRange.frames) {
+      DepthFrame& sf = src.frame(f);
+      const std::vector<float>* d = sf.sourceDepth();
+      if (!d) throw std::runtime_error("Source depth frame is missing.");
+      const std::vector<float> x = sf.depthXform().apply(*d, sf.width(), sf.height());  // DepthFrame::depth()
+      DepthFrame& df = dst.frame(f);
+      checkDims(dst, sf.width(), sf.height());
+      df.sourceDepth_ = x;
+      df.triedLoad = true;
+      df.intrinsics = sf.intrinsics;
+      df.extrinsics = sf.extrinsics;
+    }
+  }
+
+  // Op::FlowGuidedFilter, reference lib/Processor.cpp:315-590: gathers the files into one consecutive batch and runs
+  // cvd_flow_guided_filter (robust_cvd_amd/csrc/cvd_filter.h) on it.
+  void flowGuidedFilter(const DvpParams& p) {
+    if (!p.frameRange.isConsecutive()) throw std::runtime_error("Frame range must be consecutive.");
+    if (p.farConnections) throw std::runtime_error("flowGuidedFilter: farConnections is not supported by this build.");
+    const int first = p.frameRange.firstFrame(), last = p.frameRange.lastFrame();
+    const int lo = std::max(0, first - p.frameRadius);
+    const int n = last - lo + 1;
+    DepthStream& src = *video_->depthStreams_.at(p.sourceDepthStream);
+    DepthStream& dst = *video_->depthStreams_.at(p.depthStream);
+    int w = 0, h = 0;
+    std::vector<float> ff, fb;
+    std::vector<uint8_t> mf, mb;
+    for (int k = 0; k + 1 < n && p.frameRadius > 0; ++k) {
+      for (int dir = 0; dir < 2; ++dir) {
+        const int a = lo + k + dir, b = lo + k + 1 - dir;  // forward: k -> k+1, backward: k+1 -> k
+        int r, c;
+        const std::string stem = fmtInt6(a) + "_" + fmtInt6(b);
+        const std::vector<float> fl = FlowConstraintsCollection::readRawFloat(video_->path_ + "/flow/flow_" + stem + ".raw", 2, r, c);
+        if (w == 0) {
+          w = c; h = r;
+          const size_t links = static_cast<size_t>(n - 1) * w * h;
+          ff.resize(links * 2); fb.resize(links * 2); mf.resize(links); mb.resize(links);
+        }
+        if (c != w || r != h) throw std::runtime_error("Flow has the wrong size.");
+        std::copy(fl.begin(), fl.end(), (dir ? fb : ff).begin() + static_cast<size_t>(k) * w * h * 2);
+        const std::vector<uint8_t> m = FlowConstraintsCollection::readPngGray(video_->path_ + "/flow_mask/mask_" + stem + ".png", r, c);
+        if (c != w || r != h) throw std::runtime_error("Mask has the wrong size.");
+        std::copy(m.begin(), m.end(), (dir ? mb : mf).begin() + static_cast<size_t>(k) * w * h);
+      }
+    }
+    const int dw = src.width(), dh = src.height();
+    if (dw <= 0 || dh <= 0) throw std::runtime_error("Source depth stream has no frames.");
+    if (w == 0) { w = dw; h = dh; }
+    std::vector<float> depth(static_cast<size_t>(n) * dw * dh), cams(static_cast<size_t>(n) * 9);
+    for (int k = 0; k < n; ++k) {
+      DepthFrame& sf = src.frame(lo + k);
+      const std::vector<float>* d = sf.sourceDepth();
+      if (!d) throw std::runtime_error("Source depth frame is missing.");
+      const std::vector<float> x = sf.depthXform().apply(*d, dw, dh);
+      std::copy(x.begin(), x.end(), depth.begin() + static_cast<size_t>(k) * dw * dh);
+      float* c = cams.data() + static_cast<size_t>(k) * 9;
+      for (int i = 0; i < 3; ++i) c[i] = sf.extrinsics.position[i];
+      c[3] = sf.extrinsics.orientation.x_; c[4] = sf.extrinsics.orientation.y_; c[5] = sf.extrinsics.orientation.z_;
+      c[6] = sf.extrinsics.orientation.w_;
+      c[7] = sf.intrinsics.hFov; c[8] = sf.intrinsics.vFov;
+    }
+    const int count = last - first + 1;
+    std::vector<float> out(static_cast<size_t>(count) * w * h);
+    Session s;
+    s.h = cvd_create(device_);
+    if (!s.h) throw std::runtime_error(std::string("cvd_create: ") + cvd_last_error(nullptr));
+    s.check(cvd_flow_guided_filter(s.h, n, first - lo, count, h, w, dh, dw, video_->invAspect_, depth.data(), cams.data(),
+                                   ff.data(), mf.data(), fb.data(), mb.data(), p.frameRadius, p.spatialRadius, p.median ? 1 : 0,
+                                   out.data(), nullptr));
+    for (int k = 0; k < count; ++k) {  // dstDs.frame(frame).setDepth(filteredDepth), reference :585
+      DepthFrame& df = dst.frame(first + k);
+      checkDims(dst, w, h);
+      df.sourceDepth_.assign(out.begin() + static_cast<size_t>(k) * w * h, out.begin() + static_cast<size_t>(k + 1) * w * h);
+      df.triedLoad = true;
+    }
+  }
+
   void process(const DvpParams& p) {  // reference lib/Processor.cpp:115-144
     switch (p.op) {
       case Op::None: break;
       case Op::Reset: reset(p); break;
+      case Op::Copy: copy(p); break;
+      case Op::FlowGuidedFilter: flowGuidedFilter(p); break;
       case Op::GridXformSplit: gridXformSplit(p); break;
       case Op::ResetPoses: resetPoses(p); break;
       case Op::ResetDepthXforms: resetDepthXforms(p); break;

@@ -308,3 +308,56 @@ def test_constraints_are_sampled_from_the_flow_images_on_the_gpu(lib, tmp_path):
     assert fc2.numConstraints() == fc.numConstraints()
     fc2.setStaticFlagFromDynamicMask(3)
     fc2.resetStaticFlag()
+
+
+@pytest.mark.gpu
+def test_flow_guided_filter_op_matches_the_oracle(lib, tmp_path):
+    """filter_depth() of the reference (pose_optimization.py:295-325): Op.Copy then Op.FlowGuidedFilter with
+    frameRadius = radius, through the files of the dataset; result = the oracle's filter on the same arrays."""
+    from oracle.oracle import Oracle
+    from tests.filter_cases import make_case
+    F, W, H, R = 6, 48, 28, 2
+    v = synth.make_video(F, W, H, seed=54, spacing=8)
+    base = dataset_io.write_dataset(str(tmp_path / "v"), v)
+    c = make_case(F, W, H, seed=21)
+    pairs = [[k, k + 1] for k in range(F - 1)] + [[k + 1, k] for k in range(F - 1)]
+    flows = list(c["flow_fwd"]) + list(c["flow_bwd"])
+    masks = list(c["mask_fwd"]) + list(c["mask_bwd"])
+    dataset_io.write_flow_inputs(base, pairs, flows, masks, np.zeros((F, H, W, 3), np.float32))
+    dv = lib.DepthVideo()
+    lib.DepthVideoImporter.importVideo(dv, base, True)
+    dv.createDepthStream("depth_midas2", "depth_midas2", [W, H])
+    src = dv.depthStream(0)
+    for f in range(F):
+        fr = src.frame(f)
+        fr.setDepth(c["depth"][f])
+        e = fr.extrinsics
+        e.position = [float(x) for x in c["cameras"][f, :3]]
+        q = e.orientation
+        q.setCoeffs([float(x) for x in c["cameras"][f, 3:7]])
+        e.orientation = q
+        fr.extrinsics = e
+        i = fr.intrinsics
+        i.hFov, i.vFov = float(c["cameras"][f, 7]), float(c["cameras"][f, 8])
+        fr.intrinsics = i
+    dv.createDepthStream("filtered", "depth_filtered", [W, H])
+    proc = lib.DepthVideoProcessor(dv)
+    params = lib.DepthVideoProcessor.Params()
+    params.frameRange.fromString("1-4")
+    params.op = lib.DepthVideoProcessor.Op.Copy
+    params.sourceDepthStream, params.depthStream = 0, 1
+    proc.process(params)
+    assert np.array_equal(dv.depthStream(1).frame(2).depth(), c["depth"][2])
+    params.op = lib.DepthVideoProcessor.Op.FlowGuidedFilter
+    params.frameRadius = R
+    proc.process(params)
+    got = np.stack([dv.depthStream(1).frame(f).depth() for f in range(1, 5)])
+    inv_aspect = np.float32(dv.invAspect())
+    o = Oracle()
+    # batch = frames max(0, 1 - R) .. 4 = 0 .. 4, outputs 1 .. 4
+    ref = o.flow_guided_filter(c["depth"][:5], c["cameras"][:5], c["flow_fwd"][:4], c["mask_fwd"][:4], c["flow_bwd"][:4],
+                               c["mask_bwd"][:4], inv_aspect, R, first=1, count=4)
+    assert np.allclose(got, ref, rtol=2e-6, atol=0)
+    params.farConnections = True
+    with pytest.raises(RuntimeError, match="farConnections"):
+        proc.process(params)
