@@ -79,6 +79,10 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t
 /* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
 int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers,
                                     const int64_t* offsets, const float* loc6, const uint8_t* is_static);
+/* Dynamic masks of all frames, masks[F][height][width] u8 (the `dynamic_mask` colour stream; NULL forgets them):
+ * used by AdaptiveDeformationCost when params.adaptive_deformation_cost > 0 (reference lib/PoseOptimizer.cpp:559-656,
+ * 1449-1491; "Adaptive smoothness requires a dynamic mask stream." without them).  Call after cvd_set_video. */
+int32_t cvd_set_dynamic_masks(cvd_handle* h, int32_t height, int32_t width, const uint8_t* masks);
 
 /* ---- per-frame state (DepthFrame::{extrinsics,intrinsics,depthXform(),spatialXform()}) --------------- */
 int32_t cvd_set_poses(cvd_handle* h, const cvd_frame_pose* poses /* [F] */);

@@ -806,6 +806,64 @@ struct DeformationCost {
   }
 };
 
+// AdaptiveDeformationCost, reference lib/PoseOptimizer.cpp:559-656: vertex weights from the dynamic mask in the
+// constructor (:580-618), residuals of computeDeformationCost modulated in its enumeration order (:622-645)
+struct AdaptiveDeformationCost {
+  const Xform* xform;
+  double baseWeight, adaptiveWeight;
+  int gw, gh, gz;
+  std::vector<double> weights;  // gh x gw
+  AdaptiveDeformationCost(const Xform* x, const uint8_t* dynamicMask, int dw, int dh, double base, double adaptive)
+      : xform(x), baseWeight(base), adaptiveWeight(adaptive) {
+    if (x->desc.type != CVD_XFORM_DEPTH || x->desc.depth_type != CVD_DEPTH_GRID)
+      throw std::runtime_error("Adaptive deformation cost is only implemented for grid transforms.");
+    gw = x->desc.grid_size[0];
+    gh = x->desc.grid_size[1];
+    gz = std::max(1, x->desc.grid_size[2]);
+    std::vector<double> dynamicWeights(static_cast<size_t>(gw) * gh, 0.0), staticWeights(static_cast<size_t>(gw) * gh, 0.0);
+    for (int y = 0; y < dh; ++y) {
+      const double fy = double(y) * (gh - 1) / dh;
+      const int iy = int(fy);
+      const double ry = fy - iy;
+      for (int xx = 0; xx < dw; ++xx) {
+        const double fx = double(xx) * (gw - 1) / dw;
+        const int ix = int(fx);
+        const double rx = fx - ix;
+        std::vector<double>& w = dynamicMask[static_cast<size_t>(y) * dw + xx] > 127 ? staticWeights : dynamicWeights;
+        w[static_cast<size_t>(iy) * gw + ix] += (1.0 - rx) * (1.0 - ry);
+        w[static_cast<size_t>(iy) * gw + ix + 1] += rx * (1.0 - ry);
+        w[static_cast<size_t>(iy + 1) * gw + ix] += (1.0 - rx) * ry;
+        w[static_cast<size_t>(iy + 1) * gw + ix + 1] += rx * ry;
+      }
+    }
+    weights.resize(static_cast<size_t>(gw) * gh);
+    for (size_t i = 0; i < weights.size(); ++i) weights[i] = dynamicWeights[i] / (dynamicWeights[i] + staticWeights[i]);
+  }
+  template <typename T>
+  void operator()(T const* const* params, T* residuals) const {
+    xform->deformationCost(params, residuals);
+    // As written in the reference: ONE multiplication per edge, although computeGridDeformationCost emits blockSize
+    // residuals per edge.  With Scale (one parameter, the default) every residual gets its own edge's weight; with
+    // ScaleShift the first #edges residuals get the weights of edges 0 .. #edges-1 in enumeration order and the rest
+    // stay unscaled.  Restated literally.
+    int idx = 0;
+    for (int z = 0; z < gz; ++z)
+      for (int y = 0; y < gh; ++y)
+        for (int x = 0; x < gw; ++x) {
+          const double w0 = weights[static_cast<size_t>(y) * gw + x];
+          if (x > 0) {
+            const double w1 = weights[static_cast<size_t>(y) * gw + x - 1];
+            residuals[idx++] *= baseWeight + std::max(w0, w1) * adaptiveWeight;
+          }
+          if (y > 0) {
+            const double w1 = weights[static_cast<size_t>(y - 1) * gw + x];
+            residuals[idx++] *= baseWeight + std::max(w0, w1) * adaptiveWeight;
+          }
+          if (z > 0) residuals[idx++] *= baseWeight + w0 * adaptiveWeight;
+        }
+  }
+};
+
 // =====================================================================================================
 // ceres::Problem / evaluator restatement
 // =====================================================================================================
@@ -1378,6 +1436,8 @@ struct Oracle {
   std::vector<uint8_t> pairStatic;
 
   std::vector<float> sampledLoc, sampledTrip;  // results of cvdo_sample_pair / _triplet_constraints
+  std::vector<uint8_t> dynMasks;  // F * dynH * dynW (dynamic_mask stream), empty = none
+  int dynW = 0, dynH = 0;
   std::vector<int> tripletCenters;
   std::vector<int64_t> tripletOffsets;
   std::vector<float> tripletLoc;  // 6 per constraint
@@ -1751,8 +1811,9 @@ struct Oracle {
   }
 
   // addDepthDeformRegularization / addSpatialDeformRegularization, reference :1449-1522.
-  // (AdaptiveDeformationCost, :559-656, is off by default and not restated: SURVEY.md 8 a13.)
-  void addDeformRegularization(Problem& pb, const std::vector<int>& range, bool depthKind, double weight) {
+  // adaptive > 0 (depth transforms only): AdaptiveDeformationCost with the frame's dynamic mask, :1469-1484.
+  void addDeformRegularization(Problem& pb, const std::vector<int>& range, bool depthKind, double weight,
+                               double adaptive = 0.0) {
     for (int f : range) {
       Xform& x = depthKind ? depthXforms[f] : spatialXforms[f];
       if (x.numDeformationResiduals() <= 0) continue;
@@ -1762,10 +1823,19 @@ struct Oracle {
         rb.blocks.push_back(depthKind ? depthBlock(pb, f, k) : spatialBlock(pb, f, k));
         sizes.push_back(x.blockSize);
       }
-      auto cf = std::make_unique<AutoDiff<DeformationCost>>(DeformationCost{&x, weight});
-      cf->numResiduals = x.numDeformationResiduals();
-      cf->blockSizes = sizes;
-      rb.cost = std::move(cf);
+      if (depthKind && adaptive > 0.0) {
+        if (dynMasks.empty()) throw std::runtime_error("Adaptive smoothness requires a dynamic mask stream.");
+        auto cf = std::make_unique<AutoDiff<AdaptiveDeformationCost>>(AdaptiveDeformationCost(
+            &x, dynMasks.data() + static_cast<size_t>(f) * dynW * dynH, dynW, dynH, weight, adaptive));
+        cf->numResiduals = x.numDeformationResiduals();
+        cf->blockSizes = sizes;
+        rb.cost = std::move(cf);
+      } else {
+        auto cf = std::make_unique<AutoDiff<DeformationCost>>(DeformationCost{&x, weight});
+        cf->numResiduals = x.numDeformationResiduals();
+        cf->blockSizes = sizes;
+        rb.cost = std::move(cf);
+      }
       rb.lossKind = LOSS_NONE;
       pb.residuals.push_back(std::move(rb));
     }
@@ -1789,8 +1859,6 @@ struct Oracle {
 
   // Problem of poseOptimizationStep, reference lib/PoseOptimizer.cpp:890-952
   void buildPoseProblem(Problem& pb, const cvd_opt_params& p, double depthDeformReg) {
-    if (p.adaptive_deformation_cost > 0.0)
-      throw std::runtime_error("AdaptiveDeformationCost is not restated in the oracle.");
     const std::vector<int> range = rangeOf(p, F);
     std::vector<char> inRange(F, 0);
     for (int f : range) inRange[f] = 1;
@@ -1798,7 +1866,7 @@ struct Oracle {
     if (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0)
       addSceneFlowSmoothnessLoss(pb, p, range, inRange);
     if (p.position_reg > 0.0) addPositionRegularization(pb, p, range, inRange);
-    if (depthDeformReg > 0.0) addDeformRegularization(pb, range, true, depthDeformReg);
+    if (depthDeformReg > 0.0) addDeformRegularization(pb, range, true, depthDeformReg, p.adaptive_deformation_cost);
     if (p.spatial_deform_reg > 0.0) addDeformRegularization(pb, range, false, p.spatial_deform_reg);
     if (p.fix_poses)
       for (int f : range) pb.setConstant(poseParams[f].data());
@@ -1920,7 +1988,8 @@ struct Oracle {
       }
     }
     if (p.scale_reg > 0.0) addScaleRegularization(pb, p, range);
-    if (p.depth_deform_reg_initial > 0.0) addDeformRegularization(pb, range, true, p.depth_deform_reg_initial);
+    if (p.depth_deform_reg_initial > 0.0)
+      addDeformRegularization(pb, range, true, p.depth_deform_reg_initial, p.adaptive_deformation_cost);
     for (int f : range) {
       Xform& x = depthXforms[f];
       for (int k = 0; k < x.numBlocks; ++k)
@@ -2023,6 +2092,17 @@ int cvdo_set_pair_constraints(void* h, int numPairs, const int32_t* pairFrames, 
     o->pairLoc.assign(loc4, loc4 + 4 * C);
     if (isStatic) o->pairStatic.assign(isStatic, isStatic + C);
     else o->pairStatic.assign(C, 1);
+  });
+}
+int cvdo_set_dynamic_masks(void* h, int height, int width, const uint8_t* masks) {
+  Oracle* o = static_cast<Oracle*>(h);
+  CVDO_TRY(h, {
+    o->dynMasks.clear();
+    if (masks) {
+      o->dynW = width;
+      o->dynH = height;
+      o->dynMasks.assign(masks, masks + static_cast<size_t>(o->F) * width * height);
+    }
   });
 }
 int cvdo_set_triplet_constraints(void* h, int numTriplets, const int32_t* centers, const int64_t* offsets,

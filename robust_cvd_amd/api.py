@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
-    "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
+    "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
     "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
 ]
 

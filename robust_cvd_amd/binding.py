@@ -250,6 +250,15 @@ class Binding:
             self._check(self._fn("get_sampled_triplet_constraints")(self._h, _ptr(loc, C.c_float)))
         return off, loc
 
+    def set_dynamic_masks(self, masks):
+        """Dynamic masks of all frames [F, h, w] u8 (None forgets them): input of AdaptiveDeformationCost."""
+        if masks is None:
+            self._check(self._fn("set_dynamic_masks")(self._h, C.c_int(0), C.c_int(0), None))
+            return
+        mk = np.ascontiguousarray(masks, dtype=np.uint8)
+        assert mk.ndim == 3 and mk.shape[0] == self.num_frames, mk.shape
+        self._check(self._fn("set_dynamic_masks")(self._h, C.c_int(mk.shape[1]), C.c_int(mk.shape[2]), _ptr(mk, C.c_uint8)))
+
     # -- image operators in front of the sampler (SURVEY.md 8 f1) ---------------------------------------
     def corner_min_eigenval(self, bgr, timing=False):
         """cvtColor(BGR2GRAY) + cornerMinEigenVal(blockSize 3) of float BGR images [n, H, W, 3] -> [n, H, W] float32."""

@@ -47,6 +47,10 @@ struct Layout {
   double positionRegSqrt;  // sqrt(positionReg), 0 => off
   int firstFrame, lastFrame;
   int rank, world;         // residual k of a per-frame / per-triple regulariser belongs to rank k % world
+  // AdaptiveDeformationCost (reference lib/PoseOptimizer.cpp:559-656): per-frame grid-vertex weights [F][gx * gy]
+  // (dynamic fraction of the mask pixels splatted onto each vertex), nullptr => plain DeformationCost
+  const double* adaptW;
+  double adaptive;         // params.adaptiveDeformationCost
 };
 
 // cvd enums duplicated as plain ints to keep this header free of host headers.
@@ -557,7 +561,7 @@ __device__ __forceinline__ int numRegResiduals(const Layout& L) {
 
 // Evaluates regulariser residual `i` of a frame. cols/jac have room for 2*KD (>= 2) entries.
 template <int KD>
-__device__ __forceinline__ void regResidual(const Layout& L, int i, const double* __restrict__ xf, float median,
+__device__ __forceinline__ void regResidual(const Layout& L, int f, int i, const double* __restrict__ xf, float median,
                                             double& r, int& n, int* cols, double* jac) {
   constexpr double eps = 1e-6;
   n = 0;
@@ -628,14 +632,47 @@ __device__ __forceinline__ void regResidual(const Layout& L, int i, const double
       const bool pickB = ab < aa;  // min(|a|, |b|): ties keep |a|
       const double sc = pickB ? ab : aa;
       const double diff = a - b;
-      r = L.depthDeformW * diff / sc;
+      double wgt = L.depthDeformW;
+      if (L.adaptW != nullptr) {
+        // AdaptiveDeformationCost::operator(), reference lib/PoseOptimizer.cpp:622-645, literally: residual number R
+        // of computeGridDeformationCost's enumeration (vertices row-major; per vertex the x-edge, then the y-edge;
+        // N residuals per edge) is multiplied by base + max(w) * adaptive of EDGE number R while R < #edges, and is
+        // left unscaled beyond (the reference advances its index once per edge, not once per residual).  With one
+        // value parameter (Scale) R is the residual's own edge.
+        const bool xEdge = (vb == va - 1);
+        const int vy = va / L.gx, vx = va - vy * L.gx;
+        const int rowStart = vy == 0 ? 0 : (L.gx - 1) + (vy - 1) * (2 * L.gx - 1);
+        const int ord = vy == 0 ? vx - 1 : rowStart + (xEdge ? 2 * vx - 1 : (vx == 0 ? 0 : 2 * vx));
+        const int R = ord * L.N + dim;
+        const int numEdges = (L.gx - 1) * L.gy + L.gx * (L.gy - 1);
+        if (R < numEdges) {
+          int ey, ex;
+          bool ex_is_x;
+          if (R < L.gx - 1) {
+            ey = 0; ex = R + 1; ex_is_x = true;
+          } else {
+            const int q0 = R - (L.gx - 1);
+            ey = 1 + q0 / (2 * L.gx - 1);
+            const int q = q0 - (ey - 1) * (2 * L.gx - 1);
+            if (q == 0) { ex = 0; ex_is_x = false; }
+            else { ex = (q + 1) >> 1; ex_is_x = (q & 1) != 0; }
+          }
+          const double* vw = L.adaptW + static_cast<size_t>(f) * L.gx * L.gy;
+          const double w0 = vw[ey * L.gx + ex];
+          const double w1 = ex_is_x ? vw[ey * L.gx + ex - 1] : vw[(ey - 1) * L.gx + ex];
+          wgt = L.depthDeformW + (w0 < w1 ? w1 : w0) * L.adaptive;  // std::max(w0, w1)
+        } else {
+          wgt = 1.0;
+        }
+      }
+      r = wgt * diff / sc;
       const double dsda = pickB ? 0.0 : (a < 0.0 ? -1.0 : 1.0);
       const double dsdb = pickB ? (b < 0.0 ? -1.0 : 1.0) : 0.0;
       n = 2;
       cols[0] = 7 + va * L.N + dim;
-      jac[0] = L.depthDeformW * (1.0 / sc - diff / (sc * sc) * dsda);
+      jac[0] = wgt * (1.0 / sc - diff / (sc * sc) * dsda);
       cols[1] = 7 + vb * L.N + dim;
-      jac[1] = L.depthDeformW * (-1.0 / sc - diff / (sc * sc) * dsdb);
+      jac[1] = wgt * (-1.0 / sc - diff / (sc * sc) * dsdb);
       return;
     }
     i -= nEdges;

@@ -323,6 +323,12 @@ struct cvd_handle_t {
   DevBuf<float> dImgIn, dImgGray, dImgCov, dImgOut;  // cvd_imageops.h staging
   DevBuf<unsigned char> dImgMask;
   DevBuf<unsigned int> dImgTmp;
+  // AdaptiveDeformationCost: dynamic masks of all frames (cvd_set_dynamic_masks) and the vertex weights of the
+  // current depth grid
+  DevBuf<unsigned char> dDynMask;
+  DevBuf<double> dAdaptW;
+  int dynW = 0, dynH = 0, adaptGx = 0, adaptGy = 0;
+  bool haveDynMasks = false;
   DevBuf<float> dFltDepth, dFltOut, dFltFlowF, dFltFlowB;  // cvd_filter.h staging
   DevBuf<unsigned char> dFltMaskF, dFltMaskB;
   DevBuf<FilterCam> dFltCams;
@@ -568,8 +574,6 @@ static void gridXformSplit(cvd_handle* h, const cvd_xform_desc& nd) {
 
 // ---- problem -> device layout -------------------------------------------------------------------------
 static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
-  if (p.adaptive_deformation_cost > 0.0)
-    throw std::runtime_error("AdaptiveDeformationCost is not implemented (off by default in the reference).");
   if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP) {
     if (p.smooth_loss_type != CVD_SMOOTH_EUCLIDEAN_LAPLACIAN && p.smooth_loss_type != CVD_SMOOTH_REPRO_DISPARITY_LAPLACIAN)
       throw std::runtime_error("Scene-flow smoothness: only EuclideanLaplacian and ReproDisparityLaplacian are implemented "
@@ -637,6 +641,25 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   }
   if (L.scaleRegSqrt > 0.0 && (L.sregX < 2 || L.sregY < 2))
     throw std::runtime_error("scaleRegGridSize too small for this aspect ratio.");
+  // AdaptiveDeformationCost replaces DeformationCost for the depth transforms that have deformation residuals, i.e.
+  // grids (reference lib/PoseOptimizer.cpp:1465-1484: the others are skipped before the cost is constructed)
+  L.adaptW = nullptr;
+  L.adaptive = 0.0;
+  if (p.adaptive_deformation_cost > 0.0 && L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) {
+    if (!h->haveDynMasks) throw std::runtime_error("Adaptive smoothness requires a dynamic mask stream.");
+    if (L.gx < 2 || L.gy < 2) throw std::runtime_error("Adaptive deformation cost needs a grid of at least 2 x 2 vertices.");
+    if (h->adaptGx != L.gx || h->adaptGy != L.gy) {
+      const size_t G = static_cast<size_t>(L.gx) * L.gy;
+      h->dAdaptW.ensure(G * h->F);
+      hipLaunchKernelGGL(k_adaptive_weights, dim3(h->F), dim3(256), 2 * G * sizeof(double), h->stream, h->dDynMask.p, h->dynW,
+                         h->dynH, L.gx, L.gy, h->dAdaptW.p);
+      HIP_CHECK(hipGetLastError());
+      h->adaptGx = L.gx;
+      h->adaptGy = L.gy;
+    }
+    L.adaptW = h->dAdaptW.p;
+    L.adaptive = p.adaptive_deformation_cost;
+  }
   return L;
 }
 
@@ -2430,6 +2453,8 @@ int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t h
   CVD_TRY(h, {
     if (numFrames <= 0 || width <= 0 || height <= 0) throw std::runtime_error("invalid video dimensions");
     h->F = numFrames; h->W = width; h->H = height; h->aspect = aspect; h->invAspect = invAspect;
+    h->haveDynMasks = false;
+    h->adaptGx = h->adaptGy = 0;
     h->dDepth.ensure(static_cast<size_t>(numFrames) * width * height);
     HIP_CHECK(hipMemsetAsync(h->dDepth.p, 0, static_cast<size_t>(numFrames) * width * height * sizeof(float), h->stream));
     h->median.assign(numFrames, 0.f);
@@ -2656,6 +2681,19 @@ int32_t cvd_depth_param_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrame
 int32_t cvd_spatial_warp_maps(cvd_handle* h, int32_t firstFrame, int32_t numFrames, int32_t height, int32_t width,
                               float* out, double* kernelMs) {
   CVD_TRY(h, denseMaps(h, 2, firstFrame, numFrames, width, height, out, kernelMs));
+}
+int32_t cvd_set_dynamic_masks(cvd_handle* h, int32_t height, int32_t width, const uint8_t* masks) {
+  CVD_TRY(h, {
+    h->adaptGx = h->adaptGy = 0;
+    if (!masks) { h->haveDynMasks = false; return 0; }
+    if (h->F <= 0) throw std::runtime_error("no video set");
+    if (width < 1 || height < 1) throw std::runtime_error("invalid mask size");
+    h->dDynMask.upload(masks, static_cast<size_t>(h->F) * width * height, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->dynW = width;
+    h->dynH = height;
+    h->haveDynMasks = true;
+  });
 }
 int32_t cvd_corner_min_eigenval(cvd_handle* h, int32_t numImages, int32_t height, int32_t width, const float* bgr,
                                 float* out, double* kernelMs) {

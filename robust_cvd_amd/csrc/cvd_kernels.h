@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_cost_frames(Layout L, const double* __re
       int n;
       int cols[2 * KD + 2];
       double jac[2 * KD + 2];
-      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
       acc += r * r;
     }
   }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
       int n;
       int cols[2 * KD + 2];
       double jac[2 * KD + 2];
-      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
       regCost += r * r;
       for (int a = 0; a < n; ++a) {
         atomicAdd(&gs[cols[a]], jac[a] * r);
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __res
     int n;
     int cols[2 * KD + 2];
     double jac[2 * KD + 2];
-    regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+    regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
     rc.cnt[static_cast<size_t>(f) * rc.nr + i] = static_cast<unsigned char>(n);
     for (int a = 0; a < n; ++a) {
       const size_t e = (static_cast<size_t>(f) * rc.stride + a) * rc.nr + i;
@@ -1125,13 +1125,16 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const int e1 = cs.wtPtr[f + 1];
     int e = cs.wtPtr[f] + wv;
-    for (; e + 3 * nWv < e1; e += 4 * nWv) {  // four independent gathers in flight per wave
-      a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
-      a1 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + nWv] * kCB + c8];
-      a2 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + 2 * nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + 2 * nWv] * kCB + c8];
-      a3 += cs.Wb[static_cast<size_t>(cs.wtBlk[e + 3 * nWv]) * 64 + lane] * cs.qc[cs.wtFrame[e + 3 * nWv] * kCB + c8];
+    // eight independent gathers in flight per wave: the rows of the frames near the root of the elimination tree are
+    // the kernel's critical path (the root's row holds one block per frame)
+    auto term = [&](int k) { return cs.Wb[static_cast<size_t>(cs.wtBlk[k]) * 64 + lane] * cs.qc[cs.wtFrame[k] * kCB + c8]; };
+    for (; e + 7 * nWv < e1; e += 8 * nWv) {
+      const double t0 = term(e), t1 = term(e + nWv), t2 = term(e + 2 * nWv), t3 = term(e + 3 * nWv);
+      const double t4 = term(e + 4 * nWv), t5 = term(e + 5 * nWv), t6 = term(e + 6 * nWv), t7 = term(e + 7 * nWv);
+      a0 += t0; a1 += t1; a2 += t2; a3 += t3;
+      a0 += t4; a1 += t5; a2 += t6; a3 += t7;
     }
-    for (; e < e1; e += nWv) a0 += cs.Wb[static_cast<size_t>(cs.wtBlk[e]) * 64 + lane] * cs.qc[cs.wtFrame[e] * kCB + c8];
+    for (; e < e1; e += nWv) a0 += term(e);
     double ya = (a0 + a1) + (a2 + a3);
     ya += dppMove<0xB1>(ya);
     ya += dppMove<0x4E>(ya);
@@ -2086,7 +2089,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
       int n;
       int cols[2 * KD + 2];
       double jac[2 * KD + 2];
-      regResidual<KD>(L, i, xf, median[f], r, n, cols, jac);
+      regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
       regCost += r * r;
       for (int a = 0; a < n; ++a) {
         atomicAdd(&gs[cols[a]], jac[a] * r);
@@ -2157,6 +2160,37 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
     hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
   }
   if (tid == 0) ASM_STAMP(12);
+}
+
+// AdaptiveDeformationCost constructor (reference lib/PoseOptimizer.cpp:560-618): every mask pixel is splatted bilinearly
+// onto the four surrounding grid vertices, into the static (mask > 127) or the dynamic sums; vertex weight = dynamic /
+// (dynamic + static).  One workgroup per frame, LDS accumulators (the sums are order-dependent only in the last bits).
+__global__ __launch_bounds__(256) void k_adaptive_weights(const unsigned char* __restrict__ masks, int dw, int dh, int gw,
+                                                          int gh, double* __restrict__ weights) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int G = gw * gh;
+  double* dyn = sm;
+  double* sta = sm + G;
+  const int f = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sm[i] = 0.0;
+  __syncthreads();
+  const unsigned char* m = masks + static_cast<size_t>(f) * dw * dh;
+  for (int p = threadIdx.x; p < dw * dh; p += blockDim.x) {
+    const int y = p / dw, x = p - y * dw;
+    const double fy = static_cast<double>(y) * (gh - 1) / dh;
+    const int iy = static_cast<int>(fy);
+    const double ry = fy - iy;
+    const double fx = static_cast<double>(x) * (gw - 1) / dw;
+    const int ix = static_cast<int>(fx);
+    const double rx = fx - ix;
+    double* w = m[p] > 127 ? sta : dyn;
+    atomicAdd(&w[iy * gw + ix], (1.0 - rx) * (1.0 - ry));
+    atomicAdd(&w[iy * gw + ix + 1], rx * (1.0 - ry));
+    atomicAdd(&w[(iy + 1) * gw + ix], (1.0 - rx) * ry);
+    atomicAdd(&w[(iy + 1) * gw + ix + 1], rx * ry);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G; i += blockDim.x) weights[static_cast<size_t>(f) * G + i] = dyn[i] / (dyn[i] + sta[i]);
 }
 
 }  // namespace cvd

@@ -1228,6 +1228,27 @@ struct DepthVideoProcessor {
       q.hfov = df.intrinsics.hFov;
     }
     s.check(cvd_set_poses(s.h, poses.data()));
+    if (p.poseOptimizer.adaptiveDeformationCost > 0.0 && video_->hasColorStream("dynamic_mask")) {
+      // AdaptiveDeformationCost reads the frame's dynamic mask (reference lib/PoseOptimizer.cpp:1469-1481); without the
+      // stream the solver raises the reference's "Adaptive smoothness requires a dynamic mask stream."
+      const ColorStream& ms = *video_->colorStreams_.at(video_->colorStreamIndex("dynamic_mask"));
+      std::vector<uint8_t> masks;
+      int mw = 0, mh = 0;
+      for (int f = 0; f < F; ++f) {
+        const bool need = p.poseOptimizer.frameRange.frames.empty() || p.poseOptimizer.frameRange.frames.count(f);
+        const std::string fn = ms.path_ + "/frame_" + fmtInt6(f) + ms.extension_;
+        if (!fileExists(fn)) {
+          if (need) throw std::runtime_error("Dynamic mask stream is missing a frame.");
+          continue;
+        }
+        int r, c;
+        const std::vector<uint8_t> m = FlowConstraintsCollection::readPngGray(fn, r, c);
+        if (masks.empty()) { mw = c; mh = r; masks.assign(static_cast<size_t>(F) * mw * mh, 255); }
+        if (c != mw || r != mh) throw std::runtime_error("Dynamic masks have inconsistent sizes.");
+        std::copy(m.begin(), m.end(), masks.begin() + static_cast<size_t>(f) * mw * mh);
+      }
+      if (!masks.empty()) s.check(cvd_set_dynamic_masks(s.h, mh, mw, masks.data()));
+    }
     std::vector<int32_t> pf;
     std::vector<int64_t> off{0};
     std::vector<float> loc;
