@@ -575,9 +575,8 @@ static void gridXformSplit(cvd_handle* h, const cvd_xform_desc& nd) {
 // ---- problem -> device layout -------------------------------------------------------------------------
 static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
   if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP) {
-    if (p.smooth_loss_type != CVD_SMOOTH_EUCLIDEAN_LAPLACIAN && p.smooth_loss_type != CVD_SMOOTH_REPRO_DISPARITY_LAPLACIAN)
-      throw std::runtime_error("Scene-flow smoothness: only EuclideanLaplacian and ReproDisparityLaplacian are implemented "
-                               "on the device path.");
+    if (p.smooth_loss_type < CVD_SMOOTH_EUCLIDEAN_LAPLACIAN || p.smooth_loss_type > CVD_SMOOTH_REPRO_LOG_DEPTH_CONSISTENCY)
+      throw std::runtime_error("Invalid loss type.");
     if (p.intr_opt == CVD_INTR_SHARED)
       throw std::runtime_error("Scene-flow smoothness with IntrinsicsOptimization::Shared is not implemented on the "
                                "device path.");
@@ -1667,7 +1666,7 @@ static void bindTriplets(Ctx& c, const cvd_opt_params& p, ProblemKind kind) {
   if (!c.trip) return;
   c.TT = TripletTable{h->dTNdc.p, h->dTDsrc.p, h->dTStatic.p, h->dTOff.p, h->dTCenter.p, h->dTSlot.p,
                       static_cast<int>(h->tripActive.size()),
-                      p.smooth_loss_type == CVD_SMOOTH_EUCLIDEAN_LAPLACIAN ? kSmoothEuclidLaplacian : kSmoothDisparityLaplacian,
+                      static_cast<int>(p.smooth_loss_type),  // (CVD_SMOOTH_* == kSmooth*)
                       std::sqrt(std::max(0.0, p.smooth_static_weight)), std::sqrt(std::max(0.0, p.smooth_dynamic_weight))};
 }
 

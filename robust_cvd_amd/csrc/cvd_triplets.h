@@ -32,7 +32,7 @@ struct TripletTable {
   double wStaticSqrt, wDynamicSqrt;
 };
 
-enum : int { kSmoothEuclidLaplacian = 0, kSmoothDisparityLaplacian = 1 };
+enum : int { kSmoothEuclidLaplacian = 0, kSmoothDisparityLaplacian = 1, kSmoothDepthRatio = 2, kSmoothLogDepth = 3 };
 
 template <int KD, int KS>
 struct TripletSample {
@@ -150,8 +150,37 @@ __device__ __forceinline__ void evalTriplet(const Layout& L, int smoothType, con
     }
     return;
   }
-  // ReproDisparityLaplacian: frames 0 and 2 reprojected into frame 1
+  // Reprojection variants: frames 0 and 2 reprojected into frame 1.  Rows 0 / 1 are the same for all three; row 2 is
+  // the disparity Laplacian, or the consistency of D_1 with z_0->1 + z_2->1 - D_1 (depth ratio / log depth,
+  // reference lib/PoseOptimizer.cpp:393-408).
   Side<KD, KS>& s1 = T.s[1];
+  // consistency variants: r_2 = h(base, other), base = D_1, other = z_0 + z_2 - D_1; ga = dh/dbase, gb = dh/dother
+  // (Jet max / min: max(f, g) = f < g ? g : f, min(f, g) = g < f ? g : f)
+  double consGa = 0.0, consGb = 0.0, consR = 0.0;
+  if (smoothType != kSmoothDisparityLaplacian) {
+    double other = -D[1];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = q ? 2 : 0;
+      const double v[3] = {Xw[k][0] - F1.t[0], Xw[k][1] - F1.t[1], Xw[k][2] - F1.t[2]};
+      other += -(F1.R[2] * v[0] + F1.R[5] * v[1] + F1.R[8] * v[2]);
+    }
+    const double base = D[1];
+    const bool baseIsMax = !(base < other), baseIsMin = !(other < base);
+    const double mx = baseIsMax ? base : other, mn = baseIsMin ? base : other;
+    double dmx, dmn;
+    if (smoothType == kSmoothDepthRatio) {
+      consR = mx / mn - 1.0;
+      dmx = 1.0 / mn;
+      dmn = -mx / (mn * mn);
+    } else {
+      consR = log(mn / mx);
+      dmn = 1.0 / mn;
+      dmx = -1.0 / mx;
+    }
+    consGa = (baseIsMax ? dmx : 0.0) + (baseIsMin ? dmn : 0.0);
+    consGb = (baseIsMax ? 0.0 : dmx) + (baseIsMin ? 0.0 : dmn);
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -177,8 +206,9 @@ __device__ __forceinline__ void evalTriplet(const Layout& L, int smoothType, con
     vsum += w;
     dsum += zo ? iz : 1.0 / eps;
     // d r / d q: rows of M
-    const double M[3][3] = {{iz * ifx * ify, 0.0, u * iz * ify}, {0.0, iz * ify * ify, w * iz * ify},
-                            {0.0, 0.0, zo ? iz * iz : 0.0}};
+    // (row 2: d(1/z)/dq_2 = 1/z^2 for the disparity Laplacian; z = -q_2 enters `other` with weight 1 otherwise)
+    const double m22 = smoothType == kSmoothDisparityLaplacian ? (zo ? iz * iz : 0.0) : -consGb;
+    const double M[3][3] = {{iz * ifx * ify, 0.0, u * iz * ify}, {0.0, iz * ify * ify, w * iz * ify}, {0.0, 0.0, m22}};
     double G[3][3];  // M R1^T
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -215,12 +245,12 @@ __device__ __forceinline__ void evalTriplet(const Layout& L, int smoothType, con
   const bool bo = !(D[1] < eps);
   T.r[0] = (usum - 2.0 * p[1][0]) * ify;
   T.r[1] = (vsum - 2.0 * p[1][1]) * ify;
-  T.r[2] = dsum - 2.0 * (bo ? 1.0 / D[1] : 1.0 / eps);
+  T.r[2] = smoothType == kSmoothDisparityLaplacian ? dsum - 2.0 * (bo ? 1.0 / D[1] : 1.0 / eps) : consR;
   // frame 1's own dependence: fy1 (inside u, v through fx1 = A fy1 and fy1, and the outer division), D1, p1
   s1.Jp[0][6] = -(usum * ify + T.r[0]) * ify;
   s1.Jp[1][6] = -(vsum * ify + T.r[1]) * ify;
   s1.Jp[2][6] = 0.0;
-  s1.JD[2] = bo ? 2.0 / (D[1] * D[1]) : 0.0;
+  s1.JD[2] = smoothType == kSmoothDisparityLaplacian ? (bo ? 2.0 / (D[1] * D[1]) : 0.0) : consGa - consGb;
   s1.JP[0][0] = -2.0 * ify;
   s1.JP[1][1] = -2.0 * ify;
 }

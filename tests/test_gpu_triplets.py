@@ -35,7 +35,9 @@ def _params(smooth_type, ws=2.0, wd=0.5):
     return p
 
 
-@pytest.mark.parametrize("smooth_type", [SmoothLossType.ReproDisparityLaplacian, SmoothLossType.EuclideanLaplacian])
+@pytest.mark.parametrize("smooth_type", [SmoothLossType.ReproDisparityLaplacian, SmoothLossType.EuclideanLaplacian,
+                                         SmoothLossType.ReproDepthRatioConsistency,
+                                         SmoothLossType.ReproLogDepthConsistency])
 @pytest.mark.parametrize("variant", ["grid3x2", "global_bilinear_spatial", "cubic4x4_scaleshift"])
 def test_triplet_cost_gradient_hessian_match_oracle(Solver, smooth_type, variant):
     F = 6
@@ -153,7 +155,8 @@ def test_unsupported_triplet_configurations_fail_loudly(Solver):
     s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
     pose = np.zeros((5, 7)); pose[:, 6] = 0.2
     p = _params(SmoothLossType.ReproDepthRatioConsistency)
-    with pytest.raises(RuntimeError, match="only EuclideanLaplacian and ReproDisparityLaplacian"):
+    p.smooth_loss_type = 7
+    with pytest.raises(RuntimeError, match="Invalid loss type"):     # reference lib/PoseOptimizer.cpp:407
         s.evaluate(p, 0.0, pose)
     p = _params(SmoothLossType.ReproDisparityLaplacian)
     p.intr_opt = IntrinsicsOptimization.Shared
