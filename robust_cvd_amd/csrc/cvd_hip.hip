@@ -1098,7 +1098,8 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     }
     int activeFrames = 0;
     for (int f = 0; f < h->F; ++f) activeFrames += inRange[f] ? 1 : 0;
-    const long long denom = std::max<long long>(1, std::max(activeFrames, h->numCU));
+    static const double partsPerCU = []() { const char* e = std::getenv("CVD_ASM_PARTS_PER_CU"); return e ? std::atof(e) : 1.0; }();
+    const long long denom = std::max<long long>(1, std::max<long long>(activeFrames, static_cast<long long>(partsPerCU * h->numCU)));
     const int capU = static_cast<int>(std::max<long long>(kAsmThreads / 64, (static_cast<long long>(units.size()) + denom - 1) / denom));
     std::vector<AsmPart> parts;
     int slots = 0;
@@ -1426,15 +1427,24 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const double* maskp = h->dMask.p;
     const double* scalp = h->dScal.p;
     if (fast) {
-      CVD_DISPATCH_KD(c.KD, {
-        allowLds(k_matvec_pairs_fast<KD>, ldsFast);
-        if (evStart)
-          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD>), dim3(c.nItems), dim3(256), ldsFast, s, evStart, evStop, 0, c.L,
-                                c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-        else
-          hipLaunchKernelGGL((k_matvec_pairs_fast<KD>), dim3(c.nItems), dim3(256), ldsFast, s, c.L, c.T, c.it, x, fcp,
-                             maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-      });
+      // Workgroup size: a work item keeps its slot for ~20 us at 256 threads and the register budget allows two
+      // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When all items fit into one
+      // round of 128-thread workgroups the launch has no ragged second round (benchmark: 883 items, 46 -> 3x us).
+      static const int forcedNT = []() { const char* e = std::getenv("CVD_PAIRS_NT"); return e ? std::atoi(e) : 0; }();
+      const int nt = forcedNT ? forcedNT : (c.nItems <= 4 * h->numCU ? 128 : 256);
+#define CVD_LAUNCH_PAIRS_FAST(NTV)                                                                                       \
+      CVD_DISPATCH_KD(c.KD, {                                                                                            \
+        allowLds((k_matvec_pairs_fast<KD, NTV>), ldsFast);                                                               \
+        if (evStart)                                                                                                     \
+          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV>), dim3(c.nItems), dim3(NTV), ldsFast, s, evStart, evStop, 0, \
+                                c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                \
+        else                                                                                                             \
+          hipLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV>), dim3(c.nItems), dim3(NTV), ldsFast, s, c.L, c.T, c.it, x,   \
+                             fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                                      \
+      })
+      if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
+      else CVD_LAUNCH_PAIRS_FAST(256);
+#undef CVD_LAUNCH_PAIRS_FAST
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_matvec_pairs<KD, KS>, lds);
@@ -1740,7 +1750,10 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
   int invalid = 0, iteration = 0, termination = 1;
-  constexpr int kCoarseRebuildIters = 16;
+  static const int kCoarseRebuildIters = []() {
+    const char* e = std::getenv("CVD_COARSE_REBUILD_ITERS");  // development knob
+    return e ? std::max(1, std::atoi(e)) : 16;
+  }();
   int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
   bool scaleDone = false;
   cvd_iteration_record r0{};

@@ -757,22 +757,39 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
-  // coarse part of the preconditioned residual of the two frames (one wave each), see CoarseView
-  if (V.Wb != nullptr) {
+  // Prologue in ONE global round trip (the workgroup lives ~5 us, a dependent load costs ~1 us of it): every thread
+  // issues its loads of x / z / p_old / mask for both frames, the coarse correction c_f (see CoarseView) and the
+  // frame constants go to LDS in the same phase, and the search direction is formed after the barrier.  B <= 256:
+  // one element per thread.
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (V.Wb != nullptr) {  // (fused coarse variant: the correction is gathered here, one wave per frame)
     if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
     else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
   } else if (tid < 2 * kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
   }
-  __syncthreads();
+  if (tid >= 256 - 2 * FCW) {  // (the last waves: the first ones carry the coarse loads)
+    const int t = tid - (256 - 2 * FCW);
+    const int which = t / FCW, k = t % FCW;
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  double vza = 0.0, vzb = 0.0, vpa = 0.0, vpb = 0.0, vma = 0.0, vmb = 0.0;
   for (int i = tid; i < B; i += 256) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
     xa[i] = x[ia];
     xb[i] = x[ib];
-    pa[i] = (z[ia] + coarseAtLds(cl, L, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    vza = z[ia];
+    vzb = z[ib];
+    if (useBeta) { vpa = pOld[ia]; vpb = pOld[ib]; }
+    vma = mask[ia];
+    vmb = mask[ib];
     qa[i] = 0.0;
     qb[i] = 0.0;
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += 256) {
+    pa[i] = (vza + coarseAtLds(cl, L, i) + (useBeta ? beta * vpa : 0.0)) * vma;
+    pb[i] = (vzb + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * vpb : 0.0)) * vmb;
   }
   if (L.intrOpt == kIntrShared) {
     // every constraint's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1226)
@@ -782,11 +799,6 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
       pa[6] = p06;
       pb[6] = p06;
     }
-  }
-  constexpr int FCW = sizeof(FrameConst) / 8;
-  if (tid < 2 * FCW) {
-    const int which = tid / FCW, k = tid % FCW;
-    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
   }
   __syncthreads();
   for (int dir = 0; dir < 2; ++dir) {
@@ -1350,10 +1362,10 @@ __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, 
 }
 
 constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
-constexpr int kRedStride = 8 * 33 + 1;     // 256 columns in 33-padded segments of 32, +1 to skew the rows
+constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 
-template <int KD>
-__global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+template <int KD, int NT>
+__global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
@@ -1379,22 +1391,49 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
-  // coarse part of the preconditioned residual of the two frames (one wave each), see CoarseView
-  if (V.Wb != nullptr) {
+  // Prologue in ONE global round trip (the workgroup lives ~5 us, a dependent load costs ~1 us of it): every thread
+  // issues its loads of x / z / p_old / mask for both frames, the coarse correction c_f (see CoarseView) and the
+  // frame constants go to LDS in the same phase, and the search direction is formed after the barrier.  B <= 256:
+  // one element per thread.
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (V.Wb != nullptr) {  // (fused coarse variant: the correction is gathered here, one wave per frame)
     if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
     else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
   } else if (tid < 2 * kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
   }
+  if (tid >= NT - 2 * FCW) {  // (the last waves: the first ones carry the coarse loads)
+    const int t = tid - (NT - 2 * FCW);
+    const int which = t / FCW, k = t % FCW;
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  constexpr int EPT = 256 / NT;  // elements of a frame block per thread (B <= 256)
+  double vza[EPT], vzb[EPT], vpa[EPT], vpb[EPT], vma[EPT], vmb[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = tid + e * NT;
+    vza[e] = vzb[e] = vpa[e] = vpb[e] = vma[e] = vmb[e] = 0.0;
+    if (i < B) {
+      const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
+      xa[i] = x[ia];
+      xb[i] = x[ib];
+      vza[e] = z[ia];
+      vzb[e] = z[ib];
+      if (useBeta) { vpa[e] = pOld[ia]; vpb[e] = pOld[ib]; }
+      vma[e] = mask[ia];
+      vmb[e] = mask[ib];
+      qa[i] = 0.0;
+      qb[i] = 0.0;
+    }
+  }
   __syncthreads();
-  for (int i = tid; i < B; i += 256) {
-    const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
-    xa[i] = x[ia];
-    xb[i] = x[ib];
-    pa[i] = (z[ia] + coarseAtLds(cl, L, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
-    qa[i] = 0.0;
-    qb[i] = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = tid + e * NT;
+    if (i < B) {
+      pa[i] = (vza[e] + coarseAtLds(cl, L, i) + (useBeta ? beta * vpa[e] : 0.0)) * vma[e];
+      pb[i] = (vzb[e] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * vpb[e] : 0.0)) * vmb[e];
+    }
   }
   if (L.intrOpt == kIntrShared) {
     // every constraint's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1226)
@@ -1404,11 +1443,6 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
       pa[6] = p06;
       pb[6] = p06;
     }
-  }
-  constexpr int FCW = sizeof(FrameConst) / 8;
-  if (tid < 2 * FCW) {
-    const int which = tid / FCW, k = tid % FCW;
-    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
   }
   __syncthreads();
   if (tid < 18) {
@@ -1455,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
 
 
-  for (long long c = cb + tid; c < ce; c += 256) {
+  for (long long c = cb + tid; c < ce; c += NT) {
     const float2 d = T.dsrc[c];
     if (!(d.x > 0.f)) continue;
     const float4 nd = T.ndc[c];
@@ -1606,8 +1640,8 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   }
   }  // dir
   // ---- one workgroup reduction of the 27 accumulators (roles of direction 1: source = fb, target = fa).
-  // Every thread stores its values transposed into LDS (row = accumulator, column = thread, 33-padded 32-column
-  // segments), then 8 threads per accumulator sum one segment each: ~60 LDS ops per thread instead of 27 x 6
+  // Lane pairs store their values transposed into LDS (row = accumulator, column = lane pair, 33-padded 32-column
+  // segments), then 4 threads per accumulator sum one segment each: ~45 LDS ops per thread instead of 27 x 6
   // cross-lane butterfly steps.
   const FrameConst& Fa = fcs[1];
   const FrameConst& Fb = fcs[0];
@@ -1620,13 +1654,20 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
     vals[21] = aFa;
     vals[22] = aFb;
     if constexpr (KD == 1) { vals[23] = gDa[0]; vals[24] = gDa[1]; vals[25] = gDb[0]; vals[26] = gDb[1]; }
-    const int colw = (tid >> 5) * 33 + (tid & 31);
+    // neighbouring lanes are summed in registers first (one DPP swap), so only the even lanes store: half the LDS
+    // (29 KB instead of 57 KB: the workgroup's footprint drops below a quarter of the CU's 160 KB)
+    const int half = tid >> 1;
+    const int colw = (half >> 5) * 33 + (half & 31);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) W[i * kRedStride + colw] = vals[i];
+    for (int i = 0; i < NV; ++i) {
+      const double v = vals[i] + dppMove<0xB1>(vals[i]);
+      if ((tid & 1) == 0) W[i * kRedStride + colw] = v;
+    }
   }
   __syncthreads();
-  if (tid < NV * 8) {
-    const double* row = W + (tid >> 3) * kRedStride + (tid & 7) * 33;
+  constexpr int SEG = NT / 64;  // 32-column segments per accumulator row (lane pairs): 4 at 256 threads, 2 at 128
+  if (tid < NV * SEG) {
+    const double* row = W + (tid / SEG) * kRedStride + (tid % SEG) * 33;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int k = 0; k < 32; k += 4) {
@@ -1636,10 +1677,9 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
       s3 += row[k + 3];
     }
     double sacc = (s0 + s1) + (s2 + s3);
-    sacc += dppMove<0xB1>(sacc);   // 8 consecutive lanes hold one accumulator's segments
-    sacc += dppMove<0x4E>(sacc);
-    sacc += dppMove<0x141>(sacc);
-    if ((tid & 7) == 0) red[tid >> 3] = sacc;
+    sacc += dppMove<0xB1>(sacc);   // SEG consecutive lanes hold one accumulator's segments
+    if (SEG == 4) sacc += dppMove<0x4E>(sacc);
+    if (tid % SEG == 0) red[tid / SEG] = sacc;
   }
   __syncthreads();
   if (tid < 3) {
@@ -1673,7 +1713,7 @@ __global__ __launch_bounds__(256) void k_matvec_pairs_fast(Layout L, Table T, It
   // rows are grouped by frame (slot = position in the frame's item list) so that k_matvec_finish streams them
   double* outA = qPart + static_cast<size_t>(it.slot[item * 2]) * B;
   double* outB = qPart + static_cast<size_t>(it.slot[item * 2 + 1]) * B;
-  for (int i = tid; i < B; i += 256) {
+  for (int i = tid; i < B; i += NT) {
     outA[i] = qa[i];
     outB[i] = qb[i];
   }
