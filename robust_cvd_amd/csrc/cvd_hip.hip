@@ -1499,6 +1499,16 @@ static void launchBlockInverse(Ctx& c) {
   const int nT = std::min(1024, ((nTiles + 63) / 64) * 64);
   const int tpt = (nTiles + nT - 1) / nT;
   const size_t ldsChol = (static_cast<size_t>(B) * (B + 1) / 2 + B) * 8;
+  // 6x6 tiles on 512 threads when the 4x4 tiling needs more than 512: two workgroups share a CU (half the threads, the
+  // same 128 registers), so that e.g. 300 frames run in one round instead of 256 + 44 (B = 177: 465 tiles).
+  const int nb6 = (B + 5) / 6, nTiles6 = nb6 * (nb6 + 1) / 2;
+  static const bool noTs6 = std::getenv("CVD_BLOCK_INVERSE_TS4") != nullptr;  // development knob
+  if (!h->forceGeneric && !noTs6 && nTiles > 512 && nTiles6 <= 512) {
+    hipLaunchKernelGGL((k_block_inverse_sweep<1, 6>), dim3(c.L.F), dim3(((nTiles6 + 63) / 64) * 64), 0, s, c.L, h->dH.p,
+                       h->dLam.p, h->dMinv.p, h->dFail.p);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   // three tiles per thread spill: prefer the LDS Cholesky there while its triangle still fits (B <= 199)
   if (!h->forceGeneric && (tpt <= 2 || (tpt == 3 && ldsChol > 160 * 1024))) {
     if (tpt == 1)

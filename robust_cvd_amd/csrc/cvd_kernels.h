@@ -509,20 +509,21 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, doub
 // tid + t * blockDim, TPT tiles per thread); a step only needs the pivot column, which its owners publish to a
 // double-buffered LDS vector, so one barrier per pivot and ~16 FMAs + 64 B of LDS reads per tile and step.
 // Padding rows/columns (B not a multiple of 4) are identity and never swept.
-template <int TPT>
-__global__ __launch_bounds__(1024) void k_block_inverse_sweep(Layout L, const double* __restrict__ hBlocks,
+template <int TPT, int TS = 4>
+__global__ __launch_bounds__(TS == 4 ? 1024 : 512, 4) void k_block_inverse_sweep(Layout L, const double* __restrict__ hBlocks,
                                                               const double* __restrict__ lam,
                                                               float* __restrict__ minv, int* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double colBuf[2][264];
+  static_assert(TS % 2 == 0, "the pivot column is read as double2");
   const int B = L.B;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const int nT = blockDim.x;
-  const int nb = (B + 3) >> 2;
+  const int nb = (B + TS - 1) / TS;
   const int nTiles = nb * (nb + 1) / 2;
   const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
   const double* lf = lam + static_cast<size_t>(f) * B;
-  double T[TPT][4][4];
+  double T[TPT][TS][TS];
   int tI[TPT], tJ[TPT];
 #pragma unroll
   for (int t = 0; t < TPT; ++t) {
@@ -537,24 +538,24 @@ __global__ __launch_bounds__(1024) void k_block_inverse_sweep(Layout L, const do
       tJ[t] = id - I * (I + 1) / 2;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < TS; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = 4 * tI[t] + p, j = 4 * tJ[t] + q;
+      for (int q = 0; q < TS; ++q) {
+        const int i = TS * tI[t] + p, j = TS * tJ[t] + q;
         double v = (i == j) ? 1.0 : 0.0;
         if (tI[t] >= 0 && i < B && j < B) v = hf[static_cast<size_t>(i) * B + j] + (i == j ? lf[i] : 0.0);
         T[t][p][q] = v;
       }
     if (tJ[t] == 0) {  // publish pivot column 0
 #pragma unroll
-      for (int p = 0; p < 4; ++p) colBuf[0][4 * tI[t] + p] = T[t][p][0];
+      for (int p = 0; p < TS; ++p) colBuf[0][TS * tI[t] + p] = T[t][p][0];
     }
   }
   __syncthreads();
   for (int kt = 0; kt < nb; ++kt) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int k = 4 * kt + a;
+    for (int a = 0; a < TS; ++a) {
+      const int k = TS * kt + a;
       if (k >= B) break;  // uniform
       const double* col = colBuf[k & 1];
       double* nxt = colBuf[(k + 1) & 1];
@@ -564,38 +565,42 @@ __global__ __launch_bounds__(1024) void k_block_inverse_sweep(Layout L, const do
         d = 1.0;
       }
       const double id = 1.0 / d;
-      const int an = (a + 1) & 3;  // compile-time after unrolling
-      const int ktn = kt + (a == 3 ? 1 : 0);
+      const int an = (a + 1) % TS;  // compile-time after unrolling
+      const int ktn = kt + (a == TS - 1 ? 1 : 0);
 #pragma unroll
       for (int t = 0; t < TPT; ++t) {
         if (tI[t] < 0) continue;
-        const double2 ci01 = *reinterpret_cast<const double2*>(col + 4 * tI[t]);
-        const double2 ci23 = *reinterpret_cast<const double2*>(col + 4 * tI[t] + 2);
-        const double2 cj01 = *reinterpret_cast<const double2*>(col + 4 * tJ[t]);
-        const double2 cj23 = *reinterpret_cast<const double2*>(col + 4 * tJ[t] + 2);
-        const double ci[4] = {ci01.x * id, ci01.y * id, ci23.x * id, ci23.y * id};  // c_i / d
-        const double cj[4] = {cj01.x, cj01.y, cj23.x, cj23.y};
+        double ci[TS], cj[TS];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int e = 0; e < TS; e += 2) {
+          const double2 vi = *reinterpret_cast<const double2*>(col + TS * tI[t] + e);
+          const double2 vj = *reinterpret_cast<const double2*>(col + TS * tJ[t] + e);
+          ci[e] = vi.x * id;  // c_i / d
+          ci[e + 1] = vi.y * id;
+          cj[e] = vj.x;
+          cj[e + 1] = vj.y;
+        }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) T[t][p][q] -= ci[p] * cj[q];
+        for (int p = 0; p < TS; ++p)
+#pragma unroll
+          for (int q = 0; q < TS; ++q) T[t][p][q] -= ci[p] * cj[q];
         if (tI[t] == kt) {  // row k of the tile: G_kj <- c_j / d
 #pragma unroll
-          for (int q = 0; q < 4; ++q) T[t][a][q] = cj[q] * id;
+          for (int q = 0; q < TS; ++q) T[t][a][q] = cj[q] * id;
         }
         if (tJ[t] == kt) {  // column k of the tile: G_ik <- c_i / d
 #pragma unroll
-          for (int p = 0; p < 4; ++p) T[t][p][a] = ci[p];
+          for (int p = 0; p < TS; ++p) T[t][p][a] = ci[p];
           if (tI[t] == kt) T[t][a][a] = -id;
         }
         // publish the next pivot column (row k+1 of the tiles left of / on the diagonal, column k+1 below it)
         if (k + 1 < B) {
           if (tI[t] == ktn) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) nxt[4 * tJ[t] + q] = T[t][an][q];
+            for (int q = 0; q < TS; ++q) nxt[TS * tJ[t] + q] = T[t][an][q];
           } else if (tJ[t] == ktn) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) nxt[4 * tI[t] + p] = T[t][p][an];
+            for (int p = 0; p < TS; ++p) nxt[TS * tI[t] + p] = T[t][p][an];
           }
         }
       }
@@ -607,10 +612,10 @@ __global__ __launch_bounds__(1024) void k_block_inverse_sweep(Layout L, const do
   for (int t = 0; t < TPT; ++t) {
     if (tI[t] < 0) continue;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < TS; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = 4 * tI[t] + p, j = 4 * tJ[t] + q;
+      for (int q = 0; q < TS; ++q) {
+        const int i = TS * tI[t] + p, j = TS * tJ[t] + q;
         if (i < B && j < B) {
           const float v = static_cast<float>(-T[t][p][q]);
           Mf[static_cast<size_t>(i) * B + j] = v;
