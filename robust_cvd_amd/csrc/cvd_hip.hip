@@ -1428,10 +1428,11 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const double* scalp = h->dScal.p;
     if (fast) {
       // Workgroup size: a work item keeps its slot for ~20 us at 256 threads and the register budget allows two
-      // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When all items fit into one
-      // round of 128-thread workgroups the launch has no ragged second round (benchmark: 883 items, 46 -> 3x us).
+      // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When the items need more than one
+      // round at 256 threads but fit into one round of 128-thread workgroups the launch has no ragged second round
+      // (benchmark: 883 items, 44 -> 39.5 us).
       static const int forcedNT = []() { const char* e = std::getenv("CVD_PAIRS_NT"); return e ? std::atoi(e) : 0; }();
-      const int nt = forcedNT ? forcedNT : (c.nItems <= 4 * h->numCU ? 128 : 256);
+      const int nt = forcedNT ? forcedNT : (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
 #define CVD_LAUNCH_PAIRS_FAST(NTV)                                                                                       \
       CVD_DISPATCH_KD(c.KD, {                                                                                            \
         allowLds((k_matvec_pairs_fast<KD, NTV>), ldsFast);                                                               \

@@ -18,7 +18,7 @@ def avg(d, counter, kernel):
 
 
 root, tag = sys.argv[1], sys.argv[2]
-kernel = "k_matvec_pairs_fast<4>"
+kernel = "k_matvec_pairs_fast<4"  # (any workgroup-size instantiation)
 f, nf = avg(os.path.join(root, "pmc_fetch"), "FETCH_SIZE", kernel)
 w, nw = avg(os.path.join(root, "pmc_write"), "WRITE_SIZE", kernel)
 out = {
