@@ -1465,12 +1465,28 @@ struct DepthVideoProcessor {
     }
   }
 
+  // Op::ClipMaxDepth, reference lib/Processor.cpp:592-617
+  void clipMaxDepth(const DvpParams& p) {
+    DepthStream& ds = *video_->depthStreams_.at(p.depthStream);
+    for (int f : p.frameRange.frames) {
+      DepthFrame& df = ds.frame(f);
+      if (!df.enabled) continue;
+      const std::vector<float>* d = df.sourceDepth();
+      if (!d) continue;
+      std::vector<float> x = df.depthXform().apply(*d, df.width(), df.height());  // DepthFrame::depth()
+      for (float& v : x) v = std::min(v, p.maxDepth);
+      df.sourceDepth_ = std::move(x);  // setDepth(clipped)
+      df.triedLoad = true;
+    }
+  }
+
   void process(const DvpParams& p) {  // reference lib/Processor.cpp:115-144
     switch (p.op) {
       case Op::None: break;
       case Op::Reset: reset(p); break;
       case Op::Copy: copy(p); break;
       case Op::FlowGuidedFilter: flowGuidedFilter(p); break;
+      case Op::ClipMaxDepth: clipMaxDepth(p); break;
       case Op::GridXformSplit: gridXformSplit(p); break;
       case Op::ResetPoses: resetPoses(p); break;
       case Op::ResetDepthXforms: resetDepthXforms(p); break;
@@ -1682,7 +1698,7 @@ PYBIND11_MODULE(lib_python, m) {
       .def_readwrite("sourceDepthStream", &DvpParams::sourceDepthStream).def_readwrite("spatialRadius", &DvpParams::spatialRadius)
       .def_readwrite("frameRadius", &DvpParams::frameRadius).def_readwrite("depthSigma", &DvpParams::depthSigma)
       .def_readwrite("colorSigma", &DvpParams::colorSigma).def_readwrite("median", &DvpParams::median)
-      .def_readwrite("farConnections", &DvpParams::farConnections).def_readwrite("matchSeparation", &DvpParams::matchSeparation)
+      .def_readwrite("farConnections", &DvpParams::farConnections).def_readwrite("maxDepth", &DvpParams::maxDepth).def_readwrite("matchSeparation", &DvpParams::matchSeparation)
       .def_readwrite("flowConsistancyThresh", &DvpParams::flowConsistancyThresh)
       .def_readwrite("trackSpawnDistance", &DvpParams::trackSpawnDistance).def_readwrite("trackPruneDistance", &DvpParams::trackPruneDistance)
       .def_readwrite("minDynamicDistance", &DvpParams::minDynamicDistance).def_readwrite("minTrackLength", &DvpParams::minTrackLength)
@@ -1696,7 +1712,9 @@ PYBIND11_MODULE(lib_python, m) {
       .value("ComputeTracks", Op::ComputeTracks).value("GridXformSplit", Op::GridXformSplit).value("ResetPoses", Op::ResetPoses)
       .value("ResetDepthXforms", Op::ResetDepthXforms).value("ResetSpatialXforms", Op::ResetSpatialXforms)
       .value("NormalizeDepth", Op::NormalizeDepth).value("OptimizePoses", Op::OptimizePoses)
-      .value("ResetNormalizeOptimize", Op::ResetNormalizeOptimize);
+      .value("ResetNormalizeOptimize", Op::ResetNormalizeOptimize)
+      .value("ClipMaxDepth", Op::ClipMaxDepth)                              // (extensions: C++-only in the reference)
+      .value("PruneConstraintStaticFlag", Op::PruneConstraintStaticFlag);
   dvp.def(py::init<DepthVideo*>(), py::keep_alive<1, 2>())
       .def("process", &DepthVideoProcessor::process).def("reset", &DepthVideoProcessor::reset)
       .def("gridXformSplit", &DepthVideoProcessor::gridXformSplit).def("resetPoses", &DepthVideoProcessor::resetPoses)

@@ -124,6 +124,26 @@ def test_import_streams_constraints_and_video_dat(lib, dataset):
     assert open(os.path.join(base, "flow_constraints.dat"), "rb").read() == before
 
 
+def test_clip_max_depth_op(lib, dataset):
+    """Op.ClipMaxDepth, reference lib/Processor.cpp:592-617: depth <- min(depth, maxDepth) for the frames of the range."""
+    v, base = dataset
+    dv = lib.DepthVideo()
+    lib.DepthVideoImporter.importVideo(dv, base, True)
+    dv.createDepthStream("depth_midas2", "depth_midas2", [v.width, v.height])
+    proc = lib.DepthVideoProcessor(dv)
+    params = lib.DepthVideoProcessor.Params()
+    params.frameRange.fromString("2-4")
+    params.op = lib.DepthVideoProcessor.Op.ClipMaxDepth
+    params.depthStream = 0
+    params.maxDepth = float(np.median(v.depth[3]))
+    before = dv.depthStream(0).frame(5).depth().copy()
+    proc.process(params)
+    d3 = dv.depthStream(0).frame(3).depth()
+    assert d3.max() <= params.maxDepth and np.array_equal(d3, np.minimum(v.depth[3], np.float32(params.maxDepth)).astype(np.float32)) \
+        or np.allclose(d3, np.minimum(v.depth[3], params.maxDepth), rtol=3e-7)
+    assert np.array_equal(dv.depthStream(0).frame(5).depth(), before)
+
+
 def test_missing_inputs_raise_runtime_error(lib, tmp_path):
     dv = lib.DepthVideo()
     with pytest.raises(RuntimeError, match="frame file"):
