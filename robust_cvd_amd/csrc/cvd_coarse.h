@@ -68,6 +68,7 @@ struct CoarsePlan {
   const int* wuL;        //   block id of L(i, k)
   const int* wuW;        //   W block id of W(k, j)
   int nW;                // number of W blocks
+  const int* updBlk;     // per update entry: the block id it belongs to (inverse of updPtr)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -375,6 +376,8 @@ __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const d
                                                            int* __restrict__ fail, unsigned int* __restrict__ barrier) {
   __shared__ double scratch[16][2 * kCBB];
   __shared__ double fold[16][kCBB];
+  constexpr int kMaxColBlk = 40;  // staging of one column: diagonal + off-diagonal blocks (20 KB)
+  __shared__ double colAcc[kMaxColBlk * kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane >> 3, c = lane & 7;
   const int nG = gridDim.x, g = blockIdx.x;
@@ -397,7 +400,60 @@ __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const d
     for (int q = P.levelPtr[lv] + g; q < P.levelPtr[lv + 1]; q += nG) {
       const int j = P.levelCols[q];
       const int nOff = P.colPtr[j + 1] - P.colPtr[j];
-      // ---- gather: block k = 0 is the diagonal, k >= 1 the off-diagonal blocks of the column
+      // ---- gather.  The update lists of the column's blocks (diagonal: ids of block j; off-diagonal: one contiguous
+      // range, their block ids are consecutive) are cut into 16 equal slices, one per wave, whatever block an entry
+      // belongs to: a wave accumulates in registers while the block stays the same and flushes into the column's LDS
+      // staging with f64 atomics when it changes.  The serial depth per column is (updates / 16) products and ONE
+      // barrier instead of one pair of barriers per block.
+      const int d0 = P.updPtr[j], nd = P.updPtr[j + 1] - d0;
+      const int ob = P.F + P.colPtr[j];
+      const int o0 = P.updPtr[ob], no = P.updPtr[ob + nOff] - o0;
+      const int U = nd + no;
+      if (U > 0 && nOff + 1 <= kMaxColBlk) {
+        for (int i = tid; i < (nOff + 1) * kCBB; i += 1024) colAcc[i] = 0.0;
+        __syncthreads();
+        const int per = (U + 15) >> 4;
+        const int i0 = wv * per, i1 = min(U, i0 + per);
+        if (i0 < i1) {
+          auto entry = [&](int idx, int& u, int& blk) {
+            if (idx < nd) { u = d0 + idx; blk = 0; }
+            else { u = o0 + (idx - nd); blk = P.updBlk[u] - ob + 1; }
+          };
+          int u, blk;
+          entry(i0, u, blk);
+          double na = Lb[static_cast<size_t>(P.updA[u]) * kCBB + lane];
+          double nb = Lb[static_cast<size_t>(P.updB[u]) * kCBB + lane];
+          double acc = 0.0;
+          for (int idx = i0; idx < i1; ++idx) {
+            sA[lane] = na;
+            sB[lane] = nb;
+            CVD_WAVE_SYNC();
+            int nblk = -1;
+            if (idx + 1 < i1) {
+              int un;
+              entry(idx + 1, un, nblk);
+              na = Lb[static_cast<size_t>(P.updA[un]) * kCBB + lane];
+              nb = Lb[static_cast<size_t>(P.updB[un]) * kCBB + lane];
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
+            acc += s;
+            CVD_WAVE_SYNC();
+            if (nblk != blk) {  // wave-uniform
+              atomicAdd(&colAcc[blk * kCBB + lane], acc);
+              acc = 0.0;
+              blk = nblk;
+            }
+          }
+        }
+        __syncthreads();
+        for (int k = wv; k <= nOff; k += 16) {
+          const int b = (k == 0) ? j : ob + k - 1;
+          Lb[static_cast<size_t>(b) * kCBB + lane] -= colAcc[k * kCBB + lane];
+        }
+        __syncthreads();
+      } else
       for (int k = 0; k <= nOff; ++k) {
         const int b = (k == 0) ? j : P.F + P.colPtr[j] + k - 1;
         const int u0 = P.updPtr[b], u1 = P.updPtr[b + 1];

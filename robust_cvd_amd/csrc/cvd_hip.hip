@@ -341,7 +341,7 @@ struct cvd_handle_t {
     bool valid = false;   // plan built for the current table
     int nEdges = 0, nBlocks = 0, nLevels = 0;
     std::vector<int> itemEdge;
-    DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr,
+    DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr, updBlk,
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev;
     DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY;
     int nW = 0;
@@ -812,10 +812,10 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
         upd[target].push_back({F + colPtr[k] + static_cast<int>(b), F + colPtr[k] + static_cast<int>(a)});
       }
   }
-  std::vector<int> updPtr(nBlocks + 1, 0), updA, updB;
+  std::vector<int> updPtr(nBlocks + 1, 0), updA, updB, updBlk;
   for (int b = 0; b < nBlocks; ++b) {
     updPtr[b + 1] = updPtr[b] + static_cast<int>(upd[b].size());
-    for (const auto& u : upd[b]) { updA.push_back(u.first); updB.push_back(u.second); }
+    for (const auto& u : upd[b]) { updA.push_back(u.first); updB.push_back(u.second); updBlk.push_back(b); }
   }
   std::vector<int> levelPtr(nLevels + 1, 0), levelCols, lvlBlkPtr(nLevels + 1, 0), lvlBlks;
   for (int lv = 0; lv < nLevels; ++lv) {
@@ -874,10 +874,32 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.nLevels = nLevels;
   C.itemEdge = itemEdge;
   auto up = [&](DevBuf<int>& d, const std::vector<int>& v) { d.upload(v.data(), v.size(), s); };
+  if (std::getenv("CVD_COARSE_PLAN_STATS")) {  // development aid: shape of the elimination levels
+    for (int lv = 0; lv < nLevels; ++lv) {
+      long long nupd = 0, maxCol = 0, nblk = 0, maxChain = 0;
+      for (int q = levelPtr[lv]; q < levelPtr[lv + 1]; ++q) {
+        const int j = levelCols[q];
+        long long colUpd = 0, chain = 0;
+        const int nOff = colPtr[j + 1] - colPtr[j];
+        for (int k = 0; k <= nOff; ++k) {
+          const int b = (k == 0) ? j : F + colPtr[j] + k - 1;
+          const long long u = updPtr[b + 1] - updPtr[b];
+          colUpd += u;
+          chain += u ? (u + 15) / 16 + 1 : 0;
+        }
+        nblk += nOff + 1;
+        nupd += colUpd;
+        maxCol = std::max(maxCol, colUpd);
+        maxChain = std::max(maxChain, chain);
+      }
+      std::printf("level %2d: cols %3d blocks %5lld updates %6lld  max updates/col %5lld  max serial steps/col %4lld\n", lv,
+                  levelPtr[lv + 1] - levelPtr[lv], nblk, nupd, maxCol, maxChain);
+    }
+  }
   up(C.order, order); up(C.pos, pos); up(C.levelPtr, levelPtr); up(C.levelCols, levelCols);
   up(C.lvlBlkPtr, lvlBlkPtr); up(C.lvlBlks, lvlBlks); up(C.blkCol, blkCol); up(C.blkRow, blkRow);
   up(C.colPtr, colPtr); up(C.rowPtr, rowPtr); up(C.rowBlk, rowBlk); up(C.updPtr, updPtr); up(C.updA, updA);
-  up(C.updB, updB); up(C.edgeBlk, edgeBlk); up(C.edgeFa, edgeFa); up(C.edgeFb, edgeFb);
+  up(C.updB, updB); up(C.updBlk, updBlk); up(C.edgeBlk, edgeBlk); up(C.edgeFa, edgeFa); up(C.edgeFb, edgeFb);
   up(C.wPtr, wPtr); up(C.wRow, wRow); up(C.wtPtr, wtPtr); up(C.wtBlk, wtBlk); up(C.wtCol, wtCol); up(C.wtFrame, wtFrame);
   up(C.wuPtr, wuPtr); up(C.wuL, wuL); up(C.wuW, wuW);
   C.nW = nW;
@@ -900,7 +922,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.plan = CoarsePlan{F, nBlocks, nLevels, C.nEdges, C.order.p, C.pos.p, C.levelPtr.p, C.levelCols.p, C.lvlBlkPtr.p,
                       C.lvlBlks.p, C.blkCol.p, C.blkRow.p, C.colPtr.p, C.rowPtr.p, C.rowBlk.p, C.updPtr.p, C.updA.p,
                       C.updB.p, C.edgeBlk.p, C.edgeFa.p, C.edgeFb.p, C.wPtr.p, C.wRow.p, C.wtPtr.p, C.wtBlk.p, C.wtCol.p, C.wtFrame.p,
-                      C.wuPtr.p, C.wuL.p, C.wuW.p, nW};
+                      C.wuPtr.p, C.wuL.p, C.wuW.p, nW, C.updBlk.p};
   C.valid = true;
 }
 
