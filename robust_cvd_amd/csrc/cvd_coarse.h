@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __restrict__ hBlocks,
                                                      const double* __restrict__ lam, const double* __restrict__ mask,
-                                                     double* __restrict__ diagOut, unsigned char* __restrict__ modeActive) {
+                                                     double* __restrict__ diagOut, unsigned char* __restrict__ modeActive,
+                                                     double lamScale) {
   __shared__ double u[264];  // u[r] = sum over scale vertices v of H[r][v] (+ lam on the diagonal)
   __shared__ double red[4];
   __shared__ int anyScale;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __r
     double a = 0.0;
     for (int v = 0; v < nV; ++v) {
       const int cidx = 7 + v * N;
-      a += hf[static_cast<size_t>(r) * B + cidx] + (r == cidx ? lf[r] : 0.0);
+      a += hf[static_cast<size_t>(r) * B + cidx] + (r == cidx ? lamScale * lf[r] : 0.0);
     }
     u[r] = a;
     if (r >= 7 && r < 7 + L.nD && ((r - 7) % (N > 0 ? N : 1)) == 0 && mf[r] != 0.0) anyScale = 1;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __r
       return nV > 0 && anyScale != 0;
     };
     double v;
-    if (i < 7 && j < 7) v = hf[static_cast<size_t>(i) * B + j] + (i == j ? lf[i] : 0.0);
+    if (i < 7 && j < 7) v = hf[static_cast<size_t>(i) * B + j] + (i == j ? lamScale * lf[i] : 0.0);
     else if (i < 7) v = u[i];
     else if (j < 7) v = u[j];
     else v = red[0] + red[1] + red[2] + red[3];

@@ -301,6 +301,9 @@ struct cvd_handle_t {
   DevBuf<unsigned int> dAsmCount;
   int nAsmParts = 0, nAsmSlots = 0;
   int numCU = 256;
+  hipStream_t stream2 = nullptr;                       // side stream of the asynchronous coarse rebuild
+  hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr;
+  DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
@@ -348,6 +351,10 @@ struct cvd_handle_t {
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
     DevBuf<unsigned int> barrier;  // grid barrier of k_coarse_factor_mw
+    // second set of the factor's outputs: a rebuild runs on a side stream while the PCG of the same LM iteration
+    // still uses the previous factor (launchCoarseSetup / the LM loop)
+    DevBuf<double> Wb2;
+    DevBuf<int> fail2;
     CoarsePlan plan{};
   } coarse;
   bool coarseOn = false;  // this solve uses the coarse level
@@ -391,6 +398,9 @@ struct cvd_handle_t {
     for (auto& p : hStage) if (p) (void)hipHostFree(p);
     if (hPcg) (void)hipHostFree(hPcg);
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
+    if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
+    if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -910,6 +920,8 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.Lb.ensure(static_cast<size_t>(nBlocks) * kCBB);
   C.Linv.ensure(static_cast<size_t>(F) * kCBB);
   C.Wb.ensure(static_cast<size_t>(nW) * kCBB);
+  C.Wb2.ensure(static_cast<size_t>(nW) * kCBB);
+  C.fail2.ensure(1);
   C.rc.ensure(n);
   C.qc.ensure(n);
   C.fdotY.ensure(F);
@@ -1550,22 +1562,27 @@ static void launchBlockInverse(Ctx& c) {
 }
 
 // Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
-static void launchCoarseSetup(Ctx& c, const double* x) {
+// side != 0: on the side stream, into the second output set (Wb2 / fail2) and with private frame constants, so that
+// the main stream can keep solving with the previous factor meanwhile.
+static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
   cvd_handle* h = c.h;
-  hipStream_t s = h->stream;
+  hipStream_t s = side ? h->stream2 : h->stream;
   auto& C = h->coarse;
   const size_t B = c.L.B;
-  HIP_CHECK(hipMemsetAsync(C.fail.p, 0, sizeof(int), s));
+  double* WbOut = side ? C.Wb2.p : C.Wb.p;
+  int* failOut = side ? C.fail2.p : C.fail.p;
+  FrameConst* fcBuf = side ? h->dFc2.p : h->dFc.p;
+  HIP_CHECK(hipMemsetAsync(failOut, 0, sizeof(int), s));
   {
     // off-diagonal blocks of the coarse (pose-graph) matrix at the current linearisation point x (only here: the
     // factor is rebuilt on demand, not at every accepted step)
-    launchFrameConsts(c, x);
+    hipLaunchKernelGGL(k_frame_consts, dim3((c.L.F + 63) / 64), dim3(64), 0, s, c.L, x, fcBuf);
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
     if (c.nItems > 0) {
       CVD_DISPATCH(c.KD, c.KS, {
         allowLds(k_coarse_edges<KD, KS>, ldsE);
-        hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, h->dFc.p,
+        hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
                            C.itemEdgeDev.p, C.edges.p);
       });
     }
@@ -1573,20 +1590,23 @@ static void launchCoarseSetup(Ctx& c, const double* x) {
     if (h->dist())
       NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
   }
+  // (side stream: the factor will serve the NEXT iteration, whose damping is most likely a third of this one's --
+  // the trust region triples after a good step)
+  static const double lamPredict = []() { const char* e = std::getenv("CVD_COARSE_LAM_PREDICT"); return e ? std::atof(e) : 1.0 / 3.0; }();
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
-                     C.modeActive.p);
+                     C.modeActive.p, side ? lamPredict : 1.0);
   static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
   if (singleWg) {
     hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
-                       C.Linv.p, C.fail.p);
+                       C.Linv.p, failOut);
   } else {
     C.barrier.ensure(1);
     HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, sizeof(unsigned int), s));
     HIP_CHECK(hipMemsetAsync(C.Lb.p, 0, static_cast<size_t>(C.nBlocks) * kCBB * sizeof(double), s));
     hipLaunchKernelGGL(k_coarse_factor_mw, dim3(kCoarseFactorGroups), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p,
-                       C.modeActive.p, C.Lb.p, C.Linv.p, C.fail.p, C.barrier.p);
+                       C.modeActive.p, C.Lb.p, C.Linv.p, failOut, C.barrier.p);
   }
-  hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, C.Wb.p);
+  hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, WbOut);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1788,6 +1808,25 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     return e ? std::max(1, std::atoi(e)) : 16;
   }();
   int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
+  static const bool asyncCoarse = std::getenv("CVD_COARSE_SYNC") == nullptr;  // (development knob: rebuild in line)
+  bool coarsePending = false;  // a rebuild is running on the side stream
+  int factorUses = 0;          // PCG solves done with the factor in use
+  double lastRelChange = 1.0;  // relative cost change of the last accepted step
+  static const double asyncMaxChange = []() { const char* e = std::getenv("CVD_COARSE_ASYNC_MAX_CHANGE"); return e ? std::atof(e) : 1e-3; }();
+  bool freshFactor = false;    // the factor was installed right before this iteration's PCG
+  auto installPendingCoarse = [&]() {
+    if (!coarsePending) return;
+    HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseDone, 0));  // (device-side wait: the host does not block)
+    std::swap(h->coarse.Wb.p, h->coarse.Wb2.p);
+    std::swap(h->coarse.Wb.n, h->coarse.Wb2.n);
+    std::swap(h->coarse.fail.p, h->coarse.fail2.p);
+    std::swap(h->coarse.fail.n, h->coarse.fail2.n);
+    coarsePending = false;
+    freshFactor = true;
+    cgExcess = 0;
+    coarseAge = 0;
+    factorUses = 0;
+  };
   bool scaleDone = false;
   cvd_iteration_record r0{};
   r0.cost = xCost;
@@ -1827,12 +1866,31 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         // across LM iterations (lagged lam and linearisation point).  A rebuild costs about as much as
         // kCoarseRebuildIters PCG iterations; it is done once the iterations spent beyond the count observed
         // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
+        // When a factor already exists the rebuild runs on the side stream, concurrently with this iteration's PCG
+        // (which keeps the old factor), and is installed for the next iteration: its ~0.8 ms leave the critical path.
+        // Its inputs (H, lam, x, mask, the table) are not written before the install below; the frame constants,
+        // which the main stream rewrites for the candidate point, are private to the side stream.
         if (willRefresh) {
-          const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
-          launchCoarseSetup(c, h->dX.p);
-          h->tEnd(slot);
-          coarseAge = 0;
-          cgExcess = 0;
+          // (Only in the slowly changing regime -- the last accepted step changed the cost by less than 0.1 % --: while
+          // the iterates still move a lot a factor that is one iteration late costs more PCG iterations than the
+          // overlap saves, and there the rebuild stays in line.)
+          if (lastRelChange < asyncMaxChange && asyncCoarse && h->opt.coarse_level != 2 && !h->dist()) {
+            h->dFc2.ensure(c.L.F);
+            HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
+            HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
+            launchCoarseSetup(c, h->dX.p, 1);
+            HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));
+            coarsePending = true;
+            cgExcess = 0;
+          } else {
+            const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
+            launchCoarseSetup(c, h->dX.p);
+            h->tEnd(slot);
+            coarseAge = 0;
+            cgExcess = 0;
+            freshFactor = true;
+            factorUses = 0;
+          }
         } else {
           ++coarseAge;
         }
@@ -1846,8 +1904,11 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         HIP_CHECK(hipGetLastError());
         enqueueCost(c, h->dXc.p);
       });
-      if (coarseAge == 0) cgAfterRefresh = cgIters;
+      if (freshFactor) cgAfterRefresh = cgIters;
       else cgExcess += std::max(0, cgIters - cgAfterRefresh);
+      freshFactor = false;
+      ++factorUses;
+      installPendingCoarse();
       tLin += nowSeconds() - tl;
       rec.linear_iterations = cgIters;
       sum.total_linear_iterations += cgIters;
@@ -1887,6 +1948,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       if (rec.relative_decrease > Ceres::min_relative_decrease) {
         std::swap(h->dX.p, h->dXc.p);
         std::swap(h->dX.n, h->dXc.n);
+        lastRelChange = std::abs(xCost - candCost) / std::max(std::abs(xCost), 1e-300);
         xCost = candCost;
         te = nowSeconds();
         const double chk = evalFull(c, h->dX.p, true);
@@ -2411,6 +2473,10 @@ cvd_handle* cvd_create(int32_t device) {
     h->device = device;
     HIP_CHECK(hipDeviceGetAttribute(&h->numCU, hipDeviceAttributeMultiprocessorCount, device));
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // side stream of the asynchronous coarse rebuild (created here: the first use of a new stream costs ~10 ms)
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
     return h;
   } catch (const std::exception& e) {
