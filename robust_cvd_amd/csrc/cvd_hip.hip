@@ -1311,7 +1311,7 @@ static void enqueueCost(Ctx& c, const double* x) {
     HIP_CHECK(hipGetLastError());
   }
   CVD_DISPATCH_KD(c.KD, {
-    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(64), 0, s, c.L, x, h->dMedian.p, h->dRegOwner.p, h->dInRange.p,
+    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(256), static_cast<size_t>(c.L.B) * 8, s, c.L, x, h->dMedian.p, h->dRegOwner.p, h->dInRange.p,
                        h->dCostFrame.p);
   });
   HIP_CHECK(hipGetLastError());
@@ -1438,7 +1438,7 @@ static void prepareMatvec(Ctx& c, const double* x) {
   HIP_CHECK(hipMemsetAsync(h->dScal.p + S_DONE, 0, sizeof(double), h->stream));
   if (nr == 0) return;
   CVD_DISPATCH_KD(c.KD, {
-    hipLaunchKernelGGL((k_reg_cache<KD>), dim3(L.F), dim3(256), 0, h->stream, L, x, h->dMedian.p, h->dRegOwner.p,
+    hipLaunchKernelGGL((k_reg_cache<KD>), dim3(L.F), dim3(256), static_cast<size_t>(L.B) * 8, h->stream, L, x, h->dMedian.p, h->dRegOwner.p,
                        h->regCache);
   });
   HIP_CHECK(hipGetLastError());

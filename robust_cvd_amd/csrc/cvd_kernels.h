@@ -200,11 +200,14 @@ __global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it,
 }
 
 template <int KD>
-__global__ __launch_bounds__(64) void k_cost_frames(Layout L, const double* __restrict__ x,
-                                                    const float* __restrict__ median,
-                                                    const unsigned char* __restrict__ inRange,
-                                                    const unsigned char* __restrict__ rangeFlags,
-                                                    double* __restrict__ costFrame) {
+__global__ __launch_bounds__(256) void k_cost_frames(Layout L, const double* __restrict__ x,
+                                                     const float* __restrict__ median,
+                                                     const unsigned char* __restrict__ inRange,
+                                                     const unsigned char* __restrict__ rangeFlags,
+                                                     double* __restrict__ costFrame) {
+  // (the frame's parameters go through LDS: every residual would otherwise start with its own dependent global load)
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double red[4];
   const int f = blockIdx.x;
   double acc = 0.0;
   if (threadIdx.x == 0 && L.positionRegSqrt > 0.0) {
@@ -212,20 +215,26 @@ __global__ __launch_bounds__(64) void k_cost_frames(Layout L, const double* __re
     if (posRegValid(L, rangeFlags, f)) posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
     acc += cst;
   }
-  if (inRange[f]) {
-    const double* xf = x + static_cast<size_t>(f) * L.B;
+  const bool active = inRange[f] != 0;
+  if (active)
+    for (int i = threadIdx.x; i < L.B; i += 256) sm[i] = x[static_cast<size_t>(f) * L.B + i];
+  __syncthreads();
+  if (active) {
+    const float med = median[f];
     const int nr = numRegResiduals<KD>(L);
-    for (int i = threadIdx.x; i < nr; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nr; i += 256) {
       double r;
       int n;
       int cols[2 * KD + 2];
       double jac[2 * KD + 2];
-      regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
+      regResidual<KD>(L, f, i, sm, med, r, n, cols, jac);
       acc += r * r;
     }
   }
   acc = waveSum(acc);
-  if (threadIdx.x == 0) costFrame[f] = 0.5 * acc;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) costFrame[f] = 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // deterministic final sum: out[slot] = sum(a[0..na)) + sum(b[0..nb))
@@ -894,15 +903,18 @@ template <int KD>
 __global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __restrict__ x,
                                                    const float* __restrict__ median,
                                                    const unsigned char* __restrict__ owner, RegCache rc) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];  // the frame's parameters (see k_cost_frames)
   const int f = blockIdx.x;
   if (!owner[f]) return;
-  const double* xf = x + static_cast<size_t>(f) * L.B;
+  for (int i = threadIdx.x; i < L.B; i += 256) sm[i] = x[static_cast<size_t>(f) * L.B + i];
+  __syncthreads();
+  const float med = median[f];
   for (int i = threadIdx.x; i < rc.nr; i += 256) {
     double r;
     int n;
     int cols[2 * KD + 2];
     double jac[2 * KD + 2];
-    regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
+    regResidual<KD>(L, f, i, sm, med, r, n, cols, jac);
     rc.cnt[static_cast<size_t>(f) * rc.nr + i] = static_cast<unsigned char>(n);
     for (int a = 0; a < n; ++a) {
       const size_t e = (static_cast<size_t>(f) * rc.stride + a) * rc.nr + i;
