@@ -1503,6 +1503,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     HIP_CHECK(hipGetLastError());
   }
   {
+    if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_matvec_finish");
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {

@@ -949,22 +949,33 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   const int tid = threadIdx.x;
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   const size_t base = static_cast<size_t>(f) * B;
+  // One global round trip for the inputs (B <= 256: one element per thread): the loads of z / mask / p_old / x / lam
+  // are issued together with the coarse correction's, the direction is formed after the barrier and stays in a
+  // register for the damping term and p.q at the end.
   if (V.Wb != nullptr) {
     if (tid < 64) coarseFrameCorrection(V, f, tid, cl);
   } else if (tid < kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[f * kCB + tid] : 0.0;
   }
+  double vz = 0.0, vm = 0.0, vp = 0.0, vlam = 0.0, pvReg = 0.0;
+  if (tid < B) {
+    vz = z[base + tid];
+    vm = mask[base + tid];
+    if (useBeta) vp = pOld[base + tid];
+    vlam = lam[base + tid];
+    xf[tid] = x[base + tid];
+  }
+  const int e0 = fiOff[f], e1 = fiOff[f + 1];  // (before the barrier: the row gather below depends on them)
   __syncthreads();
   for (int i = tid; i < B; i += 256) {
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
-    const double pv = z[base + i] + coarseAtLds(cl, L, i) * mask[base + i] + (useBeta ? beta * pOld[base + i] : 0.0);
+    const double pv = vz + coarseAtLds(cl, L, i) * vm + (useBeta ? beta * vp : 0.0);
     pNew[base + i] = pv;
-    xf[i] = x[base + i];
-    pf[i] = pv * mask[base + i];
+    pvReg = pv;
+    pf[i] = pv * vm;
     double acc = 0.0;
     if (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) {  // (stale partial buffer without a pair kernel)
       // the frame's partial rows are contiguous: independent streaming loads, four in flight per thread
-      const int e0 = fiOff[f], e1 = fiOff[f + 1];
       const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       int e = e0;
@@ -1020,16 +1031,13 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; in both cases q is
   // all-reduced afterwards and p.q / alpha are formed by k_dot_pq on the reduced vector.
   if (distMode) {
-    for (int i = tid; i < B; i += 256) {
-      const double pv = pNew[base + i];
-      q[base + i] = qf[i] * mask[base + i] + (distMode == 1 ? lam[base + i] * pv : 0.0);
-    }
+    for (int i = tid; i < B; i += 256) q[base + i] = qf[i] * vm + (distMode == 1 ? vlam * pvReg : 0.0);
     return;
   }
   double dot = 0.0;
   for (int i = tid; i < B; i += 256) {
-    const double pv = pNew[base + i];
-    const double qv = qf[i] * mask[base + i] + lam[base + i] * pv;
+    const double pv = pvReg;
+    const double qv = qf[i] * vm + vlam * pv;
     q[base + i] = qv;
     qf[i] = qv;
     dot += pv * qv;
