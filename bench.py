@@ -227,7 +227,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if shard else "weak",
+            # default mode: the SAME problem at every N (pairs sharded) => strong; --mode replicas: one video per GPU => weak
+            "scaling": "strong" if args.mode == "shard" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -59,3 +59,22 @@ def test_zero_noise_flow_is_geometrically_consistent():
     u, w = q[:, 0] / -q[:, 2] / fx, q[:, 1] / -q[:, 2] / fy
     nx1, ny1 = -1 + 2 * loc[:, 2], 1 - 2 * loc[:, 3] / v.inv_aspect
     assert np.abs(u - nx1).max() < 1e-4 and np.abs(w - ny1).max() < 1e-4
+
+
+def test_pairs_match_reference_sampler():
+    """Pinned against the REAL reference: vectors minted by importing reference utils/frame_sampling.py
+    (tests/golden/make_pairs_golden.py), every mode that runs through sample_hierarchical."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_pairs.npz"))
+    checked = 0
+    for n in (2, 3, 5, 8, 17, 30, 100, 300):
+        for tw in (True, False):
+            got = np.asarray(synth.hierarchical_pairs(n, two_way=tw), dtype=np.int32).reshape(-1, 2)
+            assert np.array_equal(got, g[f"h2_n{n}_tw{int(tw)}"]), (n, tw)
+        got = np.asarray(synth.hierarchical_pairs(n, max_dist=1, include_mid_point=False), dtype=np.int32).reshape(-1, 2)
+        assert np.array_equal(got, g[f"consecutive_n{n}"]), n
+        got = np.asarray(synth.hierarchical_pairs(n, min_dist=2, max_dist=min(9, max(2, n - 1)), include_mid_point=False),
+                         dtype=np.int32).reshape(-1, 2)
+        assert np.array_equal(got, g[f"h1_n{n}_min2_max9"]), n
+        checked += 4
+    assert checked == 32
