@@ -34,7 +34,10 @@ typedef struct cvd_solver_options {
   int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve
                                     (8 unknowns per frame), coarse factor rebuilt on demand; 2: rebuilt every LM
                                     iteration; 0: block-Jacobi only */
-  int32_t reserved;
+  int32_t robust_loss;           /* robust loss on the static flow constraints, parameter = cvd_opt_params::robustness:
+                                    0 (default) ceres::CauchyLoss, what the reference hard-wires
+                                    (lib/PoseOptimizer.cpp:1220); 1 ceres::HuberLoss, the stress variant of BASELINE.json
+                                    configs[4] (no counterpart in the reference) */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

@@ -868,7 +868,7 @@ struct AdaptiveDeformationCost {
 // ceres::Problem / evaluator restatement
 // =====================================================================================================
 
-enum LossKind { LOSS_NONE = 0, LOSS_CAUCHY = 1, LOSS_SCALED = 2 };
+enum LossKind { LOSS_NONE = 0, LOSS_CAUCHY = 1, LOSS_SCALED = 2, LOSS_HUBER = 3 };
 
 struct ParamBlock {
   double* ptr = nullptr;
@@ -932,7 +932,7 @@ struct Problem {
   }
 };
 
-// ceres::CauchyLoss / ScaledLoss(nullptr, a) -> rho[0..2] (ceres/loss_function.cc).
+// ceres::CauchyLoss / HuberLoss / ScaledLoss(nullptr, a) -> rho[0..2] (ceres/loss_function.cc).
 static void evalLoss(int kind, double p, double s, double rho[3]) {
   if (kind == LOSS_CAUCHY) {
     const double b = p * p;
@@ -942,6 +942,19 @@ static void evalLoss(int kind, double p, double s, double rho[3]) {
     rho[0] = b * std::log(sum);
     rho[1] = std::max(std::numeric_limits<double>::min(), inv);
     rho[2] = -c * (inv * inv);
+  } else if (kind == LOSS_HUBER) {
+    // ceres::HuberLoss(a) (ceres/loss_function.cc): outlier region s > a^2
+    const double b = p * p;
+    if (s > b) {
+      const double r = std::sqrt(s);
+      rho[0] = 2.0 * p * r - b;
+      rho[1] = std::max(std::numeric_limits<double>::min(), p / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else {
+      rho[0] = s;
+      rho[1] = 1.0;
+      rho[2] = 0.0;
+    }
   } else if (kind == LOSS_SCALED) {
     rho[0] = p * s;
     rho[1] = p;
@@ -1426,6 +1439,7 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
 // =====================================================================================================
 
 struct Oracle {
+  int robustLoss = 0;  // 0 CauchyLoss (reference), 1 HuberLoss (BASELINE configs[4] stress variant): cvdo_set_robust_loss
   int F = 0, W = 0, Hh = 0;
   float aspect = 1.f, invAspect = 1.f;
   std::vector<float> depth;  // F * H * W source depth (already inverted from disparity; invalid -> 0)
@@ -1703,7 +1717,7 @@ struct Oracle {
         cf->numResiduals = 3;
         cf->blockSizes = sizes;
         rb.cost = std::move(cf);
-        rb.lossKind = LOSS_CAUCHY;
+        rb.lossKind = robustLoss == 1 ? LOSS_HUBER : LOSS_CAUCHY;  // (reference: always CauchyLoss, :1220)
         rb.lossParam = p.robustness;
         pb.residuals.push_back(std::move(rb));
       }
@@ -2071,6 +2085,12 @@ void* cvdo_create() { return new Oracle(); }
 void cvdo_destroy(void* h) { delete static_cast<Oracle*>(h); }
 const char* cvdo_last_error(void* h) { return static_cast<Oracle*>(h)->lastError.c_str(); }
 
+int cvdo_set_robust_loss(void* h, int kind) {
+  CVDO_TRY(h, {
+    if (kind != 0 && kind != 1) throw std::runtime_error("robust_loss must be 0 (Cauchy) or 1 (Huber)");
+    static_cast<Oracle*>(h)->robustLoss = kind;
+  });
+}
 int cvdo_set_video(void* h, int numFrames, int width, int height, float aspect, float invAspect) {
   CVDO_TRY(h, static_cast<Oracle*>(h)->init(numFrames, width, height, aspect, invAspect));
 }

@@ -40,6 +40,10 @@ class Oracle(Binding):
         lib = load()
         super().__init__(lib, "cvdo_", lib.cvdo_create())
 
+    def set_robust_loss(self, kind):
+        """0: CauchyLoss (reference), 1: HuberLoss -- mirrors api.Solver.set_robust_loss."""
+        self._check(self._fn("set_robust_loss")(self._h, C.c_int(int(kind))))
+
 
 # ---- stand-alone known-answer hooks ------------------------------------------------------------------
 def gather(desc: XformDesc, src_depth, lx, ly):

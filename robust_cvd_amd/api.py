@@ -23,7 +23,7 @@ class SolverOptions(C.Structure):
         ("verbose", C.c_int32),
         ("force_iterations", C.c_int32),
         ("coarse_level", C.c_int32),
-        ("reserved", C.c_int32),
+        ("robust_loss", C.c_int32),
     ]
 
 
@@ -67,11 +67,16 @@ class Solver(Binding):
         if not handle:
             raise RuntimeError("cvd_create failed: " + (lib.cvd_last_error(None) or b"").decode())
         super().__init__(lib, "cvd_", handle)
+        self._options = None
 
     def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None,
-                    force_iterations=None, coarse_level=None):
-        o = SolverOptions()
-        self._lib.cvd_solver_options_default(C.byref(o))
+                    force_iterations=None, coarse_level=None, robust_loss=None):
+        """Options persist per handle: only the fields given change (robust_loss: 0 Cauchy = reference, 1 Huber)."""
+        o = self._options
+        if o is None:
+            o = SolverOptions()
+            self._lib.cvd_solver_options_default(C.byref(o))
+            self._options = o
         if pcg_relative_tolerance is not None:
             o.pcg_relative_tolerance = pcg_relative_tolerance
         if pcg_max_iterations is not None:
@@ -84,7 +89,13 @@ class Solver(Binding):
             o.force_iterations = int(force_iterations)
         if coarse_level is not None:
             o.coarse_level = int(coarse_level)
+        if robust_loss is not None:
+            o.robust_loss = int(robust_loss)
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
+
+    def set_robust_loss(self, kind):
+        """0: ceres::CauchyLoss(robustness) (the reference, lib/PoseOptimizer.cpp:1220); 1: ceres::HuberLoss(robustness)."""
+        self.set_options(robust_loss=kind)
 
     @staticmethod
     def comm_unique_id():

@@ -36,6 +36,8 @@ struct Layout {
   double ws, wd;      // staticSpatialWeight, staticDepthWeight
   double cauchyB;     // robustness^2
   double cauchyC;     // 1 / robustness^2
+  double robustA;     // robustness (Huber: rho = 2 a sqrt(s) - a^2 beyond s = a^2)
+  int robustKind;     // kRobustCauchy (the reference's CauchyLoss, lib/PoseOptimizer.cpp:1220) | kRobustHuber
   // regularisers (already decided by the host: 0 => skipped)
   double scaleRegSqrt;   // sqrt(scaleReg) (ScaledLoss => sqrt weight on the residual)
   int sregX, sregY;      // scale-regulariser sample grid
@@ -58,6 +60,32 @@ enum : int { kDepthIdentity = 1, kDepthGlobal = 2, kDepthGrid = 3 };
 enum : int { kSpIdentity = 1, kSpVertical = 2, kSpCorners = 3, kSpBilinear = 4, kSpBicubic = 5 };
 enum : int { kLossEuclid = 0, kLossDisparity = 1, kLossRatio = 2, kLossLog = 3 };
 enum : int { kIntrFixed = 0, kIntrShared = 1, kIntrPerFrame = 2 };
+enum : int { kRobustCauchy = 0, kRobustHuber = 1 };
+
+// rho(s), rho'(s) of the robust loss on a static constraint with squared norm s.  Cauchy: ceres::CauchyLoss(a), what the
+// reference hard-wires (lib/PoseOptimizer.cpp:1220); Huber: ceres::HuberLoss(a), the stress variant BASELINE.json's
+// configs[4] names (cvd_solver_options::robust_loss).  Both have rho'' <= 0, so Ceres' corrector reduces to the plain
+// sqrt(rho') scaling of residual and Jacobian in either case.  The branch is uniform over the launch.
+__device__ __forceinline__ void robustRho(const Layout& L, double sq, double& rho0, double& rho1) {
+  if (L.robustKind == kRobustHuber) {
+    if (sq > L.cauchyB) {
+      const double r = sqrt(sq);
+      rho0 = 2.0 * L.robustA * r - L.cauchyB;
+      rho1 = fmax(2.2250738585072014e-308, L.robustA / r);
+    } else {
+      rho0 = sq;
+      rho1 = 1.0;
+    }
+  } else {
+    const double sum = 1.0 + sq * L.cauchyC;
+    rho0 = L.cauchyB * log(sum);
+    rho1 = 1.0 / sum;
+  }
+}
+__device__ __forceinline__ double robustRho1(const Layout& L, double sq) {
+  if (L.robustKind == kRobustHuber) return sq > L.cauchyB ? fmax(2.2250738585072014e-308, L.robustA / sqrt(sq)) : 1.0;
+  return 1.0 / (1.0 + sq * L.cauchyC);
+}
 
 // Per-frame constants of one evaluation point (40 doubles).
 struct FrameConst {
@@ -419,9 +447,7 @@ __device__ __forceinline__ void evalSample(const Layout& L, const FrameConst& fa
   }
 
   const double sq = s.r[0] * s.r[0] + s.r[1] * s.r[1] + s.r[2] * s.r[2];
-  const double sum = 1.0 + sq * L.cauchyC;
-  s.rho0 = L.cauchyB * log(sum);
-  s.rho1 = 1.0 / sum;
+  robustRho(L, sq, s.rho0, s.rho1);
 
   if constexpr (WANT_JAC) {
     // world-point derivatives of side a

@@ -617,6 +617,9 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   L.wd = p.static_depth_weight;
   L.cauchyB = p.robustness * p.robustness;
   L.cauchyC = 1.0 / L.cauchyB;
+  L.robustA = p.robustness;
+  if (h->opt.robust_loss != 0 && h->opt.robust_loss != 1) throw std::runtime_error("robust_loss must be 0 (Cauchy) or 1 (Huber)");
+  L.robustKind = h->opt.robust_loss;
   // scale regulariser sample grid, reference lib/PoseOptimizer.cpp:1347-1351
   int gX = p.scale_reg_grid_size;
   int gY = static_cast<int>(std::round(static_cast<float>(gX) * h->invAspect));
@@ -2530,7 +2533,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->verbose = 0;
   o->force_iterations = 0;
   o->coarse_level = 1;
-  o->reserved = 0;
+  o->robust_loss = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
 void cvd_comm_unique_id(uint8_t* out128) {

@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
         dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
       }
     }
-    const double rho1 = 1.0 / (1.0 + (r0 * r0 + r1 * r1 + r2 * r2) * L.cauchyC);
+    const double rho1 = robustRho1(L, r0 * r0 + r1 * r1 + r2 * r2);
 
     // ---- forward: dX, dq, t
     const double cf[3] = {pax * A, pay, 0.0};
@@ -1900,9 +1900,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
             dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
           }
         }
-        const double sum = 1.0 + (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * L.cauchyC;
-        const double w = 1.0 / sum;  // rho'
-        if (!side) cost += L.cauchyB * log(sum);
+        double rho0, w;  // rho, rho'
+        robustRho(L, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho0, w);
+        if (!side) cost += rho0;
 
         // d r / d q (rows): M0 = (m00, 0, m02), M1 = (0, m11, m12), M2 = (0, 0, m22)
         const double wiz = L.ws * iz;

@@ -1113,6 +1113,7 @@ struct DvpoParams {  // reference lib/PoseOptimizer.h:54-108
   FrameRange frameRange;
   int maxIterations = 1000, numThreads = 12, numSteps = 4;
   double robustness = 0.5;
+  bool huberLoss = false;  // extension (no reference counterpart): ceres::HuberLoss(robustness) instead of the CauchyLoss
   StaticLossType staticLossType = StaticLossType::ReproDisparity;
   double staticSpatialWeight = 1.0, staticDepthWeight = 1.0;
   SmoothLossType smoothLossType = SmoothLossType::ReproDisparityLaplacian;
@@ -1367,6 +1368,12 @@ struct DepthVideoProcessor {
     upload(s, p, fc);
     std::vector<int32_t> range;
     const cvd_opt_params c = toC(p.poseOptimizer, range);
+    if (p.poseOptimizer.huberLoss) {
+      cvd_solver_options so;
+      cvd_solver_options_default(&so);
+      so.robust_loss = 1;
+      s.check(cvd_set_solver_options(s.h, &so));
+    }
     {
       py::gil_scoped_release nogil;
       s.check(cvd_pose_optimization(s.h, &c));
@@ -1675,7 +1682,7 @@ PYBIND11_MODULE(lib_python, m) {
       .def(py::init<const DvpoParams&>())
       .def_readwrite("frameRange", &DvpoParams::frameRange).def_readwrite("maxIterations", &DvpoParams::maxIterations)
       .def_readwrite("numThreads", &DvpoParams::numThreads).def_readwrite("numSteps", &DvpoParams::numSteps)
-      .def_readwrite("robustness", &DvpoParams::robustness).def_readwrite("staticLossType", &DvpoParams::staticLossType)
+      .def_readwrite("robustness", &DvpoParams::robustness).def_readwrite("huberLoss", &DvpoParams::huberLoss).def_readwrite("staticLossType", &DvpoParams::staticLossType)
       .def_readwrite("staticSpatialWeight", &DvpoParams::staticSpatialWeight).def_readwrite("staticDepthWeight", &DvpoParams::staticDepthWeight)
       .def_readwrite("smoothLossType", &DvpoParams::smoothLossType).def_readwrite("smoothStaticWeight", &DvpoParams::smoothStaticWeight)
       .def_readwrite("smoothDynamicWeight", &DvpoParams::smoothDynamicWeight).def_readwrite("positionReg", &DvpoParams::positionReg)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mint tests/golden/reference_pairs.npz by IMPORTING the reference's own frame-pair sampler.
+"""Mint tests/golden/reference_py/reference_pairs.npz by IMPORTING the reference's own frame-pair sampler.
 
 The one piece of the path's inputs that is Python in the reference: `SamplePairs.sample_hierarchical2`
 (reference utils/frame_sampling.py:77-120), which produces the flow_list the optimizer's constraints are built on
@@ -7,7 +7,7 @@ The one piece of the path's inputs that is Python in the reference: `SamplePairs
 build container); the vectors it writes travel with the repository and pin `robust_cvd_amd.synth.hierarchical_pairs`
 against the real reference code (tests/test_synth.py::test_pairs_match_reference_sampler).
 
-    python tests/golden/make_pairs_golden.py
+    python tests/golden/reference_py/make_pairs_golden.py
 """
 import importlib.util
 import os

@@ -17,8 +17,9 @@ def rodrigues(w):
     return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
 
 
-def numpy_static_cost(video, pose, theta, params, loss):
-    """Independent restatement of SURVEY.md Appendix A.1-A.4 for Global/Scale depth, identity spatial."""
+def numpy_static_cost(video, pose, theta, params, loss, robust="cauchy", counts=None):
+    """Independent restatement of SURVEY.md Appendix A.1-A.4 for Global/Scale depth, identity spatial.
+    robust: "cauchy" (the reference's CauchyLoss) or "huber" (ceres::HuberLoss, the stress variant)."""
     F, W, H = video.num_frames, video.width, video.height
     A = np.float64(np.float32(video.aspect))
     inv = np.float32(video.inv_aspect)
@@ -51,7 +52,12 @@ def numpy_static_cost(video, pose, theta, params, loss):
                 else:
                     r[2] = np.log(min(z, Db) / max(z, Db))
             s = r @ r
-            total += 0.5 * b * np.log1p(s / b)
+            if robust == "cauchy":
+                total += 0.5 * b * np.log1p(s / b)
+            else:
+                total += 0.5 * (s if s <= b else 2.0 * params.robustness * np.sqrt(s) - b)
+                if counts is not None:
+                    counts[int(s > b)] += 1
     return total
 
 
@@ -79,6 +85,68 @@ def test_static_cost_matches_independent_numpy(loss):
     ref = numpy_static_cost(v, pose, theta, p, loss)
     assert ev["num_residual_blocks"] == v.num_constraints
     assert abs(ev["cost"] - ref) <= 1e-12 * abs(ref)
+
+
+@pytest.mark.parametrize("loss", [StaticLossType.ReproDisparity, StaticLossType.Euclidean])
+def test_huber_cost_matches_independent_numpy(loss):
+    """HuberLoss(robustness) on the static constraints (cvd_solver_options::robust_loss = 1; BASELINE configs[4])."""
+    v = synth.make_video(3, 48, 28, seed=4, spacing=8)
+    o = Oracle()
+    synth.load_into(o, v)
+    o.set_robust_loss(1)
+    o.reset_depth_xforms(XformDesc.global_depth())
+    o.reset_spatial_xforms(XformDesc.spatial())
+    p = OptParams.defaults()
+    p.num_threads = 1
+    p.static_loss_type = loss
+    p.scale_reg = 0.0
+    p.focal_reg = 0.0
+    p.robustness = 1.0   # the random state puts about half of the constraints beyond the Huber threshold
+    rng = np.random.default_rng(3)
+    pose = np.zeros((3, 7))
+    pose[:, :3] = rng.normal(0, 0.05, (3, 3))
+    pose[1:, 3:6] = rng.normal(0, 0.05, (2, 3))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.05, 3)
+    theta = 0.15 + rng.uniform(0, 0.05, 3)
+    o.set_xform_params(theta[:, None])
+    ev = o.evaluate(p, 0.0, pose, want_gradient=False)
+    counts = [0, 0]
+    ref = numpy_static_cost(v, pose, theta, p, loss, robust="huber", counts=counts)
+    assert min(counts) > 0.05 * sum(counts), counts   # both branches of the loss are exercised
+    assert abs(ev["cost"] - ref) <= 1e-12 * abs(ref)
+    # and the default stays the reference's Cauchy loss
+    o.set_robust_loss(0)
+    ev0 = o.evaluate(p, 0.0, pose, want_gradient=False)
+    assert abs(ev0["cost"] - numpy_static_cost(v, pose, theta, p, loss)) <= 1e-12 * abs(ev0["cost"])
+    with pytest.raises(RuntimeError):
+        o.set_robust_loss(7)
+
+
+def test_huber_gradient_matches_central_differences():
+    v = synth.make_video(4, 48, 28, seed=3, spacing=9)
+    o = Oracle()
+    synth.load_into(o, v)
+    o.set_robust_loss(1)
+    o.reset_depth_xforms(XformDesc.grid_depth(4, 3))
+    o.reset_spatial_xforms(XformDesc.spatial())
+    p = OptParams.defaults()
+    p.num_threads = 1
+    p.robustness = 1.0
+    rng = np.random.default_rng(0)
+    F, B = v.num_frames, o.block_size()
+    pose, dx, sx = random_state(o, F, XformDesc.grid_depth(4, 3), rng)
+    o.set_xform_params(dx, False)
+    g = o.evaluate(p, 0.1, pose)["gradient"]
+    h = 1e-6
+    worst, scale = 0.0, 0.0
+    for k in rng.choice(F * 7, size=12, replace=False):
+        f, j = divmod(int(k), 7)
+        Pp, Pm = pose.copy(), pose.copy()
+        Pp[f, j] += h
+        Pm[f, j] -= h
+        fd = (o.evaluate(p, 0.1, Pp, want_gradient=False)["cost"] - o.evaluate(p, 0.1, Pm, want_gradient=False)["cost"]) / (2 * h)
+        worst, scale = max(worst, abs(fd - g[f, j])), max(scale, abs(fd))
+    assert worst < 5e-6 * scale, (worst, scale)
 
 
 CONFIGS = [

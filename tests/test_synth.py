@@ -63,9 +63,9 @@ def test_zero_noise_flow_is_geometrically_consistent():
 
 def test_pairs_match_reference_sampler():
     """Pinned against the REAL reference: vectors minted by importing reference utils/frame_sampling.py
-    (tests/golden/make_pairs_golden.py), every mode that runs through sample_hierarchical."""
+    (tests/golden/reference_py/make_pairs_golden.py), every mode that runs through sample_hierarchical."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_pairs.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_py", "reference_pairs.npz"))
     checked = 0
     for n in (2, 3, 5, 8, 17, 30, 100, 300):
         for tw in (True, False):
