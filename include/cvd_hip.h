@@ -204,6 +204,14 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6)
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
 /* Number of (valid static) constraints in the compiled table of the last solve. */
 int64_t cvd_num_active_constraints(cvd_handle* h);
+/* Parity hook for the per-frame dense solve of the block-Jacobi preconditioner (no reference counterpart: Ceres'
+ * SPARSE_NORMAL_CHOLESKY, lib/PoseOptimizer.cpp:956, is replaced by PCG): inverts `num_blocks` symmetric positive
+ * definite block_size x block_size f64 matrices `a` (row-major, block after block) with the very kernel the solver uses
+ * and returns the f32 inverses.  variant 0: blocked sweep on the f64 matrix cores (the default path), 1: scalar
+ * register-tile sweep, 2: LDS Cholesky.  failed = number of non-positive pivots met. */
+int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block_size, const double* a, int32_t variant,
+                                float* inverse, int32_t* failed);
+
 /* Test hook for the coarse level of the preconditioner (state of the last LM iteration of the last solve):
  * n = 8 * frames (0 when the level was off), a_c = Z^T (J^T J + diag(lam)) Z as a dense n x n matrix assembled
  * from its blocks, a_c_inverse = the inverse the solver applied, failed = pivot failures of the factorisation.

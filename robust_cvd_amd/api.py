@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
     "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
+    "cvd_block_inverse_debug",
 ]
 
 KERNEL_CLASSES = ["evaluate_assemble", "matvec_pairs", "matvec_finish", "cg_update", "block_inverse", "cost"]
@@ -135,6 +136,19 @@ class Solver(Binding):
 
     def num_active_constraints(self):
         return int(self._lib.cvd_num_active_constraints(self._h))
+
+    def block_inverse_debug(self, blocks, variant=0):
+        """f32 inverses of SPD f64 blocks [n, B, B] through the block-Jacobi kernel (variant 0 MFMA blocked sweep = the
+        default path, 1 scalar sweep, 2 LDS Cholesky) and the number of failed pivots."""
+        import numpy as np
+        a = np.ascontiguousarray(blocks, dtype=np.float64)
+        n, B, B2 = a.shape
+        assert B == B2
+        out = np.zeros((n, B, B), dtype=np.float32)
+        fl = C.c_int32(0)
+        self._check(self._fn("block_inverse_debug")(self._h, C.c_int32(n), C.c_int32(B), a.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    C.c_int32(variant), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(fl)))
+        return out, fl.value
 
     def coarse_debug(self):
         """(A_c, A_c^-1 as applied, pivot failures) of the coarse preconditioner level after the last solve."""

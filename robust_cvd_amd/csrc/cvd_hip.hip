@@ -1528,12 +1528,33 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   }
 }
 
-// M_f^-1 = (H_ff + diag(lam_f))^-1 for every frame (f32 output).  Register-resident sweep for B <= 256 (4x4 tiles,
-// up to 3 per thread at 1024 threads); the LDS Cholesky kernel is kept for comparison (set_generic_kernels).
-static void launchBlockInverse(Ctx& c) {
-  cvd_handle* h = c.h;
+// M_f^-1 = (H_ff + diag(lam_f))^-1 for every frame (f32 output).
+//   variant 0 (default): blocked sweep on the f64 matrix cores (k_block_inverse_mfma, 16-wide pivot blocks);
+//   variant 1: scalar register-resident sweep (4x4 / 6x6 tiles); variant 2: LDS Cholesky (set_generic_kernels).
+// The three are kept because they pin each other (tests/test_gpu_block_inverse.py).
+static void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv,
+                                  int* dFail, int variant) {
   hipStream_t s = h->stream;
-  const int B = c.L.B;
+  const int B = L.B;
+  if (variant == 0) {
+    const int nbm = (B + kInvTS - 1) / kInvTS, nTilesM = nbm * (nbm + 1) / 2;
+    const size_t ldsM = static_cast<size_t>(std::max(2 * nbm + 1, 16)) * kInvTile * sizeof(double);  // (>= one tile per wave for the final transpose)
+#define CVD_LAUNCH_INV_MFMA(NWV, TPWV)                                                                                   \
+    do {                                                                                                                 \
+      allowLds((k_block_inverse_mfma<NWV, TPWV>), ldsM);                                                                 \
+      hipLaunchKernelGGL((k_block_inverse_mfma<NWV, TPWV>), dim3(L.F), dim3(NWV * 64), ldsM, s, L, dH, dLam, dMinv, dFail); \
+    } while (0)
+    if (nTilesM <= 4) CVD_LAUNCH_INV_MFMA(4, 1);
+    else if (nTilesM <= 24) CVD_LAUNCH_INV_MFMA(8, 3);
+    else if (nTilesM <= 48) CVD_LAUNCH_INV_MFMA(8, 6);
+    else if (nTilesM <= 80) CVD_LAUNCH_INV_MFMA(8, 10);
+    else if (nTilesM <= 96) CVD_LAUNCH_INV_MFMA(16, 6);
+    else if (nTilesM <= 144) CVD_LAUNCH_INV_MFMA(16, 9);
+    else throw std::runtime_error("frame block larger than 256 unknowns is not supported by the block inverse");
+#undef CVD_LAUNCH_INV_MFMA
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int nb = (B + 3) / 4, nTiles = nb * (nb + 1) / 2;
   const int nT = std::min(1024, ((nTiles + 63) / 64) * 64);
   const int tpt = (nTiles + nT - 1) / nT;
@@ -1542,27 +1563,33 @@ static void launchBlockInverse(Ctx& c) {
   // same 128 registers), so that e.g. 300 frames run in one round instead of 256 + 44 (B = 177: 465 tiles).
   const int nb6 = (B + 5) / 6, nTiles6 = nb6 * (nb6 + 1) / 2;
   static const bool noTs6 = std::getenv("CVD_BLOCK_INVERSE_TS4") != nullptr;  // development knob
-  if (!h->forceGeneric && !noTs6 && nTiles > 512 && nTiles6 <= 512) {
-    hipLaunchKernelGGL((k_block_inverse_sweep<1, 6>), dim3(c.L.F), dim3(((nTiles6 + 63) / 64) * 64), 0, s, c.L, h->dH.p,
-                       h->dLam.p, h->dMinv.p, h->dFail.p);
+  if (variant == 1 && !noTs6 && nTiles > 512 && nTiles6 <= 512) {
+    hipLaunchKernelGGL((k_block_inverse_sweep<1, 6>), dim3(L.F), dim3(((nTiles6 + 63) / 64) * 64), 0, s, L, dH, dLam, dMinv,
+                       dFail);
     HIP_CHECK(hipGetLastError());
     return;
   }
   // three tiles per thread spill: prefer the LDS Cholesky there while its triangle still fits (B <= 199)
-  if (!h->forceGeneric && (tpt <= 2 || (tpt == 3 && ldsChol > 160 * 1024))) {
+  if (variant == 1 && (tpt <= 2 || (tpt == 3 && ldsChol > 160 * 1024))) {
     if (tpt == 1)
-      hipLaunchKernelGGL(k_block_inverse_sweep<1>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+      hipLaunchKernelGGL(k_block_inverse_sweep<1>, dim3(L.F), dim3(nT), 0, s, L, dH, dLam, dMinv, dFail);
     else if (tpt == 2)
-      hipLaunchKernelGGL(k_block_inverse_sweep<2>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+      hipLaunchKernelGGL(k_block_inverse_sweep<2>, dim3(L.F), dim3(nT), 0, s, L, dH, dLam, dMinv, dFail);
     else
-      hipLaunchKernelGGL(k_block_inverse_sweep<3>, dim3(c.L.F), dim3(nT), 0, s, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p);
+      hipLaunchKernelGGL(k_block_inverse_sweep<3>, dim3(L.F), dim3(nT), 0, s, L, dH, dLam, dMinv, dFail);
   } else {
     const size_t lds = ldsChol;
     allowLds(k_block_inverse, lds);
-    hipLaunchKernelGGL(k_block_inverse, dim3(c.L.F), dim3(std::min<int>(1024, ((4 * B + 63) / 64) * 64)), lds, s, c.L,
-                       h->dH.p, h->dLam.p, h->dMinv.p, static_cast<double*>(nullptr), h->dFail.p);
+    hipLaunchKernelGGL(k_block_inverse, dim3(L.F), dim3(std::min<int>(1024, ((4 * B + 63) / 64) * 64)), lds, s, L, dH, dLam,
+                       dMinv, static_cast<double*>(nullptr), dFail);
   }
   HIP_CHECK(hipGetLastError());
+}
+
+static void launchBlockInverse(Ctx& c) {
+  cvd_handle* h = c.h;
+  static const bool scalarSweep = std::getenv("CVD_BLOCK_INVERSE_SWEEP") != nullptr;  // comparison: the scalar sweep
+  launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, h->forceGeneric ? 2 : (scalarSweep ? 1 : 0));
 }
 
 // Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
@@ -2858,6 +2885,37 @@ int32_t cvd_set_pair_graph(cvd_handle* h, int32_t numPairs, const int32_t* pairF
     h->globalEdges.assign(uniq.begin(), uniq.end());
     h->haveGlobalEdges = numPairs > 0;
     h->tableValid = false;
+  });
+}
+
+int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block_size, const double* a, int32_t variant,
+                                float* inverse, int32_t* failed) {
+  CVD_TRY(h, {
+    if (num_blocks <= 0 || block_size <= 0 || block_size > 256) throw std::runtime_error("block_inverse_debug: bad sizes");
+    if (variant < 0 || variant > 2) throw std::runtime_error("block_inverse_debug: variant must be 0, 1 or 2");
+    const size_t n = static_cast<size_t>(num_blocks) * block_size * block_size;
+    DevBuf<double> dA;
+    DevBuf<double> dL;
+    DevBuf<float> dM;
+    DevBuf<int> dF;
+    dA.ensure(n);
+    dL.ensure(static_cast<size_t>(num_blocks) * block_size);
+    dM.ensure(n);
+    dF.ensure(1);
+    hipStream_t s = h->stream;
+    dA.upload(a, n, s);
+    HIP_CHECK(hipMemsetAsync(dL.p, 0, static_cast<size_t>(num_blocks) * block_size * sizeof(double), s));
+    HIP_CHECK(hipMemsetAsync(dM.p, 0, n * sizeof(float), s));
+    HIP_CHECK(hipMemsetAsync(dF.p, 0, sizeof(int), s));
+    Layout L{};
+    L.F = num_blocks;
+    L.B = block_size;
+    launchBlockInverseRaw(h, L, dA.p, dL.p, dM.p, dF.p, variant);
+    int fl = 0;
+    dM.download(inverse, n, s);
+    dF.download(&fl, 1, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failed) *failed = fl;
   });
 }
 

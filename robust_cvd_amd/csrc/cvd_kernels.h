@@ -636,6 +636,265 @@ __global__ __launch_bounds__(TS == 4 ? 1024 : 512, 4) void k_block_inverse_sweep
 
 
 // ---------------------------------------------------------------------------------------------------
+// Block-Jacobi preconditioner on the matrix cores: the same symmetric sweep, BLOCKED with 16-wide pivot blocks so
+// that the work is dense 16x16x16 products on v_mfma_f64_16x16x4_f64 and the dependent chain is nb = ceil(B / 16)
+// block steps instead of B scalar pivots.  Sweeping pivot block k (P = G_kk^-1) maps
+//   G_kk <- -P,   G_ik <- G_ik P,   G_kj <- P G_kj,   G_ij <- G_ij - G_ik P G_kj        (i, j != k)
+// (= the composition of the block's 16 scalar sweeps) and after all nb blocks G = -A^-1.
+// Layout: the lower-triangle 16x16 tiles (i >= j) live in MFMA accumulator registers for the whole kernel, tile
+// id = wave + s * NW (TPW tiles per wave; accumulator layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 r).
+// Per block step:
+//   A  the owners of the tiles of block row / column k publish the panel A(:, k) to LDS (row tiles transposed);
+//      the owner wave of the pivot tile inverts it in-wave (scalar symmetric sweep on a 4-elements-per-lane layout,
+//      pivot row / column exchanged by lane shuffles) and publishes G_kk = -P;
+//   B  every wave forms its share of -T_i = A(i, k) (-P) (4 MFMAs per tile) into the LDS T panel;
+//   C  every wave updates its tiles: G_ij += (-T_i) A(j, k)^T (4 MFMAs per tile, operands from the two LDS panels);
+//      tiles of block row / column k are replaced by T_i resp. T_j^T, the pivot tile by -P.
+// Three barriers per block step, 3 nb in total (B = 177: 36 instead of 177).  Padding (B not a multiple of 16) is
+// identity.  f64 in, f64 arithmetic, f32 out (what k_cg_update consumes), like the scalar kernels.
+typedef double cvd_d4 __attribute__((ext_vector_type(4)));
+#ifdef CVD_INV_PROFILE  // tools/inv_bench.hip: shader-clock cycles per phase and wave of workgroup 0
+__device__ unsigned long long g_invProf[16 * 8];
+#define CVD_INV_T(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[slot] += t_ - tLast; tLast = t_; } while (0)
+#else
+#define CVD_INV_T(slot) do { } while (0)
+#endif
+__device__ __forceinline__ double readlaneF64(double v, int srcLane) {  // srcLane uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ double rowBroadcastF64(double v) {  // lane SRC of every 16-lane row to the whole row (DPP row_newbcast)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + SRC, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + SRC, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// One scalar sweep of the 16x16 pivot tile in the (row, column group) lane layout of k_block_inverse_mfma.
+template <int P>
+__device__ __forceinline__ void invPivotStep(double (&g)[4], int row, int cg, int& bad) {
+  const double gi = __shfl(g[P & 3], row + 16 * (P >> 2), 64);
+  double d = readlaneF64(g[P & 3], P + 16 * (P >> 2));
+  double cj[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) cj[e] = rowBroadcastF64<P>(g[e]);
+  if (!(d > 0.0)) {  // uniform
+    bad = 1;
+    d = 1.0;
+  }
+  // 1 / d by v_rcp_f64 + two Newton steps (~1 ulp; the result is stored as f32): the IEEE division sequence is twice as
+  // long and sits on the dependent chain of all 16 pivots
+  double id = __builtin_amdgcn_rcp(d);
+  id = fma(fma(-d, id, 1.0), id, id);
+  id = fma(fma(-d, id, 1.0), id, id);
+  const double ci = gi * id;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double v = g[e] - ci * cj[e];
+    if (row == P) v = cj[e] * id;
+    if (4 * cg + e == P) v = (row == P) ? -id : ci;
+    g[e] = v;
+  }
+}
+constexpr int kInvTS = 16;            // tile size = MFMA M = N
+constexpr int kInvLd = 17;            // LDS row stride of a tile (doubles): conflict-free operand reads
+constexpr int kInvTile = kInvTS * kInvLd;
+
+template <int NW, int TPW>
+__global__ __launch_bounds__(NW * 64, 4) void k_block_inverse_mfma(Layout L, const double* __restrict__ hBlocks,
+                                                               const double* __restrict__ lam, float* __restrict__ minv,
+                                                               int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double invSmem[];
+  const int B = L.B;
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nb = (B + kInvTS - 1) / kInvTS;
+  const int nTiles = nb * (nb + 1) / 2;
+  double* panel = invSmem;                     // [nb][16][17]  A(m, k) of the current block step
+  double* tneg = invSmem + nb * kInvTile;      // [nb][16][17]  -T_m = A(m, k) (-P)
+  double* piv = tneg + nb * kInvTile;          // [16][17]      G_kk = -P
+  const int c = lane & 15, r0 = lane >> 4;
+  const double* hf = hBlocks + static_cast<size_t>(f) * B * B;
+  const double* lf = lam + static_cast<size_t>(f) * B;
+
+#ifdef CVD_INV_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tLast = __builtin_amdgcn_s_memtime();
+#endif
+  cvd_d4 acc[TPW];
+  int tI[TPW], tJ[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    const int id = w + s * NW;
+    int I = -1, J = -1;
+    if (id < nTiles) {
+      I = static_cast<int>((sqrtf(8.f * static_cast<float>(id) + 1.f) - 1.f) * 0.5f);
+      while ((I + 1) * (I + 2) / 2 <= id) ++I;
+      while (I * (I + 1) / 2 > id) --I;
+      J = id - I * (I + 1) / 2;
+    }
+    tI[s] = __builtin_amdgcn_readfirstlane(I);
+    tJ[s] = __builtin_amdgcn_readfirstlane(J);
+    // unconditional loads from clamped addresses: all of a wave's loads are in flight before the first one is used
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kInvTS * (I < 0 ? 0 : I) + r0 + 4 * r, j = kInvTS * (J < 0 ? 0 : J) + c;
+      acc[s][r] = hf[static_cast<size_t>(min(i, B - 1)) * B + min(j, B - 1)];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = acc[s][r];
+      asm volatile("" : "+v"(v));  // (keeps the compiler from sinking the load into the bounds test below)
+      const int i = kInvTS * tI[s] + r0 + 4 * r, j = kInvTS * tJ[s] + c;
+      const bool in = tI[s] >= 0 && i < B && j < B;
+      if (tI[s] == tJ[s] && i == j && in) v += lf[i];   // damping on the diagonal (diagonal tiles only: wave-uniform)
+      acc[s][r] = in ? v : (i == j ? 1.0 : 0.0);
+    }
+  }
+  CVD_INV_T(0);
+  for (int k = 0; k < nb; ++k) {
+    // ---- A: publish the panel of block column k; the pivot tile's owner inverts it
+    bool ownsPivot = false;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      if (tI[s] < 0) continue;
+      if (tJ[s] == k && tI[s] > k) {          // A(i, k) as stored
+        int o = tI[s] * kInvTile;
+        asm volatile("" : "+s"(o));
+        double* dst = panel + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+      } else if (tI[s] == k && tJ[s] < k) {   // A(j, k) = A(k, j)^T
+        int o = tJ[s] * kInvTile;
+        asm volatile("" : "+s"(o));
+        double* dst = panel + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[c * kInvLd + r0 + 4 * r] = acc[s][r];
+      } else if (tI[s] == k && tJ[s] == k) {  // pivot tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) piv[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+        ownsPivot = true;
+      }
+    }
+    CVD_INV_T(1);
+    if (ownsPivot) {  // wave-uniform: in-wave inverse of the pivot tile, G_kk <- -P
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // lane = (row = lane & 15, column group cg = lane >> 4): 4 elements G[row][4 cg + e] per lane.  Pivot step p needs
+      //   G[p][4 cg + e]  from lane p of the SAME 16-lane row group  -> DPP row broadcast (VALU move, no LDS round trip)
+      //   G[p][p]         from one known lane                         -> v_readlane
+      //   G[row][p]       from lane row + 16 (p >> 2)                 -> the one ds_bpermute of the step
+      const int row = lane & 15, cg = lane >> 4;
+      double g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = piv[row * kInvLd + 4 * cg + e];
+      int bad = 0;
+      invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
+      invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
+      invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
+      invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
+      invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
+      invPivotStep<15>(g, row, cg, bad);
+      if (bad && lane == 0) atomicAdd(fail, 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) piv[row * kInvLd + 4 * cg + e] = g[e];
+      CVD_INV_T(2);
+    }
+    __syncthreads();
+    CVD_INV_T(3);
+    // ---- B: -T_m = A(m, k) (-P) for every m != k
+    for (int m = w; m < nb; m += NW) {
+      if (m == k) continue;
+      cvd_d4 t = {0.0, 0.0, 0.0, 0.0};
+      const double* src = panel + m * kInvTile;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(src[c * kInvLd + 4 * kk + r0], piv[(4 * kk + r0) * kInvLd + c], t, 0, 0, 0);
+      double* dst = tneg + m * kInvTile;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(r0 + 4 * r) * kInvLd + c] = t[r];
+    }
+    CVD_INV_T(4);
+    __syncthreads();
+    CVD_INV_T(5);
+    // ---- C: rank-16 update G_ij += (-T_i) A(j, k)^T of EVERY owned tile, branch-free so that the operand loads of the
+    // next tile overlap the MFMAs of this one (tiles of block row / column k read stale panel slots: their result is
+    // discarded by the fix-up below; unused slots update tile (0, 0) into a register nobody stores)
+    const int laneOp = c * kInvLd + r0;  // operand element [row = c][k = 4 kk + r0] of a panel tile
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      int oa = (tI[s] < 0 ? 0 : tI[s]) * kInvTile, ob = (tJ[s] < 0 ? 0 : tJ[s]) * kInvTile;
+      asm volatile("" : "+s"(oa), "+s"(ob));  // keep the per-tile LDS addresses out of loop-invariant VGPRs (they spill)
+      const double* ta = tneg + oa + laneOp;
+      const double* pb = panel + ob + laneOp;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4 * kk], pb[4 * kk], acc[s], 0, 0, 0);
+    }
+    // fix-up: block row / column k and the pivot tile are replaced (nb of the nTiles tiles per step)
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      if (tI[s] != k && tJ[s] != k) continue;
+      if (tI[s] == k && tJ[s] == k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = piv[(r0 + 4 * r) * kInvLd + c];
+      } else if (tJ[s] == k) {   // i > k: G_ik <- T_i
+        int o = tI[s] * kInvTile;
+        asm volatile("" : "+s"(o));
+        const double* src = tneg + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -src[(r0 + 4 * r) * kInvLd + c];
+      } else {                   // j < k: G_kj <- T_j^T
+        int o = tJ[s] * kInvTile;
+        asm volatile("" : "+s"(o));
+        const double* src = tneg + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -src[c * kInvLd + r0 + 4 * r];
+      }
+    }
+    CVD_INV_T(6);
+    __syncthreads();
+    CVD_INV_T(5);
+  }
+
+  // A^-1 = -G in f32: the tile as it lies, and its mirror image transposed through a private LDS tile so that both
+  // stores run along rows (the panels are free now: the loop ended on a barrier)
+  float* Mf = minv + static_cast<size_t>(f) * B * B;
+  double* scratch = invSmem + w * kInvTile;
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    if (tI[s] < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kInvTS * tI[s] + r0 + 4 * r, j = kInvTS * tJ[s] + c;
+      if (i < B && j < B) Mf[static_cast<size_t>(i) * B + j] = static_cast<float>(-acc[s][r]);
+    }
+    if (tI[s] != tJ[s]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kInvTS * tI[s] + c, j = kInvTS * tJ[s] + r0 + 4 * r;  // element (i, j) of the tile -> M[j][i]
+        const double v = scratch[c * kInvLd + r0 + 4 * r];
+        if (i < B && j < B) Mf[static_cast<size_t>(j) * B + i] = static_cast<float>(-v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#ifdef CVD_INV_PROFILE
+  CVD_INV_T(7);
+  if (f == 0 && lane == 0)
+    for (int q = 0; q < 8; ++q) g_invProf[w * 8 + q] = prof[q];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Block-Jacobi preconditioner: Minv_f = (H_ff + diag(lam_f))^-1.  One workgroup per frame, Cholesky of
 // the packed lower triangle in LDS, L^-1 by column-parallel forward substitution (global scratch,
 // L2-resident), Minv = L^-T L^-1.

@@ -5,9 +5,13 @@ import numpy as np
 from robust_cvd_amd import api, synth
 from robust_cvd_amd.ctypes_types import *
 
-def run(name, F, W, H, setup, params_mod=None, steps=None):
-    v = synth.make_video(F, W, H, seed=1234 + len(name))
+_videos = {}
+def run(name, F, W, H, setup, params_mod=None, steps=None, robust=0, seed=None):
+    key = (F, W, H, seed)
+    if key not in _videos: _videos[key] = synth.make_video(F, W, H, seed=seed if seed is not None else 1234 + len(name))
+    v = _videos[key]
     s = api.Solver(0); synth.load_into(s, v)
+    s.set_robust_loss(robust)
     p = OptParams.defaults()
     if params_mod: params_mod(p)
     t0 = time.time()
@@ -37,4 +41,10 @@ def mod4(p): p.ctf_long, p.ctf_short = 16, 12
 run("configs[0]", 30, 192, 112, cfg0, mod0)
 run("configs[1]", 100, 384, 224, cfg1)
 run("configs[2]", 300, 384, 224, cfg2)
-run("configs[4]-like", int(os.environ.get("CFG4_FRAMES", "200")), 640, 384, cfg4, mod4)
+# configs[4] on ONE GPU (the 8-GPU run is the driver's): 1000 frames 640x384, 16x12 grid, the reference's Cauchy loss and
+# the Huber stress variant BASELINE.json names (cvd_solver_options::robust_loss = 1)
+F4 = int(os.environ.get("CFG4_FRAMES", "1000"))
+run("configs[4] Cauchy 0.5", F4, 640, 384, cfg4, mod4, seed=1238)
+run("configs[4] Huber 0.5", F4, 640, 384, cfg4, mod4, robust=1, seed=1238)
+def mod4h(p): mod4(p); p.robustness = 0.01
+run("configs[4] Huber 0.01", F4, 640, 384, cfg4, mod4h, robust=1, seed=1238)
