@@ -766,6 +766,20 @@ struct CoarseStep {
   double* y;            // [F][kCB] by elimination position
   double* fdotY;        // [F] |y_i|^2
   const int* fail;
+  const double* wq;     // [nW][kCB] products W_block (Z^T q)_column in ROW order (slot = position in the row lists):
+                        // written column by column by coarseColumnProducts in the kernel that completes q
+};
+// Column half of y <- y - alpha W (Z^T q): the workgroup of frame f multiplies the blocks of ITS column of W (contiguous:
+// the elimination-tree path of the frame, <= tree depth blocks) with its restricted product and stores each 8-vector at
+// the block's slot in the row lists.  The row half (k_cg_update) then sums contiguous 8-vectors instead of gathering a
+// 512 B block and a restricted vector per entry -- the rows near the root of the tree hold one entry per frame and were
+// that kernel's critical path.  Fixed summation order on both sides: deterministic, no atomics.
+struct CoarseColumns {
+  const int* pos;       // frame -> elimination position (column of W)
+  const int* wPtr;      // column j: blocks [wPtr[j], wPtr[j+1])
+  const int* wSlot;     // block -> slot in the row lists
+  const double* Wb;
+  double* wq;           // [nW][kCB]
 };
 // masked restriction Z_f^T v_f of one frame's vector (LDS or global) by the calling workgroup: threads 0..6 the
 // pose-like entries, wave 1 the sum over the depth-scale vertices
@@ -822,6 +836,37 @@ __device__ __forceinline__ double dppMove(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void coarseColumnProducts(const CoarseColumns& cc, const double* __restrict__ qcF, int f, int tid,
+                                                     int nThreads) {
+  const int wv = tid >> 6, lane = tid & 63, c8 = lane & 7, nWv = nThreads >> 6;
+  if (cc.Wb == nullptr) return;
+  const int j = cc.pos[f];
+  if (j < 0) return;
+  const double qv = qcF[c8];
+  // four blocks per wave and pass, loads first (clamped index, predicated store): the path is <= tree depth blocks long and
+  // this sits at the very end of the kernel that completes q, so it is pure latency
+  constexpr int U = 4;
+  const int t1 = cc.wPtr[j + 1];
+  for (int t0 = cc.wPtr[j] + wv; t0 < t1; t0 += U * nWv) {
+    double v[U];
+    int slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tc = min(t0 + u * nWv, t1 - 1);
+      v[u] = cc.Wb[static_cast<size_t>(tc) * 64 + lane];
+      slot[u] = cc.wSlot[tc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double a = v[u] * qv;
+      a += dppMove<0xB1>(a);
+      a += dppMove<0x4E>(a);
+      a += dppMove<0x141>(a);
+      if (c8 == 0 && t0 + u * nWv < t1) cc.wq[static_cast<size_t>(slot[u]) * kCB + (lane >> 3)] = a;
+    }
+  }
 }
 __device__ __forceinline__ double readLane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

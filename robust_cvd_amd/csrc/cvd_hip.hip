@@ -345,8 +345,8 @@ struct cvd_handle_t {
     int nEdges = 0, nBlocks = 0, nLevels = 0;
     std::vector<int> itemEdge;
     DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr, updBlk,
-        updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev;
-    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY;
+        updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
+    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq;
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
@@ -852,9 +852,13 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   for (int j = 0; j < F; ++j)
     for (int t = wPtr[j]; t < wPtr[j + 1]; ++t) wt[wRow[t]].push_back({j, t});
   std::vector<int> wtPtr(F + 1, 0), wtBlk, wtCol, wtFrame;
+  std::vector<int> wSlot(nW, 0);  // W block -> its slot in the row lists (coarseColumnProducts writes there)
   for (int i = 0; i < F; ++i) {
     wtPtr[i + 1] = wtPtr[i] + static_cast<int>(wt[i].size());
-    for (const auto& e : wt[i]) { wtCol.push_back(e.first); wtBlk.push_back(e.second); wtFrame.push_back(order[e.first]); }
+    for (const auto& e : wt[i]) {
+      wSlot[e.second] = static_cast<int>(wtBlk.size());
+      wtCol.push_back(e.first); wtBlk.push_back(e.second); wtFrame.push_back(order[e.first]);
+    }
   }
   std::vector<int> wuPtr(nW + 1, 0), wuL, wuW;
   {
@@ -914,7 +918,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   up(C.colPtr, colPtr); up(C.rowPtr, rowPtr); up(C.rowBlk, rowBlk); up(C.updPtr, updPtr); up(C.updA, updA);
   up(C.updB, updB); up(C.updBlk, updBlk); up(C.edgeBlk, edgeBlk); up(C.edgeFa, edgeFa); up(C.edgeFb, edgeFb);
   up(C.wPtr, wPtr); up(C.wRow, wRow); up(C.wtPtr, wtPtr); up(C.wtBlk, wtBlk); up(C.wtCol, wtCol); up(C.wtFrame, wtFrame);
-  up(C.wuPtr, wuPtr); up(C.wuL, wuL); up(C.wuW, wuW);
+  up(C.wuPtr, wuPtr); up(C.wuL, wuL); up(C.wuW, wuW); up(C.wSlot, wSlot);
   C.nW = nW;
   up(C.itemEdgeDev, itemEdge);
   const size_t n = static_cast<size_t>(F) * kCB;
@@ -927,6 +931,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.fail2.ensure(1);
   C.rc.ensure(n);
   C.qc.ensure(n);
+  C.wq.ensure(static_cast<size_t>(nW) * kCB);
   C.fdotY.ensure(F);
   C.y.ensure(n);
   C.c.ensure(n);
@@ -1508,20 +1513,23 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   {
     if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_matvec_finish");
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
+    // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
+    const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, withCoarse ? h->coarse.Wb.p : nullptr,
+                           h->coarse.wq.p};
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
                          h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF,
-                         (withCoarse && !h->dist()) ? h->coarse.qc.p : nullptr);
+                         (withCoarse && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
     });
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
       NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
       hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
-                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p);
+                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc);
       HIP_CHECK(hipGetLastError());
     }
     h->tEnd(slot);
@@ -1674,10 +1682,10 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
                        h->hPcg);
     coarseC(init);
   };
-  const CoarseStep csOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const CoarseStep csOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const CoarseStep csOn = (coarse && !unfusedY)
                               ? CoarseStep{h->coarse.wtPtr.p, h->coarse.wtBlk.p, h->coarse.wtFrame.p, h->coarse.Wb.p,
-                                           h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p}
+                                           h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p, h->coarse.wq.p}
                               : csOff;
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,

@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nItems, RegCache rc, CoarseView V,
-                                                       double* __restrict__ qc) {
+                                                       double* __restrict__ qc, CoarseColumns cc) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -1305,7 +1305,11 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
   if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
-  if (qc != nullptr) coarseRestrict(L, qf, f, tid, V.modeActive, qc);  // Z^T q for the fused y update (CoarseStep)
+  if (qc != nullptr) {  // Z^T q and this frame's column of W (Z^T q) for the fused y update (CoarseStep)
+    coarseRestrict(L, qf, f, tid, V.modeActive, qc);
+    __syncthreads();
+    coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
+  }
   // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
   if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
     const double pq = blockSumArray(fdot, L.F, red);
@@ -1320,12 +1324,16 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
 __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                 double* __restrict__ fdot, double* __restrict__ qc,
-                                                const unsigned char* __restrict__ modeActive) {
+                                                const unsigned char* __restrict__ modeActive, CoarseColumns cc) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   __shared__ double red[8];
   const int f = blockIdx.x, tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * L.B;
-  if (qc != nullptr) coarseRestrict(L, q + base, f, tid, modeActive, qc);  // on the all-reduced q
+  if (qc != nullptr) {  // on the all-reduced q
+    coarseRestrict(L, q + base, f, tid, modeActive, qc);
+    __syncthreads();
+    coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
+  }
   double dot = 0.0;
   for (int i = tid; i < L.B; i += 256) dot += p[base + i] * q[base + i];
   dot = waveSum(dot);
@@ -1416,26 +1424,23 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   __syncthreads();
   if (rc != nullptr) coarseRestrict(L, rf, f, tid, modeActive, rc);  // Z_f^T r_f (first residual: k_coarse_apply_w)
   if (fusedY) {
-    // row f of W (Z^T q): gathered from the columns of the frame's subtree, the waves share the list
-    const int wv = tid >> 6, lane = tid & 63, c8 = lane & 7, nWv = nThreads >> 6;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const int e1 = cs.wtPtr[f + 1];
-    int e = cs.wtPtr[f] + wv;
-    // eight independent gathers in flight per wave: the rows of the frames near the root of the elimination tree are
-    // the kernel's critical path (the root's row holds one block per frame)
-    auto term = [&](int k) { return cs.Wb[static_cast<size_t>(cs.wtBlk[k]) * 64 + lane] * cs.qc[cs.wtFrame[k] * kCB + c8]; };
-    for (; e + 7 * nWv < e1; e += 8 * nWv) {
-      const double t0 = term(e), t1 = term(e + nWv), t2 = term(e + 2 * nWv), t3 = term(e + 3 * nWv);
-      const double t4 = term(e + 4 * nWv), t5 = term(e + 5 * nWv), t6 = term(e + 6 * nWv), t7 = term(e + 7 * nWv);
-      a0 += t0; a1 += t1; a2 += t2; a3 += t3;
-      a0 += t4; a1 += t5; a2 += t6; a3 += t7;
+    // row f of W (Z^T q): the 8-vectors W_block (Z^T q)_column were left in row order by coarseColumnProducts (in the
+    // kernel that completed q), so the row is a contiguous run: a wave sums eight entries per load, lane = (entry, mode)
+    const int wv = tid >> 6, lane = tid & 63, nWv = nThreads >> 6;
+    const size_t e0 = static_cast<size_t>(cs.wtPtr[f]) * kCB, e1 = static_cast<size_t>(cs.wtPtr[f + 1]) * kCB;
+    double a0 = 0.0, a1 = 0.0;
+    size_t e = e0 + static_cast<size_t>(wv) * 64 + lane;
+    const size_t stride = static_cast<size_t>(nWv) * 64;
+    for (; e + stride < e1; e += 2 * stride) {
+      a0 += cs.wq[e];
+      a1 += cs.wq[e + stride];
     }
-    for (; e < e1; e += nWv) a0 += term(e);
-    double ya = (a0 + a1) + (a2 + a3);
-    ya += dppMove<0xB1>(ya);
-    ya += dppMove<0x4E>(ya);
-    ya += dppMove<0x141>(ya);
-    if (c8 == 0) ypart[wv * kCB + (lane >> 3)] = ya;
+    if (e < e1) a0 += cs.wq[e];
+    double ya = a0 + a1;
+    ya += __shfl_xor(ya, 8, 64);
+    ya += __shfl_xor(ya, 16, 64);
+    ya += __shfl_xor(ya, 32, 64);
+    if (lane < kCB) ypart[wv * kCB + lane] = ya;
   }
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
   // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
@@ -1444,14 +1449,26 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   const int i = chunk * 64 + row;
   double acc = 0.0;
   if (i < B) {
-    double a0 = 0.0, a1 = 0.0;
+    // eight independent column loads in flight per thread (the loop is latency-bound: 4 B per lane and load)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const float* col = Mf + i;
     int j = seg;
-    for (; j + 4 < B; j += 8) {
-      a0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
-      a1 += static_cast<double>(Mf[static_cast<size_t>(j + 4) * B + i]) * rf[j + 4];
+    for (; j + 28 < B; j += 32) {
+      const float m0 = col[static_cast<size_t>(j) * B], m1 = col[static_cast<size_t>(j + 4) * B];
+      const float m2 = col[static_cast<size_t>(j + 8) * B], m3 = col[static_cast<size_t>(j + 12) * B];
+      const float m4 = col[static_cast<size_t>(j + 16) * B], m5 = col[static_cast<size_t>(j + 20) * B];
+      const float m6 = col[static_cast<size_t>(j + 24) * B], m7 = col[static_cast<size_t>(j + 28) * B];
+      a0 += static_cast<double>(m0) * rf[j];
+      a1 += static_cast<double>(m1) * rf[j + 4];
+      a2 += static_cast<double>(m2) * rf[j + 8];
+      a3 += static_cast<double>(m3) * rf[j + 12];
+      a0 += static_cast<double>(m4) * rf[j + 16];
+      a1 += static_cast<double>(m5) * rf[j + 20];
+      a2 += static_cast<double>(m6) * rf[j + 24];
+      a3 += static_cast<double>(m7) * rf[j + 28];
     }
-    if (j < B) a0 += static_cast<double>(Mf[static_cast<size_t>(j) * B + i]) * rf[j];
-    acc = a0 + a1;
+    for (; j < B; j += 4) a0 += static_cast<double>(col[static_cast<size_t>(j) * B]) * rf[j];
+    acc = (a0 + a1) + (a2 + a3);
   }
   part[tid] = acc;
   __syncthreads();
