@@ -75,6 +75,9 @@ int32_t cvd_set_video(cvd_handle* h, int32_t num_frames, int32_t width, int32_t 
  * (reference lib/DepthStream.cpp:176-216). Copied to HBM; the per-frame median used by the scale
  * regulariser (lib/PoseOptimizer.cpp:1363-1375) is taken here. */
 int32_t cvd_set_depth(cvd_handle* h, int32_t frame, const float* depth);
+/* All frames at once, depth = [F][H][W] contiguous: one host->device copy instead of F (same semantics as F calls of
+ * cvd_set_depth; the reference keeps one cv::Mat1f per DepthFrame, lib/DepthStream.h, so its binding copies frame by frame). */
+int32_t cvd_set_depth_all(cvd_handle* h, const float* depth);
 /* FlowConstraintsCollection pair constraints (reference lib/FlowConstraints.h:41-205): pair-major,
  * pair_frames[2*P], offsets[P+1], loc4[4*C] = (loc0.xy, loc1.xy) in [0,1]x[0,invAspect], is_static[C] or NULL. */
 int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames,

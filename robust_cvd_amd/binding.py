@@ -77,6 +77,9 @@ class Binding:
     def set_depth_all(self, depth):
         d = _f32(depth)
         assert d.shape == (self.num_frames, self.height, self.width), d.shape
+        if hasattr(self._lib, self._p + "set_depth_all"):  # (the product library: one copy; the oracle: frame by frame)
+            self._check(self._fn("set_depth_all")(self._h, _ptr(d, C.c_float)))
+            return
         for f in range(self.num_frames):
             self.set_depth(f, d[f])
 
