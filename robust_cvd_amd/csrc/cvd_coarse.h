@@ -674,16 +674,45 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
 // (coarseFrameCorrection); this kernel only runs with the position regulariser (whose rows read the neighbours'
 // directions) and for the test hook.
 // ---------------------------------------------------------------------------------------------------------
+// One workgroup (4 waves) per frame: the frame's column of W (its elimination-tree path, <= tree depth blocks) is dealt
+// over the waves, four blocks per wave in flight (clamped index, zero weight), so the kernel is one or two dependent
+// round trips (row index -> y gather) instead of one per four blocks of a single wave walking the whole path.
 __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, double* __restrict__ cOut,
                                                          const double* __restrict__ scal, int init) {
-  __shared__ double cl[4][kCB];
+  __shared__ double part[4][kCB];
   if (!init && scal[S_DONE] != 0.0) return;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int f = blockIdx.x * 4 + wv;
-  if (f >= F) return;
-  coarseFrameCorrection(V, f, lane, cl[wv]);
-  CVD_WAVE_SYNC();
-  if (lane < kCB) cOut[f * kCB + lane] = cl[wv][lane];
+  const int f = blockIdx.x;
+  const int r = lane >> 3;
+  const int j = V.pos[f];
+  const int w0 = V.wPtr[j], len = V.wPtr[j + 1] - w0;
+  double a0 = 0.0, a1 = 0.0;
+  for (int t0 = wv; t0 < len; t0 += 16) {
+    int row[4];
+    double wb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tc = w0 + min(t0 + 4 * u, len - 1);
+      row[u] = V.wRow[tc];
+      wb[u] = V.Wb[static_cast<size_t>(tc) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double yv = V.y[row[u] * kCB + r];
+      const double term = (t0 + 4 * u < len) ? wb[u] * yv : 0.0;
+      if (u & 1) a1 += term; else a0 += term;
+    }
+  }
+  double acc = a0 + a1;
+  acc += __shfl_xor(acc, 8, 64);   // sum over r: lanes with equal c are 8 apart
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < kCB) part[wv][lane] = acc;
+  __syncthreads();
+  if (tid < kCB) {
+    const double c = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    cOut[f * kCB + tid] = (*V.fail == 0 && V.modeActive[f * kCB + tid]) ? c : 0.0;
+  }
 }
 
 }  // namespace cvd

@@ -1673,7 +1673,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   static const bool unfusedY = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
   auto coarseC = [&](int init) {
     if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
-      hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
+      hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
   auto coarseApply = [&](int init) {
@@ -2993,7 +2993,7 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
           C.rc.upload(unit.data(), n, s);
           hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, C.dotPart.p,
                              scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0, static_cast<double*>(nullptr));
-          hipLaunchKernelGGL(k_coarse_apply_wt, dim3((F + 3) / 4), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
+          hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
                              scalTmp.p, 1);
           C.c.download(a_c_inverse + k * n, n, s);
           HIP_CHECK(hipStreamSynchronize(s));
