@@ -680,7 +680,7 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
 __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, double* __restrict__ cOut,
                                                          const double* __restrict__ scal, int init) {
   __shared__ double part[4][kCB];
-  if (!init && scal[S_DONE] != 0.0) return;
+  const double sDone = init ? 0.0 : scal[S_DONE];  // (tested at the store: the flag rides on the first round trip)
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int f = blockIdx.x;
   const int r = lane >> 3;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, do
   acc += __shfl_xor(acc, 32, 64);
   if (lane < kCB) part[wv][lane] = acc;
   __syncthreads();
-  if (tid < kCB) {
+  if (tid < kCB && sDone == 0.0) {
     const double c = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     cOut[f * kCB + tid] = (*V.fail == 0 && V.modeActive[f * kCB + tid]) ? c : 0.0;
   }

@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nItems, RegCache rc, CoarseView V,
                                                        double* __restrict__ qc, CoarseColumns cc) {
-  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
+  const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xf = sm;
@@ -1226,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   }
   const int e0 = fiOff[f], e1 = fiOff[f + 1];  // (before the barrier: the row gather below depends on them)
   __syncthreads();
+  if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
   for (int i = tid; i < B; i += 256) {
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
     const double pv = vz + coarseAtLds(cl, L, i) * vm + (useBeta ? beta * vp : 0.0);
@@ -1397,7 +1398,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     const unsigned char* __restrict__ modeActive,
                                                     double* __restrict__ hostMirror, CoarseStep cs) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  if (!init && scal[S_DONE] != 0.0) return;  // converged earlier: the iterations enqueued ahead are no-ops
+  const double sDone = init ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
   const int B = L.B;
   const int nThreads = blockDim.x;
   double* rf = sm;                 // B
@@ -1409,17 +1410,32 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   const double alpha = init ? 0.0 : scal[S_ALPHA];
-  for (int j = tid; j < B; j += nThreads) {
-    double rv;
-    if (init) {
-      dx[base + j] = 0.0;
-      rv = -g[base + j];
-    } else {
-      dx[base + j] += alpha * p[base + j];
-      rv = r[base + j] - alpha * q[base + j];
+  {
+    // one element per thread (blockDim = 256 * ceil(B / 64) >= B).  The vector loads are issued together with the
+    // scalars' and the convergence flag is tested once they are back: one dependent global round trip instead of two
+    const int j = tid;
+    double pv = 0.0, qv = 0.0, rv = 0.0, dv = 0.0;
+    if (j < B) {
+      if (init) {
+        rv = -g[base + j];
+      } else {
+        pv = p[base + j];
+        qv = q[base + j];
+        rv = r[base + j];
+        dv = dx[base + j];
+      }
     }
-    r[base + j] = rv;
-    rf[j] = rv;
+    asm volatile("" : "+v"(pv), "+v"(qv), "+v"(rv), "+v"(dv));  // (keeps the loads above the early exit)
+    if (sDone != 0.0) return;  // uniform; nothing written yet
+    if (j < B) {
+      if (!init) {
+        dv += alpha * pv;
+        rv -= alpha * qv;
+      }
+      dx[base + j] = dv;
+      r[base + j] = rv;
+      rf[j] = rv;
+    }
   }
   __syncthreads();
   if (rc != nullptr) coarseRestrict(L, rf, f, tid, modeActive, rc);  // Z_f^T r_f (first residual: k_coarse_apply_w)
@@ -1672,7 +1688,9 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
                                                            const double* __restrict__ scal, int useBeta,
                                                            double* __restrict__ qPart, CoarseView V) {
-  if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
+  // (PCG already converged: iterations enqueued ahead return -- tested after the prologue's loads have been issued, so
+  // that the flag does not cost a dependent global round trip of its own in every working launch)
+  const double sDone = scal[S_DONE];
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
   constexpr double eps = 1e-6;
@@ -1728,6 +1746,7 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
     }
   }
   __syncthreads();
+  if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * NT;
