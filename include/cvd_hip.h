@@ -203,7 +203,8 @@ int32_t cvd_flow_guided_filter(cvd_handle* h, int32_t num_frames, int32_t first_
  * cost} and their launch counts. */
 int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6);
 /* Per-launch HIP-event timing: 0 = off (default), 1 = every class, otherwise a bit mask (bit k = class k in the
- * order of cvd_get_kernel_times). Two event records per timed launch. */
+ * order of cvd_get_kernel_times). Two event records per timed launch. Bits 8..15 = sampling stride - 1 for the hot
+ * kernel's start/stop events (0: every launch, 3: every 4th launch of k_matvec_pairs carries an event pair). */
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
 /* Number of (valid static) constraints in the compiled table of the last solve. */
 int64_t cvd_num_active_constraints(cvd_handle* h);

@@ -117,8 +117,9 @@ class Solver(Binding):
     def set_generic_kernels(self, enabled=True):
         self._check(self._fn("set_generic_kernels")(self._h, C.c_int32(int(enabled))))
 
-    def set_kernel_timing(self, enabled=True, classes=None):
-        """enabled=True times every kernel class; classes=[names] only those (see KERNEL_CLASSES)."""
+    def set_kernel_timing(self, enabled=True, classes=None, sample_every=1):
+        """enabled=True times every kernel class; classes=[names] only those (see KERNEL_CLASSES); sample_every=k attaches
+        the hot kernel's start/stop event pair to every k-th launch only (a uniform sample of the launches)."""
         mask = int(bool(enabled))
         if classes is not None:
             mask = 0
@@ -126,6 +127,7 @@ class Solver(Binding):
                 mask |= 1 << KERNEL_CLASSES.index(c)
             if mask == 1:
                 mask |= 1 << 6  # keep it a mask (bit 0 alone would read as 'all')
+        mask |= (max(1, min(256, int(sample_every))) - 1) << 8
         self._check(self._fn("set_kernel_timing")(self._h, C.c_int32(mask)))
 
     def kernel_times(self):

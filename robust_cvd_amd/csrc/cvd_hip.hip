@@ -383,6 +383,8 @@ struct cvd_handle_t {
 
   // kernel timing
   int timing = 0;  // bit mask of KernelClass values to time with HIP events
+  int timingStride = 1;        // hipExtLaunchKernelGGL event pairs (tReserve) on every timingStride-th launch only
+  long long timingCounter = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
   std::vector<int> evClass;
   std::vector<int> evIter;  // PCG iteration the launch belongs to (-1 outside PCG): launches enqueued past
@@ -433,6 +435,7 @@ struct cvd_handle_t {
     start = nullptr;
     stop = nullptr;
     if (!(timing & (1 << kc))) return -1;
+    if (timingStride > 1 && (timingCounter++ % timingStride) != 0) return -1;  // uniform sample of the launches
     if (evUsed == evPool.size()) {
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a));
@@ -2917,7 +2920,13 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avgMs6, int64_t* launches6) 
 }
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
   CVD_TRY(h, {
-    h->timing = enabled == 1 ? 0x3f : enabled;  // 1 = all classes, otherwise a bit mask (bit k = class k)
+    // 1 = all classes, otherwise a bit mask (bit k = class k); bits 8..15 = sampling stride - 1 of the event pairs
+    // attached to the hot kernel's launches (0: every launch; 3: every 4th -- the start/stop events of
+    // hipExtLaunchKernelGGL serialise the dispatch, ~3 % of the iteration rate when every launch carries them)
+    h->timingStride = ((enabled >> 8) & 0xff) + 1;
+    h->timingCounter = 0;
+    enabled &= 0xff;
+    h->timing = enabled == 1 ? 0x3f : enabled;
     for (int k = 0; k < KC_COUNT; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }
   });
 }
