@@ -1314,11 +1314,20 @@ static void enqueueCost(Ctx& c, const double* x) {
   const int slot = h->tBegin(KC_COST);
   if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = (2 * c.L.B) * 8 + 2 * sizeof(FrameConst) + 8 * 8;
-    CVD_DISPATCH(c.KD, c.KS, {
-      allowLds(k_cost_items<KD, KS>, lds);
-      hipLaunchKernelGGL((k_cost_items<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
-                         h->dCostItem.p);
-    });
+    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;  // (scope of the fast kernels)
+    if (fast) {
+      CVD_DISPATCH_KD(c.KD, {
+        allowLds(k_cost_items_fast<KD>, lds);
+        hipLaunchKernelGGL((k_cost_items_fast<KD>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                           h->dCostItem.p);
+      });
+    } else {
+      CVD_DISPATCH(c.KD, c.KS, {
+        allowLds(k_cost_items<KD, KS>, lds);
+        hipLaunchKernelGGL((k_cost_items<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                           h->dCostItem.p);
+      });
+    }
     HIP_CHECK(hipGetLastError());
   }
   CVD_DISPATCH_KD(c.KD, {

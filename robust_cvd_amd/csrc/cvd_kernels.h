@@ -1678,6 +1678,106 @@ __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, 
   }
 }
 
+// Candidate-point cost on the fast path (same scope as k_matvec_pairs_fast: identity spatial transform, reprojection
+// losses): the residual chain of the fast kernels with register-resident taps.  The generic k_cost_items keeps the taps
+// of Sample<KD, KS> in dynamically indexed arrays, i.e. in scratch memory (672 B per lane, stores and dependent reloads
+// per constraint): 53 us for 1.09 M constraints where the arithmetic needs ~10.
+template <int KD>
+__global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                         const FrameConst* __restrict__ fc, double* __restrict__ costItem) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr double eps = 1e-6;
+  const int B = L.B;
+  double* xa = sm;
+  double* xb = sm + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(sm + 2 * B);
+  double* red = reinterpret_cast<double*>(fcs + 2);
+  const int item = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int fa = it.fa[item], fb = it.fb[item];
+  for (int i = tid; i < B; i += 256) {
+    xa[i] = x[static_cast<size_t>(fa) * B + i];
+    xb[i] = x[static_cast<size_t>(fb) * B + i];
+  }
+  constexpr int FCW = sizeof(FrameConst) / 8;
+  if (tid < 2 * FCW) {
+    const int which = tid / FCW, k = tid % FCW;
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  __syncthreads();
+  const int N = L.N;
+  const double A = L.aspect;
+  double acc = 0.0;
+  for (int dir = 0; dir < 2; ++dir) {
+    const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+    const FrameConst& Fa = fcs[dir];
+    const FrameConst& Fb = fcs[dir ^ 1];
+    const double* xs = dir ? xb : xa;
+    const double* xt = dir ? xa : xb;
+    const double fya = Fa.fy, fxa = Fa.fy * A;
+    const double fyb = Fb.fy;
+    const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+    for (long long c = cb + tid; c < ce; c += 256) {
+      const float2 d = T.dsrc[c];
+      if (!(d.x > 0.f)) continue;
+      const float4 nd = T.ndc[c];
+      const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
+      double Da, Db;
+      if (N == 0) {
+        Da = da;
+        Db = db;
+      } else {
+        FastTaps<KD> ta, tb;
+        fastGather<KD>(L, nd.x, nd.y, ta);
+        fastGather<KD>(L, nd.z, nd.w, tb);
+        Da = 0.0;
+        Db = 0.0;
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          if (ta.ok(k)) {
+            const int ia = ta.I(k);
+            const double wa = ta.Wt(k);
+            Da += (N == 2 ? da * xs[7 + ia * 2] + xs[7 + ia * 2 + 1] : da * xs[7 + ia]) * wa;
+          }
+          if (tb.ok(k)) {
+            const int ib = tb.I(k);
+            const double wb = tb.Wt(k);
+            Db += (N == 2 ? db * xt[7 + ib * 2] + xt[7 + ib * 2 + 1] : db * xt[7 + ib]) * wb;
+          }
+        }
+      }
+      const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
+      const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
+      const double ca[3] = {pax * fxa, pay * fya, -1.0};
+      const double Rca[3] = {dot3(Fa.R, ca), dot3(Fa.R + 3, ca), dot3(Fa.R + 6, ca)};
+      const double v[3] = {Fa.t[0] + Rca[0] * Da - Fb.t[0], Fa.t[1] + Rca[1] * Da - Fb.t[1], Fa.t[2] + Rca[2] * Da - Fb.t[2]};
+      const double q0 = Fb.R[0] * v[0] + Fb.R[3] * v[1] + Fb.R[6] * v[2];
+      const double q1 = Fb.R[1] * v[0] + Fb.R[4] * v[1] + Fb.R[7] * v[2];
+      const double q2 = Fb.R[2] * v[0] + Fb.R[5] * v[1] + Fb.R[8] * v[2];
+      const double zz = -q2;
+      const double iz = 1.0 / zz;
+      const double r0 = (q0 * iz * ifxb - pbx) * L.ws;
+      const double r1 = (q1 * iz * ifyb - pby) * L.ws;
+      double r2;
+      if (L.lossType == kLossDisparity) {
+        const double zc = !(zz < eps) ? zz : eps, bc = !(Db < eps) ? Db : eps;
+        r2 = (1.0 / zc - 1.0 / bc) * L.wd;
+      } else {
+        const bool zIsMax = !(zz < Db), zIsMin = !(Db < zz);
+        const double mx = zIsMax ? zz : Db, mn = zIsMin ? zz : Db;
+        r2 = (L.lossType == kLossRatio ? (mx / mn - 1.0) : log(mn / mx)) * L.wd;
+      }
+      double rho0, rho1;
+      robustRho(L, r0 * r0 + r1 * r1 + r2 * r2, rho0, rho1);
+      acc += rho0;
+    }
+  }
+  acc = waveSum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) costItem[item] = 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
 constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 

@@ -113,6 +113,52 @@ def test_fast_and_generic_product_kernels_agree(Solver):
         assert rel(fast["hdiag"], gen["hdiag"]) < 1e-12
 
 
+def test_fast_and_generic_candidate_cost_agree(Solver):
+    """k_cost_items_fast (candidate-point cost of the default pipeline) vs the generic kernel: a few LM iterations from the
+    same state, with the inner solve driven to 1e-10 so that both runs take the same steps; the accepted costs
+    (final_cost) come out of the candidate-cost kernels."""
+    checked = 0
+    for ddesc, loss, huber in ((XformDesc.grid_depth(5, 4), StaticLossType.ReproDisparity, 0),
+                               (XformDesc.grid_depth(4, 4, cubic=True), StaticLossType.ReproDepthRatio, 0),
+                               (XformDesc.grid_depth(6, 5, ValueXformType.ScaleShift, cubic=True), StaticLossType.ReproLogDepth, 1),
+                               (XformDesc.global_depth(ValueXformType.ScaleShift), StaticLossType.ReproDisparity, 1),
+                               (XformDesc.global_depth(), StaticLossType.ReproLogDepth, 0),
+                               (XformDesc.identity_depth(), StaticLossType.ReproDisparity, 0)):
+        v = synth.make_video(5, 64, 40, seed=43, spacing=9)
+        out = []
+        for generic in (False, True):
+            s = Solver(0)
+            synth.load_into(s, v)
+            s.reset_depth_xforms(ddesc)
+            s.reset_spatial_xforms(XformDesc.spatial())
+            rng = np.random.default_rng(11)
+            F = v.num_frames
+            pose = np.zeros((F, 7))
+            pose[:, :6] = rng.normal(0, 0.03, (F, 6))
+            pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+            dx = s.get_xform_params()
+            if dx.size:
+                dx = 0.15 + rng.uniform(0, 0.05, dx.shape)
+                s.set_xform_params(dx)
+            s.set_pose_params(pose)
+            s.set_options(pcg_relative_tolerance=1e-10, robust_loss=huber, coarse_level=0)
+            s.set_generic_kernels(generic)
+            p = OptParams.defaults()
+            p.static_loss_type = loss
+            p.max_iterations = 8   # (the first steps from a random state may be rejected)
+            s.pose_optimization_step(p, 0.1, convert_poses=False)
+            sm = s.summary()
+            # (no same-point check against evaluate() here: after a solve the poses have been through their float storage,
+            # reference q10, which moves the cost by ~1e-8 relative -- tools/cost_check.py)
+            checked += int(sm["num_successful_steps"] >= 1)
+            out.append((sm["initial_cost"], sm["final_cost"], sm["num_successful_steps"]))
+        (c0f, c1f, nf), (c0g, c1g, ng) = out
+        assert abs(c0f - c0g) <= 1e-12 * abs(c0g)
+        # fast and generic runs take steps that differ at the level of the inner solve's tolerance
+        assert nf == ng and abs(c1f - c1g) <= 1e-6 * abs(c0g), (ddesc.grid_size[:], loss, out)
+    assert checked >= 6, checked   # the accepted costs compared above came out of the candidate-cost kernels
+
+
 def test_empty_and_ragged_inputs(Solver):
     """Pairs with zero constraints, frames in no pair, all-dynamic constraints, invalid depth everywhere."""
     v = synth.make_video(6, 64, 40, seed=32, spacing=9)
