@@ -152,6 +152,195 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
   if (tid < kCBB) atomicAdd(&edgeOut[static_cast<size_t>(itemEdge[item]) * kCBB + tid], Cs[tid]);
 }
 
+// Fast path of k_coarse_edges (scope of the fast kernels: identity spatial transform, reprojection losses, per-frame
+// or fixed intrinsics): the residual / Jacobian chain of k_assemble_fast with register-resident taps, both sides of the
+// constraint at once.  The generic kernel above goes through Sample<KD, KS>, whose dynamically indexed tap arrays live in
+// scratch memory.
+template <int KD>
+__global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                           const FrameConst* __restrict__ fc,
+                                                           const int* __restrict__ itemEdge, double* __restrict__ edgeOut) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr double eps = 1e-6;
+  const int B = L.B;
+  double* xa = sm;
+  double* xb = sm + B;
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(sm + 2 * B);
+  double* Cs = reinterpret_cast<double*>(fcs + 2);  // 64
+  const int item = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int fa = it.fa[item], fb = it.fb[item];
+  for (int i = tid; i < B; i += 256) {
+    xa[i] = x[static_cast<size_t>(fa) * B + i];
+    xb[i] = x[static_cast<size_t>(fb) * B + i];
+  }
+  if (tid < 2 * (sizeof(FrameConst) / 8)) {
+    const int which = tid / (sizeof(FrameConst) / 8);
+    const int k = tid % (sizeof(FrameConst) / 8);
+    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+  }
+  if (tid < kCBB) Cs[tid] = 0.0;
+  __syncthreads();
+  double Cacc[kCBB];  // rows: modes of fa, columns: modes of fb
+#pragma unroll
+  for (int i = 0; i < kCBB; ++i) Cacc[i] = 0.0;
+  const int N = L.N;
+  const double A = L.aspect;
+  const bool haveScale = N >= 1;
+  for (int dir = 0; dir < 2; ++dir) {
+    const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+    const FrameConst& Fa = fcs[dir];      // source frame of this direction
+    const FrameConst& Fb = fcs[dir ^ 1];  // target frame
+    const double* xs = dir ? xb : xa;
+    const double* xt = dir ? xa : xb;
+    const double fya = Fa.fy, fxa = Fa.fy * A;
+    const double fyb = Fb.fy;
+    const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+    for (long long c = cb + tid; c < ce; c += 256) {
+      const float2 d = T.dsrc[c];
+      if (!(d.x > 0.f)) continue;
+      const float4 nd = T.ndc[c];
+      const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
+      double Da, Db;
+      if (N == 0) {
+        Da = da;
+        Db = db;
+      } else {
+        FastTaps<KD> ta, tb;
+        fastGather<KD>(L, nd.x, nd.y, ta);
+        fastGather<KD>(L, nd.z, nd.w, tb);
+        Da = 0.0;
+        Db = 0.0;
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          if (ta.ok(k)) {
+            const int ia = ta.I(k);
+            Da += (N == 2 ? da * xs[7 + ia * 2] + xs[7 + ia * 2 + 1] : da * xs[7 + ia]) * ta.Wt(k);
+          }
+          if (tb.ok(k)) {
+            const int ib = tb.I(k);
+            Db += (N == 2 ? db * xt[7 + ib * 2] + xt[7 + ib * 2 + 1] : db * xt[7 + ib]) * tb.Wt(k);
+          }
+        }
+      }
+      const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
+      const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
+      const double ca[3] = {pax * fxa, pay * fya, -1.0};
+      const double Rca[3] = {dot3(Fa.R, ca), dot3(Fa.R + 3, ca), dot3(Fa.R + 6, ca)};
+      const double v[3] = {Fa.t[0] + Rca[0] * Da - Fb.t[0], Fa.t[1] + Rca[1] * Da - Fb.t[1], Fa.t[2] + Rca[2] * Da - Fb.t[2]};
+      const double q0 = Fb.R[0] * v[0] + Fb.R[3] * v[1] + Fb.R[6] * v[2];
+      const double q1 = Fb.R[1] * v[0] + Fb.R[4] * v[1] + Fb.R[7] * v[2];
+      const double q2 = Fb.R[2] * v[0] + Fb.R[5] * v[1] + Fb.R[8] * v[2];
+      const double zz = -q2;
+      const double iz = 1.0 / zz;
+      const double u = q0 * iz * ifxb;
+      const double vv = q1 * iz * ifyb;
+      const double r0 = (u - pbx) * L.ws;
+      const double r1 = (vv - pby) * L.ws;
+      double r2, dr2dA, dr2dDb;
+      if (L.lossType == kLossDisparity) {
+        const bool zo = !(zz < eps), bo = !(Db < eps);
+        const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / (bo ? Db : eps);
+        r2 = (izc - ibc) * L.wd;
+        dr2dA = zo ? (-L.wd * izc * izc) : 0.0;
+        dr2dDb = bo ? (L.wd * ibc * ibc) : 0.0;
+      } else {
+        const bool zIsMax = !(zz < Db), zIsMin = !(Db < zz);
+        const double mx = zIsMax ? zz : Db, mn = zIsMin ? zz : Db;
+        if (L.lossType == kLossRatio) {
+          r2 = (mx / mn - 1.0) * L.wd;
+          const double dmx = 1.0 / mn, dmn = -mx / (mn * mn);
+          dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+          dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+        } else {
+          r2 = log(mn / mx) * L.wd;
+          const double dmn = 1.0 / mn, dmx = -1.0 / mx;
+          dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
+          dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
+        }
+      }
+      const double w = robustRho1(L, r0 * r0 + r1 * r1 + r2 * r2);
+      // d r / d q (rows): M0 = (m00, 0, m02), M1 = (0, m11, m12), M2 = (0, 0, m22)
+      const double wiz = L.ws * iz;
+      const double m00 = wiz * ifxb, m11 = wiz * ifyb, m02 = wiz * u, m12 = wiz * vv, m22 = -dr2dA;
+      // Z-projected Jacobians: 7 pose columns + the uniform depth-scale column (d r / d scale_k = JD w_k d_src and the
+      // interpolation weights sum to one) of the source side (Js) and of the target side (Jt)
+      double Js[3][kCB], Jt[3][kCB];
+      {
+        // source: G = M R_b^T ; columns: t -> G, w_i -> G (D_a dR_a,i c_a), fy -> G (D_a R_a cf), D -> G R c_a
+        double G[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          G[0][i] = m00 * Fb.R[i * 3 + 0] + m02 * Fb.R[i * 3 + 2];
+          G[1][i] = m11 * Fb.R[i * 3 + 1] + m12 * Fb.R[i * 3 + 2];
+          G[2][i] = m22 * Fb.R[i * 3 + 2];
+        }
+        const double cf[3] = {pax * A, pay, 0.0};
+        const double dXdf[3] = {Da * (Fa.R[0] * cf[0] + Fa.R[1] * cf[1]), Da * (Fa.R[3] * cf[0] + Fa.R[4] * cf[1]),
+                                Da * (Fa.R[6] * cf[0] + Fa.R[7] * cf[1])};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          Js[rr][0] = G[rr][0];
+          Js[rr][1] = G[rr][1];
+          Js[rr][2] = G[rr][2];
+          Js[rr][6] = dot3(G[rr], dXdf);
+          Js[rr][7] = haveScale ? dot3(G[rr], Rca) * da : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double dX[3] = {Da * dot3(Fa.dR[i], ca), Da * dot3(Fa.dR[i] + 3, ca), Da * dot3(Fa.dR[i] + 6, ca)};
+          Js[0][3 + i] = dot3(G[0], dX);
+          Js[1][3 + i] = dot3(G[1], dX);
+          Js[2][3 + i] = dot3(G[2], dX);
+        }
+        // target
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          Jt[0][i] = -G[0][i];
+          Jt[1][i] = -G[1][i];
+          Jt[2][i] = -G[2][i];
+          const double* D = Fb.dR[i];  // d q / d w_b,i = dR_b,i^T v
+          const double dq0 = D[0] * v[0] + D[3] * v[1] + D[6] * v[2];
+          const double dq1 = D[1] * v[0] + D[4] * v[1] + D[7] * v[2];
+          const double dq2 = D[2] * v[0] + D[5] * v[1] + D[8] * v[2];
+          Jt[0][3 + i] = m00 * dq0 + m02 * dq2;
+          Jt[1][3 + i] = m11 * dq1 + m12 * dq2;
+          Jt[2][3 + i] = m22 * dq2;
+        }
+        Jt[0][6] = -L.ws * u * ifyb;
+        Jt[1][6] = -L.ws * vv * ifyb;
+        Jt[2][6] = 0.0;
+        Jt[0][7] = 0.0;
+        Jt[1][7] = 0.0;
+        Jt[2][7] = haveScale ? dr2dDb * db : 0.0;
+      }
+      if (dir == 0) {
+#pragma unroll
+        for (int i = 0; i < kCB; ++i) {
+          const double a0 = w * Js[0][i], a1 = w * Js[1][i], a2 = w * Js[2][i];
+#pragma unroll
+          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Jt[0][j] + a1 * Jt[1][j] + a2 * Jt[2][j];
+        }
+      } else {  // source = fb, target = fa: rows (fa) take the target side
+#pragma unroll
+        for (int i = 0; i < kCB; ++i) {
+          const double a0 = w * Jt[0][i], a1 = w * Jt[1][i], a2 = w * Jt[2][i];
+#pragma unroll
+          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Js[0][j] + a1 * Js[1][j] + a2 * Js[2][j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kCBB; ++i) {
+    const double v = waveSum(Cacc[i]);
+    if ((tid & 63) == 0) atomicAdd(&Cs[i], v);
+  }
+  __syncthreads();
+  // several chunk items may share one frame pair: the edge block is zeroed by the host before the launch
+  if (tid < kCBB) atomicAdd(&edgeOut[static_cast<size_t>(itemEdge[item]) * kCBB + tid], Cs[tid]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Diagonal coarse blocks D_f = Z_f^T (H_ff + diag(lam_f)) Z_f and the mode activity flags.  Inactive modes
 // (masked unknowns, frames outside the range, the shared focal length) become identity rows.

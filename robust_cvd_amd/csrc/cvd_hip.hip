@@ -1631,11 +1631,22 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
     if (c.nItems > 0) {
-      CVD_DISPATCH(c.KD, c.KS, {
-        allowLds(k_coarse_edges<KD, KS>, ldsE);
-        hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
-                           C.itemEdgeDev.p, C.edges.p);
-      });
+      static const bool genericEdges = std::getenv("CVD_COARSE_EDGES_GENERIC") != nullptr;  // comparison knob
+      const bool fast = !h->forceGeneric && !genericEdges && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN &&
+                        c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
+      if (fast) {
+        CVD_DISPATCH_KD(c.KD, {
+          allowLds(k_coarse_edges_fast<KD>, ldsE);
+          hipLaunchKernelGGL((k_coarse_edges_fast<KD>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
+                             C.itemEdgeDev.p, C.edges.p);
+        });
+      } else {
+        CVD_DISPATCH(c.KD, c.KS, {
+          allowLds(k_coarse_edges<KD, KS>, ldsE);
+          hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
+                             C.itemEdgeDev.p, C.edges.p);
+        });
+      }
     }
     HIP_CHECK(hipGetLastError());
     if (h->dist())
