@@ -1,0 +1,75 @@
+"""Code-generation guards (no GPU needed: hipcc cross-compiles gfx950): the hot kernels must not fall back to scratch memory.
+
+Found the hard way this round: kernels that go through the generic `Sample<KD, KS>` keep its dynamically indexed tap arrays
+in scratch (672 B per lane, stores + dependent reloads per constraint) -- 53 us instead of ~17 us for the candidate cost.  The
+fast-path kernels hold their taps in registers; this test pins that property, the register budget of the blocked block-Jacobi
+inverse (two 512-thread workgroups per CU need <= 128 VGPRs) and that it really issues f64 MFMAs."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "robust_cvd_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+SOURCE = f'''
+#include <hip/hip_runtime.h>
+#include "{CSRC}/cvd_device.h"
+#include "{CSRC}/cvd_kernels.h"
+#include "{CSRC}/cvd_coarse.h"
+namespace cvd {{
+template __global__ void k_cost_items_fast<4>(Layout, Table, Items, const double*, const FrameConst*, double*);
+template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*);
+template __global__ void k_matvec_pairs_fast<4, 128>(Layout, Table, Items, const double*, const FrameConst*, const double*,
+                                                      const double*, const double*, const double*, int, double*, CoarseView);
+template __global__ void k_block_inverse_mfma<8, 10>(Layout, const double*, const double*, float*, int*);
+template __global__ void k_cost_items<4, 0>(Layout, Table, Items, const double*, const FrameConst*, double*);
+}}
+'''
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    d = tmp_path_factory.mktemp("codegen")
+    src, out = d / "k.hip", d / "k.s"
+    src.write_text(SOURCE)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only",
+                    "-o", str(out), str(src)], check=True, capture_output=True, timeout=600)
+    return out.read_text()
+
+
+def kernel_info(asm, name):
+    """(.amdhsa descriptor fields, body text) of the one kernel whose mangled name contains `name`."""
+    m = [b for b in re.findall(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", asm, re.S) if name in b[0]]
+    assert len(m) == 1, (name, [b[0] for b in m])
+    mangled, desc = m[0]
+    fields = {k: int(v) for k, v in re.findall(r"\.amdhsa_(\w+) (\d+)", desc)}
+    body = asm[asm.index(f"\n{mangled}:"):]
+    body = body[:body.index("s_endpgm")]
+    return fields, body
+
+
+@pytest.mark.parametrize("name", ["17k_cost_items_fast", "19k_coarse_edges_fast", "19k_matvec_pairs_fast"])
+def test_fast_kernels_use_no_scratch(asm, name):
+    fields, body = kernel_info(asm, name)
+    assert fields["private_segment_fixed_size"] == 0, fields
+    assert "scratch_" not in body
+
+
+def test_generic_cost_kernel_is_the_one_with_scratch_resident_taps(asm):
+    """Documents WHY the fast variants exist (if this ever turns 0 the generic path has been fixed and they can go)."""
+    fields, _ = kernel_info(asm, "12k_cost_items")
+    assert fields["private_segment_fixed_size"] > 0
+
+
+def test_block_inverse_runs_on_the_f64_matrix_cores_within_its_register_budget(asm):
+    fields, body = kernel_info(asm, "20k_block_inverse_mfma")
+    assert fields["next_free_vgpr"] <= 128, fields          # 4 waves per SIMD = two 512-thread workgroups per CU
+    assert body.count("v_mfma_f64_16x16x4") >= 8            # -T panel (4) + rank-16 update (4 per tile slot)
+    assert "row_newbcast" in body or "row_share" in body    # pivot row by DPP broadcast, not through LDS
+    assert fields["private_segment_fixed_size"] <= 512, fields  # a few spilled address temporaries, not the tile registers
