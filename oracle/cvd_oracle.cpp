@@ -33,6 +33,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -42,6 +43,7 @@
 #endif
 
 #include "../include/cvd_types.h"
+#include "block_sparse.h"
 #include "jet.h"
 
 namespace cvdo {
@@ -893,6 +895,10 @@ struct Problem {
   std::map<const double*, int> lookup;
   std::vector<ResidualBlock> residuals;
   int numActive = 0;
+  // reduced (active) unknowns grouped by frame: frame f owns [frameOff[f], frameOff[f + 1]); hPairs = frame pairs that
+  // share a residual block = the block structure of J^T J (block_sparse.h)
+  std::vector<int> frameOff;
+  std::vector<std::pair<int, int>> hPairs;
 
   int blockId(double* ptr, int size, int frame, int canon) {
     auto it = lookup.find(ptr);
@@ -918,17 +924,46 @@ struct Problem {
       blocks[it->second].lower0 = lb;
     }
   }
+  // Reduced ordering: active parameter blocks sorted by (frame, canonical offset), so that every frame's unknowns
+  // are contiguous (Ceres orders its parameter blocks itself; the order does not change the solution).
   void finalize() {
+    std::vector<int> order(blocks.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (blocks[a].frame != blocks[b].frame) return blocks[a].frame < blocks[b].frame;
+      return blocks[a].canon < blocks[b].canon;
+    });
+    int nF = 0;
+    for (const auto& b : blocks) nF = std::max(nF, b.frame + 1);
+    frameOff.assign(nF + 1, 0);
     int off = 0;
-    for (auto& b : blocks) {
+    for (int id : order) {
+      ParamBlock& b = blocks[id];
       if (b.constant) {
         b.offset = -1;
       } else {
         b.offset = off;
         off += b.size;
+        frameOff[b.frame + 1] += b.size;
       }
     }
+    for (int f = 0; f < nF; ++f) frameOff[f + 1] += frameOff[f];
     numActive = off;
+    std::set<std::pair<int, int>> pairs;
+    for (const auto& rb : residuals) {
+      int fr[8];
+      int nfr = 0;
+      for (int id : rb.blocks) {
+        if (blocks[id].offset < 0) continue;
+        const int f = blocks[id].frame;
+        bool seen = false;
+        for (int k = 0; k < nfr; ++k) seen |= (fr[k] == f);
+        if (!seen && nfr < 8) fr[nfr++] = f;
+      }
+      for (int a = 0; a < nfr; ++a)
+        for (int b = a + 1; b < nfr; ++b) pairs.insert({std::max(fr[a], fr[b]), std::min(fr[a], fr[b])});
+    }
+    hPairs.assign(pairs.begin(), pairs.end());
   }
 };
 
@@ -1045,18 +1080,26 @@ static double evaluateResidualBlock(const Problem& pb, const ResidualBlock& rb, 
 struct Evaluation {
   double cost = 0.0;
   std::vector<double> g;  // reduced gradient J^T r
-  std::vector<double> H;  // reduced dense J^T J (row-major n x n), full symmetric
+  BlockSym H;             // reduced J^T J, one dense block per coupled frame pair (block_sparse.h)
 };
 
 // Evaluator::Evaluate: cost (+ gradient + J^T J). Deterministic for any thread count: Jacobians are
-// computed in parallel, accumulation rows are owned by (frame % threads).
+// computed in parallel, accumulation rows are owned by (frame % threads).  J^T J is accumulated straight into its
+// frame-pair blocks (lower block triangle; the thread that owns the larger frame of a pair writes the block).
 static void evaluateProblem(const Problem& pb, int numThreads, bool wantDerivs, Evaluation& ev) {
   const int n = pb.numActive;
   const size_t R = pb.residuals.size();
   ev.cost = 0.0;
   if (wantDerivs) {
     ev.g.assign(n, 0.0);
-    ev.H.assign(static_cast<size_t>(n) * n, 0.0);
+    const int nF = static_cast<int>(pb.frameOff.size()) - 1;
+    if (ev.H.nb != nF || ev.H.n() != n) {
+      std::vector<int> sizes(std::max(nF, 0));
+      for (int f = 0; f < nF; ++f) sizes[f] = pb.frameOff[f + 1] - pb.frameOff[f];
+      ev.H.build(sizes, pb.hPairs);
+    } else {
+      ev.H.zero();
+    }
   }
   int T = std::max(1, numThreads);
 #ifdef _OPENMP
@@ -1091,43 +1134,78 @@ static void evaluateProblem(const Problem& pb, int numThreads, bool wantDerivs, 
 #else
       const int tid = 0, nt = 1;
 #endif
+      std::vector<int> colOf, frameOfBlock;  // per parameter block of the residual: column in J, frame (-1 constant)
       for (size_t i = c0; i < c1; ++i) {
         const ResidualBlock& rb = pb.residuals[i];
         const int nr = rb.cost->numResiduals;
         const int nb = static_cast<int>(rb.blocks.size());
         int total = 0;
-        for (int s : rb.cost->blockSizes) total += s;
+        colOf.resize(nb);
+        frameOfBlock.resize(nb);
+        bool mine = false;
+        for (int b = 0; b < nb; ++b) {
+          colOf[b] = total;
+          total += rb.cost->blockSizes[b];
+          const ParamBlock& P = pb.blocks[rb.blocks[b]];
+          frameOfBlock[b] = P.offset >= 0 ? P.frame : -1;
+          mine |= (P.offset >= 0 && (P.frame % nt) == tid);
+        }
+        if (!mine) continue;
         const double* J = jacBuf[i - c0].data();
         const double* r = resBuf[i - c0].data();
-        int ci = 0;
-        for (int bi = 0; bi < nb; ++bi) {
-          const ParamBlock& Bi = pb.blocks[rb.blocks[bi]];
-          const int si = rb.cost->blockSizes[bi];
-          if (Bi.offset >= 0 && (Bi.frame % nt) == tid) {
-            for (int a = 0; a < si; ++a) {
-              const int row = Bi.offset + a;
-              double gs = 0.0;
-              for (int k = 0; k < nr; ++k) gs += J[static_cast<size_t>(k) * total + ci + a] * r[k];
-              ev.g[row] += gs;
-              int cj = 0;
-              for (int bj = 0; bj < nb; ++bj) {
-                const ParamBlock& Bj = pb.blocks[rb.blocks[bj]];
-                const int sj = rb.cost->blockSizes[bj];
-                if (Bj.offset >= 0) {
-                  double* Hrow = &ev.H[static_cast<size_t>(row) * n + Bj.offset];
-                  for (int b = 0; b < sj; ++b) {
-                    double s = 0.0;
-                    for (int k = 0; k < nr; ++k)
-                      s += J[static_cast<size_t>(k) * total + ci + a] *
-                           J[static_cast<size_t>(k) * total + cj + b];
-                    Hrow[b] += s;
-                  }
-                }
-                cj += sj;
-              }
+        // frame-pair blocks of this residual (a handful of distinct frames): looked up once per pair
+        int fr[8], nfr = 0;
+        for (int b = 0; b < nb; ++b) {
+          const int f = frameOfBlock[b];
+          if (f < 0) continue;
+          bool seen = false;
+          for (int k = 0; k < nfr; ++k) seen |= (fr[k] == f);
+          if (!seen && nfr < 8) fr[nfr++] = f;
+        }
+        double* blkPtr[8][8];
+        int blkLd[8][8];
+        for (int a = 0; a < nfr; ++a)
+          for (int b = 0; b < nfr; ++b) {
+            blkPtr[a][b] = nullptr;
+            blkLd[a][b] = 0;
+            if (fr[a] >= fr[b] && (fr[a] % nt) == tid) {
+              const int e = ev.H.find(fr[a], fr[b]);
+              blkPtr[a][b] = ev.H.val.data() + ev.H.blkOff[e];
+              blkLd[a][b] = ev.H.size(fr[b]);
             }
           }
-          ci += si;
+        auto slot = [&](int f) { for (int k = 0; k < nfr; ++k) if (fr[k] == f) return k; return 0; };
+        for (int bi = 0; bi < nb; ++bi) {
+          const int fi = frameOfBlock[bi];
+          if (fi < 0 || (fi % nt) != tid) continue;
+          const ParamBlock& Bi = pb.blocks[rb.blocks[bi]];
+          const int si = rb.cost->blockSizes[bi];
+          const int ci = colOf[bi];
+          const int li = Bi.offset - pb.frameOff[fi];
+          const int sa = slot(fi);
+          for (int a = 0; a < si; ++a) {
+            double gs = 0.0;
+            for (int k = 0; k < nr; ++k) gs += J[static_cast<size_t>(k) * total + ci + a] * r[k];
+            ev.g[Bi.offset + a] += gs;
+          }
+          for (int bj = 0; bj < nb; ++bj) {
+            const int fj = frameOfBlock[bj];
+            if (fj < 0 || fj > fi) continue;  // lower block triangle (the diagonal blocks get both triangles)
+            const ParamBlock& Bj = pb.blocks[rb.blocks[bj]];
+            const int sj = rb.cost->blockSizes[bj];
+            const int cj = colOf[bj];
+            const int lj = Bj.offset - pb.frameOff[fj];
+            const int sb = slot(fj);
+            double* Hb = blkPtr[sa][sb];
+            const int ld = blkLd[sa][sb];
+            for (int a = 0; a < si; ++a)
+              for (int b = 0; b < sj; ++b) {
+                double s2 = 0.0;
+                for (int k = 0; k < nr; ++k)
+                  s2 += J[static_cast<size_t>(k) * total + ci + a] * J[static_cast<size_t>(k) * total + cj + b];
+                Hb[static_cast<size_t>(li + a) * ld + lj + b] += s2;
+              }
+          }
         }
       }
     }
@@ -1230,8 +1308,13 @@ static void plusProject(const Problem& pb, const std::vector<double>& x, const s
 // monotonic steps (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc restated).
 // Not restated: the projected line search Ceres runs for bound-constrained problems (only normalizeDepth
 // has bounds; they stay inactive at its solution).
+// linearSolver 0: exact block-sparse Cholesky on the frame graph (block_sparse.h), the stand-in for the reference's
+// SPARSE_NORMAL_CHOLESKY; 1: the same system assembled densely and factorised by choleskyFactor (cross-check of the
+// sparse code, small problems only).  functionTolerance: Ceres default 1e-6 unless a test asks for a tighter reference
+// solution.
 static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_solve_summary* summary,
-                         std::vector<cvd_iteration_record>* records) {
+                         std::vector<cvd_iteration_record>* records, int linearSolver = 0,
+                         double functionTolerance = -1.0) {
   using D = CeresDefaults;
   const double t0 = nowSeconds();
   double tEval = 0.0, tLin = 0.0;
@@ -1272,8 +1355,15 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
     return m;
   };
 
+  const double fTol = functionTolerance > 0.0 ? functionTolerance : D::function_tolerance;
   // Jacobi scaling from the first Jacobian: 1 / (1 + sqrt(squared column norm)).
-  for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(ev.H[static_cast<size_t>(i) * n + i]));
+  {
+    std::vector<double> hd(n);
+    ev.H.diagonal(hd.data());
+    for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(hd[i]));
+  }
+  BlockCholesky chol;
+  if (linearSolver == 0 && n > 0) chol.analyze(ev.H);
 
   double radius = D::initial_trust_region_radius;
   double decreaseFactor = 2.0;
@@ -1304,38 +1394,52 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
       rec.iteration = iteration;
 
       // ---- LevenbergMarquardtStrategy::ComputeStep on the column-scaled system
+      //      (S H S + diag(clamp(diag(S H S))) / radius) y = S g,  step = -y
       double tl = nowSeconds();
-      A.assign(static_cast<size_t>(n) * n, 0.0);
+      ev.H.diagonal(diag.data());
       for (int i = 0; i < n; ++i) {
-        const double si = scale[i];
-        const double* Hi = &ev.H[static_cast<size_t>(i) * n];
-        double* Ai = &A[static_cast<size_t>(i) * n];
-        for (int j = 0; j <= i; ++j) Ai[j] = Hi[j] * si * scale[j];
-        diag[i] = std::min(std::max(Ai[i], D::min_lm_diagonal), D::max_lm_diagonal);
-        gs[i] = ev.g[i] * si;
+        const double dii = diag[i] * scale[i] * scale[i];
+        diag[i] = std::min(std::max(dii, D::min_lm_diagonal), D::max_lm_diagonal) / radius;
+        gs[i] = ev.g[i] * scale[i];
       }
-      for (int i = 0; i < n; ++i) A[static_cast<size_t>(i) * n + i] += diag[i] / radius;
-      bool ok = choleskyFactor(A, n, numThreads);
-      if (ok) {
-        y = gs;
-        choleskySolve(A, n, y);
+      bool ok;
+      y = gs;
+      if (linearSolver == 0) {
+        ok = chol.factor(ev.H, scale.data(), diag.data(), numThreads);
+        if (ok) chol.solve(y.data());
+      } else {
+        A.assign(static_cast<size_t>(n) * n, 0.0);
+        for (int I = 0; I < ev.H.nb; ++I)
+          for (int e = ev.H.rowPtr[I]; e < ev.H.rowPtr[I + 1]; ++e) {
+            const int J = ev.H.rowCol[e];
+            const int ni = ev.H.size(I), nj = ev.H.size(J);
+            const double* Bv = ev.H.val.data() + ev.H.blkOff[e];
+            for (int a = 0; a < ni; ++a)
+              for (int b = 0; b < nj; ++b) {
+                const int row = ev.H.off[I] + a, col = ev.H.off[J] + b;
+                A[static_cast<size_t>(row) * n + col] = Bv[static_cast<size_t>(a) * nj + b] * scale[row] * scale[col];
+              }
+          }
+        for (int i = 0; i < n; ++i) A[static_cast<size_t>(i) * n + i] += diag[i];
+        ok = choleskyFactor(A, n, numThreads);
+        if (ok) choleskySolve(A, n, y);
+      }
+      if (ok)
         for (int i = 0; i < n; ++i) {
           step[i] = -y[i];
           if (!std::isfinite(step[i])) ok = false;
         }
-      }
       tLin += nowSeconds() - tl;
 
       double modelCostChange = 0.0;
       if (ok) {
         // model_cost_change = -(J step)^T (r + J step / 2) = -(step^T gs + step^T Hs step / 2)
+        for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
+        ev.H.multiply(delta.data(), y.data());
         double sg = 0.0, sHs = 0.0;
         for (int i = 0; i < n; ++i) {
           sg += step[i] * gs[i];
-          const double* Hi = &ev.H[static_cast<size_t>(i) * n];
-          double hi = 0.0;
-          for (int j = 0; j < n; ++j) hi += Hi[j] * scale[j] * step[j];
-          sHs += step[i] * scale[i] * hi;
+          sHs += delta[i] * y[i];
         }
         modelCostChange = -(sg + 0.5 * sHs);
         ok = modelCostChange > 0.0;
@@ -1380,7 +1484,7 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
         break;
       }
       // FunctionToleranceReached
-      if (std::abs(xCost - candCost) <= D::function_tolerance * xCost) {
+      if (std::abs(xCost - candCost) <= fTol * xCost) {
         // Ceres keeps the iterate it had unless the step is an improvement recorded earlier; the
         // candidate is NOT accepted here (minimizer returns before IsStepSuccessful).
         scatterState(pb, x);
@@ -1440,6 +1544,8 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
 
 struct Oracle {
   int robustLoss = 0;  // 0 CauchyLoss (reference), 1 HuberLoss (BASELINE configs[4] stress variant): cvdo_set_robust_loss
+  int linearSolver = 0;            // 0 block-sparse Cholesky (default), 1 dense Cholesky (cross-check): cvdo_set_linear_solver
+  double functionTolerance = -1.0; // <= 0: Ceres' default 1e-6 (cvdo_set_function_tolerance: tighter reference solutions)
   int F = 0, W = 0, Hh = 0;
   float aspect = 1.f, invAspect = 1.f;
   std::vector<float> depth;  // F * H * W source depth (already inverted from disparity; invalid -> 0)
@@ -1905,7 +2011,7 @@ struct Oracle {
   void poseOptimizationStep(const cvd_opt_params& p, double depthDeformReg) {
     Problem pb;
     buildPoseProblem(pb, p, depthDeformReg);
-    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records);
+    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records, linearSolver, functionTolerance);
     paramsToPoses(p);
   }
 
@@ -2009,7 +2115,7 @@ struct Oracle {
       for (int k = 0; k < x.numBlocks; ++k)
         pb.setLowerBound0(&x.params[static_cast<size_t>(k) * x.blockSize], 0.0);
     }
-    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records);
+    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records, linearSolver, functionTolerance);
     if (p.normalize_depth_from_first_frame && !range.empty()) {
       const int first = range.front();
       for (int f : range)
@@ -2048,18 +2154,28 @@ struct Oracle {
     for (const auto& b : pb.blocks)
       if (b.offset >= 0)
         for (int i = 0; i < b.size; ++i) canon[b.offset + i] = b.canon + i;
-    for (int i = 0; i < n; ++i) {
-      const int ci = canon[i];
-      if (gradient) gradient[ci] = ev.g[i];
-      for (int j = 0; j < n; ++j) {
-        const double h = ev.H[static_cast<size_t>(i) * n + j];
-        if (h == 0.0) continue;
-        const int cj = canon[j];
-        if (hfull) hfull[static_cast<size_t>(ci) * NC + cj] = h;
-        if (hdiag && ci / Bf == cj / Bf)
-          hdiag[(static_cast<size_t>(ci / Bf) * Bf + ci % Bf) * Bf + cj % Bf] = h;
+    if (gradient)
+      for (int i = 0; i < n; ++i) gradient[canon[i]] = ev.g[i];
+    const BlockSym& Hs = ev.H;
+    for (int I = 0; I < Hs.nb; ++I)
+      for (int e = Hs.rowPtr[I]; e < Hs.rowPtr[I + 1]; ++e) {
+        const int J = Hs.rowCol[e];
+        if (!hfull && J != I) continue;
+        const int ni = Hs.size(I), nj = Hs.size(J);
+        const double* Bv = Hs.val.data() + Hs.blkOff[e];
+        for (int a = 0; a < ni; ++a)
+          for (int b = 0; b < nj; ++b) {
+            const double h = Bv[static_cast<size_t>(a) * nj + b];
+            if (h == 0.0) continue;
+            const int ci = canon[Hs.off[I] + a], cj = canon[Hs.off[J] + b];
+            if (hfull) {
+              hfull[static_cast<size_t>(ci) * NC + cj] = h;
+              hfull[static_cast<size_t>(cj) * NC + ci] = h;
+            }
+            if (hdiag && ci / Bf == cj / Bf)
+              hdiag[(static_cast<size_t>(ci / Bf) * Bf + ci % Bf) * Bf + cj % Bf] = h;
+          }
       }
-    }
   }
 };
 
@@ -2091,6 +2207,13 @@ int cvdo_set_robust_loss(void* h, int kind) {
     static_cast<Oracle*>(h)->robustLoss = kind;
   });
 }
+int cvdo_set_linear_solver(void* h, int kind) {
+  CVDO_TRY(h, {
+    if (kind != 0 && kind != 1) throw std::runtime_error("linear solver must be 0 (block-sparse Cholesky) or 1 (dense Cholesky)");
+    static_cast<Oracle*>(h)->linearSolver = kind;
+  });
+}
+int cvdo_set_function_tolerance(void* h, double tol) { CVDO_TRY(h, static_cast<Oracle*>(h)->functionTolerance = tol); }
 int cvdo_set_video(void* h, int numFrames, int width, int height, float aspect, float invAspect) {
   CVDO_TRY(h, static_cast<Oracle*>(h)->init(numFrames, width, height, aspect, invAspect));
 }

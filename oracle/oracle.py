@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the oracle with g++ (seconds). Building the checker is not using it."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("cvd_oracle.cpp", "jet.h", "../include/cvd_types.h")):
+            for f in ("cvd_oracle.cpp", "jet.h", "block_sparse.cpp", "block_sparse.h", "../include/cvd_types.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -39,6 +39,14 @@ class Oracle(Binding):
     def __init__(self):
         lib = load()
         super().__init__(lib, "cvdo_", lib.cvdo_create())
+
+    def set_linear_solver(self, kind):
+        """0: exact block-sparse Cholesky on the frame graph (default), 1: dense Cholesky (cross-check, small problems)."""
+        self._check(self._fn("set_linear_solver")(self._h, C.c_int(int(kind))))
+
+    def set_function_tolerance(self, tol):
+        """Ceres' function_tolerance (default 1e-6); tests tighten it to obtain a converged reference minimum."""
+        self._check(self._fn("set_function_tolerance")(self._h, C.c_double(float(tol))))
 
     def set_robust_loss(self, kind):
         """0: CauchyLoss (reference), 1: HuberLoss -- mirrors api.Solver.set_robust_loss."""

@@ -29,8 +29,10 @@ def hierarchical_pairs(num_frames, two_way=True, min_dist=1, max_dist=None, incl
                        extra_offsets=False):
     """Re-statement of SamplePairs.sample_hierarchical(2) (reference utils/frame_sampling.py:77-120).
 
-    extra_offsets=True additionally starts every level >= 2 at quarter steps, the densification used
-    for the "~4k pairs" configuration of BASELINE.json.
+    extra_offsets = k > 0 densifies the start frames of the long-range levels: level l steps by 2^max(0, l - k)
+    instead of 2^(l - 1) ("add levels with half-step offsets until P ~ 4000").  At 300 frames:
+    k = 1 is the reference's own list (1766 directed pairs), 2 -> 2332, 3 (= True) -> 2874, 4 -> 3374, 5 -> 3808,
+    6 -> 4140 = the "~4k pairs" flow list BASELINE.json's north_star names.
     """
     if max_dist is None:
         max_dist = num_frames - 1
@@ -42,7 +44,7 @@ def hierarchical_pairs(num_frames, two_way=True, min_dist=1, max_dist=None, incl
         dist = 1 << level
         step_level = max(0, level - 1) if include_mid_point else level
         if extra_offsets:
-            step_level = max(0, level - 3)
+            step_level = max(0, level - (3 if extra_offsets is True else int(extra_offsets)))
         step = 1 << step_level
         for start in range(0, num_frames, step):
             for sign in signs:

@@ -1,0 +1,82 @@
+"""BASELINE.json configs[0..2] at their REAL sizes, as one recipe shared by the fixture minting script
+(tests/golden/make_solutions.py: CPU oracle, block-sparse exact Cholesky) and the GPU parity tests
+(tests/test_gpu_baseline_configs.py: HIP path with the default = benchmarked solver options).
+
+  config0: 30 frames 192x112, fixed intrinsics, global-scale-only deformation (one LM solve)
+  config1: 100 frames 384x224, 4x4 bicubic spline grid (one LM solve from the normalised global scale)
+  config2: 300 frames 384x224, hierarchical2 flow list (1766 directed pairs), the default pipeline of
+           pose_optimization.py: normalizeDepth + coarse-to-fine Global -> 6x4 -> 12x7 -> 17x10
+  config2_dense4k: config2 with the "~4k pairs" flow list of BASELINE.json's north_star (extra_level=6: 4140 pairs)
+"""
+import hashlib
+import os
+
+import numpy as np
+
+from robust_cvd_amd import synth
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, XformDesc
+
+SOLUTIONS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solutions")
+
+CONFIGS = {
+    # name: (frames, width, height, seed, extra pair level)
+    "config0": dict(frames=30, width=192, height=112, seed=1235),
+    "config1": dict(frames=100, width=384, height=224, seed=1236),
+    "config2": dict(frames=300, width=384, height=224, seed=1237),
+}
+
+
+def make_video(name):
+    c = CONFIGS[name]
+    return synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"])
+
+
+def input_digest(video):
+    h = hashlib.sha256()
+    for a in (video.depth, video.pairs, video.offsets, video.loc):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def params_for(name, threads=8):
+    p = OptParams.defaults()
+    p.num_threads = threads
+    if name == "config0":
+        p.intr_opt = IntrinsicsOptimization.Fixed
+        p.coarse_to_fine = 0
+        p.num_steps = 1
+    elif name == "config1":
+        p.coarse_to_fine = 0
+        p.num_steps = 1
+    return p
+
+
+def run(binding, name, video, threads=8):
+    """The solve of one config on `binding` (product Solver or test Oracle); returns the end state."""
+    p = params_for(name, threads)
+    synth.load_into(binding, video, p.focal_long)
+    binding.reset_depth_xforms(XformDesc.global_depth())
+    binding.reset_spatial_xforms(XformDesc.spatial())
+    binding.normalize_depth(p)
+    if name == "config1":
+        binding.grid_xform_split(XformDesc.grid_depth(4, 4, cubic=True))
+    binding.pose_optimization(p)
+    poses = binding.get_poses()
+    return {
+        "pose7": binding.get_pose_params().copy(),
+        "position": np.asarray(poses["position"]).copy(),
+        "orientation": np.asarray(poses["orientation"]).copy(),
+        "vfov": np.asarray(poses["vfov"]).copy(),
+        "hfov": np.asarray(poses["hfov"]).copy(),
+        "depth_params": binding.get_xform_params().copy(),
+        "grid_size": np.asarray(list(binding.xform_desc().grid_size), np.int32),
+        "summary": binding.summary(),
+    }
+
+
+def solution_path(name):
+    return os.path.join(SOLUTIONS_DIR, name + ".npz")
+
+
+def load_solution(name):
+    return dict(np.load(solution_path(name), allow_pickle=False))
