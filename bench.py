@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- LM iterations/s of the geometric-consistency optimizer on MI355X (driver contract).
 
-Metric (BASELINE.json): Gauss-Newton / Levenberg-Marquardt iterations per second on a 300-frame 384x224
-synthetic video (configs[2]: hierarchical flow_list, full LM loop).  One "step" = one LM iteration in Ceres'
-counting (Jacobian evaluation + linear solve + candidate-cost evaluation) at the FINAL coarse-to-fine grid
-(17x10 bilinear depth grid, 177 unknowns per frame, 53 100 unknowns, ~1.09 M flow constraints), starting
-from the state the coarser levels converged to.  Exactly K iterations are timed; they belong to real, naturally
+Metric (BASELINE.json): Gauss-Newton / Levenberg-Marquardt iterations per second on a 300-frame 384x224 synthetic
+video with ~4k flow pairs, full LM loop (configs[2] as north_star quotes it).  The default workload is the
+hierarchical2 flow list of the reference's sampler (utils/frame_sampling.py:77-120) densified to 4140 directed pairs
+(`--pairs-level 6`: level l starts every 2^max(0, l-6) frames) = 2.40 M flow constraints; the
+reference sampler's own 1766-pair list is timed in the same run as the secondary figure (`secondary_1766_pairs`).
+
+One "step" = one LM iteration in Ceres' counting (Jacobian evaluation + linear solve + candidate-cost evaluation) at
+the FINAL coarse-to-fine grid (17x10 bilinear depth grid, 177 unknowns per frame, 53 100 unknowns), starting from the
+state the coarser levels converged to, with the DEFAULT solver options -- the ones the parity tests
+(tests/test_gpu_baseline_configs.py) run with.  Exactly K iterations are timed; they belong to real, naturally
 converging solves of that level (when a solve converges early the start state is restored and the next begins).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --config 4 [--robust huber]      # BASELINE configs[4]: 1000 frames 640x384, 16x12 grid (one GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1 (default `--mode shard`): the SAME 300-frame problem, frame pairs sharded across the ranks
-(robust_cvd_amd/sharding.py), regularisers by frame % N; the library all-reduces [g | H_ff | cost] once per
-Jacobian evaluation and q once per PCG product over RCCL.  Total work is fixed => "strong" scaling,
-`value` = K iterations / max-over-ranks time.  `--mode replicas` instead gives every rank its own video
-(no data-path exchange, "weak" scaling, value = N x K / time).
+N > 1 (default `--mode shard`): the SAME problem, frame pairs sharded across the ranks (robust_cvd_amd/sharding.py),
+regularisers by frame % N; the library exchanges over RCCL.  Total work is fixed => "strong" scaling,
+`value` = K iterations / max-over-ranks time.  `--mode replicas` gives every rank its own video (weak scaling).
 
 The JSON line also carries
-  roofline     : dominant kernel k_matvec_pairs -- algorithmic HBM bytes per launch / average launch duration
-                 (HIP events on the solver stream, live in this run) vs the 8 TB/s HBM peak;
-  cpu_baseline : the CPU oracle (a port of the reference's Ceres problem: autodiff + exact Cholesky LM)
-                 timed on the host cores on a bounded sample, rank 0 at N = 1 only.
+  roofline     : dominant kernel k_matvec_pairs -- algorithmic HBM bytes per launch / average launch duration (HIP
+                 events on the solver stream, live in this run) vs the 8 TB/s HBM peak, the same for its counted
+                 f64 flops vs the 78.6 TF/s vector peak (`valu`), and the PMC HBM traffic of profiles/pmc_matvec_pairs.json
+                 when that file was produced from the kernel sources being benchmarked (hash check);
+  cpu_baseline : the CPU oracle (a port of the reference's Ceres problem: autodiff + exact block-sparse Cholesky LM)
+                 timed on the host cores on the SAME workload from the SAME state, rank 0 at N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,12 +40,45 @@ _ROOT = os.path.dirname(os.path.abspath(__file__))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-FRAMES, WIDTH, HEIGHT = 300, 384, 224
 SEED = 1234 + 3
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+F64_PEAK_TFLOPS = 78.6  # MI355X f64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+# f64 operations per constraint of k_matvec_pairs_fast<4> counted from the kernel source (FMA = 2): gathers 36, depths
+# and their directional derivatives 48, geometry + residual + robust weight 76, forward product 101, adjoint 97
+# 
+FLOPS_PER_CONSTRAINT = 358.0
+
+CONFIGS = {
+    2: dict(frames=300, width=384, height=224, ctf=(17, 10), label="configs[2]"),
+    4: dict(frames=1000, width=640, height=384, ctf=(16, 12), label="configs[4]"),
+}
 
 
-def prepare(solver, video, params, final_grid=(17, 10), pair_graph=None):
+def kernel_sources_digest():
+    """SHA-256 over the device / host sources of libcvd_hip.so: ties a committed PMC measurement to the code it measured."""
+    h = hashlib.sha256()
+    d = os.path.join(_ROOT, "robust_cvd_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip")):
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(fn.encode())
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def ctf_schedule(params, aspect):
+    """Grid sizes of the coarse-to-fine levels after the Global one (reference lib/PoseOptimizer.cpp:795-802,858-863)."""
+    rows, cols = params.ctf_long, params.ctf_short
+    if aspect >= 1.0:
+        rows, cols = cols, rows
+    out = []
+    for step in range(params.num_steps - 1):
+        it = (step + 1) / float(params.num_steps - 1)
+        out.append((int(1 + (cols - 1) * it + 0.5), int(1 + (rows - 1) * it + 0.5)))
+    return out
+
+
+def prepare(solver, video, params, pair_graph=None):
     """Untimed: everything pose_optimization() does before the final coarse-to-fine level."""
     from robust_cvd_amd import synth
     from robust_cvd_amd.ctypes_types import XformDesc
@@ -46,62 +86,95 @@ def prepare(solver, video, params, final_grid=(17, 10), pair_graph=None):
     t_up = time.perf_counter()
     synth.load_into(solver, video, params.focal_long)  # the boundary hands over HOST buffers: depth maps + constraints
     torch.cuda.synchronize()
-    prepare.upload_seconds = time.perf_counter() - t_up
+    upload = time.perf_counter() - t_up
     if pair_graph is not None:  # pair-sharded mode: the whole problem's frame graph for the coarse preconditioner level
         solver.set_pair_graph(pair_graph)
     solver.reset_depth_xforms(XformDesc.global_depth())
     solver.reset_spatial_xforms(XformDesc.spatial())
     solver.normalize_depth(params)
-    # CTF schedule of reference lib/PoseOptimizer.cpp:858-863 for a landscape video: Global -> 6x4 -> 12x7 -> 17x10
+    grids = ctf_schedule(params, video.aspect)
     first = True
-    for grid in (None, (6, 4), (12, 7)):
+    for grid in [None] + grids[:-1]:
         if grid is not None:
             solver.grid_xform_split(XformDesc.grid_depth(*grid))
         solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=first)
         first = False
-    solver.grid_xform_split(XformDesc.grid_depth(*final_grid))
+    solver.grid_xform_split(XformDesc.grid_depth(*grids[-1]))
+    return upload, grids[-1]
 
 
-def cpu_baseline(params, full_constraints):
-    """Oracle (kind 'port') on a bounded sample: 32 frames at the same resolution / grid, 6 LM iterations (~10 s of CPU
-    work on the GPU box's host cores).  The oracle's linear solve is an exact DENSE Cholesky (cubic in the frame count),
-    Ceres' is sparse: the Jacobian-evaluation share, which is a faithful restatement, is reported beside the total."""
+def cpu_baseline(params, video, grid, pose0, theta0, robust):
+    """Oracle (kind 'port': dual-number autodiff + Ceres-default LM + exact block-sparse Cholesky on the frame graph) on
+    the SAME workload from the SAME state as the timed GPU iterations: one LM iteration, i.e. the initial Jacobian
+    evaluation, one factorisation + solve, the candidate cost and (step accepted) the next Jacobian evaluation.  The
+    problem construction (one residual-block object per constraint, as the reference builds its Ceres problem in every
+    poseOptimizationStep) is reported beside it, not counted."""
     from robust_cvd_amd import synth
-    from robust_cvd_amd.ctypes_types import XformDesc
+    from robust_cvd_amd.ctypes_types import OptParams, XformDesc
     from oracle.oracle import Oracle
     cores = os.cpu_count() or 1
     threads = min(12, cores)  # reference default numThreads = 12 (lib/PoseOptimizer.h:57)
-    sample_frames = 32
-    video = synth.make_video(sample_frames, WIDTH, HEIGHT, seed=SEED)
-    from robust_cvd_amd.ctypes_types import OptParams
     p = OptParams.defaults()
+    for k in ("ctf_long", "ctf_short", "robustness"):
+        setattr(p, k, getattr(params, k))
     p.num_threads = threads
+    p.max_iterations = 1
     o = Oracle()
+    o.set_robust_loss(robust)
     synth.load_into(o, video, p.focal_long)
-    o.reset_depth_xforms(XformDesc.global_depth())
+    o.reset_depth_xforms(XformDesc.grid_depth(*grid))
     o.reset_spatial_xforms(XformDesc.spatial())
-    o.normalize_depth(p)
-    o.grid_xform_split(XformDesc.grid_depth(17, 10))
-    p.max_iterations = 6
+    o.set_pose_params(pose0)
+    o.set_xform_params(theta0)
     t0 = time.perf_counter()
-    o.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=True)
-    dt = time.perf_counter() - t0
+    o.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=False)
+    wall = time.perf_counter() - t0
     s = o.summary()
-    iters = max(1, s["num_iterations"])
-    sample_rate = iters / dt
-    scaled = sample_rate * video.num_constraints / float(full_constraints)
+    iters = s["num_iterations"]
+    assert iters == 1, s
     return {
-        "value": scaled, "unit": "LM iterations/s", "cores": threads, "kind": "port",
-        "sample": (f"oracle (dual-number autodiff + exact dense Cholesky LM) on {sample_frames} frames {WIDTH}x{HEIGHT}, "
-                   f"{len(video.pairs)} pairs, {video.num_constraints} constraints, 17x10 grid, {iters} LM iterations in "
-                   f"{dt:.2f} s = {sample_rate:.3f} it/s on the sample; scaled linearly in the constraint count to the "
-                   f"{full_constraints}-constraint workload (optimistic for the CPU: its solve grows super-linearly)"),
-        "sample_it_per_s": sample_rate,
-        # the same extrapolation on the residual + Jacobian evaluation time alone (no linear solve at all): an upper bound
-        # for any CPU solver built on the reference's autodiff evaluation
-        "evaluation_only_it_per_s_scaled": (iters / max(s["evaluate_seconds"], 1e-9)) * video.num_constraints / float(full_constraints),
-        "evaluate_seconds": s["evaluate_seconds"], "linear_solve_seconds": s["linear_solve_seconds"],
+        "value": iters / s["total_seconds"], "unit": "LM iterations/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle on the full benchmarked workload ({len(video.pairs)} directed pairs, {video.num_constraints} constraints, "
+                   f"{video.num_frames} frames, {grid[0]}x{grid[1]} grid) from the same state as the timed GPU iterations: 1 LM "
+                   f"iteration = {s['total_seconds']:.2f} s ({s['evaluate_seconds']:.2f} s residual + Jacobian evaluation by dual "
+                   f"numbers: two Jacobian passes and one cost pass; {s['linear_solve_seconds']:.2f} s exact block-sparse Cholesky "
+                   f"step on the frame graph); not counted: {wall - s['total_seconds']:.1f} s problem construction; {threads} "
+                   f"threads of {cores} host cores (reference default numThreads = 12); no scaling of any kind"),
+        "seconds_per_iteration": s["total_seconds"], "evaluate_seconds": s["evaluate_seconds"],
+        "linear_solve_seconds": s["linear_solve_seconds"], "problem_construction_seconds": wall - s["total_seconds"],
+        # a solver with a free linear solve on top of the reference's autodiff evaluation
+        "evaluation_only_it_per_s": iters / max(s["evaluate_seconds"], 1e-9),
+        "cost_after_iteration": s["final_cost"],
     }
+
+
+def run_iterations(solver, params, pose0, theta0, count):
+    done, cg, solves, last = 0, 0, 0, None
+    while done < count:
+        solver.set_pose_params(pose0)
+        solver.set_xform_params(theta0)
+        params.max_iterations = count - done
+        solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
+        last = solver.summary()
+        assert last["num_iterations"] >= 1, last  # (a solve from this start state never terminates at iteration 0)
+        done += last["num_iterations"]
+        cg += last["total_linear_iterations"]
+        solves += 1
+    return done, cg, solves, last
+
+
+def matvec_bytes_per_launch(video, n_active, B):
+    """Algorithmic bytes of one k_matvec_pairs launch: the 24 B constraint table entry (ndc 16 B + source depths 8 B) of
+    every constraint + per work item (undirected frame pair, chunked at 768 constraints per direction) the two frames'
+    x, z, p_old, mask blocks read and the two partial q blocks written (B doubles each).  DESIGN.md 3."""
+    import numpy as np
+    cnt = np.diff(video.offsets)
+    und = {}
+    for (a, b), n in zip(video.pairs.tolist(), cnt.tolist()):
+        k = (min(a, b), max(a, b))
+        und[k] = max(und.get(k, 0), n)
+    n_items = sum(-(-n // 768) for n in und.values())
+    return 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
 
 
 def main():
@@ -109,10 +182,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=FRAMES)
-    ap.add_argument("--pcg-tol", type=float, default=None)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2, help="BASELINE.json configs[k]")
+    ap.add_argument("--frames", type=int, default=None, help="development: override the frame count")
+    ap.add_argument("--pairs-level", type=int, default=None,
+                    help="flow-list density (synth.hierarchical_pairs extra_offsets): 1 = the reference sampler's own list "
+                         "(1766 pairs at 300 frames), 6 = the ~4k pairs of north_star (4140, default for --config 2)")
+    ap.add_argument("--robust", choices=["cauchy", "huber"], default="cauchy", help="robust loss on the flow constraints")
+    ap.add_argument("--pcg-tol", type=float, default=None, help="development: PCG forcing value (default: the library's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra-pairs", action="store_true", help="denser pair set (towards the ~4k pairs of BASELINE.json)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figure on the reference sampler's 1766-pair list")
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every kernel class (slower)")
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the hot kernel (1 = all)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="development: no HIP-event timing of the hot kernel (roofline fields are then empty)")
@@ -136,109 +215,104 @@ def main():
     from robust_cvd_amd import api, synth
     from robust_cvd_amd.ctypes_types import OptParams
 
+    cfg = CONFIGS[args.config]
+    frames = args.frames or cfg["frames"]
+    width, height = cfg["width"], cfg["height"]
+    level = args.pairs_level if args.pairs_level is not None else (6 if args.config == 2 else 1)
+    robust = 1 if args.robust == "huber" else 0
     params = OptParams.defaults()
+    params.ctf_long, params.ctf_short = cfg["ctf"]
     shard = world > 1 and args.mode == "shard"
-    video = synth.make_video(args.frames, WIDTH, HEIGHT, seed=SEED + (0 if shard or world == 1 else rank),
-                             extra_offsets=args.extra_pairs)
-    solver = api.Solver(local_rank)
-    full_pairs, full_constraints = len(video.pairs), video.num_constraints
-    if shard:
-        # RCCL communicator inside the library: rank 0 mints the id, torch.distributed carries the 128 bytes
-        from robust_cvd_amd import sharding
-        ids = [api.Solver.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        solver.comm_init(rank, world, ids[0])
-        all_pairs = video.pairs.copy()
-        mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
-        video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
-            video.pairs, video.offsets, video.loc, video.is_static, mine)
-    if args.pcg_tol is not None:
-        solver.set_options(pcg_relative_tolerance=args.pcg_tol)
-    t_prep = time.perf_counter()
-    prepare(solver, video, params, pair_graph=all_pairs if shard else None)
-    t_prep = time.perf_counter() - t_prep
-    prep_summary = solver.summary()
-
-    # State at the start of the final coarse-to-fine level: every measured LM iteration belongs to a real,
-    # naturally converging solve from here.  When a solve converges before K iterations are used up, the state is
-    # restored and the next solve starts (the restore is two small host->device uploads inside the timed region).
-    pose0 = solver.get_pose_params().copy()
-    theta0 = solver.get_xform_params().copy()
-
-    def run_iterations(count):
-        done, cg, solves, last = 0, 0, 0, None
-        while done < count:
-            solver.set_pose_params(pose0)
-            solver.set_xform_params(theta0)
-            params.max_iterations = count - done
-            solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
-            last = solver.summary()
-            done += max(1, last["num_iterations"])
-            cg += last["total_linear_iterations"]
-            solves += 1
-        return done, cg, solves, last
-
-    if args.warmup > 0:
-        run_iterations(args.warmup)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP-event timing of the dominant kernel only (two event records per timed launch): the other classes are
-    # timed in the profiles/ runs, not inside the measured region
-    # (default: every 4th launch of the hot kernel carries the start/stop event pair -- a uniform sample of the timed
-    # region's launches; the events of hipExtLaunchKernelGGL serialise the dispatch, ~3 % of the rate at every launch)
-    sample_every = 1 if args.time_all_kernels else args.time_every
-    if not args.no_kernel_timing:
-        solver.set_kernel_timing(True, classes=None if args.time_all_kernels else ["matvec_pairs"], sample_every=sample_every)
-    barrier()
-    t0 = time.perf_counter()
-    done, total_cg, n_solves, summ = run_iterations(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    assert done == args.steps, (done, args.steps)
-    ktimes = solver.kernel_times()
+    def measure(pairs_level, steps, warmup, timing, seed_offset=0):
+        """prepare + warm-up + the timed region for one flow list; returns everything the JSON line needs."""
+        video = synth.make_video(frames, width, height, seed=SEED + seed_offset, extra_offsets=pairs_level)
+        solver = api.Solver(local_rank)
+        solver.set_options(robust_loss=robust)
+        full = dict(pairs=len(video.pairs), constraints=video.num_constraints)
+        full_video = video
+        all_pairs = None
+        if shard:
+            # RCCL communicator inside the library: rank 0 mints the id, torch.distributed carries the 128 bytes
+            from robust_cvd_amd import sharding
+            import copy
+            ids = [api.Solver.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            solver.comm_init(rank, world, ids[0])
+            all_pairs = video.pairs.copy()
+            mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
+            video = copy.copy(video)
+            video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
+                full_video.pairs, full_video.offsets, full_video.loc, full_video.is_static, mine)
+        if args.pcg_tol is not None:
+            solver.set_options(pcg_relative_tolerance=args.pcg_tol)
+        t_prep = time.perf_counter()
+        upload, grid = prepare(solver, video, params, pair_graph=all_pairs)
+        t_prep = time.perf_counter() - t_prep
+        prep_summary = solver.summary()
+        # State at the start of the final coarse-to-fine level: every measured LM iteration belongs to a real, naturally
+        # converging solve from here (restoring it is two small host->device uploads inside the timed region).
+        pose0 = solver.get_pose_params().copy()
+        theta0 = solver.get_xform_params().copy()
+        if warmup > 0:
+            run_iterations(solver, params, pose0, theta0, warmup)
+        # HIP-event timing of the dominant kernel only (two event records per timed launch, on every 4th launch: a uniform
+        # sample of the timed region; the events of hipExtLaunchKernelGGL serialise the dispatch)
+        sample_every = 1 if args.time_all_kernels else args.time_every
+        if timing and not args.no_kernel_timing:
+            solver.set_kernel_timing(True, classes=None if args.time_all_kernels else ["matvec_pairs"], sample_every=sample_every)
+        barrier()
+        t0 = time.perf_counter()
+        done, total_cg, n_solves, summ = run_iterations(solver, params, pose0, theta0, steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        assert done == steps, (done, steps)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dict(video=full_video, local_video=video, solver=solver, full=full, dt=dt, total_cg=total_cg, n_solves=n_solves, summ=summ,
+                    t_prep=t_prep, upload=upload, prep_summary=prep_summary, pose0=pose0, theta0=theta0, grid=grid,
+                    sample_every=sample_every, ktimes=solver.kernel_times(), n_active=solver.num_active_constraints(),
+                    B=solver.block_size())
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    m = measure(level, args.steps, args.warmup, timing=True, seed_offset=(0 if shard or world == 1 else rank))
 
     if rank == 0:
-        n_active = solver.num_active_constraints()
-        B = solver.block_size()
-        mv = ktimes["matvec_pairs"]
-        # algorithmic bytes of one k_matvec_pairs launch: the 24 B constraint table entry (ndc 16 B + source
-        # depths 8 B) of every constraint + per work item the two frames' x, z, p_old, mask blocks read and
-        # the two partial q blocks written (B doubles each).  See DESIGN.md "k_matvec_pairs".
-        # work items = undirected frame pairs (both directions share one workgroup), chunked at 768 per direction
-        import numpy as np
-        cnt = np.diff(video.offsets)
-        und = {}
-        for (a, b), n in zip(video.pairs.tolist(), cnt.tolist()):
-            k = (min(a, b), max(a, b))
-            und[k] = max(und.get(k, 0), n)
-        n_items = sum(-(-n // 768) for n in und.values())
-        bytes_launch = 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
+        video, B, n_active = m["video"], m["B"], m["n_active"]
+        mv = m["ktimes"]["matvec_pairs"]
+        bytes_launch = matvec_bytes_per_launch(m["local_video"], n_active, B)
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
-        # HBM bytes per launch from the committed PMC run (separate rocprofv3 --pmc passes cannot run inside this
-        # process): profiles/pmc_matvec_pairs.json, FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE
-        traffic = None
+        flops_launch = FLOPS_PER_CONSTRAINT * n_active
+        tflops = (flops_launch / (mv["avg_ms"] * 1e-3)) / 1e12 if mv["avg_ms"] > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot happen inside this
+        # process): only when profiles/pmc_matvec_pairs.json was produced from the kernel sources benchmarked here and
+        # on this workload; FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE (tools/pmc_to_json.py)
+        traffic, traffic_note = None, "no PMC file"
         try:
             with open(os.path.join(_ROOT, "profiles", "pmc_matvec_pairs.json")) as fpm:
-                traffic = json.load(fpm)["traffic_bytes_per_launch"] if world == 1 and args.frames == FRAMES else None
+                pmc = json.load(fpm)
+            if pmc.get("kernel_sources_sha256") != kernel_sources_digest():
+                traffic_note = "profiles/pmc_matvec_pairs.json is stale (kernel sources changed since it was measured)"
+            elif world != 1 or pmc.get("constraints") != int(n_active):
+                traffic_note = "profiles/pmc_matvec_pairs.json was measured on another workload"
+            else:
+                traffic, traffic_note = pmc["traffic_bytes_per_launch"], "profiles/pmc_matvec_pairs.json (same kernel sources, same workload)"
         except Exception:
-            traffic = None
+            pass
         out = {
             "metric": "GN/LM iterations/sec (and ms/iter) on 300-frame 384x224 video, 1/2/4/8 GPU",
-            "value": (1 if shard else world) * args.steps / dt,
+            "value": (1 if shard else world) * args.steps / m["dt"],
             "unit": "LM iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": m["dt"] / args.steps * 1e3,
             "higher_is_better": True,
             # default mode: the SAME problem at every N (pairs sharded) => strong; --mode replicas: one video per GPU => weak
             "scaling": "strong" if args.mode == "shard" else "weak",
@@ -246,37 +320,56 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"configs[2]: {args.frames}-frame {WIDTH}x{HEIGHT} synthetic video, hierarchical2 two-way "
-                             f"flow_list ({full_pairs} directed pairs, {full_constraints} flow constraints), "
-                             f"full LM loop; timed = LM iterations at the final CTF level (17x10 bilinear grid, "
-                             f"B={B}, {args.frames * B} unknowns), Cauchy 0.5, PerFrame intrinsics"),
-                "pairs": int(full_pairs), "constraints": int(n_active), "unknowns": int(args.frames * B),
-                "parallelism": "single-gpu" if world == 1 else (f"pair-sharded dp{world} + RCCL all-reduce" if shard else "video-per-gpu"),
+                "workload": (f"{cfg['label']}: {frames}-frame {width}x{height} synthetic video, hierarchical2 two-way flow_list "
+                             f"densified to level {level} ({m['full']['pairs']} directed pairs, {m['full']['constraints']} flow "
+                             f"constraints), full LM loop; timed = LM iterations at the final CTF level ({m['grid'][0]}x{m['grid'][1]} "
+                             f"bilinear grid, B={B}, {frames * B} unknowns), {'Huber' if robust else 'Cauchy'} {params.robustness}, "
+                             f"PerFrame intrinsics, default solver options"),
+                "pairs": int(m["full"]["pairs"]), "constraints": int(n_active), "unknowns": int(frames * B),
+                "parallelism": "single-gpu" if world == 1 else (f"pair-sharded dp{world} + RCCL" if shard else "video-per-gpu"),
                 "linear_solver": "PCG on matrix-free J^T J, two-level preconditioner (per-frame block-Jacobi + pose-graph coarse level)",
-                "pcg_iterations_per_lm_iteration": total_cg / max(1, done),
-                "solves_in_timed_region": n_solves,
+                "pcg_iterations_per_lm_iteration": m["total_cg"] / max(1, args.steps),
+                "solves_in_timed_region": m["n_solves"],
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "bytes_per_launch": bytes_launch, "avg_launch_ms": mv["avg_ms"], "launches": mv["launches"],
-                "timed": f"HIP start/stop events on every {sample_every}. launch of the timed region ({mv['launches']} launches timed)",
-                "note": "f64 VALU/latency-bound, not HBM-bound: ~24 B and ~1 kflop per constraint (DESIGN.md)",
+                "timed": f"HIP start/stop events on every {m['sample_every']}. launch of the timed region ({mv['launches']} launches timed)",
+                "valu": {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
+                         "flops_per_launch": flops_launch,
+                         "note": f"{FLOPS_PER_CONSTRAINT:.0f} f64 flop per constraint counted from the kernel source (DESIGN.md 3)"},
+                "note": "f64 VALU/latency-bound, not HBM-bound (DESIGN.md 3): both fractions are reported",
             },
-            "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in ktimes.items()},
-            "kernels_launches": {k: v["launches"] for k, v in ktimes.items()},
-            "last_timed_solve": {k: summ[k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
-                                                      "initial_cost", "final_cost", "termination")},
-            "prepare_seconds": t_prep,
+            "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["ktimes"].items()},
+            "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
+            "last_timed_solve": {k: m["summ"][k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
+                                                           "initial_cost", "final_cost", "termination")},
+            "prepare_seconds": m["t_prep"],
             # host -> device hand-over of the inputs (depth maps F*H*W f32 + 16 B per constraint), once per solve sequence;
             # never part of `value` (inputs are resident when the timed region starts)
-            "upload_seconds": getattr(prepare, "upload_seconds", None),
+            "upload_seconds": m["upload"],
             "upload_bytes": int(video.depth.nbytes + video.loc.nbytes + video.is_static.nbytes),
-            "prepare_last_level": {k: prep_summary[k] for k in ("num_iterations", "total_linear_iterations", "final_cost",
-                                                                "total_seconds")},
+            "prepare_last_level": {k: m["prep_summary"][k] for k in ("num_iterations", "total_linear_iterations", "final_cost",
+                                                                     "total_seconds")},
         }
+    solver_main = m.pop("solver")
+    solver_main.close()
+    if args.config == 2 and level != 1 and not args.no_secondary and args.frames is None:
+        # secondary figure: the reference sampler's own flow list (1766 directed pairs at 300 frames), same recipe
+        m2 = measure(1, args.secondary_steps, min(args.warmup, 2), timing=False)
+        if rank == 0:
+            out["secondary_1766_pairs"] = {
+                "value": (1 if shard else world) * args.secondary_steps / m2["dt"], "unit": "LM iterations/s",
+                "ms_per_step": m2["dt"] / args.secondary_steps * 1e3, "steps": args.secondary_steps,
+                "pairs": int(m2["full"]["pairs"]), "constraints": int(m2["full"]["constraints"]),
+                "pcg_iterations_per_lm_iteration": m2["total_cg"] / max(1, args.secondary_steps),
+                "workload": "the reference sampler's hierarchical2 flow list (utils/frame_sampling.py:77-120), otherwise identical",
+            }
+        m2.pop("solver").close()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, n_active)
+            out["cpu_baseline"] = cpu_baseline(params, m["video"], m["grid"], m["pose0"], m["theta0"], robust)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -273,13 +273,23 @@ double BlockCholesky::analyze(const BlockSym& A) {
     flops_ += nk * (below * below + belowSq);           // trailing update: 2 nk sum_{i >= j} n_i n_j
     colPtr_[k + 1] = static_cast<int>(lRow_.size());
   }
-  lval_.assign(total, 0.0);
+  lbuf_.reset(new double[std::max<size_t>(total, 1)]);
+  lsize_ = total;
   return flops_;
 }
 
 bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double* extraDiag, int numThreads) {
   if (A.nb != nb_) throw std::runtime_error("BlockCholesky::factor: analyze() was run for another structure");
-  std::fill(lval_.begin(), lval_.end(), 0.0);
+  double* const lval = lbuf_.get();
+  const int T = std::max(1, numThreads);
+  {
+    const long long nChunks = static_cast<long long>((lsize_ + (1u << 20) - 1) >> 20);
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (long long c = 0; c < nChunks; ++c) {
+      const size_t b0 = static_cast<size_t>(c) << 20, b1 = std::min(lsize_, b0 + (size_t(1) << 20));
+      std::memset(lval + b0, 0, (b1 - b0) * sizeof(double));
+    }
+  }
   // scatter S A S (+ diag) into L's storage, permuted (a block whose position order is reversed is transposed)
   for (int I = 0; I < nb_; ++I) {
     const int ni = A.size(I);
@@ -293,7 +303,7 @@ bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double*
       const double* sj = scale ? scale + A.off[J] : nullptr;
       if (pi >= pj) {
         const int lb = findL(pi, pj);
-        double* D = lval_.data() + lOff_[lb];
+        double* D = lval + lOff_[lb];
         for (int a = 0; a < ni; ++a)
           for (int b = 0; b < nj; ++b)
             D[static_cast<size_t>(a) * nj + b] = B[static_cast<size_t>(a) * nj + b] * (si ? si[a] * sj[b] : 1.0);
@@ -301,14 +311,13 @@ bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double*
           for (int a = 0; a < ni; ++a) D[static_cast<size_t>(a) * ni + a] += extraDiag[A.off[I] + a];
       } else {
         const int lb = findL(pj, pi);
-        double* D = lval_.data() + lOff_[lb];
+        double* D = lval + lOff_[lb];
         for (int a = 0; a < ni; ++a)
           for (int b = 0; b < nj; ++b)
             D[static_cast<size_t>(b) * ni + a] = B[static_cast<size_t>(a) * nj + b] * (si ? si[a] * sj[b] : 1.0);
       }
     }
   }
-  const int T = std::max(1, numThreads);
   std::vector<double> Lt;  // transposes of column k's blocks below the diagonal: for block j, [nk x nj]
   std::vector<size_t> ltOff;
   bool ok = true;
@@ -316,7 +325,7 @@ bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double*
     const int nk = psize_[k];
     if (nk == 0) continue;
     const int c0 = colPtr_[k], c1 = colPtr_[k + 1];
-    double* Lkk = lval_.data() + lOff_[c0];
+    double* Lkk = lval + lOff_[c0];
     if (!potrfLower(Lkk, nk, nk)) { ok = false; break; }
     const int nBelow = c1 - c0 - 1;
     if (nBelow == 0) continue;
@@ -328,7 +337,7 @@ bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double*
     for (int b = 0; b < nBelow; ++b) {
       const int i = lRow_[c0 + 1 + b];
       const int ni = psize_[i];
-      double* X = lval_.data() + lOff_[c0 + 1 + b];
+      double* X = lval + lOff_[c0 + 1 + b];
       trsmRows(X, nk, Lkk, nk, ni, nk);
       double* Xt = Lt.data() + ltOff[b];
       for (int a = 0; a < ni; ++a)
@@ -347,14 +356,15 @@ bool BlockCholesky::factor(const BlockSym& A, const double* scale, const double*
       const int ni = psize_[i], nj = psize_[j];
       if (ni == 0 || nj == 0) continue;
       const int tb = findL(i, j);
-      double* Cij = lval_.data() + lOff_[tb];
-      gemmSub(Cij, nj, lval_.data() + lOff_[c0 + 1 + bi], nk, Lt.data() + ltOff[bj], nj, ni, nj, nk);
+      double* Cij = lval + lOff_[tb];
+      gemmSub(Cij, nj, lval + lOff_[c0 + 1 + bi], nk, Lt.data() + ltOff[bj], nj, ni, nj, nk);
     }
   }
   return ok;
 }
 
 void BlockCholesky::solve(double* b) const {
+  const double* const lval = lbuf_.get();
   const int N = poff_[nb_];
   std::vector<double> y(N);
   for (int k = 0; k < nb_; ++k)
@@ -364,7 +374,7 @@ void BlockCholesky::solve(double* b) const {
     const int nk = psize_[k];
     if (nk == 0) continue;
     const int c0 = colPtr_[k], c1 = colPtr_[k + 1];
-    const double* Lkk = lval_.data() + lOff_[c0];
+    const double* Lkk = lval + lOff_[c0];
     double* yk = y.data() + poff_[k];
     for (int c = 0; c < nk; ++c) {
       double s = yk[c];
@@ -375,7 +385,7 @@ void BlockCholesky::solve(double* b) const {
     for (int e = c0 + 1; e < c1; ++e) {
       const int i = lRow_[e];
       const int ni = psize_[i];
-      const double* Lik = lval_.data() + lOff_[e];
+      const double* Lik = lval + lOff_[e];
       double* yi = y.data() + poff_[i];
       for (int a = 0; a < ni; ++a) {
         double s = 0.0;
@@ -394,7 +404,7 @@ void BlockCholesky::solve(double* b) const {
     for (int e = c0 + 1; e < c1; ++e) {
       const int i = lRow_[e];
       const int ni = psize_[i];
-      const double* Lik = lval_.data() + lOff_[e];
+      const double* Lik = lval + lOff_[e];
       const double* yi = y.data() + poff_[i];
       for (int a = 0; a < ni; ++a) {
         const double ya = yi[a];
@@ -402,7 +412,7 @@ void BlockCholesky::solve(double* b) const {
         for (int p = 0; p < nk; ++p) yk[p] -= La[p] * ya;
       }
     }
-    const double* Lkk = lval_.data() + lOff_[c0];
+    const double* Lkk = lval + lOff_[c0];
     for (int c = nk - 1; c >= 0; --c) {
       double s = yk[c];
       for (int p = c + 1; p < nk; ++p) s -= Lkk[static_cast<size_t>(p) * nk + c] * yk[p];

@@ -12,6 +12,8 @@
 #pragma once
 
 #include <cstddef>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace cvdo {
@@ -50,7 +52,7 @@ class BlockCholesky {
   // b <- (L L^T)^-1 b
   void solve(double* b) const;
   size_t numBlocks() const { return lRow_.size(); }
-  size_t numValues() const { return lval_.size(); }
+  size_t numValues() const { return lsize_; }
   double flops() const { return flops_; }
 
  private:
@@ -60,7 +62,8 @@ class BlockCholesky {
   std::vector<int> psize_, poff_;  // sizes / scalar offsets by position
   std::vector<int> colPtr_, lRow_; // L block column k: diagonal first, then rows ascending (positions)
   std::vector<size_t> lOff_;
-  std::vector<double> lval_;
+  std::unique_ptr<double[]> lbuf_;  // L's values (uninitialised until factor(): first touch happens in parallel)
+  size_t lsize_ = 0;
   double flops_ = 0.0;
   int findL(int i, int k) const;   // block index of L(i, k), i >= k, or -1
 };

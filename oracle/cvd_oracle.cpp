@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -1363,7 +1364,13 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
     for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(hd[i]));
   }
   BlockCholesky chol;
-  if (linearSolver == 0 && n > 0) chol.analyze(ev.H);
+  if (linearSolver == 0 && n > 0) {
+    const double ta = nowSeconds();
+    const double fl = chol.analyze(ev.H);
+    if (std::getenv("CVDO_VERBOSE"))
+      std::fprintf(stderr, "[oracle] finalize+first evaluation %.2f s, block Cholesky analysis %.2f s: %zu blocks, %.2f GB, %.3f Tflop per factorisation\n",
+                   ta - t0, nowSeconds() - ta, chol.numBlocks(), chol.numValues() * 8e-9, fl * 1e-12);
+  }
 
   double radius = D::initial_trust_region_radius;
   double decreaseFactor = 2.0;
@@ -2207,6 +2214,37 @@ int cvdo_set_robust_loss(void* h, int kind) {
     static_cast<Oracle*>(h)->robustLoss = kind;
   });
 }
+// Known-answer hook for the block-sparse Cholesky (tests/test_oracle_sparse.py): the symmetric positive definite matrix
+// `dense` (n x n row-major, n = sum sizes) restricted to the block structure {diagonal blocks} + pairs[2 * npairs] is
+// factorised and  (S A S + diag(extra)) x = b  solved in place (scale / extra may be NULL); y (may be NULL) receives
+// A b through the block-sparse product.  Returns -1 when a pivot fails, else the number of blocks of L incl. fill.
+int cvdo_block_sparse_solve(int nb, const int* sizes, int npairs, const int* pairs, const double* dense,
+                            const double* scale, const double* extra, double* b, double* y, int numThreads) {
+  try {
+    std::vector<int> sz(sizes, sizes + nb);
+    std::vector<std::pair<int, int>> pr;
+    for (int i = 0; i < npairs; ++i) pr.push_back({pairs[2 * i], pairs[2 * i + 1]});
+    cvdo::BlockSym A;
+    A.build(sz, pr);
+    const int n = A.n();
+    for (int I = 0; I < A.nb; ++I)
+      for (int e = A.rowPtr[I]; e < A.rowPtr[I + 1]; ++e) {
+        const int J = A.rowCol[e];
+        for (int a = 0; a < A.size(I); ++a)
+          for (int c = 0; c < A.size(J); ++c)
+            A.val[A.blkOff[e] + static_cast<size_t>(a) * A.size(J) + c] = dense[static_cast<size_t>(A.off[I] + a) * n + A.off[J] + c];
+      }
+    if (y) A.multiply(b, y);
+    cvdo::BlockCholesky ch;
+    ch.analyze(A);
+    if (!ch.factor(A, scale, extra, numThreads)) return -1;
+    ch.solve(b);
+    return static_cast<int>(ch.numBlocks());
+  } catch (const std::exception&) {
+    return -2;
+  }
+}
+
 int cvdo_set_linear_solver(void* h, int kind) {
   CVDO_TRY(h, {
     if (kind != 0 && kind != 1) throw std::runtime_error("linear solver must be 0 (block-sparse Cholesky) or 1 (dense Cholesky)");

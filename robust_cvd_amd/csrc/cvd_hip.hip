@@ -2619,7 +2619,7 @@ void cvd_opt_params_default(cvd_opt_params* p) {
 }
 
 void cvd_solver_options_default(cvd_solver_options* o) {
-  o->pcg_relative_tolerance = 1e-1;  // = ceres::Solver::Options::eta default (inexact-step forcing value)
+  o->pcg_relative_tolerance = 5e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
   o->pcg_max_iterations = 300;
   o->pcg_check_every = 4;
   o->verbose = 0;

@@ -264,10 +264,15 @@ def test_optimize_poses_sequence_on_gpu_matches_direct_c_abi(lib, tmp_path):
     s.pose_optimization(p)
     poses = s.get_poses()
     th = s.get_xform_params()
+    # Nothing pins the global rigid transform (SURVEY.md 7 "gauge freedom"): two solves of the same problem may drift
+    # apart along it by far more than their rounding differences, so poses are compared gauge-aligned; the depth
+    # transform parameters and the field of view are gauge invariant and compared directly.
+    pos = np.stack([np.asarray(ds.frame(f).extrinsics.position) for f in frames])
+    quat = np.stack([np.asarray(ds.frame(f).extrinsics.orientation.coeffs()) for f in frames])
+    perr, rerr = synth.relative_pose_error(pos, quat, poses["position"], poses["orientation"])
+    assert perr < 1e-4 and rerr < 1e-4, (perr, rerr, np.abs(pos - poses["position"]).max())
     for f in frames:
         fr = ds.frame(f)
-        np.testing.assert_allclose(fr.extrinsics.position, poses["position"][f], atol=2e-6)
-        np.testing.assert_allclose(fr.extrinsics.orientation.coeffs(), poses["orientation"][f], atol=2e-6)
         assert abs(fr.intrinsics.vFov - poses["vfov"][f]) < 1e-6
         np.testing.assert_allclose(fr.depthXform().params(), th[f], rtol=1e-5)
     # what loaders/video_dataset.py:update_poses reads afterwards
