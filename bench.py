@@ -83,6 +83,7 @@ def prepare(solver, video, params, pair_graph=None):
     from robust_cvd_amd import synth
     from robust_cvd_amd.ctypes_types import XformDesc
     import torch
+    params.max_iterations = 1000  # (reference default; run_iterations() caps it for the timed solves)
     t_up = time.perf_counter()
     synth.load_into(solver, video, params.focal_long)  # the boundary hands over HOST buffers: depth maps + constraints
     torch.cuda.synchronize()

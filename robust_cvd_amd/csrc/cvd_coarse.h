@@ -75,10 +75,16 @@ struct CoarsePlan {
 // Off-diagonal coarse blocks: C_e[i][j] = sum over the constraints between frames (fa, fb), both directions,
 // of rho' * sum_r (J_fa Z)[r][i] (J_fb Z)[r][j].  One workgroup per work item (k_matvec_pairs' decomposition).
 // ---------------------------------------------------------------------------------------------------------
+// A work item whose frame pair was left out of the (sparsified) coarse graph -- itemEdge[item] < 0, see
+// sparsifyCoarseGraph in cvd_hip.hip -- contributes nothing to the coarse matrix: instead of the cross block its two
+// DIAGONAL contributions sum rho' (J_f Z)^T (J_f Z), f = fa and f = fb, are accumulated into dropDiag[f], which
+// k_coarse_diag subtracts from Z^T H_ff Z.  The coarse matrix is then the Galerkin operator of the kept constraints
+// (+ regularisers + damping): still SPD, and consistent on the smooth inter-frame modes it exists for.
 template <int KD, int KS>
 __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items it, const double* __restrict__ x,
                                                       const FrameConst* __restrict__ fc,
-                                                      const int* __restrict__ itemEdge, double* __restrict__ edgeOut) {
+                                                      const int* __restrict__ itemEdge, double* __restrict__ edgeOut,
+                                                      double* __restrict__ dropDiag) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
   double* xa = sm;
@@ -99,16 +105,23 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
   }
   if (tid < kCBB) Cs[tid] = 0.0;
   __syncthreads();
+  const bool haveScale = L.N >= 1;
+  const int edge = itemEdge[item];
+  // kept pair: one pass, the cross block (mode 0); dropped pair: two passes, the self blocks of fa (1) and fb (2)
+  for (int mode = (edge >= 0 ? 0 : 1); mode <= (edge >= 0 ? 0 : 2); ++mode) {
   double Cacc[kCBB];  // rows: modes of fa, columns: modes of fb
 #pragma unroll
   for (int i = 0; i < kCBB; ++i) Cacc[i] = 0.0;
-  const bool haveScale = L.N >= 1;
   for (int dir = 0; dir < 2; ++dir) {
     const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
     const FrameConst& Fs = fcs[dir];
     const FrameConst& Ft = fcs[dir ^ 1];
     const double* xs = dir ? xb : xa;
     const double* xt = dir ? xa : xb;
+    // rows take the Jacobian of fa's side (mode 0, 1) or fb's (mode 2); columns fb's (mode 0, 2) or fa's (mode 1);
+    // fa is the source side of direction 0 and the target side of direction 1
+    const bool rowIsSrc = (mode == 2) ? (dir == 1) : (dir == 0);
+    const bool colIsSrc = (mode == 1) ? (dir == 0) : (dir == 1);
     for (long long c = cb + tid; c < ce; c += 256) {
       const float2 d = T.dsrc[c];
       if (!(d.x > 0.f)) continue;
@@ -116,40 +129,40 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
       evalSample<KD, KS, true>(L, Fs, Ft, xs, xt, T.ndc[c], d, s);
       // Z-projected Jacobians of the two sides: 7 pose columns + the uniform depth-scale column
       // (d r / d scale_k = JD w_k d_src and the interpolation weights sum to one)
-      double Js[3][kCB], Jt[3][kCB];
+      double Jr[3][kCB], Jc[3][kCB];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { Js[r][i] = s.a.Jp[r][i]; Jt[r][i] = s.b.Jp[r][i]; }
-        Js[r][7] = haveScale ? s.a.JD[r] * s.a.d : 0.0;
-        Jt[r][7] = haveScale ? s.b.JD[r] * s.b.d : 0.0;
+        for (int i = 0; i < 7; ++i) {
+          Jr[r][i] = rowIsSrc ? s.a.Jp[r][i] : s.b.Jp[r][i];
+          Jc[r][i] = colIsSrc ? s.a.Jp[r][i] : s.b.Jp[r][i];
+        }
+        const double js = haveScale ? s.a.JD[r] * s.a.d : 0.0, jt = haveScale ? s.b.JD[r] * s.b.d : 0.0;
+        Jr[r][7] = rowIsSrc ? js : jt;
+        Jc[r][7] = colIsSrc ? js : jt;
       }
       const double w = s.rho1;
-      if (dir == 0) {
 #pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-          const double a0 = w * Js[0][i], a1 = w * Js[1][i], a2 = w * Js[2][i];
+      for (int i = 0; i < kCB; ++i) {
+        const double a0 = w * Jr[0][i], a1 = w * Jr[1][i], a2 = w * Jr[2][i];
 #pragma unroll
-          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Jt[0][j] + a1 * Jt[1][j] + a2 * Jt[2][j];
-        }
-      } else {  // source = fb, target = fa: rows (fa) take the target side
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-          const double a0 = w * Jt[0][i], a1 = w * Jt[1][i], a2 = w * Jt[2][i];
-#pragma unroll
-          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Js[0][j] + a1 * Js[1][j] + a2 * Js[2][j];
-        }
+        for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Jc[0][j] + a1 * Jc[1][j] + a2 * Jc[2][j];
       }
     }
   }
+  if (tid < kCBB) Cs[tid] = 0.0;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < kCBB; ++i) {
     const double v = waveSum(Cacc[i]);
     if ((tid & 63) == 0) atomicAdd(&Cs[i], v);
   }
   __syncthreads();
-  // several chunk items may share one frame pair: the edge block is zeroed by the host before the launch
-  if (tid < kCBB) atomicAdd(&edgeOut[static_cast<size_t>(itemEdge[item]) * kCBB + tid], Cs[tid]);
+  // several chunk items may share one frame pair: the outputs are zeroed by the host before the launch
+  double* out = mode == 0 ? edgeOut + static_cast<size_t>(edge) * kCBB : dropDiag + static_cast<size_t>(mode == 1 ? fa : fb) * kCBB;
+  if (tid < kCBB) atomicAdd(&out[tid], Cs[tid]);
+  __syncthreads();
+  }  // mode
 }
 
 // Fast path of k_coarse_edges (scope of the fast kernels: identity spatial transform, reprojection losses, per-frame
@@ -159,7 +172,8 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
 template <int KD>
 __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
-                                                           const int* __restrict__ itemEdge, double* __restrict__ edgeOut) {
+                                                           const int* __restrict__ itemEdge, double* __restrict__ edgeOut,
+                                                           double* __restrict__ dropDiag) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr double eps = 1e-6;
   const int B = L.B;
@@ -181,13 +195,18 @@ __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, It
   }
   if (tid < kCBB) Cs[tid] = 0.0;
   __syncthreads();
-  double Cacc[kCBB];  // rows: modes of fa, columns: modes of fb
-#pragma unroll
-  for (int i = 0; i < kCBB; ++i) Cacc[i] = 0.0;
   const int N = L.N;
   const double A = L.aspect;
   const bool haveScale = N >= 1;
+  const int edge = itemEdge[item];
+  // kept pair: one pass, the cross block (mode 0); dropped pair (see k_coarse_edges): the self blocks of fa (1), fb (2)
+  for (int mode = (edge >= 0 ? 0 : 1); mode <= (edge >= 0 ? 0 : 2); ++mode) {
+  double Cacc[kCBB];  // rows: modes of fa, columns: modes of fb
+#pragma unroll
+  for (int i = 0; i < kCBB; ++i) Cacc[i] = 0.0;
   for (int dir = 0; dir < 2; ++dir) {
+    const bool rowIsSrc = (mode == 2) ? (dir == 1) : (dir == 0);
+    const bool colIsSrc = (mode == 1) ? (dir == 0) : (dir == 1);
     const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
     const FrameConst& Fa = fcs[dir];      // source frame of this direction
     const FrameConst& Fb = fcs[dir ^ 1];  // target frame
@@ -314,31 +333,31 @@ __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, It
         Jt[1][7] = 0.0;
         Jt[2][7] = haveScale ? dr2dDb * db : 0.0;
       }
-      if (dir == 0) {
+      // (uniform selects: rows take fa's side, columns fb's for the cross block; fa is the source side of direction 0)
 #pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-          const double a0 = w * Js[0][i], a1 = w * Js[1][i], a2 = w * Js[2][i];
+      for (int i = 0; i < kCB; ++i) {
+        const double a0 = w * (rowIsSrc ? Js[0][i] : Jt[0][i]), a1 = w * (rowIsSrc ? Js[1][i] : Jt[1][i]),
+                     a2 = w * (rowIsSrc ? Js[2][i] : Jt[2][i]);
 #pragma unroll
-          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Jt[0][j] + a1 * Jt[1][j] + a2 * Jt[2][j];
-        }
-      } else {  // source = fb, target = fa: rows (fa) take the target side
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-          const double a0 = w * Jt[0][i], a1 = w * Jt[1][i], a2 = w * Jt[2][i];
-#pragma unroll
-          for (int j = 0; j < kCB; ++j) Cacc[i * kCB + j] += a0 * Js[0][j] + a1 * Js[1][j] + a2 * Js[2][j];
-        }
+        for (int j = 0; j < kCB; ++j)
+          Cacc[i * kCB + j] += a0 * (colIsSrc ? Js[0][j] : Jt[0][j]) + a1 * (colIsSrc ? Js[1][j] : Jt[1][j]) +
+                               a2 * (colIsSrc ? Js[2][j] : Jt[2][j]);
       }
     }
   }
+  if (tid < kCBB) Cs[tid] = 0.0;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < kCBB; ++i) {
     const double v = waveSum(Cacc[i]);
     if ((tid & 63) == 0) atomicAdd(&Cs[i], v);
   }
   __syncthreads();
-  // several chunk items may share one frame pair: the edge block is zeroed by the host before the launch
-  if (tid < kCBB) atomicAdd(&edgeOut[static_cast<size_t>(itemEdge[item]) * kCBB + tid], Cs[tid]);
+  // several chunk items may share one frame pair: the outputs are zeroed by the host before the launch
+  double* out = mode == 0 ? edgeOut + static_cast<size_t>(edge) * kCBB : dropDiag + static_cast<size_t>(mode == 1 ? fa : fb) * kCBB;
+  if (tid < kCBB) atomicAdd(&out[tid], Cs[tid]);
+  __syncthreads();
+  }  // mode
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, It
 __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __restrict__ hBlocks,
                                                      const double* __restrict__ lam, const double* __restrict__ mask,
                                                      double* __restrict__ diagOut, unsigned char* __restrict__ modeActive,
-                                                     double lamScale) {
+                                                     double lamScale, const double* __restrict__ dropDiag) {
   __shared__ double u[264];  // u[r] = sum over scale vertices v of H[r][v] (+ lam on the diagonal)
   __shared__ double red[4];
   __shared__ int anyScale;
@@ -386,6 +405,7 @@ __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __r
     else if (i < 7) v = u[i];
     else if (j < 7) v = u[j];
     else v = red[0] + red[1] + red[2] + red[3];
+    if (dropDiag != nullptr) v -= dropDiag[static_cast<size_t>(f) * kCBB + tid];  // pairs left out of the coarse graph
     const bool ai = active(i), aj = active(j);
     if (!(ai && aj)) v = (i == j) ? 1.0 : 0.0;
     diagOut[static_cast<size_t>(f) * kCBB + tid] = v;

@@ -58,7 +58,10 @@ struct Layout {
 // cvd enums duplicated as plain ints to keep this header free of host headers.
 enum : int { kDepthIdentity = 1, kDepthGlobal = 2, kDepthGrid = 3 };
 enum : int { kSpIdentity = 1, kSpVertical = 2, kSpCorners = 3, kSpBilinear = 4, kSpBicubic = 5 };
-enum : int { kLossEuclid = 0, kLossDisparity = 1, kLossRatio = 2, kLossLog = 3 };
+enum : int { kLossEuclid = 0, kLossDisparity = 1, kLossRatio = 2, kLossLog = 3,
+             // not a StaticLossType: DisparityDissimilarityCost of normalizeDepth's pair loop (reference
+             // lib/PoseOptimizer.cpp:425-462, 1014-1105): ONE residual 1/max(D_a, eps) - 1/max(D_b, eps), depth blocks only
+             kLossNormalizeDisparity = 4 };
 enum : int { kIntrFixed = 0, kIntrShared = 1, kIntrPerFrame = 2 };
 enum : int { kRobustCauchy = 0, kRobustHuber = 1 };
 
@@ -373,6 +376,27 @@ __device__ __forceinline__ void evalSample(const Layout& L, const FrameConst& fa
       pb[0] += phb[s.b.st.idx[k] * 2] * s.b.st.w[k];
       pb[1] += phb[s.b.st.idx[k] * 2 + 1] * s.b.st.w[k];
     }
+  }
+  if (L.lossType == kLossNormalizeDisparity) {
+    // DisparityDissimilarityCost: the poses and the spatial transforms take no part (Jet max(f, g): ties keep f)
+    const bool ao = !(Da < eps), bo = !(Db < eps);
+    const double aa = ao ? Da : eps, bb = bo ? Db : eps;
+    s.r[0] = 1.0 / aa - 1.0 / bb;
+    s.r[1] = 0.0;
+    s.r[2] = 0.0;
+    robustRho(L, s.r[0] * s.r[0], s.rho0, s.rho1);
+    if constexpr (WANT_JAC) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { s.a.Jp[r][c] = 0.0; s.b.Jp[r][c] = 0.0; }
+        s.a.JD[r] = 0.0; s.b.JD[r] = 0.0;
+        s.a.JP[r][0] = 0.0; s.a.JP[r][1] = 0.0; s.b.JP[r][0] = 0.0; s.b.JP[r][1] = 0.0;
+      }
+      s.a.JD[0] = ao ? -1.0 / (aa * aa) : 0.0;
+      s.b.JD[0] = bo ? 1.0 / (bb * bb) : 0.0;
+    }
+    return;
   }
   const double A = L.aspect;
   const double fya = fa.fy, fxa = fa.fy * A;

@@ -308,6 +308,7 @@ struct cvd_handle_t {
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
   bool tableValid = false;
+  bool tableIgnoresStatic = false;  // compiled for normalizeDepth's pair loop (every constraint, dynamic ones included)
   long long numValid = 0;
 
   // state
@@ -346,7 +347,8 @@ struct cvd_handle_t {
     std::vector<int> itemEdge;
     DevBuf<int> order, pos, levelPtr, levelCols, lvlBlkPtr, lvlBlks, blkCol, blkRow, colPtr, rowPtr, rowBlk, updPtr, updBlk,
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
-    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq;
+    DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq, dropDiag;
+    bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
@@ -590,9 +592,6 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && kind == PK_POSE_STEP) {
     if (p.smooth_loss_type < CVD_SMOOTH_EUCLIDEAN_LAPLACIAN || p.smooth_loss_type > CVD_SMOOTH_REPRO_LOG_DEPTH_CONSISTENCY)
       throw std::runtime_error("Invalid loss type.");
-    if (p.intr_opt == CVD_INTR_SHARED)
-      throw std::runtime_error("Scene-flow smoothness with IntrinsicsOptimization::Shared is not implemented on the "
-                               "device path.");
     if (!h->haveTriplets) throw std::runtime_error("Missing triplet constraints.");
   }
   Layout L{};
@@ -636,11 +635,13 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
     L.depthDeformW = depthDeformReg > 0.0 ? depthDeformReg : 0.0;
     L.spatialDeformW = p.spatial_deform_reg > 0.0 ? p.spatial_deform_reg : 0.0;
   } else {
-    if (!p.normalize_depth_from_first_frame)
-      throw std::runtime_error(
-          "normalizeDepth with normalizeDepthFromFirstFrame=false is not implemented on the device path "
-          "(the flag is not reachable from the reference's Python bindings).");
-    L.includeStatic = 0;
+    // normalizeDepthFromFirstFrame (default): no pairs at all (reference lib/PoseOptimizer.cpp:1014-1018); otherwise the
+    // pair loop of :1020-1105: one DisparityDissimilarityCost with CauchyLoss(robustness) per constraint
+    L.includeStatic = p.normalize_depth_from_first_frame ? 0 : 1;
+    if (L.includeStatic) {
+      L.lossType = kLossNormalizeDisparity;
+      L.robustKind = kRobustCauchy;  // (the reference hard-wires CauchyLoss here, :1080)
+    }
     L.scaleRegSqrt = p.scale_reg > 0.0 ? std::sqrt(p.scale_reg) : 0.0;
     L.focalRegSqrt = 0.0;
     L.depthDeformW = p.depth_deform_reg_initial > 0.0 ? p.depth_deform_reg_initial : 0.0;
@@ -678,6 +679,16 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   return L;
 }
 
+// The per-frame kernels of the solve (k_matvec_finish, k_cg_update, the block inverse, the fast pairs product) hold one
+// frame block per workgroup with at most 256 unknowns.  Checked BEFORE any work or state mutation (a coarse-to-fine
+// schedule would otherwise fail at its last level with the transforms already refined).
+constexpr int kMaxFrameBlock = 256;
+static void checkFrameBlock(size_t B, const char* what) {
+  if (B > static_cast<size_t>(kMaxFrameBlock))
+    throw std::runtime_error(fmt("%s: %zu unknowns per frame (7 + depth-transform + spatial-transform parameters) exceed the "
+                                 "%d this build supports", what, B, kMaxFrameBlock));
+}
+
 static void tapCounts(const Layout& L, int& KD, int& KS) {
   KD = (L.depthType == CVD_DEPTH_GRID) ? (L.cubic ? 16 : 4) : 1;
   switch (L.spatialType) {
@@ -685,6 +696,11 @@ static void tapCounts(const Layout& L, int& KD, int& KS) {
     case CVD_SPATIAL_BICUBIC_GRID: KS = 16; break;
     default: KS = 4;
   }
+}
+
+// Scope of the specialised fast kernels: identity spatial transform and the three reprojection losses.
+static bool fastLoss(const Layout& L) {
+  return L.lossType == CVD_STATIC_REPRO_DISPARITY || L.lossType == CVD_STATIC_REPRO_DEPTH_RATIO || L.lossType == CVD_STATIC_REPRO_LOG_DEPTH;
 }
 
 #define CVD_DISPATCH(KDv, KSv, ...)                                             \
@@ -708,6 +724,28 @@ static void tapCounts(const Layout& L, int& KD, int& KS) {
   } while (0)
 
 constexpr size_t kMaxLds = 160 * 1024;
+
+// Row panels of the packed lower triangle of a B x B frame block that fit `capDoubles` of LDS each (AsmPanels,
+// cvd_kernels.h): one panel up to B = 199, two at the reference's default deferred-spatial block B = 201.
+static AsmPanels makePanels(int B, size_t capDoubles, int& panelCap) {
+  AsmPanels P{};
+  P.n = 0;
+  P.row[0] = 0;
+  size_t biggest = 0;
+  int r0 = 0;
+  while (r0 < B) {
+    if (P.n >= 8) throw std::runtime_error(fmt("frame block of %d unknowns is too large for the assembly kernels", B));
+    const size_t base = static_cast<size_t>(r0) * (r0 + 1) / 2;
+    int r1 = r0;
+    while (r1 < B && static_cast<size_t>(r1 + 1) * (r1 + 2) / 2 - base <= capDoubles) ++r1;
+    if (r1 < std::max(r0 + 1, 7) && r1 < B) throw std::runtime_error("LDS panel too small for the assembly kernels");
+    biggest = std::max(biggest, static_cast<size_t>(r1) * (r1 + 1) / 2 - base);
+    P.row[++P.n] = r1;
+    r0 = r1;
+  }
+  panelCap = static_cast<int>(biggest);
+  return P;
+}
 
 template <typename K>
 static void allowLds(K kernel, size_t bytes) {
@@ -927,6 +965,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   const size_t n = static_cast<size_t>(F) * kCB;
   C.edges.ensure(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
   C.diag.ensure(static_cast<size_t>(F) * kCBB);
+  C.dropDiag.ensure(static_cast<size_t>(F) * kCBB);
   C.Lb.ensure(static_cast<size_t>(nBlocks) * kCBB);
   C.Linv.ensure(static_cast<size_t>(F) * kCBB);
   C.Wb.ensure(static_cast<size_t>(nW) * kCBB);
@@ -949,11 +988,56 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.valid = true;
 }
 
+// ---- coarse graph sparsification ---------------------------------------------------------------------------
+// The coarse factorisation is sparse-direct on the frame graph: its cost follows the FILL of that graph.  The reference
+// sampler's hierarchical list (utils/frame_sampling.py:77-120: distance 2^l from every 2^(l-1)-th frame) eliminates with
+// ~10 k block updates at 300 frames; the densified "~4k pairs" list of BASELINE.json (long-range pairs from nearly every
+// frame) needs ~10^6 and a 44 ms factorisation per rebuild.  The coarse level is only a preconditioner, so it may be built
+// on a SUBGRAPH: when the full graph's elimination exceeds a budget, a pair {a, b} at distance d stays in the coarse graph
+// iff both frames are multiples of s(d) = the largest power of two <= d / 8 (>= 1) -- a nested, multi-scale subgraph,
+// sparse for any flow list.  Dropped pairs are removed from the coarse operator altogether (k_coarse_edges: dropDiag),
+// which keeps it the Galerkin operator of a sub-problem: SPD and consistent on the smooth drift modes.  Measured on the
+// 4140-pair list (ms per LM iteration at the final level / PCG iterations per LM iteration): full graph 30.0 / 36
+// (44 ms per factorisation), s(d) <= d/2 (the reference sampler's own 883-edge skeleton) 16.9 / 123, d/4 12.9 / 88,
+// d/8 10.8 / 64, d/16 11.7 / 47.
+static long long coarseEliminationUpdates(int F, const std::vector<std::pair<int, int>>& edgeList) {
+  std::vector<std::set<int>> g(F);
+  for (const auto& e : edgeList) { g[e.first].insert(e.second); g[e.second].insert(e.first); }
+  std::set<std::pair<int, int>> queue;
+  for (int v = 0; v < F; ++v) queue.insert({static_cast<int>(g[v].size()), v});
+  long long updates = 0;
+  while (!queue.empty()) {
+    const int v = queue.begin()->second;
+    queue.erase(queue.begin());
+    const std::vector<int> nb(g[v].begin(), g[v].end());
+    const long long sN = static_cast<long long>(nb.size());
+    updates += sN * (sN + 1) / 2;
+    if (updates > (1ll << 40)) break;
+    for (int a : nb) queue.erase({static_cast<int>(g[a].size()), a});
+    for (int a : nb) {
+      g[a].erase(v);
+      for (int b : nb)
+        if (a != b) g[a].insert(b);
+    }
+    for (int a : nb) queue.insert({static_cast<int>(g[a].size()), a});
+    g[v].clear();
+  }
+  return updates;
+}
+static bool coarseKeepsPair(int a, int b) {
+  static const int shift = []() { const char* e = std::getenv("CVD_COARSE_KEEP_SHIFT"); return e ? std::atoi(e) : 3; }();  // development knob
+  const int d = std::abs(a - b);
+  int s2 = 1;
+  while (s2 * 2 <= (d >> shift)) s2 *= 2;
+  return (a % s2) == 0 && (b % s2) == 0;
+}
+
 // ---- compile the constraint table + work decomposition for a frame range -------------------------------
-static void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplets = false) {
+static void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplets = false, bool ignoreStatic = false) {
   std::vector<unsigned char> inRange(h->F, 0);
   for (int f : range) inRange[f] = 1;
-  if (h->tableValid && inRange == h->tableRange && withTriplets == h->tableWithTriplets) return;
+  if (h->tableValid && inRange == h->tableRange && withTriplets == h->tableWithTriplets && ignoreStatic == h->tableIgnoresStatic) return;
+  h->tableIgnoresStatic = ignoreStatic;
   hipStream_t s = h->stream;
   h->dInRange.upload(inRange.data(), inRange.size(), s);
   {
@@ -970,7 +1054,7 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     const unsigned grid = static_cast<unsigned>((h->C + bs - 1) / bs);
     hipLaunchKernelGGL(k_build_table, dim3(grid), dim3(bs), 0, s, h->W, h->H, h->invAspect, h->C, h->dLoc.p,
                        h->dStatic.p, h->dCPair.p, h->dPairA.p, h->dPairB.p, h->dInRange.p, h->dDepth.p,
-                       h->dNdc.p, h->dDsrc.p, h->dCount.p);
+                       h->dNdc.p, h->dDsrc.p, h->dCount.p, ignoreStatic ? 1 : 0);
     HIP_CHECK(hipGetLastError());
   }
   if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dCount.p, h->dCount.p, 1, ncclUint64, ncclSum, h->comm, s));
@@ -1086,6 +1170,22 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
         edgeList.push_back(key);
       }
       itemEdge[i] = it->second;
+    }
+    // sparsify the coarse graph when its elimination is too expensive (a function of the whole problem's pair graph
+    // only: identical on all ranks of a sharded run)
+    static const long long updateBudget = []() { const char* e = std::getenv("CVD_COARSE_UPDATE_BUDGET"); return e ? std::atoll(e) : 40000ll; }();
+    h->coarse.sparsified = false;
+    if (coarseEliminationUpdates(h->F, edgeList) > updateBudget) {
+      std::vector<int> newId(edgeList.size(), -1);
+      std::vector<std::pair<int, int>> kept;
+      for (size_t e = 0; e < edgeList.size(); ++e)
+        if (coarseKeepsPair(edgeList[e].first, edgeList[e].second)) {
+          newId[e] = static_cast<int>(kept.size());
+          kept.push_back(edgeList[e]);
+        }
+      for (auto& ie : itemEdge) ie = newId[ie];
+      h->coarse.sparsified = kept.size() != edgeList.size();
+      edgeList.swap(kept);
     }
     buildCoarsePlan(h, edgeList, itemEdge);
   }
@@ -1314,7 +1414,7 @@ static void enqueueCost(Ctx& c, const double* x) {
   const int slot = h->tBegin(KC_COST);
   if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = (2 * c.L.B) * 8 + 2 * sizeof(FrameConst) + 8 * 8;
-    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;  // (scope of the fast kernels)
+    const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);  // (scope of the fast kernels)
     if (fast) {
       CVD_DISPATCH_KD(c.KD, {
         allowLds(k_cost_items_fast<KD>, lds);
@@ -1372,10 +1472,13 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   launchFrameConsts(c, x);
   const size_t B = c.L.B;
   const int slot = h->tBegin(KC_ASSEMBLE);
-  const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;
+  const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);
   const size_t ldsFast = (B * (B + 1) / 2 + 2 * B + 4 * 36) * 8;
-  const size_t lds = (B * (B + 1) / 2 + 3 * B) * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
-  if (fast) {
+  // generic kernel: the packed triangle in row panels when it does not fit the LDS in one piece (B > 199)
+  const size_t ldsRest = 3 * B * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
+  int panelCap = 0;
+  const bool fastFits = ldsFast <= kMaxLds;
+  if (fast && fastFits) {
     h->dAsmScratch.ensure(static_cast<size_t>(h->nAsmSlots) * (B * (B + 1) / 2 + B + 4));
     const AsmWork work{h->dAsmParts.p, h->dAsmUnits.p, h->dAsmScratch.p, h->dAsmCount.p};
     CVD_DISPATCH_KD(c.KD, {
@@ -1385,27 +1488,34 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
                          h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
     });
   } else {
+    const AsmPanels panels = makePanels(static_cast<int>(B), (kMaxLds - ldsRest) / 8, panelCap);
+    const size_t lds = static_cast<size_t>(panelCap) * 8 + ldsRest;
     CVD_DISPATCH(c.KD, c.KS, {
       allowLds(k_assemble<KD, KS>, lds);
       hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
-                       h->dFocal.p, h->dFocal.p + c.L.F);
+                       h->dFocal.p, h->dFocal.p + c.L.F, panels, panelCap);
     });
   }
-  if (c.L.intrOpt == CVD_INTR_SHARED)
-    hipLaunchKernelGGL(k_shared_focal_fixup, dim3(1), dim3(256), 0, s, c.L, h->dFocal.p, h->dFocal.p + c.L.F, h->dMask.p,
-                       h->dG.p, h->dH.p);
   HIP_CHECK(hipGetLastError());
   if (c.trip && c.TT.nGroups > 0) {
     // scene-flow smoothness: its share of g / H_ff is added to the pair assembly's output, its cost to the frame sums
-    const size_t ldsT = (B * (B + 1) / 2 + B) * 8;
+    int panelCapT = 0;
+    const AsmPanels panelsT = makePanels(static_cast<int>(B), (kMaxLds - B * 8 - 256) / 8, panelCapT);
+    const size_t ldsT = (static_cast<size_t>(panelCapT) + B) * 8;
     CVD_DISPATCH(c.KD, c.KS, {
       allowLds(k_assemble_triplets<KD, KS>, ldsT);
       hipLaunchKernelGGL((k_assemble_triplets<KD, KS>), dim3(c.L.F), dim3(256), ldsT, s, c.L, c.TT, x, h->dFc.p,
-                         h->dMask.p, h->dFtOff.p, h->dFtList.p, h->dG.p, h->dH.p);
+                         h->dMask.p, h->dFtOff.p, h->dFtList.p, h->dG.p, h->dH.p, h->dFocal.p, h->dFocal.p + c.L.F,
+                         panelsT, panelCapT);
       hipLaunchKernelGGL((k_cost_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), 0, s, c.L, c.TT, x, h->dFc.p,
                          h->dCostFrame.p);
     });
+    HIP_CHECK(hipGetLastError());
+  }
+  if (c.L.intrOpt == CVD_INTR_SHARED) {  // (after the triplet assembly: it adds its share of the focal sums)
+    hipLaunchKernelGGL(k_shared_focal_fixup, dim3(1), dim3(256), 0, s, c.L, h->dFocal.p, h->dFocal.p + c.L.F, h->dMask.p,
+                       h->dG.p, h->dH.p);
     HIP_CHECK(hipGetLastError());
   }
   h->tEnd(slot);
@@ -1475,7 +1585,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
-    const bool fast = !h->forceGeneric && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN;
+    const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);
     // (plain launches unless the launch is timed: hipExtLaunchKernelGGL is not used inside a graph capture)
     const FrameConst* fcp = h->dFc.p;
     const double* maskp = h->dMask.p;
@@ -1533,7 +1643,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.nItems, h->regCache, cF,
+                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, h->qRows, h->regCache, cF,
                          (withCoarse && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
     });
     HIP_CHECK(hipGetLastError());
@@ -1629,34 +1739,38 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
     // factor is rebuilt on demand, not at every accepted step)
     hipLaunchKernelGGL(k_frame_consts, dim3((c.L.F + 63) / 64), dim3(64), 0, s, c.L, x, fcBuf);
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
+    if (C.sparsified) HIP_CHECK(hipMemsetAsync(C.dropDiag.p, 0, static_cast<size_t>(c.L.F) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
     if (c.nItems > 0) {
       static const bool genericEdges = std::getenv("CVD_COARSE_EDGES_GENERIC") != nullptr;  // comparison knob
-      const bool fast = !h->forceGeneric && !genericEdges && c.KS == 0 && c.L.lossType != CVD_STATIC_EUCLIDEAN &&
+      const bool fast = !h->forceGeneric && !genericEdges && c.KS == 0 && fastLoss(c.L) &&
                         c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
       if (fast) {
         CVD_DISPATCH_KD(c.KD, {
           allowLds(k_coarse_edges_fast<KD>, ldsE);
           hipLaunchKernelGGL((k_coarse_edges_fast<KD>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
-                             C.itemEdgeDev.p, C.edges.p);
+                             C.itemEdgeDev.p, C.edges.p, C.dropDiag.p);
         });
       } else {
         CVD_DISPATCH(c.KD, c.KS, {
           allowLds(k_coarse_edges<KD, KS>, ldsE);
           hipLaunchKernelGGL((k_coarse_edges<KD, KS>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
-                             C.itemEdgeDev.p, C.edges.p);
+                             C.itemEdgeDev.p, C.edges.p, C.dropDiag.p);
         });
       }
     }
     HIP_CHECK(hipGetLastError());
-    if (h->dist())
+    if (h->dist()) {
       NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
+      if (C.sparsified)
+        NCCL_CHECK(ncclAllReduce(C.dropDiag.p, C.dropDiag.p, static_cast<size_t>(c.L.F) * kCBB, ncclDouble, ncclSum, h->comm, s));
+    }
   }
   // (side stream: the factor will serve the NEXT iteration, whose damping is most likely a third of this one's --
   // the trust region triples after a good step)
   static const double lamPredict = []() { const char* e = std::getenv("CVD_COARSE_LAM_PREDICT"); return e ? std::atof(e) : 1.0 / 3.0; }();
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
-                     C.modeActive.p, side ? lamPredict : 1.0);
+                     C.modeActive.p, side ? lamPredict : 1.0, C.sparsified ? C.dropDiag.p : nullptr);
   static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
   if (singleWg) {
     hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
@@ -1843,8 +1957,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   Ctx c;
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, kind);
+  checkFrameBlock(static_cast<size_t>(c.L.B), "solve");
   tapCounts(c.L, c.KD, c.KS);
-  compileTable(h, range, wantsTriplets(p, kind));
+  compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
   refreshMedians(h);
   c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
   c.nItems = static_cast<int>(h->itemFa.size());
@@ -1852,7 +1967,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   bindTriplets(c, p, kind);
-  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric;
+  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
+                kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
   buildMask(h, c.L, p, kind, range);
   uploadState(h, c.L, h->dX);
@@ -2111,6 +2227,14 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
   int initGrid[3] = {1, 1, 1};
   if (h->ddesc.depth_type == CVD_DEPTH_GRID)
     for (int i = 0; i < 3; ++i) initGrid[i] = h->ddesc.grid_size[i];
+  // largest frame block of the schedule: validated before any state changes, then used to reserve the device buffers
+  const int Nval = (h->ddesc.depth_type == CVD_DEPTH_IDENTITY) ? 0 : valueNumParams(h->ddesc.value_xform);
+  size_t nDmax = static_cast<size_t>(h->nD());
+  if (p.coarse_to_fine && h->ddesc.depth_type != CVD_DEPTH_IDENTITY && p.num_steps > 1)
+    nDmax = std::max(nDmax, static_cast<size_t>(ctfCols) * ctfRows * initGrid[2] * Nval);
+  size_t nSmax = p.deferred_spatial_opt ? static_cast<size_t>(dsoRows) * dsoCols * 2 : static_cast<size_t>(h->nS());
+  const size_t Bmax = 7 + nDmax + nSmax;
+  checkFrameBlock(Bmax, "poseOptimization (largest level of the coarse-to-fine / deferred-spatial schedule)");
   if (p.deferred_spatial_opt) {
     cvd_xform_desc sd{};
     sd.type = CVD_XFORM_SPATIAL;
@@ -2120,13 +2244,6 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
   {
     // Reserve the device buffers for the largest block of the schedule up front: growing them level by level
     // costs a hipFree + hipMalloc (milliseconds, with a device synchronisation) per buffer and level.
-    const int N = (h->ddesc.depth_type == CVD_DEPTH_IDENTITY) ? 0 : valueNumParams(h->ddesc.value_xform);
-    size_t nDmax = static_cast<size_t>(h->nD());
-    if (p.coarse_to_fine && h->ddesc.depth_type != CVD_DEPTH_IDENTITY)
-      nDmax = std::max(nDmax, static_cast<size_t>(ctfCols) * ctfRows * initGrid[2] * N);
-    size_t nSmax = static_cast<size_t>(h->nS());
-    if (p.deferred_spatial_opt) nSmax = std::max(nSmax, static_cast<size_t>(dsoRows) * dsoCols * 2);
-    const size_t Bmax = 7 + nDmax + nSmax;
     const size_t n = static_cast<size_t>(h->F) * Bmax;
     h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
     h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);

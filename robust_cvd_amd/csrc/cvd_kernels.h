@@ -119,7 +119,9 @@ __global__ void k_build_table(int W, int H, float invAspect, long long C, const 
                               const int* __restrict__ pairA, const int* __restrict__ pairB,
                               const unsigned char* __restrict__ inRange, const float* __restrict__ depth,
                               float4* __restrict__ ndc, float2* __restrict__ dsrc,
-                              unsigned long long* __restrict__ nValid) {
+                              unsigned long long* __restrict__ nValid, int ignoreStatic) {
+  // ignoreStatic: normalizeDepth's pair loop takes every constraint, dynamic ones included (reference
+  // lib/PoseOptimizer.cpp:1036-1052 never looks at isStatic)
   const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   bool ok = false;
   if (c < C) {
@@ -140,7 +142,7 @@ __global__ void k_build_table(int W, int H, float invAspect, long long C, const 
     const size_t fs = static_cast<size_t>(W) * H;
     float da = depth[fa * fs + static_cast<size_t>(ay) * W + ax];
     float db = depth[fb * fs + static_cast<size_t>(by) * W + bx];
-    ok = isStatic[c] && inRange[fa] && inRange[fb] && isfinite(da) && da > 0.f && isfinite(db) && db > 0.f;
+    ok = (ignoreStatic || isStatic[c]) && inRange[fa] && inRange[fb] && isfinite(da) && da > 0.f && isfinite(db) && db > 0.f;
     if (!ok) { da = 0.f; db = 0.f; }
     ndc[c] = n;
     dsrc[c] = make_float2(da, db);
@@ -259,6 +261,15 @@ __device__ __forceinline__ int packedIdx(int i, int j) {  // i >= j
   return i * (i + 1) / 2 + j;
 }
 
+// Row panels of the packed lower triangle for k_assemble / k_assemble_triplets: the triangle of a frame block
+// (B (B + 1) / 2 doubles: 162 KB at B = 201, the reference's default deferred-spatial layout 7 + 170 + 24) no longer
+// fits the 160 KB of LDS beyond B = 199, so the kernels accumulate it panel by panel -- rows [row[k], row[k + 1]) per
+// pass over the frame's constraints (the Jacobians are re-evaluated per pass; one pass whenever the triangle fits).
+struct AsmPanels {
+  int n;
+  int row[9];  // n + 1 boundaries, row[0] = 0, row[n] = B
+};
+
 template <int KD, int KS>
 __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const double* __restrict__ x,
                                                   const FrameConst* __restrict__ fc, const double* __restrict__ mask,
@@ -268,25 +279,39 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
                                                   const int* __restrict__ fpOff, const int* __restrict__ fpList,
                                                   double* __restrict__ gOut, double* __restrict__ hOut,
                                                   double* __restrict__ costFrame, double* __restrict__ focalG,
-                                                  double* __restrict__ focalH) {
+                                                  double* __restrict__ focalH, AsmPanels panels, int panelCap) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
-  const int npk = B * (B + 1) / 2;
-  double* Hs = sm;             // packed lower triangle
-  double* gs = Hs + npk;       // B
+  double* Hs = sm;             // one row panel of the packed lower triangle (panelCap doubles)
+  double* gs = Hs + panelCap;  // B
   double* xf = gs + B;         // B
   double* xo = xf + B;         // B
   FrameConst* fcs = reinterpret_cast<FrameConst*>(xo + B);  // [0] = own frame, [1] = other frame
   double* red = reinterpret_cast<double*>(fcs + 2);          // 4 * 36
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
-  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
   for (int i = tid; i < B; i += 256) {
     gs[i] = 0.0;
     xf[i] = x[static_cast<size_t>(f) * B + i];
   }
   constexpr int FCW = sizeof(FrameConst) / 8;
   if (tid < FCW) reinterpret_cast<double*>(fcs)[tid] = reinterpret_cast<const double*>(fc + f)[tid];
+  const double* mf = mask + static_cast<size_t>(f) * B;
+  double* hf = hOut + static_cast<size_t>(f) * B * B;
+  double staticCost = 0.0, regCostTotal = 0.0;
+
+  for (int pass = 0; pass < panels.n; ++pass) {
+  const int r0 = panels.row[pass], r1 = panels.row[pass + 1];
+  const int base = r0 * (r0 + 1) / 2, npk = r1 * (r1 + 1) / 2 - base;
+  const bool first = pass == 0;  // gradient, cost and the shared-focal sums are taken in the first pass only
+  // entry (hi, lo), hi >= lo, of the triangle: in this panel iff r0 <= hi < r1
+#define CVD_PANEL_ADD(hi_, lo_, val_)                                                       \
+  do {                                                                                      \
+    const int hi__ = (hi_);                                                                 \
+    if (hi__ >= r0 && hi__ < r1) atomicAdd(&Hs[packedIdx(hi__, (lo_)) - base], (val_));     \
+  } while (0)
+  __syncthreads();
+  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
   __syncthreads();
 
   // register accumulators of the pose-like 7x7 block + gradient (all lanes hit the same addresses)
@@ -328,22 +353,24 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
             s.a.Jp[rr][6] = tot;
             s.b.Jp[rr][6] = tot;
           }
-          if (!side) {
+          if (!side && first) {
             shG += w * (s.a.Jp[0][6] * s.r[0] + s.a.Jp[1][6] * s.r[1] + s.a.Jp[2][6] * s.r[2]);
             shH += w * (s.a.Jp[0][6] * s.a.Jp[0][6] + s.a.Jp[1][6] * s.a.Jp[1][6] + s.a.Jp[2][6] * s.a.Jp[2][6]);
           }
         }
         const Side<KD, KS>& me = side ? s.b : s.a;
-        if (!side) cost += s.rho0;  // count every constraint once
-        // pose-like block
-        int q = 0;
+        if (!side && first) cost += s.rho0;  // count every constraint once
+        // pose-like block (rows 0..6: first panel)
+        if (first) {
+          int q = 0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          gp[i] += w * (me.Jp[0][i] * s.r[0] + me.Jp[1][i] * s.r[1] + me.Jp[2][i] * s.r[2]);
+          for (int i = 0; i < 7; ++i) {
+            gp[i] += w * (me.Jp[0][i] * s.r[0] + me.Jp[1][i] * s.r[1] + me.Jp[2][i] * s.r[2]);
 #pragma unroll
-          for (int j = 0; j <= i; ++j) {
-            PP[q] += w * (me.Jp[0][i] * me.Jp[0][j] + me.Jp[1][i] * me.Jp[1][j] + me.Jp[2][i] * me.Jp[2][j]);
-            ++q;
+            for (int j = 0; j <= i; ++j) {
+              PP[q] += w * (me.Jp[0][i] * me.Jp[0][j] + me.Jp[1][i] * me.Jp[1][j] + me.Jp[2][i] * me.Jp[2][j]);
+              ++q;
+            }
           }
         }
         // tap columns
@@ -353,11 +380,13 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
           double Jt[3];
           sideTapCol(L, me, t, ct, Jt);
           const double wj0 = w * Jt[0], wj1 = w * Jt[1], wj2 = w * Jt[2];
-          atomicAdd(&gs[ct], wj0 * s.r[0] + wj1 * s.r[1] + wj2 * s.r[2]);
-          const int rowBase = ct * (ct + 1) / 2;
+          if (first) atomicAdd(&gs[ct], wj0 * s.r[0] + wj1 * s.r[1] + wj2 * s.r[2]);
+          if (ct >= r0 && ct < r1) {
+            const int rowBase = ct * (ct + 1) / 2 - base;
 #pragma unroll
-          for (int i = 0; i < 7; ++i)
-            atomicAdd(&Hs[rowBase + i], wj0 * me.Jp[0][i] + wj1 * me.Jp[1][i] + wj2 * me.Jp[2][i]);
+            for (int i = 0; i < 7; ++i)
+              atomicAdd(&Hs[rowBase + i], wj0 * me.Jp[0][i] + wj1 * me.Jp[1][i] + wj2 * me.Jp[2][i]);
+          }
           for (int t2 = 0; t2 <= t; ++t2) {
             int c2;
             double J2[3];
@@ -366,58 +395,65 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
             // tap columns of one sample are distinct but not sorted (border folding keeps row-major order,
             // spatial columns follow depth columns) -> order the pair
             const int hi = ct > c2 ? ct : c2, lo = ct > c2 ? c2 : ct;
-            atomicAdd(&Hs[packedIdx(hi, lo)], val);
+            CVD_PANEL_ADD(hi, lo, val);
           }
         }
       }
     }
   }
   __syncthreads();
-  // block reduction of the register accumulators
-  {
+  if (first) {
+    // block reduction of the register accumulators
+    {
 #pragma unroll
-    for (int i = 0; i < 28; ++i) PP[i] = waveSum(PP[i]);
+      for (int i = 0; i < 28; ++i) PP[i] = waveSum(PP[i]);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) gp[i] = waveSum(gp[i]);
-    cost = waveSum(cost);
-    const int wv = tid >> 6;
-    if ((tid & 63) == 0) {
+      for (int i = 0; i < 7; ++i) gp[i] = waveSum(gp[i]);
+      cost = waveSum(cost);
+      const int wv = tid >> 6;
+      if ((tid & 63) == 0) {
 #pragma unroll
-      for (int i = 0; i < 28; ++i) red[wv * 36 + i] = PP[i];
+        for (int i = 0; i < 28; ++i) red[wv * 36 + i] = PP[i];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) red[wv * 36 + 28 + i] = gp[i];
-      red[wv * 36 + 35] = cost;
+        for (int i = 0; i < 7; ++i) red[wv * 36 + 28 + i] = gp[i];
+        red[wv * 36 + 35] = cost;
+      }
     }
+    __syncthreads();
+    if (tid < 28) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= tid) ++i;
+      const int j = tid - i * (i + 1) / 2;
+      Hs[packedIdx(i, j)] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];  // (rows 0..6 are in panel 0: r1 >= 7)
+    } else if (tid < 35) {
+      gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
+    }
+    __syncthreads();
+    staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < 28) {
-    int i = 0;
-    while ((i + 1) * (i + 2) / 2 <= tid) ++i;
-    const int j = tid - i * (i + 1) / 2;
-    Hs[packedIdx(i, j)] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
-  } else if (tid < 35) {
-    gs[tid - 28] += red[tid] + red[36 + tid] + red[72 + tid] + red[108 + tid];
-  }
-  __syncthreads();
-  const double staticCost = 0.5 * (red[35] + red[36 + 35] + red[72 + 35] + red[108 + 35]);
-  __syncthreads();
   if (L.intrOpt == kIntrShared) {
     // The focal column of every constraint belongs to frame 0's slot: publish this frame's static focal
     // gradient / diagonal for k_shared_focal_fixup and drop the entries from the frame's own block (for f != 0
     // they are off-diagonal couplings with frame 0, which the block-Jacobi preconditioner does not hold).
-    shG = waveSum(shG);
-    shH = waveSum(shH);
-    if ((tid & 63) == 0) { red[tid >> 6] = shG; red[4 + (tid >> 6)] = shH; }
-    __syncthreads();
-    if (tid == 0) {
-      focalG[f] = red[0] + red[1] + red[2] + red[3];
-      focalH[f] = red[4] + red[5] + red[6] + red[7];
-      gs[6] = 0.0;
-      Hs[packedIdx(6, 6)] = 0.0;
+    if (first) {
+      shG = waveSum(shG);
+      shH = waveSum(shH);
+      if ((tid & 63) == 0) { red[tid >> 6] = shG; red[4 + (tid >> 6)] = shH; }
+      __syncthreads();
+      if (tid == 0) {
+        focalG[f] = red[0] + red[1] + red[2] + red[3];
+        focalH[f] = red[4] + red[5] + red[6] + red[7];
+        gs[6] = 0.0;
+        Hs[packedIdx(6, 6)] = 0.0;
+      }
     }
     if (f != 0) {
-      for (int j = tid; j < B; j += 256)
-        if (j != 6) Hs[j > 6 ? packedIdx(j, 6) : packedIdx(6, j)] = 0.0;
+      for (int j = tid; j < B; j += 256) {
+        if (j == 6) continue;
+        const int hi = j > 6 ? j : 6, lo = j > 6 ? 6 : j;
+        if (hi >= r0 && hi < r1) Hs[packedIdx(hi, lo) - base] = 0.0;
+      }
     }
     __syncthreads();
   }
@@ -432,18 +468,18 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
       int cols[2 * KD + 2];
       double jac[2 * KD + 2];
       regResidual<KD>(L, f, i, xf, median[f], r, n, cols, jac);
-      regCost += r * r;
+      if (first) regCost += r * r;
       for (int a = 0; a < n; ++a) {
-        atomicAdd(&gs[cols[a]], jac[a] * r);
+        if (first) atomicAdd(&gs[cols[a]], jac[a] * r);
         for (int b = 0; b <= a; ++b) {
           const int hi = cols[a] > cols[b] ? cols[a] : cols[b];
           const int lo = cols[a] > cols[b] ? cols[b] : cols[a];
-          atomicAdd(&Hs[packedIdx(hi, lo)], jac[a] * jac[b]);
+          CVD_PANEL_ADD(hi, lo, jac[a] * jac[b]);
         }
       }
     }
   }
-  if (tid == 0 && L.positionRegSqrt > 0.0) {
+  if (tid == 0 && L.positionRegSqrt > 0.0 && first) {
     double o3[3] = {0, 0, 0}, dg = 0.0, cst = 0.0;
     posRegFrame(L, rangeFlags, f, x, nullptr, o3, dg, cst);
     for (int i = 0; i < 3; ++i) {
@@ -452,21 +488,30 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
     }
     regCost += cst;
   }
-  regCost = waveSum(regCost);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = regCost;
-  __syncthreads();
-  if (tid == 0) costFrame[f] = staticCost + 0.5 * (red[0] + red[1] + red[2] + red[3]);
-
-  // write-out with the constant-parameter mask applied (constant columns drop out of J)
-  const double* mf = mask + static_cast<size_t>(f) * B;
-  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
-  double* hf = hOut + static_cast<size_t>(f) * B * B;
-  for (int idx = tid; idx < B * B; idx += 256) {
-    const int i = idx / B, j = idx - i * B;
-    const int hi = i > j ? i : j, lo = i > j ? j : i;
-    hf[idx] = Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
+  if (first) {
+    regCost = waveSum(regCost);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = regCost;
+    __syncthreads();
+    regCostTotal = 0.5 * (red[0] + red[1] + red[2] + red[3]);
   }
+  __syncthreads();
+  // write-out of this panel with the constant-parameter mask applied (constant columns drop out of J): entry (i, j),
+  // j <= i, goes to both triangles of the full block
+  for (int idx = tid; idx < npk; idx += 256) {
+    int i = static_cast<int>((sqrt(8.0 * static_cast<double>(idx + base) + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > idx + base) --i;
+    while ((i + 1) * (i + 2) / 2 <= idx + base) ++i;
+    const int j = idx + base - i * (i + 1) / 2;
+    const double v = Hs[idx] * mf[i] * mf[j];
+    hf[static_cast<size_t>(i) * B + j] = v;
+    hf[static_cast<size_t>(j) * B + i] = v;
+  }
+#undef CVD_PANEL_ADD
+  }  // pass
+  if (tid == 0) costFrame[f] = staticCost + regCostTotal;
+  __syncthreads();
+  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] = gs[i] * mf[i];
 }
 
 // IntrinsicsOptimization::Shared: frame 0's focal slot receives the static focal gradient / diagonal of all frames.
@@ -1194,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        const double* __restrict__ pOld, double* __restrict__ pNew,
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nItems, RegCache rc, CoarseView V,
+                                                       int distMode, int nRows, RegCache rc, CoarseView V,
                                                        double* __restrict__ qc, CoarseColumns cc) {
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1252,9 +1297,10 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   }
   __syncthreads();
   if (L.intrOpt == kIntrShared && f == 0 && L.includeStatic) {
-    // shared focal: frame 0's slot collects the focal adjoint of EVERY work item (both sides)
+    // shared focal: frame 0's slot collects the focal adjoint of EVERY partial row (both sides of every pair item, the
+    // three rows of every triplet group)
     double a = 0.0;
-    for (int k = tid; k < 2 * nItems; k += 256) a += qPart[static_cast<size_t>(k) * B + 6];
+    for (int k = tid; k < nRows; k += 256) a += qPart[static_cast<size_t>(k) * B + 6];
     a = waveSum(a);
     if ((tid & 63) == 0) atomicAdd(&qf[6], a);
     __syncthreads();

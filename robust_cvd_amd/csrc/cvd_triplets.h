@@ -7,7 +7,9 @@
 //       r = [ (u01 + u21 - 2 p1.x) / fy1,  (v01 + v21 - 2 p1.y) / fy1,  1/max(z01,eps) + 1/max(z21,eps) - 2/max(D1,eps) ]
 //   EuclideanLaplacian: r = X0 + X2 - 2 X1 (world points).
 // ScaledLoss(nullptr, w): cost 0.5 w |r|^2 with w = smoothStaticWeight / smoothDynamicWeight by the constraint's flag.
-// The two depth-consistency variants and IntrinsicsOptimization::Shared with triplets are rejected by the host.
+// IntrinsicsOptimization::Shared (reference lib/PoseOptimizer.cpp:1306-1330): one focal block, frame 0's, for all three
+// observations -- its column is the sum of the three sides' focal columns and lives in frame 0's slot, exactly as for
+// the pair constraints (k_assemble / k_shared_focal_fixup, k_matvec_finish).
 //
 // Layout: 36 B per constraint in HBM (3 x float2 ndc, 3 x float source depth, invalid = depth 0 in slot 0), groups
 // keyed by the centre frame.  Kernels mirror the pair path: cost per group, frame-major assembly of g / H_ff
@@ -289,16 +291,26 @@ __global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTabl
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const int* __restrict__ ftOff, const int* __restrict__ ftList,
-                                                           double* __restrict__ gOut, double* __restrict__ hOut) {
+                                                           double* __restrict__ gOut, double* __restrict__ hOut,
+                                                           double* __restrict__ focalG, double* __restrict__ focalH,
+                                                           AsmPanels panels, int panelCap) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
-  const int npk = B * (B + 1) / 2;
-  double* Hs = sm;
-  double* gs = Hs + npk;
+  double* Hs = sm;             // one row panel of the packed lower triangle (AsmPanels, cvd_kernels.h)
+  double* gs = Hs + panelCap;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (ftOff[f] == ftOff[f + 1]) return;
-  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
   for (int i = tid; i < B; i += 256) gs[i] = 0.0;
+  const bool shared = L.intrOpt == kIntrShared;
+  double shG = 0.0, shH = 0.0;  // shared focal: gradient / squared column norm, taken once per constraint (centre visit)
+  const double* mf = mask + static_cast<size_t>(f) * B;
+  double* hf = hOut + static_cast<size_t>(f) * B * B;
+  for (int pass = 0; pass < panels.n; ++pass) {
+  const int r0 = panels.row[pass], r1 = panels.row[pass + 1];
+  const int base = r0 * (r0 + 1) / 2, npk = r1 * (r1 + 1) / 2 - base;
+  const bool first = pass == 0;
+  __syncthreads();
+  for (int i = tid; i < npk; i += 256) Hs[i] = 0.0;
   __syncthreads();
   for (int e = ftOff[f]; e < ftOff[f + 1]; ++e) {
     const int code = ftList[e];
@@ -312,13 +324,29 @@ __global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTabl
       evalTriplet<KD, KS>(L, T.smoothType, fc[f1 - 1], fc[f1], fc[f1 + 1], x + static_cast<size_t>(f1 - 1) * B,
                           x + static_cast<size_t>(f1) * B, x + static_cast<size_t>(f1 + 1) * B, T.ndc + c * 3,
                           T.dsrc + c * 3, s);
-      const Side<KD, KS>& me = s.s[role];
       const double w = ws * ws;
+      if (shared) {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const double tot = s.s[0].Jp[rr][6] + s.s[1].Jp[rr][6] + s.s[2].Jp[rr][6];
+          s.s[0].Jp[rr][6] = tot;
+          s.s[1].Jp[rr][6] = tot;
+          s.s[2].Jp[rr][6] = tot;
+        }
+        if (role == 1 && first) {
+          const Side<KD, KS>& c1 = s.s[1];
+          shG += w * (c1.Jp[0][6] * s.r[0] + c1.Jp[1][6] * s.r[1] + c1.Jp[2][6] * s.r[2]);
+          shH += w * (c1.Jp[0][6] * c1.Jp[0][6] + c1.Jp[1][6] * c1.Jp[1][6] + c1.Jp[2][6] * c1.Jp[2][6]);
+        }
+      }
+      const Side<KD, KS>& me = s.s[role];
       // all columns through LDS atomics (this loss is off by default: no register-blocked fast path)
-      for (int i = 0; i < 7; ++i) {
-        atomicAdd(&gs[i], w * (me.Jp[0][i] * s.r[0] + me.Jp[1][i] * s.r[1] + me.Jp[2][i] * s.r[2]));
-        for (int j = 0; j <= i; ++j)
-          atomicAdd(&Hs[packedIdx(i, j)], w * (me.Jp[0][i] * me.Jp[0][j] + me.Jp[1][i] * me.Jp[1][j] + me.Jp[2][i] * me.Jp[2][j]));
+      if (first) {
+        for (int i = 0; i < 7; ++i) {
+          atomicAdd(&gs[i], w * (me.Jp[0][i] * s.r[0] + me.Jp[1][i] * s.r[1] + me.Jp[2][i] * s.r[2]));
+          for (int j = 0; j <= i; ++j)
+            atomicAdd(&Hs[packedIdx(i, j)], w * (me.Jp[0][i] * me.Jp[0][j] + me.Jp[1][i] * me.Jp[1][j] + me.Jp[2][i] * me.Jp[2][j]));
+        }
       }
       const int nt = sideNumTapCols(L, me);
       for (int t = 0; t < nt; ++t) {
@@ -326,28 +354,50 @@ __global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTabl
         double Jt[3];
         sideTapCol(L, me, t, ct, Jt);
         const double wj0 = w * Jt[0], wj1 = w * Jt[1], wj2 = w * Jt[2];
-        atomicAdd(&gs[ct], wj0 * s.r[0] + wj1 * s.r[1] + wj2 * s.r[2]);
-        const int rowBase = ct * (ct + 1) / 2;
-        for (int i = 0; i < 7; ++i) atomicAdd(&Hs[rowBase + i], wj0 * me.Jp[0][i] + wj1 * me.Jp[1][i] + wj2 * me.Jp[2][i]);
+        if (first) atomicAdd(&gs[ct], wj0 * s.r[0] + wj1 * s.r[1] + wj2 * s.r[2]);
+        if (ct >= r0 && ct < r1) {
+          const int rowBase = ct * (ct + 1) / 2 - base;
+          for (int i = 0; i < 7; ++i) atomicAdd(&Hs[rowBase + i], wj0 * me.Jp[0][i] + wj1 * me.Jp[1][i] + wj2 * me.Jp[2][i]);
+        }
         for (int t2 = 0; t2 <= t; ++t2) {
           int c2;
           double J2[3];
           sideTapCol(L, me, t2, c2, J2);
           const int hi = ct > c2 ? ct : c2, lo = ct > c2 ? c2 : ct;
-          atomicAdd(&Hs[packedIdx(hi, lo)], wj0 * J2[0] + wj1 * J2[1] + wj2 * J2[2]);
+          if (hi >= r0 && hi < r1) atomicAdd(&Hs[packedIdx(hi, lo) - base], wj0 * J2[0] + wj1 * J2[1] + wj2 * J2[2]);
         }
       }
     }
   }
   __syncthreads();
-  const double* mf = mask + static_cast<size_t>(f) * B;
-  for (int i = tid; i < B; i += 256) gOut[static_cast<size_t>(f) * B + i] += gs[i] * mf[i];
-  double* hf = hOut + static_cast<size_t>(f) * B * B;
-  for (int idx = tid; idx < B * B; idx += 256) {
-    const int i = idx / B, j = idx - i * B;
-    const int hi = i > j ? i : j, lo = i > j ? j : i;
-    hf[idx] += Hs[packedIdx(hi, lo)] * mf[i] * mf[j];
+  // panel write-out: ADDED to what the pair assembly wrote
+  for (int idx = tid; idx < npk; idx += 256) {
+    int i = static_cast<int>((sqrt(8.0 * static_cast<double>(idx + base) + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > idx + base) --i;
+    while ((i + 1) * (i + 2) / 2 <= idx + base) ++i;
+    const int j = idx + base - i * (i + 1) / 2;
+    // shared focal (as in k_assemble): gradient / diagonal go to frame 0's slot through k_shared_focal_fixup (which runs
+    // after this kernel); the column's couplings with other frames' unknowns are not held by the block preconditioner
+    if (shared && ((i == 6 && j == 6) || (f != 0 && (i == 6 || j == 6)))) continue;
+    const double v = Hs[idx] * mf[i] * mf[j];
+    hf[static_cast<size_t>(i) * B + j] += v;
+    if (i != j) hf[static_cast<size_t>(j) * B + i] += v;
   }
+  }  // pass
+  __syncthreads();
+  if (shared) {
+    __shared__ double redS[8];
+    shG = waveSum(shG);
+    shH = waveSum(shH);
+    if ((tid & 63) == 0) { redS[tid >> 6] = shG; redS[4 + (tid >> 6)] = shH; }
+    __syncthreads();
+    if (tid == 0) {
+      focalG[f] += redS[0] + redS[1] + redS[2] + redS[3];
+      focalH[f] += redS[4] + redS[5] + redS[6] + redS[7];
+    }
+  }
+  for (int i = tid; i < B; i += 256)
+    if (!(shared && i == 6)) gOut[static_cast<size_t>(f) * B + i] += gs[i] * mf[i];
 }
 
 // ---- product: one workgroup per triplet group, three partial rows (one per frame) -------------------------------
@@ -381,6 +431,11 @@ __global__ __launch_bounds__(256) void k_matvec_triplets(Layout L, TripletTable 
     qs[i] = 0.0;
   }
   __syncthreads();
+  if (L.intrOpt == kIntrShared && tid < 3) {
+    // every observation's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1306-1330)
+    ps[tid * B + 6] = (z[6] + (useBeta ? beta * pOld[6] : 0.0)) * mask[6];
+  }
+  if (L.intrOpt == kIntrShared) __syncthreads();
   for (long long c = T.off[2 * g] + tid; c < T.off[2 * g + 1]; c += 256) {
     if (!(T.dsrc[c * 3] > 0.f)) continue;
     const double ws = T.isStatic[c] ? T.wStaticSqrt : T.wDynamicSqrt;

@@ -1097,7 +1097,69 @@ struct FlowConstraintsCollection {
         kv.second.isStatic[i] = isFar(kv.first - 1, c[0], c[1]) && isFar(kv.first, c[2], c[3]) && isFar(kv.first + 1, c[4], c[5]);
       }
   }
-  void pruneStaticFlag(int) { throw std::runtime_error("pruneStaticFlag is outside the optimizer path of this build."); }
+  // reference lib/FlowConstraints.cpp:662-748: every NON-static pair constraint stamps a disk of radius `distance` around
+  // its end point into the mask of that end point's frame; afterwards every pair / triplet constraint with an end point on
+  // a stamped pixel becomes non-static as well.  Pixel = int(loc * w) for both coordinates (:696-697: loc.y is scaled by
+  // invAspect, so `* w` lands on the row); raster = the "down" colour stream.  The reference's std::map iteration order
+  // is irrelevant: the masks are complete before the second pass.  Host loop over a host container, as in the reference.
+  void pruneStaticFlag(int distance) {
+    if (distance < 0) throw std::runtime_error("pruneStaticFlag: negative distance");
+    if (!video_->hasColorStream("down")) throw std::runtime_error("Color stream 'down' does not exist.");
+    const ColorStream& down = *video_->colorStreams_[video_->colorStreamIndex("down")];
+    int w = down.width_, h = down.height_;
+    if (w <= 0 || h <= 0) {
+      // stream created without an explicit size: the reference's ColorStream takes it from its first image
+      std::ifstream is(down.path_ + "/frame_" + fmtInt6(0) + down.extension_, std::ios::binary);
+      if (is) {
+        h = rd<int32_t>(is);
+        w = rd<int32_t>(is);
+      } else {  // no images on disk (constraints came from the cache file): the video's own raster
+        w = video_->width_;
+        h = video_->height_;
+      }
+    }
+    if (w <= 0 || h <= 0) throw std::runtime_error("pruneStaticFlag: the 'down' colour stream has no size");
+    const int F = video_->numFrames();
+    std::vector<std::vector<uint8_t>> masks(F);
+    auto maskOf = [&](int f) -> std::vector<uint8_t>& {
+      std::vector<uint8_t>& m = masks.at(f);
+      if (m.empty()) m.assign(static_cast<size_t>(w) * h, 0);
+      return m;
+    };
+    const long long r2 = static_cast<long long>(distance) * distance;
+    auto stamp = [&](int f, float lx, float ly) {
+      const int x = static_cast<int>(lx * w), y = static_cast<int>(ly * w);
+      std::vector<uint8_t>& m = maskOf(f);
+      for (int my = std::max(0, y - distance); my <= std::min(h - 1, y + distance); ++my)
+        for (int mx = std::max(0, x - distance); mx <= std::min(w - 1, x + distance); ++mx)
+          if (static_cast<long long>(mx - x) * (mx - x) + static_cast<long long>(my - y) * (my - y) <= r2)  // buildDiskMask
+            m[static_cast<size_t>(my) * w + mx] = 255;
+    };
+    for (auto& kv : pairs_)
+      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+        if (kv.second.isStatic[i]) continue;
+        const auto& c = kv.second.loc[i];
+        stamp(kv.first.first, c[0], c[1]);
+        stamp(kv.first.second, c[2], c[3]);
+      }
+    auto hit = [&](int f, float lx, float ly) {
+      const std::vector<uint8_t>& m = masks.at(f);
+      if (m.empty()) return false;
+      const int x = static_cast<int>(lx * w), y = static_cast<int>(ly * w);
+      if (x < 0 || x >= w || y < 0 || y >= h) throw std::runtime_error("constraint outside the 'down' raster");
+      return m[static_cast<size_t>(y) * w + x] != 0;
+    };
+    for (auto& kv : pairs_)
+      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+        const auto& c = kv.second.loc[i];
+        if (hit(kv.first.first, c[0], c[1]) || hit(kv.first.second, c[2], c[3])) kv.second.isStatic[i] = 0;
+      }
+    for (auto& kv : triplets_)
+      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+        const auto& c = kv.second.loc[i];
+        if (hit(kv.first - 1, c[0], c[1]) || hit(kv.first, c[2], c[3]) || hit(kv.first + 1, c[4], c[5])) kv.second.isStatic[i] = 0;
+      }
+  }
   // extension: explicit flags (what setStaticFlagFromDynamicMask would compute), per pair in map order
   void setStaticFlags(int a, int b, const std::vector<uint8_t>& flags) {
     auto& pc = pairs_.at({a, b});
@@ -1507,6 +1569,12 @@ struct DepthVideoProcessor {
 
 using namespace cvdhost;
 
+// numpy view of a std::array member that keeps its parent object alive (element assignment writes through)
+template <typename T, size_t N>
+static py::array_t<T> memberView(py::object parent, std::array<T, N>& member) {
+  return py::array_t<T>({static_cast<py::ssize_t>(N)}, {static_cast<py::ssize_t>(sizeof(T))}, member.data(), parent);
+}
+
 PYBIND11_MODULE(lib_python, m) {
   m.doc() = "MI355X-native drop-in for robust_cvd's lib_python (optimizer path only)";
   m.def("initLib", []() {});
@@ -1528,7 +1596,9 @@ PYBIND11_MODULE(lib_python, m) {
       .def("setCoeffs", [](Quaternionf& q, const std::array<float, 4>& c) { q.x_ = c[0]; q.y_ = c[1]; q.z_ = c[2]; q.w_ = c[3]; });
   py::class_<Extrinsics>(m, "Extrinsics")
       .def(py::init())
-      .def_readwrite("position", &Extrinsics::position)
+      // (the reference returns a numpy view of the Eigen member: `e.position[0] = x` writes through, lib/PythonBindings.cpp:181)
+      .def_property("position", [](py::object self) { return memberView(self, self.cast<Extrinsics&>().position); },
+                    [](Extrinsics& e, const std::array<float, 3>& v) { e.position = v; })
       .def_readwrite("orientation", &Extrinsics::orientation)
       .def("left", &Extrinsics::left).def("right", &Extrinsics::right).def("down", &Extrinsics::down)
       .def("up", &Extrinsics::up).def("forward", &Extrinsics::forward).def("backward", &Extrinsics::backward);
@@ -1549,12 +1619,29 @@ PYBIND11_MODULE(lib_python, m) {
       .def(py::init())
       .def_readwrite("type", &XformDescriptor::type).def_readwrite("depthType", &XformDescriptor::depthType)
       .def_readwrite("spatialType", &XformDescriptor::spatialType).def_readwrite("valueXform", &XformDescriptor::valueXform)
-      .def_readwrite("gridSize", &XformDescriptor::gridSize).def_readwrite("depthMinMax", &XformDescriptor::depthMinMax)
+      // (numpy views of the members, as pybind11/eigen.h gives the reference: `d.gridSize[0] = 17` writes through,
+      // lib/PythonBindings.cpp:237-238)
+      .def_property("gridSize", [](py::object self) { return memberView(self, self.cast<XformDescriptor&>().gridSize); },
+                    [](XformDescriptor& d, const std::array<int, 3>& v) { d.gridSize = v; })
+      .def_property("depthMinMax", [](py::object self) { return memberView(self, self.cast<XformDescriptor&>().depthMinMax); },
+                    [](XformDescriptor& d, const std::array<double, 2>& v) { d.depthMinMax = v; })
       .def_readwrite("cubicInterpolation", &XformDescriptor::cubicInterpolation)
       .def("reset", &XformDescriptor::reset, py::arg("type") = XformType::Depth)
       .def("str", &XformDescriptor::str).def("parse", &XformDescriptor::parse);
 
   py::class_<Xform>(m, "Xform")
+      // Xform::clone (reference lib/DepthMapTransform.cpp:353-357, bound at lib/PythonBindings.cpp:246): a new transform of the
+      // same descriptor with the parameters copied; Python owns the clone
+      .def("clone", [](const Xform& x) -> py::object {
+        if (x.desc_.type == XformType::Depth) {
+          std::unique_ptr<DepthXform> c = createDepthXform(x.desc_);
+          c->params_ = x.params_;
+          return py::cast(std::move(c));
+        }
+        std::unique_ptr<SpatialXform> c = createSpatialXform(x.desc_);
+        c->params_ = x.params_;
+        return py::cast(std::move(c));
+      })
       .def("copyFrom", &Xform::copyFrom)
       .def("desc", &Xform::desc, py::return_value_policy::copy)
       .def("str", &Xform::str)
@@ -1655,6 +1742,16 @@ PYBIND11_MODULE(lib_python, m) {
       .def("setStaticFlagFromDynamicMask", &FlowConstraintsCollection::setStaticFlagFromDynamicMask)
       .def("pruneStaticFlag", &FlowConstraintsCollection::pruneStaticFlag)
       .def("setStaticFlags", &FlowConstraintsCollection::setStaticFlags)
+      // extensions (test access): the isStatic flags and the (loc0.xy, loc1.xy) rows of one pair
+      .def("staticFlags", [](const FlowConstraintsCollection& c, int a, int b) { return c.pairs_.at({a, b}).isStatic; })
+      .def("pairLocations", [](const FlowConstraintsCollection& c, int a, int b) {
+        const auto& loc = c.pairs_.at({a, b}).loc;
+        py::array_t<float> out({static_cast<py::ssize_t>(loc.size()), static_cast<py::ssize_t>(4)});
+        auto o = out.mutable_unchecked<2>();
+        for (size_t i = 0; i < loc.size(); ++i)
+          for (int k = 0; k < 4; ++k) o(i, k) = loc[i][k];
+        return out;
+      })
       .def("numPairs", &FlowConstraintsCollection::numPairs)
       .def("numConstraints", &FlowConstraintsCollection::numConstraints)
       .def("compute", &FlowConstraintsCollection::compute, py::call_guard<py::gil_scoped_release>())

@@ -359,6 +359,36 @@ def test_normalize_depth_matches_oracle(Solver):
     assert abs(th["hip"][0, 0] * med - 1) < 1e-4
 
 
+@pytest.mark.parametrize("variant", ["global", "grid4x3", "global_scaleshift"])
+def test_normalize_depth_pair_loop_matches_oracle(Solver, variant):
+    """normalizeDepth with normalizeDepthFromFirstFrame = false (reference lib/PoseOptimizer.cpp:1014-1115): one
+    DisparityDissimilarityCost + CauchyLoss per constraint (dynamic ones included), scale and deformation regularisers,
+    lower bound 0 on theta[0]; no copy of the first frame's transform afterwards."""
+    v = synth.make_video(8, 96, 56, seed=36)
+    v.is_static = (np.random.default_rng(2).uniform(size=v.num_constraints) > 0.2).astype(np.uint8)  # flags are ignored here
+    objs = _pair(Solver, v)
+    p = OptParams.defaults()
+    p.num_threads = 4
+    p.normalize_depth_from_first_frame = 0
+    th, sm, ev = {}, {}, {}
+    for k, s in objs.items():
+        if variant == "grid4x3":
+            s.reset_depth_xforms(XformDesc.grid_depth(4, 3))
+        elif variant == "global_scaleshift":
+            s.reset_depth_xforms(XformDesc.global_depth(ValueXformType.ScaleShift))
+        else:
+            s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        th[k] = s.get_xform_params()
+        sm[k] = s.summary()
+    assert sm["hip"]["num_residual_blocks"] == sm["oracle"]["num_residual_blocks"]
+    assert abs(sm["hip"]["initial_cost"] - sm["oracle"]["initial_cost"]) <= 1e-9 * abs(sm["oracle"]["initial_cost"])
+    assert abs(sm["hip"]["final_cost"] - sm["oracle"]["final_cost"]) <= 1e-6 * abs(sm["oracle"]["final_cost"])
+    assert rel(th["hip"], th["oracle"]) < 1e-3
+    assert not np.all(th["hip"] == th["hip"][0])   # every frame keeps its own transform
+
+
 @pytest.mark.parametrize("cfg", ["config1_global_fixed", "config2_cubic4x4", "ctf_default"])
 def test_full_solve_reaches_the_oracle_minimum(Solver, cfg):
     """BASELINE configs[0] / configs[1] (reduced sizes so the exact-Cholesky oracle finishes in seconds) and the
@@ -397,6 +427,60 @@ def test_full_solve_reaches_the_oracle_minimum(Solver, cfg):
     assert np.abs(out["hip"][0]["vfov"] - out["oracle"][0]["vfov"]).max() < 1e-3
     # deformed depth (what DepthXform::apply consumes): per-vertex scale params agree
     assert rel(out["hip"][1], out["oracle"][1]) < 1e-2
+
+
+@pytest.mark.parametrize("variant", ["deferred_spatial_default_grid", "graduate_deform_reg", "deferred_spatial_small_grid"])
+def test_schedule_variants_match_oracle(Solver, variant):
+    """poseOptimization's schedule options (reference lib/PoseOptimizer.cpp:836-841, 874-887): the deferred spatial step
+    (a 4x3 bicubic spatial grid after the last depth level -- with the default 17x10 depth grid the frame block is
+    7 + 170 + 24 = 201 unknowns, assembled in two row panels) and the graduated depth-deformation regulariser.
+    Default solver options; end state against the oracle."""
+    v = synth.make_video(12, 192, 112, seed=41)
+    objs = _pair(Solver, v)
+    out = {}
+    for k, s in objs.items():
+        p = OptParams.defaults()
+        p.num_threads = 8
+        if variant == "deferred_spatial_default_grid":
+            p.deferred_spatial_opt = 1
+        elif variant == "deferred_spatial_small_grid":
+            p.deferred_spatial_opt = 1
+            p.ctf_long, p.ctf_short = 6, 4
+        else:
+            p.graduate_depth_deform_reg = 1
+            p.ctf_long, p.ctf_short = 8, 5
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[k] = (s.get_poses(), s.get_xform_params(), s.summary(), s.xform_desc(True), s.get_xform_params(True), s.block_size())
+    sh, so = out["hip"][2], out["oracle"][2]
+    assert sh["termination"] == 0 and so["termination"] == 0
+    if variant == "deferred_spatial_default_grid":
+        assert out["hip"][5] == 201
+    if variant != "graduate_deform_reg":
+        assert int(out["hip"][3].spatial_type) == int(SpatialXformType.BicubicGrid) and list(out["hip"][3].grid_size)[:2] == [4, 3]
+        assert np.abs(out["hip"][4] - out["oracle"][4]).max() < 1e-4   # spatial grid parameters (NDC units)
+    assert abs(sh["final_cost"] - so["final_cost"]) <= 1e-6 * abs(so["final_cost"]), (sh["final_cost"], so["final_cost"])
+    perr, rerr = synth.relative_pose_error(out["hip"][0]["position"], out["hip"][0]["orientation"],
+                                           out["oracle"][0]["position"], out["oracle"][0]["orientation"])
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+    assert rel(out["hip"][1], out["oracle"][1]) < 1e-3
+
+
+def test_frame_blocks_beyond_the_supported_size_fail_before_any_work(Solver):
+    """ScaleShift on the default 17x10 grid needs 7 + 340 = 347 unknowns per frame (> 256): rejected up front, with the
+    transforms untouched (the old build failed after the coarse levels had already run)."""
+    v = synth.make_video(4, 96, 56, seed=3)
+    s = Solver(0)
+    synth.load_into(s, v)
+    s.reset_depth_xforms(XformDesc.global_depth(ValueXformType.ScaleShift))
+    s.reset_spatial_xforms(XformDesc.spatial())
+    p = OptParams.defaults()
+    before = s.get_xform_params().copy()
+    with pytest.raises(RuntimeError, match="unknowns per frame"):
+        s.pose_optimization(p)
+    assert int(s.xform_desc().depth_type) == 2 and np.array_equal(s.get_xform_params(), before)
 
 
 def test_full_size_cost_is_additive_over_pair_subsets(Solver):

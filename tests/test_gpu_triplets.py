@@ -158,7 +158,58 @@ def test_unsupported_triplet_configurations_fail_loudly(Solver):
     p.smooth_loss_type = 7
     with pytest.raises(RuntimeError, match="Invalid loss type"):     # reference lib/PoseOptimizer.cpp:407
         s.evaluate(p, 0.0, pose)
-    p = _params(SmoothLossType.ReproDisparityLaplacian)
+
+
+@pytest.mark.parametrize("smooth_type", [SmoothLossType.ReproDisparityLaplacian, SmoothLossType.EuclideanLaplacian])
+@pytest.mark.parametrize("variant", ["grid3x2", "global"])
+def test_triplets_with_shared_intrinsics_match_oracle(Solver, smooth_type, variant):
+    """IntrinsicsOptimization::Shared with the smoothness loss (reference lib/PoseOptimizer.cpp:1306-1330): the focal
+    block of all three observations is frame 0's."""
+    F = 6
+    v = synth.make_video(F, 96, 56, seed=6)
+    trip = synth.make_triplets(v, spacing=20.0)
+    objs = _pair(Solver, v, trip)
+    rng = np.random.default_rng(4)
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.03, (F, 6))
+    pose[:, 6] = 0.21
+    p = _params(smooth_type)
     p.intr_opt = IntrinsicsOptimization.Shared
-    with pytest.raises(RuntimeError, match="Shared"):
-        s.evaluate(p, 0.0, pose)
+    res = {}
+    for k, s in objs.items():
+        s.reset_depth_xforms(XformDesc.grid_depth(3, 2) if variant == "grid3x2" else XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        th = s.get_xform_params(False)
+        s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)), False)
+        res[k] = s.evaluate(p, 0.1, pose, want_hdiag=True, want_hfull=True)
+    a, b = res["hip"], res["oracle"]
+    assert a["num_residual_blocks"] == b["num_residual_blocks"]
+    assert abs(a["cost"] - b["cost"]) <= TOL * abs(b["cost"])
+    assert rel(a["gradient"], b["gradient"]) < TOL
+    assert rel(a["hdiag"], b["hdiag"]) < TOL
+    assert rel(a["hfull"], b["hfull"]) < TOL
+    B = a["gradient"].shape[1]
+    assert np.all(a["gradient"][1:, 6] == 0.0) and a["gradient"][0, 6] != 0.0   # one focal length: frame 0's slot
+    p0 = _params(smooth_type, 0.0, 0.0)
+    p0.intr_opt = IntrinsicsOptimization.Shared
+    assert abs(objs["hip"].evaluate(p0, 0.1, pose)["cost"] - a["cost"]) > 1e-3 * abs(a["cost"])
+
+
+def test_full_solve_with_smoothness_and_shared_intrinsics(Solver):
+    F = 10
+    v = synth.make_video(F, 96, 56, seed=22)
+    trip = synth.make_triplets(v, spacing=16.0)
+    objs = _pair(Solver, v, trip)
+    out = {}
+    for k, s in objs.items():
+        s.reset_depth_xforms(XformDesc.global_depth()); s.reset_spatial_xforms(XformDesc.spatial())
+        p = _params(SmoothLossType.ReproDisparityLaplacian, 1.0, 0.25)
+        p.intr_opt = IntrinsicsOptimization.Shared
+        p.num_threads = 4
+        p.ctf_long, p.ctf_short = 6, 4
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[k] = (s.summary(), s.get_poses())
+    assert abs(out["hip"][0]["final_cost"] - out["oracle"][0]["final_cost"]) <= 1e-5 * abs(out["oracle"][0]["final_cost"])
+    assert np.abs(out["hip"][1]["vfov"] - out["oracle"][1]["vfov"]).max() < 1e-4
+    assert np.ptp(out["hip"][1]["vfov"]) == 0.0   # one field of view for all frames (reference :979-982)

@@ -95,6 +95,84 @@ def test_nested_params_are_references_and_assignment_copies(lib):
     assert params.depthXformDesc.depthType == lib.DepthXformType.Global
 
 
+def test_members_write_through_and_clone(lib):
+    """The reference binds Eigen members (numpy views): element assignment on gridSize / depthMinMax / position writes
+    through (lib/PythonBindings.cpp:181, 237-238); Xform.clone (:246) copies descriptor and parameters."""
+    d = lib.XformDescriptor()
+    d.type, d.depthType, d.valueXform = lib.XformType.Depth, lib.DepthXformType.Grid, lib.ValueXformType.Scale
+    d.gridSize = [4, 3, 1]
+    d.gridSize[0] = 6
+    d.gridSize[1] += 2
+    assert list(d.gridSize) == [6, 5, 1] and d.str() == "Grid(Scale, Linear, 6, 5, 1)"
+    d.depthMinMax[1] = 7.5
+    assert list(d.depthMinMax) == [0.0, 7.5]
+    view = d.gridSize
+    del d
+    view[2] = 1  # the view keeps its parent alive
+    e = lib.Extrinsics()
+    e.position[2] = 3.0
+    e.position = [1.0, 2.0, e.position[2]]
+    assert list(e.position) == [1.0, 2.0, 3.0]
+
+
+def test_xform_clone(lib, dataset):
+    v, base = dataset
+    from tests.drop_in_caller import build_pose_optimizer
+    dv, _ = build_pose_optimizer(lib, base, "midas2", list(range(v.num_frames)), None)
+    ds = dv.depthStream(0)
+    g = lib.XformDescriptor()
+    g.type, g.depthType, g.valueXform = lib.XformType.Depth, lib.DepthXformType.Grid, lib.ValueXformType.Scale
+    g.gridSize = [3, 2, 1]
+    ds.resetDepthXforms(g)
+    x = ds.frame(2).depthXform()
+    x.setParams([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    c = x.clone()
+    assert isinstance(c, lib.DepthXform) and c.desc().str() == x.desc().str() and c.params() == x.params()
+    x.setParams([9.0] * 6)
+    assert c.params() == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]   # a copy, owned by Python
+    ds.frame(3).depthXform().copyFrom(c)
+    assert ds.frame(3).depthXform().params() == c.params()
+    s = ds.frame(2).spatialXform().clone()
+    assert isinstance(s, lib.SpatialXform) and s.numParams() == 0
+
+
+def test_prune_static_flag(lib, dataset):
+    """pruneStaticFlag (reference lib/FlowConstraints.cpp:662-748) against a plain numpy restatement: disks of radius
+    `distance` around the end points of the non-static constraints, then every constraint touching a stamped pixel."""
+    v, base = dataset
+    from tests.drop_in_caller import build_pose_optimizer
+    dv, fc = build_pose_optimizer(lib, base, "midas2", list(range(v.num_frames)), None)
+    w, h, F = v.width, v.height, v.num_frames
+    rng = np.random.default_rng(3)
+    keys = [tuple(int(x) for x in p) for p in v.pairs]
+    flags = {}
+    for a, b in keys:
+        n = len(fc.staticFlags(a, b))
+        f = (rng.uniform(size=n) > 0.03).astype(np.uint8)  # a few dynamic constraints per pair
+        fc.setStaticFlags(a, b, list(f))
+        flags[(a, b)] = f
+    dist = 4
+    masks = np.zeros((F, h, w), bool)
+    yy, xx = np.mgrid[0:h, 0:w]
+    locs = {k: np.asarray(fc.pairLocations(*k)) for k in keys}
+    for (a, b) in keys:
+        for i in np.nonzero(flags[(a, b)] == 0)[0]:
+            for fr, (lx, ly) in ((a, locs[(a, b)][i, 0:2]), (b, locs[(a, b)][i, 2:4])):
+                x, y = int(np.float32(lx) * np.float32(w)), int(np.float32(ly) * np.float32(w))
+                masks[fr] |= (xx - x) ** 2 + (yy - y) ** 2 <= dist * dist
+    fc.pruneStaticFlag(dist)
+    changed = 0
+    for (a, b) in keys:
+        l = locs[(a, b)]
+        x0, y0 = (l[:, 0] * np.float32(w)).astype(int), (l[:, 1] * np.float32(w)).astype(int)
+        x1, y1 = (l[:, 2] * np.float32(w)).astype(int), (l[:, 3] * np.float32(w)).astype(int)
+        want = flags[(a, b)].astype(bool) & ~(masks[a][y0, x0] | masks[b][y1, x1])
+        got = np.asarray(fc.staticFlags(a, b), bool)
+        assert np.array_equal(got, want), (a, b)
+        changed += int((flags[(a, b)].astype(bool) & ~want).sum())
+    assert changed > 0
+
+
 def test_import_streams_constraints_and_video_dat(lib, dataset):
     v, base = dataset
     from tests.drop_in_caller import build_pose_optimizer
