@@ -88,6 +88,14 @@ int32_t cvd_set_depth_all(cvd_handle* h, const float* depth);
  * pair_frames[2*P], offsets[P+1], loc4[4*C] = (loc0.xy, loc1.xy) in [0,1]x[0,invAspect], is_static[C] or NULL. */
 int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames,
                                  const int64_t* offsets, const float* loc4, const uint8_t* is_static);
+/* Dense mode -- the reference's matchSeparation = 0 regime (lib/FlowConstraints.cpp:315-329: buildDiskMask(0) is a 1x1 disk,
+ * so every masked pixel whose flow target rounds into the image becomes a constraint, :381-465).  Instead of a constraint
+ * list the optimizer is handed the flow and mask images of every directed pair -- flow[P][H][W][2] f32 in pixels,
+ * mask[P][H][W] u8 (non-zero = valid), at the size given to cvd_set_video -- and its kernels read flow / mask / depth
+ * directly (17 B per pixel pair); nothing is sampled or tabulated.  Every constraint is static.  Replaces the constraint
+ * list (cvd_set_pair_constraints switches back).  Supported for the default residual configuration (cvd_last_error says
+ * which otherwise). */
+int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* flow, const uint8_t* mask);
 /* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
 int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers,
                                     const int64_t* offsets, const float* loc6, const uint8_t* is_static);

@@ -49,7 +49,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
     "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
-    "cvd_set_pair_constraints", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
+    "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
@@ -113,6 +113,17 @@ class Solver(Binding):
         import numpy as np
         pf = np.ascontiguousarray(pair_frames, dtype=np.int32).reshape(-1, 2)
         self._check(self._fn("set_pair_graph")(self._h, C.c_int32(pf.shape[0]), pf.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def set_pair_flows(self, pair_frames, flow, mask):
+        """Dense mode (the reference's matchSeparation = 0): flow [P, H, W, 2] f32 pixels and mask [P, H, W] u8 of every
+        directed pair instead of a constraint list; the kernels read the images directly."""
+        import numpy as np
+        pf = np.ascontiguousarray(pair_frames, dtype=np.int32).reshape(-1, 2)
+        fl = np.ascontiguousarray(flow, dtype=np.float32)
+        mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert fl.shape == (pf.shape[0], self.height, self.width, 2) and mk.shape == fl.shape[:3], (fl.shape, mk.shape)
+        self._check(self._fn("set_pair_flows")(self._h, C.c_int32(pf.shape[0]), pf.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               fl.ctypes.data_as(C.POINTER(C.c_float)), mk.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def set_generic_kernels(self, enabled=True):
         self._check(self._fn("set_generic_kernels")(self._h, C.c_int32(int(enabled))))

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
 // or fixed intrinsics): the residual / Jacobian chain of k_assemble_fast with register-resident taps, both sides of the
 // constraint at once.  The generic kernel above goes through Sample<KD, KS>, whose dynamically indexed tap arrays live in
 // scratch memory.
-template <int KD>
+template <int KD, bool DENSE = false>
 __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const int* __restrict__ itemEdge, double* __restrict__ edgeOut,
@@ -215,10 +215,12 @@ __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, It
     const double fya = Fa.fy, fxa = Fa.fy * A;
     const double fyb = Fb.fy;
     const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+    const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
+    const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
     for (long long c = cb + tid; c < ce; c += 256) {
-      const float2 d = T.dsrc[c];
-      if (!(d.x > 0.f)) continue;
-      const float4 nd = T.ndc[c];
+      float4 nd;
+      float2 d;
+      if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
       const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
       double Da, Db;
       if (N == 0) {

@@ -28,6 +28,7 @@
 #include <functional>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -268,6 +269,10 @@ struct cvd_handle_t {
   DevBuf<float4> dLoc, dNdc;
   DevBuf<float2> dDsrc;
   DevBuf<unsigned char> dStatic, dInRange, dRegOwner;
+  // dense mode (cvd_set_pair_flows): flow / mask images of every directed pair instead of a constraint list
+  bool dense = false;
+  DevBuf<float2> dFlow;
+  DevBuf<unsigned char> dFMask;
 
   // multi-GPU (pair-sharded): one RCCL communicator, this rank owns the regularisers of frames f % world == rank
   ncclComm_t comm = nullptr;
@@ -703,6 +708,36 @@ static bool fastLoss(const Layout& L) {
   return L.lossType == CVD_STATIC_REPRO_DISPARITY || L.lossType == CVD_STATIC_REPRO_DEPTH_RATIO || L.lossType == CVD_STATIC_REPRO_LOG_DEPTH;
 }
 
+constexpr long long kListChunk = 768;    // constraints per direction and work item (list mode)
+constexpr long long kDenseChunk = 8192;  // pixel slots per direction and work item (dense mode)
+
+static Table makeTable(cvd_handle* h) {
+  Table T{};
+  T.ndc = h->dense ? nullptr : h->dNdc.p;
+  T.dsrc = h->dense ? nullptr : h->dDsrc.p;
+  T.pairA = h->dPairA.p;
+  T.pairB = h->dPairB.p;
+  T.pairOff = h->dPairOff.p;
+  T.flow = h->dense ? h->dFlow.p : nullptr;
+  T.fmask = h->dense ? h->dFMask.p : nullptr;
+  T.depth = h->dDepth.p;
+  T.W = h->W;
+  T.H = h->H;
+  T.sx = 1.f / static_cast<float>(h->W);                 // reference lib/FlowConstraints.cpp:371: Vector2f scale(1.f / w, invAspect / h)
+  T.sy = h->invAspect / static_cast<float>(h->H);
+  T.invAspect = h->invAspect;
+  return T;
+}
+// Dense mode runs on the specialised fast kernels only (the default residual configuration of the reference pipeline).
+static void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
+  if (!h->dense) return;
+  if (KS != 0 || !fastLoss(L) || L.lossType != CVD_STATIC_REPRO_DISPARITY || L.N != 1 || L.robustKind != 0 || trip ||
+      L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || h->dist() || L.cubic)
+    throw std::runtime_error("dense mode (cvd_set_pair_flows) supports the default residual configuration only: identity spatial "
+                             "transform, ReproDisparity loss, Cauchy robustifier, Scale value transform, Global or bilinear "
+                             "grid, per-frame or fixed intrinsics, no smoothness triplets, one GPU");
+}
+
 #define CVD_DISPATCH(KDv, KSv, ...)                                             \
   do {                                                                          \
     if (KDv == 1 && KSv == 0) { constexpr int KD = 1, KS = 0; __VA_ARGS__; }     \
@@ -752,8 +787,14 @@ static void allowLds(K kernel, size_t bytes) {
   if (bytes > kMaxLds)
     throw std::runtime_error(fmt("per-frame block needs %zu B of LDS (> 160 KiB): frame block too large", bytes));
   if (bytes > 48 * 1024) {
-    static std::map<const void*, size_t> granted;  // one driver call per kernel and high-water mark, not per launch
-    size_t& g = granted[reinterpret_cast<const void*>(kernel)];
+    // one driver call per (device, kernel) and high-water mark, not per launch; handles on several GPUs / host threads
+    // share this cache
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    static std::mutex grantedMutex;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(grantedMutex);
+    size_t& g = granted[{dev, reinterpret_cast<const void*>(kernel)}];
     if (bytes > g) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(bytes)));
@@ -1045,11 +1086,20 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     for (int f = 0; f < h->F; ++f) owner[f] = inRange[f] && (f % h->world == h->rank);
     h->dRegOwner.upload(owner.data(), owner.size(), s);
   }
-  h->dNdc.ensure(std::max<long long>(h->C, 1));
-  h->dDsrc.ensure(std::max<long long>(h->C, 1));
   h->dCount.ensure(1);
   HIP_CHECK(hipMemsetAsync(h->dCount.p, 0, sizeof(unsigned long long), s));
-  if (h->C > 0) {
+  if (h->dense) {
+    // no table: the kernels read the images; only the number of valid constraints is needed here
+    if (h->C > 0) {
+      const unsigned grid = static_cast<unsigned>((h->C + 255) / 256);
+      hipLaunchKernelGGL(k_dense_count, dim3(grid), dim3(256), 0, s, makeTable(h), h->P, h->dInRange.p, h->dCount.p);
+      HIP_CHECK(hipGetLastError());
+    }
+  } else {
+    h->dNdc.ensure(std::max<long long>(h->C, 1));
+    h->dDsrc.ensure(std::max<long long>(h->C, 1));
+  }
+  if (h->C > 0 && !h->dense) {
     const int bs = 256;
     const unsigned grid = static_cast<unsigned>((h->C + bs - 1) / bs);
     hipLaunchKernelGGL(k_build_table, dim3(grid), dim3(bs), 0, s, h->W, h->H, h->invAspect, h->C, h->dLoc.p,
@@ -1085,7 +1135,8 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     long long n0 = 0, n1 = 0, o0 = 0, o1 = 0;
     if (e.second[0] >= 0) { o0 = h->pairOff[e.second[0]]; n0 = h->pairOff[e.second[0] + 1] - o0; }
     if (e.second[1] >= 0) { o1 = h->pairOff[e.second[1]]; n1 = h->pairOff[e.second[1] + 1] - o1; }
-    const long long nItems = std::max<long long>(1, (std::max(n0, n1) + 767) / 768);
+    const long long chunk = h->dense ? kDenseChunk : kListChunk;
+    const long long nItems = std::max<long long>(1, (std::max(n0, n1) + chunk - 1) / chunk);
     const long long c0 = (n0 + nItems - 1) / nItems, c1 = (n1 + nItems - 1) / nItems;
     for (long long k = 0; k < nItems; ++k) {
       const long long b0 = o0 + std::min(n0, k * c0), e0 = o0 + std::min(n0, (k + 1) * c0);
@@ -1417,9 +1468,15 @@ static void enqueueCost(Ctx& c, const double* x) {
     const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);  // (scope of the fast kernels)
     if (fast) {
       CVD_DISPATCH_KD(c.KD, {
-        allowLds(k_cost_items_fast<KD>, lds);
-        hipLaunchKernelGGL((k_cost_items_fast<KD>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
-                           h->dCostItem.p);
+        if (h->dense) {
+          allowLds((k_cost_items_fast<KD, true>), lds);
+          hipLaunchKernelGGL((k_cost_items_fast<KD, true>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                             h->dCostItem.p);
+        } else {
+          allowLds((k_cost_items_fast<KD, false>), lds);
+          hipLaunchKernelGGL((k_cost_items_fast<KD, false>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                             h->dCostItem.p);
+        }
       });
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
@@ -1482,10 +1539,17 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
     h->dAsmScratch.ensure(static_cast<size_t>(h->nAsmSlots) * (B * (B + 1) / 2 + B + 4));
     const AsmWork work{h->dAsmParts.p, h->dAsmUnits.p, h->dAsmScratch.p, h->dAsmCount.p};
     CVD_DISPATCH_KD(c.KD, {
-      allowLds(k_assemble_fast<KD>, ldsFast);
-      hipLaunchKernelGGL((k_assemble_fast<KD>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
-                         h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
-                         h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+      if (h->dense) {
+        allowLds((k_assemble_fast<KD, true>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<KD, true>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
+                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+      } else {
+        allowLds((k_assemble_fast<KD, false>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<KD, false>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
+                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+      }
     });
   } else {
     const AsmPanels panels = makePanels(static_cast<int>(B), (kMaxLds - ldsRest) / 8, panelCap);
@@ -1597,18 +1661,34 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       // (benchmark: 883 items, 44 -> 39.5 us).
       static const int forcedNT = []() { const char* e = std::getenv("CVD_PAIRS_NT"); return e ? std::atoi(e) : 0; }();
       const int nt = forcedNT ? forcedNT : (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
-#define CVD_LAUNCH_PAIRS_FAST(NTV)                                                                                       \
+      // SPEC = 1: the default pipeline's variant (one value parameter, ReproDisparity, Cauchy) fixed at compile time
+      const bool spec = c.L.N == 1 && c.L.lossType == CVD_STATIC_REPRO_DISPARITY && c.L.robustKind == 0;
+#define CVD_LAUNCH_PAIRS_FAST_S(NTV, SPECV)                                                                              \
       CVD_DISPATCH_KD(c.KD, {                                                                                            \
-        allowLds((k_matvec_pairs_fast<KD, NTV>), ldsFast);                                                               \
+        allowLds((k_matvec_pairs_fast<KD, NTV, SPECV>), ldsFast);                                                        \
         if (evStart)                                                                                                     \
-          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV>), dim3(c.nItems), dim3(NTV), ldsFast, s, evStart, evStop, 0, \
+          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV, SPECV>), dim3(c.nItems), dim3(NTV), ldsFast, s, evStart, evStop, 0, \
                                 c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                \
         else                                                                                                             \
-          hipLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV>), dim3(c.nItems), dim3(NTV), ldsFast, s, c.L, c.T, c.it, x,   \
+          hipLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV, SPECV>), dim3(c.nItems), dim3(NTV), ldsFast, s, c.L, c.T, c.it, x, \
                              fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                                      \
       })
-      if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
+#define CVD_LAUNCH_PAIRS_FAST(NTV) do { if (spec) CVD_LAUNCH_PAIRS_FAST_S(NTV, 1); else CVD_LAUNCH_PAIRS_FAST_S(NTV, 0); } while (0)
+      if (h->dense) {
+        // dense mode: flow / mask / depth read directly (17 B per pixel pair), grid columns in 8 lane-keyed private copies
+        const size_t ldsDense = ldsFast + 8 * 2 * B * 8;
+        CVD_DISPATCH_KD(c.KD, {
+          allowLds((k_matvec_pairs_fast<KD, 256, 1, true>), ldsDense);
+          if (evStart)
+            hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, 1, true>), dim3(c.nItems), dim3(256), ldsDense, s, evStart, evStop, 0,
+                                  c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+          else
+            hipLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, 1, true>), dim3(c.nItems), dim3(256), ldsDense, s, c.L, c.T, c.it, x,
+                               fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+        });
+      } else if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
       else CVD_LAUNCH_PAIRS_FAST(256);
+#undef CVD_LAUNCH_PAIRS_FAST_S
 #undef CVD_LAUNCH_PAIRS_FAST
     } else {
       CVD_DISPATCH(c.KD, c.KS, {
@@ -1747,9 +1827,15 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
                         c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
       if (fast) {
         CVD_DISPATCH_KD(c.KD, {
-          allowLds(k_coarse_edges_fast<KD>, ldsE);
-          hipLaunchKernelGGL((k_coarse_edges_fast<KD>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
-                             C.itemEdgeDev.p, C.edges.p, C.dropDiag.p);
+          if (h->dense) {
+            allowLds((k_coarse_edges_fast<KD, true>), ldsE);
+            hipLaunchKernelGGL((k_coarse_edges_fast<KD, true>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
+                               C.itemEdgeDev.p, C.edges.p, C.dropDiag.p);
+          } else {
+            allowLds((k_coarse_edges_fast<KD, false>), ldsE);
+            hipLaunchKernelGGL((k_coarse_edges_fast<KD, false>), dim3(c.nItems), dim3(256), ldsE, s, c.L, c.T, c.it, x, fcBuf,
+                               C.itemEdgeDev.p, C.edges.p, C.dropDiag.p);
+          }
         });
       } else {
         CVD_DISPATCH(c.KD, c.KS, {
@@ -1961,12 +2047,13 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   tapCounts(c.L, c.KD, c.KS);
   compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
   refreshMedians(h);
-  c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
+  c.T = makeTable(h);
   c.nItems = static_cast<int>(h->itemFa.size());
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   bindTriplets(c, p, kind);
+  if (c.L.includeStatic) checkDenseScope(h, c.L, c.KS, c.trip);
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
@@ -2250,7 +2337,7 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
     h->dQ.ensure(n); h->dHd.ensure(n); h->dMask.ensure(n);
     h->dH.ensure(n * Bmax); h->dMinv.ensure(n * Bmax);
     // one undirected work item per ~768 constraints and pair: bounded by pairs + constraints / 768
-    h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / 768) + 1) * 2 * Bmax);
+    h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / (h->dense ? kDenseChunk : kListChunk)) + 1) * 2 * Bmax);
   }
   cvd_solve_summary total{};
   auto accumulate = [&](const cvd_solve_summary& s, bool first) {
@@ -2332,11 +2419,12 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   tapCounts(c.L, c.KD, c.KS);
   compileTable(h, range, wantsTriplets(p, PK_POSE_STEP));
   refreshMedians(h);
-  c.T = Table{h->dNdc.p, h->dDsrc.p, h->dPairA.p, h->dPairB.p, h->dPairOff.p};
+  c.T = makeTable(h);
   c.nItems = static_cast<int>(h->itemFa.size());
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   bindTriplets(c, p, PK_POSE_STEP);
+  checkDenseScope(h, c.L, c.KS, c.trip);
   h->coarseOn = false;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);
@@ -2796,6 +2884,20 @@ int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t h
     h->tableValid = false;
     h->P = 0;
     h->C = 0;
+    h->dense = false;
+    // everything keyed by frame index belongs to the previous video (stale triplet centres / pair graph
+    // indexed past a smaller F)
+    h->haveTriplets = false;
+    h->tripCenter.clear();
+    h->tripOff.clear();
+    h->tripC = 0;
+    h->tripActive.clear();
+    h->haveGlobalEdges = false;
+    h->globalEdges.clear();
+    h->coarse.valid = false;
+    h->pairA.clear();
+    h->pairB.clear();
+    h->pairOff.assign(1, 0);
   });
 }
 
@@ -2831,7 +2933,19 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
       if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
       return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
     });
+    if (numPairs < 0 || !offsets || (numPairs > 0 && !pairFrames)) throw std::runtime_error("invalid pair constraints");
+    if (offsets[0] != 0) throw std::runtime_error("pair constraint offsets must start at 0");
+    for (int i = 0; i < numPairs; ++i)
+      if (offsets[i + 1] < offsets[i]) throw std::runtime_error("pair constraint offsets must be non-decreasing");
+    for (int k = 1; k < numPairs; ++k)  // (order is sorted by key: duplicates are neighbours)
+      if (pairFrames[2 * order[k]] == pairFrames[2 * order[k - 1]] && pairFrames[2 * order[k] + 1] == pairFrames[2 * order[k - 1] + 1])
+        throw std::runtime_error("duplicate directed frame pair in the constraint list (merge the two lists: the reference keeps "
+                                 "one entry per pair key, lib/FlowConstraints.h:149)");
     const long long C = offsets[numPairs];
+    if (C > 0 && !loc4) throw std::runtime_error("invalid pair constraints");
+    h->dense = false;
+    h->dFlow.release();
+    h->dFMask.release();
     h->P = numPairs;
     h->C = C;
     h->pairA.resize(numPairs);
@@ -2863,6 +2977,48 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
     h->dStatic.upload(st.data(), C, s);
     h->dCPair.upload(cpair.data(), C, s);
     HIP_CHECK(hipStreamSynchronize(s));
+    h->tableValid = false;
+  });
+}
+
+int32_t cvd_set_pair_flows(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames, const float* flow, const uint8_t* mask) {
+  CVD_TRY(h, {
+    if (h->F <= 0) throw std::runtime_error("no video set");
+    if (numPairs < 0 || (numPairs > 0 && (!pairFrames || !flow || !mask))) throw std::runtime_error("invalid pair flows");
+    const long long npx = static_cast<long long>(h->W) * h->H;
+    // the reference iterates a std::map<std::pair<int,int>> (lib/FlowConstraints.h:149): sort by key, reject duplicates
+    std::vector<int> order(numPairs);
+    for (int i = 0; i < numPairs; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
+      return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
+    });
+    h->pairA.resize(numPairs);
+    h->pairB.resize(numPairs);
+    h->pairOff.assign(numPairs + 1, 0);
+    for (int k = 0; k < numPairs; ++k) {
+      const int a = pairFrames[2 * order[k]], b = pairFrames[2 * order[k] + 1];
+      if (a < 0 || a >= h->F || b < 0 || b >= h->F) throw std::runtime_error("pair frame out of range");
+      if (k > 0 && h->pairA[k - 1] == a && h->pairB[k - 1] == b) throw std::runtime_error("duplicate frame pair");
+      h->pairA[k] = a;
+      h->pairB[k] = b;
+      h->pairOff[k + 1] = static_cast<long long>(k + 1) * npx;
+    }
+    hipStream_t s = h->stream;
+    h->dFlow.ensure(static_cast<size_t>(std::max(numPairs, 1)) * npx);
+    h->dFMask.ensure(static_cast<size_t>(std::max(numPairs, 1)) * npx);
+    for (int k = 0; k < numPairs; ++k) {  // pair-major in key order on the device
+      const size_t src = static_cast<size_t>(order[k]) * npx, dst = static_cast<size_t>(k) * npx;
+      HIP_CHECK(hipMemcpyAsync(h->dFlow.p + dst, reinterpret_cast<const float2*>(flow) + src, npx * sizeof(float2), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(h->dFMask.p + dst, mask + src, npx, hipMemcpyHostToDevice, s));
+    }
+    h->dPairA.upload(h->pairA.data(), numPairs, s);
+    h->dPairB.upload(h->pairB.data(), numPairs, s);
+    h->dPairOff.upload(h->pairOff.data(), numPairs + 1, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->P = numPairs;
+    h->C = static_cast<long long>(numPairs) * npx;
+    h->dense = true;
     h->tableValid = false;
   });
 }

@@ -26,7 +26,76 @@ struct Table {
   const int* pairA;     // per pair
   const int* pairB;
   const long long* pairOff;  // P + 1
+  // Dense mode (cvd_set_pair_flows: the reference's matchSeparation = 0 regime, lib/FlowConstraints.cpp:315-329, 381-465 --
+  // every masked pixel whose flow target rounds into the image is a constraint): there is NO table; constraint slot c of
+  // pair p is pixel c - pairOff[p] (pairOff[p] = p * W * H) and the kernels read flow / mask / depth directly,
+  // 8 + 1 + 4 + 4 = 17 B per pixel pair (SURVEY.md 8d "dense mode").
+  const float2* flow;           // [P][H][W] pixels
+  const unsigned char* fmask;   // [P][H][W]
+  const float* depth;           // [F][H][W] source depth
+  int W, H;
+  float sx, sy, invAspect;      // loc = pixel * (1 / W, invAspect / H), float as in the reference (:371)
 };
+
+// One constraint of the pair-major / frame-major fast kernels: (ndc of both end points, the two source depths); false =
+// skipped.  DENSE = false: the compiled 24 B table entry.  DENSE = true: built on the fly from the flow / mask / depth
+// images with the reference's float arithmetic -- candidate test of FlowConstraintsCollection::compute (reference
+// lib/FlowConstraints.cpp:436-460: mask, target pixel int(x + flow + 0.5) in bounds), constraint scaling (:371), then the
+// Observation constructor (lib/PoseOptimizer.cpp:104-116, identical to k_build_table).  fa / fb = source / target frame,
+// pixBase = first slot of the pair.
+template <bool DENSE>
+__device__ __forceinline__ bool loadConstraint(const Table& T, long long c, long long pixBase, int fa, int fb, float4& n,
+                                               float2& d) {
+  if constexpr (!DENSE) {
+    d = T.dsrc[c];
+    if (!(d.x > 0.f)) return false;
+    n = T.ndc[c];
+    return true;
+  } else {
+    if (!T.fmask[c]) return false;
+    const int pix = static_cast<int>(c - pixBase);
+    const int iy = pix / T.W, ix = pix - iy * T.W;
+    const float2 f = T.flow[c];
+    const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
+    if (!(isfinite(fx1) && isfinite(fy1))) return false;
+    const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
+    if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
+    const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
+    const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
+    n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
+    n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
+    n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
+    n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
+    int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
+    int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
+    int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
+    int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
+    ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
+    bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
+    const size_t fs = static_cast<size_t>(T.W) * T.H;
+    const float da = T.depth[fa * fs + static_cast<size_t>(ay) * T.W + ax];
+    const float db = T.depth[fb * fs + static_cast<size_t>(by) * T.W + bx];
+    if (!(isfinite(da) && da > 0.f && isfinite(db) && db > 0.f)) return false;
+    d = make_float2(da, db);
+    return true;
+  }
+}
+
+// Valid constraints of the dense mode (what k_build_table counts for the list mode).
+__global__ void k_dense_count(Table T, int P, const unsigned char* __restrict__ inRange, unsigned long long* __restrict__ nValid) {
+  const long long npx = static_cast<long long>(T.W) * T.H;
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (c < npx * P) {
+    const int p = static_cast<int>(c / npx);
+    const int fa = T.pairA[p], fb = T.pairB[p];
+    float4 n;
+    float2 d;
+    ok = inRange[fa] && inRange[fb] && fa != fb && loadConstraint<true>(T, c, static_cast<long long>(p) * npx, fa, fb, n, d);
+  }
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(nValid, static_cast<unsigned long long>(__popcll(b)));
+}
 
 // Work items of the pair-major kernels: one UNDIRECTED frame pair {fa < fb} with a chunk of the constraints
 // of the directed pair fa->fb (range[0..1]) and of fb->fa (range[2..3]); either may be empty.  Both directions
@@ -1728,7 +1797,7 @@ __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, 
 // losses): the residual chain of the fast kernels with register-resident taps.  The generic k_cost_items keeps the taps
 // of Sample<KD, KS> in dynamically indexed arrays, i.e. in scratch memory (672 B per lane, stores and dependent reloads
 // per constraint): 53 us for 1.09 M constraints where the arithmetic needs ~10.
-template <int KD>
+template <int KD, bool DENSE = false>
 __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                          const FrameConst* __restrict__ fc, double* __restrict__ costItem) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1763,10 +1832,12 @@ __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Item
     const double fya = Fa.fy, fxa = Fa.fy * A;
     const double fyb = Fb.fy;
     const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+    const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
+    const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
     for (long long c = cb + tid; c < ce; c += 256) {
-      const float2 d = T.dsrc[c];
-      if (!(d.x > 0.f)) continue;
-      const float4 nd = T.ndc[c];
+      float4 nd;
+      float2 d;
+      if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
       const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
       double Da, Db;
       if (N == 0) {
@@ -1824,10 +1895,17 @@ __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Item
   if (tid == 0) costItem[item] = 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// A wave-uniform double as a scalar (SGPR pair): the compiler cannot prove that an LDS load is uniform.
+__device__ __forceinline__ double uniformValue(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
 constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 
-template <int KD, int NT>
+// SPEC = 1: the default pipeline's variant fixed at compile time (one value parameter per vertex, ReproDisparity loss,
+// Cauchy robustifier): the branches on the runtime Layout fields drop out of the constraint loop.
+template <int KD, int NT, int SPEC = 0, bool DENSE = false>
 __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
@@ -1851,6 +1929,11 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
   double* E = reinterpret_cast<double*>(fcs + 2);  // E_a[9], E_b[9]
   double* red = E + 18;                            // 27 reduced accumulators
   double* W = red + 32;                            // transposed reduction scratch: kRedVals rows x kRedStride
+  // Dense mode: neighbouring lanes are neighbouring pixels and hit the SAME grid vertices -- 64-way same-address LDS
+  // atomics.  The grid columns are therefore accumulated into kPriv lane-keyed private copies (after W) and folded
+  // before the epilogue.
+  constexpr int kPriv = DENSE ? 8 : 1;
+  double* qpriv = W + static_cast<size_t>(kRedVals) * kRedStride;  // DENSE: [kPriv][2][B]
   double* cl = W;                                  // prologue only: 2 x kCB coarse corrections
   const int item = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1891,6 +1974,8 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
       qb[i] = 0.0;
     }
   }
+  if constexpr (DENSE)
+    for (int i = tid; i < kPriv * 2 * B; i += NT) qpriv[i] = 0.0;
   __syncthreads();
   if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
 #pragma unroll
@@ -1919,7 +2004,8 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
   }
   __syncthreads();
 
-  const int N = L.N;
+  const int N = SPEC ? 1 : L.N;
+  const int lossType = SPEC ? static_cast<int>(kLossDisparity) : L.lossType;
   const double A = L.aspect;
   // The pose-level accumulators are kept per ROLE (source / target) and swapped between the two directions, so
   // that one reduction serves both: O_src of direction 0 and O_tgt of direction 1 both contract with dR of frame
@@ -1950,15 +2036,26 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
 #pragma unroll
     for (int n = 0; n < 2; ++n) { const double o = gDa[n]; gDa[n] = gDb[n]; gDb[n] = o; }
   }
-  const double fya = Fa.fy, fxa = Fa.fy * A;
-  const double fyb = Fb.fy;
+  // The frame constants are the same for every lane: hand them to the loop as SCALAR values (v_readfirstlane of the
+  // LDS copy -> SGPRs; a VALU instruction takes one scalar operand).  Rotations and translations of both frames are
+  // 24 doubles = 48 VGPRs less per lane: 193 -> 14x VGPRs, three waves per SIMD instead of two.
+  double RaU[9], RbU[9], taU[3], tbU[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { RaU[i] = uniformValue(Fa.R[i]); RbU[i] = uniformValue(Fb.R[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { taU[i] = uniformValue(Fa.t[i]); tbU[i] = uniformValue(Fb.t[i]); }
+  // (E and the pose part of p stay LDS broadcast reads inside the loop: as scalars too they overflow the SGPR file --
+  // 80 spills -- and hoisted into VGPRs they cost the third wave)
+  const double fya = uniformValue(Fa.fy), fxa = fya * A;
+  const double fyb = uniformValue(Fb.fy);
   const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
 
-
+  const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
+  const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
   for (long long c = cb + tid; c < ce; c += NT) {
-    const float2 d = T.dsrc[c];
-    if (!(d.x > 0.f)) continue;
-    const float4 nd = T.ndc[c];
+    float4 nd;
+    float2 d;
+    if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
     const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
     FastTaps<KD> ta, tb;
     fastGather<KD>(L, nd.x, nd.y, ta);
@@ -1998,12 +2095,12 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
     const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
     const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
     const double ca[3] = {pax * fxa, pay * fya, -1.0};
-    const double Rca[3] = {dot3(Fa.R, ca), dot3(Fa.R + 3, ca), dot3(Fa.R + 6, ca)};
-    const double v[3] = {Fa.t[0] + Rca[0] * Da - Fb.t[0], Fa.t[1] + Rca[1] * Da - Fb.t[1],
-                         Fa.t[2] + Rca[2] * Da - Fb.t[2]};
-    const double q0 = Fb.R[0] * v[0] + Fb.R[3] * v[1] + Fb.R[6] * v[2];
-    const double q1 = Fb.R[1] * v[0] + Fb.R[4] * v[1] + Fb.R[7] * v[2];
-    const double q2 = Fb.R[2] * v[0] + Fb.R[5] * v[1] + Fb.R[8] * v[2];
+    const double Rca[3] = {dot3(RaU, ca), dot3(RaU + 3, ca), dot3(RaU + 6, ca)};
+    const double v[3] = {taU[0] + Rca[0] * Da - tbU[0], taU[1] + Rca[1] * Da - tbU[1],
+                         taU[2] + Rca[2] * Da - tbU[2]};
+    const double q0 = RbU[0] * v[0] + RbU[3] * v[1] + RbU[6] * v[2];
+    const double q1 = RbU[1] * v[0] + RbU[4] * v[1] + RbU[7] * v[2];
+    const double q2 = RbU[2] * v[0] + RbU[5] * v[1] + RbU[8] * v[2];
     const double zz = -q2;
     const double iz = 1.0 / zz;
     const double u = q0 * iz * ifxb;
@@ -2011,7 +2108,7 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
     const double r0 = (u - pbx) * L.ws;
     const double r1 = (vv - pby) * L.ws;
     double r2, dr2dA, dr2dDb;
-    if (L.lossType == kLossDisparity) {
+    if (lossType == kLossDisparity) {
       const bool zo = !(zz < eps), bo = !(Db < eps);
       const double zc = zo ? zz : eps, bc = bo ? Db : eps;
       const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / bc;
@@ -2021,7 +2118,7 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
     } else {
       const bool zIsMax = !(zz < Db), zIsMin = !(Db < zz);
       const double mx = zIsMax ? zz : Db, mn = zIsMin ? zz : Db;
-      if (L.lossType == kLossRatio) {
+      if (lossType == kLossRatio) {
         r2 = (mx / mn - 1.0) * L.wd;
         const double dmx = 1.0 / mn, dmn = -mx / (mn * mn);
         dr2dA = ((zIsMax ? dmx : 0.0) + (zIsMin ? dmn : 0.0)) * L.wd;
@@ -2033,20 +2130,21 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
         dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
       }
     }
-    const double rho1 = robustRho1(L, r0 * r0 + r1 * r1 + r2 * r2);
+    const double sq = r0 * r0 + r1 * r1 + r2 * r2;
+    const double rho1 = SPEC ? 1.0 / (1.0 + sq * L.cauchyC) : robustRho1(L, sq);
 
     // ---- forward: dX, dq, t
     const double cf[3] = {pax * A, pay, 0.0};
-    const double Rcf[3] = {Fa.R[0] * cf[0] + Fa.R[1] * cf[1], Fa.R[3] * cf[0] + Fa.R[4] * cf[1],
-                           Fa.R[6] * cf[0] + Fa.R[7] * cf[1]};
+    const double Rcf[3] = {RaU[0] * cf[0] + RaU[1] * cf[1], RaU[3] * cf[0] + RaU[4] * cf[1],
+                           RaU[6] * cf[0] + RaU[7] * cf[1]};
     const double Eca[3] = {dot3(Esrc, ca), dot3(Esrc + 3, ca), dot3(Esrc + 6, ca)};
     const double pfa = pa[6], pfb = pb[6];
     double w3[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) w3[i] = pa[i] + Da * (Eca[i] + pfa * Rcf[i]) + sDa * Rca[i] - pb[i];
-    const double dq0 = Fb.R[0] * w3[0] + Fb.R[3] * w3[1] + Fb.R[6] * w3[2] + Eb[0] * v[0] + Eb[3] * v[1] + Eb[6] * v[2];
-    const double dq1 = Fb.R[1] * w3[0] + Fb.R[4] * w3[1] + Fb.R[7] * w3[2] + Eb[1] * v[0] + Eb[4] * v[1] + Eb[7] * v[2];
-    const double dq2 = Fb.R[2] * w3[0] + Fb.R[5] * w3[1] + Fb.R[8] * w3[2] + Eb[2] * v[0] + Eb[5] * v[1] + Eb[8] * v[2];
+    const double dq0 = RbU[0] * w3[0] + RbU[3] * w3[1] + RbU[6] * w3[2] + Eb[0] * v[0] + Eb[3] * v[1] + Eb[6] * v[2];
+    const double dq1 = RbU[1] * w3[0] + RbU[4] * w3[1] + RbU[7] * w3[2] + Eb[1] * v[0] + Eb[4] * v[1] + Eb[7] * v[2];
+    const double dq2 = RbU[2] * w3[0] + RbU[5] * w3[1] + RbU[8] * w3[2] + Eb[2] * v[0] + Eb[5] * v[1] + Eb[8] * v[2];
     const double wiz = L.ws * iz;
     const double m00 = wiz * ifxb, m11 = wiz * ifyb, m02 = wiz * u, m12 = wiz * vv;
     const double pfr = pfb * ifyb;
@@ -2057,8 +2155,8 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
     // ---- backward
     const double yq0 = m00 * t0, yq1 = m11 * t1, yq2 = m02 * t0 + m12 * t1 - dr2dA * t2;
     aFb -= (L.ws * u * t0 + L.ws * vv * t1) * ifyb;
-    const double yX[3] = {Fb.R[0] * yq0 + Fb.R[1] * yq1 + Fb.R[2] * yq2, Fb.R[3] * yq0 + Fb.R[4] * yq1 + Fb.R[5] * yq2,
-                          Fb.R[6] * yq0 + Fb.R[7] * yq1 + Fb.R[8] * yq2};
+    const double yX[3] = {RbU[0] * yq0 + RbU[1] * yq1 + RbU[2] * yq2, RbU[3] * yq0 + RbU[4] * yq1 + RbU[5] * yq2,
+                          RbU[6] * yq0 + RbU[7] * yq1 + RbU[8] * yq2};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       aT[i] += yX[i];
@@ -2078,26 +2176,29 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
         gDa[0] += ga * da; gDa[1] += ga;
         gDb[0] += gb * db; gDb[1] += gb;
       } else {
+      // (dense: this lane's private copy; qa / qb are swapped per direction, the private copies are indexed by role)
+      double* qaw = DENSE ? qpriv + (static_cast<size_t>(tid & (kPriv - 1)) * 2 + dir) * B : qa;
+      double* qbw = DENSE ? qpriv + (static_cast<size_t>(tid & (kPriv - 1)) * 2 + (dir ^ 1)) * B : qb;
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
         if (ta.ok(k)) {
           const int ia = ta.I(k);
           const double wa = ta.Wt(k);
           if (N == 2) {
-            atomicAdd(&qa[7 + ia * 2], ga * wa * da);
-            atomicAdd(&qa[7 + ia * 2 + 1], ga * wa);
+            atomicAdd(&qaw[7 + ia * 2], ga * wa * da);
+            atomicAdd(&qaw[7 + ia * 2 + 1], ga * wa);
           } else {
-            atomicAdd(&qa[7 + ia], ga * wa * da);
+            atomicAdd(&qaw[7 + ia], ga * wa * da);
           }
         }
         if (tb.ok(k)) {
           const int ib = tb.I(k);
           const double wb = tb.Wt(k);
           if (N == 2) {
-            atomicAdd(&qb[7 + ib * 2], gb * wb * db);
-            atomicAdd(&qb[7 + ib * 2 + 1], gb * wb);
+            atomicAdd(&qbw[7 + ib * 2], gb * wb * db);
+            atomicAdd(&qbw[7 + ib * 2 + 1], gb * wb);
           } else {
-            atomicAdd(&qb[7 + ib], gb * wb * db);
+            atomicAdd(&qbw[7 + ib], gb * wb * db);
           }
         }
       }
@@ -2176,6 +2277,20 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
   }
   __syncthreads();
   { double* t = qa; qa = qb; qb = t; }  // undo the role swap
+  if constexpr (DENSE) {
+    // private copy [k][0] collected frame fa's grid columns (source of direction 0, target of direction 1), [k][1] fb's
+    for (int i = tid; i < B; i += NT) {
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int k = 0; k < kPriv; ++k) {
+        sa += qpriv[(static_cast<size_t>(k) * 2 + 0) * B + i];
+        sb += qpriv[(static_cast<size_t>(k) * 2 + 1) * B + i];
+      }
+      qa[i] += sa;
+      qb[i] += sb;
+    }
+    __syncthreads();
+  }
   // rows are grouped by frame (slot = position in the frame's item list) so that k_matvec_finish streams them
   double* outA = qPart + static_cast<size_t>(it.slot[item * 2]) * B;
   double* outB = qPart + static_cast<size_t>(it.slot[item * 2 + 1]) * B;
@@ -2204,7 +2319,7 @@ __device__ unsigned long long g_asmProf[2048 * 16];
 #else
 #define ASM_STAMP(slot) do {} while (0)
 #endif
-template <int KD>
+template <int KD, bool DENSE = false>
 __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
@@ -2276,10 +2391,11 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
       const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
       const long long cBegin = T.pairOff[p] + __builtin_amdgcn_readfirstlane(unit.y);
       const long long cEnd = cBegin + kAsmUnit < T.pairOff[p + 1] ? cBegin + kAsmUnit : T.pairOff[p + 1];
+      const int fsrc = side ? o : f, ftgt = side ? f : o;
       for (long long c = cBegin + lane; c < cEnd; c += 64) {
-        const float2 d = T.dsrc[c];
-        if (!(d.x > 0.f)) continue;
-        const float4 nd = T.ndc[c];
+        float4 nd;
+        float2 d;
+        if (!loadConstraint<DENSE>(T, c, T.pairOff[p], fsrc, ftgt, nd, d)) continue;
         const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
         FastTaps<KD> ta, tb;
         fastGather<KD>(L, nd.x, nd.y, ta);

@@ -248,6 +248,70 @@ def make_video(num_frames, width, height, seed=1234, pairs=None, spacing=12.5, f
               "field_amp": field_amp})
 
 
+def make_dense_flows(video: SyntheticVideo, flow_noise_px=0.25, seed=99, invalid_fraction=0.02):
+    """Flow and mask IMAGES of every directed pair of `video` (what flow/flow_%06d_%06d.raw and flow_mask/mask_*.png hold,
+    reference lib/FlowConstraints.cpp:226-255): flow [P, H, W, 2] float32 in pixels from the true geometry + noise,
+    mask [P, H, W] uint8 (0 where the target falls outside the image or behind the camera, plus a random
+    `invalid_fraction` standing in for the forward/backward consistency check).  Input of the dense mode."""
+    rng = np.random.default_rng(seed)
+    F, W, H = video.num_frames, video.width, video.height
+    A = float(video.aspect)
+    fy = video.true_fy
+    fx = fy * A
+    R = rodrigues(video.true_w)
+    t = video.true_t
+    gx, gy = np.meshgrid(np.arange(W), np.arange(H))
+    nx = -1.0 + 2.0 * gx / W
+    ny = 1.0 - 2.0 * gy / H
+    P = len(video.pairs)
+    flow = np.zeros((P, H, W, 2), np.float32)
+    mask = np.zeros((P, H, W), np.uint8)
+    cam = np.stack([nx * fx, ny * fy, -np.ones_like(nx)], axis=-1)
+    for k, (a, b) in enumerate(np.asarray(video.pairs).tolist()):
+        D = scene_depth(t[a], R[a], fx, fy, nx, ny)
+        X = t[a] + D[..., None] * (cam @ R[a].T)
+        q = (X - t[b]) @ R[b]
+        z = -q[..., 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = q[..., 0] / z / fx
+            v = q[..., 1] / z / fy
+        x1 = (u + 1.0) * 0.5 * W + rng.normal(0.0, flow_noise_px, size=u.shape)
+        y1 = (1.0 - v) * 0.5 * H + rng.normal(0.0, flow_noise_px, size=v.shape)
+        ok = (z > 1e-3) & np.isfinite(x1) & np.isfinite(y1) & (x1 > -0.5) & (x1 < W - 0.5) & (y1 > -0.5) & (y1 < H - 0.5)
+        ok &= rng.uniform(size=ok.shape) >= invalid_fraction
+        flow[k, ..., 0] = np.where(ok, x1 - gx, 0.0)
+        flow[k, ..., 1] = np.where(ok, y1 - gy, 0.0)
+        mask[k] = np.where(ok, 255, 0)
+    return flow, mask
+
+
+def dense_constraints_from_flows(video: SyntheticVideo, flow, mask):
+    """The constraint list the reference's FlowConstraintsCollection::compute produces from these images with
+    matchSeparation = 0 (lib/FlowConstraints.cpp:436-460, 352-397: every masked pixel whose target int(x + flow + 0.5) is
+    in bounds; loc = pixel * (1 / w, invAspect / h) in float).  Returns (offsets [P + 1] int64, loc [C, 4] float32) in
+    row-major pixel order per pair (the reference orders by corner response: irrelevant to the cost, a sum)."""
+    W, H = video.width, video.height
+    sx = np.float32(1.0) / np.float32(W)
+    sy = np.float32(video.inv_aspect) / np.float32(H)
+    gx, gy = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    off, chunks = [0], []
+    for k in range(flow.shape[0]):
+        fx1 = gx + flow[k, ..., 0].astype(np.float32)
+        fy1 = gy + flow[k, ..., 1].astype(np.float32)
+        with np.errstate(invalid="ignore"):
+            ix1 = np.trunc(fx1 + np.float32(0.5))   # C++ float -> int conversion truncates towards zero
+            iy1 = np.trunc(fy1 + np.float32(0.5))
+        sel = (mask[k] != 0) & np.isfinite(fx1) & np.isfinite(fy1) & (ix1 >= 0) & (ix1 < W) & (iy1 >= 0) & (iy1 < H)
+        l = np.empty((int(sel.sum()), 4), np.float32)
+        l[:, 0] = gx[sel] * sx
+        l[:, 1] = gy[sel] * sy
+        l[:, 2] = fx1[sel] * sx
+        l[:, 3] = fy1[sel] * sy
+        chunks.append(l)
+        off.append(off[-1] + l.shape[0])
+    return np.asarray(off, np.int64), (np.concatenate(chunks, 0) if chunks else np.zeros((0, 4), np.float32))
+
+
 def make_triplets(video: SyntheticVideo, spacing=25.0, seed=77, flow_noise_px=0.25, dynamic_fraction=0.25):
     """Triplet constraints of the scene-flow smoothness loss (reference lib/FlowConstraints.h:116-205, keyed by the
     centre frame): points sampled in frame c, projected with the true geometry into c-1 and c+1 (+ flow noise).

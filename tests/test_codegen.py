@@ -22,9 +22,11 @@ SOURCE = f'''
 #include "{CSRC}/cvd_coarse.h"
 namespace cvd {{
 template __global__ void k_cost_items_fast<4>(Layout, Table, Items, const double*, const FrameConst*, double*);
-template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*);
+template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*, double*);
 template __global__ void k_matvec_pairs_fast<4, 128>(Layout, Table, Items, const double*, const FrameConst*, const double*,
                                                       const double*, const double*, const double*, int, double*, CoarseView);
+template __global__ void k_matvec_pairs_fast<4, 256, 1>(Layout, Table, Items, const double*, const FrameConst*, const double*,
+                                                         const double*, const double*, const double*, int, double*, CoarseView);
 template __global__ void k_block_inverse_mfma<8, 10>(Layout, const double*, const double*, float*, int*);
 template __global__ void k_cost_items<4, 0>(Layout, Table, Items, const double*, const FrameConst*, double*);
 }}
@@ -54,11 +56,21 @@ def kernel_info(asm, name):
     return fields, body
 
 
-@pytest.mark.parametrize("name", ["17k_cost_items_fast", "19k_coarse_edges_fast", "19k_matvec_pairs_fast"])
+@pytest.mark.parametrize("name", ["17k_cost_items_fast", "19k_coarse_edges_fast", "19k_matvec_pairs_fastILi4ELi128ELi0",
+                                  "19k_matvec_pairs_fastILi4ELi256ELi1"])
 def test_fast_kernels_use_no_scratch(asm, name):
     fields, body = kernel_info(asm, name)
     assert fields["private_segment_fixed_size"] == 0, fields
     assert "scratch_" not in body
+
+
+def test_specialised_pairs_product_fits_three_waves_per_simd(asm):
+    """The default pipeline's variant of the hot kernel (SPEC = 1: one value parameter, ReproDisparity, Cauchy fixed at compile
+    time; the frames' rotations / translations handed to the loop as scalars) must stay within 168 VGPRs = three waves per SIMD
+    (the runtime-variant kernel needs ~190: two)."""
+    fields, body = kernel_info(asm, "19k_matvec_pairs_fastILi4ELi256ELi1")
+    assert fields["next_free_vgpr"] <= 168, fields
+    assert "v_readfirstlane_b32" in body
 
 
 def test_generic_cost_kernel_is_the_one_with_scratch_resident_taps(asm):

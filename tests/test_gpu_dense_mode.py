@@ -1,0 +1,112 @@
+"""GPU parity of the DENSE mode (cvd_set_pair_flows: the reference's matchSeparation = 0 regime, lib/FlowConstraints.cpp:315-329,
+381-465 -- every masked pixel whose flow target rounds into the image is a constraint).  The device kernels read the flow /
+mask / depth images directly (17 B per pixel pair, no table); the oracle gets the equivalent constraint LIST, built from the same
+images by synth.dense_constraints_from_flows (a numpy restatement of the reference's candidate test and scaling)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from robust_cvd_amd import synth
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, XformDesc
+from tests.helpers import rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def Solver():
+    from robust_cvd_amd import api
+    return api.Solver
+
+
+def _setup(Solver, frames=6, w=96, h=56, seed=61):
+    v = synth.make_video(frames, w, h, seed=seed)
+    flow, mask = synth.make_dense_flows(v)
+    off, loc = synth.dense_constraints_from_flows(v, flow, mask)
+    hip, orc = Solver(0), Oracle()
+    for s in (hip, orc):
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.reset_poses()
+    hip.set_pair_flows(v.pairs, flow, mask)
+    orc.set_pair_constraints(v.pairs, off, loc, None)
+    return v, hip, orc, int(off[-1])
+
+
+@pytest.mark.parametrize("variant", ["global", "grid6x4", "grid17x10", "global_fixed_intrinsics"])
+def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant):
+    v, hip, orc, n = _setup(Solver)
+    F = v.num_frames
+    rng = np.random.default_rng(3)
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.02, (F, 6))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+    p = OptParams.defaults()
+    p.num_threads = 4
+    if variant == "global_fixed_intrinsics":
+        p.intr_opt = IntrinsicsOptimization.Fixed
+    res = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        s.reset_depth_xforms({"global": XformDesc.global_depth(), "global_fixed_intrinsics": XformDesc.global_depth(),
+                              "grid6x4": XformDesc.grid_depth(6, 4), "grid17x10": XformDesc.grid_depth(17, 10)}[variant])
+        s.reset_spatial_xforms(XformDesc.spatial())
+        th = s.get_xform_params()
+        s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)))
+        small = F * s.block_size() <= 300
+        res[k] = s.evaluate(p, 0.1, pose, want_gradient=True, want_hdiag=True, want_hfull=small)
+    a, b = res["hip"], res["oracle"]
+    assert hip.num_active_constraints() == n
+    assert a["num_residual_blocks"] == b["num_residual_blocks"]
+    assert abs(a["cost"] - b["cost"]) <= TOL * abs(b["cost"]), (a["cost"], b["cost"])
+    assert rel(a["gradient"], b["gradient"]) < TOL
+    assert rel(a["hdiag"], b["hdiag"]) < TOL
+    if a["hfull"] is not None:
+        assert rel(a["hfull"], b["hfull"]) < TOL   # the matrix-free product, column by column
+
+
+def test_dense_solve_reaches_the_oracle_minimum(Solver):
+    v, hip, orc, _ = _setup(Solver, frames=8, seed=62)
+    out = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        p = OptParams.defaults()
+        p.num_threads = 8
+        p.ctf_long, p.ctf_short = 6, 4
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[k] = (s.summary(), s.get_poses(), s.get_xform_params())
+    fh, fo = out["hip"][0]["final_cost"], out["oracle"][0]["final_cost"]
+    assert abs(fh - fo) <= 1e-6 * abs(fo), (fh, fo)
+    perr, rerr = synth.relative_pose_error(out["hip"][1]["position"], out["hip"][1]["orientation"],
+                                           out["oracle"][1]["position"], out["oracle"][1]["orientation"])
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+    assert rel(out["hip"][2], out["oracle"][2]) < 1e-3
+
+
+def test_dense_mode_and_the_equivalent_list_agree_on_the_device(Solver):
+    """The same constraints as images (dense kernels) and as a list (table kernels): identical problem, two code paths."""
+    v, hip, _, n = _setup(Solver, seed=63)
+    flow, mask = synth.make_dense_flows(v)
+    off, loc = synth.dense_constraints_from_flows(v, flow, mask)
+    p = OptParams.defaults()
+    res = {}
+    for k in ("dense", "list"):
+        if k == "list":
+            hip.set_pair_constraints(v.pairs, off, loc, None)
+        hip.reset_depth_xforms(XformDesc.grid_depth(6, 4))
+        hip.reset_spatial_xforms(XformDesc.spatial())
+        res[k] = hip.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+    assert abs(res["dense"]["cost"] - res["list"]["cost"]) <= 1e-12 * abs(res["list"]["cost"])
+    assert rel(res["dense"]["gradient"], res["list"]["gradient"]) < 1e-11
+    assert rel(res["dense"]["hdiag"], res["list"]["hdiag"]) < 1e-11
+
+
+def test_dense_mode_rejects_configurations_outside_its_scope(Solver):
+    v, hip, _, _ = _setup(Solver, frames=4, seed=64)
+    from robust_cvd_amd.ctypes_types import SpatialXformType
+    hip.reset_depth_xforms(XformDesc.global_depth())
+    hip.reset_spatial_xforms(XformDesc.spatial(SpatialXformType.BilinearGrid, 3, 2))
+    with pytest.raises(RuntimeError, match="dense mode"):
+        hip.evaluate(OptParams.defaults(), 0.1)

@@ -384,7 +384,8 @@ def test_normalize_depth_pair_loop_matches_oracle(Solver, variant):
         sm[k] = s.summary()
     assert sm["hip"]["num_residual_blocks"] == sm["oracle"]["num_residual_blocks"]
     assert abs(sm["hip"]["initial_cost"] - sm["oracle"]["initial_cost"]) <= 1e-9 * abs(sm["oracle"]["initial_cost"])
-    assert abs(sm["hip"]["final_cost"] - sm["oracle"]["final_cost"]) <= 1e-6 * abs(sm["oracle"]["final_cost"])
+    # (a global ScaleShift fits the scale regulariser exactly: both costs are ~1e-18 there)
+    assert abs(sm["hip"]["final_cost"] - sm["oracle"]["final_cost"]) <= 1e-6 * abs(sm["oracle"]["final_cost"]) + 1e-12
     assert rel(th["hip"], th["oracle"]) < 1e-3
     assert not np.all(th["hip"] == th["hip"][0])   # every frame keeps its own transform
 
