@@ -15,6 +15,7 @@ converging solves of that level (when a solve converges early the start state is
 
     python bench.py --gpus 1 --steps K --warmup W
     python bench.py --config 4 [--robust huber]      # BASELINE configs[4]: 1000 frames 640x384, 16x12 grid (one GPU)
+    python bench.py --dense --steps 8 --warmup 1     # configs[2] dense: every masked pixel of 1766 pairs (146 M constraints)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 N > 1 (default `--mode shard`): the SAME problem, frame pairs sharded across the ranks (robust_cvd_amd/sharding.py),
@@ -86,6 +87,8 @@ def prepare(solver, video, params, pair_graph=None):
     params.max_iterations = 1000  # (reference default; run_iterations() caps it for the timed solves)
     t_up = time.perf_counter()
     synth.load_into(solver, video, params.focal_long)  # the boundary hands over HOST buffers: depth maps + constraints
+    if getattr(video, "dense_flow", None) is not None:     # dense mode: flow / mask images replace the constraint list
+        solver.set_pair_flows(video.pairs, video.dense_flow, video.dense_mask)
     torch.cuda.synchronize()
     upload = time.perf_counter() - t_up
     if pair_graph is not None:  # pair-sharded mode: the whole problem's frame graph for the coarse preconditioner level
@@ -189,6 +192,9 @@ def main():
                     help="flow-list density (synth.hierarchical_pairs extra_offsets): 1 = the reference sampler's own list "
                          "(1766 pairs at 300 frames), 6 = the ~4k pairs of north_star (4140, default for --config 2)")
     ap.add_argument("--robust", choices=["cauchy", "huber"], default="cauchy", help="robust loss on the flow constraints")
+    ap.add_argument("--dense", action="store_true",
+                    help="dense mode (the reference's matchSeparation = 0): flow / mask images of every pair instead of the "
+                         "sampled constraint list; the kernels read flow, mask and depth directly, 17 B per pixel pair")
     ap.add_argument("--pcg-tol", type=float, default=None, help="development: PCG forcing value (default: the library's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figure on the reference sampler's 1766-pair list")
@@ -219,7 +225,7 @@ def main():
     cfg = CONFIGS[args.config]
     frames = args.frames or cfg["frames"]
     width, height = cfg["width"], cfg["height"]
-    level = args.pairs_level if args.pairs_level is not None else (6 if args.config == 2 else 1)
+    level = args.pairs_level if args.pairs_level is not None else (6 if args.config == 2 and not args.dense else 1)
     robust = 1 if args.robust == "huber" else 0
     params = OptParams.defaults()
     params.ctf_long, params.ctf_short = cfg["ctf"]
@@ -232,8 +238,14 @@ def main():
 
     def measure(pairs_level, steps, warmup, timing, seed_offset=0):
         """prepare + warm-up + the timed region for one flow list; returns everything the JSON line needs."""
-        video = synth.make_video(frames, width, height, seed=SEED + seed_offset, extra_offsets=pairs_level)
+        video = synth.make_video(frames, width, height, seed=SEED + seed_offset, extra_offsets=pairs_level,
+                                 spacing=(1e9 if args.dense else 12.5))  # (dense: the sampled list is not used)
         solver = api.Solver(local_rank)
+        if args.dense:
+            assert world == 1, "dense mode runs on one GPU"
+            t_flow = time.perf_counter()
+            video.dense_flow, video.dense_mask = synth.make_dense_flows(video)
+            print(f"[bench] dense flows of {len(video.pairs)} pairs generated in {time.perf_counter() - t_flow:.1f} s", file=sys.stderr)
         solver.set_options(robust_loss=robust)
         full = dict(pairs=len(video.pairs), constraints=video.num_constraints)
         full_video = video
@@ -266,7 +278,8 @@ def main():
         # sample of the timed region; the events of hipExtLaunchKernelGGL serialise the dispatch)
         sample_every = 1 if args.time_all_kernels else args.time_every
         if timing and not args.no_kernel_timing:
-            solver.set_kernel_timing(True, classes=None if args.time_all_kernels else ["matvec_pairs"], sample_every=sample_every)
+            classes = None if args.time_all_kernels else (["matvec_pairs", "cost", "evaluate_assemble"] if args.dense else ["matvec_pairs"])
+            solver.set_kernel_timing(True, classes=classes, sample_every=sample_every)
         barrier()
         t0 = time.perf_counter()
         done, total_cg, n_solves, summ = run_iterations(solver, params, pose0, theta0, steps)
@@ -287,7 +300,15 @@ def main():
     if rank == 0:
         video, B, n_active = m["video"], m["B"], m["n_active"]
         mv = m["ktimes"]["matvec_pairs"]
-        bytes_launch = matvec_bytes_per_launch(m["local_video"], n_active, B)
+        if args.dense:
+            # flow 8 B + mask 1 B + d_src0 4 B + gathered d_src1 4 B = 17 B per pixel pair (every pixel slot of
+            # every pair is read) + per work item (8192 slots per direction) the frame blocks as in the list mode
+            npx = width * height
+            slots = len(video.pairs) * npx
+            und = {(min(a, b), max(a, b)) for a, b in video.pairs.tolist()}
+            bytes_launch = 17.0 * slots + len(und) * (-(-npx // 8192)) * (2 * 4 + 2) * B * 8.0
+        else:
+            bytes_launch = matvec_bytes_per_launch(m["local_video"], n_active, B)
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
         flops_launch = FLOPS_PER_CONSTRAINT * n_active
         tflops = (flops_launch / (mv["avg_ms"] * 1e-3)) / 1e12 if mv["avg_ms"] > 0 else 0.0
@@ -321,9 +342,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"{cfg['label']}: {frames}-frame {width}x{height} synthetic video, hierarchical2 two-way flow_list "
-                             f"densified to level {level} ({m['full']['pairs']} directed pairs, {m['full']['constraints']} flow "
-                             f"constraints), full LM loop; timed = LM iterations at the final CTF level ({m['grid'][0]}x{m['grid'][1]} "
+                "workload": (f"{cfg['label']}{' dense' if args.dense else ''}: {frames}-frame {width}x{height} synthetic video, hierarchical2 two-way flow_list "
+                             f"densified to level {level} ({m['full']['pairs']} directed pairs, "
+                             + (f"DENSE mode: every masked pixel is a constraint, {n_active} flow constraints read from the flow / mask / "
+                                f"depth images" if args.dense else f"{m['full']['constraints']} flow constraints") + "), full LM loop; timed = LM iterations at the final CTF level ({m['grid'][0]}x{m['grid'][1]} "
                              f"bilinear grid, B={B}, {frames * B} unknowns), {'Huber' if robust else 'Cauchy'} {params.robustness}, "
                              f"PerFrame intrinsics, default solver options"),
                 "pairs": int(m["full"]["pairs"]), "constraints": int(n_active), "unknowns": int(frames * B),
@@ -342,6 +364,15 @@ def main():
                          "note": f"{FLOPS_PER_CONSTRAINT:.0f} f64 flop per constraint counted from the kernel source (DESIGN.md 3)"},
                 "note": "f64 VALU/latency-bound, not HBM-bound (DESIGN.md 3): both fractions are reported",
             },
+            **({"dense_kernels": {
+                # the other two image-reading kernels, same 17 B per pixel slot (the cost class also holds the small
+                # per-frame regulariser kernels; the assemble class reads every slot twice: once per side)
+                "cost": {"avg_ms": m["ktimes"]["cost"]["avg_ms"], "GB/s": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6,
+                         "frac_hbm": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
+                "assemble": {"avg_ms": m["ktimes"]["evaluate_assemble"]["avg_ms"],
+                             "GB/s": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6,
+                             "frac_hbm": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
+            }} if args.dense else {}),
             "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["ktimes"].items()},
             "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
             "last_timed_solve": {k: m["summ"][k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
@@ -356,7 +387,7 @@ def main():
         }
     solver_main = m.pop("solver")
     solver_main.close()
-    if args.config == 2 and level != 1 and not args.no_secondary and args.frames is None:
+    if args.config == 2 and level != 1 and not args.no_secondary and args.frames is None and not args.dense:
         # secondary figure: the reference sampler's own flow list (1766 directed pairs at 300 frames), same recipe
         m2 = measure(1, args.secondary_steps, min(args.warmup, 2), timing=False)
         if rank == 0:
@@ -369,7 +400,7 @@ def main():
             }
         m2.pop("solver").close()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dense:
             out["cpu_baseline"] = cpu_baseline(params, m["video"], m["grid"], m["pose0"], m["theta0"], robust)
         print(json.dumps(out), flush=True)
     if dist is not None:

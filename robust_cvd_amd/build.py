@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB, SRC, "-L/opt/rocm/lib", "-lrccl"]
+    cmd = [hipcc] + FLAGS + ["-o", LIB, SRC, "-L/opt/rocm/lib", "-lrccl", "-lrocsolver", "-lrocblas"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -926,4 +926,107 @@ __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, do
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// DENSE coarse level.  The sparse factorisation above follows the fill of the frame graph: fine for the reference
+// sampler's hierarchical flow list (~10 k block updates at 300 frames), hopeless for a flow list with long-range pairs
+// from nearly every frame (the "~4k pairs" list of BASELINE.json: ~10^6 updates, 44 ms per factorisation).  For such
+// graphs the coarse matrix (8 F unknowns: 2400 at 300 frames) is simply treated as dense: assembled from the same
+// diagonal / edge blocks, inverted by rocSOLVER (potrf + potri: the one plain dense library solve of this path) and
+// applied as an f32 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
+// r^T z, 23 MB streamed).  Unknowns in FRAME order (8 f + mode); inactive modes are identity rows.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges, const double* __restrict__ diag,
+                                                              const double* __restrict__ edges,
+                                                              const int* __restrict__ edgeFa, const int* __restrict__ edgeFb,
+                                                              const unsigned char* __restrict__ modeActive,
+                                                              double* __restrict__ A) {
+  const size_t n = static_cast<size_t>(F) * kCB;
+  const int b = blockIdx.x, t = threadIdx.x, i = t >> 3, j = t & 7;
+  if (b < F) {
+    A[(static_cast<size_t>(b) * kCB + i) * n + b * kCB + j] = diag[static_cast<size_t>(b) * kCBB + t];
+  } else if (b - F < nEdges) {
+    const int e = b - F, fa = edgeFa[e], fb = edgeFb[e];  // block stored rows = fa, columns = fb
+    double v = edges[static_cast<size_t>(e) * kCBB + t];
+    if (!modeActive[fa * kCB + i] || !modeActive[fb * kCB + j]) v = 0.0;
+    A[(static_cast<size_t>(fa) * kCB + i) * n + fb * kCB + j] = v;
+    A[(static_cast<size_t>(fb) * kCB + j) * n + fa * kCB + i] = v;
+  }
+}
+
+// potri(lower) on the column-major view leaves the inverse in what is the UPPER triangle of the row-major array:
+// mirrored into a full symmetric f32 matrix (an SPD approximation is all the preconditioner needs); info != 0 (not
+// positive definite) switches the level off through `fail`.
+__global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* __restrict__ A, const int* __restrict__ info,
+                                                           float* __restrict__ out, int* __restrict__ fail) {
+  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx == 0 && (info[0] != 0 || info[1] != 0)) *fail = 1;
+  if (idx >= static_cast<size_t>(n) * n) return;
+  const size_t r = idx / n, c = idx - r * n;
+  out[idx] = static_cast<float>(c >= r ? A[r * n + c] : A[c * n + r]);
+}
+
+// c_f = (A_c^-1 Z^T r)_f for the 8 modes of frame f (one workgroup per frame: 8 rows x n, 32 threads per row) and this
+// frame's share of r^T Z A_c^-1 Z^T r; the last workgroup closes the PCG scalars exactly as k_coarse_apply_w does.
+__global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const float* __restrict__ Ainv,
+                                                            const double* __restrict__ rc, double* __restrict__ cOut,
+                                                            const unsigned char* __restrict__ modeActive,
+                                                            double* __restrict__ dotPart, double* __restrict__ scal,
+                                                            unsigned int* __restrict__ counter, const int* __restrict__ fail,
+                                                            int init, double tol2, double* __restrict__ hostMirror) {
+  __shared__ double cs[kCB];
+  __shared__ double red[4];
+  __shared__ int flag;
+  if (!init && scal[S_DONE] != 0.0) return;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int m = tid >> 5, part = tid & 31;
+  const size_t n = static_cast<size_t>(F) * kCB;
+  // 16-byte loads (n = 8 F: every row starts on a 16-byte boundary), four in flight per thread: the kernel streams 4 n^2
+  // bytes (23 MB at 300 frames) and is latency-bound otherwise
+  const float4* row = reinterpret_cast<const float4*>(Ainv + (static_cast<size_t>(f) * kCB + m) * n);
+  const size_t n4 = n / 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  auto dot4 = [&](size_t j) {
+    const float4 w = row[j];
+    const double* r = rc + 4 * j;
+    return (static_cast<double>(w.x) * r[0] + static_cast<double>(w.y) * r[1]) +
+           (static_cast<double>(w.z) * r[2] + static_cast<double>(w.w) * r[3]);
+  };
+  size_t j = part;
+  for (; j + 96 < n4; j += 128) {
+    const float4 w0 = row[j], w1 = row[j + 32], w2 = row[j + 64], w3 = row[j + 96];
+    const double* r0 = rc + 4 * j;
+    a0 += (static_cast<double>(w0.x) * r0[0] + static_cast<double>(w0.y) * r0[1]) + (static_cast<double>(w0.z) * r0[2] + static_cast<double>(w0.w) * r0[3]);
+    a1 += (static_cast<double>(w1.x) * r0[128] + static_cast<double>(w1.y) * r0[129]) + (static_cast<double>(w1.z) * r0[130] + static_cast<double>(w1.w) * r0[131]);
+    a2 += (static_cast<double>(w2.x) * r0[256] + static_cast<double>(w2.y) * r0[257]) + (static_cast<double>(w2.z) * r0[258] + static_cast<double>(w2.w) * r0[259]);
+    a3 += (static_cast<double>(w3.x) * r0[384] + static_cast<double>(w3.y) * r0[385]) + (static_cast<double>(w3.z) * r0[386] + static_cast<double>(w3.w) * r0[387]);
+  }
+  for (; j < n4; j += 32) a0 += dot4(j);
+  double acc = (a0 + a1) + (a2 + a3);
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  if (part == 0) {
+    const bool on = *fail == 0 && modeActive[f * kCB + m];
+    const double c = on ? acc : 0.0;
+    cs[m] = c * rc[static_cast<size_t>(f) * kCB + m];
+    cOut[f * kCB + m] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCB; ++k) t += cs[k];
+    dotPart[f] = t;
+  }
+  if (!lastBlockArrives(counter, gridDim.x, &flag)) return;
+  double t = 0.0;
+  for (int b = tid; b < static_cast<int>(gridDim.x); b += 256) t += dotPart[b];
+  t = waveSum(t);
+  if ((tid & 63) == 0) red[tid >> 6] = t;
+  __syncthreads();
+  if (tid == 0) pcgFinishScalars(scal, init, scal[S_RZPART] + ((red[0] + red[1]) + (red[2] + red[3])), scal[S_RR], tol2, hostMirror);
+}
+
 }  // namespace cvd

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <array>
@@ -354,6 +356,13 @@ struct cvd_handle_t {
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
     DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq, dropDiag;
     bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
+    // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f32 matrix, two buffers for the side-stream rebuild
+    bool denseMode = false;
+    bool denseReady = false;  // denseInv holds an inverse for this plan (possibly of an earlier solve: a usable, stale preconditioner)
+    DevBuf<double> denseA;
+    DevBuf<float> denseInv, denseInv2;
+    DevBuf<int> denseInfo;
+    rocblas_handle rb[2] = {nullptr, nullptr};  // [0] main stream, [1] side stream
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
@@ -402,6 +411,7 @@ struct cvd_handle_t {
 
   ~cvd_handle_t() {
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& rbh : coarse.rb) if (rbh) (void)rocblas_destroy_handle(rbh);
     if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
     for (auto& p : hStage) if (p) (void)hipHostFree(p);
@@ -1027,6 +1037,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
                       C.updB.p, C.edgeBlk.p, C.edgeFa.p, C.edgeFb.p, C.wPtr.p, C.wRow.p, C.wtPtr.p, C.wtBlk.p, C.wtCol.p, C.wtFrame.p,
                       C.wuPtr.p, C.wuL.p, C.wuW.p, nW, C.updBlk.p};
   C.valid = true;
+  C.denseReady = false;
 }
 
 // ---- coarse graph sparsification ---------------------------------------------------------------------------
@@ -1224,9 +1235,15 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     }
     // sparsify the coarse graph when its elimination is too expensive (a function of the whole problem's pair graph
     // only: identical on all ranks of a sharded run)
-    static const long long updateBudget = []() { const char* e = std::getenv("CVD_COARSE_UPDATE_BUDGET"); return e ? std::atoll(e) : 40000ll; }();
+    // (read per compile, not cached: tests force the dense / sparsified variants on small problems through it)
+    const long long updateBudget = []() { const char* e = std::getenv("CVD_COARSE_UPDATE_BUDGET"); return e ? std::atoll(e) : 40000ll; }();
     h->coarse.sparsified = false;
-    if (coarseEliminationUpdates(h->F, edgeList) > updateBudget) {
+    h->coarse.denseMode = false;
+    const int denseMaxUnknowns = []() { const char* e = std::getenv("CVD_COARSE_DENSE_MAX"); return e ? std::atoi(e) : 4096; }();
+    const bool overBudget = coarseEliminationUpdates(h->F, edgeList) > updateBudget;
+    if (overBudget && h->F * kCB <= denseMaxUnknowns && !h->dist()) {
+      h->coarse.denseMode = true;  // small enough to invert as a dense matrix: keeps every pair (cvd_coarse.h)
+    } else if (overBudget) {
       std::vector<int> newId(edgeList.size(), -1);
       std::vector<std::pair<int, int>> kept;
       for (size_t e = 0; e < edgeList.size(); ++e)
@@ -1288,7 +1305,7 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
     for (int f = 0; f < h->F; ++f) {
       for (const int code : framePairs[f]) {
         const long long n = h->pairOff[(code >> 1) + 1] - h->pairOff[code >> 1];
-        for (long long o = 0; o < n; o += kAsmUnit) units.push_back(make_int2(code, static_cast<int>(o)));
+        for (long long o = 0; o < n; o += (h->dense ? kAsmUnitDense : kAsmUnit)) units.push_back(make_int2(code, static_cast<int>(o)));
       }
       fuOff[f + 1] = static_cast<int>(units.size());
     }
@@ -1716,7 +1733,8 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_matvec_finish");
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
-    const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, withCoarse ? h->coarse.Wb.p : nullptr,
+    const bool fusedCoarse = withCoarse && !h->coarse.denseMode;
+    const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, fusedCoarse ? h->coarse.Wb.p : nullptr,
                            h->coarse.wq.p};
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
@@ -1724,7 +1742,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
                          h->dist() ? (h->rank == 0 ? 1 : 2) : 0, h->qRows, h->regCache, cF,
-                         (withCoarse && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
+                         (fusedCoarse && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
     });
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
@@ -1857,6 +1875,31 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
   static const double lamPredict = []() { const char* e = std::getenv("CVD_COARSE_LAM_PREDICT"); return e ? std::atof(e) : 1.0 / 3.0; }();
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
                      C.modeActive.p, side ? lamPredict : 1.0, C.sparsified ? C.dropDiag.p : nullptr);
+  if (C.denseMode) {
+    const int n = c.L.F * kCB;
+    if (!C.rb[side]) {
+      if (rocblas_create_handle(&C.rb[side]) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
+      if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
+    }
+    C.denseA.ensure(static_cast<size_t>(n) * n);
+    C.denseInv.ensure(static_cast<size_t>(n) * n);
+    C.denseInv2.ensure(static_cast<size_t>(n) * n);
+    C.denseInfo.ensure(2);
+    HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
+    HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(c.L.F + C.nEdges), dim3(64), 0, s, c.L.F, C.nEdges, C.diag.p, C.edges.p,
+                       C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
+    HIP_CHECK(hipGetLastError());
+    // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
+    if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
+      throw std::runtime_error("rocsolver_dpotrf failed");
+    if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
+      throw std::runtime_error("rocsolver_dpotri failed");
+    hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
+                       C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
   if (singleWg) {
     hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
@@ -1893,13 +1936,21 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   double* rc = coarse ? h->coarse.rc.p : nullptr;
   // Coarse level per iteration: y = W Z^T r is kept up to date inside k_cg_update (CoarseStep: y <- y - alpha W Z^T q,
   // |y|^2 closes r^T z), so only c = W^T y remains as a launch; the first residual goes through k_coarse_apply_w.
-  static const bool unfusedY = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
+  static const bool unfusedEnv = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
+  const bool denseCoarse = coarse && h->coarse.denseMode;
+  const bool unfusedY = unfusedEnv || denseCoarse;  // (the dense level has no W to recur on: Z^T r is restricted every iteration)
   auto coarseC = [&](int init) {
     if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
   auto coarseApply = [&](int init) {
+    if (denseCoarse) {
+      hipLaunchKernelGGL(k_coarse_dense_apply, dim3(F), dim3(256), 0, s, F, h->coarse.denseInv.p, h->coarse.rc.p, h->coarse.c.p,
+                         h->coarse.modeActive.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init,
+                         tol2, h->hPcg);
+      return;
+    }
     hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
                        h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2,
                        h->hPcg);
@@ -2116,6 +2167,13 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double lastRelChange = 1.0;  // relative cost change of the last accepted step
   static const double asyncMaxChange = []() { const char* e = std::getenv("CVD_COARSE_ASYNC_MAX_CHANGE"); return e ? std::atof(e) : 1e-3; }();
   bool freshFactor = false;    // the factor was installed right before this iteration's PCG
+  if (h->coarseOn && h->coarse.denseMode && h->coarse.denseReady) {
+    // Dense level: the inverse left by the previous solve on this handle (the previous coarse-to-fine level, or the last
+    // optimisation of the same video) is a perfectly good SPD preconditioner to start with -- its ~6 ms rocSOLVER rebuild
+    // is not paid in line but started beside the first PCG and installed for the second LM iteration.
+    coarseAge = 0;
+    cgExcess = kCoarseRebuildIters;
+  }
   auto installPendingCoarse = [&]() {
     if (!coarsePending) return;
     HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseDone, 0));  // (device-side wait: the host does not block)
@@ -2123,11 +2181,14 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     std::swap(h->coarse.Wb.n, h->coarse.Wb2.n);
     std::swap(h->coarse.fail.p, h->coarse.fail2.p);
     std::swap(h->coarse.fail.n, h->coarse.fail2.n);
+    std::swap(h->coarse.denseInv.p, h->coarse.denseInv2.p);
+    std::swap(h->coarse.denseInv.n, h->coarse.denseInv2.n);
     coarsePending = false;
     freshFactor = true;
     cgExcess = 0;
     coarseAge = 0;
     factorUses = 0;
+    if (h->coarse.denseMode) h->coarse.denseReady = true;
   };
   bool scaleDone = false;
   cvd_iteration_record r0{};
@@ -2176,7 +2237,9 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
           // (Only in the slowly changing regime -- the last accepted step changed the cost by less than 0.1 % --: while
           // the iterates still move a lot a factor that is one iteration late costs more PCG iterations than the
           // overlap saves, and there the rebuild stays in line.)
-          if (lastRelChange < asyncMaxChange && asyncCoarse && h->opt.coarse_level != 2 && !h->dist()) {
+          // (the dense level's rocSOLVER inversion is a chain of small kernels, ~6 ms at 2400 unknowns, that hardly
+          // occupies the device: always beside the PCG once a first inverse exists)
+          if ((lastRelChange < asyncMaxChange || (h->coarse.denseMode && coarseAge >= 0)) && asyncCoarse && h->opt.coarse_level != 2 && !h->dist()) {
             h->dFc2.ensure(c.L.F);
             HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
             HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
@@ -2188,6 +2251,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
             const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
             launchCoarseSetup(c, h->dX.p);
             h->tEnd(slot);
+            if (h->coarse.denseMode) h->coarse.denseReady = true;
             coarseAge = 0;
             cgExcess = 0;
             freshFactor = true;
@@ -3293,10 +3357,15 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
         for (size_t k = 0; k < n; ++k) {
           unit[k] = 1.0;
           C.rc.upload(unit.data(), n, s);
-          hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, C.dotPart.p,
-                             scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0, static_cast<double*>(nullptr));
-          hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
-                             scalTmp.p, 1);
+          if (C.denseMode) {
+            hipLaunchKernelGGL(k_coarse_dense_apply, dim3(F), dim3(256), 0, s, F, C.denseInv.p, C.rc.p, C.c.p, C.modeActive.p,
+                               C.dotPart.p, scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0, static_cast<double*>(nullptr));
+          } else {
+            hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, C.plan, C.Wb.p, C.rc.p, C.y.p, C.dotPart.p,
+                               scalTmp.p, h->dCounters.p + 3, C.fail.p, 1, 0.0, static_cast<double*>(nullptr));
+            hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, C.c.p,
+                               scalTmp.p, 1);
+          }
           C.c.download(a_c_inverse + k * n, n, s);
           HIP_CHECK(hipStreamSynchronize(s));
           unit[k] = 0.0;

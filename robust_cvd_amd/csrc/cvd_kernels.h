@@ -113,6 +113,13 @@ struct Items {
 // levels of the hierarchical flow list) do not set the kernel's duration.  Parts of a split frame publish their
 // packed partial blocks and the last one to arrive folds them (lastBlockArrives on a per-frame counter).
 constexpr int kAsmUnit = 128;
+// Dense mode: 2048 pixel slots per unit, dealt to the 64 lanes in runs of 32 consecutive pixels (see kDenseRun)
+constexpr int kAsmUnitDense = 2048;
+// Dense mode lane mapping.  Consecutive pixels fall into the same grid cell, i.e. hit the same four vertices: with lane =
+// pixel every LDS atomic of a wave would collide 64-fold.  Each lane therefore walks its own run of kDenseRun = 32
+// consecutive pixels: the 64 lanes of a wave are 32 pixels apart (wider than a cell of the 17x10 grid at 384 px), and
+// a lane's eight consecutive 8-byte flow entries share one 64-byte line, so the images are still streamed once.
+constexpr int kDenseRun = 32;
 struct AsmPart {
   int frame;
   int u0, u1;   // unit range
@@ -1906,7 +1913,7 @@ constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed
 // SPEC = 1: the default pipeline's variant fixed at compile time (one value parameter per vertex, ReproDisparity loss,
 // Cauchy robustifier): the branches on the runtime Layout fields drop out of the constraint loop.
 template <int KD, int NT, int SPEC = 0, bool DENSE = false>
-__global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
@@ -2052,6 +2059,8 @@ __global__ __launch_bounds__(NT) void k_matvec_pairs_fast(Layout L, Table T, Ite
 
   const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
   const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
+  // (dense mode keeps lane = pixel here: the private accumulator copies take care of the same-vertex collisions, and
+  // the run-per-lane mapping of the assembly kernel measured slower for this kernel: 1.00 vs 0.75 ms)
   for (long long c = cb + tid; c < ce; c += NT) {
     float4 nd;
     float2 d;
@@ -2390,9 +2399,14 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
       const double fyb = Fb.fy;
       const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
       const long long cBegin = T.pairOff[p] + __builtin_amdgcn_readfirstlane(unit.y);
-      const long long cEnd = cBegin + kAsmUnit < T.pairOff[p + 1] ? cBegin + kAsmUnit : T.pairOff[p + 1];
+      constexpr int kUnit = DENSE ? kAsmUnitDense : kAsmUnit;
+      const long long cEnd = cBegin + kUnit < T.pairOff[p + 1] ? cBegin + kUnit : T.pairOff[p + 1];
       const int fsrc = side ? o : f, ftgt = side ? f : o;
-      for (long long c = cBegin + lane; c < cEnd; c += 64) {
+      // list mode: lane = constraint, stride 64; dense mode: every lane walks its own run of kDenseRun pixels
+      const long long cFirst = DENSE ? cBegin + static_cast<long long>(lane) * kDenseRun : cBegin + lane;
+      const long long cStop = DENSE ? (cFirst + kDenseRun < cEnd ? cFirst + kDenseRun : cEnd) : cEnd;
+      constexpr long long cStep = DENSE ? 1 : 64;
+      for (long long c = cFirst; c < cStop; c += cStep) {
         float4 nd;
         float2 d;
         if (!loadConstraint<DENSE>(T, c, T.pairOff[p], fsrc, ftgt, nd, d)) continue;

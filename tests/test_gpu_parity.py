@@ -631,6 +631,54 @@ def test_unsupported_configurations_fail_loudly(Solver):
         s.grid_xform_split(XformDesc.global_depth())
 
 
+@pytest.mark.parametrize("variant", ["dense", "sparsified"])
+def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant, monkeypatch):
+    """Flow lists whose frame graph fills in under elimination (long-range pairs from nearly every frame) get the DENSE
+    coarse level (A_c inverted by rocSOLVER, applied as an f32 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
+    (dropped pairs removed from the coarse operator).  Both are forced here on a small problem through the elimination
+    budget: A_c^-1 as applied really is the inverse (dense: to f32 accuracy), the operator stays SPD, and the solve
+    reaches the same minimum as with the exact sparse level."""
+    F = 24
+    v = synth.make_video(F, 128, 72, seed=12, extra_offsets=6)
+
+    def run(env):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        s = Solver(0)
+        synth.load_into(s, v)
+        s.set_options(coarse_level=2)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        for k in env:
+            monkeypatch.delenv(k)
+        return s
+
+    ref = run({})
+    env = {"CVD_COARSE_UPDATE_BUDGET": "0"}
+    if variant == "sparsified":
+        env["CVD_COARSE_DENSE_MAX"] = "0"
+    s = run(env)
+    dbg = s.coarse_debug()
+    assert dbg is not None and dbg["failed"] == 0
+    A, Ai = dbg["a_c"], dbg["a_c_inverse"]
+    assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max() and np.linalg.eigvalsh(A)[0] > 0.0
+    err = np.abs(Ai @ A - np.eye(A.shape[0])).max()
+    assert err < (2e-2 if variant == "dense" else 1e-8), err   # (dense: f32 inverse of a badly scaled f64 matrix)
+    if variant == "sparsified":   # fewer off-diagonal blocks than the full graph of the reference run
+        Aref = ref.coarse_debug()["a_c"]
+        nz = lambda M: int((np.abs(M.reshape(F, 8, F, 8)).max(axis=(1, 3)) > 0).sum())
+        assert nz(A) < nz(Aref)
+    a, b = s.summary(), ref.summary()
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-6 * abs(b["final_cost"])
+    pa, pb = s.get_poses(), ref.get_poses()
+    perr, rerr = synth.relative_pose_error(pa["position"], pa["orientation"], pb["position"], pb["orientation"])
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+
+
 def test_two_level_preconditioner(Solver):
     """Coarse (pose-graph) level of the PCG preconditioner, robust_cvd_amd/csrc/cvd_coarse.h.
 
