@@ -290,7 +290,38 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        comm = solver.comm_times() if shard else None
+        equiv = None
+        if shard and timing:
+            # N = 1 equivalence: one full solve of the final level from the common start state, sharded over all ranks and,
+            # on rank 0, unsharded on its own GPU -- the sharded mode must reproduce the single-GPU result
+            solver.set_kernel_timing(False)
+            solver.set_pose_params(pose0)
+            solver.set_xform_params(theta0)
+            params.max_iterations = 1000
+            solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
+            sh_sum, sh_pose, sh_theta = solver.summary(), solver.get_poses(), solver.get_xform_params().copy()
+            if rank == 0:
+                import numpy as np
+                single = api.Solver(local_rank)
+                single.set_options(robust_loss=robust)
+                synth.load_into(single, full_video, params.focal_long)
+                from robust_cvd_amd.ctypes_types import XformDesc
+                single.reset_depth_xforms(XformDesc.grid_depth(*grid))
+                single.reset_spatial_xforms(XformDesc.spatial())
+                single.set_pose_params(pose0)
+                single.set_xform_params(theta0)
+                single.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
+                s1, p1 = single.summary(), single.get_poses()
+                perr, rerr = synth.relative_pose_error(sh_pose["position"], sh_pose["orientation"], p1["position"], p1["orientation"])
+                equiv = {"final_cost_sharded": sh_sum["final_cost"], "final_cost_single_gpu": s1["final_cost"],
+                         "final_cost_rel_diff": abs(sh_sum["final_cost"] - s1["final_cost"]) / abs(s1["final_cost"]),
+                         "lm_iterations": [sh_sum["num_iterations"], s1["num_iterations"]],
+                         "pose_err": perr, "rot_err": rerr,
+                         "theta_rel_diff": float(np.abs(sh_theta - single.get_xform_params()).max() / np.abs(sh_theta).max())}
+                single.close()
         return dict(video=full_video, local_video=video, solver=solver, full=full, dt=dt, total_cg=total_cg, n_solves=n_solves, summ=summ,
+                    comm=comm, equivalence=equiv,
                     t_prep=t_prep, upload=upload, prep_summary=prep_summary, pose0=pose0, theta0=theta0, grid=grid,
                     sample_every=sample_every, ktimes=solver.kernel_times(), n_active=solver.num_active_constraints(),
                     B=solver.block_size())
@@ -373,6 +404,12 @@ def main():
                              "GB/s": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6,
                              "frac_hbm": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
             }} if args.dense else {}),
+            **({"rccl": {"ranks": world, "frames_owned_per_rank": -(-frames // world),
+                         "exchange_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["comm"].items()},
+                         "exchange_counts": {k: v["count"] for k, v in m["comm"].items()},
+                         "n1_equivalence": m["equivalence"],
+                         "note": "per Jacobian evaluation: all-reduce g + cost, reduce-scatter H_ff to the frames' owners, all-gather "
+                                 "diag(H) and the f32 block inverses; per PCG product: all-reduce q (rank 0's timings)"}} if shard else {}),
             "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["ktimes"].items()},
             "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
             "last_timed_solve": {k: m["summ"][k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",

@@ -216,6 +216,11 @@ int32_t cvd_flow_guided_filter(cvd_handle* h, int32_t num_frames, int32_t first_
  * solver's own stream: fills {evaluate_assemble, matvec_pairs, matvec_finish, cg_update, block_inverse,
  * cost} and their launch counts. */
 int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6);
+/* Exchange steps of the pair-sharded mode (RCCL on the solver stream), timed with HIP events whenever kernel timing is on:
+ * fills {evaluation exchange: all-reduce g / cost, reduce-scatter H_ff, all-gather diag(H) and the f32 block inverses;
+ * product exchange: all-reduce q per PCG product; coarse exchange: edge blocks, diagonal blocks} -- average ms per
+ * occurrence and counts. */
+int32_t cvd_get_comm_times(cvd_handle* h, double* avg_ms3, int64_t* counts3);
 /* Per-launch HIP-event timing: 0 = off (default), 1 = every class, otherwise a bit mask (bit k = class k in the
  * order of cvd_get_kernel_times). Two event records per timed launch. Bits 8..15 = sampling stride - 1 for the hot
  * kernel's start/stop events (0: every launch, 3: every 4th launch of k_matvec_pairs carries an event pair). */

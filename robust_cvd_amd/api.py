@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
+    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
     "cvd_block_inverse_debug",
 ]
 
@@ -146,6 +146,13 @@ class Solver(Binding):
         n = (C.c_int64 * 6)()
         self._check(self._fn("get_kernel_times")(self._h, ms, n))
         return {k: {"avg_ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def comm_times(self):
+        """Average ms / counts of the sharded mode's exchange steps (see cvd_get_comm_times)."""
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
+        self._check(self._fn("get_comm_times")(self._h, ms, n))
+        return {k: {"avg_ms": ms[i], "count": n[i]} for i, k in enumerate(("evaluate_exchange", "product_exchange", "coarse_exchange"))}
 
     def num_active_constraints(self):
         return int(self._lib.cvd_num_active_constraints(self._h))

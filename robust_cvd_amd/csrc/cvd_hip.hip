@@ -232,7 +232,9 @@ static void matrixToQuat(const double R[3][3], double q[4] /*x,y,z,w*/) {
   }
 }
 
-enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPDATE, KC_INVERSE, KC_COST, KC_COUNT };
+enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPDATE, KC_INVERSE, KC_COST, KC_COUNT,
+                   // exchange steps of the pair-sharded multi-GPU mode (cvd_get_comm_times): timed whenever any class is
+                   KC_COMM_EVAL = KC_COUNT, KC_COMM_PRODUCT, KC_COMM_COARSE, KC_TOTAL };
 
 struct Ceres {  // ceres::Solver::Options defaults used on this path
   static constexpr double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
@@ -281,6 +283,12 @@ struct cvd_handle_t {
   int rank = 0, world = 1;
   bool distForced = false;  // test hook (CVD_FORCE_DIST with a 1-rank communicator): run the multi-rank code path
   bool dist() const { return world > 1 || distForced; }
+  // Frame ownership of the sharded mode: rank r owns the contiguous chunk [r Fc, (r + 1) Fc), Fc = ceil(F / world): it
+  // receives the reduced H_ff of those frames (reduce-scatter), inverts them and all-gathers the f32 inverses.
+  int ownChunk() const { return (F + world - 1) / world; }
+  int ownFirst() const { return std::min(F, rank * ownChunk()); }
+  int ownCount() const { return std::min(F, (rank + 1) * ownChunk()) - ownFirst(); }
+  int framesPadded() const { return dist() ? ownChunk() * world : F; }
   bool haveTriplets = false;
   // scene-flow smoothness triplets (cvd_triplets.h): groups keyed by the centre frame
   std::vector<int> tripCenter;
@@ -406,8 +414,8 @@ struct cvd_handle_t {
   std::vector<int> evIter;  // PCG iteration the launch belongs to (-1 outside PCG): launches enqueued past
   int curPcgIter = -1;      // convergence are no-ops and are dropped from the statistics (tDropFrom)
   size_t evUsed = 0;
-  double kcMs[KC_COUNT] = {0};
-  long long kcN[KC_COUNT] = {0};
+  double kcMs[KC_TOTAL] = {0};
+  long long kcN[KC_TOTAL] = {0};
 
   ~cvd_handle_t() {
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -429,7 +437,7 @@ struct cvd_handle_t {
 
   // ---- timing helpers --------------------------------------------------------------------------------
   int tBegin(int kc) {
-    if (!(timing & (1 << kc))) return -1;
+    if (kc >= KC_COUNT ? timing == 0 : !(timing & (1 << kc))) return -1;
     if (evUsed == evPool.size()) {
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a));
@@ -1015,7 +1023,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   up(C.itemEdgeDev, itemEdge);
   const size_t n = static_cast<size_t>(F) * kCB;
   C.edges.ensure(static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB);
-  C.diag.ensure(static_cast<size_t>(F) * kCBB);
+  C.diag.ensure(static_cast<size_t>(h->framesPadded()) * kCBB);
   C.dropDiag.ensure(static_cast<size_t>(F) * kCBB);
   C.Lb.ensure(static_cast<size_t>(nBlocks) * kCBB);
   C.Linv.ensure(static_cast<size_t>(F) * kCBB);
@@ -1432,7 +1440,18 @@ static void ensureBuffers(Ctx& c) {
   h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
   h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
   h->dHd.ensure(n);
-  h->dH.ensure(n * B); h->dMinv.ensure(n * B);
+  {
+    // (sharded mode: room for world x chunk frames so that the reduce-scatter / all-gather chunks are equal; the tail
+    // frames are zero and stay zero)
+    const size_t nPad = static_cast<size_t>(h->framesPadded()) * B;
+    const bool grow = h->dH.n < nPad * B;
+    h->dH.ensure(nPad * B); h->dMinv.ensure(nPad * B); h->dHd.ensure(nPad);
+    if (h->dist() && (grow || nPad > n)) {
+      HIP_CHECK(hipMemsetAsync(h->dH.p, 0, nPad * B * sizeof(double), h->stream));
+      HIP_CHECK(hipMemsetAsync(h->dMinv.p, 0, nPad * B * sizeof(float), h->stream));
+      HIP_CHECK(hipMemsetAsync(h->dHd.p, 0, nPad * sizeof(double), h->stream));
+    }
+  }
   h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(std::max(h->qRows, c.nItems * 2)) * B));
   h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
   h->dCostItem.ensure(std::max(1, c.nItems));
@@ -1601,15 +1620,31 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   }
   h->tEnd(slot);
   if (h->dist()) {
-    // the exchange step of the pair-sharded mode: one all-reduce of [g | H_ff | per-frame cost] per Jacobian evaluation
+    // The exchange step of the pair-sharded mode, once per Jacobian evaluation: the gradient and the per-frame costs
+    // are all-reduced (F x B + F doubles); the frame blocks H_ff are REDUCE-SCATTERED to the frames' owners (75 MB at
+    // B = 177: each rank receives 1 / world of it), which extract the diagonal, invert their own blocks and all-gather
+    // the results -- diag(H) here (F x B doubles), the f32 inverses after the damping is known (launchBlockInverse), the
+    // 8x8 coarse diagonal blocks in launchCoarseSetup.  Against one all-reduce of H_ff: 3/4 of the bytes on the wire and
+    // 1 / world of the inverse work per rank.
+    const int ct = h->tBegin(KC_COMM_EVAL);
+    const size_t chunkH = static_cast<size_t>(h->ownChunk()) * B * B;
     NCCL_CHECK(ncclGroupStart());
     NCCL_CHECK(ncclAllReduce(h->dG.p, h->dG.p, c.n, ncclDouble, ncclSum, h->comm, s));
-    NCCL_CHECK(ncclAllReduce(h->dH.p, h->dH.p, c.n * B, ncclDouble, ncclSum, h->comm, s));
     NCCL_CHECK(ncclAllReduce(h->dCostFrame.p, h->dCostFrame.p, c.L.F, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclReduceScatter(h->dH.p, h->dH.p + static_cast<size_t>(h->rank) * chunkH, chunkH, ncclDouble, ncclSum, h->comm, s));
     NCCL_CHECK(ncclGroupEnd());
+    Layout own = c.L;
+    own.F = h->ownCount();
+    if (own.F > 0)
+      hipLaunchKernelGGL(k_extract_diag, dim3((static_cast<size_t>(own.F) * B + 255) / 256), dim3(256), 0, s, own,
+                         h->dH.p + static_cast<size_t>(h->ownFirst()) * B * B, h->dHd.p + static_cast<size_t>(h->ownFirst()) * B);
+    const size_t chunkD = static_cast<size_t>(h->ownChunk()) * B;
+    NCCL_CHECK(ncclAllGather(h->dHd.p + static_cast<size_t>(h->rank) * chunkD, h->dHd.p, chunkD, ncclDouble, h->comm, s));
+    h->tEnd(ct);
+  } else {
+    hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
   }
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
-  hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
   HIP_CHECK(hipGetLastError());
   if (withStats) {  // |g|_max and |x| of the new point in the same read-back (lam = 0: only those two are used)
     HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
@@ -1747,7 +1782,9 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
+      const int ct = h->tBegin(KC_COMM_PRODUCT);
       NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
+      h->tEnd(ct);
       hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
                          withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc);
       HIP_CHECK(hipGetLastError());
@@ -1817,7 +1854,24 @@ static void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* 
 static void launchBlockInverse(Ctx& c) {
   cvd_handle* h = c.h;
   static const bool scalarSweep = std::getenv("CVD_BLOCK_INVERSE_SWEEP") != nullptr;  // comparison: the scalar sweep
-  launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, h->forceGeneric ? 2 : (scalarSweep ? 1 : 0));
+  const int variant = h->forceGeneric ? 2 : (scalarSweep ? 1 : 0);
+  if (!h->dist()) {
+    launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, variant);
+    return;
+  }
+  // sharded mode: every rank inverts the blocks of ITS frames (it alone holds their reduced H_ff) and the f32 inverses
+  // are all-gathered: 4 B^2 bytes per frame on the wire instead of replicated inverse work on every rank
+  const size_t B = c.L.B;
+  Layout own = c.L;
+  own.F = h->ownCount();
+  const size_t f0 = h->ownFirst();
+  if (own.F > 0)
+    launchBlockInverseRaw(h, own, h->dH.p + f0 * B * B, h->dLam.p + f0 * B, h->dMinv.p + f0 * B * B, h->dFail.p, variant);
+  const int ct = h->tBegin(KC_COMM_EVAL);
+  const size_t chunk = static_cast<size_t>(h->ownChunk()) * B * B;
+  NCCL_CHECK(ncclAllGather(h->dMinv.p + static_cast<size_t>(h->rank) * chunk, h->dMinv.p, chunk, ncclFloat, h->comm, h->stream));
+  NCCL_CHECK(ncclAllReduce(h->dFail.p, h->dFail.p, 1, ncclInt, ncclSum, h->comm, h->stream));
+  h->tEnd(ct);
 }
 
 // Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
@@ -1865,9 +1919,11 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
     }
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
+      const int ct = h->tBegin(KC_COMM_COARSE);
       NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
       if (C.sparsified)
         NCCL_CHECK(ncclAllReduce(C.dropDiag.p, C.dropDiag.p, static_cast<size_t>(c.L.F) * kCBB, ncclDouble, ncclSum, h->comm, s));
+      h->tEnd(ct);
     }
   }
   // (side stream: the factor will serve the NEXT iteration, whose damping is most likely a third of this one's --
@@ -1875,6 +1931,14 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
   static const double lamPredict = []() { const char* e = std::getenv("CVD_COARSE_LAM_PREDICT"); return e ? std::atof(e) : 1.0 / 3.0; }();
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
                      C.modeActive.p, side ? lamPredict : 1.0, C.sparsified ? C.dropDiag.p : nullptr);
+  if (h->dist()) {
+    // the diagonal coarse blocks come from H_ff, which a rank holds for its own frames only: all-gather the owners' 8x8
+    // blocks (the mode flags depend on the mask alone and are right everywhere)
+    const int ct = h->tBegin(KC_COMM_COARSE);
+    const size_t chunk = static_cast<size_t>(h->ownChunk()) * kCBB;
+    NCCL_CHECK(ncclAllGather(C.diag.p + static_cast<size_t>(h->rank) * chunk, C.diag.p, chunk, ncclDouble, h->comm, s));
+    h->tEnd(ct);
+  }
   if (C.denseMode) {
     const int n = c.L.F * kCB;
     if (!C.rb[side]) {
@@ -2212,7 +2276,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       rec.iteration = iteration;
 
       double tl = nowSeconds();
-      hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dScale.p,
+      hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dHd.p, h->dScale.p,
                          scaleDone ? 0 : 1, radius, h->dLam.p);
       scaleDone = true;
       // The block-Jacobi level follows lam every LM iteration; the coarse level is rebuilt on demand (below).
@@ -2514,7 +2578,13 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
     *nres = static_cast<int32_t>(h->numValid + (c.trip ? h->numValidTrip : 0) + regBlocks);
   }
   if (gradient) h->dG.download(gradient, c.n, s);
-  if (hdiag) h->dH.download(hdiag, c.n * c.L.B, s);
+  if (hdiag) {
+    if (h->dist()) {  // (parity hook: collect the owners' reduced blocks)
+      const size_t chunk = static_cast<size_t>(h->ownChunk()) * c.L.B * c.L.B;
+      NCCL_CHECK(ncclAllGather(h->dH.p + static_cast<size_t>(h->rank) * chunk, h->dH.p, chunk, ncclDouble, h->comm, s));
+    }
+    h->dH.download(hdiag, c.n * c.L.B, s);
+  }
   HIP_CHECK(hipStreamSynchronize(s));
   if (hfull) {
     // column j of J^T J = matvec with the unit vector e_j (lam = 0)
@@ -3275,6 +3345,14 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avgMs6, int64_t* launches6) 
     }
   });
 }
+int32_t cvd_get_comm_times(cvd_handle* h, double* avgMs3, int64_t* counts3) {
+  CVD_TRY(h, {
+    for (int k = 0; k < 3; ++k) {
+      avgMs3[k] = h->kcN[KC_COUNT + k] ? h->kcMs[KC_COUNT + k] / h->kcN[KC_COUNT + k] : 0.0;
+      counts3[k] = h->kcN[KC_COUNT + k];
+    }
+  });
+}
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
   CVD_TRY(h, {
     // 1 = all classes, otherwise a bit mask (bit k = class k); bits 8..15 = sampling stride - 1 of the event pairs
@@ -3284,7 +3362,7 @@ int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
     h->timingCounter = 0;
     enabled &= 0xff;
     h->timing = enabled == 1 ? 0x3f : enabled;
-    for (int k = 0; k < KC_COUNT; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }
+    for (int k = 0; k < KC_TOTAL; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }
   });
 }
 int64_t cvd_num_active_constraints(cvd_handle* h) { return h ? h->numValid : 0; }

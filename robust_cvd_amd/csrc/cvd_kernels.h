@@ -615,13 +615,14 @@ __global__ __launch_bounds__(256) void k_shared_focal_fixup(Layout L, const doub
 // Unknowns nothing depends on (h_jj == 0: constant or absent parameter blocks) get lam = 1, so that the
 // damped system is the identity on them and their step is exactly 0.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_lm_diag(Layout L, const double* __restrict__ hdiagBlocks, double* __restrict__ scale,
+// hdiag = diag(H_ff) of every frame as a flat F x B vector (k_extract_diag; all-gathered from the frames' owners in the
+// pair-sharded multi-GPU mode, where a rank holds the reduced H_ff of its own frames only).
+__global__ void k_lm_diag(Layout L, const double* __restrict__ hdiag, double* __restrict__ scale,
                           int computeScale, double radius, double* __restrict__ lam) {
   const size_t n = static_cast<size_t>(L.F) * L.B;
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const size_t f = i / L.B, c = i - f * L.B;
-  const double h = hdiagBlocks[(f * L.B + c) * L.B + c];
+  const double h = hdiag[i];
   if (computeScale) scale[i] = 1.0 / (1.0 + sqrt(h));
   const double s = scale[i];
   if (h == 0.0) {

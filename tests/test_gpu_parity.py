@@ -599,8 +599,17 @@ def test_sharded_code_path_on_one_rank(Solver, monkeypatch):
         p.smooth_static_weight, p.smooth_dynamic_weight = 0.5, 0.25
         s.normalize_depth(p)
         ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+        if forced:
+            s.set_kernel_timing(True)
         s.pose_optimization(p)
         out.append((ev, s.get_xform_params(), s.summary()))
+        if forced:
+            # the exchange steps really ran: reduce-scatter H_ff / all-gather diag + f32 inverses per Jacobian evaluation,
+            # one all-reduce of q per PCG product, the coarse blocks per preconditioner rebuild
+            ct = s.comm_times()
+            assert ct["evaluate_exchange"]["count"] >= 2 * out[-1][2]["num_successful_steps"]
+            assert ct["product_exchange"]["count"] >= out[-1][2]["total_linear_iterations"]
+            assert ct["coarse_exchange"]["count"] >= 2 and ct["product_exchange"]["avg_ms"] > 0.0
     monkeypatch.delenv("CVD_FORCE_DIST", raising=False)
     a, b = out
     assert abs(a[0]["cost"] - b[0]["cost"]) <= 1e-12 * abs(a[0]["cost"])
