@@ -1002,9 +1002,43 @@ static void evalLoss(int kind, double p, double s, double rho[3]) {
   }
 }
 
-// One residual block: values (+ Jacobian, by dual numbers in passes of kStride exactly like
-// ceres::DynamicAutoDiffCostFunction::Evaluate), then the loss corrector (ceres/corrector.cc).
-// `jac` is laid out [numResiduals x totalParams] row-major over the concatenated parameter blocks.
+// Values (+ Jacobian, by dual numbers in passes of kStride exactly like ceres::DynamicAutoDiffCostFunction::Evaluate) of
+// one cost function at the parameter blocks pd[b].  `jac` is laid out [numResiduals x totalParams] row-major over the
+// concatenated parameter blocks.  No loss function here.
+static void evaluateCostFunctionAt(const CostFunction& cf, const double* const* pd, double* res, double* jac) {
+  const int nb = static_cast<int>(cf.blockSizes.size());
+  const int nr = cf.numResiduals;
+  int total = 0;
+  for (int b = 0; b < nb; ++b) total += cf.blockSizes[b];
+  if (!jac) {
+    cf.evalD(pd, res);
+    return;
+  }
+  std::vector<Jet> store(total);
+  std::vector<const Jet*> pj(nb);
+  {
+    int k = 0;
+    for (int b = 0; b < nb; ++b) {
+      pj[b] = &store[k];
+      for (int i = 0; i < cf.blockSizes[b]; ++i) store[k++] = Jet(pd[b][i]);
+    }
+  }
+  std::vector<Jet> out(nr);
+  for (int start = 0; start < total; start += kStride) {
+    const int end = std::min(total, start + kStride);
+    for (int k = start; k < end; ++k) store[k].v[k - start] = 1.0;
+    cf.evalJ(pj.data(), out.data());
+    for (int k = start; k < end; ++k) {
+      for (int r = 0; r < nr; ++r) jac[static_cast<size_t>(r) * total + k] = out[r].v[k - start];
+      store[k].v[k - start] = 0.0;
+    }
+    if (start == 0)
+      for (int r = 0; r < nr; ++r) res[r] = out[r].a;
+  }
+  if (total == 0) cf.evalD(pd, res);
+}
+
+// One residual block at the current state of its parameter blocks, then the loss corrector (ceres/corrector.cc).
 static double evaluateResidualBlock(const Problem& pb, const ResidualBlock& rb, double* res, double* jac) {
   const CostFunction& cf = *rb.cost;
   const int nb = static_cast<int>(rb.blocks.size());
@@ -1014,33 +1048,7 @@ static double evaluateResidualBlock(const Problem& pb, const ResidualBlock& rb, 
 
   std::vector<const double*> pd(nb);
   for (int b = 0; b < nb; ++b) pd[b] = pb.blocks[rb.blocks[b]].ptr;
-
-  if (!jac) {
-    cf.evalD(pd.data(), res);
-  } else {
-    std::vector<Jet> store(total);
-    std::vector<const Jet*> pj(nb);
-    {
-      int k = 0;
-      for (int b = 0; b < nb; ++b) {
-        pj[b] = &store[k];
-        for (int i = 0; i < cf.blockSizes[b]; ++i) store[k++] = Jet(pd[b][i]);
-      }
-    }
-    std::vector<Jet> out(nr);
-    for (int start = 0; start < total; start += kStride) {
-      const int end = std::min(total, start + kStride);
-      for (int k = start; k < end; ++k) store[k].v[k - start] = 1.0;
-      cf.evalJ(pj.data(), out.data());
-      for (int k = start; k < end; ++k) {
-        for (int r = 0; r < nr; ++r) jac[static_cast<size_t>(r) * total + k] = out[r].v[k - start];
-        store[k].v[k - start] = 0.0;
-      }
-      if (start == 0)
-        for (int r = 0; r < nr; ++r) res[r] = out[r].a;
-    }
-    if (total == 0) cf.evalD(pd.data(), res);
-  }
+  evaluateCostFunctionAt(cf, pd.data(), res, jac);
 
   double sq = 0.0;
   for (int r = 0; r < nr; ++r) sq += res[r] * res[r];
@@ -1545,6 +1553,100 @@ static void solveProblem(Problem& pb, int maxIterations, int numThreads, cvd_sol
   if (summary) *summary = sum;
 }
 
+#ifdef CVDO_WITH_CERES
+}  // namespace cvdo
+#include <ceres/ceres.h>
+namespace cvdo {
+// ---- the "true Ceres" column: the SAME residual blocks handed to a real ceres::Problem -------------------
+// Built only with `make -C oracle CERES=1` on a machine that has Ceres (none here: SURVEY.md 8c).  Every oracle residual
+// block becomes a ceres::CostFunction whose values / Jacobians come from the oracle's dual-number evaluation; the loss
+// functions (ceres::CauchyLoss / HuberLoss / ScaledLoss), the corrector, the trust-region loop, its termination tests and
+// SPARSE_NORMAL_CHOLESKY are Ceres' own -- exactly the parts the oracle restates from Ceres' published algorithm, so a
+// matching end state pins them (tests/test_oracle_ceres.py).
+class OracleCostFunction : public ceres::CostFunction {
+ public:
+  explicit OracleCostFunction(const CostFunction* cf) : cf_(cf) {
+    set_num_residuals(cf->numResiduals);
+    for (int sz : cf->blockSizes) mutable_parameter_block_sizes()->push_back(sz);
+  }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    const int nb = static_cast<int>(cf_->blockSizes.size());
+    const int nr = cf_->numResiduals;
+    int total = 0;
+    for (int sz : cf_->blockSizes) total += sz;
+    if (!jacobians) {
+      evaluateCostFunctionAt(*cf_, parameters, residuals, nullptr);
+      return true;
+    }
+    std::vector<double> jac(static_cast<size_t>(nr) * total);
+    evaluateCostFunctionAt(*cf_, parameters, residuals, jac.data());
+    int col = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int sz = cf_->blockSizes[b];
+      if (jacobians[b])
+        for (int r = 0; r < nr; ++r)
+          for (int k = 0; k < sz; ++k) jacobians[b][r * sz + k] = jac[static_cast<size_t>(r) * total + col + k];
+      col += sz;
+    }
+    return true;
+  }
+
+ private:
+  const CostFunction* cf_;
+};
+
+static void solveProblemCeres(Problem& pb, int maxIterations, int numThreads, cvd_solve_summary* summary,
+                              std::vector<cvd_iteration_record>* records) {
+  ceres::Problem problem;
+  for (const auto& rb : pb.residuals) {
+    ceres::LossFunction* loss = nullptr;
+    if (rb.lossKind == LOSS_CAUCHY) loss = new ceres::CauchyLoss(rb.lossParam);
+    else if (rb.lossKind == LOSS_HUBER) loss = new ceres::HuberLoss(rb.lossParam);
+    else if (rb.lossKind == LOSS_SCALED) loss = new ceres::ScaledLoss(nullptr, rb.lossParam, ceres::TAKE_OWNERSHIP);
+    std::vector<double*> ptrs;
+    for (int id : rb.blocks) ptrs.push_back(pb.blocks[id].ptr);
+    problem.AddResidualBlock(new OracleCostFunction(rb.cost.get()), loss, ptrs);
+  }
+  for (const auto& b : pb.blocks) {
+    if (!problem.HasParameterBlock(b.ptr)) continue;
+    if (b.constant) problem.SetParameterBlockConstant(b.ptr);
+    if (b.hasLower0) problem.SetParameterLowerBound(b.ptr, 0, b.lower0);
+  }
+  ceres::Solver::Options options;  // what the reference sets (lib/PoseOptimizer.cpp:955-961), nothing else
+  options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
+  options.minimizer_progress_to_stdout = false;
+  options.max_num_iterations = maxIterations;
+  options.num_threads = numThreads;
+  ceres::Solver::Summary cs;
+  ceres::Solve(options, &problem, &cs);
+  cvd_solve_summary sum{};
+  sum.num_residual_blocks = static_cast<int>(pb.residuals.size());
+  sum.num_parameters = cs.num_effective_parameters_reduced;
+  sum.num_iterations = static_cast<int>(cs.iterations.size()) - 1;
+  sum.num_successful_steps = cs.num_successful_steps;
+  sum.termination = cs.termination_type == ceres::CONVERGENCE ? 0 : (cs.termination_type == ceres::NO_CONVERGENCE ? 1 : 2);
+  sum.initial_cost = cs.initial_cost;
+  sum.final_cost = cs.final_cost;
+  sum.total_seconds = cs.total_time_in_seconds;
+  sum.evaluate_seconds = cs.residual_evaluation_time_in_seconds + cs.jacobian_evaluation_time_in_seconds;
+  sum.linear_solve_seconds = cs.linear_solver_time_in_seconds;
+  if (summary) *summary = sum;
+  if (records)
+    for (const auto& it : cs.iterations) {
+      cvd_iteration_record r{};
+      r.iteration = it.iteration;
+      r.step_is_successful = it.step_is_successful ? 1 : 0;
+      r.cost = it.cost;
+      r.cost_change = it.cost_change;
+      r.gradient_max_norm = it.gradient_max_norm;
+      r.step_norm = it.step_norm;
+      r.relative_decrease = it.relative_decrease;
+      r.trust_region_radius = it.trust_region_radius;
+      records->push_back(r);
+    }
+}
+#endif  // CVDO_WITH_CERES
+
 // =====================================================================================================
 // The optimizer (reference lib/PoseOptimizer.cpp:748-1549, lib/Processor.cpp:888-1013)
 // =====================================================================================================
@@ -1580,6 +1682,20 @@ struct Oracle {
   std::string lastError;
 
   const float* depthImg(int f) const { return &depth[static_cast<size_t>(f) * W * Hh]; }
+
+  // linearSolver 0 / 1: the oracle's own Ceres-default LM (block-sparse / dense Cholesky); 2: a real ceres::Solve
+  void solveAny(Problem& pb, const cvd_opt_params& p) {
+    if (linearSolver == 2) {
+#ifdef CVDO_WITH_CERES
+      pb.finalize();
+      solveProblemCeres(pb, p.max_iterations, p.num_threads, &lastSummary, &records);
+#else
+      throw std::runtime_error("this oracle was built without Ceres (make -C oracle CERES=1 on a machine that has it)");
+#endif
+      return;
+    }
+    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records, linearSolver, functionTolerance);
+  }
 
   // ---- frame range helpers (FrameRange: ordered set of frame ids) -----------------------------------
   static std::vector<int> rangeOf(const cvd_opt_params& p, int F) {
@@ -2018,7 +2134,7 @@ struct Oracle {
   void poseOptimizationStep(const cvd_opt_params& p, double depthDeformReg) {
     Problem pb;
     buildPoseProblem(pb, p, depthDeformReg);
-    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records, linearSolver, functionTolerance);
+    solveAny(pb, p);
     paramsToPoses(p);
   }
 
@@ -2122,7 +2238,7 @@ struct Oracle {
       for (int k = 0; k < x.numBlocks; ++k)
         pb.setLowerBound0(&x.params[static_cast<size_t>(k) * x.blockSize], 0.0);
     }
-    solveProblem(pb, p.max_iterations, p.num_threads, &lastSummary, &records, linearSolver, functionTolerance);
+    solveAny(pb, p);
     if (p.normalize_depth_from_first_frame && !range.empty()) {
       const int first = range.front();
       for (int f : range)
@@ -2247,9 +2363,17 @@ int cvdo_block_sparse_solve(int nb, const int* sizes, int npairs, const int* pai
 
 int cvdo_set_linear_solver(void* h, int kind) {
   CVDO_TRY(h, {
-    if (kind != 0 && kind != 1) throw std::runtime_error("linear solver must be 0 (block-sparse Cholesky) or 1 (dense Cholesky)");
+    if (kind < 0 || kind > 2)
+      throw std::runtime_error("linear solver must be 0 (block-sparse Cholesky), 1 (dense Cholesky) or 2 (real ceres::Solve)");
     static_cast<Oracle*>(h)->linearSolver = kind;
   });
+}
+int cvdo_has_ceres() {
+#ifdef CVDO_WITH_CERES
+  return 1;
+#else
+  return 0;
+#endif
 }
 int cvdo_set_function_tolerance(void* h, double tol) { CVDO_TRY(h, static_cast<Oracle*>(h)->functionTolerance = tol); }
 int cvdo_set_video(void* h, int numFrames, int width, int height, float aspect, float invAspect) {

@@ -41,7 +41,8 @@ class Oracle(Binding):
         super().__init__(lib, "cvdo_", lib.cvdo_create())
 
     def set_linear_solver(self, kind):
-        """0: exact block-sparse Cholesky on the frame graph (default), 1: dense Cholesky (cross-check, small problems)."""
+        """0: exact block-sparse Cholesky on the frame graph (default), 1: dense Cholesky (cross-check, small problems),
+        2: the same residual blocks through a real ceres::Solve (only when built with `make -C oracle CERES=1`)."""
         self._check(self._fn("set_linear_solver")(self._h, C.c_int(int(kind))))
 
     def set_function_tolerance(self, tol):
@@ -51,6 +52,11 @@ class Oracle(Binding):
     def set_robust_loss(self, kind):
         """0: CauchyLoss (reference), 1: HuberLoss -- mirrors api.Solver.set_robust_loss."""
         self._check(self._fn("set_robust_loss")(self._h, C.c_int(int(kind))))
+
+
+def has_ceres():
+    """True when the oracle library was built against a real Ceres (make -C oracle CERES=1)."""
+    return bool(load().cvdo_has_ceres())
 
 
 # ---- stand-alone known-answer hooks ------------------------------------------------------------------

@@ -94,3 +94,113 @@ def write_dataset(base_dir, video, model_type="midas2", fps=30.0):
     for d in ("color_full", "color_down"):
         os.makedirs(os.path.join(base_dir, d), exist_ok=True)
     return base_dir
+
+
+def read_video_dat(path):
+    """Reader of `video.dat` as DepthVideo::save writes it (reference lib/DepthVideo.cpp:300-385, file format 13; the
+    reference's own load() cannot read this release's files): frames' pts, the colour streams'
+    descriptions and, per depth stream, the transform descriptors and per frame {intrinsics, extrinsics, enabled, depth
+    transform parameters, spatial transform parameters}.  Little endian, strings = u64 length + bytes, transforms =
+    {i32 XformType, descriptor string} + raw doubles (lib/DepthMapTransform.cpp:270-279, 1493-1506).  This is how results of a
+    real reference install (tools/make_reference_golden.py) are read back for comparison."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    pos = 0
+
+    def take(fmt):
+        nonlocal pos
+        v = struct.unpack_from("<" + fmt, raw, pos)
+        pos += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def take_str():
+        nonlocal pos
+        n = take("Q")
+        s = raw[pos:pos + n].decode()
+        pos += n
+        return s
+
+    def desc_num_params(xtype, text):
+        """Number of doubles following a transform descriptor (Xform::params_ size)."""
+        name, _, args = text.partition("(")
+        args = [a.strip() for a in args.rstrip(")").split(",") if a.strip()]
+        nval = {"Scale": 1, "ScaleShift": 2}
+        if xtype == 0:  # depth
+            if name == "Identity":
+                return 0
+            if name == "Global":
+                return nval[args[0]]
+            if name == "Grid":  # Grid(value, Linear|Cubic, x, y, z[, min, max])
+                return nval[args[0]] * int(args[2]) * int(args[3]) * int(args[4])
+        else:
+            if name == "Identity":
+                return 0
+            if name == "VerticalLinear":
+                return 4
+            if name == "CornersBilinear":
+                return 8
+            if name in ("BilinearGrid", "BicubicGrid"):
+                return int(args[0]) * int(args[1]) * 2
+        raise ValueError(f"unknown transform descriptor {text!r}")
+
+    def take_desc():
+        xtype = take("i")
+        return xtype, take_str()
+
+    def take_xform():
+        xtype, text = take_desc()
+        n = desc_num_params(xtype, text)
+        vals = np.frombuffer(raw, dtype="<f8", count=n, offset=pos_ref()).copy()
+        advance(8 * n)
+        return {"desc": text, "params": vals}
+
+    def pos_ref():
+        return pos
+
+    def advance(n):
+        nonlocal pos
+        pos += n
+
+    magic, version, dp_format, num_frames = take("IIIi")
+    if magic != 0xDEADBEEF or version < 9:
+        raise ValueError("not a video.dat file")
+    pts = np.frombuffer(raw, dtype="<f4", count=num_frames, offset=pos).copy()
+    pos += 4 * num_frames
+    color = []
+    for _ in range(take("i")):
+        name, dirn, ext = take_str(), take_str(), take_str()
+        cvtype, w, h = take("iii")
+        gop = take("B")
+        if gop:
+            raise ValueError("GOP tables are not supported")
+        color.append({"name": name, "dir": dirn, "extension": ext, "type": cvtype, "width": w, "height": h})
+    depth_streams = []
+    for _ in range(take("i")):
+        name, dirn = take_str(), take_str()
+        ddesc, sdesc = take_desc(), take_desc()
+        w, h = take("ii")
+        if take("B"):
+            raise ValueError("GOP tables are not supported")
+        frames = []
+        for _f in range(num_frames):
+            projection, vfov, hfov, clat, clon = take("iffff")
+            position = np.array(take("fff"), np.float32)
+            orientation = np.array(take("ffff"), np.float32)  # x, y, z, w
+            enabled = bool(take("B"))
+            dx, sx = take_xform(), take_xform()
+            frames.append({"vfov": vfov, "hfov": hfov, "projection": projection, "position": position,
+                           "orientation": orientation, "enabled": enabled, "depth_xform": dx, "spatial_xform": sx})
+        depth_streams.append({"name": name, "dir": dirn, "depth_desc": ddesc[1], "spatial_desc": sdesc[1], "width": w,
+                              "height": h, "frames": frames})
+    duration, w, h, aspect, inv_aspect, magic2 = take("fiiffI")
+    if magic2 != 0xDEADBEEF or pos != len(raw):
+        raise ValueError("video.dat: trailing marker mismatch")
+    return {"version": version, "pts": pts, "color_streams": color, "depth_streams": depth_streams, "duration": duration,
+            "width": w, "height": h, "aspect": aspect, "inv_aspect": inv_aspect}
+
+
+def poses_from_video_dat(video, stream=-1):
+    """(position [F, 3], orientation xyzw [F, 4], vfov [F], depth-transform parameters [F, n]) of one depth stream."""
+    fr = video["depth_streams"][stream]["frames"]
+    return (np.stack([f["position"] for f in fr]), np.stack([f["orientation"] for f in fr]),
+            np.array([f["vfov"] for f in fr], np.float32), np.stack([f["depth_xform"]["params"] for f in fr]))
