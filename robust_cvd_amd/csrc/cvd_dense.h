@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_apply_depth(Layout L, int W, int H, int
   float lx, ly;
   pixelLoc(px, py, W, H, lx, ly);
   Taps<KD> t;
-  depthGather<KD>(L, lx, ly, t);
+  depthGather<KD>(L, lx, ly, depth[pix], t);
   const double* th = x + static_cast<size_t>(f) * L.B + 7;
   double D = 0.0;
   for (int k = 0; k < t.n; ++k) {
@@ -56,16 +56,16 @@ __global__ __launch_bounds__(256) void k_apply_depth(Layout L, int W, int H, int
 
 // out[f][y][x][n] = sum_k w_k theta_f[k][n] (f64, N channels)
 template <int KD>
-__global__ __launch_bounds__(256) void k_param_map(Layout L, int W, int H, int frame0, const double* __restrict__ x,
-                                                   double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_param_map(Layout L, int W, int H, int frame0, const float* __restrict__ depth,
+                                                   const double* __restrict__ x, double* __restrict__ out) {
   const int pidx = blockIdx.x * blockDim.x + threadIdx.x;  // pixels of one frame, flattened: no idle row tails
   if (pidx >= W * H) return;
   const int py = pidx / W, px = pidx - py * W;
   const int f = frame0 + blockIdx.z;
   float lx, ly;
   pixelLoc(px, py, W, H, lx, ly);
-  Taps<KD> t;
-  depthGather<KD>(L, lx, ly, t);
+  Taps<KD> t;  // (the source depth only matters for depth-wise grids: reference lib/DepthMapTransform.cpp:966-975)
+  depthGather<KD>(L, lx, ly, depth[(static_cast<size_t>(f) * H + py) * W + px], t);
   const double* th = x + static_cast<size_t>(f) * L.B + 7;
   double a0 = 0.0, a1 = 0.0;
   for (int k = 0; k < t.n; ++k) {

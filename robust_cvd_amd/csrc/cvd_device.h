@@ -24,6 +24,10 @@ struct Layout {
   int cubic;
   int gx, gy;     // grid cols / rows (1 for Global)
   double maxcx, maxcy;  // nextafter(g-1, 0)
+  // depth-wise axis of the grid (gridSize.z > 1, reference lib/DepthMapTransform.cpp:709-729, 771-779): the third grid
+  // coordinate is the SOURCE DISPARITY of the sample, (1 / d_src - dispMin) / dispInterval clamped to [0, maxcz]
+  int gz;
+  double maxcz, dispMin, dispInterval;
   int nD;         // depth params per frame
   // spatial transform
   int spatialType;  // cvd_spatial_xform_type
@@ -247,12 +251,57 @@ __host__ __device__ __forceinline__ int bicubicTaps(float lx, float ly, int gx, 
   return n;
 }
 
+// Number of deformation edges of the depth grid (x-, y- and z-neighbours; reference lib/DepthMapTransform.cpp:996-1002)
+__host__ __device__ __forceinline__ int gridNumEdges(int gx, int gy, int gz) {
+  return (gx - 1) * gy * gz + gx * (gy - 1) * gz + gx * gy * (gz - 1);
+}
+
+// GridDepthXform::linearGather with a depth-wise axis (reference lib/DepthMapTransform.cpp:739-851): 8 taps (spatial and
+// depth-wise), or 2 (depth-wise only: gridSize.x == gridSize.y == 1).  srcDepth is the f32 source depth of the sample.
+template <int K>
+__device__ __forceinline__ void depthwiseTaps(const Layout& L, float lx, float ly, float srcDepth, Taps<K>& t) {
+  const double srcDisparity = 1.0 / static_cast<double>(srcDepth);
+  double sz = (srcDisparity - L.dispMin) / L.dispInterval;
+  sz = sz < 0.0 ? 0.0 : (sz > L.maxcz ? L.maxcz : sz);  // std::clamp
+  const int iz = static_cast<int>(sz);
+  const double rz = sz - static_cast<double>(iz);
+  if (L.gx > 1) {
+    if constexpr (K >= 8) {
+      int idx4[4];
+      double w4[4];
+      bilinearTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, idx4, w4);
+      const int zs = L.gx * L.gy;
+      t.n = 8;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t.idx[k] = idx4[k] + iz * zs;
+        t.w[k] = w4[k] * (1.0 - rz);
+        t.idx[4 + k] = idx4[k] + (iz + 1) * zs;
+        t.w[4 + k] = w4[k] * rz;
+      }
+    } else {
+      t.n = 0;
+    }
+  } else {
+    if constexpr (K >= 2) {
+      t.n = 2;
+      t.idx[0] = iz;     t.w[0] = 1.0 - rz;
+      t.idx[1] = iz + 1; t.w[1] = rz;
+    } else {
+      t.n = 0;
+    }
+  }
+}
+
+// srcDepth: the sample's source depth -- only the depth-wise grids look at it.
 template <int KD>
-__device__ __forceinline__ void depthGather(const Layout& L, float lx, float ly, Taps<KD>& t) {
+__device__ __forceinline__ void depthGather(const Layout& L, float lx, float ly, float srcDepth, Taps<KD>& t) {
   if (L.depthType == kDepthGlobal) {
     t.n = 1;
     t.idx[0] = 0;
     t.w[0] = 1.0;
+  } else if (L.depthType == kDepthGrid && L.gz > 1) {
+    depthwiseTaps<KD>(L, lx, ly, srcDepth, t);
   } else if (L.depthType == kDepthGrid) {
     if constexpr (KD >= 16) {
       if (L.cubic) {
@@ -356,8 +405,8 @@ __device__ __forceinline__ void evalSample(const Layout& L, const FrameConst& fa
   constexpr double eps = 1e-6;
   s.a.d = static_cast<double>(dsrc.x);
   s.b.d = static_cast<double>(dsrc.y);
-  depthGather<KD>(L, ndc.x, ndc.y, s.a.dt);
-  depthGather<KD>(L, ndc.z, ndc.w, s.b.dt);
+  depthGather<KD>(L, ndc.x, ndc.y, dsrc.x, s.a.dt);
+  depthGather<KD>(L, ndc.z, ndc.w, dsrc.y, s.b.dt);
   spatialGather<KS>(L, ndc.x, ndc.y, s.a.st);
   spatialGather<KS>(L, ndc.z, ndc.w, s.b.st);
 
@@ -604,7 +653,7 @@ __device__ __forceinline__ int numRegResiduals(const Layout& L) {
   int n = 0;
   if (L.scaleRegSqrt > 0.0) n += L.sregX * L.sregY;
   if (L.focalRegSqrt > 0.0) n += 1;
-  if (L.depthDeformW > 0.0 && L.depthType == kDepthGrid) n += ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+  if (L.depthDeformW > 0.0 && L.depthType == kDepthGrid) n += gridNumEdges(L.gx, L.gy, L.gz) * L.N;
   if (L.spatialDeformW > 0.0) n += L.nS;
   return n;
 }
@@ -624,7 +673,7 @@ __device__ __forceinline__ void regResidual(const Layout& L, int f, int i, const
       const float lx = __fadd_rn(-1.f, __fdiv_rn(__fmul_rn(2.f, static_cast<float>(x)), static_cast<float>(L.sregX - 1)));
       const float ly = __fadd_rn(-1.f, __fdiv_rn(__fmul_rn(2.f, static_cast<float>(y)), static_cast<float>(L.sregY - 1)));
       Taps<KD> t;
-      depthGather<KD>(L, lx, ly, t);
+      depthGather<KD>(L, lx, ly, median, t);
       const double d = static_cast<double>(median);
       double D = (L.depthType == kDepthIdentity) ? d : 0.0;
       const double* th = xf + 7;
@@ -659,22 +708,33 @@ __device__ __forceinline__ void regResidual(const Layout& L, int f, int i, const
     i -= 1;
   }
   if (L.depthDeformW > 0.0 && L.depthType == kDepthGrid) {
-    const int nEdges = ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+    const int nEdges = gridNumEdges(L.gx, L.gy, L.gz) * L.N;
     if (i < nEdges) {
-      // enumerate edges in any order (a sum): first the x-edges, then the y-edges
+      // enumerate edges in any order (a sum): the x-edges, then the y-edges, then the z-edges of every vertex layer
       const int dim = i % L.N;
       int e = i / L.N;
       int va, vb;
-      const int nxE = (L.gx - 1) * L.gy;
+      const int zs = L.gx * L.gy;
+      const int nxE = (L.gx - 1) * L.gy * L.gz, nyE = L.gx * (L.gy - 1) * L.gz;
       if (e < nxE) {
+        const int perLayer = (L.gx - 1) * L.gy;
+        const int z = e / perLayer;
+        e -= z * perLayer;
         const int y = e / (L.gx - 1), x = e - y * (L.gx - 1) + 1;
-        va = x + y * L.gx;
+        va = x + y * L.gx + z * zs;
         vb = va - 1;
-      } else {
+      } else if (e < nxE + nyE) {
         e -= nxE;
+        const int perLayer = L.gx * (L.gy - 1);
+        const int z = e / perLayer;
+        e -= z * perLayer;
         const int y = e / L.gx + 1, x = e - (y - 1) * L.gx;
-        va = x + y * L.gx;
+        va = x + y * L.gx + z * zs;
         vb = va - L.gx;
+      } else {
+        e -= nxE + nyE;  // vertex (x, y, z), z >= 1, with its neighbour one layer below
+        va = e + zs;
+        vb = e;
       }
       const double a = xf[7 + va * L.N + dim];
       const double b = xf[7 + vb * L.N + dim];

@@ -549,9 +549,15 @@ static void resetXforms(cvd_handle* h, const cvd_xform_desc& d, bool spatial) {
   const int nb = xformNumBlocks(d), bs = xformBlockSize(d);
   if (!spatial) {
     if (d.type != CVD_XFORM_DEPTH) throw std::runtime_error("Transform has the wrong type.");
-    if (d.depth_type == CVD_DEPTH_GRID && d.grid_size[2] > 1)
-      throw std::runtime_error("Depth-wise (gridSize.z > 1) grids are not implemented on the device path.");
-    if (d.depth_type == CVD_DEPTH_GRID && !d.cubic_interpolation && bs != 1 && d.grid_size[0] > 1)
+    if (d.depth_type == CVD_DEPTH_GRID && d.grid_size[2] > 1) {
+      // GridDepthXform ctor, reference lib/DepthMapTransform.cpp:709-717
+      if (d.depth_min_max[0] <= 0.0 || d.depth_min_max[1] <= 0.0) throw std::runtime_error("Depth values must be positive.");
+      if (d.depth_min_max[1] - d.depth_min_max[0] <= 0.0) throw std::runtime_error("Depth range must be positive.");
+      if (d.cubic_interpolation)
+        throw std::runtime_error("Cubic interpolation of depth-wise grids is not defined (reference lib/DepthMapTransform.cpp:944 "
+                                 "never applies the depth-wise weights).");
+    }
+    if (d.depth_type == CVD_DEPTH_GRID && !d.cubic_interpolation && bs != 1 && (d.grid_size[0] > 1 || d.grid_size[2] > 1))
       throw std::runtime_error(
           "Linear grid gather is only defined for 1-parameter value transforms (reference "
           "lib/DepthMapTransform.cpp:829 aliases the blocks otherwise).");
@@ -627,6 +633,15 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   L.gy = h->ddesc.depth_type == CVD_DEPTH_GRID ? h->ddesc.grid_size[1] : 1;
   L.maxcx = std::nextafter(static_cast<double>(L.gx - 1), 0.0);
   L.maxcy = std::nextafter(static_cast<double>(L.gy - 1), 0.0);
+  L.gz = h->ddesc.depth_type == CVD_DEPTH_GRID ? std::max(1, h->ddesc.grid_size[2]) : 1;
+  L.maxcz = std::nextafter(static_cast<double>(L.gz - 1), 0.0);
+  L.dispMin = 0.0;
+  L.dispInterval = 1.0;
+  if (L.gz > 1) {  // reference lib/DepthMapTransform.cpp:719-729
+    const double dmin = 1.0 / h->ddesc.depth_min_max[1], dmax = 1.0 / h->ddesc.depth_min_max[0];
+    L.dispMin = dmin;
+    L.dispInterval = (dmax - dmin) / (L.gz - 1);
+  }
   L.nD = h->nD();
   L.spatialType = h->sdesc.spatial_type;
   L.sgx = h->sdesc.grid_size[0];
@@ -686,6 +701,7 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
   L.adaptive = 0.0;
   if (p.adaptive_deformation_cost > 0.0 && L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) {
     if (!h->haveDynMasks) throw std::runtime_error("Adaptive smoothness requires a dynamic mask stream.");
+    if (L.gz > 1) throw std::runtime_error("AdaptiveDeformationCost with a depth-wise grid is not implemented on the device path.");
     if (L.gx < 2 || L.gy < 2) throw std::runtime_error("Adaptive deformation cost needs a grid of at least 2 x 2 vertices.");
     if (h->adaptGx != L.gx || h->adaptGy != L.gy) {
       const size_t G = static_cast<size_t>(L.gx) * L.gy;
@@ -714,6 +730,8 @@ static void checkFrameBlock(size_t B, const char* what) {
 
 static void tapCounts(const Layout& L, int& KD, int& KS) {
   KD = (L.depthType == CVD_DEPTH_GRID) ? (L.cubic ? 16 : 4) : 1;
+  // depth-wise grids: 8 taps (spatial x depth-wise) run in the 16-slot instantiation, 2 taps (depth-wise only) in the 4-slot
+  if (L.depthType == CVD_DEPTH_GRID && L.gz > 1) KD = L.gx > 1 ? 16 : 4;
   switch (L.spatialType) {
     case CVD_SPATIAL_IDENTITY: KS = 0; break;
     case CVD_SPATIAL_BICUBIC_GRID: KS = 16; break;
@@ -723,6 +741,7 @@ static void tapCounts(const Layout& L, int& KD, int& KS) {
 
 // Scope of the specialised fast kernels: identity spatial transform and the three reprojection losses.
 static bool fastLoss(const Layout& L) {
+  if (L.gz > 1) return false;  // (the fast kernels gather 2-D grids only)
   return L.lossType == CVD_STATIC_REPRO_DISPARITY || L.lossType == CVD_STATIC_REPRO_DEPTH_RATIO || L.lossType == CVD_STATIC_REPRO_LOG_DEPTH;
 }
 
@@ -1673,7 +1692,7 @@ static void prepareMatvec(Ctx& c, const double* x) {
   int nr = 0;
   if (L.scaleRegSqrt > 0.0) nr += L.sregX * L.sregY;
   if (L.focalRegSqrt > 0.0) nr += 1;
-  if (L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) nr += ((L.gx - 1) * L.gy + L.gx * (L.gy - 1)) * L.N;
+  if (L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) nr += gridNumEdges(L.gx, L.gy, L.gz) * L.N;
   if (L.spatialDeformW > 0.0) nr += L.nS;
   const int stride = std::max(2, c.KD * std::max(1, L.N));
   const size_t entries = static_cast<size_t>(L.F) * stride * std::max(nr, 1);
@@ -2741,7 +2760,7 @@ static void denseMaps(cvd_handle* h, int kind, int first, int count, int w, int 
     });
   } else if (kind == 1) {
     CVD_DISPATCH_KD(KD, {
-      hipLaunchKernelGGL((k_param_map<KD>), grid, block, 0, s, L, w, hh, first, h->dX.p, h->dDense.p);
+      hipLaunchKernelGGL((k_param_map<KD>), grid, block, 0, s, L, w, hh, first, h->dDepth.p, h->dX.p, h->dDense.p);
     });
   } else {
     if (KS == 0) hipLaunchKernelGGL((k_warp_map<0>), grid, block, 0, s, L, w, hh, first, h->dX.p, reinterpret_cast<float2*>(h->dDense.p));

@@ -92,7 +92,7 @@ __device__ __forceinline__ void evalTriplet(const Layout& L, int smoothType, con
   for (int k = 0; k < 3; ++k) {
     Side<KD, KS>& s = T.s[k];
     s.d = static_cast<double>(ds[k]);
-    depthGather<KD>(L, nd[k].x, nd[k].y, s.dt);
+    depthGather<KD>(L, nd[k].x, nd[k].y, ds[k], s.dt);
     spatialGather<KS>(L, nd[k].x, nd[k].y, s.st);
     D[k] = sideDepth(L, s, X[k]);
     p[k][0] = static_cast<double>(nd[k].x);

@@ -347,7 +347,8 @@ struct Xform {
     return desc_.spatialType == SpatialXformType::Identity ? 0 : 2;
   }
   // taps of one sample (depth or spatial), using the shared host/device spline helpers
-  int gather(float lx, float ly, int* idx, double* w) const {
+  // srcDepth: the sample's source depth, looked at by depth-wise grids only (gridSize.z > 1)
+  int gather(float lx, float ly, int* idx, double* w, float srcDepth = 0.f) const {
     const int gx = desc_.gridSize[0], gy = desc_.gridSize[1];
     const double mx = std::nextafter(static_cast<double>(gx - 1), 0.0), my = std::nextafter(static_cast<double>(gy - 1), 0.0);
     if (desc_.type == XformType::Depth) {
@@ -355,7 +356,30 @@ struct Xform {
         case DepthXformType::Identity: return 0;
         case DepthXformType::Global: idx[0] = 0; w[0] = 1.0; return 1;
         case DepthXformType::Grid:
-          if (desc_.gridSize[2] > 1) throw std::runtime_error("Depth-wise grids are not supported on this path.");
+          if (desc_.gridSize[2] > 1) {
+            // GridDepthXform::linearGather with a depth-wise axis, reference lib/DepthMapTransform.cpp:771-851
+            if (desc_.cubicInterpolation) throw std::runtime_error("Cubic interpolation of depth-wise grids is not defined.");
+            const int gz = desc_.gridSize[2];
+            const double dmin = 1.0 / desc_.depthMinMax[1], dmax = 1.0 / desc_.depthMinMax[0];
+            const double interval = (dmax - dmin) / (gz - 1), mz = std::nextafter(static_cast<double>(gz - 1), 0.0);
+            double sz = (1.0 / static_cast<double>(srcDepth) - dmin) / interval;
+            sz = sz < 0.0 ? 0.0 : (sz > mz ? mz : sz);
+            const int iz = static_cast<int>(sz);
+            const double rz = sz - iz;
+            if (gx > 1) {
+              int i4[4];
+              double w4[4];
+              cvd::bilinearTaps(lx, ly, gx, gy, mx, my, i4, w4);
+              for (int k = 0; k < 4; ++k) {
+                idx[k] = i4[k] + iz * gx * gy;           w[k] = w4[k] * (1.0 - rz);
+                idx[4 + k] = i4[k] + (iz + 1) * gx * gy; w[4 + k] = w4[k] * rz;
+              }
+              return 8;
+            }
+            idx[0] = iz; w[0] = 1.0 - rz;
+            idx[1] = iz + 1; w[1] = rz;
+            return 2;
+          }
           if (desc_.cubicInterpolation) return cvd::bicubicTaps(lx, ly, gx, gy, mx, my, idx, w);
           cvd::bilinearTaps(lx, ly, gx, gy, mx, my, idx, w);
           return 4;
@@ -425,7 +449,7 @@ struct DepthXform : Xform {
         const float lx = -1.f + x * xs;
         const double d = src[static_cast<size_t>(y) * w + x];
         if (N == 0) { dst[static_cast<size_t>(y) * w + x] = static_cast<float>(d); continue; }
-        const int n = gather(lx, ly, idx, wt);
+        const int n = gather(lx, ly, idx, wt, src[static_cast<size_t>(y) * w + x]);
         double D = 0.0;
         for (int k = 0; k < n; ++k)
           D += ((N == 2) ? (d * params_[idx[k] * 2] + params_[idx[k] * 2 + 1]) : d * params_[idx[k]]) * wt[k];
@@ -734,11 +758,13 @@ py::array DepthXform::paramMap(const DepthFrame& dfc) const {  // reference lib/
   const float xs = 2.f / (w - 1.f), ys = 2.f / (h - 1.f);
   int idx[16];
   double wt[16];
+  const std::vector<float>* src = desc_.gridSize[2] > 1 ? df.sourceDepth() : nullptr;  // (depth-wise grids: reference :953,966)
+  if (desc_.gridSize[2] > 1 && !src) throw std::runtime_error("Missing depth image.");
   for (int y = 0; y < h; ++y) {
     const float ly = 1.f - y * ys;
     for (int x = 0; x < w; ++x) {
       const float lx = -1.f + x * xs;
-      const int n = gather(lx, ly, idx, wt);
+      const int n = gather(lx, ly, idx, wt, src ? (*src)[static_cast<size_t>(y) * w + x] : 0.f);
       double* o = dst + (static_cast<size_t>(y) * w + x) * N;
       for (int d = 0; d < N; ++d) o[d] = 0.0;
       for (int k = 0; k < n; ++k)
