@@ -376,7 +376,7 @@ def main():
                 "workload": (f"{cfg['label']}{' dense' if args.dense else ''}: {frames}-frame {width}x{height} synthetic video, hierarchical2 two-way flow_list "
                              f"densified to level {level} ({m['full']['pairs']} directed pairs, "
                              + (f"DENSE mode: every masked pixel is a constraint, {n_active} flow constraints read from the flow / mask / "
-                                f"depth images" if args.dense else f"{m['full']['constraints']} flow constraints") + "), full LM loop; timed = LM iterations at the final CTF level ({m['grid'][0]}x{m['grid'][1]} "
+                                f"depth images" if args.dense else f"{m['full']['constraints']} flow constraints") + f"), full LM loop; timed = LM iterations at the final CTF level ({m['grid'][0]}x{m['grid'][1]} "
                              f"bilinear grid, B={B}, {frames * B} unknowns), {'Huber' if robust else 'Cauchy'} {params.robustness}, "
                              f"PerFrame intrinsics, default solver options"),
                 "pairs": int(m["full"]["pairs"]), "constraints": int(n_active), "unknowns": int(frames * B),
