@@ -540,7 +540,7 @@ def test_full_size_zero_noise_recovery(Solver):
 
 def test_rccl_communicator_world_size_one(Solver):
     """The pair-sharded code path (RCCL all-reduces of g / H_ff / cost / q on the solver stream) with a 1-rank
-    communicator must reproduce the plain single-GPU solve bit for bit.  (N > 1 needs N GPUs: the decomposition itself
+    communicator must reproduce the plain single-GPU solve (to rounding: LDS f64 atomics make the sums order dependent).  (N > 1 needs N GPUs: the decomposition itself
     is covered on CPU by tests/test_sharding_gloo.py.)"""
     v = synth.make_video(8, 96, 56, seed=38)
     out = []
