@@ -954,13 +954,22 @@ __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges,
 }
 
 // potri(lower) on the column-major view leaves the inverse in what is the UPPER triangle of the row-major array:
-// mirrored into a full symmetric f32 matrix (an SPD approximation is all the preconditioner needs); info != 0 (not
-// positive definite) switches the level off through `fail`.
+// mirrored into a full symmetric f32 matrix (an SPD approximation is all the preconditioner needs).  info != 0: the
+// factorisation met a non-positive pivot.  The coarse matrix is singular along the gauge directions up to the LM
+// damping, so with a small damping this happens now and then (and not reproducibly: rocBLAS sums in varying order).  A
+// rebuild beside the solver then hands back a copy of the inverse in use (`keep`: nothing changes at the swap); a
+// first build has nothing to fall back on and switches the level off through `fail`.
 __global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* __restrict__ A, const int* __restrict__ info,
-                                                           float* __restrict__ out, int* __restrict__ fail) {
+                                                           float* __restrict__ out, int* __restrict__ fail,
+                                                           const float* __restrict__ keep) {
   const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (idx == 0 && (info[0] != 0 || info[1] != 0)) *fail = 1;
+  const bool bad = info[0] != 0 || info[1] != 0;
+  if (idx == 0 && bad && keep == nullptr) *fail = 1;
   if (idx >= static_cast<size_t>(n) * n) return;
+  if (bad && keep != nullptr) {
+    out[idx] = keep[idx];
+    return;
+  }
   const size_t r = idx / n, c = idx - r * n;
   out[idx] = static_cast<float>(c >= r ? A[r * n + c] : A[c * n + r]);
 }

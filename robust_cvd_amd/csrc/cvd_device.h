@@ -853,6 +853,21 @@ struct CoarseStep {
   const double* wq;     // [nW][kCB] products W_block (Z^T q)_column in ROW order (slot = position in the row lists):
                         // written column by column by coarseColumnProducts in the kernel that completes q
 };
+// Dense coarse level fused into k_cg_update (Ainv == nullptr: off).  c = A_c^-1 Z^T r is linear in r, so with
+// r <- r - alpha q it obeys c <- c - alpha A_c^-1 (Z^T q): the product needs only qc = Z^T q, which the kernel that
+// completed q left behind, i.e. nothing k_cg_update's own frame workgroups produce -- F extra workgroups of the same
+// launch do it (8 rows of the f32 inverse each) and the separate k_coarse_dense_apply launch disappears from the
+// iteration.  Z^T r is carried the same way (rc <- rc - alpha qc); both start from directly computed values at the
+// first residual of every PCG solve.
+struct DenseStep {
+  const float* Ainv;    // [8F][8F] f32
+  const double* qc;     // Z^T q, [F][kCB]
+  double* rc;           // Z^T r, [F][kCB]
+  double* c;            // A_c^-1 Z^T r, [F][kCB]
+  double* dotPart;      // [F] this frame's share of r^T Z A_c^-1 Z^T r
+  const unsigned char* modeActive;
+  const int* fail;
+};
 // Column half of y <- y - alpha W (Z^T q): the workgroup of frame f multiplies the blocks of ITS column of W (contiguous:
 // the elimination-tree path of the frame, <= tree depth blocks) with its restricted product and stores each 8-vector at
 // the block's slot in the row lists.  The row half (k_cg_update) then sums contiguous 8-vectors instead of gathering a

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -34,6 +35,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cvd_hip.h"
@@ -236,6 +238,66 @@ enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPD
                    // exchange steps of the pair-sharded multi-GPU mode (cvd_get_comm_times): timed whenever any class is
                    KC_COMM_EVAL = KC_COUNT, KC_COMM_PRODUCT, KC_COMM_COARSE, KC_TOTAL };
 
+// A helper host thread for work that is many small enqueues on the SIDE stream (the dense coarse level's rocSOLVER
+// inversion is ~250 kernel launches, ~2.3 ms of host time): submitted there, the main thread goes on enqueuing the
+// PCG and the device never idles between the block inverse and the first product.  One job at a time.
+class SideWorker {
+ public:
+  ~SideWorker() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  void submit(std::function<void()> job) {
+    wait();
+    std::lock_guard<std::mutex> g(m_);
+    if (!th_.joinable()) th_ = std::thread([this]() { run(); });
+    job_ = std::move(job);
+    busy_ = true;
+    cv_.notify_all();
+  }
+  // returns once the submitted job has finished ENQUEUING; rethrows what it threw
+  void wait() {
+    std::unique_lock<std::mutex> g(m_);
+    cv_.wait(g, [this]() { return !busy_; });
+    if (err_) {
+      std::exception_ptr e = err_;
+      err_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  void waitNoThrow() noexcept {
+    try { wait(); } catch (...) {}
+  }
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> g(m_);
+    while (true) {
+      cv_.wait(g, [this]() { return quit_ || (busy_ && job_); });
+      if (quit_) return;
+      std::function<void()> job = std::move(job_);
+      job_ = nullptr;
+      g.unlock();
+      std::exception_ptr e;
+      try { job(); } catch (...) { e = std::current_exception(); }
+      g.lock();
+      err_ = e;
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool busy_ = false, quit_ = false;
+  std::exception_ptr err_;
+};
+
 struct Ceres {  // ceres::Solver::Options defaults used on this path
   static constexpr double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
   static constexpr double min_relative_decrease = 1e-3;
@@ -317,7 +379,8 @@ struct cvd_handle_t {
   int nAsmParts = 0, nAsmSlots = 0;
   int numCU = 256;
   hipStream_t stream2 = nullptr;                       // side stream of the asynchronous coarse rebuild
-  hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr;
+  SideWorker sideWorker;                               // host thread that enqueues the dense rebuild there
+  hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr, evCoarseRead = nullptr;  // (evCoarseRead: the rebuild has consumed H, lam, x)
   DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
@@ -418,6 +481,7 @@ struct cvd_handle_t {
   long long kcN[KC_TOTAL] = {0};
 
   ~cvd_handle_t() {
+    sideWorker.waitNoThrow();
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& rbh : coarse.rb) if (rbh) (void)rocblas_destroy_handle(rbh);
     if (comm) (void)ncclCommDestroy(comm);
@@ -427,6 +491,7 @@ struct cvd_handle_t {
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
+    if (evCoarseRead) (void)hipEventDestroy(evCoarseRead);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1677,6 +1742,10 @@ static bool coarseFusedConsumers() {
   static const bool v = std::getenv("CVD_COARSE_FUSED") != nullptr;  // experiment: c_f formed inside the consumers
   return v;
 }
+static bool coarseDenseFused() {
+  static const bool v = std::getenv("CVD_COARSE_DENSE_UNFUSED") == nullptr;  // comparison knob: separate k_coarse_dense_apply launch
+  return v;
+}
 static CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
   if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto& C = h->coarse;
@@ -1788,6 +1857,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
     const bool fusedCoarse = withCoarse && !h->coarse.denseMode;
+    const bool denseFused = withCoarse && h->coarse.denseMode && coarseDenseFused() && !h->dist();  // (needs Z^T q: DenseStep)
     const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, fusedCoarse ? h->coarse.Wb.p : nullptr,
                            h->coarse.wq.p};
     const int slot = h->tBegin(KC_MATVEC_FINISH);
@@ -1796,7 +1866,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
                          h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
                          h->dist() ? (h->rank == 0 ? 1 : 2) : 0, h->qRows, h->regCache, cF,
-                         (fusedCoarse && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
+                         ((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
     });
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
@@ -1958,29 +2028,46 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
     NCCL_CHECK(ncclAllGather(C.diag.p + static_cast<size_t>(h->rank) * chunk, C.diag.p, chunk, ncclDouble, h->comm, s));
     h->tEnd(ct);
   }
+  // (everything below works on the coarse level's own buffers: the solver's H, lam, x have been consumed)
+  if (side) HIP_CHECK(hipEventRecord(h->evCoarseRead, s));
   if (C.denseMode) {
     const int n = c.L.F * kCB;
-    if (!C.rb[side]) {
-      if (rocblas_create_handle(&C.rb[side]) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
-      if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
-    }
     C.denseA.ensure(static_cast<size_t>(n) * n);
     C.denseInv.ensure(static_cast<size_t>(n) * n);
     C.denseInv2.ensure(static_cast<size_t>(n) * n);
     C.denseInfo.ensure(2);
-    HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
-    HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(c.L.F + C.nEdges), dim3(64), 0, s, c.L.F, C.nEdges, C.diag.p, C.edges.p,
-                       C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
-    HIP_CHECK(hipGetLastError());
-    // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
-    if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
-      throw std::runtime_error("rocsolver_dpotrf failed");
-    if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
-      throw std::runtime_error("rocsolver_dpotri failed");
-    hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
-                       C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut);
-    HIP_CHECK(hipGetLastError());
+    const int F = c.L.F, nEdges = C.nEdges;
+    // (everything the job needs by value: it may still be enqueuing while the caller's frame moves on)
+    auto job = [h, s, side, n, F, nEdges, failOut]() {
+      auto& C = h->coarse;
+      HIP_CHECK(hipSetDevice(h->device));
+      if (!C.rb[side]) {
+        if (rocblas_create_handle(&C.rb[side]) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
+        if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
+      }
+      HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
+      HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
+      hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, s, F, nEdges, C.diag.p, C.edges.p,
+                         C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
+      HIP_CHECK(hipGetLastError());
+      // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
+      if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
+        throw std::runtime_error("rocsolver_dpotrf failed");
+      if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
+        throw std::runtime_error("rocsolver_dpotri failed");
+      hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
+                         C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut,
+                         side ? C.denseInv.p : nullptr);
+      HIP_CHECK(hipGetLastError());
+      if (side) HIP_CHECK(hipEventRecord(h->evCoarseDone, s));
+    };
+    static const bool noWorker = std::getenv("CVD_COARSE_NO_WORKER") != nullptr;  // comparison knob
+    if (side && !noWorker) {
+      h->sideWorker.submit(job);  // ~250 launches: enqueued by the helper thread while this one enqueues the PCG
+    } else {
+      h->sideWorker.wait();
+      job();
+    }
     return;
   }
   static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
@@ -2044,9 +2131,15 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
                               ? CoarseStep{h->coarse.wtPtr.p, h->coarse.wtBlk.p, h->coarse.wtFrame.p, h->coarse.Wb.p,
                                            h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p, h->coarse.wq.p}
                               : csOff;
+  const DenseStep dsOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // dense level: c <- c - alpha A_c^-1 Z^T q inside k_cg_update (F extra workgroups) instead of a launch of its own
+  const bool denseFused = denseCoarse && coarseDenseFused() && !h->dist();
+  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
+                                                h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
+                                    : dsOff;
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p, h->hPcg, csOff);
+                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff);
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -2065,10 +2158,10 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     h->curPcgIter = it;
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p,
-                       h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
-                       (coarse && unfusedY) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn);
-    if (coarse) { if (unfusedY) coarseApply(0); else coarseC(0); }
+    hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? 2 * F : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+                       h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
+                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn);
+    if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
     std::swap(pOld, pNew);
@@ -2174,6 +2267,10 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   if (h->F <= 0) throw std::runtime_error("no video set");
   if (!h->poseParamsValid) posesToParams(h);
   const std::vector<int> range = rangeOf(p, h->F);
+  struct WorkerGuard {  // (also on the exception paths)
+    cvd_handle* h;
+    ~WorkerGuard() { h->sideWorker.waitNoThrow(); }
+  } workerGuard{h};
   Ctx c;
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, kind);
@@ -2257,8 +2354,16 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     coarseAge = 0;
     cgExcess = kCoarseRebuildIters;
   }
+  // The dense level's rebuild (~6.5 ms of dependent rocSOLVER kernels) outlasts one PCG solve (~5 ms at 4140 pairs): it is
+  // installed after the SECOND solve that runs beside it (a fixed lag, not an event query: the iteration sequence stays
+  // a function of the data alone), so that the main stream never waits for it.
+  static const int kDenseInstallLag = []() { const char* e = std::getenv("CVD_COARSE_DENSE_LAG"); return e ? std::max(1, std::atoi(e)) : 2; }();
+  int pendingSolves = 0;  // PCG solves run since the pending rebuild was started
   auto installPendingCoarse = [&]() {
     if (!coarsePending) return;
+    if (h->coarse.denseMode && ++pendingSolves < kDenseInstallLag) return;
+    pendingSolves = 0;
+    h->sideWorker.wait();  // (the helper thread has finished enqueuing: normally long ago)
     HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseDone, 0));  // (device-side wait: the host does not block)
     std::swap(h->coarse.Wb.p, h->coarse.Wb2.p);
     std::swap(h->coarse.Wb.n, h->coarse.Wb2.n);
@@ -2301,7 +2406,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       // The block-Jacobi level follows lam every LM iteration; the coarse level is rebuilt on demand (below).
       // (Lagging the block inverse as well is ~4% faster on the benchmark but makes the converged parameters
       // visibly sensitive to rounding noise along the weak gauge directions.)
-      const bool willRefresh = !h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters;
+      const bool willRefresh = !coarsePending &&
+                               (!h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters);
       {
         const int slot = h->tBegin(KC_INVERSE);
         launchBlockInverse(c);
@@ -2327,7 +2433,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
             HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
             HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
             launchCoarseSetup(c, h->dX.p, 1);
-            HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));
+            if (!h->coarse.denseMode) HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));  // (dense: recorded by the job)
             coarsePending = true;
             cgExcess = 0;
           } else {
@@ -2353,6 +2459,28 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         HIP_CHECK(hipGetLastError());
         enqueueCost(c, h->dXc.p);
       });
+      static const bool dbgCoarse = std::getenv("CVD_DEBUG_COARSE") != nullptr;
+      if (dbgCoarse && h->coarseOn && h->coarse.denseMode) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        int fl[2] = {-1, -1};
+        HIP_CHECK(hipMemcpy(&fl[0], h->coarse.fail.p, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&fl[1], h->coarse.fail2.p, 4, hipMemcpyDeviceToHost));
+        const size_t nn = static_cast<size_t>(c.L.F) * kCB;
+        std::vector<float> dg(nn);
+        HIP_CHECK(hipMemcpy2D(dg.data(), 4, h->coarse.denseInv.p, (nn + 1) * 4, 4, nn, hipMemcpyDeviceToHost));
+        double tr = 0.0;
+        for (float v : dg) tr += v;
+        std::vector<double> cc(nn);
+        HIP_CHECK(hipMemcpy(cc.data(), h->coarse.c.p, nn * 8, hipMemcpyDeviceToHost));
+        double cn = 0.0;
+        for (double v : cc) cn += v * v;
+        fprintf(stderr, "[coarse dbg] it %d pcg %d fail %d fail2 %d inv %p trace %.10e |c| %.6e pending %d\n", iteration, cgIters, fl[0], fl[1],
+                (void*)h->coarse.denseInv.p, tr, std::sqrt(cn), coarsePending ? 1 : 0);
+      }
+      // a rebuild still pending past this point (the dense level's fixed lag) must have read its inputs before the next
+      // evaluation rewrites them: the side stream competes with a main stream that is never idle, so "enqueued 4 ms ago"
+      // is not "executed" (device-side wait, satisfied long ago in the normal case)
+      if (coarsePending) HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseRead, 0));
       if (freshFactor) cgAfterRefresh = cgIters;
       else cgExcess += std::max(0, cgIters - cgAfterRefresh);
       freshFactor = false;
@@ -2431,6 +2559,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       }
     }
   }
+  h->sideWorker.wait();  // (a rebuild started beside the last PCG: its enqueuing must not outlive this frame)
   downloadState(h, c.L, h->dX);
   h->tCollect();
   sum.num_iterations = iteration;
@@ -2931,6 +3060,7 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseRead, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
     return h;
   } catch (const std::exception& e) {

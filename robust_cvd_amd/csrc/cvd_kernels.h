@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
                                                     double tol2, double* __restrict__ rc,
                                                     const unsigned char* __restrict__ modeActive,
-                                                    double* __restrict__ hostMirror, CoarseStep cs) {
+                                                    double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const double sDone = init ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
   const int B = L.B;
@@ -1529,10 +1529,71 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   double* red = part + nThreads;   // 2 * 16 wave partials + 10
   double* ypart = red + 48;        // 16 waves x kCB partial sums of the fused y update + kCB squares
   const bool fusedY = !init && cs.Wb != nullptr;
+  const bool fusedDense = !init && ds.Ainv != nullptr;  // (the grid then has F extra workgroups)
+  const int nWaves = nThreads >> 6;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   const double alpha = init ? 0.0 : scal[S_ALPHA];
+  if (f >= L.F) {
+    // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
+    // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
+    const int g = f - L.F, wv = tid >> 6, lane = tid & 63, nWv = nThreads >> 6;
+    const size_t n = static_cast<size_t>(L.F) * kCB, n4 = n / 4;
+    const bool on0 = *ds.fail == 0;
+    double accs[2] = {0.0, 0.0};  // rows wv and wv + nWv (nWv >= 4: blockDim is a multiple of 256)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int m = wv + rr * nWv;
+      if (m >= kCB) break;
+      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
+      constexpr int U = 2;  // (register budget: the kernel must keep two 768-thread workgroups per CU)
+      const double2* qc2 = reinterpret_cast<const double2*>(ds.qc);
+      double acc = 0.0;
+      for (size_t j0 = lane; j0 < n4; j0 += U * 64) {
+        float4 w[U];
+        double2 qa[U], qb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const size_t j = j0 + u * 64;
+          const bool in = j < n4;
+          const size_t jc = in ? j : 0;
+          w[u] = row[jc];
+          if (!in) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          qa[u] = qc2[2 * jc];
+          qb[u] = qc2[2 * jc + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          acc += (static_cast<double>(w[u].x) * qa[u].x + static_cast<double>(w[u].y) * qa[u].y) +
+                 (static_cast<double>(w[u].z) * qb[u].x + static_cast<double>(w[u].w) * qb[u].y);
+      }
+      accs[rr] = acc;
+    }
+    asm volatile("" : "+v"(accs[0]), "+v"(accs[1]));  // (keeps the loads above the early exit)
+    if (sDone != 0.0) return;                          // uniform; nothing written yet
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int m = wv + rr * nWv;
+      if (m >= kCB) break;
+      const double d = waveSum(accs[rr]);
+      if (lane == 0) {
+        const int e = g * kCB + m;
+        const double rcn = ds.rc[e] - alpha * ds.qc[e];
+        const double cn = (on0 && ds.modeActive[e]) ? ds.c[e] - alpha * d : 0.0;
+        ds.rc[e] = rcn;
+        ds.c[e] = cn;
+        ypart[m] = cn * rcn;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kCB; ++k) t += ypart[k];
+      ds.dotPart[g] = t;
+    }
+  } else {
   {
     // one element per thread (blockDim = 256 * ceil(B / 64) >= B).  The vector loads are issued together with the
     // scalars' and the convergence flag is tested once they are back: one dependent global round trip instead of two
@@ -1621,7 +1682,6 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   }
   rz = waveSum(rz);
   rr = waveSum(rr);
-  const int nWaves = nThreads >> 6;
   if ((tid & 63) == 0) { red[tid >> 6] = rz; red[16 + (tid >> 6)] = rr; }
   __syncthreads();
   if (tid == 0) {
@@ -1648,13 +1708,15 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
       cs.fdotY[f] = t;
     }
   }
+  }  // frame workgroups
   // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
-  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 40))) {
+  if (lastBlockArrives(counter, gridDim.x, reinterpret_cast<int*>(red + 40))) {
     double a = 0.0, b = 0.0, cY = 0.0;
     for (int k = tid; k < L.F; k += nThreads) {
       a += fdotRZ[k];
       b += fdotRR[k];
       if (fusedY) cY += cs.fdotY[k];
+      if (fusedDense) cY += ds.dotPart[k];
     }
     a = waveSum(a);
     b = waveSum(b);
@@ -1667,6 +1729,8 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
       for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; ys += ypart[w]; }
       if (fusedY) {  // two-level r^T z; a broken-down coarse factorisation switches the level off (consumers use c = 0)
         pcgFinishScalars(scal, 0, rzs + (*cs.fail == 0 ? ys : 0.0), rrs, tol2, hostMirror);
+      } else if (fusedDense) {  // (a failed inverse left c = 0 and zero shares)
+        pcgFinishScalars(scal, 0, rzs + ys, rrs, tol2, hostMirror);
       } else if (rc != nullptr) {  // first residual: k_coarse_apply_w adds its part of r^T z and finishes the scalars
         scal[S_RZPART] = rzs;
         scal[S_RR] = rrs;
