@@ -429,6 +429,9 @@ struct cvd_handle_t {
     bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
     // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f32 matrix, two buffers for the side-stream rebuild
     bool denseMode = false;
+    hipGraphExec_t denseGraph = nullptr;  // the side stream's assemble + potrf + potri sequence (launchCoarseSetup)
+    std::array<const void*, 8> denseGraphKey{};
+    int denseGraphState = 0;              // 0 first direct call still to come, 1 capture allowed, -1 capture unsupported
     bool denseReady = false;  // denseInv holds an inverse for this plan (possibly of an earlier solve: a usable, stale preconditioner)
     DevBuf<double> denseA;
     DevBuf<float> denseInv, denseInv2;
@@ -483,6 +486,7 @@ struct cvd_handle_t {
   ~cvd_handle_t() {
     sideWorker.waitNoThrow();
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (coarse.denseGraph) (void)hipGraphExecDestroy(coarse.denseGraph);
     for (auto& rbh : coarse.rb) if (rbh) (void)rocblas_destroy_handle(rbh);
     if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
@@ -2045,16 +2049,59 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
         if (rocblas_create_handle(&C.rb[side]) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
         if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
       }
-      HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
-      HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
-      hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, s, F, nEdges, C.diag.p, C.edges.p,
-                         C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
-      HIP_CHECK(hipGetLastError());
-      // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
-      if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
-        throw std::runtime_error("rocsolver_dpotrf failed");
-      if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
-        throw std::runtime_error("rocsolver_dpotri failed");
+      // memsets + assembly + potrf + potri: ~250 small launches, ~2.3 ms of host time when issued one by one.  Beside the
+      // solver (side stream) the sequence is captured ONCE into a hipGraph and replayed with a single launch; the graph is
+      // keyed on every pointer / size baked into its nodes.  A capture that rocSOLVER does not support falls back to direct
+      // calls for good (state -1).
+      auto direct = [&]() {
+        HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
+        HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, s, F, nEdges, C.diag.p, C.edges.p,
+                           C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
+        HIP_CHECK(hipGetLastError());
+        // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
+        if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
+          throw std::runtime_error("rocsolver_dpotrf failed");
+        if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
+          throw std::runtime_error("rocsolver_dpotri failed");
+      };
+      static const bool graphOff = std::getenv("CVD_COARSE_NO_GRAPH") != nullptr;  // comparison knob
+      const std::array<const void*, 8> key{C.denseA.p, C.denseInfo.p, C.diag.p, C.edges.p, C.edgeFa.p, C.modeActive.p,
+                                           reinterpret_cast<const void*>(static_cast<size_t>(n)),
+                                           reinterpret_cast<const void*>(static_cast<size_t>(nEdges))};
+      if (!side || graphOff || C.denseGraphState < 0) {
+        direct();
+      } else if (C.denseGraphState == 0) {
+        direct();  // (first call on this handle: rocBLAS sizes its workspace, loads its kernels -- not capturable)
+        C.denseGraphState = 1;
+      } else {
+        if (C.denseGraph != nullptr && C.denseGraphKey != key) {
+          (void)hipGraphExecDestroy(C.denseGraph);
+          C.denseGraph = nullptr;
+        }
+        if (C.denseGraph == nullptr) {
+          hipGraph_t g = nullptr;
+          bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+          if (ok) {
+            try { direct(); } catch (...) { ok = false; }
+            if (hipStreamEndCapture(s, &g) != hipSuccess || g == nullptr) ok = false;
+          }
+          if (ok && hipGraphInstantiate(&C.denseGraph, g, nullptr, nullptr, 0) != hipSuccess) {
+            ok = false;
+            C.denseGraph = nullptr;
+          }
+          if (g != nullptr) (void)hipGraphDestroy(g);
+          (void)hipGetLastError();
+          if (!ok) {
+            C.denseGraphState = -1;
+            C.denseGraph = nullptr;
+          } else {
+            C.denseGraphKey = key;
+          }
+        }
+        if (C.denseGraph != nullptr) HIP_CHECK(hipGraphLaunch(C.denseGraph, s));
+        else direct();
+      }
       hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
                          C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut,
                          side ? C.denseInv.p : nullptr);
@@ -2099,7 +2146,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   const int nChunks = static_cast<int>((B + 63) / 64);
   const int nThreads = 256 * nChunks;
   double* fd = h->dFdot.p;
-  const size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
+  size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
   for (int i = 0; i < 9; ++i) h->hPcg[i] = 0.0;  // device progress mirror (pcgFinishScalars): nothing applied yet
   const bool coarse = h->coarseOn;
@@ -2137,6 +2184,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
                                                 h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
                                     : dsOff;
+  if (denseFused) ldsU = std::max(ldsU, (static_cast<size_t>(F) * kCB + nThreads + 16) * 8);  // (its workgroups: Z^T q + partial sums)
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
                      h->coarse.modeActive.p, h->hPcg, csOff, dsOff);
@@ -2158,7 +2206,7 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
     h->curPcgIter = it;
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? 2 * F : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+    hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
                        (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn);
     if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
@@ -2173,7 +2221,8 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   // k - kRunAhead + 1 iterations is known to be clear: nothing but the PCG kernels is in the stream, the device is
   // never starved (kRunAhead iterations are queued ahead) and kRunAhead - 1 early-exit iterations are wasted per
   // solve.  The rule is a function of iteration counts only, hence identical on all ranks of a sharded run.
-  const int kRunAhead = lockstep ? 1 : 2;
+  static const int runAheadEnv = []() { const char* e = std::getenv("CVD_PCG_RUN_AHEAD"); return e ? std::max(1, std::atoi(e)) : 2; }();
+  const int kRunAhead = lockstep ? 1 : runAheadEnv;
   volatile double* prog = h->hPcg;
   while (enq < maxIt) {
     if (enq >= kRunAhead - 1) {
@@ -2474,8 +2523,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
         HIP_CHECK(hipMemcpy(cc.data(), h->coarse.c.p, nn * 8, hipMemcpyDeviceToHost));
         double cn = 0.0;
         for (double v : cc) cn += v * v;
-        fprintf(stderr, "[coarse dbg] it %d pcg %d fail %d fail2 %d inv %p trace %.10e |c| %.6e pending %d\n", iteration, cgIters, fl[0], fl[1],
-                (void*)h->coarse.denseInv.p, tr, std::sqrt(cn), coarsePending ? 1 : 0);
+        fprintf(stderr, "[coarse dbg] it %d pcg %d fail %d fail2 %d inv %p trace %.10e |c| %.6e pending %d graph %d/%p\n", iteration, cgIters, fl[0], fl[1],
+                (void*)h->coarse.denseInv.p, tr, std::sqrt(cn), coarsePending ? 1 : 0, h->coarse.denseGraphState, (void*)h->coarse.denseGraph);
       }
       // a rebuild still pending past this point (the dense level's fixed lag) must have read its inputs before the next
       // evaluation rewrites them: the side stream competes with a main stream that is never idle, so "enqueued 4 ms ago"

@@ -112,6 +112,7 @@ struct Items {
 // and the units into parts (one workgroup each) of bounded size, so that frames with many pairs (the long-range
 // levels of the hierarchical flow list) do not set the kernel's duration.  Parts of a split frame publish their
 // packed partial blocks and the last one to arrive folds them (lastBlockArrives on a per-frame counter).
+constexpr int kDenseFramesPerGroup = 2;  // frames per dense-level workgroup of k_cg_update (DenseStep)
 constexpr int kAsmUnit = 128;
 // Dense mode: 2048 pixel slots per unit, dealt to the 64 lanes in runs of 32 consecutive pixels (see kDenseRun)
 constexpr int kAsmUnitDense = 2048;
@@ -1538,60 +1539,85 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   if (f >= L.F) {
     // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
     // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
-    const int g = f - L.F, wv = tid >> 6, lane = tid & 63, nWv = nThreads >> 6;
-    const size_t n = static_cast<size_t>(L.F) * kCB, n4 = n / 4;
-    const bool on0 = *ds.fail == 0;
-    double accs[2] = {0.0, 0.0};  // rows wv and wv + nWv (nWv >= 4: blockDim is a multiple of 256)
+    // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the inverse are issued
+    // at once, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in LDS
+    constexpr int kDenseLoads = 8;
+    const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
+    const size_t n = static_cast<size_t>(L.F) * kCB;
+    const int n4 = static_cast<int>(n / 4);
+    double* qcs = sm;                       // n doubles (the frame workgroups' layout is not used here)
+    double* psum = sm + n;                  // nThreads partial sums
+    // kDenseFramesPerGroup frames per workgroup, one after the other: F + F / 2 workgroups of 768 threads still fit the
+    // device in ONE round (two per CU), F + F do not
+    const int g0 = (f - L.F) * kDenseFramesPerGroup;
+    float4 w[kDenseLoads];
+    {
+      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + m) * n);
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int m = wv + rr * nWv;
-      if (m >= kCB) break;
-      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
-      constexpr int U = 2;  // (register budget: the kernel must keep two 768-thread workgroups per CU)
-      const double2* qc2 = reinterpret_cast<const double2*>(ds.qc);
-      double acc = 0.0;
-      for (size_t j0 = lane; j0 < n4; j0 += U * 64) {
-        float4 w[U];
-        double2 qa[U], qb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const size_t j = j0 + u * 64;
-          const bool in = j < n4;
-          const size_t jc = in ? j : 0;
-          w[u] = row[jc];
-          if (!in) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          qa[u] = qc2[2 * jc];
-          qb[u] = qc2[2 * jc + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          acc += (static_cast<double>(w[u].x) * qa[u].x + static_cast<double>(w[u].y) * qa[u].y) +
-                 (static_cast<double>(w[u].z) * qb[u].x + static_cast<double>(w[u].w) * qb[u].y);
+      for (int u = 0; u < kDenseLoads; ++u) {
+        const int j = part + u * per;
+        w[u] = row[j < n4 ? j : 0];
+        if (j >= n4) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      accs[rr] = acc;
     }
-    asm volatile("" : "+v"(accs[0]), "+v"(accs[1]));  // (keeps the loads above the early exit)
-    if (sDone != 0.0) return;                          // uniform; nothing written yet
+    for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = ds.qc[i];
+    const bool on0 = *ds.fail == 0;
+    __syncthreads();
+    if (sDone != 0.0) return;  // uniform; nothing written yet
+    for (int rep = 0; rep < kDenseFramesPerGroup; ++rep) {
+      const int g = g0 + rep;
+      if (g >= L.F) break;
+      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
+      if (rep > 0) {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int m = wv + rr * nWv;
-      if (m >= kCB) break;
-      const double d = waveSum(accs[rr]);
-      if (lane == 0) {
-        const int e = g * kCB + m;
-        const double rcn = ds.rc[e] - alpha * ds.qc[e];
-        const double cn = (on0 && ds.modeActive[e]) ? ds.c[e] - alpha * d : 0.0;
+        for (int u = 0; u < kDenseLoads; ++u) {
+          const int j = part + u * per;
+          w[u] = row[j < n4 ? j : 0];
+          if (j >= n4) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      const int e = g * kCB + (tid < kCB ? tid : 0);
+      const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
+      const bool on = on0 && ds.modeActive[e];
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < kDenseLoads; ++u) {
+        const int j = part + u * per;
+        const double* q4 = qcs + 4 * (j < n4 ? j : 0);
+        acc += (static_cast<double>(w[u].x) * q4[0] + static_cast<double>(w[u].y) * q4[1]) +
+               (static_cast<double>(w[u].z) * q4[2] + static_cast<double>(w[u].w) * q4[3]);
+      }
+      for (int j = part + kDenseLoads * per; j < n4; j += per) {  // (more than 8 x per float4 per row: F > 3 nThreads / 8)
+        const float4 ww = row[j];
+        const double* q4 = qcs + 4 * j;
+        acc += (static_cast<double>(ww.x) * q4[0] + static_cast<double>(ww.y) * q4[1]) +
+               (static_cast<double>(ww.z) * q4[2] + static_cast<double>(ww.w) * q4[3]);
+      }
+      psum[tid] = acc;
+      __syncthreads();
+      if (tid < kCB * 8) {  // 8 lanes per row fold its `per` partials, then three shuffle steps
+        const int r = tid >> 3, l = tid & 7;
+        double t = 0.0;
+        for (int k = l; k < per; k += 8) t += psum[r * per + k];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (l == 0) psum[nThreads + r] = t;
+      }
+      __syncthreads();
+      if (tid < kCB) {
+        const double d = psum[nThreads + tid];
+        const double rcn = rcOld - alpha * qcv;
+        const double cn = on ? cOld - alpha * d : 0.0;
         ds.rc[e] = rcn;
         ds.c[e] = cn;
-        ypart[m] = cn * rcn;
+        double t = cn * rcn;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (tid == 0) ds.dotPart[g] = t;
       }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < kCB; ++k) t += ypart[k];
-      ds.dotPart[g] = t;
+      __syncthreads();  // (psum is reused by the next frame)
     }
   } else {
   {

@@ -28,3 +28,10 @@ for p, c in zip(rows, rows[1:]):
 print("transition                                                            count   mean gap us   total ms")
 for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:24]:
     print(f"{k[0][:32]:32s} -> {k[1][:32]:32s} {len(v):6d} {sum(v) / len(v):10.2f} {sum(v) / 1e3:10.3f}")
+# every idle gap above 30 us of the last fifth of the window, with the kernels around it
+tail = rows[int(len(rows) * 0.8):]
+print("gaps > 30 us (time since the window's start in ms, gap in us, previous kernel -> next kernel [duration us])")
+for i in range(1, len(tail)):
+    gap = (tail[i][0] - tail[i - 1][1]) / 1e3
+    if gap > 30.0:
+        print(f"  t {((tail[i][0] - tail[0][0]) / 1e6):9.3f}  gap {gap:8.1f}   {tail[i - 1][2][:28]:28s} [{(tail[i - 1][1] - tail[i - 1][0]) / 1e3:7.1f}] -> {tail[i][2][:28]:28s} [{(tail[i][1] - tail[i][0]) / 1e3:7.1f}]")
