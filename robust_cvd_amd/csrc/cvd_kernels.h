@@ -2114,6 +2114,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2
   for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
   double aFa = 0.0, aFb = 0.0;
   double gDa[2] = {0.0, 0.0}, gDb[2] = {0.0, 0.0};  // KD == 1: every sample hits the one depth block -> registers
+  const long long units0 = (it.range[item * 4 + 1] - it.range[item * 4] + 63) >> 6;  // wave-units of direction 0
   for (int dir = 0; dir < 2; ++dir) {
   const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
   // role swap for the reverse pair (source = fb, target = fa): swap every per-frame pointer
@@ -2152,7 +2153,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2
   const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
   // (dense mode keeps lane = pixel here: the private accumulator copies take care of the same-vertex collisions, and
   // the run-per-lane mapping of the assembly kernel measured slower for this kernel: 1.00 vs 0.75 ms)
-  for (long long c = cb + tid; c < ce; c += NT) {
+  // Wave-units of 64 constraints are dealt round-robin over the waves ACROSS the two directions: direction 1 starts with
+  // the wave after the one that took direction 0's last unit.  With ~9 units per direction and 4 waves the slowest wave
+  // walks 5 units instead of 3 + 3 (both directions' remainders used to land on waves 0, 1).
+  const int firstUnit = dir == 0 ? (tid >> 6) : static_cast<int>(((tid >> 6) - units0) & (NT / 64 - 1));
+  for (long long c = cb + firstUnit * 64 + (tid & 63); c < ce; c += NT) {
     float4 nd;
     float2 d;
     if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
