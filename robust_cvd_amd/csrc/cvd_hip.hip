@@ -2320,13 +2320,24 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     cvd_handle* h;
     ~WorkerGuard() { h->sideWorker.waitNoThrow(); }
   } workerGuard{h};
+  static const bool dbgSetup = std::getenv("CVD_DEBUG_SETUP") != nullptr;  // development: where a solve's fixed cost goes
+  double tPhase = nowSeconds();
+  auto phase = [&](const char* what) {
+    if (!dbgSetup) return;
+    const double t = nowSeconds();
+    fprintf(stderr, "[setup] %-14s %8.1f us\n", what, (t - tPhase) * 1e6);
+    tPhase = t;
+  };
   Ctx c;
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, kind);
   checkFrameBlock(static_cast<size_t>(c.L.B), "solve");
   tapCounts(c.L, c.KD, c.KS);
+  phase("layout");
   compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
+  phase("table");
   refreshMedians(h);
+  phase("medians");
   c.T = makeTable(h);
   c.nItems = static_cast<int>(h->itemFa.size());
   c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
@@ -2337,8 +2348,11 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
+  phase("buffers");
   buildMask(h, c.L, p, kind, range);
+  phase("mask");
   uploadState(h, c.L, h->dX);
+  phase("upload");
   hipStream_t s = h->stream;
   HIP_CHECK(hipMemsetAsync(h->dDx.p, 0, c.n * sizeof(double), s));
   HIP_CHECK(hipMemsetAsync(h->dR.p, 0, c.n * sizeof(double), s));
@@ -2363,6 +2377,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double xCost = evalFull(c, h->dX.p);
   tEval += nowSeconds() - te;
   sum.initial_cost = xCost;
+  phase("first eval");
 
   auto stats = [&]() {
     enqueueStats(c);
@@ -2381,6 +2396,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     for (double v : hd) na += (v != 0.0);
     sum.num_parameters = na;
   }
+  phase("stats");
 
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
@@ -2608,8 +2624,10 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
       }
     }
   }
+  phase("LM loop");
   h->sideWorker.wait();  // (a rebuild started beside the last PCG: its enqueuing must not outlive this frame)
   downloadState(h, c.L, h->dX);
+  phase("download");
   h->tCollect();
   sum.num_iterations = iteration;
   sum.termination = termination;
@@ -3106,7 +3124,14 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipDeviceGetAttribute(&h->numCU, hipDeviceAttributeMultiprocessorCount, device));
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     // side stream of the asynchronous coarse rebuild (created here: the first use of a new stream costs ~10 ms)
-    HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    {
+      // the side stream carries the coarse level's rebuild: long chains of SMALL kernels (rocSOLVER's panel factorisations
+      // run on one workgroup) that must not queue behind the solver's device-filling launches -- highest priority
+      int prioLow = 0, prioHigh = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+      static const bool flatPrio = std::getenv("CVD_SIDE_STREAM_FLAT") != nullptr;  // comparison knob
+      HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, flatPrio ? prioLow : prioHigh));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseRead, hipEventDisableTiming));
