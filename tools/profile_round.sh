@@ -19,6 +19,11 @@ CVD_PCG_LOCKSTEP=1 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_matvec_p
 K="k_matvec_pairs_fast|k_assemble_fast|k_cg_update|k_matvec_finish"
 CVD_PCG_LOCKSTEP=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_a -- $B --steps 4 --warmup 1 > $OUT/pmc_sq_a.log 2>&1
 CVD_PCG_LOCKSTEP=1 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_b -- $B --steps 4 --warmup 1 > $OUT/pmc_sq_b.log 2>&1
+# BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 60 and 300 frames)
+python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
+python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_huber.json 2>> $OUT/bench.err
+python $R/bench.py --dense --frames 60 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_60.json 2>> $OUT/bench.err
+python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_dense_300.json 2>> $OUT/bench.err
 python $R/tools/lm_trace.py 300 > $OUT/pipeline.log 2>&1
 CVD_PAIRS_LEVEL=6 python $R/tools/lm_trace.py 300 > $OUT/pipeline_4140.log 2>&1
 # summaries (small, committed under profiles/)
@@ -32,4 +37,4 @@ python $R/tools/pmc_to_json.py $OUT $TAG > $OUT/pmc_matvec_pairs.json 2> $OUT/pm
 cp $OUT/trace/*/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 cp $OUT/trace1766/*/*kernel_stats.csv $OUT/bench_1766_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace $OUT/trace1766 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq_a $OUT/pmc_sq_b
-tail -c 400 $OUT/bench.json; echo; grep TOTAL $OUT/pipeline.log $OUT/pipeline_4140.log | cut -c1-220; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv
+tail -c 400 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_60 dense_300; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; grep TOTAL $OUT/pipeline.log $OUT/pipeline_4140.log | cut -c1-220; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv
