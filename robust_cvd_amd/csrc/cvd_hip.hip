@@ -41,6 +41,7 @@
 #include "../../include/cvd_hip.h"
 #include "cvd_kernels.h"
 #include "cvd_coarse.h"
+#include "cvd_cross.h"
 #include "cvd_triplets.h"
 #include "cvd_dense.h"
 #include "cvd_sampling.h"
@@ -383,6 +384,11 @@ struct cvd_handle_t {
   hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr, evCoarseRead = nullptr;  // (evCoarseRead: the rebuild has consumed H, lam, x)
   DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
+  // explicit cross blocks of the dense mode (cvd_cross.h): undirected pairs, their rows, the blocks
+  std::vector<int> xFa, xFb;
+  DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff;
+  DevBuf<long long> dXRange;
+  DevBuf<double> dXBlocks;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
   bool tableValid = false;
@@ -1257,6 +1263,38 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
       frameItems[fb].push_back(item * 2 + 1);
     }
   }
+  // ---- explicit-block mode of the dense mode (cvd_cross.h): one entry per undirected pair with both directions' whole
+  // pixel ranges, two partial rows each, rows grouped by frame
+  h->xFa.clear();
+  h->xFb.clear();
+  if (h->dense) {
+    std::vector<long long> xRange;
+    std::vector<std::vector<int>> frameRows(h->F);
+    for (const auto& e : edges) {
+      const int fa = e.first.first, fb = e.first.second;
+      long long b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+      if (e.second[0] >= 0) { b0 = h->pairOff[e.second[0]]; e0 = h->pairOff[e.second[0] + 1]; }
+      if (e.second[1] >= 0) { b1 = h->pairOff[e.second[1]]; e1 = h->pairOff[e.second[1] + 1]; }
+      if (b0 >= e0 && b1 >= e1) continue;
+      const int k = static_cast<int>(h->xFa.size());
+      h->xFa.push_back(fa);
+      h->xFb.push_back(fb);
+      xRange.insert(xRange.end(), {b0, e0, b1, e1});
+      frameRows[fa].push_back(k * 2 + 0);
+      frameRows[fb].push_back(k * 2 + 1);
+    }
+    std::vector<int> xFiOff(h->F + 1, 0), xSlot(std::max<size_t>(1, h->xFa.size() * 2), 0);
+    int row = 0;
+    for (int f = 0; f < h->F; ++f) {
+      for (int code : frameRows[f]) xSlot[code] = row++;
+      xFiOff[f + 1] = row;
+    }
+    h->dXFa.upload(h->xFa.data(), h->xFa.size(), s);
+    h->dXFb.upload(h->xFb.data(), h->xFb.size(), s);
+    h->dXRange.upload(xRange.data(), xRange.size(), s);
+    h->dXSlot.upload(xSlot.data(), xSlot.size(), s);
+    h->dXFiOff.upload(xFiOff.data(), xFiOff.size(), s);
+  }
   // ---- scene-flow smoothness triplets: table, active groups (all three frames in range; groups are sharded
   // over the ranks like the per-frame regularisers), per-frame (group, role) lists and their partial-product rows
   h->tripActive.clear();
@@ -1461,6 +1499,7 @@ struct Ctx {
   int boundDepth0 = 0;
   bool trip = false;  // scene-flow smoothness triplets are part of this problem
   TripletTable TT{};
+  bool cross = false;  // dense mode with explicit cross blocks (cvd_cross.h)
 };
 
 // Pinned staging buffer `which` with room for n doubles (pageable transfers of the F x B vectors cost ~1 ms each).
@@ -1647,6 +1686,38 @@ static void enqueueStats(Ctx& c) {
 }
 
 // cost + gradient + diagonal blocks at x
+// Dense mode with explicit cross blocks (cvd_cross.h) whenever the problem is in its scope.
+static bool crossScope(cvd_handle* h, const Ctx& c) {
+  const bool off = std::getenv("CVD_DENSE_MATRIX_FREE") != nullptr;  // comparison knob (read per solve: the tests toggle it)
+  return h->dense && !off && !h->dist() && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
+         c.L.N == 1 && c.L.nD > 0 && c.KD <= 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
+         c.L.B <= 256;
+}
+static CrossPairs crossPairs(cvd_handle* h) {
+  return CrossPairs{h->dXFa.p, h->dXFb.p, h->dXRange.p, h->dXSlot.p, static_cast<int>(h->xFa.size())};
+}
+// X_ab of every undirected pair at the linearisation point x (frame constants in dFc are those of x)
+static void launchCrossAssemble(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  const size_t B = c.L.B, G = c.L.nD;
+  h->dXBlocks.ensure(h->xFa.size() * B * B);
+  // panel width: the largest that fits the LDS next to x (2 B), the frame constants, PP (56) and GP (7 G)
+  const size_t fixedDoubles = 2 * B + 2 * sizeof(FrameConst) / 8 + 56 + 7 * G;
+  int panelW = static_cast<int>(((kMaxLds - 8192) / 8 - fixedDoubles) / (G + 7));
+  panelW = std::max(1, std::min<int>(panelW, static_cast<int>(G)));
+  const int nPanels = static_cast<int>((G + panelW - 1) / panelW);
+  panelW = static_cast<int>((G + nPanels - 1) / nPanels);  // (even panels)
+  const size_t lds = (fixedDoubles + static_cast<size_t>(panelW) * (G + 7)) * 8;
+  CVD_DISPATCH_KD(c.KD, {
+    if constexpr (KD <= 4) {
+      allowLds((k_cross_assemble<KD>), lds);
+      hipLaunchKernelGGL((k_cross_assemble<KD>), dim3(static_cast<unsigned>(h->xFa.size()), nPanels), dim3(kCrossThreads), lds,
+                         h->stream, c.L, c.T, crossPairs(h), x, h->dFc.p, panelW, h->dXBlocks.p);
+    }
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
 static double evalFull(Ctx& c, const double* x, bool withStats = false) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
@@ -1706,6 +1777,7 @@ static double evalFull(Ctx& c, const double* x, bool withStats = false) {
                        h->dG.p, h->dH.p);
     HIP_CHECK(hipGetLastError());
   }
+  if (c.cross) launchCrossAssemble(c, x);  // (same timing class: it is part of the Jacobian evaluation)
   h->tEnd(slot);
   if (h->dist()) {
     // The exchange step of the pair-sharded mode, once per Jacobian evaluation: the gradient and the per-frame costs
@@ -1788,7 +1860,20 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
   hipStream_t s = h->stream;
   const CoarseView cF = coarseView(h, withCoarse, coarseFusedConsumers());  // z + Z c: the coarse part of the preconditioned residual
   const size_t B = c.L.B;
-  if (c.L.includeStatic && c.nItems > 0) {
+  if (c.cross) {
+    // explicit cross blocks (dense mode): one workgroup per undirected pair streams its B x B block
+    hipEvent_t evStart, evStop;
+    (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
+    const size_t ldsX = (3 * B + (kCrossThreads / 64) * B + 2 * kCB) * 8;
+    const unsigned nP = static_cast<unsigned>(h->xFa.size());
+    if (evStart)
+      hipExtLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, evStart, evStop, 0, c.L, crossPairs(h),
+                            h->dXBlocks.p, h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    else
+      hipLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, c.L, crossPairs(h), h->dXBlocks.p, h->dMask.p, z,
+                         pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    HIP_CHECK(hipGetLastError());
+  } else if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
     const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
     hipEvent_t evStart, evStop;
@@ -1867,10 +1952,11 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     const int slot = h->tBegin(KC_MATVEC_FINISH);
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
-                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFiOff.p, h->dFiList.p, h->dQPart.p, z, pOld, pNew,
-                         h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
-                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, h->qRows, h->regCache, cF,
-                         ((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr, cc);
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, c.cross ? h->dXFiOff.p : h->dFiOff.p, h->dFiList.p,
+                         h->dQPart.p, z, pOld, pNew, h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
+                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.cross ? static_cast<int>(h->xFa.size()) * 2 : h->qRows,
+                         h->regCache, cF, ((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr, cc,
+                         c.cross ? h->dH.p : nullptr);
     });
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
@@ -2345,6 +2431,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
   bindTriplets(c, p, kind);
   if (c.L.includeStatic) checkDenseScope(h, c.L, c.KS, c.trip);
+  c.cross = crossScope(h, c);
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
@@ -2768,6 +2855,7 @@ static void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformR
   c.n = static_cast<size_t>(c.L.F) * c.L.B;
   bindTriplets(c, p, PK_POSE_STEP);
   checkDenseScope(h, c.L, c.KS, c.trip);
+  c.cross = crossScope(h, c);
   h->coarseOn = false;
   ensureBuffers(c);
   buildMask(h, c.L, p, PK_POSE_STEP, range);

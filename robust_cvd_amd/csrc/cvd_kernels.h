@@ -1318,7 +1318,10 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
                                                        double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nRows, RegCache rc, CoarseView V,
-                                                       double* __restrict__ qc, CoarseColumns cc) {
+                                                       double* __restrict__ qc, CoarseColumns cc,
+                                                       const double* __restrict__ Hdiag) {
+  // Hdiag != nullptr (explicit cross blocks, cvd_cross.h): the partial rows hold the OFF-diagonal blocks' products only;
+  // the frame-diagonal part, regularisers included, is H_ff p_f with the assembled H_ff.
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -1383,7 +1386,23 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
     if ((tid & 63) == 0) atomicAdd(&qf[6], a);
     __syncthreads();
   }
-  if (inRange[f]) {
+  if (Hdiag != nullptr) {
+    // symmetric block: column access, coalesced over the row index; four independent loads in flight
+    const double* Hf = Hdiag + static_cast<size_t>(f) * B * B;
+    for (int i = tid; i < B; i += 256) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int j = 0;
+      for (; j + 3 < B; j += 4) {
+        a0 += Hf[static_cast<size_t>(j) * B + i] * pf[j];
+        a1 += Hf[static_cast<size_t>(j + 1) * B + i] * pf[j + 1];
+        a2 += Hf[static_cast<size_t>(j + 2) * B + i] * pf[j + 2];
+        a3 += Hf[static_cast<size_t>(j + 3) * B + i] * pf[j + 3];
+      }
+      for (; j < B; ++j) a0 += Hf[static_cast<size_t>(j) * B + i] * pf[j];
+      qf[i] += (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+  } else if (inRange[f]) {
     // J_reg^T (J_reg p) from the cached rows (k_reg_cache)
     for (int i = tid; i < rc.nr; i += 256) {
       const int n = rc.cnt[static_cast<size_t>(f) * rc.nr + i];

@@ -34,8 +34,13 @@ def _setup(Solver, frames=6, w=96, h=56, seed=61):
     return v, hip, orc, int(off[-1])
 
 
+@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
 @pytest.mark.parametrize("variant", ["global", "grid6x4", "grid17x10", "global_fixed_intrinsics"])
-def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant):
+def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant, product, monkeypatch):
+    """`product`: the two device paths of J^T J p in dense mode -- explicit cross blocks X_ab assembled once per evaluation
+    (cvd_cross.h, the default; grid17x10 needs two column panels) and the matrix-free kernel (CVD_DENSE_MATRIX_FREE)."""
+    if product == "matrix_free":
+        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
     v, hip, orc, n = _setup(Solver)
     F = v.num_frames
     rng = np.random.default_rng(3)
@@ -53,7 +58,7 @@ def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, varian
         s.reset_spatial_xforms(XformDesc.spatial())
         th = s.get_xform_params()
         s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)))
-        small = F * s.block_size() <= 300
+        small = F * s.block_size() <= 1100
         res[k] = s.evaluate(p, 0.1, pose, want_gradient=True, want_hdiag=True, want_hfull=small)
     a, b = res["hip"], res["oracle"]
     assert hip.num_active_constraints() == n
@@ -65,7 +70,10 @@ def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, varian
         assert rel(a["hfull"], b["hfull"]) < TOL   # the matrix-free product, column by column
 
 
-def test_dense_solve_reaches_the_oracle_minimum(Solver):
+@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
+def test_dense_solve_reaches_the_oracle_minimum(Solver, product, monkeypatch):
+    if product == "matrix_free":
+        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
     v, hip, orc, _ = _setup(Solver, frames=8, seed=62)
     out = {}
     for k, s in (("hip", hip), ("oracle", orc)):
