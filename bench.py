@@ -331,17 +331,24 @@ def main():
     if rank == 0:
         video, B, n_active = m["video"], m["B"], m["n_active"]
         mv = m["ktimes"]["matvec_pairs"]
+        dense_explicit = args.dense and not os.environ.get("CVD_DENSE_MATRIX_FREE")
         if args.dense:
-            # flow 8 B + mask 1 B + d_src0 4 B + gathered d_src1 4 B = 17 B per pixel pair (every pixel slot of
-            # every pair is read) + per work item (8192 slots per direction) the frame blocks as in the list mode
             npx = width * height
             slots = len(video.pairs) * npx
             und = {(min(a, b), max(a, b)) for a, b in video.pairs.tolist()}
-            bytes_launch = 17.0 * slots + len(und) * (-(-npx // 8192)) * (2 * 4 + 2) * B * 8.0
+            if dense_explicit:
+                # explicit cross blocks (cvd_cross.h, the default at the bilinear levels): a product streams one B x B f64 block
+                # per undirected pair + per pair the two frames' z, p_old, mask blocks in and two partial rows out
+                bytes_launch = len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0)
+            else:
+                # flow 8 B + mask 1 B + d_src0 4 B + gathered d_src1 4 B = 17 B per pixel pair (every pixel slot
+                # of every pair is read) + per work item (8192 slots per direction) the frame blocks as in the list mode
+                bytes_launch = 17.0 * slots + len(und) * (-(-npx // 8192)) * (2 * 4 + 2) * B * 8.0
         else:
             bytes_launch = matvec_bytes_per_launch(m["local_video"], n_active, B)
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
-        flops_launch = FLOPS_PER_CONSTRAINT * n_active
+        # (explicit blocks: y_a = X p_b and y_b = X^T p_a, 4 B^2 flop per pair)
+        flops_launch = (len(und) * 4.0 * B * B) if (args.dense and dense_explicit) else FLOPS_PER_CONSTRAINT * n_active
         tflops = (flops_launch / (mv["avg_ms"] * 1e-3)) / 1e12 if mv["avg_ms"] > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot happen inside this
         # process): only when profiles/pmc_matvec_pairs.json was produced from the kernel sources benchmarked here and
@@ -386,18 +393,22 @@ def main():
                 "solves_in_timed_region": m["n_solves"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_cross_matvec" if (args.dense and dense_explicit) else "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "bytes_per_launch": bytes_launch, "avg_launch_ms": mv["avg_ms"], "launches": mv["launches"],
                 "timed": f"HIP start/stop events on every {m['sample_every']}. launch of the timed region ({mv['launches']} launches timed)",
                 "valu": {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
                          "flops_per_launch": flops_launch,
-                         "note": f"{FLOPS_PER_CONSTRAINT:.0f} f64 flop per constraint counted from the kernel source (DESIGN.md 3)"},
-                "note": "f64 VALU/latency-bound, not HBM-bound (DESIGN.md 3): both fractions are reported",
+                         "note": ("4 B^2 flop per undirected pair (y_a = X p_b, y_b = X^T p_a)" if (args.dense and dense_explicit) else
+                                  f"{FLOPS_PER_CONSTRAINT:.0f} f64 flop per constraint counted from the kernel source (DESIGN.md 3)")},
+                "note": ("dense mode, explicit cross blocks: the product streams the assembled blocks (HBM-bound); the step is "
+                         "dominated by the block ASSEMBLY, see dense_kernels (f64 VALU / LDS-atomic bound)" if (args.dense and dense_explicit)
+                         else "f64 VALU/latency-bound, not HBM-bound (DESIGN.md 3): both fractions are reported"),
             },
             **({"dense_kernels": {
-                # the other two image-reading kernels, same 17 B per pixel slot (the cost class also holds the small
-                # per-frame regulariser kernels; the assemble class reads every slot twice: once per side)
+                # the image-reading kernels, 17 B per pixel slot and pass (the cost class also holds the small per-frame
+                # regulariser kernels; the assemble class reads every slot twice for the frame-diagonal blocks -- once per side --
+                # and, with explicit cross blocks, 1 + panels more times for X_ab: reported against the two diagonal passes)
                 "cost": {"avg_ms": m["ktimes"]["cost"]["avg_ms"], "GB/s": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6,
                          "frac_hbm": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
                 "assemble": {"avg_ms": m["ktimes"]["evaluate_assemble"]["avg_ms"],

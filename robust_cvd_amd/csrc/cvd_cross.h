@@ -9,8 +9,8 @@
 //     X_ab = sum over the constraints of {a -> b, b -> a} of rho' J_a^T J_b          (B x B doubles, a < b)
 // are assembled ONCE per Jacobian evaluation (k_cross_assemble) and a product streams them (k_cross_matvec: 2 B^2 flop
 // per 8 B^2 bytes -- HBM-bound); the frame-diagonal part of J^T J p comes from H_ff, which the assembly kernels form anyway
-// (k_matvec_finish, explicit = 1).  Scope: the fast kernels' (identity spatial transform, reprojection losses, one value
-// parameter per vertex, Global / bilinear grids, Fixed / PerFrame intrinsics), single GPU, no triplets.
+// (k_matvec_finish, Hdiag).  Scope: the fast kernels' (identity spatial transform, reprojection losses, one value
+// parameter per vertex, bilinear grids, Fixed / PerFrame intrinsics), single GPU, no triplets.
 //
 // A constraint's Jacobian row on either side is [ pose part Jp (3 x 7) | JD (3) x tap factors ]: the grid columns are
 // rank one in (residual, tap).  Per constraint the block receives
@@ -18,8 +18,8 @@
 //     pose x grid   7 x 4   (w Jp_a^T JD_b) fac_b[k]           -> LDS f64 atomics
 //     grid x pose   4 x 7   fac_a[k] (w JD_a^T Jp_b)           -> LDS f64 atomics
 //     grid x grid   4 x 4   (w JD_a . JD_b) fac_a[k] fac_b[l]  -> LDS f64 atomics
-// The grid x grid part (G^2 doubles: 231 KB at the 17x10 grid) exceeds the LDS, so a workgroup owns a PANEL of the block's
-// grid columns and the pair's pixels are walked once per panel (two panels at G = 170).
+// The grid x grid part (G^2 doubles: 231 KB at the 17x10 grid) exceeds the LDS, so it is accumulated in column PANELS by a
+// kernel of its own (two panels at G = 170; see k_cross_assemble).
 #pragma once
 
 #include "cvd_kernels.h"
@@ -155,25 +155,31 @@ __device__ __forceinline__ void crossRows(const Layout& L, const FrameConst& Fs,
   o.JDT2 = dr2dDb;
 }
 
-// One workgroup per (undirected pair, panel of the block's grid columns).  LDS: x of both frames, 2 frame constants,
-// PP (49, folded with atomics at the end), GP (G x 7, panel 0 only), PG (7 x pw), GG (G x pw).
-template <int KD>
+// Two kernels share the walk over a pair's pixels (GRID template flag):
+//   GRID = 0, one workgroup per pair: the pose rows / columns -- PP (49 per-lane accumulators, folded at the end), GP
+//            (G x 7) and PG (7 x G) in LDS.  This is the register-heavy half (both sides' 3 x 7 pose Jacobians).
+//   GRID = 1, one workgroup per (pair, panel of the block's grid COLUMNS): the G x panel part of the grid x grid block.
+//            Needs only the two depth rows and the taps of a constraint -- the pose Jacobians are dead code here -- so it
+//            runs at twice the occupancy, which is what the second walk over the pixels costs.
+// LDS: x of both frames, 2 frame constants, then PPs (56) + GP + PG, or GG (G x panelW).
+template <int KD, bool GRID>
 __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Table T, CrossPairs cp, const double* __restrict__ x,
                                                                   const FrameConst* __restrict__ fc, int panelW,
                                                                   double* __restrict__ X) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B, G = L.nD;  // (one value parameter per vertex: nD = vertices)
-  const int pair = blockIdx.x, panel = blockIdx.y;
-  const int v0 = panel * panelW, v1 = (v0 + panelW < G) ? v0 + panelW : G, pw = v1 - v0;
+  const int pair = blockIdx.x, panel = GRID ? blockIdx.y : 0;
+  const int v0 = GRID ? panel * panelW : 0, v1 = GRID ? ((v0 + panelW < G) ? v0 + panelW : G) : G, pw = v1 - v0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kCrossThreads / 64;
   double* xa = sm;
   double* xb = xa + B;
   FrameConst* fcs = reinterpret_cast<FrameConst*>(xb + B);
-  double* PPs = reinterpret_cast<double*>(fcs + 2);  // 49 (+ pad)
-  double* GP = PPs + 56;                             // G x 7
-  double* PG = GP + static_cast<size_t>(G) * 7;      // 7 x pw
-  double* GG = PG + 7 * static_cast<size_t>(panelW); // G x pw
+  double* acc0 = reinterpret_cast<double*>(fcs + 2);
+  double* PPs = acc0;                                  // GRID = 0: 49 (+ pad)
+  double* GP = PPs + 56;                               //           G x 7
+  double* PG = GP + static_cast<size_t>(G) * 7;        //           7 x G
+  double* GG = acc0;                                   // GRID = 1: G x panelW
   const int fa = cp.fa[pair], fb = cp.fb[pair];
   for (int i = tid; i < B; i += kCrossThreads) {
     xa[i] = x[static_cast<size_t>(fa) * B + i];
@@ -182,13 +188,13 @@ __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Tabl
   constexpr int FCW = sizeof(FrameConst) / 8;
   for (int i = tid; i < 2 * FCW; i += kCrossThreads)
     reinterpret_cast<double*>(fcs)[i] = reinterpret_cast<const double*>(fc + (i < FCW ? fa : fb))[i % FCW];
-  const int nLds = 56 + G * 7 + 7 * panelW + G * panelW;
-  for (int i = tid; i < nLds; i += kCrossThreads) PPs[i] = 0.0;
+  const int nLds = GRID ? G * panelW : 56 + G * 14;
+  for (int i = tid; i < nLds; i += kCrossThreads) acc0[i] = 0.0;
   __syncthreads();
 
-  double PP[49];
+  double PP[GRID ? 1 : 49];
 #pragma unroll
-  for (int i = 0; i < 49; ++i) PP[i] = 0.0;
+  for (int i = 0; i < (GRID ? 1 : 49); ++i) PP[i] = 0.0;
   for (int dir = 0; dir < 2; ++dir) {
     const long long cb = cp.range[pair * 4 + dir * 2], ce = cp.range[pair * 4 + dir * 2 + 1];
     if (cb >= ce) continue;
@@ -209,46 +215,50 @@ __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Tabl
         CrossRows<KD> R;
         crossRows<KD>(L, Fs, Ft, xs, xt, nd, d, R);
         // row side = frame fa, column side = frame fb
-        const double(*Jr)[7] = dir ? R.JpT : R.JpS;  // pose rows of fa
-        const double(*Jc)[7] = dir ? R.JpS : R.JpT;  // pose rows of fb
         const double JDr[3] = {dir ? 0.0 : R.JDS[0], dir ? 0.0 : R.JDS[1], dir ? R.JDT2 : R.JDS[2]};
         const double JDc[3] = {dir ? R.JDS[0] : 0.0, dir ? R.JDS[1] : 0.0, dir ? R.JDS[2] : R.JDT2};
         const FastTaps<KD>& tr = dir ? R.tt : R.ts;
         const FastTaps<KD>& tc = dir ? R.ts : R.tt;
         const double dr = dir ? R.dt : R.ds, dc = dir ? R.ds : R.dt;
         const double w = R.w;
-        double vA[7], vB[7];
+        if constexpr (GRID) {
+          const double sDD = w * (JDr[0] * JDc[0] + JDr[1] * JDc[1] + JDr[2] * JDc[2]);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const double a0 = w * Jr[0][i], a1 = w * Jr[1][i], a2 = w * Jr[2][i];
+          for (int k = 0; k < KD; ++k) {
+            const int ir = tr.I(k);
+            const double fr = sDD * tr.Wt(k) * dr;
 #pragma unroll
-          for (int j = 0; j < 7; ++j) PP[i * 7 + j] += a0 * Jc[0][j] + a1 * Jc[1][j] + a2 * Jc[2][j];
-          vA[i] = a0 * JDc[0] + a1 * JDc[1] + a2 * JDc[2];                        // pose_a x (depth of b)
-          vB[i] = w * (JDr[0] * Jc[0][i] + JDr[1] * Jc[1][i] + JDr[2] * Jc[2][i]);  // (depth of a) x pose_b
-        }
-        const double sDD = w * (JDr[0] * JDc[0] + JDr[1] * JDc[1] + JDr[2] * JDc[2]);
+            for (int l = 0; l < KD; ++l) {
+              const int jc = tc.I(l) - v0;
+              if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], fr * (tc.Wt(l) * dc));
+            }
+          }
+        } else {
+          const double(*Jr)[7] = dir ? R.JpT : R.JpS;  // pose rows of fa
+          const double(*Jc)[7] = dir ? R.JpS : R.JpT;  // pose rows of fb
+          double vA[7], vB[7];
 #pragma unroll
-        for (int k = 0; k < KD; ++k) {
-          const int ir = tr.I(k), ic = tc.I(k) - v0;
-          const double fr = tr.Wt(k) * dr, fcl = tc.Wt(k) * dc;
-          if (panel == 0) {
+          for (int i = 0; i < 7; ++i) {
+            const double a0 = w * Jr[0][i], a1 = w * Jr[1][i], a2 = w * Jr[2][i];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) PP[i * 7 + j] += a0 * Jc[0][j] + a1 * Jc[1][j] + a2 * Jc[2][j];
+            vA[i] = a0 * JDc[0] + a1 * JDc[1] + a2 * JDc[2];                        // pose_a x (depth of b)
+            vB[i] = w * (JDr[0] * Jc[0][i] + JDr[1] * Jc[1][i] + JDr[2] * Jc[2][i]);  // (depth of a) x pose_b
+          }
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const int ir = tr.I(k), ic = tc.I(k);
+            const double fr = tr.Wt(k) * dr, fcl = tc.Wt(k) * dc;
 #pragma unroll
             for (int j = 0; j < 7; ++j) atomicAdd(&GP[ir * 7 + j], fr * vB[j]);
-          }
-          if (ic >= 0 && ic < pw) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) atomicAdd(&PG[i * panelW + ic], vA[i] * fcl);
-          }
-#pragma unroll
-          for (int l = 0; l < KD; ++l) {
-            const int jc = tc.I(l) - v0;
-            if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], sDD * fr * (tc.Wt(l) * dc));
+            for (int i = 0; i < 7; ++i) atomicAdd(&PG[i * G + ic], vA[i] * fcl);
           }
         }
       }
     }
   }
-  if (panel == 0) {
+  if constexpr (!GRID) {
 #pragma unroll
     for (int i = 0; i < 49; ++i) {
       const double s = waveSum(PP[i]);
@@ -256,19 +266,17 @@ __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Tabl
     }
   }
   __syncthreads();
-  // ---- flush this panel into the pair's B x B block (row-major, rows = fa's unknowns)
+  // ---- flush into the pair's B x B block (row-major, rows = fa's unknowns)
   double* Xp = X + static_cast<size_t>(pair) * B * B;
-  if (panel == 0) {
+  if constexpr (GRID) {
+    for (int i = tid; i < G * pw; i += kCrossThreads) {
+      const int r = i / pw, cidx = i - r * pw;
+      Xp[static_cast<size_t>(7 + r) * B + 7 + v0 + cidx] = GG[r * panelW + cidx];
+    }
+  } else {
     for (int i = tid; i < 49; i += kCrossThreads) Xp[static_cast<size_t>(i / 7) * B + (i % 7)] = PPs[i];
     for (int i = tid; i < G * 7; i += kCrossThreads) Xp[static_cast<size_t>(7 + i / 7) * B + (i % 7)] = GP[i];
-  }
-  for (int i = tid; i < 7 * pw; i += kCrossThreads) {
-    const int r = i / pw, cidx = i - r * pw;
-    Xp[static_cast<size_t>(r) * B + 7 + v0 + cidx] = PG[r * panelW + cidx];
-  }
-  for (int i = tid; i < G * pw; i += kCrossThreads) {
-    const int r = i / pw, cidx = i - r * pw;
-    Xp[static_cast<size_t>(7 + r) * B + 7 + v0 + cidx] = GG[r * panelW + cidx];
+    for (int i = tid; i < 7 * G; i += kCrossThreads) Xp[static_cast<size_t>(i / G) * B + 7 + (i % G)] = PG[i];
   }
 }
 

@@ -1686,11 +1686,13 @@ static void enqueueStats(Ctx& c) {
 }
 
 // cost + gradient + diagonal blocks at x
-// Dense mode with explicit cross blocks (cvd_cross.h) whenever the problem is in its scope.
+// Dense mode with explicit cross blocks (cvd_cross.h) whenever the problem is in its scope.  (Bilinear grids only: at the
+// Global level every pixel hits the one vertex -- same-address LDS atomics, 52 ms per assembly measured -- and the 8 x 8
+// problem is cheap to solve matrix-free.)
 static bool crossScope(cvd_handle* h, const Ctx& c) {
   const bool off = std::getenv("CVD_DENSE_MATRIX_FREE") != nullptr;  // comparison knob (read per solve: the tests toggle it)
   return h->dense && !off && !h->dist() && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
-         c.L.N == 1 && c.L.nD > 0 && c.KD <= 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
+         c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
          c.L.B <= 256;
 }
 static CrossPairs crossPairs(cvd_handle* h) {
@@ -1701,18 +1703,23 @@ static void launchCrossAssemble(Ctx& c, const double* x) {
   cvd_handle* h = c.h;
   const size_t B = c.L.B, G = c.L.nD;
   h->dXBlocks.ensure(h->xFa.size() * B * B);
-  // panel width: the largest that fits the LDS next to x (2 B), the frame constants, PP (56) and GP (7 G)
-  const size_t fixedDoubles = 2 * B + 2 * sizeof(FrameConst) / 8 + 56 + 7 * G;
-  int panelW = static_cast<int>(((kMaxLds - 8192) / 8 - fixedDoubles) / (G + 7));
+  // pose rows / columns: one workgroup per pair; grid x grid: column panels of the largest width that fits the LDS
+  const size_t fixedDoubles = 2 * B + 2 * sizeof(FrameConst) / 8;
+  int panelW = static_cast<int>(((kMaxLds - 8192) / 8 - fixedDoubles) / G);
   panelW = std::max(1, std::min<int>(panelW, static_cast<int>(G)));
   const int nPanels = static_cast<int>((G + panelW - 1) / panelW);
   panelW = static_cast<int>((G + nPanels - 1) / nPanels);  // (even panels)
-  const size_t lds = (fixedDoubles + static_cast<size_t>(panelW) * (G + 7)) * 8;
+  const size_t ldsPose = (fixedDoubles + 56 + 14 * G) * 8;
+  const size_t ldsGrid = (fixedDoubles + static_cast<size_t>(panelW) * G) * 8;
+  const unsigned nP = static_cast<unsigned>(h->xFa.size());
   CVD_DISPATCH_KD(c.KD, {
-    if constexpr (KD <= 4) {
-      allowLds((k_cross_assemble<KD>), lds);
-      hipLaunchKernelGGL((k_cross_assemble<KD>), dim3(static_cast<unsigned>(h->xFa.size()), nPanels), dim3(kCrossThreads), lds,
-                         h->stream, c.L, c.T, crossPairs(h), x, h->dFc.p, panelW, h->dXBlocks.p);
+    if constexpr (KD == 4) {
+      allowLds((k_cross_assemble<KD, false>), ldsPose);
+      hipLaunchKernelGGL((k_cross_assemble<KD, false>), dim3(nP), dim3(kCrossThreads), ldsPose, h->stream, c.L, c.T, crossPairs(h),
+                         x, h->dFc.p, static_cast<int>(G), h->dXBlocks.p);
+      allowLds((k_cross_assemble<KD, true>), ldsGrid);
+      hipLaunchKernelGGL((k_cross_assemble<KD, true>), dim3(nP, nPanels), dim3(kCrossThreads), ldsGrid, h->stream, c.L, c.T,
+                         crossPairs(h), x, h->dFc.p, panelW, h->dXBlocks.p);
     }
   });
   HIP_CHECK(hipGetLastError());
