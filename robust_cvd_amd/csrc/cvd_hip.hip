@@ -386,7 +386,7 @@ struct cvd_handle_t {
   DevBuf<long long> dItemRange;
   // explicit cross blocks of the dense mode (cvd_cross.h): undirected pairs, their rows, the blocks
   std::vector<int> xFa, xFb;
-  DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff;
+  DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff, dXPairEdge;
   DevBuf<long long> dXRange;
   DevBuf<double> dXBlocks;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
@@ -1390,6 +1390,16 @@ static void compileTable(cvd_handle* h, const std::vector<int>& range, bool with
       edgeList.swap(kept);
     }
     buildCoarsePlan(h, edgeList, itemEdge);
+    if (h->dense) {  // edge block of every cross pair (cvd_cross.h: k_coarse_edges_cross)
+      std::map<std::pair<int, int>, int> edgeOfPair;
+      for (size_t i = 0; i < h->itemFa.size(); ++i) edgeOfPair[{h->itemFa[i], h->itemFb[i]}] = itemEdge[i];
+      std::vector<int> pairEdge(std::max<size_t>(1, h->xFa.size()), -1);
+      for (size_t k = 0; k < h->xFa.size(); ++k) {
+        auto it = edgeOfPair.find({h->xFa[k], h->xFb[k]});
+        if (it != edgeOfPair.end()) pairEdge[k] = it->second;
+      }
+      h->dXPairEdge.upload(pairEdge.data(), pairEdge.size(), s);
+    }
   }
   std::vector<int> fiOff(h->F + 1, 0), fiList, fpOff(h->F + 1, 0), fpList;
   for (int f = 0; f < h->F; ++f) {
@@ -2079,7 +2089,12 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     if (C.sparsified) HIP_CHECK(hipMemsetAsync(C.dropDiag.p, 0, static_cast<size_t>(c.L.F) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
-    if (c.nItems > 0) {
+    static const bool crossEdgesOff = std::getenv("CVD_COARSE_EDGES_MATRIX_FREE") != nullptr;  // comparison knob
+    if (c.cross && !C.sparsified && !crossEdgesOff) {
+      // explicit cross blocks exist for this linearisation point: the edge blocks are reductions of them
+      hipLaunchKernelGGL(k_coarse_edges_cross, dim3(static_cast<unsigned>(h->xFa.size())), dim3(256), 0, s, c.L, crossPairs(h),
+                         h->dXBlocks.p, h->dXPairEdge.p, C.edges.p);
+    } else if (c.nItems > 0) {
       static const bool genericEdges = std::getenv("CVD_COARSE_EDGES_GENERIC") != nullptr;  // comparison knob
       const bool fast = !h->forceGeneric && !genericEdges && c.KS == 0 && fastLoss(c.L) &&
                         c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
