@@ -24,6 +24,11 @@ python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secon
 python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_huber.json 2>> $OUT/bench.err
 python $R/bench.py --dense --frames 60 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_60.json 2>> $OUT/bench.err
 python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_dense_300.json 2>> $OUT/bench.err
+python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300_allkernels.json 2>> $OUT/bench.err
+CVD_DENSE_MATRIX_FREE=1 python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300_matrix_free.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense -- python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/trace_dense.log 2>&1
+python $R/tools/kernel_durations.py $OUT/trace_dense $TAG > $OUT/kernel_durations_dense.txt 2>&1
+rm -rf $OUT/trace_dense
 python $R/tools/lm_trace.py 300 > $OUT/pipeline.log 2>&1
 CVD_PAIRS_LEVEL=6 python $R/tools/lm_trace.py 300 > $OUT/pipeline_4140.log 2>&1
 # summaries (small, committed under profiles/)
@@ -37,4 +42,4 @@ python $R/tools/pmc_to_json.py $OUT $TAG > $OUT/pmc_matvec_pairs.json 2> $OUT/pm
 cp $OUT/trace/*/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 cp $OUT/trace1766/*/*kernel_stats.csv $OUT/bench_1766_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace $OUT/trace1766 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq_a $OUT/pmc_sq_b
-tail -c 400 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_60 dense_300; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; grep TOTAL $OUT/pipeline.log $OUT/pipeline_4140.log | cut -c1-220; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv
+tail -c 400 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_60 dense_300 dense_300_matrix_free; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; grep TOTAL $OUT/pipeline.log $OUT/pipeline_4140.log | cut -c1-220; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv
