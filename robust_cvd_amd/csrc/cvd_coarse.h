@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __r
                                                      const double* __restrict__ lam, const double* __restrict__ mask,
                                                      double* __restrict__ diagOut, unsigned char* __restrict__ modeActive,
                                                      double lamScale, const double* __restrict__ dropDiag) {
-  __shared__ double u[264];  // u[r] = sum over scale vertices v of H[r][v] (+ lam on the diagonal)
+  __shared__ double u[520];  // u[r] = sum over scale vertices v of H[r][v] (+ lam on the diagonal); B <= 512
   __shared__ double red[4];
   __shared__ int anyScale;
   const int B = L.B, f = blockIdx.x, tid = threadIdx.x;
@@ -972,6 +972,41 @@ __global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* 
   }
   const size_t r = idx / n, c = idx - r * n;
   out[idx] = static_cast<float>(c >= r ? A[r * n + c] : A[c * n + r]);
+}
+
+// Frame blocks beyond the register-resident inverses (B > 256: ScaleShift value transforms on the 17x10 grid, B = 347): the
+// block-Jacobi inverses go through rocSOLVER's strided-batched potrf / potri.  k_blocks_add_diag forms H_ff + diag(lam) in
+// a scratch copy, k_blocks_pack mirrors the inverse (left in the row-major array's upper triangle, see k_coarse_dense_pack)
+// into the f32 blocks; a block whose factorisation failed becomes the inverse of its diagonal and is counted in `fail`.
+__global__ __launch_bounds__(256) void k_blocks_add_diag(int B, size_t total, const double* __restrict__ H,
+                                                         const double* __restrict__ lam, double* __restrict__ out) {
+  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t f = idx / (static_cast<size_t>(B) * B), rem = idx - f * B * B;
+  const int i = static_cast<int>(rem / B), j = static_cast<int>(rem - static_cast<size_t>(i) * B);
+  double v = H[idx];
+  if (i == j) {
+    v += lam[f * B + i];
+    if (!(v > 0.0)) v = 1.0;  // (masked unknown without damping: identity row, as the register-resident kernels treat it)
+  }
+  out[idx] = v;
+}
+__global__ __launch_bounds__(256) void k_blocks_pack(int B, size_t total, const double* __restrict__ A, const double* __restrict__ H,
+                                                     const double* __restrict__ lam, const int* __restrict__ info,
+                                                     float* __restrict__ out, int* __restrict__ fail) {
+  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t bb = static_cast<size_t>(B) * B;
+  const size_t f = idx / bb, rem = idx - f * bb;
+  const int i = static_cast<int>(rem / B), j = static_cast<int>(rem - static_cast<size_t>(i) * B);
+  const int nf = static_cast<int>(total / bb);
+  if (info[f] != 0 || info[nf + f] != 0) {
+    if (rem == 0) atomicAdd(fail, 1);
+    const double d = H[f * bb + static_cast<size_t>(i) * B + i] + lam[f * B + i];
+    out[idx] = (i == j) ? static_cast<float>(d > 0.0 ? 1.0 / d : 1.0) : 0.f;
+    return;
+  }
+  out[idx] = static_cast<float>(j >= i ? A[f * bb + static_cast<size_t>(i) * B + j] : A[f * bb + static_cast<size_t>(j) * B + i]);
 }
 
 // c_f = (A_c^-1 Z^T r)_f for the 8 modes of frame f (one workgroup per frame: 8 rows x n, 32 threads per row) and this

@@ -381,6 +381,9 @@ struct cvd_handle_t {
   int numCU = 256;
   hipStream_t stream2 = nullptr;                       // side stream of the asynchronous coarse rebuild
   SideWorker sideWorker;                               // host thread that enqueues the dense rebuild there
+  rocblas_handle rbMain = nullptr;                     // main-stream handle (batched block inverses beyond B = 256)
+  DevBuf<double> dInvScratch;
+  DevBuf<int> dInvInfo;
   hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr, evCoarseRead = nullptr;  // (evCoarseRead: the rebuild has consumed H, lam, x)
   DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
@@ -493,6 +496,7 @@ struct cvd_handle_t {
     sideWorker.waitNoThrow();
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (coarse.denseGraph) (void)hipGraphExecDestroy(coarse.denseGraph);
+    if (rbMain) (void)rocblas_destroy_handle(rbMain);
     for (auto& rbh : coarse.rb) if (rbh) (void)rocblas_destroy_handle(rbh);
     if (comm) (void)ncclCommDestroy(comm);
     if (hScal) (void)hipHostFree(hScal);
@@ -796,7 +800,7 @@ static Layout makeLayout(cvd_handle* h, const cvd_opt_params& p, double depthDef
 // The per-frame kernels of the solve (k_matvec_finish, k_cg_update, the block inverse, the fast pairs product) hold one
 // frame block per workgroup with at most 256 unknowns.  Checked BEFORE any work or state mutation (a coarse-to-fine
 // schedule would otherwise fail at its last level with the transforms already refined).
-constexpr int kMaxFrameBlock = 256;
+constexpr int kMaxFrameBlock = 512;
 static void checkFrameBlock(size_t B, const char* what) {
   if (B > static_cast<size_t>(kMaxFrameBlock))
     throw std::runtime_error(fmt("%s: %zu unknowns per frame (7 + depth-transform + spatial-transform parameters) exceed the "
@@ -817,6 +821,7 @@ static void tapCounts(const Layout& L, int& KD, int& KS) {
 // Scope of the specialised fast kernels: identity spatial transform and the three reprojection losses.
 static bool fastLoss(const Layout& L) {
   if (L.gz > 1) return false;  // (the fast kernels gather 2-D grids only)
+  if (L.B > 256) return false;  // (and hold one element of a frame block per thread)
   return L.lossType == CVD_STATIC_REPRO_DISPARITY || L.lossType == CVD_STATIC_REPRO_DEPTH_RATIO || L.lossType == CVD_STATIC_REPRO_LOG_DEPTH;
 }
 
@@ -1959,7 +1964,7 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
     HIP_CHECK(hipGetLastError());
   }
   {
-    if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_matvec_finish");
+    if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_matvec_finish");
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
     const bool fusedCoarse = withCoarse && !h->coarse.denseMode;
@@ -1997,6 +2002,31 @@ static void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* 
                                   int* dFail, int variant) {
   hipStream_t s = h->stream;
   const int B = L.B;
+  if (B > 256) {
+    // beyond the register-resident kernels (their tile sets end at B = 256): rocSOLVER's strided-batched Cholesky
+    // factorisation + inverse of all frames' H_ff + diag(lam), mirrored into the f32 blocks (cvd_coarse.h: k_blocks_*).
+    // Reached by two-parameter value transforms on large grids (ScaleShift at 17x10: B = 347); off the tuned path.
+    if (!h->rbMain) {
+      if (rocblas_create_handle(&h->rbMain) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
+      if (rocblas_set_stream(h->rbMain, s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
+    }
+    const size_t bb = static_cast<size_t>(B) * B, total = bb * L.F;
+    h->dInvScratch.ensure(total);
+    h->dInvInfo.ensure(2 * static_cast<size_t>(L.F));
+    HIP_CHECK(hipMemsetAsync(h->dInvInfo.p, 0, 2 * static_cast<size_t>(L.F) * sizeof(int), s));
+    const unsigned grid = static_cast<unsigned>((total + 255) / 256);
+    hipLaunchKernelGGL(k_blocks_add_diag, dim3(grid), dim3(256), 0, s, B, total, dH, dLam, h->dInvScratch.p);
+    HIP_CHECK(hipGetLastError());
+    if (rocsolver_dpotrf_strided_batched(h->rbMain, rocblas_fill_lower, B, h->dInvScratch.p, B, static_cast<rocblas_stride>(bb),
+                                         h->dInvInfo.p, L.F) != rocblas_status_success)
+      throw std::runtime_error("rocsolver_dpotrf_strided_batched failed");
+    if (rocsolver_dpotri_strided_batched(h->rbMain, rocblas_fill_lower, B, h->dInvScratch.p, B, static_cast<rocblas_stride>(bb),
+                                         h->dInvInfo.p + L.F, L.F) != rocblas_status_success)
+      throw std::runtime_error("rocsolver_dpotri_strided_batched failed");
+    hipLaunchKernelGGL(k_blocks_pack, dim3(grid), dim3(256), 0, s, B, total, h->dInvScratch.p, dH, dLam, h->dInvInfo.p, dMinv, dFail);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (variant == 0) {
     const int nbm = (B + kInvTS - 1) / kInvTS, nTilesM = nbm * (nbm + 1) / 2;
     const size_t ldsM = static_cast<size_t>(std::max(2 * nbm + 1, 16)) * kInvTile * sizeof(double);  // (>= one tile per wave for the final transpose)
@@ -2249,10 +2279,10 @@ static int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = n
   hipStream_t s = h->stream;
   const int F = c.L.F;
   const size_t B = c.L.B;
-  if (B > 256) throw std::runtime_error("frame block larger than 256 unknowns is not supported by k_cg_update");
+  if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_cg_update");
   prepareMatvec(c, x);
   const int nChunks = static_cast<int>((B + 63) / 64);
-  const int nThreads = 256 * nChunks;
+  const int nThreads = (B > 256 ? 128 : 256) * nChunks;  // (k_cg_update: four segments per row up to B = 256, two beyond)
   double* fd = h->dFdot.p;
   size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;

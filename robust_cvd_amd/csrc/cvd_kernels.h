@@ -1169,23 +1169,32 @@ __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items i
     const int which = t / FCW, k = t % FCW;
     reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
   }
-  double vza = 0.0, vzb = 0.0, vpa = 0.0, vpb = 0.0, vma = 0.0, vmb = 0.0;
-  for (int i = tid; i < B; i += 256) {
-    const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
-    xa[i] = x[ia];
-    xb[i] = x[ib];
-    vza = z[ia];
-    vzb = z[ib];
-    if (useBeta) { vpa = pOld[ia]; vpb = pOld[ib]; }
-    vma = mask[ia];
-    vmb = mask[ib];
-    qa[i] = 0.0;
-    qb[i] = 0.0;
+  // (two elements per thread: B <= 512 -- the generic kernel serves the blocks beyond the fast kernels' 256)
+  double vza[2] = {0.0, 0.0}, vzb[2] = {0.0, 0.0}, vpa[2] = {0.0, 0.0}, vpb[2] = {0.0, 0.0}, vma[2] = {0.0, 0.0}, vmb[2] = {0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + e * 256;
+    if (i < B) {
+      const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
+      xa[i] = x[ia];
+      xb[i] = x[ib];
+      vza[e] = z[ia];
+      vzb[e] = z[ib];
+      if (useBeta) { vpa[e] = pOld[ia]; vpb[e] = pOld[ib]; }
+      vma[e] = mask[ia];
+      vmb[e] = mask[ib];
+      qa[i] = 0.0;
+      qb[i] = 0.0;
+    }
   }
   __syncthreads();
-  for (int i = tid; i < B; i += 256) {
-    pa[i] = (vza + coarseAtLds(cl, L, i) + (useBeta ? beta * vpa : 0.0)) * vma;
-    pb[i] = (vzb + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * vpb : 0.0)) * vmb;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + e * 256;
+    if (i < B) {
+      pa[i] = (vza[e] + coarseAtLds(cl, L, i) + (useBeta ? beta * vpa[e] : 0.0)) * vma[e];
+      pb[i] = (vzb[e] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * vpb[e] : 0.0)) * vmb[e];
+    }
   }
   if (L.intrOpt == kIntrShared) {
     // every constraint's focal column is frame 0's slot (reference lib/PoseOptimizer.cpp:1226)
@@ -1342,23 +1351,31 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   } else if (tid < kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[f * kCB + tid] : 0.0;
   }
-  double vz = 0.0, vm = 0.0, vp = 0.0, vlam = 0.0, pvReg = 0.0;
-  if (tid < B) {
-    vz = z[base + tid];
-    vm = mask[base + tid];
-    if (useBeta) vp = pOld[base + tid];
-    vlam = lam[base + tid];
-    xf[tid] = x[base + tid];
+  // (two elements per thread: B <= 512)
+  double vz[2] = {0.0, 0.0}, vm[2] = {0.0, 0.0}, vp[2] = {0.0, 0.0}, vlam[2] = {0.0, 0.0}, pvReg[2] = {0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + e * 256;
+    if (i < B) {
+      vz[e] = z[base + i];
+      vm[e] = mask[base + i];
+      if (useBeta) vp[e] = pOld[base + i];
+      vlam[e] = lam[base + i];
+      xf[i] = x[base + i];
+    }
   }
   const int e0 = fiOff[f], e1 = fiOff[f + 1];  // (before the barrier: the row gather below depends on them)
   __syncthreads();
   if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
-  for (int i = tid; i < B; i += 256) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + e * 256;
+    if (i >= B) continue;
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
-    const double pv = vz + coarseAtLds(cl, L, i) * vm + (useBeta ? beta * vp : 0.0);
+    const double pv = vz[e] + coarseAtLds(cl, L, i) * vm[e] + (useBeta ? beta * vp[e] : 0.0);
     pNew[base + i] = pv;
-    pvReg = pv;
-    pf[i] = pv * vm;
+    pvReg[e] = pv;
+    pf[i] = pv * vm[e];
     double acc = 0.0;
     if (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) {  // (stale partial buffer without a pair kernel)
       // the frame's partial rows are contiguous: independent streaming loads, four in flight per thread
@@ -1434,13 +1451,20 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
   // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; in both cases q is
   // all-reduced afterwards and p.q / alpha are formed by k_dot_pq on the reduced vector.
   if (distMode) {
-    for (int i = tid; i < B; i += 256) q[base + i] = qf[i] * vm + (distMode == 1 ? vlam * pvReg : 0.0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = tid + e * 256;
+      if (i < B) q[base + i] = qf[i] * vm[e] + (distMode == 1 ? vlam[e] * pvReg[e] : 0.0);
+    }
     return;
   }
   double dot = 0.0;
-  for (int i = tid; i < B; i += 256) {
-    const double pv = pvReg;
-    const double qv = qf[i] * vm + vlam * pv;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + e * 256;
+    if (i >= B) continue;
+    const double pv = pvReg[e];
+    const double qv = qf[i] * vm[e] + vlam[e] * pv;
     q[base + i] = qv;
     qf[i] = qv;
     dot += pv * qv;
@@ -1530,6 +1554,7 @@ __device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int 
 // alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
 // partial r.z and r.r.  One workgroup per frame with 256 threads per 64-row chunk (blockDim = 256 * ceil(B/64),
 // B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
+// 256 < B <= 512: 128 threads per chunk (two segments per row), same layout otherwise.
 // init != 0: dx = 0, r = -g (already masked), z = Minv r.
 __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
                                                     const float* __restrict__ minv, const double* __restrict__ p,
@@ -1690,10 +1715,25 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
   // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
   const float* Mf = minv + static_cast<size_t>(f) * B * B;
-  const int chunk = tid >> 8, row = tid & 63, seg = (tid >> 6) & 3;
+  const bool wide = B > 256;  // (two segments per row: blockDim = 128 * ceil(B / 64) <= 1024)
+  const int chunk = wide ? tid >> 7 : tid >> 8, row = tid & 63, seg = wide ? (tid >> 6) & 1 : (tid >> 6) & 3;
   const int i = chunk * 64 + row;
   double acc = 0.0;
-  if (i < B) {
+  if (wide) {
+    if (i < B) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const float* col = Mf + i;
+      int j = seg;
+      for (; j + 6 < B; j += 8) {
+        a0 += static_cast<double>(col[static_cast<size_t>(j) * B]) * rf[j];
+        a1 += static_cast<double>(col[static_cast<size_t>(j + 2) * B]) * rf[j + 2];
+        a2 += static_cast<double>(col[static_cast<size_t>(j + 4) * B]) * rf[j + 4];
+        a3 += static_cast<double>(col[static_cast<size_t>(j + 6) * B]) * rf[j + 6];
+      }
+      for (; j < B; j += 2) a0 += static_cast<double>(col[static_cast<size_t>(j) * B]) * rf[j];
+      acc = (a0 + a1) + (a2 + a3);
+    }
+  } else if (i < B) {
     // eight independent column loads in flight per thread (the loop is latency-bound: 4 B per lane and load)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const float* col = Mf + i;
@@ -1719,8 +1759,8 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
   __syncthreads();
   double rz = 0.0, rr = 0.0;
   if (seg == 0 && i < B) {
-    const int b0 = chunk * 256 + row;
-    const double zv = part[b0] + part[b0 + 64] + part[b0 + 128] + part[b0 + 192];
+    const int b0 = wide ? chunk * 128 + row : chunk * 256 + row;
+    const double zv = wide ? part[b0] + part[b0 + 64] : part[b0] + part[b0 + 64] + part[b0 + 128] + part[b0 + 192];
     z[base + i] = zv;
     rz = rf[i] * zv;
     rr = rf[i] * rf[i];

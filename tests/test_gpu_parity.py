@@ -430,11 +430,16 @@ def test_full_solve_reaches_the_oracle_minimum(Solver, cfg):
     assert rel(out["hip"][1], out["oracle"][1]) < 1e-2
 
 
-@pytest.mark.parametrize("variant", ["deferred_spatial_default_grid", "graduate_deform_reg", "deferred_spatial_small_grid"])
+@pytest.mark.parametrize("variant", ["deferred_spatial_default_grid", "graduate_deform_reg", "deferred_spatial_small_grid",
+                                     "scale_shift_default_grid"])
 def test_schedule_variants_match_oracle(Solver, variant):
     """poseOptimization's schedule options (reference lib/PoseOptimizer.cpp:836-841, 874-887): the deferred spatial step
     (a 4x3 bicubic spatial grid after the last depth level -- with the default 17x10 depth grid the frame block is
-    7 + 170 + 24 = 201 unknowns, assembled in two row panels) and the graduated depth-deformation regulariser.
+    7 + 170 + 24 = 201 unknowns, assembled in two row panels) and the graduated depth-deformation regulariser;
+    scale_shift_default_grid: two value parameters per vertex (ValueXform ScaleShift) on a BICUBIC 17x10 grid (the
+    reference's linear gather is defined for one-parameter value transforms only, so this is a single solve after an explicit
+    gridXformSplit, not the coarse-to-fine schedule): a frame block of 7 + 340 = 347 unknowns -- beyond the register-resident
+    kernels (generic product, two elements per thread in the per-frame kernels, batched rocSOLVER block inverses).
     Default solver options; end state against the oracle."""
     v = synth.make_video(12, 192, 112, seed=41)
     objs = _pair(Solver, v)
@@ -447,19 +452,26 @@ def test_schedule_variants_match_oracle(Solver, variant):
         elif variant == "deferred_spatial_small_grid":
             p.deferred_spatial_opt = 1
             p.ctf_long, p.ctf_short = 6, 4
-        else:
+        elif variant == "graduate_deform_reg":
             p.graduate_depth_deform_reg = 1
             p.ctf_long, p.ctf_short = 8, 5
-        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_depth_xforms(XformDesc.global_depth(ValueXformType.ScaleShift) if variant == "scale_shift_default_grid"
+                             else XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())
         s.normalize_depth(p)
+        if variant == "scale_shift_default_grid":
+            p.coarse_to_fine = 0
+            p.num_steps = 1
+            s.grid_xform_split(XformDesc.grid_depth(17, 10, ValueXformType.ScaleShift, cubic=True))
         s.pose_optimization(p)
         out[k] = (s.get_poses(), s.get_xform_params(), s.summary(), s.xform_desc(True), s.get_xform_params(True), s.block_size())
     sh, so = out["hip"][2], out["oracle"][2]
     assert sh["termination"] == 0 and so["termination"] == 0
     if variant == "deferred_spatial_default_grid":
         assert out["hip"][5] == 201
-    if variant != "graduate_deform_reg":
+    if variant == "scale_shift_default_grid":
+        assert out["hip"][5] == 347
+    if variant.startswith("deferred"):
         assert int(out["hip"][3].spatial_type) == int(SpatialXformType.BicubicGrid) and list(out["hip"][3].grid_size)[:2] == [4, 3]
         assert np.abs(out["hip"][4] - out["oracle"][4]).max() < 1e-4   # spatial grid parameters (NDC units)
     assert abs(sh["final_cost"] - so["final_cost"]) <= 1e-6 * abs(so["final_cost"]), (sh["final_cost"], so["final_cost"])
@@ -470,14 +482,15 @@ def test_schedule_variants_match_oracle(Solver, variant):
 
 
 def test_frame_blocks_beyond_the_supported_size_fail_before_any_work(Solver):
-    """ScaleShift on the default 17x10 grid needs 7 + 340 = 347 unknowns per frame (> 256): rejected up front, with the
-    transforms untouched (the old build failed after the coarse levels had already run)."""
+    """ScaleShift on a 24x14 grid needs 7 + 672 = 679 unknowns per frame (> 512): rejected up front, with the transforms
+    untouched (the old build failed after the coarse levels had already run)."""
     v = synth.make_video(4, 96, 56, seed=3)
     s = Solver(0)
     synth.load_into(s, v)
     s.reset_depth_xforms(XformDesc.global_depth(ValueXformType.ScaleShift))
     s.reset_spatial_xforms(XformDesc.spatial())
     p = OptParams.defaults()
+    p.ctf_long, p.ctf_short = 24, 14
     before = s.get_xform_params().copy()
     with pytest.raises(RuntimeError, match="unknowns per frame"):
         s.pose_optimization(p)
