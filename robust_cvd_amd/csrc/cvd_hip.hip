@@ -441,6 +441,7 @@ struct cvd_handle_t {
     hipGraphExec_t denseGraph = nullptr;  // the side stream's assemble + potrf + potri sequence (launchCoarseSetup)
     std::array<const void*, 8> denseGraphKey{};
     int denseGraphState = 0;              // 0 first direct call still to come, 1 capture allowed, -1 capture unsupported
+    int denseForB = 0;        // frame-block size of the problem that inverse was built for (a coarse-to-fine level)
     bool denseReady = false;  // denseInv holds an inverse for this plan (possibly of an earlier solve: a usable, stale preconditioner)
     DevBuf<double> denseA;
     DevBuf<float> denseInv, denseInv2;
@@ -2551,7 +2552,8 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
   double lastRelChange = 1.0;  // relative cost change of the last accepted step
   static const double asyncMaxChange = []() { const char* e = std::getenv("CVD_COARSE_ASYNC_MAX_CHANGE"); return e ? std::atof(e) : 1e-3; }();
   bool freshFactor = false;    // the factor was installed right before this iteration's PCG
-  if (h->coarseOn && h->coarse.denseMode && h->coarse.denseReady) {
+  static const bool carryAcrossLevels = std::getenv("CVD_COARSE_CARRY_LEVELS") != nullptr;  // comparison knob
+  if (h->coarseOn && h->coarse.denseMode && h->coarse.denseReady && (h->coarse.denseForB == c.L.B || carryAcrossLevels)) {
     // Dense level: the inverse left by the previous solve on this handle (the previous coarse-to-fine level, or the last
     // optimisation of the same video) is a perfectly good SPD preconditioner to start with -- its ~6 ms rocSOLVER rebuild
     // is not paid in line but started beside the first PCG and installed for the second LM iteration.
@@ -2580,7 +2582,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
     cgExcess = 0;
     coarseAge = 0;
     factorUses = 0;
-    if (h->coarse.denseMode) h->coarse.denseReady = true;
+    if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
   };
   bool scaleDone = false;
   cvd_iteration_record r0{};
@@ -2644,7 +2646,7 @@ static void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg,
             const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
             launchCoarseSetup(c, h->dX.p);
             h->tEnd(slot);
-            if (h->coarse.denseMode) h->coarse.denseReady = true;
+            if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
             coarseAge = 0;
             cgExcess = 0;
             freshFactor = true;
