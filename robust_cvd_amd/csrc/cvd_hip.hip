@@ -3749,7 +3749,7 @@ int32_t cvd_set_pair_graph(cvd_handle* h, int32_t numPairs, const int32_t* pairF
 int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block_size, const double* a, int32_t variant,
                                 float* inverse, int32_t* failed) {
   CVD_TRY(h, {
-    if (num_blocks <= 0 || block_size <= 0 || block_size > 256) throw std::runtime_error("block_inverse_debug: bad sizes");
+    if (num_blocks <= 0 || block_size <= 0 || block_size > kMaxFrameBlock) throw std::runtime_error("block_inverse_debug: bad sizes");
     if (variant < 0 || variant > 2) throw std::runtime_error("block_inverse_debug: variant must be 0, 1 or 2");
     const size_t n = static_cast<size_t>(num_blocks) * block_size * block_size;
     DevBuf<double> dA;

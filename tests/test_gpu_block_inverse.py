@@ -28,15 +28,17 @@ def spd_blocks(n, B, seed, cond=1e3):
     return out
 
 
-# block sizes of the coarse-to-fine schedule (8, 31, 91, 177), configs[4] (199), tile-boundary cases and the maximum (256)
-SIZES = [1, 7, 8, 15, 16, 17, 31, 32, 33, 91, 96, 128, 177, 192, 199, 208, 209, 255, 256]
+# block sizes of the coarse-to-fine schedule (8, 31, 91, 177), configs[4] (199), tile-boundary cases, the largest block of the
+# register-resident kernels (256) and blocks beyond it (257, 347 = ScaleShift on 17x10, 512), which take the batched rocSOLVER route
+SIZES = [1, 7, 8, 15, 16, 17, 31, 32, 33, 91, 96, 128, 177, 192, 199, 208, 209, 255, 256, 257, 347, 512]
 
 
 @pytest.mark.parametrize("B", SIZES)
 def test_block_inverse_matches_numpy(solver, B):
     a = spd_blocks(5, B, seed=100 + B)
     ref = np.linalg.inv(a)
-    for variant in ((0, 1, 2) if B <= 199 else (0, 1)):   # the LDS Cholesky keeps the packed triangle in LDS: B <= 199
+    # (the LDS Cholesky keeps the packed triangle in LDS: B <= 199; beyond 256 every variant is the batched rocSOLVER route)
+    for variant in ((0, 1, 2) if B <= 199 else ((0, 1) if B <= 256 else (0,))):
         m, failed = solver.block_inverse_debug(a, variant)
         assert failed == 0, (variant, failed)
         m = m.astype(np.float64)
@@ -69,6 +71,11 @@ def test_block_inverse_reports_non_positive_pivots(solver):
     for variant in (0, 1):
         _, failed = solver.block_inverse_debug(a, variant)
         assert failed > 0, variant
+    a = spd_blocks(3, 300, seed=8)   # (the batched route: the failed block is reported, the others are inverted)
+    a[2] = -a[2]
+    m, failed = solver.block_inverse_debug(a, 0)
+    assert failed == 1
+    assert np.abs(m[0].astype(np.float64) @ a[0] - np.eye(300)).max() < 2e-3
 
 
 def test_many_blocks_full_size(solver):
