@@ -380,6 +380,7 @@ struct cvd_handle_t {
   int nAsmParts = 0, nAsmSlots = 0;
   int numCU = 256;
   hipStream_t stream2 = nullptr;                       // side stream of the asynchronous coarse rebuild
+  hipStream_t streamCapture = nullptr;                 // capture-only stream of its hipGraph (never executes anything)
   SideWorker sideWorker;                               // host thread that enqueues the dense rebuild there
   rocblas_handle rbMain = nullptr;                     // main-stream handle (batched block inverses beyond B = 256)
   DevBuf<double> dInvScratch;
@@ -507,6 +508,7 @@ struct cvd_handle_t {
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
     if (evCoarseRead) (void)hipEventDestroy(evCoarseRead);
+    if (streamCapture) (void)hipStreamDestroy(streamCapture);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -2192,10 +2194,10 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
       // solver (side stream) the sequence is captured ONCE into a hipGraph and replayed with a single launch; the graph is
       // keyed on every pointer / size baked into its nodes.  A capture that rocSOLVER does not support falls back to direct
       // calls for good (state -1).
-      auto direct = [&]() {
-        HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
-        HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), s));
-        hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, s, F, nEdges, C.diag.p, C.edges.p,
+      auto direct = [&](hipStream_t st) {
+        HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), st));
+        HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, st, F, nEdges, C.diag.p, C.edges.p,
                            C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
         HIP_CHECK(hipGetLastError());
         // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
@@ -2209,9 +2211,9 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
                                            reinterpret_cast<const void*>(static_cast<size_t>(n)),
                                            reinterpret_cast<const void*>(static_cast<size_t>(nEdges))};
       if (!side || graphOff || C.denseGraphState < 0) {
-        direct();
+        direct(s);
       } else if (C.denseGraphState == 0) {
-        direct();  // (first call on this handle: rocBLAS sizes its workspace, loads its kernels -- not capturable)
+        direct(s);  // (first call on this handle: rocBLAS sizes its workspace, loads its kernels -- not capturable)
         C.denseGraphState = 1;
       } else {
         if (C.denseGraph != nullptr && C.denseGraphKey != key) {
@@ -2219,12 +2221,19 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
           C.denseGraph = nullptr;
         }
         if (C.denseGraph == nullptr) {
+          // Captured on a PRIVATE stream that nothing else ever touches: while the side stream itself were capturing, the
+          // main thread's waits on events recorded there (evCoarseRead, evCoarseDone) would be capture-isolation errors --
+          // it reaches them during the capture whenever the PCG beside it is short (eta = 0.1: 15 iterations).
+          if (!h->streamCapture) HIP_CHECK(hipStreamCreateWithFlags(&h->streamCapture, hipStreamNonBlocking));
+          hipStream_t sc = h->streamCapture;
           hipGraph_t g = nullptr;
-          bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+          bool ok = rocblas_set_stream(C.rb[side], sc) == rocblas_status_success &&
+                    hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal) == hipSuccess;
           if (ok) {
-            try { direct(); } catch (...) { ok = false; }
-            if (hipStreamEndCapture(s, &g) != hipSuccess || g == nullptr) ok = false;
+            try { direct(sc); } catch (...) { ok = false; }
+            if (hipStreamEndCapture(sc, &g) != hipSuccess || g == nullptr) ok = false;
           }
+          if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
           if (ok && hipGraphInstantiate(&C.denseGraph, g, nullptr, nullptr, 0) != hipSuccess) {
             ok = false;
             C.denseGraph = nullptr;
@@ -2239,7 +2248,7 @@ static void launchCoarseSetup(Ctx& c, const double* x, int side = 0) {
           }
         }
         if (C.denseGraph != nullptr) HIP_CHECK(hipGraphLaunch(C.denseGraph, s));
-        else direct();
+        else direct(s);
       }
       hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
                          C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut,
