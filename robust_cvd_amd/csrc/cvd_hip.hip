@@ -851,11 +851,11 @@ static Table makeTable(cvd_handle* h) {
 // Dense mode runs on the specialised fast kernels only (the default residual configuration of the reference pipeline).
 static void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
   if (!h->dense) return;
-  if (KS != 0 || !fastLoss(L) || L.lossType != CVD_STATIC_REPRO_DISPARITY || L.N != 1 || L.robustKind != 0 || trip ||
-      L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || h->dist() || L.cubic)
-    throw std::runtime_error("dense mode (cvd_set_pair_flows) supports the default residual configuration only: identity spatial "
-                             "transform, ReproDisparity loss, Cauchy robustifier, Scale value transform, Global or bilinear "
-                             "grid, per-frame or fixed intrinsics, no smoothness triplets, one GPU");
+  if (KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || h->dist() || L.cubic)
+    throw std::runtime_error("dense mode (cvd_set_pair_flows) supports the fast kernels' residual configurations only: identity "
+                             "spatial transform, a reprojection loss (ReproDisparity / ReproDepthRatio / ReproLogDepth), Scale "
+                             "value transform, Global or bilinear grid, per-frame or fixed intrinsics, no smoothness triplets, "
+                             "one GPU");
 }
 
 #define CVD_DISPATCH(KDv, KSv, ...)                                             \
@@ -1931,15 +1931,21 @@ static void launchMatvec(Ctx& c, const double* x, const double* z, const double*
       if (h->dense) {
         // dense mode: flow / mask / depth read directly (17 B per pixel pair), grid columns in 8 lane-keyed private copies
         const size_t ldsDense = ldsFast + 8 * 2 * B * 8;
-        CVD_DISPATCH_KD(c.KD, {
-          allowLds((k_matvec_pairs_fast<KD, 256, 1, true>), ldsDense);
-          if (evStart)
-            hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, 1, true>), dim3(c.nItems), dim3(256), ldsDense, s, evStart, evStop, 0,
-                                  c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-          else
-            hipLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, 1, true>), dim3(c.nItems), dim3(256), ldsDense, s, c.L, c.T, c.it, x,
-                               fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
-        });
+#define CVD_LAUNCH_PAIRS_DENSE(SPECV)                                                                                     \
+        CVD_DISPATCH_KD(c.KD, {                                                                                          \
+          if constexpr (KD <= 4) { /* (dense mode: Global and bilinear grids) */                                         \
+            allowLds((k_matvec_pairs_fast<KD, 256, SPECV, true>), ldsDense);                                             \
+            if (evStart)                                                                                                 \
+              hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, SPECV, true>), dim3(c.nItems), dim3(256), ldsDense, s, evStart, \
+                                    evStop, 0, c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF); \
+            else                                                                                                         \
+              hipLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, SPECV, true>), dim3(c.nItems), dim3(256), ldsDense, s, c.L, c.T, \
+                                 c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                         \
+          }                                                                                                              \
+        })
+        if (spec) CVD_LAUNCH_PAIRS_DENSE(1);
+        else CVD_LAUNCH_PAIRS_DENSE(0);  // (the other reprojection losses / the Huber robustifier: runtime branches)
+#undef CVD_LAUNCH_PAIRS_DENSE
       } else if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
       else CVD_LAUNCH_PAIRS_FAST(256);
 #undef CVD_LAUNCH_PAIRS_FAST_S

@@ -35,7 +35,8 @@ def _setup(Solver, frames=6, w=96, h=56, seed=61):
 
 
 @pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
-@pytest.mark.parametrize("variant", ["global", "grid6x4", "grid17x10", "global_fixed_intrinsics"])
+@pytest.mark.parametrize("variant", ["global", "grid6x4", "grid17x10", "global_fixed_intrinsics", "grid6x4_huber_ratio",
+                                     "global_log_depth"])
 def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant, product, monkeypatch):
     """`product`: the two device paths of J^T J p in dense mode -- explicit cross blocks X_ab assembled once per evaluation
     (cvd_cross.h, the default; grid17x10 needs two column panels) and the matrix-free kernel (CVD_DENSE_MATRIX_FREE)."""
@@ -51,10 +52,16 @@ def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, varian
     p.num_threads = 4
     if variant == "global_fixed_intrinsics":
         p.intr_opt = IntrinsicsOptimization.Fixed
+    if variant == "grid6x4_huber_ratio":   # the other robustifier and the other reprojection losses through the same kernels
+        p.static_loss_type = 2
+    if variant == "global_log_depth":
+        p.static_loss_type = 3
     res = {}
     for k, s in (("hip", hip), ("oracle", orc)):
+        s.set_robust_loss(1 if variant == "grid6x4_huber_ratio" else 0)
         s.reset_depth_xforms({"global": XformDesc.global_depth(), "global_fixed_intrinsics": XformDesc.global_depth(),
-                              "grid6x4": XformDesc.grid_depth(6, 4), "grid17x10": XformDesc.grid_depth(17, 10)}[variant])
+                              "grid6x4": XformDesc.grid_depth(6, 4), "grid17x10": XformDesc.grid_depth(17, 10),
+                              "grid6x4_huber_ratio": XformDesc.grid_depth(6, 4), "global_log_depth": XformDesc.global_depth()}[variant])
         s.reset_spatial_xforms(XformDesc.spatial())
         th = s.get_xform_params()
         s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)))
