@@ -2052,6 +2052,16 @@ __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Item
   if (tid == 0) costItem[item] = 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// 1 / x to f64 accuracy (1-2 ulp; not correctly rounded): hardware estimate + two Newton steps, 5 instructions instead of the
+// ~10 of the IEEE division sequence (div_scale x2, rcp, fma chain, div_fmas, div_fixup).  For the hot product's loop only.
+__device__ __forceinline__ double rcpFast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 // A wave-uniform double as a scalar (SGPR pair): the compiler cannot prove that an LDS load is uniform.
 __device__ __forceinline__ double uniformValue(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -2266,7 +2276,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2
     const double q1 = RbU[1] * v[0] + RbU[4] * v[1] + RbU[7] * v[2];
     const double q2 = RbU[2] * v[0] + RbU[5] * v[1] + RbU[8] * v[2];
     const double zz = -q2;
-    const double iz = 1.0 / zz;
+    const double iz = SPEC ? rcpFast(zz) : 1.0 / zz;
     const double u = q0 * iz * ifxb;
     const double vv = q1 * iz * ifyb;
     const double r0 = (u - pbx) * L.ws;
@@ -2275,7 +2285,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2
     if (lossType == kLossDisparity) {
       const bool zo = !(zz < eps), bo = !(Db < eps);
       const double zc = zo ? zz : eps, bc = bo ? Db : eps;
-      const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / bc;
+      const double izc = zo ? iz : 1.0 / eps, ibc = SPEC ? rcpFast(bc) : 1.0 / bc;
       r2 = (izc - ibc) * L.wd;
       dr2dA = zo ? (-L.wd * izc * izc) : 0.0;
       dr2dDb = bo ? (L.wd * ibc * ibc) : 0.0;
@@ -2295,7 +2305,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2
       }
     }
     const double sq = r0 * r0 + r1 * r1 + r2 * r2;
-    const double rho1 = SPEC ? 1.0 / (1.0 + sq * L.cauchyC) : robustRho1(L, sq);
+    const double rho1 = SPEC ? rcpFast(1.0 + sq * L.cauchyC) : robustRho1(L, sq);
 
     // ---- forward: dX, dq, t
     const double cf[3] = {pax * A, pay, 0.0};
