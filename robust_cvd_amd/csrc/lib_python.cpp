@@ -828,6 +828,14 @@ struct FlowConstraintsCollection {
   FlowConstraintsParams params_;
   std::map<std::pair<int, int>, PairConstraints> pairs_;
   std::map<int, TripletConstraints> triplets_;
+  // matchSeparation = 0 (reference :315-329, 381-395: every masked in-bounds pixel is a constraint): the flow fields and masks
+  // the constraints were computed from are kept, in pairs_ order, so that DepthVideoProcessor can hand the SOLVER the images
+  // (cvd_set_pair_flows: dense mode, 17 B per pixel pair) instead of the materialised list.  Valid while every constraint is
+  // static and the collection is what compute() produced.
+  std::vector<float> denseFlow_;
+  std::vector<uint8_t> denseMask_;
+  int denseW_ = 0, denseH_ = 0;
+  bool denseValid_ = false;
 
   FlowConstraintsCollection(const DepthVideo& video, const FlowConstraintsParams& params)
       : video_(&video), path_(video.path_), params_(params) {  // reference :44-94
@@ -982,6 +990,10 @@ struct FlowConstraintsCollection {
     };
     const size_t px = static_cast<size_t>(w) * h;
     const size_t batch = std::max<size_t>(1, (512ull << 20) / (px * 18));  // ~512 MiB of flow + mask per call
+    const bool keepDense = params_.matchSeparation == 0 && !(haveDyn && params_.minDynamicDistance > 0);
+    denseFlow_.clear();
+    denseMask_.clear();
+    denseValid_ = false;
     {  // pairs
       std::vector<std::pair<int, int>> keys;
       for (auto& kv : pairs_) keys.push_back(kv.first);
@@ -1001,6 +1013,10 @@ struct FlowConstraintsCollection {
                                               static_cast<float>(params_.minDynamicDistance), off.data()));
         std::vector<float> loc(static_cast<size_t>(off[n]) * 4);
         if (!loc.empty()) dev.check(cvd_get_sampled_constraints(dev.h, loc.data()));
+        if (keepDense) {
+          denseFlow_.insert(denseFlow_.end(), flow.begin(), flow.end());
+          denseMask_.insert(denseMask_.end(), mask.begin(), mask.end());
+        }
         for (size_t k = 0; k < n; ++k) {
           PairConstraints& pc = pairs_.at(keys[k0 + k]);
           const size_t cnt = static_cast<size_t>(off[k + 1] - off[k]);
@@ -1009,6 +1025,11 @@ struct FlowConstraintsCollection {
           pc.isStatic.assign(cnt, 1);
         }
       }
+    }
+    if (keepDense && !pairs_.empty()) {
+      denseW_ = w;
+      denseH_ = h;
+      denseValid_ = true;
     }
     {  // triplets (reference :467-550): flows centre -> previous and centre -> next
       std::vector<int> keys;
@@ -1089,6 +1110,13 @@ struct FlowConstraintsCollection {
   void resetStaticFlag() {
     for (auto& kv : pairs_) std::fill(kv.second.isStatic.begin(), kv.second.isStatic.end(), 1);
     for (auto& kv : triplets_) std::fill(kv.second.isStatic.begin(), kv.second.isStatic.end(), 1);
+  }
+  // dense hand-over is valid only while every pair constraint is static (the images carry no per-constraint flags)
+  bool allPairConstraintsStatic() const {
+    for (auto& kv : pairs_)
+      for (uint8_t st : kv.second.isStatic)
+        if (!st) return false;
+    return true;
   }
   void setStaticFlagFromDynamicMask(int distance) {  // reference :573-660
     if (!video_->hasColorStream("dynamic_mask")) { resetStaticFlag(); return; }
@@ -1243,6 +1271,7 @@ struct DvpParams {  // reference lib/Processor.h:60-90
 struct DepthVideoProcessor {
   DepthVideo* video_;
   int device_ = 0;
+  bool usedFlowImages_ = false;  // the last normalizeDepth / optimizePoses handed the solver flow images (dense mode)
   explicit DepthVideoProcessor(DepthVideo* v) : video_(v) {}
 
   void resetPoses(const DvpParams& p) {  // reference lib/Processor.cpp:987-1003
@@ -1338,20 +1367,34 @@ struct DepthVideoProcessor {
       }
       if (!masks.empty()) s.check(cvd_set_dynamic_masks(s.h, mh, mw, masks.data()));
     }
-    std::vector<int32_t> pf;
-    std::vector<int64_t> off{0};
-    std::vector<float> loc;
-    std::vector<uint8_t> st;
-    for (auto& kv : fc.pairs_) {
-      pf.push_back(kv.first.first);
-      pf.push_back(kv.first.second);
-      for (size_t i = 0; i < kv.second.loc.size(); ++i) {
-        loc.insert(loc.end(), kv.second.loc[i].begin(), kv.second.loc[i].end());
-        st.push_back(kv.second.isStatic[i]);
+    // matchSeparation = 0 collections whose flow images are at hand and match the depth stream's raster go to the solver as
+    // images (dense mode: nothing materialised on the device); LIB_PYTHON_NO_DENSE forces the list (comparison / tests)
+    const bool denseHandOver = fc.denseValid_ && fc.denseW_ == w && fc.denseH_ == h && std::getenv("LIB_PYTHON_NO_DENSE") == nullptr &&
+                               fc.denseMask_.size() == fc.pairs_.size() * static_cast<size_t>(w) * h && fc.allPairConstraintsStatic();
+    usedFlowImages_ = denseHandOver;
+    if (denseHandOver) {
+      std::vector<int32_t> pf;
+      for (auto& kv : fc.pairs_) {
+        pf.push_back(kv.first.first);
+        pf.push_back(kv.first.second);
       }
-      off.push_back(static_cast<int64_t>(st.size()));
+      s.check(cvd_set_pair_flows(s.h, static_cast<int>(pf.size() / 2), pf.data(), fc.denseFlow_.data(), fc.denseMask_.data()));
+    } else {
+      std::vector<int32_t> pf;
+      std::vector<int64_t> off{0};
+      std::vector<float> loc;
+      std::vector<uint8_t> st;
+      for (auto& kv : fc.pairs_) {
+        pf.push_back(kv.first.first);
+        pf.push_back(kv.first.second);
+        for (size_t i = 0; i < kv.second.loc.size(); ++i) {
+          loc.insert(loc.end(), kv.second.loc[i].begin(), kv.second.loc[i].end());
+          st.push_back(kv.second.isStatic[i]);
+        }
+        off.push_back(static_cast<int64_t>(st.size()));
+      }
+      s.check(cvd_set_pair_constraints(s.h, static_cast<int>(pf.size() / 2), pf.data(), off.data(), loc.data(), st.data()));
     }
-    s.check(cvd_set_pair_constraints(s.h, static_cast<int>(pf.size() / 2), pf.data(), off.data(), loc.data(), st.data()));
     if (!fc.triplets_.empty()) {
       // scene-flow smoothness triplets, keyed by the centre frame (reference lib/FlowConstraints.h:156-167); groups at
       // the sequence ends cannot form a triple and are not handed over
@@ -1780,6 +1823,7 @@ PYBIND11_MODULE(lib_python, m) {
       })
       .def("numPairs", &FlowConstraintsCollection::numPairs)
       .def("numConstraints", &FlowConstraintsCollection::numConstraints)
+      .def("holdsFlowImages", [](const FlowConstraintsCollection& c) { return c.denseValid_; })  // (extension: dense hand-over possible)
       .def("compute", &FlowConstraintsCollection::compute, py::call_guard<py::gil_scoped_release>())
       .def_readwrite("device", &FlowConstraintsCollection::device_);
 
@@ -1850,5 +1894,6 @@ PYBIND11_MODULE(lib_python, m) {
       .def("gridXformSplit", &DepthVideoProcessor::gridXformSplit).def("resetPoses", &DepthVideoProcessor::resetPoses)
       .def("resetDepthXforms", &DepthVideoProcessor::resetDepthXforms).def("resetSpatialXforms", &DepthVideoProcessor::resetSpatialXforms)
       .def("normalizeDepth", &DepthVideoProcessor::normalizeDepth).def("optimizePoses", &DepthVideoProcessor::optimizePoses)
-      .def_readwrite("device", &DepthVideoProcessor::device_);
+      .def_readwrite("device", &DepthVideoProcessor::device_)
+      .def_readonly("usedFlowImages", &DepthVideoProcessor::usedFlowImages_);  // (extension, with `device`)
 }

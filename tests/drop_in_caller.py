@@ -61,3 +61,4 @@ def optimize_poses(lib, dv, fc, frames, opt_params, use_global_scale=False):
         processor.normalizeDepth(params, fc)
         processor.optimizePoses(params, fc)
     dv.save()
+    return processor

@@ -456,6 +456,58 @@ def test_constraints_are_sampled_from_the_flow_images_on_the_gpu(lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_match_separation_zero_goes_to_the_solver_as_images(lib, tmp_path, monkeypatch):
+    """FlowConstraintsParams.matchSeparation = 0 (reference lib/FlowConstraints.cpp:315-329, 381-395: every masked in-bounds
+    pixel is a constraint): the collection keeps the flow / mask images it was computed from and DepthVideoProcessor hands
+    THOSE to the solver (cvd_set_pair_flows, dense mode) instead of the materialised list.  Same optimize_poses() sequence
+    with the hand-over switched off (LIB_PYTHON_NO_DENSE: the list path) must end in the same state."""
+    import json
+    from tests.drop_in_caller import build_pose_optimizer, optimize_poses
+    v = synth.make_video(8, 96, 56, seed=71)
+    flows, masks = synth.make_dense_flows(v)
+    F, H, W = v.num_frames, v.height, v.width
+    colors = np.random.default_rng(5).uniform(0, 1, (F, H, W, 3)).astype(np.float32)
+    frames = list(range(F))
+    res = {}
+    for mode in ("images", "list"):
+        base = dataset_io.write_dataset(str(tmp_path / mode), v)
+        os.remove(os.path.join(base, "flow_constraints.dat"))
+        with open(os.path.join(base, "flow_list.json"), "w") as f:
+            json.dump([["src", "dst"]] + v.pairs.tolist(), f)
+        dataset_io.write_flow_inputs(base, v.pairs, flows, masks, colors)
+        if mode == "list":
+            monkeypatch.setenv("LIB_PYTHON_NO_DENSE", "1")
+        opt = lib.DepthVideoPoseOptimizer.Params()
+        opt.ctfLong, opt.ctfShort = 6, 4
+        # (tests/drop_in_caller.build_pose_optimizer with matchSeparation = 0 and no dynamic-mask flags)
+        from tests.drop_in_caller import CV_32FC3
+        dv = lib.DepthVideo()
+        lib.DepthVideoImporter.importVideo(dv, base, False)
+        dv.createColorStream("full", "color_full", ".png", CV_32FC3)
+        dv.createColorStream("down", "color_down", ".raw", CV_32FC3)
+        dv.createDepthStream("depth_midas2", "depth_midas2", [-1, -1])
+        dv.save()
+        fcp = lib.FlowConstraintsParams()
+        fcp.frameRange.resolve(dv.numFrames(), True)
+        fcp.matchSeparation = 0
+        fc = lib.FlowConstraintsCollection(dv, fcp)        # no cache: compute (+ save)
+        assert fc.holdsFlowImages()
+        n_valid = int(synth.dense_constraints_from_flows(v, flows, masks)[0][-1])
+        assert fc.numConstraints() == n_valid             # the materialised list: every valid pixel, as the reference would
+        proc = optimize_poses(lib, dv, fc, frames, opt)
+        assert proc.usedFlowImages == (mode == "images")
+        ds = dv.depthStream(dv.numDepthStreams() - 1)
+        res[mode] = (np.stack([np.asarray(ds.frame(f).extrinsics.position) for f in frames]),
+                     np.stack([np.asarray(ds.frame(f).extrinsics.orientation.coeffs()) for f in frames]),
+                     np.stack([np.asarray(ds.frame(f).depthXform().params()) for f in frames]),
+                     ds.depthXformDesc().str())
+    assert res["images"][3] == res["list"][3] == "Grid(Scale, Linear, 6, 4, 1)"
+    perr, rerr = synth.relative_pose_error(res["images"][0], res["images"][1], res["list"][0], res["list"][1])
+    assert perr < 1e-4 and rerr < 1e-4, (perr, rerr)
+    np.testing.assert_allclose(res["images"][2], res["list"][2], rtol=1e-4)
+
+
+@pytest.mark.gpu
 def test_flow_guided_filter_op_matches_the_oracle(lib, tmp_path):
     """filter_depth() of the reference (pose_optimization.py:295-325): Op.Copy then Op.FlowGuidedFilter with
     frameRadius = radius, through the files of the dataset; result = the oracle's filter on the same arrays."""
