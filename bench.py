@@ -435,8 +435,9 @@ def main():
         }
     solver_main = m.pop("solver")
     solver_main.close()
-    if args.config == 2 and level != 1 and not args.no_secondary and args.frames is None and not args.dense:
-        # secondary figure: the reference sampler's own flow list (1766 directed pairs at 300 frames), same recipe
+    if args.config == 2 and level != 1 and not args.no_secondary and args.frames is None and not args.dense and world == 1:
+        # secondary figure: the reference sampler's own flow list (1766 directed pairs at 300 frames), same recipe (single-GPU
+        # runs only: a multi-rank run times the headline workload and nothing else)
         m2 = measure(1, args.secondary_steps, min(args.warmup, 2), timing=False)
         if rank == 0:
             out["secondary_1766_pairs"] = {
