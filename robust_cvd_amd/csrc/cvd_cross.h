@@ -37,7 +37,8 @@ struct CrossPairs {
 };
 
 constexpr int kCrossThreads = 512;
-constexpr int kCrossRun = 32;  // consecutive pixels per lane (see kDenseRun: lanes of a wave then touch different cells)
+constexpr int kCrossRun = 16;  // consecutive pixels per lane (see kDenseRun: lanes of a wave then touch different cells;
+                               // 32 -> 16 measured 12 % off the three assembly kernels, 8 the same, 4 and 64 worse)
 
 // Everything of one constraint that the block needs: both sides' pose rows, depth-row factors, taps.
 template <int KD>

@@ -114,13 +114,13 @@ struct Items {
 // packed partial blocks and the last one to arrive folds them (lastBlockArrives on a per-frame counter).
 constexpr int kDenseFramesPerGroup = 2;  // frames per dense-level workgroup of k_cg_update (DenseStep)
 constexpr int kAsmUnit = 128;
-// Dense mode: 2048 pixel slots per unit, dealt to the 64 lanes in runs of 32 consecutive pixels (see kDenseRun)
-constexpr int kAsmUnitDense = 2048;
+// Dense mode: 1024 pixel slots per unit, dealt to the 64 lanes in runs of 16 consecutive pixels (see kDenseRun)
+constexpr int kAsmUnitDense = 1024;
 // Dense mode lane mapping.  Consecutive pixels fall into the same grid cell, i.e. hit the same four vertices: with lane =
-// pixel every LDS atomic of a wave would collide 64-fold.  Each lane therefore walks its own run of kDenseRun = 32
-// consecutive pixels: the 64 lanes of a wave are 32 pixels apart (wider than a cell of the 17x10 grid at 384 px), and
-// a lane's eight consecutive 8-byte flow entries share one 64-byte line, so the images are still streamed once.
-constexpr int kDenseRun = 32;
+// pixel every LDS atomic of a wave would collide 64-fold.  Each lane therefore walks its own run of kDenseRun = 16
+// consecutive pixels (two 64-byte lines of flow per lane: the images are still streamed once).  Measured on the three
+// assembly kernels together: runs of 32 pixels 25.6 ms, 16: 22.5 ms, 8: 22.7 ms, 64: 28.6 ms (150 frames).
+constexpr int kDenseRun = 16;
 struct AsmPart {
   int frame;
   int u0, u1;   // unit range
