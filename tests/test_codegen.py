@@ -20,7 +20,9 @@ SOURCE = f'''
 #include "{CSRC}/cvd_device.h"
 #include "{CSRC}/cvd_kernels.h"
 #include "{CSRC}/cvd_coarse.h"
+#include "{CSRC}/cvd_cross.h"
 namespace cvd {{
+template __global__ void k_cross_assemble<4, true>(Layout, Table, CrossPairs, const double*, const FrameConst*, int, double*);
 template __global__ void k_cost_items_fast<4>(Layout, Table, Items, const double*, const FrameConst*, double*);
 template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*, double*);
 template __global__ void k_matvec_pairs_fast<4, 128>(Layout, Table, Items, const double*, const FrameConst*, const double*,
@@ -85,3 +87,23 @@ def test_block_inverse_runs_on_the_f64_matrix_cores_within_its_register_budget(a
     assert body.count("v_mfma_f64_16x16x4") >= 8            # -T panel (4) + rank-16 update (4 per tile slot)
     assert "row_newbcast" in body or "row_share" in body    # pivot row by DPP broadcast, not through LDS
     assert fields["private_segment_fixed_size"] <= 512, fields  # a few spilled address temporaries, not the tile registers
+
+
+def test_update_kernel_register_budget(asm):
+    """k_cg_update runs 768-thread workgroups at B = 177 and, with the dense coarse level fused in, F + F / 2 of them.  A first
+    version of the fused GEMV held every row's loads in flight at once (98 VGPRs and 10 us slower); the kernel streams
+    Minv + A_c^-1 (60 MB) and is bandwidth-bound at its current 86 -- the guard keeps it from creeping back up, and out of
+    scratch."""
+    fields, body = kernel_info(asm, "11k_cg_update")
+    assert fields["next_free_vgpr"] <= 96, fields
+    assert fields["private_segment_fixed_size"] == 0, fields
+
+
+def test_dense_mode_block_kernels(asm):
+    """Explicit cross blocks (cvd_cross.h): the streaming product is light (no scratch, <= 64 VGPRs: latency is hidden by
+    occupancy); the grid-panel half of the assembly must not drag the pose Jacobians along (they are dead code there:
+    no scratch, well below the 256 VGPRs of the pose half)."""
+    fields, _ = kernel_info(asm, "14k_cross_matvec")
+    assert fields["private_segment_fixed_size"] == 0 and fields["next_free_vgpr"] <= 64, fields
+    fields, _ = kernel_info(asm, "16k_cross_assembleILi4ELb1")
+    assert fields["private_segment_fixed_size"] == 0 and fields["next_free_vgpr"] <= 168, fields
