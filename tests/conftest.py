@@ -27,11 +27,27 @@ def have_gpu():
     return _has_gpu()
 
 
+def _try_build(what, fn):
+    """Builds one native piece; on a machine without its toolchain the failure is remembered, not raised: tests that need the
+    piece fail at their own import / load with the real error, pure-Python tests (sharding, synth, formats) still run."""
+    try:
+        fn()
+    except (FileNotFoundError, OSError, RuntimeError, Exception) as e:  # noqa: BLE001 (subprocess / toolchain errors)
+        _BUILD_ERRORS[what] = e
+
+
+_BUILD_ERRORS = {}
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_native():
     """Both native pieces are built in-tree before any test (seconds when up to date)."""
     from robust_cvd_amd import build as b
-    b.build()
-    b.build_lib_python()
+    _try_build("libcvd_hip", b.build)
+    _try_build("lib_python", b.build_lib_python)
     from oracle import oracle as o
-    o.build()
+    _try_build("oracle", o.build)
+    if _BUILD_ERRORS:
+        import warnings
+        warnings.warn("native build(s) failed, dependent tests will fail on load: " +
+                      "; ".join(f"{k}: {v}" for k, v in _BUILD_ERRORS.items()))
