@@ -1,0 +1,34 @@
+"""The committed evidence under profiles/ belongs to the code in the tree (no GPU needed)."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_pmc_traffic_file_was_measured_on_these_kernel_sources():
+    """bench.py reports roofline.traffic from profiles/pmc_matvec_pairs.json only when the file's hash of the kernel sources
+    matches the tree (separate rocprofv3 --pmc passes cannot run inside the bench process).  A source change without
+    `bash tools/pmc_refresh.sh` leaves the bench line without its traffic figure: caught here."""
+    import bench
+    with open(os.path.join(ROOT, "profiles", "pmc_matvec_pairs.json")) as f:
+        pmc = json.load(f)
+    assert pmc["kernel_sources_sha256"] == bench.kernel_sources_digest()
+    assert pmc["constraints"] == 2396032 and pmc["traffic_bytes_per_launch"] > 0
+
+
+def test_committed_bench_lines_follow_the_contract():
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_bench.json")))
+    assert lines, "no round-2 bench line under profiles/"
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["unit"] == "GB/s"
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
