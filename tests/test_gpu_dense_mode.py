@@ -100,6 +100,41 @@ def test_dense_solve_reaches_the_oracle_minimum(Solver, product, monkeypatch):
     assert rel(out["hip"][2], out["oracle"][2]) < 1e-3
 
 
+@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
+def test_dense_one_directional_pairs_and_odd_raster(Solver, product, monkeypatch):
+    """Only the a -> b direction of every frame pair (the reverse range of each undirected work item / block is empty) on a
+    raster whose pixel count is no multiple of the kernels' run length or unit size (90 x 50)."""
+    if product == "matrix_free":
+        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
+    v = synth.make_video(5, 90, 50, seed=66)
+    flow, mask = synth.make_dense_flows(v)
+    keep = np.flatnonzero(v.pairs[:, 0] < v.pairs[:, 1])
+    v.pairs, flow, mask = v.pairs[keep], flow[keep], mask[keep]
+    off, loc = synth.dense_constraints_from_flows(v, flow, mask)
+    hip, orc = Solver(0), Oracle()
+    for s in (hip, orc):
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.reset_poses()
+    hip.set_pair_flows(v.pairs, flow, mask)
+    orc.set_pair_constraints(v.pairs, off, loc, None)
+    rng = np.random.default_rng(4)
+    pose = np.zeros((v.num_frames, 7))
+    pose[:, :6] = rng.normal(0, 0.02, (v.num_frames, 6))
+    pose[:, 6] = 0.2
+    p = OptParams.defaults()
+    p.num_threads = 4
+    res = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        s.reset_depth_xforms(XformDesc.grid_depth(6, 4))
+        s.reset_spatial_xforms(XformDesc.spatial())
+        res[k] = s.evaluate(p, 0.1, pose, want_gradient=True, want_hdiag=True, want_hfull=True)
+    a, b = res["hip"], res["oracle"]
+    assert a["num_residual_blocks"] == b["num_residual_blocks"]
+    assert abs(a["cost"] - b["cost"]) <= TOL * abs(b["cost"])
+    assert rel(a["gradient"], b["gradient"]) < TOL and rel(a["hdiag"], b["hdiag"]) < TOL and rel(a["hfull"], b["hfull"]) < TOL
+
+
 def test_dense_mode_and_the_equivalent_list_agree_on_the_device(Solver):
     """The same constraints as images (dense kernels) and as a list (table kernels): identical problem, two code paths."""
     v, hip, _, n = _setup(Solver, seed=63)
