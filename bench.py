@@ -56,14 +56,14 @@ CONFIGS = {
 
 
 def kernel_sources_digest():
-    """SHA-256 over the device / host sources of libcvd_hip.so: ties a committed PMC measurement to the code it measured."""
+    """SHA-256 over the headers that define the hot kernel (k_matvec_pairs_fast and the device functions it inlines): ties a
+    committed PMC measurement to the kernel it measured."""
     h = hashlib.sha256()
     d = os.path.join(_ROOT, "robust_cvd_amd", "csrc")
-    for fn in sorted(os.listdir(d)):
-        if fn.endswith((".h", ".hip")):
-            with open(os.path.join(d, fn), "rb") as f:
-                h.update(fn.encode())
-                h.update(f.read())
+    for fn in ("cvd_device.h", "cvd_kernels.h"):
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(fn.encode())
+            h.update(f.read())
     return h.hexdigest()
 
 

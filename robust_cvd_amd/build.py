@@ -3,28 +3,63 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "cvd_hip.hip")
-DEPS = [SRC] + sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h")) + \
-       [os.path.join(_HERE, "..", "include", "cvd_hip.h"), os.path.join(_HERE, "..", "include", "cvd_types.h")]
+CSRC = os.path.join(_HERE, "csrc")
+# translation units of libcvd_hip.so (compiled in parallel; every unit includes cvd_host.h + the kernel headers it launches)
+UNITS = ["cvd_api", "cvd_setup", "cvd_eval", "cvd_matvec", "cvd_precond", "cvd_solve", "cvd_frontend"]
 LIB = os.path.join(_HERE, "lib", "libcvd_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics"]
+OBJ = os.path.join(_HERE, "lib", "obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-cuda-compat"]
+LINK = ["-L/opt/rocm/lib", "-lrccl", "-lrocsolver", "-lrocblas"]
+
+
+def _deps(unit):
+    """Prerequisites of a unit's object file from the compiler's own dependency file (the unit alone before the first build)."""
+    d = os.path.join(OBJ, unit + ".d")
+    src = os.path.join(CSRC, unit + ".hip")
+    if not os.path.exists(d):
+        return None
+    with open(d) as f:
+        txt = f.read().replace("\\\n", " ")
+    out = [t for t in txt.split(":", 1)[1].split() if not t.startswith("/opt/") and not t.startswith("/usr/")]
+    return out or [src]
+
+
+def _stale(unit):
+    o = os.path.join(OBJ, unit + ".o")
+    deps = _deps(unit)
+    if deps is None or not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(_stale(u) or os.path.getmtime(os.path.join(OBJ, u + ".o")) > t for u in UNITS)
+
+
+def _compile(unit, hipcc, verbose):
+    src = os.path.join(CSRC, unit + ".hip")
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", os.path.join(OBJ, unit + ".o"), "-MD", "-MF", os.path.join(OBJ, unit + ".d")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB, SRC, "-L/opt/rocm/lib", "-lrccl", "-lrocsolver", "-lrocblas"]
+    todo = [u for u in UNITS if force or _stale(u)]
+    with ThreadPoolExecutor(max_workers=min(len(todo) or 1, os.cpu_count() or 1)) as pool:
+        list(pool.map(lambda u: _compile(u, hipcc, verbose), todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [os.path.join(OBJ, u + ".o") for u in UNITS] + LINK
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 
@@ -43,7 +78,7 @@ def build_lib_python(force=False, verbose=False):
     import pybind11
     import sysconfig
     out = lib_python_path()
-    deps = [PY_SRC, LIB, os.path.join(_HERE, "csrc", "cvd_device.h")]
+    deps = [PY_SRC, LIB, os.path.join(CSRC, "cvd_device.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     build(force=False, verbose=verbose)

@@ -81,7 +81,7 @@ struct CoarsePlan {
 // k_coarse_diag subtracts from Z^T H_ff Z.  The coarse matrix is then the Galerkin operator of the kept constraints
 // (+ regularisers + damping): still SPD, and consistent on the smooth inter-frame modes it exists for.
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items it, const double* __restrict__ x,
                                                       const FrameConst* __restrict__ fc,
                                                       const int* __restrict__ itemEdge, double* __restrict__ edgeOut,
                                                       double* __restrict__ dropDiag) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, Items i
 // constraint at once.  The generic kernel above goes through Sample<KD, KS>, whose dynamically indexed tap arrays live in
 // scratch memory.
 template <int KD, bool DENSE = false>
-__global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const int* __restrict__ itemEdge, double* __restrict__ edgeOut,
                                                            double* __restrict__ dropDiag) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Table T, It
 // Diagonal coarse blocks D_f = Z_f^T (H_ff + diag(lam_f)) Z_f and the mode activity flags.  Inactive modes
 // (masked unknowns, frames outside the range, the shared focal length) become identity rows.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __restrict__ hBlocks,
+inline __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __restrict__ hBlocks,
                                                      const double* __restrict__ lam, const double* __restrict__ mask,
                                                      double* __restrict__ diagOut, unsigned char* __restrict__ modeActive,
                                                      double lamScale, const double* __restrict__ dropDiag) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const double* __r
 //   C: off-diagonal blocks: L_ij = (gathered) Linv_jj^T
 // One wave per block, lane = (row, column) of the 8x8 block.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const double* __restrict__ diag,
+inline __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const double* __restrict__ diag,
                                                         const double* __restrict__ edges,
                                                         const unsigned char* __restrict__ modeActive,
                                                         double* __restrict__ Lb, double* __restrict__ Linv,
@@ -581,7 +581,7 @@ __device__ __forceinline__ void coarseGridBarrier(unsigned int* counter, unsigne
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const double* __restrict__ diag,
+inline __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const double* __restrict__ diag,
                                                            const double* __restrict__ edges,
                                                            const unsigned char* __restrict__ modeActive,
                                                            double* __restrict__ Lb, double* __restrict__ Linv,
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, const d
 //   W_jj = Linv_jj,    W_ij = -Linv_ii sum_{k on the path below i, L_ik != 0} L_ik W_kj.
 // lane = (r, c) of the 8x8 block.  The (L_ik, W_kj) gather list of every W block is built on the host.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double* __restrict__ Lb,
+inline __global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double* __restrict__ Lb,
                                                      const double* __restrict__ Linv, double* __restrict__ Wb) {
   __shared__ double scratch[4][3 * kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_coarse_winv(CoarsePlan P, const double*
 // y = W (Z^T r): row i gathers W_ij rc_j over the columns j of its subtree (fixed order).  One workgroup per
 // row, the four waves take interleaved quarters of the list; coarse indices are frame * 8 + mode.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
+inline __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const double* __restrict__ Wb,
                                                          const double* __restrict__ rc, double* __restrict__ y,
                                                          double* __restrict__ dotPart, double* __restrict__ scal,
                                                          unsigned int* __restrict__ counter,
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(1024) void k_coarse_apply_w(CoarsePlan P, const dou
 // One workgroup (4 waves) per frame: the frame's column of W (its elimination-tree path, <= tree depth blocks) is dealt
 // over the waves, four blocks per wave in flight (clamped index, zero weight), so the kernel is one or two dependent
 // round trips (row index -> y gather) instead of one per four blocks of a single wave walking the whole path.
-__global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, double* __restrict__ cOut,
+inline __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, double* __restrict__ cOut,
                                                          const double* __restrict__ scal, int init) {
   __shared__ double part[4][kCB];
   const double sDone = init ? 0.0 : scal[S_DONE];  // (tested at the store: the flag rides on the first round trip)
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, int F, do
 // applied as an f32 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
 // r^T z, 23 MB streamed).  Unknowns in FRAME order (8 f + mode); inactive modes are identity rows.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges, const double* __restrict__ diag,
+inline __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges, const double* __restrict__ diag,
                                                               const double* __restrict__ edges,
                                                               const int* __restrict__ edgeFa, const int* __restrict__ edgeFb,
                                                               const unsigned char* __restrict__ modeActive,
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges,
 // damping, so with a small damping this happens now and then (and not reproducibly: rocBLAS sums in varying order).  A
 // rebuild beside the solver then hands back a copy of the inverse in use (`keep`: nothing changes at the swap); a
 // first build has nothing to fall back on and switches the level off through `fail`.
-__global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* __restrict__ A, const int* __restrict__ info,
+inline __global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* __restrict__ A, const int* __restrict__ info,
                                                            float* __restrict__ out, int* __restrict__ fail,
                                                            const float* __restrict__ keep) {
   const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* 
 // block-Jacobi inverses go through rocSOLVER's strided-batched potrf / potri.  k_blocks_add_diag forms H_ff + diag(lam) in
 // a scratch copy, k_blocks_pack mirrors the inverse (left in the row-major array's upper triangle, see k_coarse_dense_pack)
 // into the f32 blocks; a block whose factorisation failed becomes the inverse of its diagonal and is counted in `fail`.
-__global__ __launch_bounds__(256) void k_blocks_add_diag(int B, size_t total, const double* __restrict__ H,
+inline __global__ __launch_bounds__(256) void k_blocks_add_diag(int B, size_t total, const double* __restrict__ H,
                                                          const double* __restrict__ lam, double* __restrict__ out) {
   const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void k_blocks_add_diag(int B, size_t total, co
   }
   out[idx] = v;
 }
-__global__ __launch_bounds__(256) void k_blocks_pack(int B, size_t total, const double* __restrict__ A, const double* __restrict__ H,
+inline __global__ __launch_bounds__(256) void k_blocks_pack(int B, size_t total, const double* __restrict__ A, const double* __restrict__ H,
                                                      const double* __restrict__ lam, const int* __restrict__ info,
                                                      float* __restrict__ out, int* __restrict__ fail) {
   const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_blocks_pack(int B, size_t total, const 
 
 // c_f = (A_c^-1 Z^T r)_f for the 8 modes of frame f (one workgroup per frame: 8 rows x n, 32 threads per row) and this
 // frame's share of r^T Z A_c^-1 Z^T r; the last workgroup closes the PCG scalars exactly as k_coarse_apply_w does.
-__global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const float* __restrict__ Ainv,
+inline __global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const float* __restrict__ Ainv,
                                                             const double* __restrict__ rc, double* __restrict__ cOut,
                                                             const unsigned char* __restrict__ modeActive,
                                                             double* __restrict__ dotPart, double* __restrict__ scal,

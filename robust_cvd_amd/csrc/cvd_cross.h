@@ -164,7 +164,7 @@ __device__ __forceinline__ void crossRows(const Layout& L, const FrameConst& Fs,
 //            runs at twice the occupancy, which is what the second walk over the pixels costs.
 // LDS: x of both frames, 2 frame constants, then PPs (56) + GP + PG, or GG (G x panelW).
 template <int KD, bool GRID>
-__global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Table T, CrossPairs cp, const double* __restrict__ x,
+inline __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Table T, CrossPairs cp, const double* __restrict__ x,
                                                                   const FrameConst* __restrict__ fc, int panelW,
                                                                   double* __restrict__ X) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout L, Tabl
 // q rows of one undirected pair from its block: y_a = X p_b, y_b = X^T p_a with p = (z + Z c + beta p_old) * mask (the
 // search direction, formed here exactly as the matrix-free product forms it).  Each wave streams its rows once, fully
 // coalesced: a row's dot product with p_b gives y_a[row], the same loads scaled by p_a[row] accumulate y_b per column.
-__global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L, CrossPairs cp, const double* __restrict__ X,
+inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L, CrossPairs cp, const double* __restrict__ X,
                                                                 const double* __restrict__ mask, const double* __restrict__ z,
                                                                 const double* __restrict__ pOld, const double* __restrict__ scal,
                                                                 int useBeta, double* __restrict__ qPart, CoarseView V) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L, CrossP
 // and its total -- a reduction of the 250 KB block instead of a third walk over the pair's pixels (k_coarse_edges_fast:
 // 9.9 ms per rebuild at 300 frames).  One workgroup per pair; rows coalesced, one wave per row.  Stored rows = fa, columns = fb
 // like k_coarse_edges; `pairEdge` < 0: the pair has no edge block.
-__global__ __launch_bounds__(256) void k_coarse_edges_cross(Layout L, CrossPairs cp, const double* __restrict__ X,
+inline __global__ __launch_bounds__(256) void k_coarse_edges_cross(Layout L, CrossPairs cp, const double* __restrict__ X,
                                                             const int* __restrict__ pairEdge, double* __restrict__ edgeOut) {
   __shared__ double rowG[256];      // sum over the grid columns of row r
   __shared__ double colP[4][8];     // per wave: sum over the grid rows of pose column j

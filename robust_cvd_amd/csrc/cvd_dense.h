@@ -28,7 +28,7 @@ __device__ __forceinline__ void pixelLoc(int x, int y, int w, int h, float& lx, 
 
 // out[f][y][x] = D(depth[f][y][x]; theta_f) as f32
 template <int KD>
-__global__ __launch_bounds__(256) void k_apply_depth(Layout L, int W, int H, int frame0, const float* __restrict__ depth,
+inline __global__ __launch_bounds__(256) void k_apply_depth(Layout L, int W, int H, int frame0, const float* __restrict__ depth,
                                                      const double* __restrict__ x, float* __restrict__ out) {
   const int pidx = blockIdx.x * blockDim.x + threadIdx.x;  // pixels of one frame, flattened: no idle row tails
   if (pidx >= W * H) return;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_apply_depth(Layout L, int W, int H, int
 
 // out[f][y][x][n] = sum_k w_k theta_f[k][n] (f64, N channels)
 template <int KD>
-__global__ __launch_bounds__(256) void k_param_map(Layout L, int W, int H, int frame0, const float* __restrict__ depth,
+inline __global__ __launch_bounds__(256) void k_param_map(Layout L, int W, int H, int frame0, const float* __restrict__ depth,
                                                    const double* __restrict__ x, double* __restrict__ out) {
   const int pidx = blockIdx.x * blockDim.x + threadIdx.x;  // pixels of one frame, flattened: no idle row tails
   if (pidx >= W * H) return;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_param_map(Layout L, int W, int H, int f
 
 // out[f][y][x][2] = sum_k u_k phi_f[k][0..1] (f32), for a (h, w) raster
 template <int KS>
-__global__ __launch_bounds__(256) void k_warp_map(Layout L, int W, int H, int frame0, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_warp_map(Layout L, int W, int H, int frame0, const double* __restrict__ x,
                                                   float2* __restrict__ out) {
   const int pidx = blockIdx.x * blockDim.x + threadIdx.x;  // pixels of one frame, flattened: no idle row tails
   if (pidx >= W * H) return;

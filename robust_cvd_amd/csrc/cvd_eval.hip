@@ -1,0 +1,229 @@
+// cvd_eval.hip -- cost / gradient / frame-diagonal blocks (and the dense mode's explicit cross blocks) at a point.
+#include "cvd_host.h"
+
+namespace cvd {
+
+void launchFrameConsts(Ctx& c, const double* x) {
+  hipLaunchKernelGGL(k_frame_consts, dim3((c.L.F + 63) / 64), dim3(64), 0, c.h->stream, c.L, x, c.h->dFc.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+// The LM loop is latency-bound on its read-backs (a handful of scalars per decision): poll instead of the
+// interrupt-driven hipStreamSynchronize / hipEventSynchronize, whose wake-up costs tens of microseconds.
+void spinStream(hipStream_t s) {
+  hipError_t e;
+  while ((e = hipStreamQuery(s)) == hipErrorNotReady) {}
+  HIP_CHECK(e);
+}
+void spinEvent(hipEvent_t ev) {
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
+  HIP_CHECK(e);
+}
+void readScalars(Ctx& c) {
+  HIP_CHECK(hipMemcpyAsync(c.h->hScal, c.h->dScal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
+  spinStream(c.h->stream);
+}
+
+// cost only at x: enqueueCost leaves it in S_COST on the device, evalCost also reads it back
+void enqueueCost(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  launchFrameConsts(c, x);
+  const int slot = h->tBegin(KC_COST);
+  if (c.L.includeStatic && c.nItems > 0) {
+    const size_t lds = (2 * c.L.B) * 8 + 2 * sizeof(FrameConst) + 8 * 8;
+    const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);  // (scope of the fast kernels)
+    if (fast) {
+      CVD_DISPATCH_KD(c.KD, {
+        if (h->dense) {
+          allowLds((k_cost_items_fast<KD, true>), lds);
+          hipLaunchKernelGGL((k_cost_items_fast<KD, true>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                             h->dCostItem.p);
+        } else {
+          allowLds((k_cost_items_fast<KD, false>), lds);
+          hipLaunchKernelGGL((k_cost_items_fast<KD, false>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                             h->dCostItem.p);
+        }
+      });
+    } else {
+      CVD_DISPATCH(c.KD, c.KS, {
+        allowLds(k_cost_items<KD, KS>, lds);
+        hipLaunchKernelGGL((k_cost_items<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, h->dFc.p,
+                           h->dCostItem.p);
+      });
+    }
+    HIP_CHECK(hipGetLastError());
+  }
+  CVD_DISPATCH_KD(c.KD, {
+    hipLaunchKernelGGL((k_cost_frames<KD>), dim3(c.L.F), dim3(256), static_cast<size_t>(c.L.B) * 8, s, c.L, x, h->dMedian.p, h->dRegOwner.p, h->dInRange.p,
+                       h->dCostFrame.p);
+  });
+  HIP_CHECK(hipGetLastError());
+  if (c.trip && c.TT.nGroups > 0) {
+    // scene-flow smoothness: group costs are added to the centre frames' entries
+    CVD_DISPATCH(c.KD, c.KS, {
+      hipLaunchKernelGGL((k_cost_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), 0, s, c.L, c.TT, x, h->dFc.p,
+                         h->dCostFrame.p);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
+                     h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
+  HIP_CHECK(hipGetLastError());
+  if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
+  h->tEnd(slot);
+}
+double evalCost(Ctx& c, const double* x) {
+  enqueueCost(c, x);
+  readScalars(c);
+  return c.h->hScal[S_COST];
+}
+
+// step statistics (k_step_stats) into the device scalars; the caller reads them back
+void enqueueStats(Ctx& c) {
+  cvd_handle* h = c.h;
+  const int G = static_cast<int>(std::min<size_t>(128, (c.n + 511) / 512));
+  h->dStatPart.ensure(6 * 128);
+  hipLaunchKernelGGL(k_step_stats, dim3(G), dim3(256), 0, h->stream, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
+                     h->dX.p, h->dHd.p, h->dScal.p, h->dStatPart.p, h->dCounters.p + 2);
+  HIP_CHECK(hipGetLastError());
+}
+
+// cost + gradient + diagonal blocks at x
+// Dense mode with explicit cross blocks (cvd_cross.h) whenever the problem is in its scope.  (Bilinear grids only: at the
+// Global level every pixel hits the one vertex -- same-address LDS atomics, 52 ms per assembly measured -- and the 8 x 8
+// problem is cheap to solve matrix-free.)
+bool crossScope(cvd_handle* h, const Ctx& c) {
+  const bool off = std::getenv("CVD_DENSE_MATRIX_FREE") != nullptr;  // comparison knob (read per solve: the tests toggle it)
+  return h->dense && !off && !h->dist() && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
+         c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
+         c.L.B <= 256;
+}
+CrossPairs crossPairs(cvd_handle* h) {
+  return CrossPairs{h->dXFa.p, h->dXFb.p, h->dXRange.p, h->dXSlot.p, static_cast<int>(h->xFa.size())};
+}
+// X_ab of every undirected pair at the linearisation point x (frame constants in dFc are those of x)
+void launchCrossAssemble(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  const size_t B = c.L.B, G = c.L.nD;
+  h->dXBlocks.ensure(h->xFa.size() * B * B);
+  // pose rows / columns: one workgroup per pair; grid x grid: column panels of the largest width that fits the LDS
+  const size_t fixedDoubles = 2 * B + 2 * sizeof(FrameConst) / 8;
+  int panelW = static_cast<int>(((kMaxLds - 8192) / 8 - fixedDoubles) / G);
+  panelW = std::max(1, std::min<int>(panelW, static_cast<int>(G)));
+  const int nPanels = static_cast<int>((G + panelW - 1) / panelW);
+  panelW = static_cast<int>((G + nPanels - 1) / nPanels);  // (even panels)
+  const size_t ldsPose = (fixedDoubles + 56 + 14 * G) * 8;
+  const size_t ldsGrid = (fixedDoubles + static_cast<size_t>(panelW) * G) * 8;
+  const unsigned nP = static_cast<unsigned>(h->xFa.size());
+  CVD_DISPATCH_KD(c.KD, {
+    if constexpr (KD == 4) {
+      allowLds((k_cross_assemble<KD, false>), ldsPose);
+      hipLaunchKernelGGL((k_cross_assemble<KD, false>), dim3(nP), dim3(kCrossThreads), ldsPose, h->stream, c.L, c.T, crossPairs(h),
+                         x, h->dFc.p, static_cast<int>(G), h->dXBlocks.p);
+      allowLds((k_cross_assemble<KD, true>), ldsGrid);
+      hipLaunchKernelGGL((k_cross_assemble<KD, true>), dim3(nP, nPanels), dim3(kCrossThreads), ldsGrid, h->stream, c.L, c.T,
+                         crossPairs(h), x, h->dFc.p, panelW, h->dXBlocks.p);
+    }
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
+double evalFull(Ctx& c, const double* x, bool withStats) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  launchFrameConsts(c, x);
+  const size_t B = c.L.B;
+  const int slot = h->tBegin(KC_ASSEMBLE);
+  const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);
+  const size_t ldsFast = (B * (B + 1) / 2 + 2 * B + 4 * 36) * 8;
+  // generic kernel: the packed triangle in row panels when it does not fit the LDS in one piece (B > 199)
+  const size_t ldsRest = 3 * B * 8 + 2 * sizeof(FrameConst) + 4 * 36 * 8;
+  int panelCap = 0;
+  const bool fastFits = ldsFast <= kMaxLds;
+  if (fast && fastFits) {
+    h->dAsmScratch.ensure(static_cast<size_t>(h->nAsmSlots) * (B * (B + 1) / 2 + B + 4));
+    const AsmWork work{h->dAsmParts.p, h->dAsmUnits.p, h->dAsmScratch.p, h->dAsmCount.p};
+    CVD_DISPATCH_KD(c.KD, {
+      if (h->dense) {
+        allowLds((k_assemble_fast<KD, true>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<KD, true>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
+                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+      } else {
+        allowLds((k_assemble_fast<KD, false>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<KD, false>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
+                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
+      }
+    });
+  } else {
+    const AsmPanels panels = makePanels(static_cast<int>(B), (kMaxLds - ldsRest) / 8, panelCap);
+    const size_t lds = static_cast<size_t>(panelCap) * 8 + ldsRest;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_assemble<KD, KS>, lds);
+      hipLaunchKernelGGL((k_assemble<KD, KS>), dim3(c.L.F), dim3(256), lds, s, c.L, c.T, x, h->dFc.p, h->dMask.p,
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, h->dFpOff.p, h->dFpList.p, h->dG.p, h->dH.p, h->dCostFrame.p,
+                       h->dFocal.p, h->dFocal.p + c.L.F, panels, panelCap);
+    });
+  }
+  HIP_CHECK(hipGetLastError());
+  if (c.trip && c.TT.nGroups > 0) {
+    // scene-flow smoothness: its share of g / H_ff is added to the pair assembly's output, its cost to the frame sums
+    int panelCapT = 0;
+    const AsmPanels panelsT = makePanels(static_cast<int>(B), (kMaxLds - B * 8 - 256) / 8, panelCapT);
+    const size_t ldsT = (static_cast<size_t>(panelCapT) + B) * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_assemble_triplets<KD, KS>, ldsT);
+      hipLaunchKernelGGL((k_assemble_triplets<KD, KS>), dim3(c.L.F), dim3(256), ldsT, s, c.L, c.TT, x, h->dFc.p,
+                         h->dMask.p, h->dFtOff.p, h->dFtList.p, h->dG.p, h->dH.p, h->dFocal.p, h->dFocal.p + c.L.F,
+                         panelsT, panelCapT);
+      hipLaunchKernelGGL((k_cost_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), 0, s, c.L, c.TT, x, h->dFc.p,
+                         h->dCostFrame.p);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
+  if (c.L.intrOpt == CVD_INTR_SHARED) {  // (after the triplet assembly: it adds its share of the focal sums)
+    hipLaunchKernelGGL(k_shared_focal_fixup, dim3(1), dim3(256), 0, s, c.L, h->dFocal.p, h->dFocal.p + c.L.F, h->dMask.p,
+                       h->dG.p, h->dH.p);
+    HIP_CHECK(hipGetLastError());
+  }
+  if (c.cross) launchCrossAssemble(c, x);  // (same timing class: it is part of the Jacobian evaluation)
+  h->tEnd(slot);
+  if (h->dist()) {
+    // The exchange step of the pair-sharded mode, once per Jacobian evaluation: the gradient and the per-frame costs
+    // are all-reduced (F x B + F doubles); the frame blocks H_ff are REDUCE-SCATTERED to the frames' owners (75 MB at
+    // B = 177: each rank receives 1 / world of it), which extract the diagonal, invert their own blocks and all-gather
+    // the results -- diag(H) here (F x B doubles), the f32 inverses after the damping is known (launchBlockInverse), the
+    // 8x8 coarse diagonal blocks in launchCoarseSetup.  Against one all-reduce of H_ff: 3/4 of the bytes on the wire and
+    // 1 / world of the inverse work per rank.
+    const int ct = h->tBegin(KC_COMM_EVAL);
+    const size_t chunkH = static_cast<size_t>(h->ownChunk()) * B * B;
+    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(ncclAllReduce(h->dG.p, h->dG.p, c.n, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclAllReduce(h->dCostFrame.p, h->dCostFrame.p, c.L.F, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclReduceScatter(h->dH.p, h->dH.p + static_cast<size_t>(h->rank) * chunkH, chunkH, ncclDouble, ncclSum, h->comm, s));
+    NCCL_CHECK(ncclGroupEnd());
+    Layout own = c.L;
+    own.F = h->ownCount();
+    if (own.F > 0)
+      hipLaunchKernelGGL(k_extract_diag, dim3((static_cast<size_t>(own.F) * B + 255) / 256), dim3(256), 0, s, own,
+                         h->dH.p + static_cast<size_t>(h->ownFirst()) * B * B, h->dHd.p + static_cast<size_t>(h->ownFirst()) * B);
+    const size_t chunkD = static_cast<size_t>(h->ownChunk()) * B;
+    NCCL_CHECK(ncclAllGather(h->dHd.p + static_cast<size_t>(h->rank) * chunkD, h->dHd.p, chunkD, ncclDouble, h->comm, s));
+    h->tEnd(ct);
+  } else {
+    hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);
+  }
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
+  HIP_CHECK(hipGetLastError());
+  if (withStats) {  // |g|_max and |x| of the new point in the same read-back (lam = 0: only those two are used)
+    HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    enqueueStats(c);
+  }
+  readScalars(c);
+  return h->hScal[S_COST];
+}
+
+}  // namespace cvd

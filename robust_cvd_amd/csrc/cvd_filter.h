@@ -104,7 +104,7 @@ __device__ __forceinline__ float filterWeight(float d, float ref) {
 }
 
 template <int CAP>  // CAP = capacity of the per-thread sample list (median only); 0: mean
-__global__ __launch_bounds__(256) void k_flow_guided_filter(FilterArgs A) {
+inline __global__ __launch_bounds__(256) void k_flow_guided_filter(FilterArgs A) {
 #pragma clang fp contract(off)
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= A.w * A.h) return;

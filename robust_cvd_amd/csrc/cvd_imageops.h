@@ -24,7 +24,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {  // BORDER_DEFAULT: gf
 }
 
 // cvtColor(COLOR_BGR2GRAY) on float images: 0.114 B + 0.587 G + 0.299 R, left to right, no contraction.
-__global__ __launch_bounds__(256) void k_bgr_to_gray(const float* __restrict__ bgr, size_t pixels, float* __restrict__ gray) {
+inline __global__ __launch_bounds__(256) void k_bgr_to_gray(const float* __restrict__ bgr, size_t pixels, float* __restrict__ gray) {
 #pragma clang fp contract(off)  // every product is rounded on its own (the __f*_rn intrinsics alone do not stop FMA fusion)
   const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= pixels) return;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_bgr_to_gray(const float* __restrict__ b
 
 // Sobel 3x3 derivatives scaled by 1 / (2^(aperture-1) * blockSize) = 1/12 (the scale sits on the smoothing taps, as
 // in OpenCV's Sobel), then cov = (dx dx, dx dy, dy dy).
-__global__ __launch_bounds__(256) void k_sobel_cov(const float* __restrict__ gray, int w, int h, float* __restrict__ cov) {
+inline __global__ __launch_bounds__(256) void k_sobel_cov(const float* __restrict__ gray, int w, int h, float* __restrict__ cov) {
 #pragma clang fp contract(off)
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= w * h) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_sobel_cov(const float* __restrict__ gra
 }
 
 // boxFilter(3x3, normalize = false) of cov, then calcMinEigenVal: a = A/2, c = C/2, (a + c) - sqrt((a - c)^2 + B^2).
-__global__ __launch_bounds__(256) void k_box_min_eigenval(const float* __restrict__ cov, int w, int h,
+inline __global__ __launch_bounds__(256) void k_box_min_eigenval(const float* __restrict__ cov, int w, int h,
                                                           float* __restrict__ out) {
 #pragma clang fp contract(off)
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -131,7 +131,7 @@ __device__ inline void chamferRowScan(unsigned int* row, int w, bool backward, l
 }
 
 // One workgroup per image. tmp: (h + 4) x (w + 4) unsigned ints per image (2-pixel frame of kDistMax).
-__global__ __launch_bounds__(kChamferThreads) void k_chamfer_5x5(const unsigned char* __restrict__ mask, int w, int h,
+inline __global__ __launch_bounds__(kChamferThreads) void k_chamfer_5x5(const unsigned char* __restrict__ mask, int w, int h,
                                                                  unsigned int* __restrict__ tmpAll,
                                                                  float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smRaw[];

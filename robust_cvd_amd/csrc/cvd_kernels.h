@@ -82,7 +82,7 @@ __device__ __forceinline__ bool loadConstraint(const Table& T, long long c, long
 }
 
 // Valid constraints of the dense mode (what k_build_table counts for the list mode).
-__global__ void k_dense_count(Table T, int P, const unsigned char* __restrict__ inRange, unsigned long long* __restrict__ nValid) {
+inline __global__ void k_dense_count(Table T, int P, const unsigned char* __restrict__ inRange, unsigned long long* __restrict__ nValid) {
   const long long npx = static_cast<long long>(T.W) * T.H;
   const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   bool ok = false;
@@ -182,7 +182,7 @@ __device__ __forceinline__ bool lastBlockArrives(unsigned int* counter, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameConst* __restrict__ fc) {
+inline __global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameConst* __restrict__ fc) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= L.F) return;
   FrameConst c;
@@ -191,7 +191,7 @@ __global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameCons
 }
 
 // Observation ctor, reference lib/PoseOptimizer.cpp:104-116 (float arithmetic, no FMA contraction).
-__global__ void k_build_table(int W, int H, float invAspect, long long C, const float4* __restrict__ loc,
+inline __global__ void k_build_table(int W, int H, float invAspect, long long C, const float4* __restrict__ loc,
                               const unsigned char* __restrict__ isStatic, const int* __restrict__ cpair,
                               const int* __restrict__ pairA, const int* __restrict__ pairB,
                               const unsigned char* __restrict__ inRange, const float* __restrict__ depth,
@@ -232,7 +232,7 @@ __global__ void k_build_table(int W, int H, float invAspect, long long C, const 
 // candidate-point cost: pair-major over work items
 // ---------------------------------------------------------------------------------------------------
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it, const double* __restrict__ x,
                                                     const FrameConst* __restrict__ fc, double* __restrict__ costItem) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_cost_items(Layout L, Table T, Items it,
 }
 
 template <int KD>
-__global__ __launch_bounds__(256) void k_cost_frames(Layout L, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_cost_frames(Layout L, const double* __restrict__ x,
                                                      const float* __restrict__ median,
                                                      const unsigned char* __restrict__ inRange,
                                                      const unsigned char* __restrict__ rangeFlags,
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_cost_frames(Layout L, const double* __r
 }
 
 // deterministic final sum: out[slot] = sum(a[0..na)) + sum(b[0..nb))
-__global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int na, const double* __restrict__ b,
+inline __global__ __launch_bounds__(256) void k_sum2(const double* __restrict__ a, int na, const double* __restrict__ b,
                                               int nb, double* __restrict__ out, int slot) {
   __shared__ double red[4];
   double acc = 0.0;
@@ -348,7 +348,7 @@ struct AsmPanels {
 };
 
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const double* __restrict__ x,
                                                   const FrameConst* __restrict__ fc, const double* __restrict__ mask,
                                                   const float* __restrict__ median,
                                                   const unsigned char* __restrict__ inRange,
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_assemble(Layout L, Table T, const doubl
 }
 
 // IntrinsicsOptimization::Shared: frame 0's focal slot receives the static focal gradient / diagonal of all frames.
-__global__ __launch_bounds__(256) void k_shared_focal_fixup(Layout L, const double* __restrict__ focalG,
+inline __global__ __launch_bounds__(256) void k_shared_focal_fixup(Layout L, const double* __restrict__ focalG,
                                                             const double* __restrict__ focalH,
                                                             const double* __restrict__ mask, double* __restrict__ g,
                                                             double* __restrict__ hBlocks) {
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void k_shared_focal_fixup(Layout L, const doub
 // ---------------------------------------------------------------------------------------------------
 // hdiag = diag(H_ff) of every frame as a flat F x B vector (k_extract_diag; all-gathered from the frames' owners in the
 // pair-sharded multi-GPU mode, where a rank holds the reduced H_ff of its own frames only).
-__global__ void k_lm_diag(Layout L, const double* __restrict__ hdiag, double* __restrict__ scale,
+inline __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiag, double* __restrict__ scale,
                           int computeScale, double radius, double* __restrict__ lam) {
   const size_t n = static_cast<size_t>(L.F) * L.B;
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -642,7 +642,7 @@ __global__ void k_lm_diag(Layout L, const double* __restrict__ hdiag, double* __
 // double-buffered LDS vector, so one barrier per pivot and ~16 FMAs + 64 B of LDS reads per tile and step.
 // Padding rows/columns (B not a multiple of 4) are identity and never swept.
 template <int TPT, int TS = 4>
-__global__ __launch_bounds__(TS == 4 ? 1024 : 512, 4) void k_block_inverse_sweep(Layout L, const double* __restrict__ hBlocks,
+inline __global__ __launch_bounds__(TS == 4 ? 1024 : 512, 4) void k_block_inverse_sweep(Layout L, const double* __restrict__ hBlocks,
                                                               const double* __restrict__ lam,
                                                               float* __restrict__ minv, int* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double colBuf[2][264];
@@ -824,7 +824,7 @@ constexpr int kInvLd = 17;            // LDS row stride of a tile (doubles): con
 constexpr int kInvTile = kInvTS * kInvLd;
 
 template <int NW, int TPW>
-__global__ __launch_bounds__(NW * 64, 4) void k_block_inverse_mfma(Layout L, const double* __restrict__ hBlocks,
+inline __global__ __launch_bounds__(NW * 64, 4) void k_block_inverse_mfma(Layout L, const double* __restrict__ hBlocks,
                                                                const double* __restrict__ lam, float* __restrict__ minv,
                                                                int* __restrict__ fail) {
   extern __shared__ __attribute__((aligned(16))) double invSmem[];
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_block_inverse_mfma(Layout L, con
 // the packed lower triangle in LDS, L^-1 by column-parallel forward substitution (global scratch,
 // L2-resident), Minv = L^-T L^-1.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
+inline __global__ __launch_bounds__(1024) void k_block_inverse(Layout L, const double* __restrict__ hBlocks,
                                                         const double* __restrict__ lam, float* __restrict__ minv,
                                                         double* __restrict__ work, int* __restrict__ fail) {
   // Everything stays in LDS (packed lower triangle A, B(B+1)/2 doubles + one column buffer):
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(1024) void k_block_inverse(Layout L, const double* 
 // per-frame reduction (k_matvec_finish) is a gather, so there are no global atomics.
 // ---------------------------------------------------------------------------------------------------
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_matvec_pairs(Layout L, Table T, Items it, const double* __restrict__ x,
                                                       const FrameConst* __restrict__ fc,
                                                       const double* __restrict__ mask, const double* __restrict__ z,
                                                       const double* __restrict__ pOld,
@@ -1291,7 +1291,7 @@ struct RegCache {
 };
 
 template <int KD>
-__global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __restrict__ x,
                                                    const float* __restrict__ median,
                                                    const unsigned char* __restrict__ owner, RegCache rc) {
   extern __shared__ __attribute__((aligned(16))) double sm[];  // the frame's parameters (see k_cost_frames)
@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double* __res
 }
 
 template <int KD>
-__global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
                                                        const double* __restrict__ mask,
                                                        const double* __restrict__ lam, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ inRange,
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* _
 }
 
 // p.q of the all-reduced product (multi-GPU only) + alpha, same last-workgroup pattern as k_matvec_finish.
-__global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
+inline __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                 double* __restrict__ fdot, double* __restrict__ qc,
                                                 const unsigned char* __restrict__ modeActive, CoarseColumns cc) {
@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int 
 // B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
 // 256 < B <= 512: 128 threads per chunk (two segments per row), same layout otherwise.
 // init != 0: dx = 0, r = -g (already masked), z = Minv r.
-__global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
+inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
                                                     const float* __restrict__ minv, const double* __restrict__ p,
                                                     const double* __restrict__ q, double* __restrict__ scal,
                                                     unsigned int* __restrict__ counter, double* __restrict__ dx,
@@ -1827,7 +1827,7 @@ __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const do
 }
 
 // Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|.
-__global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ dx,
+inline __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ dx,
                                                     const double* __restrict__ g, const double* __restrict__ r,
                                                     const double* __restrict__ lam, const double* __restrict__ x,
                                                     const double* __restrict__ hdiagActive, double* __restrict__ scal,
@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __re
 }
 
 // xcand = x + dx with the lower bound 0 on theta_k[0] when requested (ParameterBlock::Plus projection).
-__global__ void k_apply_step(Layout L, int boundDepth0, const double* __restrict__ x, const double* __restrict__ dx,
+inline __global__ void k_apply_step(Layout L, int boundDepth0, const double* __restrict__ x, const double* __restrict__ dx,
                              double* __restrict__ xc) {
   const size_t n = static_cast<size_t>(L.F) * L.B;
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1896,7 +1896,7 @@ __global__ void k_apply_step(Layout L, int boundDepth0, const double* __restrict
   xc[i] = v;
 }
 
-__global__ void k_extract_diag(Layout L, const double* __restrict__ hBlocks, double* __restrict__ out) {
+inline __global__ void k_extract_diag(Layout L, const double* __restrict__ hBlocks, double* __restrict__ out) {
   const size_t n = static_cast<size_t>(L.F) * L.B;
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1955,7 +1955,7 @@ __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, 
 // of Sample<KD, KS> in dynamically indexed arrays, i.e. in scratch memory (672 B per lane, stores and dependent reloads
 // per constraint): 53 us for 1.09 M constraints where the arithmetic needs ~10.
 template <int KD, bool DENSE = false>
-__global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                          const FrameConst* __restrict__ fc, double* __restrict__ costItem) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr double eps = 1e-6;
@@ -2073,7 +2073,7 @@ constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed
 // SPEC = 1: the default pipeline's variant fixed at compile time (one value parameter per vertex, ReproDisparity loss,
 // Cauchy robustifier): the branches on the runtime Layout fields drop out of the constraint loop.
 template <int KD, int NT, int SPEC = 0, bool DENSE = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
@@ -2494,7 +2494,7 @@ __device__ unsigned long long g_asmProf[2048 * 16];
 #define ASM_STAMP(slot) do {} while (0)
 #endif
 template <int KD, bool DENSE = false>
-__global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
+inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
                                                        const unsigned char* __restrict__ regOwner,
@@ -2966,7 +2966,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T
 // AdaptiveDeformationCost constructor (reference lib/PoseOptimizer.cpp:560-618): every mask pixel is splatted bilinearly
 // onto the four surrounding grid vertices, into the static (mask > 127) or the dynamic sums; vertex weight = dynamic /
 // (dynamic + static).  One workgroup per frame, LDS accumulators (the sums are order-dependent only in the last bits).
-__global__ __launch_bounds__(256) void k_adaptive_weights(const unsigned char* __restrict__ masks, int dw, int dh, int gw,
+inline __global__ __launch_bounds__(256) void k_adaptive_weights(const unsigned char* __restrict__ masks, int dw, int dh, int gw,
                                                           int gh, double* __restrict__ weights) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int G = gw * gh;

@@ -1,0 +1,170 @@
+// cvd_matvec.hip -- the PCG product q = (J^T J + diag(lam)) p: pair-major partial products, per-frame finish, exchange.
+#include "cvd_host.h"
+
+namespace cvd {
+
+bool coarseFusedConsumers() {
+  static const bool v = std::getenv("CVD_COARSE_FUSED") != nullptr;  // experiment: c_f formed inside the consumers
+  return v;
+}
+bool coarseDenseFused() {
+  static const bool v = std::getenv("CVD_COARSE_DENSE_UNFUSED") == nullptr;  // comparison knob: separate k_coarse_dense_apply launch
+  return v;
+}
+CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
+  if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  auto& C = h->coarse;
+  return CoarseView{C.pos.p, C.wPtr.p, C.wRow.p, walk ? C.Wb.p : nullptr, C.y.p, C.modeActive.p, C.fail.p, C.c.p};
+}
+
+// Fills the regulariser Jacobian cache for the products at linearisation point x (before runPcg / the J^T J hook).
+void prepareMatvec(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  const Layout& L = c.L;
+  // the per-frame constants must be those of x: a rejected LM step leaves the candidate's behind (evalCost)
+  launchFrameConsts(c, x);
+  int nr = 0;
+  if (L.scaleRegSqrt > 0.0) nr += L.sregX * L.sregY;
+  if (L.focalRegSqrt > 0.0) nr += 1;
+  if (L.depthDeformW > 0.0 && L.depthType == CVD_DEPTH_GRID) nr += gridNumEdges(L.gx, L.gy, L.gz) * L.N;
+  if (L.spatialDeformW > 0.0) nr += L.nS;
+  const int stride = std::max(2, c.KD * std::max(1, L.N));
+  const size_t entries = static_cast<size_t>(L.F) * stride * std::max(nr, 1);
+  h->dRegJac.ensure(entries);
+  h->dRegCol.ensure(entries);
+  h->dRegCnt.ensure(static_cast<size_t>(L.F) * std::max(nr, 1));
+  h->regCache = RegCache{h->dRegJac.p, h->dRegCol.p, h->dRegCnt.p, nr, stride};
+  HIP_CHECK(hipMemsetAsync(h->dScal.p + S_DONE, 0, sizeof(double), h->stream));
+  if (nr == 0) return;
+  CVD_DISPATCH_KD(c.KD, {
+    hipLaunchKernelGGL((k_reg_cache<KD>), dim3(L.F), dim3(256), static_cast<size_t>(L.B) * 8, h->stream, L, x, h->dMedian.p, h->dRegOwner.p,
+                       h->regCache);
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
+void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta,
+                         const double* lam, double* q, bool withCoarse) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const CoarseView cF = coarseView(h, withCoarse, coarseFusedConsumers());  // z + Z c: the coarse part of the preconditioned residual
+  const size_t B = c.L.B;
+  if (c.cross) {
+    // explicit cross blocks (dense mode): one workgroup per undirected pair streams its B x B block
+    hipEvent_t evStart, evStop;
+    (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
+    const size_t ldsX = (3 * B + (kCrossThreads / 64) * B + 2 * kCB) * 8;
+    const unsigned nP = static_cast<unsigned>(h->xFa.size());
+    if (evStart)
+      hipExtLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, evStart, evStop, 0, c.L, crossPairs(h),
+                            h->dXBlocks.p, h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    else
+      hipLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, c.L, crossPairs(h), h->dXBlocks.p, h->dMask.p, z,
+                         pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    HIP_CHECK(hipGetLastError());
+  } else if (c.L.includeStatic && c.nItems > 0) {
+    const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
+    const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
+    hipEvent_t evStart, evStop;
+    (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
+    const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);
+    // (plain launches unless the launch is timed: hipExtLaunchKernelGGL is not used inside a graph capture)
+    const FrameConst* fcp = h->dFc.p;
+    const double* maskp = h->dMask.p;
+    const double* scalp = h->dScal.p;
+    if (fast) {
+      // Workgroup size: a work item keeps its slot for ~20 us at 256 threads and the register budget allows two
+      // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When the items need more than one
+      // round at 256 threads but fit into one round of 128-thread workgroups the launch has no ragged second round
+      // (benchmark: 883 items, 44 -> 39.5 us).
+      static const int forcedNT = []() { const char* e = std::getenv("CVD_PAIRS_NT"); return e ? std::atoi(e) : 0; }();
+      const int nt = forcedNT ? forcedNT : (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
+      // SPEC = 1: the default pipeline's variant (one value parameter, ReproDisparity, Cauchy) fixed at compile time
+      const bool spec = c.L.N == 1 && c.L.lossType == CVD_STATIC_REPRO_DISPARITY && c.L.robustKind == 0;
+#define CVD_LAUNCH_PAIRS_FAST_S(NTV, SPECV)                                                                              \
+      CVD_DISPATCH_KD(c.KD, {                                                                                            \
+        allowLds((k_matvec_pairs_fast<KD, NTV, SPECV>), ldsFast);                                                        \
+        if (evStart)                                                                                                     \
+          hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV, SPECV>), dim3(c.nItems), dim3(NTV), ldsFast, s, evStart, evStop, 0, \
+                                c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                \
+        else                                                                                                             \
+          hipLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV, SPECV>), dim3(c.nItems), dim3(NTV), ldsFast, s, c.L, c.T, c.it, x, \
+                             fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                                      \
+      })
+#define CVD_LAUNCH_PAIRS_FAST(NTV) do { if (spec) CVD_LAUNCH_PAIRS_FAST_S(NTV, 1); else CVD_LAUNCH_PAIRS_FAST_S(NTV, 0); } while (0)
+      if (h->dense) {
+        // dense mode: flow / mask / depth read directly (17 B per pixel pair), grid columns in 8 lane-keyed private copies
+        const size_t ldsDense = ldsFast + 8 * 2 * B * 8;
+#define CVD_LAUNCH_PAIRS_DENSE(SPECV)                                                                                     \
+        CVD_DISPATCH_KD(c.KD, {                                                                                          \
+          if constexpr (KD <= 4) { /* (dense mode: Global and bilinear grids) */                                         \
+            allowLds((k_matvec_pairs_fast<KD, 256, SPECV, true>), ldsDense);                                             \
+            if (evStart)                                                                                                 \
+              hipExtLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, SPECV, true>), dim3(c.nItems), dim3(256), ldsDense, s, evStart, \
+                                    evStop, 0, c.L, c.T, c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF); \
+            else                                                                                                         \
+              hipLaunchKernelGGL((k_matvec_pairs_fast<KD, 256, SPECV, true>), dim3(c.nItems), dim3(256), ldsDense, s, c.L, c.T, \
+                                 c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                         \
+          }                                                                                                              \
+        })
+        if (spec) CVD_LAUNCH_PAIRS_DENSE(1);
+        else CVD_LAUNCH_PAIRS_DENSE(0);  // (the other reprojection losses / the Huber robustifier: runtime branches)
+#undef CVD_LAUNCH_PAIRS_DENSE
+      } else if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
+      else CVD_LAUNCH_PAIRS_FAST(256);
+#undef CVD_LAUNCH_PAIRS_FAST_S
+#undef CVD_LAUNCH_PAIRS_FAST
+    } else {
+      CVD_DISPATCH(c.KD, c.KS, {
+        allowLds(k_matvec_pairs<KD, KS>, lds);
+        if (evStart)
+          hipExtLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, evStart, evStop, 0, c.L, c.T,
+                                c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);
+        else
+          hipLaunchKernelGGL((k_matvec_pairs<KD, KS>), dim3(c.nItems), dim3(256), lds, s, c.L, c.T, c.it, x, fcp, maskp, z,
+                             pOld, scalp, useBeta, h->dQPart.p, cF);
+      });
+    }
+    HIP_CHECK(hipGetLastError());
+  }
+  if (c.trip && c.TT.nGroups > 0) {
+    const size_t ldsT = (9 * B + 3 * kCB) * 8;
+    CVD_DISPATCH(c.KD, c.KS, {
+      allowLds(k_matvec_triplets<KD, KS>, ldsT);
+      hipLaunchKernelGGL((k_matvec_triplets<KD, KS>), dim3(c.TT.nGroups), dim3(256), ldsT, s, c.L, c.TT, x, h->dFc.p,
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
+  {
+    if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_matvec_finish");
+    const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
+    // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
+    const bool fusedCoarse = withCoarse && !h->coarse.denseMode;
+    const bool denseFused = withCoarse && h->coarse.denseMode && coarseDenseFused() && !h->dist();  // (needs Z^T q: DenseStep)
+    const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, fusedCoarse ? h->coarse.Wb.p : nullptr,
+                           h->coarse.wq.p};
+    const int slot = h->tBegin(KC_MATVEC_FINISH);
+    CVD_DISPATCH_KD(c.KD, {
+      hipLaunchKernelGGL((k_matvec_finish<KD>), dim3(c.L.F), dim3(256), lds, s, c.L, x, h->dMask.p, lam,
+                         h->dMedian.p, h->dRegOwner.p, h->dInRange.p, c.cross ? h->dXFiOff.p : h->dFiOff.p, h->dFiList.p,
+                         h->dQPart.p, z, pOld, pNew, h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
+                         h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.cross ? static_cast<int>(h->xFa.size()) * 2 : h->qRows,
+                         h->regCache, cF, ((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr, cc,
+                         c.cross ? h->dH.p : nullptr);
+    });
+    HIP_CHECK(hipGetLastError());
+    if (h->dist()) {
+      // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
+      const int ct = h->tBegin(KC_COMM_PRODUCT);
+      NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
+      h->tEnd(ct);
+      hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
+                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc);
+      HIP_CHECK(hipGetLastError());
+    }
+    h->tEnd(slot);
+  }
+}
+
+}  // namespace cvd

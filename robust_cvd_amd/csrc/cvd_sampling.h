@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned int orderedBits(float v) {  // ascending flo
   const unsigned int u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__global__ __launch_bounds__(256) void k_fc_candidates(SamplingArgs A, int pair0, const int* __restrict__ pairFrames,
+inline __global__ __launch_bounds__(256) void k_fc_candidates(SamplingArgs A, int pair0, const int* __restrict__ pairFrames,
                                                        const float2* __restrict__ flow,
                                                        const unsigned char* __restrict__ mask,
                                                        unsigned long long* __restrict__ keys,
@@ -124,7 +124,7 @@ __device__ __forceinline__ bool fcTripletCandidate(const SamplingArgs& A, int fc
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_fc_triplet_candidates(SamplingArgs A, int g0, const int* __restrict__ centers,
+inline __global__ __launch_bounds__(256) void k_fc_triplet_candidates(SamplingArgs A, int g0, const int* __restrict__ centers,
                                                                const float2* __restrict__ flow10,
                                                                const unsigned char* __restrict__ mask10,
                                                                const float2* __restrict__ flow12,
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_fc_triplet_candidates(SamplingArgs A, i
 // slab: [pairs in batch][W*H][4] accepted constraints in rank order; count[pb] = how many.
 // TRIPLET: flow = c -> c-1, flow2 = c -> c+1 and the slab holds 6 floats per constraint (3 x float2).
 template <bool TRIPLET>
-__global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, const unsigned long long* __restrict__ sortedKeys,
+inline __global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, const unsigned long long* __restrict__ sortedKeys,
                                                   const unsigned int* __restrict__ nValid,
                                                   const float2* __restrict__ flow, const float2* __restrict__ flow2,
                                                   float2* __restrict__ slab, unsigned int* __restrict__ count) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void k_fc_greedy(SamplingArgs A, int pair0, con
 }
 
 // compaction of one batch: slab rows -> the pair's slice of the output
-__global__ __launch_bounds__(256) void k_fc_compact(int npx, int width, int pair0, const long long* __restrict__ offsets,
+inline __global__ __launch_bounds__(256) void k_fc_compact(int npx, int width, int pair0, const long long* __restrict__ offsets,
                                                     const float2* __restrict__ slab, float2* __restrict__ out) {
   const int pb = blockIdx.y;
   const long long o0 = offsets[pair0 + pb] * width, n = (offsets[pair0 + pb + 1] - offsets[pair0 + pb]) * width;

@@ -1,0 +1,546 @@
+// cvd_solve.hip -- the PCG loop, the Levenberg-Marquardt driver (Ceres defaults) and the evaluation hook.
+#include "cvd_host.h"
+
+namespace cvd {
+
+// PCG on (H + diag(lam)) dx = -g with the block-Jacobi preconditioner; returns iterations used.
+// Three launches per iteration (pairs product, per-frame finish, per-frame update).  alpha / beta live on
+// the device: the last workgroup of k_matvec_finish / k_cg_update reduces the per-frame partial dot products
+// (agent-scope release/acquire ticket), so there is neither a scalar kernel nor a host round trip in the loop.
+int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const int F = c.L.F;
+  const size_t B = c.L.B;
+  if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_cg_update");
+  prepareMatvec(c, x);
+  const int nChunks = static_cast<int>((B + 63) / 64);
+  const int nThreads = (B > 256 ? 128 : 256) * nChunks;  // (k_cg_update: four segments per row up to B = 256, two beyond)
+  double* fd = h->dFdot.p;
+  size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
+  const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
+  for (int i = 0; i < 9; ++i) h->hPcg[i] = 0.0;  // device progress mirror (pcgFinishScalars): nothing applied yet
+  const bool coarse = h->coarseOn;
+  double* rc = coarse ? h->coarse.rc.p : nullptr;
+  // Coarse level per iteration: y = W Z^T r is kept up to date inside k_cg_update (CoarseStep: y <- y - alpha W Z^T q,
+  // |y|^2 closes r^T z), so only c = W^T y remains as a launch; the first residual goes through k_coarse_apply_w.
+  static const bool unfusedEnv = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
+  const bool denseCoarse = coarse && h->coarse.denseMode;
+  const bool unfusedY = unfusedEnv || denseCoarse;  // (the dense level has no W to recur on: Z^T r is restricted every iteration)
+  auto coarseC = [&](int init) {
+    if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
+      hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
+                         h->dScal.p, init);
+  };
+  auto coarseApply = [&](int init) {
+    if (denseCoarse) {
+      hipLaunchKernelGGL(k_coarse_dense_apply, dim3(F), dim3(256), 0, s, F, h->coarse.denseInv.p, h->coarse.rc.p, h->coarse.c.p,
+                         h->coarse.modeActive.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init,
+                         tol2, h->hPcg);
+      return;
+    }
+    hipLaunchKernelGGL(k_coarse_apply_w, dim3(F), dim3(1024), 0, s, h->coarse.plan, h->coarse.Wb.p, h->coarse.rc.p,
+                       h->coarse.y.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init, tol2,
+                       h->hPcg);
+    coarseC(init);
+  };
+  const CoarseStep csOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const CoarseStep csOn = (coarse && !unfusedY)
+                              ? CoarseStep{h->coarse.wtPtr.p, h->coarse.wtBlk.p, h->coarse.wtFrame.p, h->coarse.Wb.p,
+                                           h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p, h->coarse.wq.p}
+                              : csOff;
+  const DenseStep dsOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // dense level: c <- c - alpha A_c^-1 Z^T q inside k_cg_update (F extra workgroups) instead of a launch of its own
+  const bool denseFused = denseCoarse && coarseDenseFused() && !h->dist();
+  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
+                                                h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
+                                    : dsOff;
+  if (denseFused) ldsU = std::max(ldsU, (static_cast<size_t>(F) * kCB + nThreads + 16) * 8);  // (its workgroups: Z^T q + partial sums)
+  hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
+                     h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
+                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff);
+  if (coarse) coarseApply(1);
+  HIP_CHECK(hipGetLastError());
+  double* pOld = h->dP0.p;
+  double* pNew = h->dP1.p;
+  const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
+  const int every = std::max(1, c.h->opt.pcg_check_every);
+  // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
+  // batches of `every` iterations and reads the control scalars of batch b only before enqueuing batch b + 2, so
+  // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
+  // (profiling aid: CVD_PCG_LOCKSTEP=1 checks after every iteration and never runs ahead, so that per-launch
+  // counter averages contain no early-exit launches)
+  static const bool lockstep = std::getenv("CVD_PCG_LOCKSTEP") != nullptr;
+  const size_t firstTimerSlot = h->evUsed;
+  int enq = 0;
+  auto enqueueIteration = [&](int it, int useBeta) {
+    h->curPcgIter = it;
+    launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
+    const int slot = h->tBegin(KC_CG_UPDATE);
+    hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+                       h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
+                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn);
+    if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
+    HIP_CHECK(hipGetLastError());
+    h->tEnd(slot);
+    std::swap(pOld, pNew);
+  };
+  // (Replaying the batch as a hipGraph was tried: the ~6 us between the five dependent launches of an iteration are
+  // device-side dependency resolution, not host launch latency -- no gain, removed.)
+  // Convergence is decided on the device (S_DONE); the last workgroup of every iteration also mirrors its progress
+  // into pinned host memory (pcgFinishScalars).  Iteration k is enqueued once the done flag after exactly
+  // k - kRunAhead + 1 iterations is known to be clear: nothing but the PCG kernels is in the stream, the device is
+  // never starved (kRunAhead iterations are queued ahead) and kRunAhead - 1 early-exit iterations are wasted per
+  // solve.  The rule is a function of iteration counts only, hence identical on all ranks of a sharded run.
+  static const int runAheadEnv = []() { const char* e = std::getenv("CVD_PCG_RUN_AHEAD"); return e ? std::max(1, std::atoi(e)) : 2; }();
+  const int kRunAhead = lockstep ? 1 : runAheadEnv;
+  volatile double* prog = h->hPcg;
+  while (enq < maxIt) {
+    if (enq >= kRunAhead - 1) {
+      const int need = enq - kRunAhead + 1;
+      for (unsigned long long spins = 0; static_cast<int>(prog[0]) - 1 < need; ++spins) {
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+          // never spin forever on a mirror that cannot advance: a faulted stream reports here, and an idle stream
+          // whose iterations did not publish progress is a logic error
+          const hipError_t e = hipStreamQuery(s);
+          if (e != hipErrorNotReady) {
+            HIP_CHECK(e);
+            if (static_cast<int>(prog[0]) - 1 < need) throw std::runtime_error("PCG progress mirror stalled");
+          }
+        }
+      }
+      if (prog[1 + (need & 7)] != 0.0) break;
+    }
+    enqueueIteration(enq, enq > 0 ? 1 : 0);
+    ++enq;
+    if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
+      readScalars(c);
+      std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq - 1, h->hScal[S_RZ],
+                  h->hScal[S_RZPART], h->hScal[S_ALPHA], h->hScal[S_BETA], h->hScal[S_PQ], h->hScal[S_DONE]);
+    }
+  }
+  h->curPcgIter = -1;
+  if (tail) tail();  // follow-up work that does not need the host's decision rides on the same read-back
+  readScalars(c);    // drains the stream; S_DONE / S_ITERS are final
+  if (h->hScal[S_DONE] == 2.0) throw std::runtime_error("PCG produced NaN");
+  const int iters = static_cast<int>(h->hScal[S_ITERS]);
+  h->tDropFrom(firstTimerSlot, iters);
+  return iters;
+}
+
+// Scene-flow smoothness triplets of this problem (reference lib/PoseOptimizer.cpp:899): on when a weight is > 0.
+bool wantsTriplets(const cvd_opt_params& p, ProblemKind kind) {
+  return kind == PK_POSE_STEP && (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0);
+}
+void bindTriplets(Ctx& c, const cvd_opt_params& p, ProblemKind kind) {
+  cvd_handle* h = c.h;
+  c.trip = wantsTriplets(p, kind) && c.L.includeStatic;
+  if (!c.trip) return;
+  c.TT = TripletTable{h->dTNdc.p, h->dTDsrc.p, h->dTStatic.p, h->dTOff.p, h->dTCenter.p, h->dTSlot.p,
+                      static_cast<int>(h->tripActive.size()),
+                      static_cast<int>(p.smooth_loss_type),  // (CVD_SMOOTH_* == kSmooth*)
+                      std::sqrt(std::max(0.0, p.smooth_static_weight)), std::sqrt(std::max(0.0, p.smooth_dynamic_weight))};
+}
+void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, ProblemKind kind) {
+  const double t0 = nowSeconds();
+  if (h->F <= 0) throw std::runtime_error("no video set");
+  if (!h->poseParamsValid) posesToParams(h);
+  const std::vector<int> range = rangeOf(p, h->F);
+  struct WorkerGuard {  // (also on the exception paths)
+    cvd_handle* h;
+    ~WorkerGuard() { h->sideWorker.waitNoThrow(); }
+  } workerGuard{h};
+  static const bool dbgSetup = std::getenv("CVD_DEBUG_SETUP") != nullptr;  // development: where a solve's fixed cost goes
+  double tPhase = nowSeconds();
+  auto phase = [&](const char* what) {
+    if (!dbgSetup) return;
+    const double t = nowSeconds();
+    fprintf(stderr, "[setup] %-14s %8.1f us\n", what, (t - tPhase) * 1e6);
+    tPhase = t;
+  };
+  Ctx c;
+  c.h = h;
+  c.L = makeLayout(h, p, depthDeformReg, kind);
+  checkFrameBlock(static_cast<size_t>(c.L.B), "solve");
+  tapCounts(c.L, c.KD, c.KS);
+  phase("layout");
+  compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
+  phase("table");
+  refreshMedians(h);
+  phase("medians");
+  c.T = makeTable(h);
+  c.nItems = static_cast<int>(h->itemFa.size());
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
+  c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  c.boundDepth0 = (kind == PK_NORMALIZE && c.L.N > 0) ? 1 : 0;
+  bindTriplets(c, p, kind);
+  if (c.L.includeStatic) checkDenseScope(h, c.L, c.KS, c.trip);
+  c.cross = crossScope(h, c);
+  h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
+                kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
+  ensureBuffers(c);
+  phase("buffers");
+  buildMask(h, c.L, p, kind, range);
+  phase("mask");
+  uploadState(h, c.L, h->dX);
+  phase("upload");
+  hipStream_t s = h->stream;
+  HIP_CHECK(hipMemsetAsync(h->dDx.p, 0, c.n * sizeof(double), s));
+  HIP_CHECK(hipMemsetAsync(h->dR.p, 0, c.n * sizeof(double), s));
+  HIP_CHECK(hipMemsetAsync(h->dFail.p, 0, sizeof(int), s));
+
+  cvd_solve_summary sum{};
+  long long regBlocks = 0;
+  {
+    const long long nr = static_cast<long long>(range.size());
+    if (c.L.scaleRegSqrt > 0.0) regBlocks += nr * c.L.sregX * c.L.sregY;
+    if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
+    if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
+    if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+    if (c.L.positionRegSqrt > 0.0)
+      for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
+        regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
+  }
+  sum.num_residual_blocks = static_cast<int>((c.L.includeStatic ? h->numValid : 0) + (c.trip ? h->numValidTrip : 0) + regBlocks);
+
+  double tEval = 0.0, tLin = 0.0;
+  double te = nowSeconds();
+  double xCost = evalFull(c, h->dX.p);
+  tEval += nowSeconds() - te;
+  sum.initial_cost = xCost;
+  phase("first eval");
+
+  auto stats = [&]() {
+    enqueueStats(c);
+    readScalars(c);
+  };
+  HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+  stats();
+  double gmax = h->hScal[S_GMAX];
+  double xNorm = std::sqrt(h->hScal[S_XX]);
+  {
+    // number of active unknowns
+    std::vector<double> hd(c.n);
+    h->dHd.download(hd.data(), c.n, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    int na = 0;
+    for (double v : hd) na += (v != 0.0);
+    sum.num_parameters = na;
+  }
+  phase("stats");
+
+  double radius = Ceres::initial_radius;
+  double decrease = 2.0;
+  int invalid = 0, iteration = 0, termination = 1;
+  static const int kCoarseRebuildIters = []() {
+    const char* e = std::getenv("CVD_COARSE_REBUILD_ITERS");  // development knob
+    return e ? std::max(1, std::atoi(e)) : 16;
+  }();
+  int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
+  static const bool asyncCoarse = std::getenv("CVD_COARSE_SYNC") == nullptr;  // (development knob: rebuild in line)
+  bool coarsePending = false;  // a rebuild is running on the side stream
+  int factorUses = 0;          // PCG solves done with the factor in use
+  double lastRelChange = 1.0;  // relative cost change of the last accepted step
+  static const double asyncMaxChange = []() { const char* e = std::getenv("CVD_COARSE_ASYNC_MAX_CHANGE"); return e ? std::atof(e) : 1e-3; }();
+  bool freshFactor = false;    // the factor was installed right before this iteration's PCG
+  static const bool carryAcrossLevels = std::getenv("CVD_COARSE_CARRY_LEVELS") != nullptr;  // comparison knob
+  if (h->coarseOn && h->coarse.denseMode && h->coarse.denseReady && (h->coarse.denseForB == c.L.B || carryAcrossLevels)) {
+    // Dense level: the inverse left by the previous solve on this handle (the previous coarse-to-fine level, or the last
+    // optimisation of the same video) is a perfectly good SPD preconditioner to start with -- its ~6 ms rocSOLVER rebuild
+    // is not paid in line but started beside the first PCG and installed for the second LM iteration.
+    coarseAge = 0;
+    cgExcess = kCoarseRebuildIters;
+  }
+  // The dense level's rebuild (~6.5 ms of dependent rocSOLVER kernels) outlasts one PCG solve (~5 ms at 4140 pairs): it is
+  // installed after the SECOND solve that runs beside it (a fixed lag, not an event query: the iteration sequence stays
+  // a function of the data alone), so that the main stream never waits for it.
+  static const int kDenseInstallLag = []() { const char* e = std::getenv("CVD_COARSE_DENSE_LAG"); return e ? std::max(1, std::atoi(e)) : 2; }();
+  int pendingSolves = 0;  // PCG solves run since the pending rebuild was started
+  auto installPendingCoarse = [&]() {
+    if (!coarsePending) return;
+    if (h->coarse.denseMode && ++pendingSolves < kDenseInstallLag) return;
+    pendingSolves = 0;
+    h->sideWorker.wait();  // (the helper thread has finished enqueuing: normally long ago)
+    HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseDone, 0));  // (device-side wait: the host does not block)
+    std::swap(h->coarse.Wb.p, h->coarse.Wb2.p);
+    std::swap(h->coarse.Wb.n, h->coarse.Wb2.n);
+    std::swap(h->coarse.fail.p, h->coarse.fail2.p);
+    std::swap(h->coarse.fail.n, h->coarse.fail2.n);
+    std::swap(h->coarse.denseInv.p, h->coarse.denseInv2.p);
+    std::swap(h->coarse.denseInv.n, h->coarse.denseInv2.n);
+    coarsePending = false;
+    freshFactor = true;
+    cgExcess = 0;
+    coarseAge = 0;
+    factorUses = 0;
+    if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
+  };
+  bool scaleDone = false;
+  cvd_iteration_record r0{};
+  r0.cost = xCost;
+  r0.gradient_max_norm = gmax;
+  r0.trust_region_radius = radius;
+  r0.step_is_successful = 1;
+  h->records.push_back(r0);
+  if (h->opt.verbose)
+    printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n"
+           "%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", 0, xCost, 0.0, gmax, 0.0, 0.0, radius, 0);
+
+  if (sum.num_parameters == 0 || (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations)) {
+    termination = 0;
+  } else {
+    while (true) {
+      if (iteration >= p.max_iterations) { termination = 1; break; }
+      if (radius < Ceres::min_radius) { termination = 0; break; }
+      ++iteration;
+      cvd_iteration_record rec{};
+      rec.iteration = iteration;
+
+      double tl = nowSeconds();
+      hipLaunchKernelGGL(k_lm_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dHd.p, h->dScale.p,
+                         scaleDone ? 0 : 1, radius, h->dLam.p);
+      scaleDone = true;
+      // The block-Jacobi level follows lam every LM iteration; the coarse level is rebuilt on demand (below).
+      // (Lagging the block inverse as well is ~4% faster on the benchmark but makes the converged parameters
+      // visibly sensitive to rounding noise along the weak gauge directions.)
+      const bool willRefresh = !coarsePending &&
+                               (!h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters);
+      {
+        const int slot = h->tBegin(KC_INVERSE);
+        launchBlockInverse(c);
+        h->tEnd(slot);
+      }
+      if (h->coarseOn) {
+        // The coarse factor is only a preconditioner: any SPD approximation of Z^T A Z serves, so it is kept
+        // across LM iterations (lagged lam and linearisation point).  A rebuild costs about as much as
+        // kCoarseRebuildIters PCG iterations; it is done once the iterations spent beyond the count observed
+        // right after the last rebuild add up to that (coarse_level 2: rebuild every LM iteration).
+        // When a factor already exists the rebuild runs on the side stream, concurrently with this iteration's PCG
+        // (which keeps the old factor), and is installed for the next iteration: its ~0.8 ms leave the critical path.
+        // Its inputs (H, lam, x, mask, the table) are not written before the install below; the frame constants,
+        // which the main stream rewrites for the candidate point, are private to the side stream.
+        if (willRefresh) {
+          // (Only in the slowly changing regime -- the last accepted step changed the cost by less than 0.1 % --: while
+          // the iterates still move a lot a factor that is one iteration late costs more PCG iterations than the
+          // overlap saves, and there the rebuild stays in line.)
+          // (the dense level's rocSOLVER inversion is a chain of small kernels, ~6 ms at 2400 unknowns, that hardly
+          // occupies the device: always beside the PCG once a first inverse exists)
+          if ((lastRelChange < asyncMaxChange || (h->coarse.denseMode && coarseAge >= 0)) && asyncCoarse && h->opt.coarse_level != 2 && !h->dist()) {
+            h->dFc2.ensure(c.L.F);
+            HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
+            HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
+            launchCoarseSetup(c, h->dX.p, 1);
+            if (!h->coarse.denseMode) HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));  // (dense: recorded by the job)
+            coarsePending = true;
+            cgExcess = 0;
+          } else {
+            const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
+            launchCoarseSetup(c, h->dX.p);
+            h->tEnd(slot);
+            if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
+            coarseAge = 0;
+            cgExcess = 0;
+            freshFactor = true;
+            factorUses = 0;
+          }
+        } else {
+          ++coarseAge;
+        }
+      }
+      // one read-back for the PCG result, the step statistics and the cost of the candidate point (the
+      // candidate is formed speculatively; it is simply not used when the model decrease is invalid)
+      const int cgIters = runPcg(c, h->dX.p, [&]() {
+        enqueueStats(c);
+        hipLaunchKernelGGL(k_apply_step, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, c.boundDepth0, h->dX.p,
+                           h->dDx.p, h->dXc.p);
+        HIP_CHECK(hipGetLastError());
+        enqueueCost(c, h->dXc.p);
+      });
+      static const bool dbgCoarse = std::getenv("CVD_DEBUG_COARSE") != nullptr;
+      if (dbgCoarse && h->coarseOn && h->coarse.denseMode) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        int fl[2] = {-1, -1};
+        HIP_CHECK(hipMemcpy(&fl[0], h->coarse.fail.p, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&fl[1], h->coarse.fail2.p, 4, hipMemcpyDeviceToHost));
+        const size_t nn = static_cast<size_t>(c.L.F) * kCB;
+        std::vector<float> dg(nn);
+        HIP_CHECK(hipMemcpy2D(dg.data(), 4, h->coarse.denseInv.p, (nn + 1) * 4, 4, nn, hipMemcpyDeviceToHost));
+        double tr = 0.0;
+        for (float v : dg) tr += v;
+        std::vector<double> cc(nn);
+        HIP_CHECK(hipMemcpy(cc.data(), h->coarse.c.p, nn * 8, hipMemcpyDeviceToHost));
+        double cn = 0.0;
+        for (double v : cc) cn += v * v;
+        fprintf(stderr, "[coarse dbg] it %d pcg %d fail %d fail2 %d inv %p trace %.10e |c| %.6e pending %d graph %d/%p\n", iteration, cgIters, fl[0], fl[1],
+                (void*)h->coarse.denseInv.p, tr, std::sqrt(cn), coarsePending ? 1 : 0, h->coarse.denseGraphState, (void*)h->coarse.denseGraph);
+      }
+      // a rebuild still pending past this point (the dense level's fixed lag) must have read its inputs before the next
+      // evaluation rewrites them: the side stream competes with a main stream that is never idle, so "enqueued 4 ms ago"
+      // is not "executed" (device-side wait, satisfied long ago in the normal case)
+      if (coarsePending) HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseRead, 0));
+      if (freshFactor) cgAfterRefresh = cgIters;
+      else cgExcess += std::max(0, cgIters - cgAfterRefresh);
+      freshFactor = false;
+      ++factorUses;
+      installPendingCoarse();
+      tLin += nowSeconds() - tl;
+      rec.linear_iterations = cgIters;
+      sum.total_linear_iterations += cgIters;
+      const double dg = h->hScal[S_DG], dr = h->hScal[S_DR], dld = h->hScal[S_DLD], dd = h->hScal[S_DD];
+      const double modelCostChange = -0.5 * dg + 0.5 * dr + 0.5 * dld;
+      bool ok = std::isfinite(modelCostChange) && modelCostChange > 0.0 && std::isfinite(dd);
+      if (!ok) {
+        if (++invalid >= Ceres::max_consecutive_invalid) { termination = 2; break; }
+        radius /= decrease;
+        decrease *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        continue;
+      }
+      invalid = 0;
+      double candCost = h->hScal[S_COST];
+      if (!std::isfinite(candCost)) candCost = std::numeric_limits<double>::max();
+      const double stepNorm = std::sqrt(dd);
+      rec.step_norm = stepNorm;
+      rec.cost_change = xCost - candCost;
+      rec.relative_decrease = (xCost - candCost) / modelCostChange;
+      bool stop = false;
+      if (stepNorm <= Ceres::parameter_tolerance * (xNorm + Ceres::parameter_tolerance)) stop = true;
+      if (!stop && std::abs(xCost - candCost) <= Ceres::function_tolerance * xCost) stop = true;
+      if (h->opt.force_iterations) stop = false;
+      if (stop) {
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+        termination = 0;
+        break;
+      }
+      if (rec.relative_decrease > Ceres::min_relative_decrease) {
+        std::swap(h->dX.p, h->dXc.p);
+        std::swap(h->dX.n, h->dXc.n);
+        lastRelChange = std::abs(xCost - candCost) / std::max(std::abs(xCost), 1e-300);
+        xCost = candCost;
+        te = nowSeconds();
+        const double chk = evalFull(c, h->dX.p, true);
+        (void)chk;
+        tEval += nowSeconds() - te;
+        gmax = h->hScal[S_GMAX];
+        xNorm = std::sqrt(h->hScal[S_XX]);
+        ++sum.num_successful_steps;
+        rec.step_is_successful = 1;
+        const double q = rec.relative_decrease;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * q - 1.0, 3));
+        radius = std::min(Ceres::max_radius, radius);
+        decrease = 2.0;
+        rec.cost = xCost;
+        rec.gradient_max_norm = gmax;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+        if (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) { termination = 0; break; }
+      } else {
+        radius /= decrease;
+        decrease *= 2.0;
+        rec.cost = xCost;
+        rec.trust_region_radius = radius;
+        h->records.push_back(rec);
+        if (h->opt.verbose)
+          printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
+                 stepNorm, rec.relative_decrease, radius, cgIters);
+      }
+    }
+  }
+  phase("LM loop");
+  h->sideWorker.wait();  // (a rebuild started beside the last PCG: its enqueuing must not outlive this frame)
+  downloadState(h, c.L, h->dX);
+  phase("download");
+  h->tCollect();
+  sum.num_iterations = iteration;
+  sum.termination = termination;
+  sum.final_cost = xCost;
+  sum.total_seconds = nowSeconds() - t0;
+  sum.evaluate_seconds = tEval;
+  sum.linear_solve_seconds = tLin;
+  h->summary = sum;
+}
+void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, const double* pose7,
+                     double* cost, int32_t* nres, double* gradient, double* hdiag, double* hfull) {
+  if (pose7) {
+    h->poseParams.resize(h->F);
+    for (int f = 0; f < h->F; ++f)
+      for (int i = 0; i < 7; ++i) h->poseParams[f][i] = pose7[f * 7 + i];
+    h->poseParamsValid = true;
+  } else {
+    posesToParams(h);
+  }
+  const std::vector<int> range = rangeOf(p, h->F);
+  Ctx c;
+  c.h = h;
+  c.L = makeLayout(h, p, depthDeformReg, PK_POSE_STEP);
+  tapCounts(c.L, c.KD, c.KS);
+  compileTable(h, range, wantsTriplets(p, PK_POSE_STEP));
+  refreshMedians(h);
+  c.T = makeTable(h);
+  c.nItems = static_cast<int>(h->itemFa.size());
+  c.it = Items{h->dItemFa.p, h->dItemFb.p, h->dItemRange.p, h->dItemSlot.p, c.nItems};
+  c.n = static_cast<size_t>(c.L.F) * c.L.B;
+  bindTriplets(c, p, PK_POSE_STEP);
+  checkDenseScope(h, c.L, c.KS, c.trip);
+  c.cross = crossScope(h, c);
+  h->coarseOn = false;
+  ensureBuffers(c);
+  buildMask(h, c.L, p, PK_POSE_STEP, range);
+  uploadState(h, c.L, h->dX);
+  hipStream_t s = h->stream;
+  double cst;
+  if (!gradient && !hdiag && !hfull) {
+    cst = evalCost(c, h->dX.p);
+  } else {
+    cst = evalFull(c, h->dX.p);
+  }
+  if (cost) *cost = cst;
+  if (nres) {
+    long long regBlocks = 0;
+    const long long nr = static_cast<long long>(range.size());
+    if (c.L.scaleRegSqrt > 0.0) regBlocks += nr * c.L.sregX * c.L.sregY;
+    if (c.L.focalRegSqrt > 0.0) regBlocks += nr;
+    if (c.L.depthDeformW > 0.0 && c.L.depthType == CVD_DEPTH_GRID) regBlocks += nr;
+    if (c.L.spatialDeformW > 0.0 && c.L.nS > 0) regBlocks += nr;
+    if (c.L.positionRegSqrt > 0.0)
+      for (int k = c.L.firstFrame; k < c.L.lastFrame - 1; ++k)
+        regBlocks += (h->tableRange[k] && h->tableRange[k + 1] && h->tableRange[k + 2]) ? 1 : 0;
+    *nres = static_cast<int32_t>(h->numValid + (c.trip ? h->numValidTrip : 0) + regBlocks);
+  }
+  if (gradient) h->dG.download(gradient, c.n, s);
+  if (hdiag) {
+    if (h->dist()) {  // (parity hook: collect the owners' reduced blocks)
+      const size_t chunk = static_cast<size_t>(h->ownChunk()) * c.L.B * c.L.B;
+      NCCL_CHECK(ncclAllGather(h->dH.p + static_cast<size_t>(h->rank) * chunk, h->dH.p, chunk, ncclDouble, h->comm, s));
+    }
+    h->dH.download(hdiag, c.n * c.L.B, s);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (hfull) {
+    // column j of J^T J = matvec with the unit vector e_j (lam = 0)
+    std::vector<double> e(c.n, 0.0), col(c.n);
+    HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    prepareMatvec(c, h->dX.p);
+    for (size_t j = 0; j < c.n; ++j) {
+      e[j] = 1.0;
+      h->dZ.upload(e.data(), c.n, s);
+      launchMatvec(c, h->dX.p, h->dZ.p, h->dP0.p, h->dP1.p, 0, h->dLam.p, h->dQ.p);
+      h->dQ.download(col.data(), c.n, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (size_t i = 0; i < c.n; ++i) hfull[i * c.n + j] = col[i];
+      e[j] = 0.0;
+    }
+  }
+}
+
+}  // namespace cvd

@@ -42,7 +42,7 @@ struct TripletSample {
   Side<KD, KS> s[3];
 };
 
-__global__ void k_build_triplet_table(int W, int H, float invAspect, long long C, const float* __restrict__ loc6,
+inline __global__ void k_build_triplet_table(int W, int H, float invAspect, long long C, const float* __restrict__ loc6,
                                       const int* __restrict__ cgroup, const int* __restrict__ center, int F,
                                       const unsigned char* __restrict__ inRange, const float* __restrict__ depth,
                                       float2* __restrict__ ndc, float* __restrict__ dsrc,
@@ -259,7 +259,7 @@ __device__ __forceinline__ void evalTriplet(const Layout& L, int smoothType, con
 
 // ---- cost: one workgroup per triplet group, added to costFrame[centre] -----------------------------------------
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_cost_triplets(Layout L, TripletTable T, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_cost_triplets(Layout L, TripletTable T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc, double* __restrict__ costFrame) {
   __shared__ double red[4];
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_cost_triplets(Layout L, TripletTable T,
 // ---- assembly: one workgroup per frame; adds the triplet part of g_f and H_ff to the pair assembly's output ---
 // frameTripOff / frameTripList: per frame the (group << 2 | role) entries, role = position of the frame in the triplet.
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTable T, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTable T, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const int* __restrict__ ftOff, const int* __restrict__ ftList,
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k_assemble_triplets(Layout L, TripletTabl
 
 // ---- product: one workgroup per triplet group, three partial rows (one per frame) -------------------------------
 template <int KD, int KS>
-__global__ __launch_bounds__(256) void k_matvec_triplets(Layout L, TripletTable T, const double* __restrict__ x,
+inline __global__ __launch_bounds__(256) void k_matvec_triplets(Layout L, TripletTable T, const double* __restrict__ x,
                                                          const FrameConst* __restrict__ fc,
                                                          const double* __restrict__ mask, const double* __restrict__ z,
                                                          const double* __restrict__ pOld,
