@@ -17,10 +17,13 @@ converging solves of that level (when a solve converges early the start state is
     python bench.py --config 4 [--robust huber]      # BASELINE configs[4]: 1000 frames 640x384, 16x12 grid (one GPU)
     python bench.py --dense --steps 8 --warmup 1     # configs[2] dense: every masked pixel of 1766 pairs (146 M constraints)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...                     # no launcher: spawns the N ranks itself (re-exec under torch.distributed.run)
 
 N > 1 (default `--mode shard`): the SAME problem, frame pairs sharded across the ranks (robust_cvd_amd/sharding.py),
 regularisers by frame % N; the library exchanges over RCCL.  Total work is fixed => "strong" scaling,
 `value` = K iterations / max-over-ranks time.  `--mode replicas` gives every rank its own video (weak scaling).
+The ranks of the bench itself talk over gloo (barrier, the 128-byte RCCL id, the max over ranks): the library's
+communicator is the only RCCL user in the process.
 
 The JSON line also carries
   roofline     : dominant kernel k_matvec_pairs -- algorithmic HBM bytes per launch / average launch duration (HIP
@@ -93,6 +96,17 @@ def prepare(solver, video, params, pair_graph=None):
     upload = time.perf_counter() - t_up
     if pair_graph is not None:  # pair-sharded mode: the whole problem's frame graph for the coarse preconditioner level
         solver.set_pair_graph(pair_graph)
+    # the whole pipeline once, as pose_optimization.py runs it (normalizeDepth + every coarse-to-fine level): the FIRST run in
+    # this process, i.e. including every one-time cost (kernel loading, buffer growth)
+    solver.reset_depth_xforms(XformDesc.global_depth())
+    solver.reset_spatial_xforms(XformDesc.spatial())
+    torch.cuda.synchronize()
+    t_pipe = time.perf_counter()
+    solver.normalize_depth(params)
+    solver.pose_optimization(params)
+    pipeline_first = time.perf_counter() - t_pipe
+    pipe_summary = solver.summary()
+    solver.reset_poses(params.focal_long)
     solver.reset_depth_xforms(XformDesc.global_depth())
     solver.reset_spatial_xforms(XformDesc.spatial())
     solver.normalize_depth(params)
@@ -104,10 +118,11 @@ def prepare(solver, video, params, pair_graph=None):
         solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=first)
         first = False
     solver.grid_xform_split(XformDesc.grid_depth(*grids[-1]))
-    return upload, grids[-1]
+    return upload, grids[-1], {"seconds": pipeline_first, "lm_iterations": pipe_summary["num_iterations"],
+                               "pcg_iterations": pipe_summary["total_linear_iterations"], "final_cost": pipe_summary["final_cost"]}
 
 
-def cpu_baseline(params, video, grid, pose0, theta0, robust):
+def cpu_baseline(params, video, grid, pose0, theta0, robust, iterations=1):
     """Oracle (kind 'port': dual-number autodiff + Ceres-default LM + exact block-sparse Cholesky on the frame graph) on
     the SAME workload from the SAME state as the timed GPU iterations: one LM iteration, i.e. the initial Jacobian
     evaluation, one factorisation + solve, the candidate cost and (step accepted) the next Jacobian evaluation.  The
@@ -122,7 +137,7 @@ def cpu_baseline(params, video, grid, pose0, theta0, robust):
     for k in ("ctf_long", "ctf_short", "robustness"):
         setattr(p, k, getattr(params, k))
     p.num_threads = threads
-    p.max_iterations = 1
+    p.max_iterations = iterations
     o = Oracle()
     o.set_robust_loss(robust)
     synth.load_into(o, video, p.focal_long)
@@ -135,16 +150,16 @@ def cpu_baseline(params, video, grid, pose0, theta0, robust):
     wall = time.perf_counter() - t0
     s = o.summary()
     iters = s["num_iterations"]
-    assert iters == 1, s
+    assert iters == iterations, s
     return {
         "value": iters / s["total_seconds"], "unit": "LM iterations/s", "cores": threads, "kind": "port",
         "sample": (f"oracle on the full benchmarked workload ({len(video.pairs)} directed pairs, {video.num_constraints} constraints, "
-                   f"{video.num_frames} frames, {grid[0]}x{grid[1]} grid) from the same state as the timed GPU iterations: 1 LM "
-                   f"iteration = {s['total_seconds']:.2f} s ({s['evaluate_seconds']:.2f} s residual + Jacobian evaluation by dual "
+                   f"{video.num_frames} frames, {grid[0]}x{grid[1]} grid) from the same state as the timed GPU iterations: {iters} LM "
+                   f"iteration(s) = {s['total_seconds']:.2f} s ({s['evaluate_seconds']:.2f} s residual + Jacobian evaluation by dual "
                    f"numbers: two Jacobian passes and one cost pass; {s['linear_solve_seconds']:.2f} s exact block-sparse Cholesky "
                    f"step on the frame graph); not counted: {wall - s['total_seconds']:.1f} s problem construction; {threads} "
                    f"threads of {cores} host cores (reference default numThreads = 12); no scaling of any kind"),
-        "seconds_per_iteration": s["total_seconds"], "evaluate_seconds": s["evaluate_seconds"],
+        "seconds_per_iteration": s["total_seconds"] / max(1, iters), "evaluate_seconds": s["evaluate_seconds"],
         "linear_solve_seconds": s["linear_solve_seconds"], "problem_construction_seconds": wall - s["total_seconds"],
         # a solver with a free linear solve on top of the reference's autodiff evaluation
         "evaluation_only_it_per_s": iters / max(s["evaluate_seconds"], 1e-9),
@@ -152,7 +167,7 @@ def cpu_baseline(params, video, grid, pose0, theta0, robust):
     }
 
 
-def run_iterations(solver, params, pose0, theta0, count):
+def run_iterations(solver, params, pose0, theta0, count, records_out=None):
     done, cg, solves, last = 0, 0, 0, None
     while done < count:
         solver.set_pose_params(pose0)
@@ -161,6 +176,8 @@ def run_iterations(solver, params, pose0, theta0, count):
         solver.pose_optimization_step(params, params.depth_deform_reg_final, convert_poses=False)
         last = solver.summary()
         assert last["num_iterations"] >= 1, last  # (a solve from this start state never terminates at iteration 0)
+        if records_out is not None and solves == 0:
+            records_out.extend(solver.records())   # (after the timed region's first solve; read outside the hot loop's kernels)
         done += last["num_iterations"]
         cg += last["total_linear_iterations"]
         solves += 1
@@ -179,6 +196,24 @@ def matvec_bytes_per_launch(video, n_active, B):
         und[k] = max(und.get(k, 0), n)
     n_items = sum(-(-n // 768) for n in und.values())
     return 24.0 * n_active + n_items * (2 * 4 + 2) * B * 8.0
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU of this node."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -203,24 +238,36 @@ def main():
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the hot kernel (1 = all)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="development: no HIP-event timing of the hot kernel (roofline fields are then empty)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="N > 1: pair-sharded (strong) or one video per GPU (weak)")
+    ap.add_argument("--pcg-lockstep", action="store_true", help="profiling: no PCG run-ahead (clean per-launch counter averages)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N = 1: the oracle runs the SAME number of LM iterations as the last timed solve from the same state and the "
+                         "final costs must agree to 1e-6 (minutes of CPU time)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
+    # (the library first: its librccl.so.1 is the ROCm one it was built against; torch's bundled copy has the same soname)
+    from robust_cvd_amd import api, synth
+    from robust_cvd_amd.ctypes_types import OptParams
+    api.load_library()
     import torch
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    from robust_cvd_amd import api, synth
-    from robust_cvd_amd.ctypes_types import OptParams
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     cfg = CONFIGS[args.config]
     frames = args.frames or cfg["frames"]
@@ -264,8 +311,10 @@ def main():
                 full_video.pairs, full_video.offsets, full_video.loc, full_video.is_static, mine)
         if args.pcg_tol is not None:
             solver.set_options(pcg_relative_tolerance=args.pcg_tol)
+        if args.pcg_lockstep:
+            solver.set_options(pcg_lockstep=1)
         t_prep = time.perf_counter()
-        upload, grid = prepare(solver, video, params, pair_graph=all_pairs)
+        upload, grid, pipeline_first = prepare(solver, video, params, pair_graph=all_pairs)
         t_prep = time.perf_counter() - t_prep
         prep_summary = solver.summary()
         # State at the start of the final coarse-to-fine level: every measured LM iteration belongs to a real, naturally
@@ -290,20 +339,39 @@ def main():
             solver.set_kernel_timing(True, classes=classes, sample_every=sample_every)
         barrier()
         t0 = time.perf_counter()
-        done, total_cg, n_solves, summ = run_iterations(solver, params, pose0, theta0, steps)
+        records = []
+        done, total_cg, n_solves, summ = run_iterations(solver, params, pose0, theta0, steps, records)
         barrier()
         dt = time.perf_counter() - t0
         assert done == steps, (done, steps)
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         comm = solver.comm_times() if shard else None
+        ktimes = solver.kernel_times()
+        solver.set_kernel_timing(False)
+        # the whole pipeline again on the warm handle (steady state of a process that optimises video after video)
+        from robust_cvd_amd.ctypes_types import XformDesc
+        solver.reset_poses(params.focal_long)
+        solver.reset_depth_xforms(XformDesc.global_depth())
+        solver.reset_spatial_xforms(XformDesc.spatial())
+        params.max_iterations = 1000
+        barrier()
+        t_pipe = time.perf_counter()
+        solver.normalize_depth(params)
+        solver.pose_optimization(params)
+        barrier()
+        pipeline_warm = time.perf_counter() - t_pipe
+        pipe_sum = solver.summary()
+        pipeline = {"first_run_in_process_seconds": pipeline_first["seconds"], "seconds": pipeline_warm,
+                    "lm_iterations": pipe_sum["num_iterations"], "pcg_iterations": pipe_sum["total_linear_iterations"],
+                    "final_cost": pipe_sum["final_cost"],
+                    "what": "normalizeDepth + poseOptimization (all coarse-to-fine levels) on the benchmarked video, inputs resident"}
         equiv = None
         if shard and timing:
             # N = 1 equivalence: one full solve of the final level from the common start state, sharded over all ranks and,
             # on rank 0, unsharded on its own GPU -- the sharded mode must reproduce the single-GPU result
-            solver.set_kernel_timing(False)
             solver.set_pose_params(pose0)
             solver.set_xform_params(theta0)
             params.max_iterations = 1000
@@ -313,6 +381,8 @@ def main():
                 import numpy as np
                 single = api.Solver(local_rank)
                 single.set_options(robust_loss=robust)
+                if args.pcg_tol is not None:
+                    single.set_options(pcg_relative_tolerance=args.pcg_tol)
                 synth.load_into(single, full_video, params.focal_long)
                 from robust_cvd_amd.ctypes_types import XformDesc
                 single.reset_depth_xforms(XformDesc.grid_depth(*grid))
@@ -329,9 +399,10 @@ def main():
                          "theta_rel_diff": float(np.abs(sh_theta - single.get_xform_params()).max() / np.abs(sh_theta).max())}
                 single.close()
         return dict(video=full_video, local_video=video, solver=solver, full=full, dt=dt, total_cg=total_cg, n_solves=n_solves, summ=summ, cold=cold,
+                    pipeline=pipeline, records=records,
                     comm=comm, equivalence=equiv,
                     t_prep=t_prep, upload=upload, prep_summary=prep_summary, pose0=pose0, theta0=theta0, grid=grid,
-                    sample_every=sample_every, ktimes=solver.kernel_times(), n_active=solver.num_active_constraints(),
+                    sample_every=sample_every, ktimes=ktimes, n_active=solver.num_active_constraints(),
                     B=solver.block_size())
 
     m = measure(level, args.steps, args.warmup, timing=True, seed_offset=(0 if shard or world == 1 else rank))
@@ -433,9 +504,11 @@ def main():
             "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
             "last_timed_solve": {k: m["summ"][k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
                                                            "initial_cost", "final_cost", "termination")},
-            "cold_first_solve": ({**m["cold"], "note": "the warm-up solve: first solve of the final level on this handle (its coarse level is "
-                                  "built in line; the timed solves reuse the handle and start from the inverse the previous solve left)"}
+            # every solve builds its coarse level in line (one persistent kernel) and carries nothing over from the solve before:
+            # the timed solves ARE cold solves; the warm-up solve additionally pays first-launch costs of the final level's kernels
+            "cold_first_solve": ({**m["cold"], "note": "the warm-up solve = the first solve of the final level on this handle"}
                                  if m["cold"] else None),
+            "pipeline": m["pipeline"],
             "prepare_seconds": m["t_prep"],
             # host -> device hand-over of the inputs (depth maps F*H*W f32 + 16 B per constraint), once per solve sequence;
             # never part of `value` (inputs are resident when the timed region starts)
@@ -461,7 +534,24 @@ def main():
         m2.pop("solver").close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dense:
-            out["cpu_baseline"] = cpu_baseline(params, m["video"], m["grid"], m["pose0"], m["theta0"], robust)
+            cb = cpu_baseline(params, m["video"], m["grid"], m["pose0"], m["theta0"], robust)
+            # results, not only speed: the oracle's cost after ITS first LM iteration (exact sparse Cholesky step) against the
+            # GPU's after the first iteration of the first timed solve (PCG step to eta), same start state
+            recs = m["records"]
+            if len(recs) >= 2:
+                g1 = recs[1]["cost"]
+                cb["gpu_cost_after_iteration"] = g1
+                cb["cost_rel_diff_after_iteration"] = abs(g1 - cb["cost_after_iteration"]) / abs(cb["cost_after_iteration"])
+                if cb["cost_rel_diff_after_iteration"] > 1e-4:
+                    print(f"[bench] WARNING: GPU and oracle disagree after one LM iteration: {g1} vs {cb['cost_after_iteration']}", file=sys.stderr)
+            out["cpu_baseline"] = cb
+            if args.verify:
+                k = m["summ"]["num_iterations"]
+                cv = cpu_baseline(params, m["video"], m["grid"], m["pose0"], m["theta0"], robust, iterations=k)
+                rel = abs(cv["cost_after_iteration"] - m["summ"]["final_cost"]) / abs(cv["cost_after_iteration"])
+                out["verify"] = {"lm_iterations": k, "oracle_final_cost": cv["cost_after_iteration"], "gpu_final_cost": m["summ"]["final_cost"],
+                                 "rel_diff": rel, "oracle_seconds": cv["seconds_per_iteration"] * k}
+                assert rel <= 1e-6, out["verify"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

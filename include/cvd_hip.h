@@ -44,6 +44,17 @@ typedef struct cvd_solver_options {
                                     0 (default) ceres::CauchyLoss, what the reference hard-wires
                                     (lib/PoseOptimizer.cpp:1220); 1 ceres::HuberLoss, the stress variant of BASELINE.json
                                     configs[4] (no counterpart in the reference) */
+  /* ---- variant selection for tests / measurements (per handle; all default 0 = the product path) ---- */
+  int32_t force_sharded_path;     /* 1: a 1-rank communicator runs the multi-rank code path (owner chunks, exchange calls) */
+  int32_t dense_matrix_free;      /* dense mode: 1 = matrix-free products everywhere (no explicit cross blocks) */
+  int32_t block_inverse_variant;  /* 0: MFMA blocked sweep (default); 1: scalar register-resident sweep */
+  int32_t pcg_lockstep;           /* profiling: 1 = the host never enqueues a PCG iteration ahead of the convergence flag, so
+                                     that per-launch counter averages contain no early-exit launches */
+  int32_t coarse_dense_max_unknowns; /* the coarse level is inverted as ONE dense matrix up to this many unknowns
+                                     (8 per frame) when its sparse elimination is too expensive; default 4096 */
+  int32_t coarse_reserved;
+  int64_t coarse_update_budget;   /* 8x8 block updates of the sparse elimination beyond which the coarse level goes dense
+                                     (or, beyond coarse_dense_max_unknowns, is built on a sparsified graph); default 40000 */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -68,6 +79,11 @@ int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
  * counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
 void cvd_comm_unique_id(uint8_t* out128);
 int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
+/* Test backend of the exchange layer: the `world` ranks are handles of THIS process on ONE device, each driven by its
+ * own host thread; handles that pass the same `group_key` form one group.  RCCL refuses two ranks on one device, so
+ * this is how the multi-rank code paths run with world > 1 on a single-GPU box (tests/test_gpu_two_ranks.py).
+ * Host-synchronous; never used by a multi-GPU run. */
+int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, uint64_t group_key);
 /* Pair-sharded mode only: the frame pairs of the WHOLE problem (2 * num_pairs frame indices, direction and order
  * irrelevant), identical on every rank.  The coarse level of the preconditioner is built on this graph; without it
  * a multi-rank solve falls back to the block-Jacobi level alone.  Call after cvd_set_video. */
@@ -239,6 +255,9 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
  * n = 8 * frames (0 when the level was off), a_c = Z^T (J^T J + diag(lam)) Z as a dense n x n matrix assembled
  * from its blocks, a_c_inverse = the inverse the solver applied, failed = pivot failures of the factorisation.
  * Any output pointer may be NULL. */
+/* Test hook: the dense SPD inverse of the dense coarse level (cvd_dense_inverse.h) on one n x n f64 matrix (row-major,
+ * symmetric); inverse = n x n f32; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
+int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, float* inverse, int32_t* failed);
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 
 #ifdef __cplusplus

@@ -24,6 +24,13 @@ class SolverOptions(C.Structure):
         ("force_iterations", C.c_int32),
         ("coarse_level", C.c_int32),
         ("robust_loss", C.c_int32),
+        ("force_sharded_path", C.c_int32),
+        ("dense_matrix_free", C.c_int32),
+        ("block_inverse_variant", C.c_int32),
+        ("pcg_lockstep", C.c_int32),
+        ("coarse_dense_max_unknowns", C.c_int32),
+        ("coarse_reserved", C.c_int32),
+        ("coarse_update_budget", C.c_int64),
     ]
 
 
@@ -48,14 +55,14 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
-    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
+    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
     "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
     "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
-    "cvd_block_inverse_debug",
+    "cvd_block_inverse_debug", "cvd_dense_inverse_debug",
 ]
 
 KERNEL_CLASSES = ["evaluate_assemble", "matvec_pairs", "matvec_finish", "cg_update", "block_inverse", "cost"]
@@ -71,7 +78,7 @@ class Solver(Binding):
         self._options = None
 
     def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None,
-                    force_iterations=None, coarse_level=None, robust_loss=None):
+                    force_iterations=None, coarse_level=None, robust_loss=None, **variants):
         """Options persist per handle: only the fields given change (robust_loss: 0 Cauchy = reference, 1 Huber)."""
         o = self._options
         if o is None:
@@ -92,6 +99,10 @@ class Solver(Binding):
             o.coarse_level = int(coarse_level)
         if robust_loss is not None:
             o.robust_loss = int(robust_loss)
+        for k, v in variants.items():  # force_sharded_path, dense_matrix_free, block_inverse_variant, pcg_lockstep, coarse_*
+            if k not in dict(SolverOptions._fields_):
+                raise TypeError(f"unknown solver option {k!r}")
+            setattr(o, k, int(v))
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
 
     def set_robust_loss(self, kind):
@@ -107,6 +118,10 @@ class Solver(Binding):
     def comm_init(self, rank, world, unique_id: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._fn("comm_init")(self._h, C.c_int32(rank), C.c_int32(world), buf))
+
+    def comm_init_local_group(self, rank, world, group_key):
+        """Test backend of the exchange layer: `world` handles of this process (one host thread each) form a group."""
+        self._check(self._fn("comm_init_local_group")(self._h, C.c_int32(rank), C.c_int32(world), C.c_uint64(group_key)))
 
     def set_pair_graph(self, pair_frames):
         """Frame pairs of the whole problem (pair-sharded multi-GPU mode): same array on every rank."""
@@ -168,6 +183,19 @@ class Solver(Binding):
         fl = C.c_int32(0)
         self._check(self._fn("block_inverse_debug")(self._h, C.c_int32(n), C.c_int32(B), a.ctypes.data_as(C.POINTER(C.c_double)),
                                                     C.c_int32(variant), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(fl)))
+        return out, fl.value
+
+    def dense_inverse_debug(self, a):
+        """f32 inverse of one dense SPD f64 matrix [n, n] through the dense coarse level's kernel (k_dense_spd_inverse) and
+        its failure word (1: non-positive pivot, bit 30: barrier timeout)."""
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        n = a.shape[0]
+        assert a.shape == (n, n)
+        out = np.zeros((n, n), dtype=np.float32)
+        fl = C.c_int32(0)
+        self._check(self._fn("dense_inverse_debug")(self._h, C.c_int32(n), a.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(fl)))
         return out, fl.value
 
     def coarse_debug(self):

@@ -42,7 +42,7 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
     const size_t n = static_cast<size_t>(h->F) * Bmax;
     h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
     h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);
-    h->dQ.ensure(n); h->dHd.ensure(n); h->dMask.ensure(n);
+    h->dQ.ensure(n + static_cast<size_t>(h->F) * kCB + 8); h->dHd.ensure(n); h->dMask.ensure(n);
     h->dH.ensure(n * Bmax); h->dMinv.ensure(n * Bmax);
     // one undirected work item per ~768 constraints and pair: bounded by pairs + constraints / 768
     h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / (h->dense ? kDenseChunk : kListChunk)) + 1) * 2 * Bmax);
@@ -142,18 +142,15 @@ cvd_handle* cvd_create(int32_t device) {
     h->device = device;
     HIP_CHECK(hipDeviceGetAttribute(&h->numCU, hipDeviceAttributeMultiprocessorCount, device));
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    // side stream of the asynchronous coarse rebuild (created here: the first use of a new stream costs ~10 ms)
+    // side stream of the asynchronous rebuild of the sparse coarse level (created here: the first use of a new stream
+    // costs ~10 ms): a few small dependent kernels that must not queue behind the solver's device-filling launches
     {
-      // the side stream carries the coarse level's rebuild: long chains of SMALL kernels (rocSOLVER's panel factorisations
-      // run on one workgroup) that must not queue behind the solver's device-filling launches -- highest priority
       int prioLow = 0, prioHigh = 0;
       HIP_CHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-      static const bool flatPrio = std::getenv("CVD_SIDE_STREAM_FLAT") != nullptr;  // comparison knob
-      HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, flatPrio ? prioLow : prioHigh));
+      HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prioHigh));
     }
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseRead, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
     return h;
   } catch (const std::exception& e) {
@@ -207,8 +204,22 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->force_iterations = 0;
   o->coarse_level = 1;
   o->robust_loss = 0;
+  o->force_sharded_path = 0;
+  o->dense_matrix_free = 0;
+  o->block_inverse_variant = 0;
+  o->pcg_lockstep = 0;
+  o->coarse_dense_max_unknowns = 4096;
+  o->coarse_reserved = 0;
+  o->coarse_update_budget = 40000;
 }
-int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) { CVD_TRY(h, h->opt = *o); }
+int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
+  CVD_TRY(h, {
+    if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
+      h->tableValid = false;  // (the coarse level's variant is chosen when the table is compiled)
+    h->opt = *o;
+    h->distForced = h->world == 1 && (h->comm != nullptr || h->localGroup) && o->force_sharded_path != 0;
+  });
+}
 void cvd_comm_unique_id(uint8_t* out128) {
   ncclUniqueId id;
   std::memset(&id, 0, sizeof(id));
@@ -224,8 +235,20 @@ int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t*
     NCCL_CHECK(ncclCommInitRank(&h->comm, world, id, rank));
     h->rank = rank;
     h->world = world;
+    h->localGroup.reset();
     // test hook: with one rank the collectives are no-ops, but the sharded-mode kernels and call sequence still run
-    h->distForced = world == 1 && std::getenv("CVD_FORCE_DIST") != nullptr;
+    h->distForced = world == 1 && h->opt.force_sharded_path != 0;
+    h->tableValid = false;
+  });
+}
+int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, uint64_t group_key) {
+  CVD_TRY(h, {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("invalid rank / world size");
+    if (h->comm) { NCCL_CHECK(ncclCommDestroy(h->comm)); h->comm = nullptr; }
+    h->localGroup = joinLocalGroup(group_key, world);
+    h->rank = rank;
+    h->world = world;
+    h->distForced = world == 1 && h->opt.force_sharded_path != 0;
     h->tableValid = false;
   });
 }
@@ -651,6 +674,29 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
     dF.download(&fl, 1, s);
     HIP_CHECK(hipStreamSynchronize(s));
     if (failed) *failed = fl;
+  });
+}
+
+int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, float* inverse, int32_t* failed) {
+  CVD_TRY(h, {
+    if (n <= 0 || n > 8192) throw std::runtime_error("dense_inverse_debug: bad size");
+    const size_t nn = static_cast<size_t>(n) * n;
+    DevBuf<double> dA;
+    DevBuf<float> dM;
+    DevBuf<int> dF;
+    dA.ensure(nn);
+    dM.ensure(nn);
+    dF.ensure(2);
+    hipStream_t s = h->stream;
+    dA.upload(a, nn, s);
+    HIP_CHECK(hipMemsetAsync(dM.p, 0, nn * sizeof(float), s));
+    HIP_CHECK(hipMemsetAsync(dF.p, 0, 2 * sizeof(int), s));
+    launchDenseSpdInverse(h, n, dA.p, dM.p, dF.p, s, dF.p + 1);
+    int fl[2] = {0, 0};
+    dM.download(inverse, nn, s);
+    dF.download(fl, 2, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failed) *failed = fl[0];
   });
 }
 

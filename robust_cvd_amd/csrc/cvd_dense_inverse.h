@@ -1,0 +1,287 @@
+// cvd_dense_inverse.h -- inverse of ONE dense symmetric positive definite f64 matrix (the dense coarse level of the
+// two-level preconditioner: A_c = Z^T (J^T J + D) Z, 8 unknowns per frame, n = 2400 at 300 frames) on the f64 matrix cores
+// of the WHOLE device, as one persistent kernel.  Replaces rocSOLVER's potrf + potri (~250 dependent micro-kernels,
+// 6.5 ms) on the product path.
+//
+// Algorithm: the symmetric sweep operator of k_block_inverse_mfma (cvd_kernels.h), blocked with 16-wide pivot tiles, spread
+// over the device.  Sweeping pivot tile k (P = G_kk^-1) maps
+//     G_kk <- -P,   G_ik <- G_ik P,   G_kj <- P G_kj,   G_ij <- G_ij - G_ik P G_kj      (i, j != k)
+// and after all nT = n / 16 steps G = -A^-1.  n^3 flop like potrf + potri, but ONE uniform step: every tile of the lower
+// triangle receives a rank-16 update in every step, so the work is perfectly balanced and nothing shrinks.
+//
+// Layout: the lower-triangle 16x16 tiles live in MFMA ACCUMULATOR registers for the whole kernel (23 MB at n = 2400 =
+// 90 KB per CU).  The triangle is cut into S x S super-tiles, one per workgroup (8 waves, TPW = ceil(S^2 / 8) tiles per
+// wave): a workgroup's tiles then need only S row blocks and S column blocks of the pivot panel A(:, k).  S is the smallest
+// value for which the super-tiles fit one workgroup per CU (n = 2400: S = 7, 253 workgroups), so every workgroup is
+// resident and the grid barrier below cannot strand one.
+//
+// Per step k:  [grid barrier]  the 2 S panel tiles + (-P) come from the global panel buffer into LDS (agent-scope loads);
+// -T_m = A(m, k) (-P) for the workgroup's row blocks (4 MFMAs each);  every tile:  G_ij += (-T_i) A(j, k)^T (4 MFMAs),
+// tiles of block row / column k and the pivot tile are replaced;  then the owners of block column / row k + 1 PUBLISH
+// their freshly updated tiles as the next panel (write-through stores into the other half of the double buffer) and the
+// owner wave of tile (k + 1, k + 1) inverts it in-wave (invPivotStep: DPP / readlane / one bpermute per pivot) and
+// publishes -P.  One grid barrier per step; the dependent chain of a step is panel load -> T -> update of the next pivot
+// tile -> its 16 scalar pivots -> publish.
+//
+// Inter-workgroup visibility (cdna_hip_programming.md Guideline 16, recipe R1): payload stores are agent-scope relaxed
+// atomic stores (write-through, sc1), every storing wave drains vmcnt(0) before the workgroup arrives at the barrier
+// counter; payload loads are agent-scope relaxed atomic loads, so no fence is needed on either side.  The counter is
+// monotonic (step k waits for (k + 1) x gridDim arrivals) and is zeroed by the host before the launch; every spin is
+// bounded and a timeout raises `fail` and releases all workgroups.
+#pragma once
+
+#include "cvd_kernels.h"
+
+namespace cvd {
+
+constexpr int kDinvNW = 8;  // waves per workgroup
+
+__device__ __forceinline__ void dinvStore(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double dinvLoad(const double* p) {
+  return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+// Arrive at the monotonic counter (counter[0]) and wait for `target` arrivals.  Returns false when the kernel is being
+// abandoned (a workgroup timed out: counter[1] != 0, and bit 30 of *fail is set); uniform over the workgroup.
+__device__ __forceinline__ bool dinvGridBarrier(unsigned int* counter, unsigned int target, int* fail, int* ldsFlag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through payload stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 1023u) == 0 && __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (spins > (1u << 22)) {  // ~1 s: a workgroup is not resident or has left -- abandon, never hang the device
+        __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(fail, 0x40000000);
+        ok = 0;
+        break;
+      }
+    }
+    *ldsFlag = ok;
+  }
+  __syncthreads();
+  return *ldsFlag != 0;
+}
+
+// A: n x n f64 row-major (lda = n), symmetric, only the lower triangle is read.  out: n x n f32, the full symmetric
+// inverse.  A non-positive pivot (the coarse matrix is singular along the gauge directions up to the damping) leaves `out`
+// untouched: when *outValid says it holds an earlier inverse that one stays in use -- any SPD approximation serves the
+// preconditioner -- otherwise *fail = 1 (the level is switched off by its consumers).  Success sets *outValid = 1.
+// Bit 30 of *fail = barrier timeout.
+// panel: 2 x nT x 256 doubles, pinv: 2 x 256 doubles, barrier: three zeroed words (arrivals, abandon flag, bad pivots);
+// *fail zeroed by the host.  gridDim.x = nS (nS + 1) / 2.
+template <int TPW>
+inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n, int S, int nS, const double* __restrict__ A,
+                                                                           float* __restrict__ out, int* __restrict__ fail,
+                                                                           double* __restrict__ panel, double* __restrict__ pinv,
+                                                                           unsigned int* __restrict__ barrier, int* __restrict__ outValid) {
+  extern __shared__ __attribute__((aligned(16))) double dinvSmem[];
+  __shared__ int barrierOk;
+  const int nT = (n + kInvTS - 1) / kInvTS;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, r0 = lane >> 4;
+  // super-tile (SI >= SJ) of this workgroup
+  int SI = static_cast<int>((sqrtf(8.f * static_cast<float>(blockIdx.x) + 1.f) - 1.f) * 0.5f);
+  while ((SI + 1) * (SI + 2) / 2 <= static_cast<int>(blockIdx.x)) ++SI;
+  while (SI * (SI + 1) / 2 > static_cast<int>(blockIdx.x)) --SI;
+  const int SJ = static_cast<int>(blockIdx.x) - SI * (SI + 1) / 2;
+  const int rowBase = SI * S, colBase = SJ * S;
+  double* arow = dinvSmem;                      // [S] A(rowBase + m, k)
+  double* acol = arow + S * kInvTile;           // [S] A(colBase + m, k)
+  double* tneg = acol + S * kInvTile;           // [S] -T of the row blocks
+  double* tnegc = tneg + S * kInvTile;          // [S] -T of the column blocks (only when block row k lies in this super-tile)
+  double* piv = tnegc + S * kInvTile;           // -P
+  double* scratch = piv + kInvTile + w * kInvTile;  // one private tile per wave
+
+  cvd_d4 acc[TPW];
+  // tile slot s of this wave: (li, lj) within the super-tile, packed into ONE scalar register per slot (li | lj << 8, -1 =
+  // empty slot): four unpacked index arrays of TPW entries spill the SGPR file
+  int tCode[TPW];
+#define DINV_LI(s) (tCode[s] & 0xff)
+#define DINV_LJ(s) ((tCode[s] >> 8) & 0xff)
+#define DINV_I(s) (tCode[s] < 0 ? -1 : rowBase + DINV_LI(s))
+#define DINV_J(s) (tCode[s] < 0 ? -1 : colBase + DINV_LJ(s))
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    const int l = w + s * kDinvNW;
+    int li = l / S, lj = l - li * S;
+    int I = rowBase + li, J = colBase + lj;
+    int code = li | (lj << 8);
+    if (l >= S * S || I >= nT || J >= nT || I < J) { I = -1; J = -1; code = -1; }
+    tCode[s] = __builtin_amdgcn_readfirstlane(code);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kInvTS * (I < 0 ? 0 : I) + r0 + 4 * r, j = kInvTS * (J < 0 ? 0 : J) + c;
+      const double v = A[static_cast<size_t>(min(i, n - 1)) * n + min(j, n - 1)];
+      acc[s][r] = (I >= 0 && i < n && j < n) ? v : (i == j ? 1.0 : 0.0);
+    }
+  }
+
+  // Publishes what step `k` will read: block column k (tiles I > k), block row k transposed (tiles J < k), and -P of the
+  // pivot tile (k, k), inverted in-wave by its owner.
+  auto publish = [&](int k) {
+    double* pk = panel + static_cast<size_t>(k & 1) * nT * 256;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      if (DINV_I(s) < 0) continue;
+      if (DINV_J(s) == k && DINV_I(s) > k) {
+        double* dst = pk + static_cast<size_t>(DINV_I(s)) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dinvStore(dst + (r0 + 4 * r) * 16 + c, acc[s][r]);
+      } else if (DINV_I(s) == k && DINV_J(s) < k) {
+        // A(j, k) = A(k, j)^T: through the private LDS tile so that the global stores run along rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double* dst = pk + static_cast<size_t>(DINV_J(s)) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dinvStore(dst + (r0 + 4 * r) * 16 + c, scratch[c * kInvLd + r0 + 4 * r]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else if (DINV_I(s) == k && DINV_J(s) == k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int row = lane & 15, cg = lane >> 4;
+        double g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = scratch[row * kInvLd + 4 * cg + e];
+        int bad = 0;
+        invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
+        invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
+        invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
+        invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
+        invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
+        invPivotStep<15>(g, row, cg, bad);
+        if (bad && lane == 0) atomicAdd(barrier + 2, 1u);
+        double* dst = pinv + static_cast<size_t>(k & 1) * 256;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dinvStore(dst + row * 16 + 4 * cg + e, g[e]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+
+  publish(0);
+  const unsigned int nGroups = gridDim.x;
+  bool alive = true;
+  for (int k = 0; k < nT; ++k) {
+    if (!dinvGridBarrier(barrier, static_cast<unsigned int>(k + 1) * nGroups, fail, &barrierOk)) { alive = false; break; }
+    // ---- the panel tiles of this super-tile's row and column blocks, and -P, into LDS
+    {
+      const double* pk = panel + static_cast<size_t>(k & 1) * nT * 256;
+      const double* pp = pinv + static_cast<size_t>(k & 1) * 256;
+      const int total = (2 * S + 1) * 256;
+      for (int e = threadIdx.x; e < total; e += kDinvNW * 64) {
+        const int t = e >> 8, q = e & 255, rr = q >> 4, cc = q & 15;
+        if (t == 2 * S) {
+          piv[rr * kInvLd + cc] = dinvLoad(pp + q);
+        } else {
+          const int m = t < S ? t : t - S;
+          const int blk = (t < S ? rowBase : colBase) + m;
+          double v = 0.0;
+          if (blk < nT && blk != k) v = dinvLoad(pk + static_cast<size_t>(blk) * 256 + q);
+          (t < S ? arow : acol)[m * kInvTile + rr * kInvLd + cc] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- -T_m = A(m, k) (-P): the row blocks, and the column blocks when block row k lies in this super-tile
+    const bool hasRowK = k >= rowBase && k < rowBase + S;
+    for (int m = w; m < (hasRowK ? 2 * S : S); m += kDinvNW) {
+      const double* src = (m < S ? arow + m * kInvTile : acol + (m - S) * kInvTile);
+      cvd_d4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(src[c * kInvLd + 4 * kk + r0], piv[(4 * kk + r0) * kInvLd + c], t, 0, 0, 0);
+      double* dst = (m < S ? tneg + m * kInvTile : tnegc + (m - S) * kInvTile);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(r0 + 4 * r) * kInvLd + c] = t[r];
+    }
+    __syncthreads();
+    // ---- rank-16 update of every owned tile (tiles of block row / column k read zeroed panel slots; replaced below)
+    const int laneOp = c * kInvLd + r0;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      int oa = (tCode[s] < 0 ? 0 : DINV_LI(s)) * kInvTile, ob = (tCode[s] < 0 ? 0 : DINV_LJ(s)) * kInvTile;
+      asm volatile("" : "+s"(oa), "+s"(ob));
+      const double* ta = tneg + oa + laneOp;
+      const double* pb = acol + ob + laneOp;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4 * kk], pb[4 * kk], acc[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      if (DINV_I(s) < 0 || (DINV_I(s) != k && DINV_J(s) != k)) continue;
+      if (DINV_I(s) == k && DINV_J(s) == k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = piv[(r0 + 4 * r) * kInvLd + c];
+      } else if (DINV_J(s) == k) {  // i > k: G_ik <- T_i
+        int o = (tCode[s] < 0 ? 0 : DINV_LI(s)) * kInvTile;
+        asm volatile("" : "+s"(o));
+        const double* src = tneg + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -src[(r0 + 4 * r) * kInvLd + c];
+      } else {                  // j < k: G_kj <- T_j^T
+        int o = (tCode[s] < 0 ? 0 : DINV_LJ(s)) * kInvTile;
+        asm volatile("" : "+s"(o));
+        const double* src = tnegc + o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -src[c * kInvLd + r0 + 4 * r];
+      }
+    }
+    if (k + 1 < nT) publish(k + 1);
+  }
+  if (!alive) return;
+  // (every pivot was inverted before the last barrier: the count is final)
+  const unsigned int nBad = __hip_atomic_load(barrier + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nBad != 0u) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *outValid == 0) atomicOr(fail, 1);
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *outValid = 1;
+
+  // A^-1 = -G in f32: the tile as it lies and its mirror image (transposed through the private LDS tile)
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    if (DINV_I(s) < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kInvTS * DINV_I(s) + r0 + 4 * r, j = kInvTS * DINV_J(s) + c;
+      if (i < n && j < n) out[static_cast<size_t>(i) * n + j] = static_cast<float>(-acc[s][r]);
+    }
+    if (DINV_I(s) != DINV_J(s)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kInvTS * DINV_I(s) + c, j = kInvTS * DINV_J(s) + r0 + 4 * r;  // element (i, j) of the tile -> out[j][i]
+        const double v = scratch[c * kInvLd + r0 + 4 * r];
+        if (i < n && j < n) out[static_cast<size_t>(j) * n + i] = static_cast<float>(-v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+#undef DINV_LI
+#undef DINV_LJ
+#undef DINV_I
+#undef DINV_J
+
+}  // namespace cvd

@@ -71,7 +71,7 @@ void enqueueCost(Ctx& c, const double* x) {
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostItem.p, (c.L.includeStatic ? c.nItems : 0),
                      h->dCostFrame.p, c.L.F, h->dScal.p, S_COST);
   HIP_CHECK(hipGetLastError());
-  if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dScal.p + S_COST, h->dScal.p + S_COST, 1, ncclDouble, ncclSum, h->comm, s));
+  if (h->dist()) commAllReduce(h, h->dScal.p + S_COST, 1, CT_F64, s);
   h->tEnd(slot);
 }
 double evalCost(Ctx& c, const double* x) {
@@ -95,7 +95,7 @@ void enqueueStats(Ctx& c) {
 // Global level every pixel hits the one vertex -- same-address LDS atomics, 52 ms per assembly measured -- and the 8 x 8
 // problem is cheap to solve matrix-free.)
 bool crossScope(cvd_handle* h, const Ctx& c) {
-  const bool off = std::getenv("CVD_DENSE_MATRIX_FREE") != nullptr;  // comparison knob (read per solve: the tests toggle it)
+  const bool off = h->opt.dense_matrix_free != 0;  // comparison variant
   return h->dense && !off && !h->dist() && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
          c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
          c.L.B <= 256;
@@ -200,18 +200,18 @@ double evalFull(Ctx& c, const double* x, bool withStats) {
     // 1 / world of the inverse work per rank.
     const int ct = h->tBegin(KC_COMM_EVAL);
     const size_t chunkH = static_cast<size_t>(h->ownChunk()) * B * B;
-    NCCL_CHECK(ncclGroupStart());
-    NCCL_CHECK(ncclAllReduce(h->dG.p, h->dG.p, c.n, ncclDouble, ncclSum, h->comm, s));
-    NCCL_CHECK(ncclAllReduce(h->dCostFrame.p, h->dCostFrame.p, c.L.F, ncclDouble, ncclSum, h->comm, s));
-    NCCL_CHECK(ncclReduceScatter(h->dH.p, h->dH.p + static_cast<size_t>(h->rank) * chunkH, chunkH, ncclDouble, ncclSum, h->comm, s));
-    NCCL_CHECK(ncclGroupEnd());
+    commGroupStart(h);
+    commAllReduce(h, h->dG.p, c.n, CT_F64, s);
+    commAllReduce(h, h->dCostFrame.p, c.L.F, CT_F64, s);
+    commReduceScatter(h, h->dH.p, h->dH.p + static_cast<size_t>(h->rank) * chunkH, chunkH, CT_F64, s);
+    commGroupEnd(h);
     Layout own = c.L;
     own.F = h->ownCount();
     if (own.F > 0)
       hipLaunchKernelGGL(k_extract_diag, dim3((static_cast<size_t>(own.F) * B + 255) / 256), dim3(256), 0, s, own,
                          h->dH.p + static_cast<size_t>(h->ownFirst()) * B * B, h->dHd.p + static_cast<size_t>(h->ownFirst()) * B);
     const size_t chunkD = static_cast<size_t>(h->ownChunk()) * B;
-    NCCL_CHECK(ncclAllGather(h->dHd.p + static_cast<size_t>(h->rank) * chunkD, h->dHd.p, chunkD, ncclDouble, h->comm, s));
+    commAllGather(h, h->dHd.p + static_cast<size_t>(h->rank) * chunkD, h->dHd.p, chunkD, CT_F64, s);
     h->tEnd(ct);
   } else {
     hipLaunchKernelGGL(k_extract_diag, dim3((c.n + 255) / 256), dim3(256), 0, s, c.L, h->dH.p, h->dHd.p);

@@ -22,6 +22,7 @@
 #include <functional>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <stdexcept>
@@ -144,66 +145,6 @@ enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPD
                    // exchange steps of the pair-sharded multi-GPU mode (cvd_get_comm_times): timed whenever any class is
                    KC_COMM_EVAL = KC_COUNT, KC_COMM_PRODUCT, KC_COMM_COARSE, KC_TOTAL };
 
-// A helper host thread for work that is many small enqueues on the SIDE stream (the dense coarse level's rocSOLVER
-// inversion is ~250 kernel launches, ~2.3 ms of host time): submitted there, the main thread goes on enqueuing the
-// PCG and the device never idles between the block inverse and the first product.  One job at a time.
-class SideWorker {
- public:
-  ~SideWorker() {
-    {
-      std::lock_guard<std::mutex> g(m_);
-      quit_ = true;
-    }
-    cv_.notify_all();
-    if (th_.joinable()) th_.join();
-  }
-  void submit(std::function<void()> job) {
-    wait();
-    std::lock_guard<std::mutex> g(m_);
-    if (!th_.joinable()) th_ = std::thread([this]() { run(); });
-    job_ = std::move(job);
-    busy_ = true;
-    cv_.notify_all();
-  }
-  // returns once the submitted job has finished ENQUEUING; rethrows what it threw
-  void wait() {
-    std::unique_lock<std::mutex> g(m_);
-    cv_.wait(g, [this]() { return !busy_; });
-    if (err_) {
-      std::exception_ptr e = err_;
-      err_ = nullptr;
-      std::rethrow_exception(e);
-    }
-  }
-  void waitNoThrow() noexcept {
-    try { wait(); } catch (...) {}
-  }
-
- private:
-  void run() {
-    std::unique_lock<std::mutex> g(m_);
-    while (true) {
-      cv_.wait(g, [this]() { return quit_ || (busy_ && job_); });
-      if (quit_) return;
-      std::function<void()> job = std::move(job_);
-      job_ = nullptr;
-      g.unlock();
-      std::exception_ptr e;
-      try { job(); } catch (...) { e = std::current_exception(); }
-      g.lock();
-      err_ = e;
-      busy_ = false;
-      cv_.notify_all();
-    }
-  }
-  std::thread th_;
-  std::mutex m_;
-  std::condition_variable cv_;
-  std::function<void()> job_;
-  bool busy_ = false, quit_ = false;
-  std::exception_ptr err_;
-};
-
 struct Ceres {  // ceres::Solver::Options defaults used on this path
   static constexpr double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
   static constexpr double min_relative_decrease = 1e-3;
@@ -213,7 +154,16 @@ struct Ceres {  // ceres::Solver::Options defaults used on this path
 
 enum ProblemKind { PK_POSE_STEP = 0, PK_NORMALIZE = 1 };
 
+// exchange layer of the pair-sharded mode (cvd_comm.hip)
+enum CommType { CT_F64 = 0, CT_F32, CT_I32, CT_U64 };
+struct LocalGroup;  // test backend: the ranks are handles of one process on one device
+
 }  // namespace cvd
+
+namespace cvd {
+std::shared_ptr<LocalGroup> joinLocalGroup(unsigned long long key, int world);
+void leaveLocalGroup(LocalGroup& g);
+}
 
 using namespace cvd;
 
@@ -249,7 +199,10 @@ struct cvd_handle_t {
   // multi-GPU (pair-sharded): one RCCL communicator, this rank owns the regularisers of frames f % world == rank
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
-  bool distForced = false;  // test hook (CVD_FORCE_DIST with a 1-rank communicator): run the multi-rank code path
+  std::shared_ptr<LocalGroup> localGroup;  // test backend of the exchange layer (cvd_comm_init_local_group)
+  DevBuf<unsigned char> dCommStage;
+  DevBuf<const unsigned char*> dCommPtrs;
+  bool distForced = false;  // test hook (cvd_solver_options::force_sharded_path with a 1-rank communicator): run the multi-rank code path
   bool dist() const { return world > 1 || distForced; }
   // Frame ownership of the sharded mode: rank r owns the contiguous chunk [r Fc, (r + 1) Fc), Fc = ceil(F / world): it
   // receives the reduced H_ff of those frames (reduce-scatter), inverts them and all-gathers the f32 inverses.
@@ -284,13 +237,11 @@ struct cvd_handle_t {
   DevBuf<unsigned int> dAsmCount;
   int nAsmParts = 0, nAsmSlots = 0;
   int numCU = 256;
-  hipStream_t stream2 = nullptr;                       // side stream of the asynchronous coarse rebuild
-  hipStream_t streamCapture = nullptr;                 // capture-only stream of its hipGraph (never executes anything)
-  SideWorker sideWorker;                               // host thread that enqueues the dense rebuild there
+  hipStream_t stream2 = nullptr;                       // side stream of the asynchronous rebuild of the SPARSE coarse level
   rocblas_handle rbMain = nullptr;                     // main-stream handle (batched block inverses beyond B = 256)
   DevBuf<double> dInvScratch;
   DevBuf<int> dInvInfo;
-  hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr, evCoarseRead = nullptr;  // (evCoarseRead: the rebuild has consumed H, lam, x)
+  hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr;
   DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
   // explicit cross blocks of the dense mode (cvd_cross.h): undirected pairs, their rows, the blocks
@@ -342,21 +293,17 @@ struct cvd_handle_t {
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
     DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq, dropDiag;
     bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
-    // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f32 matrix, two buffers for the side-stream rebuild
+    // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f32 matrix, built in line by k_dense_spd_inverse
     bool denseMode = false;
-    hipGraphExec_t denseGraph = nullptr;  // the side stream's assemble + potrf + potri sequence (launchCoarseSetup)
-    std::array<const void*, 8> denseGraphKey{};
-    int denseGraphState = 0;              // 0 first direct call still to come, 1 capture allowed, -1 capture unsupported
-    int denseForB = 0;        // frame-block size of the problem that inverse was built for (a coarse-to-fine level)
-    bool denseReady = false;  // denseInv holds an inverse for this plan (possibly of an earlier solve: a usable, stale preconditioner)
-    DevBuf<double> denseA;
-    DevBuf<float> denseInv, denseInv2;
-    DevBuf<int> denseInfo;
-    rocblas_handle rb[2] = {nullptr, nullptr};  // [0] main stream, [1] side stream
+    int denseForB = 0;        // frame-block size of the problem the last build was for (a coarse-to-fine level)
+    bool denseReady = false;  // a build for this plan has been launched: denseValid says whether denseInv holds an inverse
+    DevBuf<double> denseA, densePanel;
+    DevBuf<float> denseInv;
+    DevBuf<int> denseValid;
     int nW = 0;
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
-    DevBuf<unsigned int> barrier;  // grid barrier of k_coarse_factor_mw
+    DevBuf<unsigned int> barrier;  // grid barrier words of k_coarse_factor_mw / k_dense_spd_inverse
     // second set of the factor's outputs: a rebuild runs on a side stream while the PCG of the same LM iteration
     // still uses the previous factor (launchCoarseSetup / the LM loop)
     DevBuf<double> Wb2;
@@ -400,20 +347,16 @@ struct cvd_handle_t {
   long long kcN[KC_TOTAL] = {0};
 
   ~cvd_handle_t() {
-    sideWorker.waitNoThrow();
     for (auto& e : evPool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (coarse.denseGraph) (void)hipGraphExecDestroy(coarse.denseGraph);
     if (rbMain) (void)rocblas_destroy_handle(rbMain);
-    for (auto& rbh : coarse.rb) if (rbh) (void)rocblas_destroy_handle(rbh);
     if (comm) (void)ncclCommDestroy(comm);
+    if (localGroup) leaveLocalGroup(*localGroup);
     if (hScal) (void)hipHostFree(hScal);
     for (auto& p : hStage) if (p) (void)hipHostFree(p);
     if (hPcg) (void)hipHostFree(hPcg);
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
-    if (evCoarseRead) (void)hipEventDestroy(evCoarseRead);
-    if (streamCapture) (void)hipStreamDestroy(streamCapture);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -549,6 +492,12 @@ void allowLds(K kernel, size_t bytes) {
 
 // ---- functions shared between the translation units (cvd_setup.hip, cvd_eval.hip, cvd_matvec.hip, cvd_precond.hip,
 // cvd_solve.hip, cvd_frontend.hip, cvd_api.hip) ---------------------------------------------------------------------
+// in-place sum / sum to the owner's chunk `rank` / concatenation in rank order; send may alias recv as RCCL's in-place forms do
+void commAllReduce(cvd_handle* h, void* buf, size_t count, CommType t, hipStream_t s);
+void commReduceScatter(cvd_handle* h, const void* send, void* recv, size_t recvCount, CommType t, hipStream_t s);
+void commAllGather(cvd_handle* h, const void* send, void* recv, size_t sendCount, CommType t, hipStream_t s);
+void commGroupStart(cvd_handle* h);
+void commGroupEnd(cvd_handle* h);
 std::vector<int> rangeOf(const cvd_opt_params& p, int F);
 void posesToParams(cvd_handle* h);
 void paramsToPoses(cvd_handle* h, const cvd_opt_params& params);
@@ -580,7 +529,9 @@ CrossPairs crossPairs(cvd_handle* h);
 void launchCrossAssemble(Ctx& c, const double* x);
 double evalFull(Ctx& c, const double* x, bool withStats = false);
 bool coarseFusedConsumers();
-bool coarseDenseFused();
+bool fusedExchange(cvd_handle* h, bool withCoarse);
+size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, float* out, int* fail, hipStream_t s, int* outValid);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);
 void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta, const double* lam,

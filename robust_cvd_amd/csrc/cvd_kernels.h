@@ -1328,7 +1328,7 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nRows, RegCache rc, CoarseView V,
                                                        double* __restrict__ qc, CoarseColumns cc,
-                                                       const double* __restrict__ Hdiag) {
+                                                       const double* __restrict__ Hdiag, double* __restrict__ pqOut) {
   // Hdiag != nullptr (explicit cross blocks, cvd_cross.h): the partial rows hold the OFF-diagonal blocks' products only;
   // the frame-diagonal part, regularisers included, is H_ff p_f with the assembled H_ff.
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
@@ -1448,9 +1448,11 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     atomicAdd(&qf[tid], acc);
   }
   __syncthreads();
-  // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; in both cases q is
-  // all-reduced afterwards and p.q / alpha are formed by k_dot_pq on the reduced vector.
-  if (distMode) {
+  // distMode (pair-sharded multi-GPU): 1 = this rank adds the damping term, 2 = it does not; q is all-reduced afterwards.
+  // pqOut == nullptr: p.q / alpha are formed by k_dot_pq on the reduced vector.  pqOut != nullptr (FUSED exchange): the
+  // product, its restriction Z^T q and p.q are all linear in q, so this rank's shares of the three travel in ONE
+  // all-reduce ([q | Z^T q | p.q] contiguous) and k_cg_update forms alpha from the reduced p.q itself.
+  if (distMode && pqOut == nullptr) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int i = tid + e * 256;
@@ -1464,7 +1466,7 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     const int i = tid + e * 256;
     if (i >= B) continue;
     const double pv = pvReg[e];
-    const double qv = qf[i] * vm[e] + vlam[e] * pv;
+    const double qv = qf[i] * vm[e] + (distMode == 2 ? 0.0 : vlam[e] * pv);
     q[base + i] = qv;
     qf[i] = qv;
     dot += pv * qv;
@@ -1482,8 +1484,12 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
   if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
     const double pq = blockSumArray(fdot, L.F, red);
     if (tid == 0) {
-      scal[S_PQ] = pq;
-      scal[S_ALPHA] = scal[S_RZ] / pq;
+      if (pqOut != nullptr) {
+        *pqOut = pq;  // (this rank's share: reduced with q)
+      } else {
+        scal[S_PQ] = pq;
+        scal[S_ALPHA] = scal[S_RZ] / pq;
+      }
     }
   }
 }
@@ -1564,7 +1570,8 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
                                                     double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
                                                     double tol2, double* __restrict__ rc,
                                                     const unsigned char* __restrict__ modeActive,
-                                                    double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds) {
+                                                    double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
+                                                    const double* __restrict__ pqReduced) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const double sDone = init ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
   const int B = L.B;
@@ -1579,7 +1586,9 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
-  const double alpha = init ? 0.0 : scal[S_ALPHA];
+  // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
+  // last workgroup to arrive, i.e. after every workgroup has read it here)
+  const double alpha = init ? 0.0 : (pqReduced != nullptr ? scal[S_RZ] / *pqReduced : scal[S_ALPHA]);
   if (f >= L.F) {
     // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
     // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z

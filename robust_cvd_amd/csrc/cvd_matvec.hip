@@ -4,13 +4,12 @@
 namespace cvd {
 
 bool coarseFusedConsumers() {
-  static const bool v = std::getenv("CVD_COARSE_FUSED") != nullptr;  // experiment: c_f formed inside the consumers
-  return v;
+  return false;  // (c_f formed inside the consumers: measured slower than the k_coarse_apply_wt launch; kept as a code path of CoarseView)
 }
-bool coarseDenseFused() {
-  static const bool v = std::getenv("CVD_COARSE_DENSE_UNFUSED") == nullptr;  // comparison knob: separate k_coarse_dense_apply launch
-  return v;
-}
+// Pair-sharded mode: the product's exchange carries [q | Z^T q | p.q] in one all-reduce unless the SPARSE coarse level is on
+// (its column products need the reduced Z^T q: k_dot_pq).  Layout: [q (F B) | Z^T q (8 F, dense coarse level only) | p.q].
+bool fusedExchange(cvd_handle* h, bool withCoarse) { return !withCoarse || h->coarse.denseMode; }
+size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse) { return c.n + (withDenseCoarse ? static_cast<size_t>(c.L.F) * kCB : 0); }
 CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
   if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto& C = h->coarse;
@@ -77,8 +76,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
       // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When the items need more than one
       // round at 256 threads but fit into one round of 128-thread workgroups the launch has no ragged second round
       // (benchmark: 883 items, 44 -> 39.5 us).
-      static const int forcedNT = []() { const char* e = std::getenv("CVD_PAIRS_NT"); return e ? std::atoi(e) : 0; }();
-      const int nt = forcedNT ? forcedNT : (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
+      const int nt = (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
       // SPEC = 1: the default pipeline's variant (one value parameter, ReproDisparity, Cauchy) fixed at compile time
       const bool spec = c.L.N == 1 && c.L.lossType == CVD_STATIC_REPRO_DISPARITY && c.L.robustKind == 0;
 #define CVD_LAUNCH_PAIRS_FAST_S(NTV, SPECV)                                                                              \
@@ -141,7 +139,13 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
     const bool fusedCoarse = withCoarse && !h->coarse.denseMode;
-    const bool denseFused = withCoarse && h->coarse.denseMode && coarseDenseFused() && !h->dist();  // (needs Z^T q: DenseStep)
+    const bool denseFused = withCoarse && h->coarse.denseMode;  // (needs Z^T q: DenseStep)
+    // pair-sharded mode, FUSED exchange (dense coarse level or none): this rank's q, Z^T q and p.q lie contiguously behind
+    // q and travel in one all-reduce; k_cg_update forms alpha from the reduced p.q.  With the sparse coarse level the
+    // column products need the REDUCED Z^T q: q alone is exchanged and k_dot_pq finishes the product.
+    const bool fusedX = h->dist() && fusedExchange(h, withCoarse);
+    double* qcX = q + c.n;
+    double* pqX = q + exchangeOffsetPq(c, denseFused);
     const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, fusedCoarse ? h->coarse.Wb.p : nullptr,
                            h->coarse.wq.p};
     const int slot = h->tBegin(KC_MATVEC_FINISH);
@@ -150,14 +154,19 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
                          h->dMedian.p, h->dRegOwner.p, h->dInRange.p, c.cross ? h->dXFiOff.p : h->dFiOff.p, h->dFiList.p,
                          h->dQPart.p, z, pOld, pNew, h->dScal.p, h->dCounters.p, useBeta, q, h->dFdot.p,
                          h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.cross ? static_cast<int>(h->xFa.size()) * 2 : h->qRows,
-                         h->regCache, cF, ((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr, cc,
-                         c.cross ? h->dH.p : nullptr);
+                         h->regCache, cF,
+                         fusedX ? (denseFused ? qcX : nullptr) : (((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr), cc,
+                         c.cross ? h->dH.p : nullptr, fusedX ? pqX : nullptr);
     });
     HIP_CHECK(hipGetLastError());
-    if (h->dist()) {
+    if (fusedX) {
+      const int ct = h->tBegin(KC_COMM_PRODUCT);
+      commAllReduce(h, q, exchangeOffsetPq(c, denseFused) + 1, CT_F64, s);
+      h->tEnd(ct);
+    } else if (h->dist()) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
       const int ct = h->tBegin(KC_COMM_PRODUCT);
-      NCCL_CHECK(ncclAllReduce(q, q, c.n, ncclDouble, ncclSum, h->comm, s));
+      commAllReduce(h, q, c.n, CT_F64, s);
       h->tEnd(ct);
       hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
                          withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc);

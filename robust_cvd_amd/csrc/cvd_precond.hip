@@ -1,5 +1,6 @@
 // cvd_precond.hip -- the two-level preconditioner: per-frame block inverses and the pose-graph coarse level.
 #include "cvd_host.h"
+#include "cvd_dense_inverse.h"
 
 namespace cvd {
 
@@ -62,8 +63,7 @@ void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, con
   // 6x6 tiles on 512 threads when the 4x4 tiling needs more than 512: two workgroups share a CU (half the threads, the
   // same 128 registers), so that e.g. 300 frames run in one round instead of 256 + 44 (B = 177: 465 tiles).
   const int nb6 = (B + 5) / 6, nTiles6 = nb6 * (nb6 + 1) / 2;
-  static const bool noTs6 = std::getenv("CVD_BLOCK_INVERSE_TS4") != nullptr;  // development knob
-  if (variant == 1 && !noTs6 && nTiles > 512 && nTiles6 <= 512) {
+  if (variant == 1 && nTiles > 512 && nTiles6 <= 512) {
     hipLaunchKernelGGL((k_block_inverse_sweep<1, 6>), dim3(L.F), dim3(((nTiles6 + 63) / 64) * 64), 0, s, L, dH, dLam, dMinv,
                        dFail);
     HIP_CHECK(hipGetLastError());
@@ -88,8 +88,7 @@ void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, con
 
 void launchBlockInverse(Ctx& c) {
   cvd_handle* h = c.h;
-  static const bool scalarSweep = std::getenv("CVD_BLOCK_INVERSE_SWEEP") != nullptr;  // comparison: the scalar sweep
-  const int variant = h->forceGeneric ? 2 : (scalarSweep ? 1 : 0);
+  const int variant = h->forceGeneric ? 2 : (h->opt.block_inverse_variant == 1 ? 1 : 0);
   if (!h->dist()) {
     launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, variant);
     return;
@@ -104,9 +103,42 @@ void launchBlockInverse(Ctx& c) {
     launchBlockInverseRaw(h, own, h->dH.p + f0 * B * B, h->dLam.p + f0 * B, h->dMinv.p + f0 * B * B, h->dFail.p, variant);
   const int ct = h->tBegin(KC_COMM_EVAL);
   const size_t chunk = static_cast<size_t>(h->ownChunk()) * B * B;
-  NCCL_CHECK(ncclAllGather(h->dMinv.p + static_cast<size_t>(h->rank) * chunk, h->dMinv.p, chunk, ncclFloat, h->comm, h->stream));
-  NCCL_CHECK(ncclAllReduce(h->dFail.p, h->dFail.p, 1, ncclInt, ncclSum, h->comm, h->stream));
+  commAllGather(h, h->dMinv.p + static_cast<size_t>(h->rank) * chunk, h->dMinv.p, chunk, CT_F32, h->stream);
+  commAllReduce(h, h->dFail.p, 1, CT_I32, h->stream);
   h->tEnd(ct);
+}
+
+// out (f32, n x n) = A^-1 for one dense SPD f64 matrix (cvd_dense_inverse.h): one persistent launch, one workgroup per
+// super-tile of S x S 16-wide tiles, S the smallest for which the grid fits one workgroup per CU.
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, float* out, int* fail, hipStream_t s, int* outValid) {
+  auto& C = h->coarse;
+  const int nT = (n + kInvTS - 1) / kInvTS;
+  int S = 1;
+  auto groups = [&](int sv) { const int nS = (nT + sv - 1) / sv; return nS * (nS + 1) / 2; };
+  while (groups(S) > h->numCU) ++S;
+  const int nS = (nT + S - 1) / S;
+  const int tpw = (S * S + kDinvNW - 1) / kDinvNW;
+  const size_t lds = static_cast<size_t>(4 * S + 1 + kDinvNW) * kInvTile * sizeof(double);
+  if (tpw > 25 || lds > kMaxLds) throw std::runtime_error(fmt("dense coarse level: %d unknowns are too many for the dense inverse", n));
+  C.densePanel.ensure(static_cast<size_t>(2) * nT * 256 + 2 * 256);
+  C.barrier.ensure(4);
+  HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, 4 * sizeof(unsigned int), s));
+  double* panel = C.densePanel.p;
+  double* pinv = panel + static_cast<size_t>(2) * nT * 256;
+#define CVD_LAUNCH_DINV(TPWV)                                                                                            \
+  do {                                                                                                                   \
+    allowLds((k_dense_spd_inverse<TPWV>), lds);                                                                          \
+    hipLaunchKernelGGL((k_dense_spd_inverse<TPWV>), dim3(groups(S)), dim3(kDinvNW * 64), lds, s, n, S, nS, A, out, fail, panel, \
+                       pinv, C.barrier.p, outValid);                                                                    \
+  } while (0)
+  if (tpw <= 2) CVD_LAUNCH_DINV(2);
+  else if (tpw <= 5) CVD_LAUNCH_DINV(5);
+  else if (tpw <= 8) CVD_LAUNCH_DINV(8);
+  else if (tpw <= 13) CVD_LAUNCH_DINV(13);
+  else if (tpw <= 18) CVD_LAUNCH_DINV(18);
+  else CVD_LAUNCH_DINV(25);
+#undef CVD_LAUNCH_DINV
+  HIP_CHECK(hipGetLastError());
 }
 
 // Coarse level for the current (H, lam): diagonal blocks, block-sparse Cholesky, explicit inverse (cvd_coarse.h).
@@ -128,14 +160,12 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     if (C.sparsified) HIP_CHECK(hipMemsetAsync(C.dropDiag.p, 0, static_cast<size_t>(c.L.F) * kCBB * sizeof(double), s));
     const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
-    static const bool crossEdgesOff = std::getenv("CVD_COARSE_EDGES_MATRIX_FREE") != nullptr;  // comparison knob
-    if (c.cross && !C.sparsified && !crossEdgesOff) {
+    if (c.cross && !C.sparsified) {
       // explicit cross blocks exist for this linearisation point: the edge blocks are reductions of them
       hipLaunchKernelGGL(k_coarse_edges_cross, dim3(static_cast<unsigned>(h->xFa.size())), dim3(256), 0, s, c.L, crossPairs(h),
                          h->dXBlocks.p, h->dXPairEdge.p, C.edges.p);
     } else if (c.nItems > 0) {
-      static const bool genericEdges = std::getenv("CVD_COARSE_EDGES_GENERIC") != nullptr;  // comparison knob
-      const bool fast = !h->forceGeneric && !genericEdges && c.KS == 0 && fastLoss(c.L) &&
+      const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L) &&
                         c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
       if (fast) {
         CVD_DISPATCH_KD(c.KD, {
@@ -160,15 +190,15 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     HIP_CHECK(hipGetLastError());
     if (h->dist()) {
       const int ct = h->tBegin(KC_COMM_COARSE);
-      NCCL_CHECK(ncclAllReduce(C.edges.p, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, ncclDouble, ncclSum, h->comm, s));
+      commAllReduce(h, C.edges.p, static_cast<size_t>(C.nEdges) * kCBB, CT_F64, s);
       if (C.sparsified)
-        NCCL_CHECK(ncclAllReduce(C.dropDiag.p, C.dropDiag.p, static_cast<size_t>(c.L.F) * kCBB, ncclDouble, ncclSum, h->comm, s));
+        commAllReduce(h, C.dropDiag.p, static_cast<size_t>(c.L.F) * kCBB, CT_F64, s);
       h->tEnd(ct);
     }
   }
   // (side stream: the factor will serve the NEXT iteration, whose damping is most likely a third of this one's --
   // the trust region triples after a good step)
-  static const double lamPredict = []() { const char* e = std::getenv("CVD_COARSE_LAM_PREDICT"); return e ? std::atof(e) : 1.0 / 3.0; }();
+  constexpr double lamPredict = 1.0 / 3.0;
   hipLaunchKernelGGL(k_coarse_diag, dim3(c.L.F), dim3(256), 0, s, c.L, h->dH.p, h->dLam.p, h->dMask.p, C.diag.p,
                      C.modeActive.p, side ? lamPredict : 1.0, C.sparsified ? C.dropDiag.p : nullptr);
   if (h->dist()) {
@@ -176,112 +206,34 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     // blocks (the mode flags depend on the mask alone and are right everywhere)
     const int ct = h->tBegin(KC_COMM_COARSE);
     const size_t chunk = static_cast<size_t>(h->ownChunk()) * kCBB;
-    NCCL_CHECK(ncclAllGather(C.diag.p + static_cast<size_t>(h->rank) * chunk, C.diag.p, chunk, ncclDouble, h->comm, s));
+    commAllGather(h, C.diag.p + static_cast<size_t>(h->rank) * chunk, C.diag.p, chunk, CT_F64, s);
     h->tEnd(ct);
   }
   // (everything below works on the coarse level's own buffers: the solver's H, lam, x have been consumed)
-  if (side) HIP_CHECK(hipEventRecord(h->evCoarseRead, s));
   if (C.denseMode) {
+    // dense level: A_c assembled from the same blocks and inverted by ONE persistent kernel on the f64 matrix cores
+    // (cvd_dense_inverse.h), f32 inverse out; in line on the solver's stream
+    if (side) throw std::logic_error("the dense coarse level is built in line");
     const int n = c.L.F * kCB;
     C.denseA.ensure(static_cast<size_t>(n) * n);
     C.denseInv.ensure(static_cast<size_t>(n) * n);
-    C.denseInv2.ensure(static_cast<size_t>(n) * n);
-    C.denseInfo.ensure(2);
-    const int F = c.L.F, nEdges = C.nEdges;
-    // (everything the job needs by value: it may still be enqueuing while the caller's frame moves on)
-    auto job = [h, s, side, n, F, nEdges, failOut]() {
-      auto& C = h->coarse;
-      HIP_CHECK(hipSetDevice(h->device));
-      if (!C.rb[side]) {
-        if (rocblas_create_handle(&C.rb[side]) != rocblas_status_success) throw std::runtime_error("rocblas_create_handle failed");
-        if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
-      }
-      // memsets + assembly + potrf + potri: ~250 small launches, ~2.3 ms of host time when issued one by one.  Beside the
-      // solver (side stream) the sequence is captured ONCE into a hipGraph and replayed with a single launch; the graph is
-      // keyed on every pointer / size baked into its nodes.  A capture that rocSOLVER does not support falls back to direct
-      // calls for good (state -1).
-      auto direct = [&](hipStream_t st) {
-        HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), st));
-        HIP_CHECK(hipMemsetAsync(C.denseInfo.p, 0, 2 * sizeof(int), st));
-        hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(F + nEdges), dim3(64), 0, st, F, nEdges, C.diag.p, C.edges.p,
-                           C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
-        HIP_CHECK(hipGetLastError());
-        // A_c = L L^T, A_c^-1 (rocSOLVER; symmetric input, so the row-major array serves as its own column-major view)
-        if (rocsolver_dpotrf(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p) != rocblas_status_success)
-          throw std::runtime_error("rocsolver_dpotrf failed");
-        if (rocsolver_dpotri(C.rb[side], rocblas_fill_lower, n, C.denseA.p, n, C.denseInfo.p + 1) != rocblas_status_success)
-          throw std::runtime_error("rocsolver_dpotri failed");
-      };
-      static const bool graphOff = std::getenv("CVD_COARSE_NO_GRAPH") != nullptr;  // comparison knob
-      const std::array<const void*, 8> key{C.denseA.p, C.denseInfo.p, C.diag.p, C.edges.p, C.edgeFa.p, C.modeActive.p,
-                                           reinterpret_cast<const void*>(static_cast<size_t>(n)),
-                                           reinterpret_cast<const void*>(static_cast<size_t>(nEdges))};
-      if (!side || graphOff || C.denseGraphState < 0) {
-        direct(s);
-      } else if (C.denseGraphState == 0) {
-        direct(s);  // (first call on this handle: rocBLAS sizes its workspace, loads its kernels -- not capturable)
-        C.denseGraphState = 1;
-      } else {
-        if (C.denseGraph != nullptr && C.denseGraphKey != key) {
-          (void)hipGraphExecDestroy(C.denseGraph);
-          C.denseGraph = nullptr;
-        }
-        if (C.denseGraph == nullptr) {
-          // Captured on a PRIVATE stream that nothing else ever touches: while the side stream itself were capturing, the
-          // main thread's waits on events recorded there (evCoarseRead, evCoarseDone) would be capture-isolation errors --
-          // it reaches them during the capture whenever the PCG beside it is short (eta = 0.1: 15 iterations).
-          if (!h->streamCapture) HIP_CHECK(hipStreamCreateWithFlags(&h->streamCapture, hipStreamNonBlocking));
-          hipStream_t sc = h->streamCapture;
-          hipGraph_t g = nullptr;
-          bool ok = rocblas_set_stream(C.rb[side], sc) == rocblas_status_success &&
-                    hipStreamBeginCapture(sc, hipStreamCaptureModeThreadLocal) == hipSuccess;
-          if (ok) {
-            try { direct(sc); } catch (...) { ok = false; }
-            if (hipStreamEndCapture(sc, &g) != hipSuccess || g == nullptr) ok = false;
-          }
-          if (rocblas_set_stream(C.rb[side], s) != rocblas_status_success) throw std::runtime_error("rocblas_set_stream failed");
-          if (ok && hipGraphInstantiate(&C.denseGraph, g, nullptr, nullptr, 0) != hipSuccess) {
-            ok = false;
-            C.denseGraph = nullptr;
-          }
-          if (g != nullptr) (void)hipGraphDestroy(g);
-          (void)hipGetLastError();
-          if (!ok) {
-            C.denseGraphState = -1;
-            C.denseGraph = nullptr;
-          } else {
-            C.denseGraphKey = key;
-          }
-        }
-        if (C.denseGraph != nullptr) HIP_CHECK(hipGraphLaunch(C.denseGraph, s));
-        else direct(s);
-      }
-      hipLaunchKernelGGL(k_coarse_dense_pack, dim3(static_cast<unsigned>((static_cast<size_t>(n) * n + 255) / 256)), dim3(256), 0, s, n,
-                         C.denseA.p, C.denseInfo.p, side ? C.denseInv2.p : C.denseInv.p, failOut,
-                         side ? C.denseInv.p : nullptr);
-      HIP_CHECK(hipGetLastError());
-      if (side) HIP_CHECK(hipEventRecord(h->evCoarseDone, s));
-    };
-    static const bool noWorker = std::getenv("CVD_COARSE_NO_WORKER") != nullptr;  // comparison knob
-    if (side && !noWorker) {
-      h->sideWorker.submit(job);  // ~250 launches: enqueued by the helper thread while this one enqueues the PCG
-    } else {
-      h->sideWorker.wait();
-      job();
-    }
+    HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
+    hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(c.L.F + C.nEdges), dim3(64), 0, s, c.L.F, C.nEdges, C.diag.p, C.edges.p,
+                       C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
+    HIP_CHECK(hipGetLastError());
+    // (a rebuild that meets a non-positive pivot keeps the inverse in use when a build for this problem has succeeded)
+    C.denseValid.ensure(1);
+    if (!(C.denseReady && C.denseForB == static_cast<int>(c.L.B))) HIP_CHECK(hipMemsetAsync(C.denseValid.p, 0, sizeof(int), s));
+    launchDenseSpdInverse(h, n, C.denseA.p, C.denseInv.p, failOut, s, C.denseValid.p);
+    C.denseReady = true;
+    C.denseForB = c.L.B;
     return;
   }
-  static const bool singleWg = std::getenv("CVD_COARSE_FACTOR_1WG") != nullptr;  // comparison / fallback
-  if (singleWg) {
-    hipLaunchKernelGGL(k_coarse_factor, dim3(1), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p, C.modeActive.p, C.Lb.p,
-                       C.Linv.p, failOut);
-  } else {
-    C.barrier.ensure(1);
-    HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, sizeof(unsigned int), s));
-    HIP_CHECK(hipMemsetAsync(C.Lb.p, 0, static_cast<size_t>(C.nBlocks) * kCBB * sizeof(double), s));
-    hipLaunchKernelGGL(k_coarse_factor_mw, dim3(kCoarseFactorGroups), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p,
-                       C.modeActive.p, C.Lb.p, C.Linv.p, failOut, C.barrier.p);
-  }
+  C.barrier.ensure(4);
+  HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, sizeof(unsigned int), s));
+  HIP_CHECK(hipMemsetAsync(C.Lb.p, 0, static_cast<size_t>(C.nBlocks) * kCBB * sizeof(double), s));
+  hipLaunchKernelGGL(k_coarse_factor_mw, dim3(kCoarseFactorGroups), dim3(1024), 0, s, C.plan, C.diag.p, C.edges.p,
+                     C.modeActive.p, C.Lb.p, C.Linv.p, failOut, C.barrier.p);
   hipLaunchKernelGGL(k_coarse_winv, dim3((c.L.F + 3) / 4), dim3(256), 0, s, C.plan, C.Lb.p, C.Linv.p, WbOut);
   HIP_CHECK(hipGetLastError());
 }

@@ -644,7 +644,7 @@ static long long coarseEliminationUpdates(int F, const std::vector<std::pair<int
   return updates;
 }
 static bool coarseKeepsPair(int a, int b) {
-  static const int shift = []() { const char* e = std::getenv("CVD_COARSE_KEEP_SHIFT"); return e ? std::atoi(e) : 3; }();  // development knob
+  constexpr int shift = 3;  // (d/2: 123 PCG iterations per LM iteration on the 4140-pair list, d/4: 88, d/8: 64, d/16: 47 but a costlier factor)
   const int d = std::abs(a - b);
   int s2 = 1;
   while (s2 * 2 <= (d >> shift)) s2 *= 2;
@@ -685,7 +685,7 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
                        h->dNdc.p, h->dDsrc.p, h->dCount.p, ignoreStatic ? 1 : 0);
     HIP_CHECK(hipGetLastError());
   }
-  if (h->dist()) NCCL_CHECK(ncclAllReduce(h->dCount.p, h->dCount.p, 1, ncclUint64, ncclSum, h->comm, s));
+  if (h->dist()) commAllReduce(h, h->dCount.p, 1, CT_U64, s);
   unsigned long long nv = 0;
   HIP_CHECK(hipMemcpyAsync(&nv, h->dCount.p, sizeof(nv), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -728,9 +728,7 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
   // Longest items first: the pair-major kernels run one workgroup per item in launch order, ~2.7 rounds of the device at the
   // benchmark's 2070 items -- with the short items last the final, partly filled round is short too.  (Stable: equal sizes
   // keep the frame-pair order.)
-  static const bool itemOrderOff = std::getenv("CVD_ITEMS_UNSORTED") != nullptr;  // comparison knob
-  if (!itemOrderOff)
-    std::stable_sort(itemList.begin(), itemList.end(), [](const ItemDesc& a, const ItemDesc& b) {
+  std::stable_sort(itemList.begin(), itemList.end(), [](const ItemDesc& a, const ItemDesc& b) {
       return (a.e0 - a.b0) + (a.e1 - a.b1) > (b.e0 - b.b0) + (b.e1 - b.b1);
     });
   for (const ItemDesc& d : itemList) {
@@ -847,13 +845,12 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     }
     // sparsify the coarse graph when its elimination is too expensive (a function of the whole problem's pair graph
     // only: identical on all ranks of a sharded run)
-    // (read per compile, not cached: tests force the dense / sparsified variants on small problems through it)
-    const long long updateBudget = []() { const char* e = std::getenv("CVD_COARSE_UPDATE_BUDGET"); return e ? std::atoll(e) : 40000ll; }();
+    const long long updateBudget = h->opt.coarse_update_budget;
     h->coarse.sparsified = false;
     h->coarse.denseMode = false;
-    const int denseMaxUnknowns = []() { const char* e = std::getenv("CVD_COARSE_DENSE_MAX"); return e ? std::atoi(e) : 4096; }();
+    const int denseMaxUnknowns = h->opt.coarse_dense_max_unknowns;
     const bool overBudget = coarseEliminationUpdates(h->F, edgeList) > updateBudget;
-    if (overBudget && h->F * kCB <= denseMaxUnknowns && !h->dist()) {
+    if (overBudget && h->F * kCB <= denseMaxUnknowns) {
       h->coarse.denseMode = true;  // small enough to invert as a dense matrix: keeps every pair (cvd_coarse.h)
     } else if (overBudget) {
       std::vector<int> newId(edgeList.size(), -1);
@@ -933,7 +930,7 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     }
     int activeFrames = 0;
     for (int f = 0; f < h->F; ++f) activeFrames += inRange[f] ? 1 : 0;
-    static const double partsPerCU = []() { const char* e = std::getenv("CVD_ASM_PARTS_PER_CU"); return e ? std::atof(e) : 1.0; }();
+    constexpr double partsPerCU = 1.0;
     const long long denom = std::max<long long>(1, std::max<long long>(activeFrames, static_cast<long long>(partsPerCU * h->numCU)));
     const int capU = static_cast<int>(std::max<long long>(kAsmThreads / 64, (static_cast<long long>(units.size()) + denom - 1) / denom));
     std::vector<AsmPart> parts;
@@ -1037,7 +1034,8 @@ void ensureBuffers(Ctx& c) {
   const size_t n = c.n;
   const size_t B = c.L.B;
   h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
-  h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n); h->dQ.ensure(n);
+  h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);
+  h->dQ.ensure(n + static_cast<size_t>(c.L.F) * kCB + 8);  // (+ [Z^T q | p.q]: the fused exchange of the pair-sharded mode)
   h->dHd.ensure(n);
   {
     // (sharded mode: room for world x chunk frames so that the reduce-scatter / all-gather chunks are equal; the tail

@@ -24,9 +24,8 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   double* rc = coarse ? h->coarse.rc.p : nullptr;
   // Coarse level per iteration: y = W Z^T r is kept up to date inside k_cg_update (CoarseStep: y <- y - alpha W Z^T q,
   // |y|^2 closes r^T z), so only c = W^T y remains as a launch; the first residual goes through k_coarse_apply_w.
-  static const bool unfusedEnv = std::getenv("CVD_COARSE_UNFUSED_Y") != nullptr;  // comparison: separate y = W Z^T r launch
   const bool denseCoarse = coarse && h->coarse.denseMode;
-  const bool unfusedY = unfusedEnv || denseCoarse;  // (the dense level has no W to recur on: Z^T r is restricted every iteration)
+  const bool unfusedY = denseCoarse;  // (the dense level has no W to recur on: Z^T r is restricted every iteration)
   auto coarseC = [&](int init) {
     if (c.L.positionRegSqrt > 0.0 || c.trip || !coarseFusedConsumers())
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
@@ -51,14 +50,17 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
                               : csOff;
   const DenseStep dsOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // dense level: c <- c - alpha A_c^-1 Z^T q inside k_cg_update (F extra workgroups) instead of a launch of its own
-  const bool denseFused = denseCoarse && coarseDenseFused() && !h->dist();
-  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
+  const bool denseFused = denseCoarse;
+  // pair-sharded mode with the fused exchange (cvd_matvec.hip): Z^T q and p.q arrive all-reduced behind q
+  const bool fusedX = h->dist() && fusedExchange(h, coarse);
+  const double* pqReduced = fusedX ? h->dQ.p + exchangeOffsetPq(c, denseFused) : nullptr;
+  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + c.n : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
                                                 h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
                                     : dsOff;
   if (denseFused) ldsU = std::max(ldsU, (static_cast<size_t>(F) * kCB + nThreads + 16) * 8);  // (its workgroups: Z^T q + partial sums)
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff);
+                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr));
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -70,7 +72,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
   // (profiling aid: CVD_PCG_LOCKSTEP=1 checks after every iteration and never runs ahead, so that per-launch
   // counter averages contain no early-exit launches)
-  static const bool lockstep = std::getenv("CVD_PCG_LOCKSTEP") != nullptr;
+  const bool lockstep = h->opt.pcg_lockstep != 0;
   const size_t firstTimerSlot = h->evUsed;
   int enq = 0;
   auto enqueueIteration = [&](int it, int useBeta) {
@@ -79,7 +81,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
     const int slot = h->tBegin(KC_CG_UPDATE);
     hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
-                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn);
+                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced);
     if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -92,8 +94,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   // k - kRunAhead + 1 iterations is known to be clear: nothing but the PCG kernels is in the stream, the device is
   // never starved (kRunAhead iterations are queued ahead) and kRunAhead - 1 early-exit iterations are wasted per
   // solve.  The rule is a function of iteration counts only, hence identical on all ranks of a sharded run.
-  static const int runAheadEnv = []() { const char* e = std::getenv("CVD_PCG_RUN_AHEAD"); return e ? std::max(1, std::atoi(e)) : 2; }();
-  const int kRunAhead = lockstep ? 1 : runAheadEnv;
+  const int kRunAhead = lockstep ? 1 : 2;  // (3-4 iterations ahead: no change, the host is not late)
   volatile double* prog = h->hPcg;
   while (enq < maxIt) {
     if (enq >= kRunAhead - 1) {
@@ -146,10 +147,13 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   if (h->F <= 0) throw std::runtime_error("no video set");
   if (!h->poseParamsValid) posesToParams(h);
   const std::vector<int> range = rangeOf(p, h->F);
-  struct WorkerGuard {  // (also on the exception paths)
+  // A coarse rebuild still running on the side stream when the solve ends (or throws) must finish before anything on the
+  // main stream -- the next solve's in-line setup, a table upload -- touches the coarse buffers again.
+  struct PendingGuard {
     cvd_handle* h;
-    ~WorkerGuard() { h->sideWorker.waitNoThrow(); }
-  } workerGuard{h};
+    bool pending = false;
+    ~PendingGuard() { if (pending) (void)hipStreamWaitEvent(h->stream, h->evCoarseDone, 0); }
+  } pendingGuard{h};
   static const bool dbgSetup = std::getenv("CVD_DEBUG_SETUP") != nullptr;  // development: where a solve's fixed cost goes
   double tPhase = nowSeconds();
   auto phase = [&](const char* what) {
@@ -232,48 +236,25 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
   int invalid = 0, iteration = 0, termination = 1;
-  static const int kCoarseRebuildIters = []() {
-    const char* e = std::getenv("CVD_COARSE_REBUILD_ITERS");  // development knob
-    return e ? std::max(1, std::atoi(e)) : 16;
-  }();
+  constexpr int kCoarseRebuildIters = 16;
   int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
-  static const bool asyncCoarse = std::getenv("CVD_COARSE_SYNC") == nullptr;  // (development knob: rebuild in line)
-  bool coarsePending = false;  // a rebuild is running on the side stream
+  bool& coarsePending = pendingGuard.pending;  // a rebuild is running on the side stream
   int factorUses = 0;          // PCG solves done with the factor in use
   double lastRelChange = 1.0;  // relative cost change of the last accepted step
-  static const double asyncMaxChange = []() { const char* e = std::getenv("CVD_COARSE_ASYNC_MAX_CHANGE"); return e ? std::atof(e) : 1e-3; }();
+  constexpr double asyncMaxChange = 1e-3;
   bool freshFactor = false;    // the factor was installed right before this iteration's PCG
-  static const bool carryAcrossLevels = std::getenv("CVD_COARSE_CARRY_LEVELS") != nullptr;  // comparison knob
-  if (h->coarseOn && h->coarse.denseMode && h->coarse.denseReady && (h->coarse.denseForB == c.L.B || carryAcrossLevels)) {
-    // Dense level: the inverse left by the previous solve on this handle (the previous coarse-to-fine level, or the last
-    // optimisation of the same video) is a perfectly good SPD preconditioner to start with -- its ~6 ms rocSOLVER rebuild
-    // is not paid in line but started beside the first PCG and installed for the second LM iteration.
-    coarseAge = 0;
-    cgExcess = kCoarseRebuildIters;
-  }
-  // The dense level's rebuild (~6.5 ms of dependent rocSOLVER kernels) outlasts one PCG solve (~5 ms at 4140 pairs): it is
-  // installed after the SECOND solve that runs beside it (a fixed lag, not an event query: the iteration sequence stays
-  // a function of the data alone), so that the main stream never waits for it.
-  static const int kDenseInstallLag = []() { const char* e = std::getenv("CVD_COARSE_DENSE_LAG"); return e ? std::max(1, std::atoi(e)) : 2; }();
-  int pendingSolves = 0;  // PCG solves run since the pending rebuild was started
   auto installPendingCoarse = [&]() {
     if (!coarsePending) return;
-    if (h->coarse.denseMode && ++pendingSolves < kDenseInstallLag) return;
-    pendingSolves = 0;
-    h->sideWorker.wait();  // (the helper thread has finished enqueuing: normally long ago)
     HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseDone, 0));  // (device-side wait: the host does not block)
     std::swap(h->coarse.Wb.p, h->coarse.Wb2.p);
     std::swap(h->coarse.Wb.n, h->coarse.Wb2.n);
     std::swap(h->coarse.fail.p, h->coarse.fail2.p);
     std::swap(h->coarse.fail.n, h->coarse.fail2.n);
-    std::swap(h->coarse.denseInv.p, h->coarse.denseInv2.p);
-    std::swap(h->coarse.denseInv.n, h->coarse.denseInv2.n);
     coarsePending = false;
     freshFactor = true;
     cgExcess = 0;
     coarseAge = 0;
     factorUses = 0;
-    if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
   };
   bool scaleDone = false;
   cvd_iteration_record r0{};
@@ -323,21 +304,19 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
           // (Only in the slowly changing regime -- the last accepted step changed the cost by less than 0.1 % --: while
           // the iterates still move a lot a factor that is one iteration late costs more PCG iterations than the
           // overlap saves, and there the rebuild stays in line.)
-          // (the dense level's rocSOLVER inversion is a chain of small kernels, ~6 ms at 2400 unknowns, that hardly
-          // occupies the device: always beside the PCG once a first inverse exists)
-          if ((lastRelChange < asyncMaxChange || (h->coarse.denseMode && coarseAge >= 0)) && asyncCoarse && h->opt.coarse_level != 2 && !h->dist()) {
+          // (the dense level's inverse is one persistent kernel that wants every CU: always in line)
+          if (lastRelChange < asyncMaxChange && !h->coarse.denseMode && h->opt.coarse_level != 2 && !h->dist()) {
             h->dFc2.ensure(c.L.F);
             HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
             HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
             launchCoarseSetup(c, h->dX.p, 1);
-            if (!h->coarse.denseMode) HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));  // (dense: recorded by the job)
+            HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));
             coarsePending = true;
             cgExcess = 0;
           } else {
             const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
             launchCoarseSetup(c, h->dX.p);
             h->tEnd(slot);
-            if (h->coarse.denseMode) { h->coarse.denseReady = true; h->coarse.denseForB = c.L.B; }
             coarseAge = 0;
             cgExcess = 0;
             freshFactor = true;
@@ -356,28 +335,6 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
         HIP_CHECK(hipGetLastError());
         enqueueCost(c, h->dXc.p);
       });
-      static const bool dbgCoarse = std::getenv("CVD_DEBUG_COARSE") != nullptr;
-      if (dbgCoarse && h->coarseOn && h->coarse.denseMode) {
-        HIP_CHECK(hipStreamSynchronize(s));
-        int fl[2] = {-1, -1};
-        HIP_CHECK(hipMemcpy(&fl[0], h->coarse.fail.p, 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&fl[1], h->coarse.fail2.p, 4, hipMemcpyDeviceToHost));
-        const size_t nn = static_cast<size_t>(c.L.F) * kCB;
-        std::vector<float> dg(nn);
-        HIP_CHECK(hipMemcpy2D(dg.data(), 4, h->coarse.denseInv.p, (nn + 1) * 4, 4, nn, hipMemcpyDeviceToHost));
-        double tr = 0.0;
-        for (float v : dg) tr += v;
-        std::vector<double> cc(nn);
-        HIP_CHECK(hipMemcpy(cc.data(), h->coarse.c.p, nn * 8, hipMemcpyDeviceToHost));
-        double cn = 0.0;
-        for (double v : cc) cn += v * v;
-        fprintf(stderr, "[coarse dbg] it %d pcg %d fail %d fail2 %d inv %p trace %.10e |c| %.6e pending %d graph %d/%p\n", iteration, cgIters, fl[0], fl[1],
-                (void*)h->coarse.denseInv.p, tr, std::sqrt(cn), coarsePending ? 1 : 0, h->coarse.denseGraphState, (void*)h->coarse.denseGraph);
-      }
-      // a rebuild still pending past this point (the dense level's fixed lag) must have read its inputs before the next
-      // evaluation rewrites them: the side stream competes with a main stream that is never idle, so "enqueued 4 ms ago"
-      // is not "executed" (device-side wait, satisfied long ago in the normal case)
-      if (coarsePending) HIP_CHECK(hipStreamWaitEvent(s, h->evCoarseRead, 0));
       if (freshFactor) cgAfterRefresh = cgIters;
       else cgExcess += std::max(0, cgIters - cgAfterRefresh);
       freshFactor = false;
@@ -457,7 +414,6 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
     }
   }
   phase("LM loop");
-  h->sideWorker.wait();  // (a rebuild started beside the last PCG: its enqueuing must not outlive this frame)
   downloadState(h, c.L, h->dX);
   phase("download");
   h->tCollect();
@@ -521,7 +477,7 @@ void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, con
   if (hdiag) {
     if (h->dist()) {  // (parity hook: collect the owners' reduced blocks)
       const size_t chunk = static_cast<size_t>(h->ownChunk()) * c.L.B * c.L.B;
-      NCCL_CHECK(ncclAllGather(h->dH.p + static_cast<size_t>(h->rank) * chunk, h->dH.p, chunk, ncclDouble, h->comm, s));
+      commAllGather(h, h->dH.p + static_cast<size_t>(h->rank) * chunk, h->dH.p, chunk, CT_F64, s);
     }
     h->dH.download(hdiag, c.n * c.L.B, s);
   }

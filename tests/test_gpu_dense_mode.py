@@ -20,11 +20,12 @@ def Solver():
     return api.Solver
 
 
-def _setup(Solver, frames=6, w=96, h=56, seed=61):
+def _setup(Solver, frames=6, w=96, h=56, seed=61, matrix_free=False):
     v = synth.make_video(frames, w, h, seed=seed)
     flow, mask = synth.make_dense_flows(v)
     off, loc = synth.dense_constraints_from_flows(v, flow, mask)
     hip, orc = Solver(0), Oracle()
+    hip.set_options(dense_matrix_free=int(matrix_free))
     for s in (hip, orc):
         s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
         s.set_depth_all(v.depth)
@@ -37,12 +38,10 @@ def _setup(Solver, frames=6, w=96, h=56, seed=61):
 @pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
 @pytest.mark.parametrize("variant", ["global", "grid6x4", "grid17x10", "global_fixed_intrinsics", "grid6x4_huber_ratio",
                                      "global_log_depth"])
-def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant, product, monkeypatch):
+def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, variant, product):
     """`product`: the two device paths of J^T J p in dense mode -- explicit cross blocks X_ab assembled once per evaluation
-    (cvd_cross.h, the default; grid17x10 needs two column panels) and the matrix-free kernel (CVD_DENSE_MATRIX_FREE)."""
-    if product == "matrix_free":
-        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
-    v, hip, orc, n = _setup(Solver)
+    (cvd_cross.h, the default; grid17x10 needs two column panels) and the matrix-free kernel (solver option dense_matrix_free)."""
+    v, hip, orc, n = _setup(Solver, matrix_free=product == "matrix_free")
     F = v.num_frames
     rng = np.random.default_rng(3)
     pose = np.zeros((F, 7))
@@ -78,10 +77,8 @@ def test_dense_cost_gradient_blocks_and_products_match_the_oracle(Solver, varian
 
 
 @pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
-def test_dense_solve_reaches_the_oracle_minimum(Solver, product, monkeypatch):
-    if product == "matrix_free":
-        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
-    v, hip, orc, _ = _setup(Solver, frames=8, seed=62)
+def test_dense_solve_reaches_the_oracle_minimum(Solver, product):
+    v, hip, orc, _ = _setup(Solver, frames=8, seed=62, matrix_free=product == "matrix_free")
     out = {}
     for k, s in (("hip", hip), ("oracle", orc)):
         p = OptParams.defaults()
@@ -101,17 +98,16 @@ def test_dense_solve_reaches_the_oracle_minimum(Solver, product, monkeypatch):
 
 
 @pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
-def test_dense_one_directional_pairs_and_odd_raster(Solver, product, monkeypatch):
+def test_dense_one_directional_pairs_and_odd_raster(Solver, product):
     """Only the a -> b direction of every frame pair (the reverse range of each undirected work item / block is empty) on a
     raster whose pixel count is no multiple of the kernels' run length or unit size (90 x 50)."""
-    if product == "matrix_free":
-        monkeypatch.setenv("CVD_DENSE_MATRIX_FREE", "1")
     v = synth.make_video(5, 90, 50, seed=66)
     flow, mask = synth.make_dense_flows(v)
     keep = np.flatnonzero(v.pairs[:, 0] < v.pairs[:, 1])
     v.pairs, flow, mask = v.pairs[keep], flow[keep], mask[keep]
     off, loc = synth.dense_constraints_from_flows(v, flow, mask)
     hip, orc = Solver(0), Oracle()
+    hip.set_options(dense_matrix_free=int(product == "matrix_free"))
     for s in (hip, orc):
         s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
         s.set_depth_all(v.depth)

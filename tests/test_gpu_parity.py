@@ -590,17 +590,16 @@ def test_rccl_communicator_world_size_one(Solver):
         s.pose_optimization_step(OptParams.defaults(), 0.1)
 
 
-def test_sharded_code_path_on_one_rank(Solver, monkeypatch):
-    """CVD_FORCE_DIST: a 1-rank communicator runs the pair-sharded mode's kernels and call sequence for real (partial q +
+def test_sharded_code_path_on_one_rank(Solver):
+    """force_sharded_path: a 1-rank communicator runs the pair-sharded mode's kernels and call sequence for real (partial q +
     RCCL all-reduce + k_dot_pq, restriction from the reduced product, all-reduced coarse edge blocks, cost reduction);
     the result must match the plain single-GPU solve."""
     v = synth.make_video(8, 96, 56, seed=38)
     trip = synth.make_triplets(v, spacing=20.0)
     out = []
     for forced in (False, True):
-        if forced:
-            monkeypatch.setenv("CVD_FORCE_DIST", "1")
         s = Solver(0)
+        s.set_options(force_sharded_path=int(forced))
         s.comm_init(0, 1, Solver.comm_unique_id())
         synth.load_into(s, v)
         s.set_triplet_constraints(*trip)
@@ -623,7 +622,6 @@ def test_sharded_code_path_on_one_rank(Solver, monkeypatch):
             assert ct["evaluate_exchange"]["count"] >= 2 * out[-1][2]["num_successful_steps"]
             assert ct["product_exchange"]["count"] >= out[-1][2]["total_linear_iterations"]
             assert ct["coarse_exchange"]["count"] >= 2 and ct["product_exchange"]["avg_ms"] > 0.0
-    monkeypatch.delenv("CVD_FORCE_DIST", raising=False)
     a, b = out
     assert abs(a[0]["cost"] - b[0]["cost"]) <= 1e-12 * abs(a[0]["cost"])
     assert rel(b[0]["gradient"], a[0]["gradient"]) < 1e-12
@@ -654,21 +652,17 @@ def test_unsupported_configurations_fail_loudly(Solver):
 
 
 @pytest.mark.parametrize("tol", [None, 0.3])
-def test_dense_coarse_level_rebuilt_beside_the_solver(Solver, tol, monkeypatch):
-    """The default policy of the dense coarse level (coarse_level = 1): the rocSOLVER inversion runs on the side stream, enqueued
-    by the helper thread (captured into a hipGraph from its second run on), installed at a fixed lag and carried over between
-    solves of a level.  Forced on a small problem; several solves on ONE handle so that first build, direct side rebuild,
-    graph capture and graph replay all happen; tol = 0.3 makes the PCG beside the rebuild a handful of iterations, i.e. the
-    main thread reaches its event waits while the helper thread is still capturing (a capture on the side stream itself
-    turned those waits into hipErrorStreamCaptureIsolation).  End state against the exact sparse level."""
+def test_dense_coarse_level_over_several_solves(Solver, tol):
+    """The dense coarse level (A_c inverted in line by k_dense_spd_inverse, one persistent launch per rebuild), forced on a small
+    problem; several pipelines on ONE handle so that first builds, on-demand rebuilds and the keep-on-failure bookkeeping across
+    coarse-to-fine levels all happen; tol = 0.3 makes the PCG solves a handful of iterations.  End state against the exact
+    sparse level."""
     v = synth.make_video(24, 128, 72, seed=12, extra_offsets=6)
 
-    def run(env, repeats):
-        for k, val in env.items():
-            monkeypatch.setenv(k, val)
+    def run(options, repeats):
         s = Solver(0)
         synth.load_into(s, v)
-        s.set_options(pcg_relative_tolerance=tol)
+        s.set_options(pcg_relative_tolerance=tol, **options)
         out = []
         for _ in range(repeats):
             s.reset_poses()
@@ -679,12 +673,10 @@ def test_dense_coarse_level_rebuilt_beside_the_solver(Solver, tol, monkeypatch):
             s.normalize_depth(p)
             s.pose_optimization(p)
             out.append((s.summary(), s.get_poses(), s.get_xform_params().copy()))
-        for k in env:
-            monkeypatch.delenv(k)
         return out
 
     ref = run({}, 1)[0]   # (this small graph factorises exactly: the sparse level)
-    runs = run({"CVD_COARSE_UPDATE_BUDGET": "0"}, 3)
+    runs = run({"coarse_update_budget": 0}, 3)
     for sm, poses, theta in runs:
         assert sm["termination"] == 0
         if tol is None:
@@ -693,41 +685,37 @@ def test_dense_coarse_level_rebuilt_beside_the_solver(Solver, tol, monkeypatch):
             assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
         else:
             # (steps solved to 30 % stop the LM loop by function_tolerance at preconditioner-dependent points: this variant
-            # is about the rebuild machinery running beside very short solves, not about where such a sloppy solve ends)
+            # is about the rebuild bookkeeping around very short solves, not about where such a sloppy solve ends)
             assert np.isfinite(sm["final_cost"]) and sm["final_cost"] <= sm["initial_cost"]
 
 
 @pytest.mark.parametrize("variant", ["dense", "sparsified"])
-def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant, monkeypatch):
+def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant):
     """Flow lists whose frame graph fills in under elimination (long-range pairs from nearly every frame) get the DENSE
-    coarse level (A_c inverted by rocSOLVER, applied as an f32 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
+    coarse level (A_c inverted by k_dense_spd_inverse, applied as an f32 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
     (dropped pairs removed from the coarse operator).  Both are forced here on a small problem through the elimination
     budget: A_c^-1 as applied really is the inverse (dense: to f32 accuracy), the operator stays SPD, and the solve
     reaches the same minimum as with the exact sparse level."""
     F = 24
     v = synth.make_video(F, 128, 72, seed=12, extra_offsets=6)
 
-    def run(env):
-        for k, val in env.items():
-            monkeypatch.setenv(k, val)
+    def run(options):
         s = Solver(0)
         synth.load_into(s, v)
-        s.set_options(coarse_level=2)
+        s.set_options(coarse_level=2, **options)
         s.reset_depth_xforms(XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())
         p = OptParams.defaults()
         p.ctf_long, p.ctf_short = 6, 4
         s.normalize_depth(p)
         s.pose_optimization(p)
-        for k in env:
-            monkeypatch.delenv(k)
         return s
 
     ref = run({})
-    env = {"CVD_COARSE_UPDATE_BUDGET": "0"}
+    options = {"coarse_update_budget": 0}
     if variant == "sparsified":
-        env["CVD_COARSE_DENSE_MAX"] = "0"
-    s = run(env)
+        options["coarse_dense_max_unknowns"] = 0
+    s = run(options)
     dbg = s.coarse_debug()
     assert dbg is not None and dbg["failed"] == 0
     A, Ai = dbg["a_c"], dbg["a_c_inverse"]

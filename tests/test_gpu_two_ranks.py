@@ -1,0 +1,142 @@
+"""GPU (-m gpu): the pair-sharded multi-GPU mode with WORLD SIZE 2 on one GPU.
+
+RCCL refuses two ranks on one device ("Duplicate GPU detected") and the GPU boxes have one GPU, so the two ranks are two
+handles of this process, each driven by its own host thread, exchanging through the library's local-group backend
+(cvd_comm_init_local_group, cvd_comm.hip: same call sites, same buffers, same in-place forms as the RCCL backend --
+host-synchronous, for tests only).  What runs for real with world = 2: pair shards per rank, regularisers by frame % 2,
+frame ownership in chunks of ceil(F / 2) with padding (odd F), reduce-scatter of the H_ff blocks to the owners, all-gather
+of diag(H) and of the f32 block inverses, the coarse level's all-reduced edge blocks / all-gathered diagonal blocks, the
+FUSED product exchange [q | Z^T q | p.q] with the dense coarse level and the q-only exchange + k_dot_pq with the sparse one.
+
+Bars: evaluation (cost / gradient / H_ff) 1e-9 against the single-rank handle, end state 1e-3 (final cost 1e-6)."""
+import threading
+
+import numpy as np
+import pytest
+
+from robust_cvd_amd import sharding, synth
+from robust_cvd_amd.ctypes_types import OptParams, XformDesc
+
+pytestmark = pytest.mark.gpu
+
+_KEY = [1000]
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def run_ranks(world, body):
+    """body(rank) on `world` threads (ctypes releases the GIL inside the library); re-raises the first failure."""
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            out[r] = body(r)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def solve_sharded(v, world, options, grid, trip=None, smooth=None):
+    from robust_cvd_amd import api
+    _KEY[0] += 1
+    key = _KEY[0]
+    shards = sharding.shard_pairs(v.pairs, v.offsets, world)
+
+    def body(rank):
+        s = api.Solver(0)
+        if options:
+            s.set_options(**options)
+        s.comm_init_local_group(rank, world, key)
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.set_pair_constraints(*sharding.take_pairs(v.pairs, v.offsets, v.loc, v.is_static, shards[rank]))
+        if trip is not None:
+            s.set_triplet_constraints(*trip)
+        s.set_pair_graph(v.pairs)
+        s.reset_poses()
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = grid
+        if smooth:
+            p.smooth_static_weight, p.smooth_dynamic_weight = smooth
+        s.normalize_depth(p)
+        ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+        s.pose_optimization(p)
+        res = (ev, s.get_poses(), s.get_xform_params().copy(), s.summary())
+        s.close()
+        return res
+
+    return run_ranks(world, body)
+
+
+def solve_single(v, options, grid, trip=None, smooth=None):
+    from robust_cvd_amd import api
+    s = api.Solver(0)
+    if options:
+        s.set_options(**options)
+    synth.load_into(s, v)
+    if trip is not None:
+        s.set_triplet_constraints(*trip)
+    s.reset_depth_xforms(XformDesc.global_depth())
+    s.reset_spatial_xforms(XformDesc.spatial())
+    p = OptParams.defaults()
+    p.ctf_long, p.ctf_short = grid
+    if smooth:
+        p.smooth_static_weight, p.smooth_dynamic_weight = smooth
+    s.normalize_depth(p)
+    ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+    s.pose_optimization(p)
+    res = (ev, s.get_poses(), s.get_xform_params().copy(), s.summary())
+    s.close()
+    return res
+
+
+def compare(ranks, single):
+    for ev, poses, theta, summ in ranks:
+        assert abs(ev["cost"] - single[0]["cost"]) <= 1e-9 * abs(single[0]["cost"])
+        assert rel(ev["gradient"], single[0]["gradient"]) < 1e-9
+        assert rel(ev["hdiag"], single[0]["hdiag"]) < 1e-9
+        assert abs(summ["final_cost"] - single[3]["final_cost"]) <= 1e-6 * abs(single[3]["final_cost"])
+        perr, rerr = synth.relative_pose_error(poses["position"], poses["orientation"], single[1]["position"],
+                                               single[1]["orientation"])
+        assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+        assert rel(theta, single[2]) < 1e-3
+        it_a, it_b = summ["total_linear_iterations"], single[3]["total_linear_iterations"]
+        assert abs(it_a - it_b) <= 0.2 * it_b + 5, (it_a, it_b)   # same preconditioner => same PCG effort
+    # both ranks hold the same state (every host decision is a function of reduced values)
+    assert np.array_equal(ranks[0][2], ranks[1][2])
+    assert ranks[0][3]["num_iterations"] == ranks[1][3]["num_iterations"]
+
+
+@pytest.mark.parametrize("coarse", ["sparse", "dense", "sparsified", "off"])
+def test_two_ranks_match_the_single_gpu_solve(coarse):
+    """Odd frame count (owner chunks of 5 + 4 frames, one padded frame), default coarse-to-fine pipeline on a small grid."""
+    v = synth.make_video(9, 96, 56, seed=52, extra_offsets=4)
+    options = {"sparse": {}, "dense": {"coarse_update_budget": 0},
+               "sparsified": {"coarse_update_budget": 0, "coarse_dense_max_unknowns": 0}, "off": {"coarse_level": 0}}[coarse]
+    single = solve_single(v, options, (6, 4))
+    ranks = solve_sharded(v, 2, options, (6, 4))
+    compare(ranks, single)
+
+
+def test_two_ranks_with_triplets_and_three_ranks():
+    """Scene-flow smoothness triplets (groups sharded by index) on two ranks, and a world of three (chunks 4 + 4 + 2 of 10)."""
+    v = synth.make_video(10, 96, 56, seed=53)
+    trip = synth.make_triplets(v, spacing=20.0)
+    single = solve_single(v, {}, (6, 4), trip, (0.5, 0.25))
+    compare(solve_sharded(v, 2, {}, (6, 4), trip, (0.5, 0.25)), single)
+    ranks3 = solve_sharded(v, 3, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25))
+    compare(ranks3[:2], solve_single(v, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25)))
+    assert np.array_equal(ranks3[0][2], ranks3[2][2])

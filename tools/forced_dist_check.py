@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU: the pair-sharded code path (owner exchange, per-product all-reduce, sparsified coarse level with all-reduced blocks) on
-the FULL benchmark problem with a 1-rank RCCL communicator (CVD_FORCE_DIST), against the plain single-GPU solve of the same
+the FULL benchmark problem with a 1-rank RCCL communicator (solver option force_sharded_path), against the plain single-GPU solve of the same
 level.  N > 1 needs N GPUs; this is what one box can check.  usage: forced_dist_check.py [pairs_level]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,13 +14,18 @@ level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 v = synth.make_video(300, 384, 224, seed=bench.SEED, extra_offsets=level)
 res = {}
 for mode in ("single", "forced_dist"):
-    if mode == "forced_dist":
-        os.environ["CVD_FORCE_DIST"] = "1"
     s = api.Solver(0)
     if mode == "forced_dist":
+        s.set_options(force_sharded_path=1)
         s.comm_init(0, 1, api.Solver.comm_unique_id())
     p = OptParams.defaults()
     bench.prepare(s, v, p, pair_graph=(v.pairs if mode == "forced_dist" else None))
+    pose0, theta0 = s.get_pose_params().copy(), s.get_xform_params().copy()
+    p.max_iterations = 1000
+    s.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=False)   # (warm-up: first launches of this level)
+    s.set_pose_params(pose0)
+    s.set_xform_params(theta0)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     p.max_iterations = 1000
     s.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=False)
