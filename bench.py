@@ -231,6 +231,8 @@ def main():
                     help="dense mode (the reference's matchSeparation = 0): flow / mask images of every pair instead of the "
                          "sampled constraint list; the kernels read flow, mask and depth directly, 17 B per pixel pair")
     ap.add_argument("--pcg-tol", type=float, default=None, help="development: PCG forcing value (default: the library's)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="development: any integer field of cvd_solver_options (e.g. coarse_rebuild_excess=8, coarse_level=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figure on the reference sampler's 1766-pair list")
     ap.add_argument("--secondary-steps", type=int, default=10)
@@ -254,11 +256,11 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
-    # (the library first: its librccl.so.1 is the ROCm one it was built against; torch's bundled copy has the same soname)
+    # (torch first, as every test does: its bundled HIP runtime / librccl.so.1 carry the sonames libcvd_hip.so asks for, so the
+    # process holds ONE copy of each -- loading the library first made hipGetDeviceCount fail under the mixed runtimes)
+    import torch
     from robust_cvd_amd import api, synth
     from robust_cvd_amd.ctypes_types import OptParams
-    api.load_library()
-    import torch
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
@@ -313,6 +315,9 @@ def main():
             solver.set_options(pcg_relative_tolerance=args.pcg_tol)
         if args.pcg_lockstep:
             solver.set_options(pcg_lockstep=1)
+        for kv in args.opt:
+            name, val = kv.split("=")
+            solver.set_options(**{name: int(val)})
         t_prep = time.perf_counter()
         upload, grid, pipeline_first = prepare(solver, video, params, pair_graph=all_pairs)
         t_prep = time.perf_counter() - t_prep

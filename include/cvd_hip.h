@@ -52,7 +52,8 @@ typedef struct cvd_solver_options {
                                      that per-launch counter averages contain no early-exit launches */
   int32_t coarse_dense_max_unknowns; /* the coarse level is inverted as ONE dense matrix up to this many unknowns
                                      (8 per frame) when its sparse elimination is too expensive; default 4096 */
-  int32_t coarse_reserved;
+  int32_t coarse_rebuild_excess;  /* coarse_level 1: the coarse level is rebuilt once the PCG iterations spent beyond the count seen
+                                     right after the last rebuild add up to this many (about what a rebuild costs); default 16 */
   int64_t coarse_update_budget;   /* 8x8 block updates of the sparse elimination beyond which the coarse level goes dense
                                      (or, beyond coarse_dense_max_unknowns, is built on a sparsified graph); default 40000 */
 } cvd_solver_options;
@@ -113,6 +114,13 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t
  * which otherwise). */
 int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* flow, const uint8_t* mask);
 /* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
+/* 1 when a problem with these parameters / transform descriptors lies within the scope of the dense mode (identity spatial
+ * transform, a reprojection loss, Scale value transform, Global or bilinear grid, per-frame or fixed intrinsics, no
+ * smoothness triplets, one GPU, frame block <= 256); 0: hand the constraints over as a list (cvd_set_pair_constraints) --
+ * a dense-mode solve outside the scope fails instead of falling back.  problem: 0 = poseOptimization, 1 = normalizeDepth.
+ * What lib_python's FlowConstraintsCollection asks before it keeps a matchSeparation = 0 collection as images. */
+int32_t cvd_dense_mode_supported(const cvd_opt_params* params, const cvd_xform_desc* depth, const cvd_xform_desc* spatial,
+                                 int32_t have_triplets, int32_t world_size, int32_t problem);
 int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers,
                                     const int64_t* offsets, const float* loc6, const uint8_t* is_static);
 /* Dynamic masks of all frames, masks[F][height][width] u8 (the `dynamic_mask` colour stream; NULL forgets them):

@@ -29,7 +29,7 @@ class SolverOptions(C.Structure):
         ("block_inverse_variant", C.c_int32),
         ("pcg_lockstep", C.c_int32),
         ("coarse_dense_max_unknowns", C.c_int32),
-        ("coarse_reserved", C.c_int32),
+        ("coarse_rebuild_excess", C.c_int32),
         ("coarse_update_budget", C.c_int64),
     ]
 
@@ -56,7 +56,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
     "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
-    "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
+    "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_dense_mode_supported", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",

@@ -209,7 +209,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->block_inverse_variant = 0;
   o->pcg_lockstep = 0;
   o->coarse_dense_max_unknowns = 4096;
-  o->coarse_reserved = 0;
+  o->coarse_rebuild_excess = 16;
   o->coarse_update_budget = 40000;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
@@ -325,6 +325,7 @@ int32_t cvd_set_depth_all(cvd_handle* h, const float* depth) {
 int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t* pairFrames, const int64_t* offsets,
                                  const float* loc4, const uint8_t* isStatic) {
   CVD_TRY(h, {
+    if (numPairs < 0 || !offsets || (numPairs > 0 && !pairFrames)) throw std::runtime_error("invalid pair constraints");
     // the reference iterates a std::map<std::pair<int,int>> (lib/FlowConstraints.h:149): sort by key
     std::vector<int> order(numPairs);
     for (int i = 0; i < numPairs; ++i) order[i] = i;
@@ -332,7 +333,6 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
       if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
       return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
     });
-    if (numPairs < 0 || !offsets || (numPairs > 0 && !pairFrames)) throw std::runtime_error("invalid pair constraints");
     if (offsets[0] != 0) throw std::runtime_error("pair constraint offsets must start at 0");
     for (int i = 0; i < numPairs; ++i)
       if (offsets[i + 1] < offsets[i]) throw std::runtime_error("pair constraint offsets must be non-decreasing");
@@ -342,6 +342,9 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
                                  "one entry per pair key, lib/FlowConstraints.h:149)");
     const long long C = offsets[numPairs];
     if (C > 0 && !loc4) throw std::runtime_error("invalid pair constraints");
+    for (int k = 0; k < numPairs; ++k)  // (everything is validated before the handle changes)
+      if (pairFrames[2 * k] < 0 || pairFrames[2 * k] >= h->F || pairFrames[2 * k + 1] < 0 || pairFrames[2 * k + 1] >= h->F)
+        throw std::runtime_error("pair frame out of range");
     h->dense = false;
     h->dFlow.release();
     h->dFMask.release();
@@ -392,17 +395,21 @@ int32_t cvd_set_pair_flows(cvd_handle* h, int32_t numPairs, const int32_t* pairF
       if (pairFrames[2 * a] != pairFrames[2 * b]) return pairFrames[2 * a] < pairFrames[2 * b];
       return pairFrames[2 * a + 1] < pairFrames[2 * b + 1];
     });
-    h->pairA.resize(numPairs);
-    h->pairB.resize(numPairs);
-    h->pairOff.assign(numPairs + 1, 0);
+    // (built aside and committed to the handle only after every check has passed: a throw leaves the old list intact)
+    std::vector<int> newA(numPairs), newB(numPairs);
+    std::vector<long long> newOff(numPairs + 1, 0);
     for (int k = 0; k < numPairs; ++k) {
       const int a = pairFrames[2 * order[k]], b = pairFrames[2 * order[k] + 1];
       if (a < 0 || a >= h->F || b < 0 || b >= h->F) throw std::runtime_error("pair frame out of range");
-      if (k > 0 && h->pairA[k - 1] == a && h->pairB[k - 1] == b) throw std::runtime_error("duplicate frame pair");
-      h->pairA[k] = a;
-      h->pairB[k] = b;
-      h->pairOff[k + 1] = static_cast<long long>(k + 1) * npx;
+      if (k > 0 && newA[k - 1] == a && newB[k - 1] == b) throw std::runtime_error("duplicate frame pair");
+      newA[k] = a;
+      newB[k] = b;
+      newOff[k + 1] = static_cast<long long>(k + 1) * npx;
     }
+    h->tableValid = false;
+    h->pairA.swap(newA);
+    h->pairB.swap(newB);
+    h->pairOff.swap(newOff);
     hipStream_t s = h->stream;
     h->dFlow.ensure(static_cast<size_t>(std::max(numPairs, 1)) * npx);
     h->dFMask.ensure(static_cast<size_t>(std::max(numPairs, 1)) * npx);
@@ -420,6 +427,12 @@ int32_t cvd_set_pair_flows(cvd_handle* h, int32_t numPairs, const int32_t* pairF
     h->dense = true;
     h->tableValid = false;
   });
+}
+
+int32_t cvd_dense_mode_supported(const cvd_opt_params* p, const cvd_xform_desc* depth, const cvd_xform_desc* spatial,
+                                 int32_t have_triplets, int32_t world_size, int32_t problem) {
+  if (!p || !depth || !spatial) return 0;
+  return denseModeSupported(*p, *depth, *spatial, have_triplets != 0, world_size, problem == 1) ? 1 : 0;
 }
 
 int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t numTriplets, const int32_t* centers, const int64_t* offsets,

@@ -10,7 +10,7 @@
 // A_c = Z^T A Z is block-sparse on the frame graph (8x8 blocks, one per frame and per undirected frame pair):
 //   * off-diagonal blocks  sum_c rho' (J_a Z_a)^T (J_b Z_b)           k_coarse_edges   (once per linearisation)
 //   * diagonal blocks      Z_f^T (H_ff + diag(lam_f)) Z_f             k_coarse_diag    (once per LM iteration)
-//   * block-sparse Cholesky A_c = L L^T on a host-computed plan        k_coarse_factor  (one workgroup)
+//   * block-sparse Cholesky A_c = L L^T on a host-computed plan        k_coarse_factor_mw (32 workgroups, grid barrier per level)
 //   * W = L^-1, block-sparse: W_ij != 0 only if i is an ancestor of j in the elimination tree; its columns are
 //     independent chains, one wave each                                k_coarse_winv
 //   * per PCG iteration y = W Z^T r (k_coarse_apply_w, which also closes the PCG scalars: r^T Z c = |y|^2); the
@@ -416,145 +416,9 @@ inline __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Block-sparse Cholesky A_c = L L^T, one workgroup, left-looking by levels of the elimination plan:
-//   A: every block (i, j) of the level's columns gathers  A_ij - sum_k L_ik L_jk^T   (complete: k is in a lower level)
-//   B: diagonal blocks: dense 8x8 Cholesky and the inverse of its factor (Linv)
-//   C: off-diagonal blocks: L_ij = (gathered) Linv_jj^T
-// One wave per block, lane = (row, column) of the 8x8 block.
-// ---------------------------------------------------------------------------------------------------------
-inline __global__ __launch_bounds__(1024) void k_coarse_factor(CoarsePlan P, const double* __restrict__ diag,
-                                                        const double* __restrict__ edges,
-                                                        const unsigned char* __restrict__ modeActive,
-                                                        double* __restrict__ Lb, double* __restrict__ Linv,
-                                                        int* __restrict__ fail) {
-  __shared__ double scratch[16][2 * kCBB];
-  __shared__ double fold[16][kCBB];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int r = lane >> 3, c = lane & 7;
-  const int nW = blockDim.x >> 6;
-  // load: diagonal blocks by position, edge blocks (masked by the mode flags, transposed if needed), fill = 0
-  for (int b = wv; b < P.nBlocks; b += nW) Lb[static_cast<size_t>(b) * kCBB + lane] = 0.0;
-  __syncthreads();
-  for (int j = wv; j < P.F; j += nW) Lb[static_cast<size_t>(j) * kCBB + lane] = diag[static_cast<size_t>(P.order[j]) * kCBB + lane];
-  for (int e = wv; e < P.nEdges; e += nW) {
-    const int code = P.edgeBlk[e];
-    const int b = code >> 1, tr = code & 1;
-    const int fa = P.edgeFa[e], fb = P.edgeFb[e];
-    // stored rows = fa, columns = fb; block (i, j) has rows = frame of position i
-    const int ra = tr ? c : r, cb2 = tr ? r : c;  // element of the stored block that lands at (r, c)
-    double v = edges[static_cast<size_t>(e) * kCBB + ra * kCB + cb2];
-    if (!modeActive[fa * kCB + ra] || !modeActive[fb * kCB + cb2]) v = 0.0;
-    Lb[static_cast<size_t>(b) * kCBB + lane] = v;
-  }
-  __syncthreads();
-  for (int lv = 0; lv < P.nLevels; ++lv) {
-    // ---- A: gather updates (operand blocks staged through LDS, the next pair prefetched into registers).
-    // Wide levels: one wave per block.  Narrow levels (the top of the tree: few blocks, long update lists): all
-    // waves split the list of one block and their partial sums are folded in wave order.
-    const int q0 = P.lvlBlkPtr[lv], q1 = P.lvlBlkPtr[lv + 1];
-    const bool coop = (q1 - q0) < nW;
-    for (int q = coop ? q0 : q0 + wv; q < q1; q += coop ? 1 : nW) {
-      const int b = P.lvlBlks[q];
-      const int u0 = P.updPtr[b], u1 = P.updPtr[b + 1];
-      const int ustep = coop ? nW : 1;
-      double acc = 0.0;
-      double* sA = scratch[wv];
-      double* sB = scratch[wv] + kCBB;
-      double na = 0.0, nb = 0.0;
-      int uidx = coop ? u0 + wv : u0;
-      if (uidx < u1) {
-        na = Lb[static_cast<size_t>(P.updA[uidx]) * kCBB + lane];
-        nb = Lb[static_cast<size_t>(P.updB[uidx]) * kCBB + lane];
-      }
-      for (; uidx < u1; uidx += ustep) {
-        sA[lane] = na;
-        sB[lane] = nb;
-        CVD_WAVE_SYNC();
-        if (uidx + ustep < u1) {
-          na = Lb[static_cast<size_t>(P.updA[uidx + ustep]) * kCBB + lane];
-          nb = Lb[static_cast<size_t>(P.updB[uidx + ustep]) * kCBB + lane];
-        }
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < kCB; ++m) s += sA[r * kCB + m] * sB[c * kCB + m];
-        acc += s;
-        CVD_WAVE_SYNC();
-      }
-      if (!coop) {
-        Lb[static_cast<size_t>(b) * kCBB + lane] -= acc;
-      } else {
-        fold[wv][lane] = acc;
-        __syncthreads();
-        if (wv == 0) {
-          double t = 0.0;
-          for (int w = 0; w < nW; ++w) t += fold[w][lane];
-          Lb[static_cast<size_t>(b) * kCBB + lane] -= t;
-        }
-        __syncthreads();
-      }
-    }
-    __syncthreads();
-    // ---- B: diagonal blocks of the level
-    for (int q = P.levelPtr[lv] + wv; q < P.levelPtr[lv + 1]; q += nW) {
-      const int j = P.levelCols[q];
-      double* S = scratch[wv];
-      S[lane] = Lb[static_cast<size_t>(j) * kCBB + lane];
-      // in-place Cholesky (lower), one wave, lane = (r, c)
-      for (int k = 0; k < kCB; ++k) {
-        CVD_WAVE_SYNC();
-        double d = S[k * kCB + k];
-        if (!(d > 0.0)) {
-          if (lane == 0) atomicAdd(fail, 1);
-          d = 1.0;
-        }
-        const double sd = sqrt(d);
-        const double lrk = S[r * kCB + k] / sd, lck = S[c * kCB + k] / sd;
-        CVD_WAVE_SYNC();
-        if (c == k && r >= k) S[lane] = (r == k) ? sd : lrk;
-        else if (r > k && c > k && c <= r) S[lane] -= lrk * lck;
-      }
-      CVD_WAVE_SYNC();
-      if (c > r) S[lane] = 0.0;
-      CVD_WAVE_SYNC();
-      Lb[static_cast<size_t>(j) * kCBB + lane] = S[lane];
-      // inverse of the lower-triangular factor: lane c < 8 solves column c by forward substitution
-      double* Iv = Linv + static_cast<size_t>(j) * kCBB;
-      if (lane < kCB) {
-        double col[kCB];
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-          double v = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-          for (int m = 0; m < kCB; ++m)
-            if (m < i) v -= S[i * kCB + m] * col[m];
-          col[i] = v / S[i * kCB + i];
-        }
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) Iv[i * kCB + lane] = col[i];
-      }
-    }
-    __syncthreads();
-    // ---- C: off-diagonal blocks of the level's columns: L_ij = G Linv_jj^T
-    for (int q = P.lvlBlkPtr[lv] + wv; q < P.lvlBlkPtr[lv + 1]; q += nW) {
-      const int b = P.lvlBlks[q];
-      if (b < P.F) continue;
-      const int j = P.blkCol[b];
-      const double* G = Lb + static_cast<size_t>(b) * kCBB + r * kCB;
-      const double* Iv = Linv + static_cast<size_t>(j) * kCBB + c * kCB;
-      double s = 0.0;
-#pragma unroll
-      for (int m = 0; m < kCB; ++m) s += G[m] * Iv[m];
-      CVD_WAVE_SYNC();  // every lane has read its row of G before the block is overwritten
-      scratch[wv][lane] = s;
-      CVD_WAVE_SYNC();
-      Lb[static_cast<size_t>(b) * kCBB + lane] = scratch[wv][lane];
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Multi-workgroup variant of the factorisation.  A column's work (gather for its blocks, diagonal Cholesky,
+// Block-sparse Cholesky A_c = L L^T, left-looking by levels of the elimination plan (per column: gather
+// A_ij - sum_k L_ik L_jk^T over the columns of lower levels, dense 8x8 Cholesky of the diagonal block and the inverse of
+// its factor, L_ij = G Linv_jj^T for the off-diagonal blocks), on several workgroups.  A column's work (gather for its blocks, diagonal Cholesky,
 // scaling of its off-diagonal blocks) depends only on columns of LOWER levels, so a workgroup takes whole columns
 // and the workgroups meet once per level at a grid barrier (all kCoarseFactorGroups workgroups are co-resident:
 // far fewer than CUs).  Inside a column the 16 waves split every update list and fold their partial sums in wave
@@ -588,6 +452,8 @@ inline __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, 
                                                            int* __restrict__ fail, unsigned int* __restrict__ barrier) {
   __shared__ double scratch[16][2 * kCBB];
   __shared__ double fold[16][kCBB];
+  __shared__ double foldLast[16][kCBB];
+  __shared__ int edgeBlkOf[16][2];
   constexpr int kMaxColBlk = 40;  // staging of one column: diagonal + off-diagonal blocks (20 KB)
   __shared__ double colAcc[kMaxColBlk * kCBB];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -614,19 +480,24 @@ inline __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, 
       const int nOff = P.colPtr[j + 1] - P.colPtr[j];
       // ---- gather.  The update lists of the column's blocks (diagonal: ids of block j; off-diagonal: one contiguous
       // range, their block ids are consecutive) are cut into 16 equal slices, one per wave, whatever block an entry
-      // belongs to: a wave accumulates in registers while the block stays the same and flushes into the column's LDS
-      // staging with f64 atomics when it changes.  The serial depth per column is (updates / 16) products and ONE
-      // barrier instead of one pair of barriers per block.
+      // belongs to: a wave accumulates in registers while the block stays the same and flushes when it changes.  A block in
+      // the MIDDLE of a wave's slice belongs to that wave alone (plain store into the column's LDS staging); the partial
+      // sums of the slice's FIRST and LAST block -- blocks that neighbouring slices may share -- are parked per wave and
+      // folded in wave order afterwards.  No atomics: the factor is bit-identical from run to run and from rank to rank
+      // (the ranks of a sharded solve each build it and must take the same PCG decisions).  The serial depth per column is
+      // (updates / 16) products and two barriers instead of one pair of barriers per block.
       const int d0 = P.updPtr[j], nd = P.updPtr[j + 1] - d0;
       const int ob = P.F + P.colPtr[j];
       const int o0 = P.updPtr[ob], no = P.updPtr[ob + nOff] - o0;
       const int U = nd + no;
       if (U > 0 && nOff + 1 <= kMaxColBlk) {
         for (int i = tid; i < (nOff + 1) * kCBB; i += 1024) colAcc[i] = 0.0;
+        if (lane < 2) edgeBlkOf[wv][lane] = -1;
         __syncthreads();
         const int per = (U + 15) >> 4;
         const int i0 = wv * per, i1 = min(U, i0 + per);
         if (i0 < i1) {
+          bool firstFlush = true;
           auto entry = [&](int idx, int& u, int& blk) {
             if (idx < nd) { u = d0 + idx; blk = 0; }
             else { u = o0 + (idx - nd); blk = P.updBlk[u] - ob + 1; }
@@ -653,10 +524,27 @@ inline __global__ __launch_bounds__(1024) void k_coarse_factor_mw(CoarsePlan P, 
             acc += s;
             CVD_WAVE_SYNC();
             if (nblk != blk) {  // wave-uniform
-              atomicAdd(&colAcc[blk * kCBB + lane], acc);
+              if (firstFlush) {
+                fold[wv][lane] = acc;
+                if (lane == 0) edgeBlkOf[wv][0] = blk;
+              } else if (nblk < 0) {
+                foldLast[wv][lane] = acc;
+                if (lane == 0) edgeBlkOf[wv][1] = blk;
+              } else {
+                colAcc[blk * kCBB + lane] = acc;
+              }
+              firstFlush = false;
               acc = 0.0;
               blk = nblk;
             }
+          }
+        }
+        __syncthreads();
+        if (wv == 0) {
+          for (int w2 = 0; w2 < 16; ++w2) {
+            const int b0 = edgeBlkOf[w2][0], b1 = edgeBlkOf[w2][1];
+            if (b0 >= 0) colAcc[b0 * kCBB + lane] += fold[w2][lane];
+            if (b1 >= 0) colAcc[b1 * kCBB + lane] += foldLast[w2][lane];
           }
         }
         __syncthreads();
@@ -931,8 +819,8 @@ inline __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, in
 // sampler's hierarchical flow list (~10 k block updates at 300 frames), hopeless for a flow list with long-range pairs
 // from nearly every frame (the "~4k pairs" list of BASELINE.json: ~10^6 updates, 44 ms per factorisation).  For such
 // graphs the coarse matrix (8 F unknowns: 2400 at 300 frames) is simply treated as dense: assembled from the same
-// diagonal / edge blocks, inverted by rocSOLVER (potrf + potri: the one plain dense library solve of this path) and
-// applied as an f32 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
+// diagonal / edge blocks, inverted by ONE persistent kernel on the f64 matrix cores (k_dense_spd_inverse,
+// cvd_dense_inverse.h) and applied as an f32 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
 // r^T z, 23 MB streamed).  Unknowns in FRAME order (8 f + mode); inactive modes are identity rows.
 // ---------------------------------------------------------------------------------------------------------
 inline __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges, const double* __restrict__ diag,
@@ -953,30 +841,10 @@ inline __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int 
   }
 }
 
-// potri(lower) on the column-major view leaves the inverse in what is the UPPER triangle of the row-major array:
-// mirrored into a full symmetric f32 matrix (an SPD approximation is all the preconditioner needs).  info != 0: the
-// factorisation met a non-positive pivot.  The coarse matrix is singular along the gauge directions up to the LM
-// damping, so with a small damping this happens now and then (and not reproducibly: rocBLAS sums in varying order).  A
-// rebuild beside the solver then hands back a copy of the inverse in use (`keep`: nothing changes at the swap); a
-// first build has nothing to fall back on and switches the level off through `fail`.
-inline __global__ __launch_bounds__(256) void k_coarse_dense_pack(int n, const double* __restrict__ A, const int* __restrict__ info,
-                                                           float* __restrict__ out, int* __restrict__ fail,
-                                                           const float* __restrict__ keep) {
-  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
-  const bool bad = info[0] != 0 || info[1] != 0;
-  if (idx == 0 && bad && keep == nullptr) *fail = 1;
-  if (idx >= static_cast<size_t>(n) * n) return;
-  if (bad && keep != nullptr) {
-    out[idx] = keep[idx];
-    return;
-  }
-  const size_t r = idx / n, c = idx - r * n;
-  out[idx] = static_cast<float>(c >= r ? A[r * n + c] : A[c * n + r]);
-}
-
 // Frame blocks beyond the register-resident inverses (B > 256: ScaleShift value transforms on the 17x10 grid, B = 347): the
 // block-Jacobi inverses go through rocSOLVER's strided-batched potrf / potri.  k_blocks_add_diag forms H_ff + diag(lam) in
-// a scratch copy, k_blocks_pack mirrors the inverse (left in the row-major array's upper triangle, see k_coarse_dense_pack)
+// a scratch copy, k_blocks_pack mirrors the inverse
+// (rocSOLVER's potri(lower) on the column-major view leaves the inverse in the UPPER triangle of the row-major array)
 // into the f32 blocks; a block whose factorisation failed becomes the inverse of its diagonal and is counted in `fail`.
 inline __global__ __launch_bounds__(256) void k_blocks_add_diag(int B, size_t total, const double* __restrict__ H,
                                                          const double* __restrict__ lam, double* __restrict__ out) {

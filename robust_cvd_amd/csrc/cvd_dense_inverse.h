@@ -36,6 +36,13 @@ namespace cvd {
 
 constexpr int kDinvNW = 8;  // waves per workgroup
 
+#ifdef CVD_DINV_PROFILE  // tools/dinv_bench.hip: shader-clock cycles per phase, wave and workgroup
+__device__ unsigned long long g_dinvProf[256 * kDinvNW * 8];
+#define CVD_DINV_T(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[slot] += t_ - tLast; tLast = t_; } while (0)
+#else
+#define CVD_DINV_T(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ void dinvStore(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -47,6 +54,9 @@ __device__ __forceinline__ double dinvLoad(const double* p) {
 
 // Arrive at the monotonic counter (counter[0]) and wait for `target` arrivals.  Returns false when the kernel is being
 // abandoned (a workgroup timed out: counter[1] != 0, and bit 30 of *fail is set); uniform over the workgroup.
+// (A split-phase variant -- arrive right after publishing, update the tiles nobody else needs, then wait -- was measured
+// and is slower: a step is bound by three dependent memory round trips (drain of the write-through stores ~2.5 us, the
+// counter, the agent-scope panel loads) plus the 16 scalar pivots, not by the rank-16 updates it would have hidden.)
 __device__ __forceinline__ bool dinvGridBarrier(unsigned int* counter, unsigned int target, int* fail, int* ldsFlag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through payload stores have landed
   __syncthreads();
@@ -85,6 +95,8 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
                                                                            unsigned int* __restrict__ barrier, int* __restrict__ outValid) {
   extern __shared__ __attribute__((aligned(16))) double dinvSmem[];
   __shared__ int barrierOk;
+  // S^2 <= 8 TPW tiles per workgroup => (2 S + 1) x 256 panel elements over 512 threads
+  constexpr int kPanelLoads = (TPW <= 2 ? 4 : TPW <= 5 ? 6 : TPW <= 8 ? 8 : TPW <= 13 ? 10 : TPW <= 18 ? 12 : 14) + 1;
   const int nT = (n + kInvTS - 1) / kInvTS;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,6 +142,7 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   // pivot tile (k, k), inverted in-wave by its owner.
   auto publish = [&](int k) {
     double* pk = panel + static_cast<size_t>(k & 1) * nT * 256;
+    bool ownsPivot = false;
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       if (DINV_I(s) < 0) continue;
@@ -151,53 +164,76 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
       } else if (DINV_I(s) == k && DINV_J(s) == k) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int row = lane & 15, cg = lane >> 4;
-        double g[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = scratch[row * kInvLd + 4 * cg + e];
-        int bad = 0;
-        invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
-        invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
-        invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
-        invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
-        invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
-        invPivotStep<15>(g, row, cg, bad);
-        if (bad && lane == 0) atomicAdd(barrier + 2, 1u);
-        double* dst = pinv + static_cast<size_t>(k & 1) * 256;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dinvStore(dst + row * 16 + 4 * cg + e, g[e]);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        ownsPivot = true;
       }
+    }
+    if (ownsPivot) {  // wave-uniform; the 16 scalar pivots exist ONCE in the code, not once per tile slot
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int row = lane & 15, cg = lane >> 4;
+      double g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = scratch[row * kInvLd + 4 * cg + e];
+      int bad = 0;
+      invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
+      invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
+      invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
+      invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
+      invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
+      invPivotStep<15>(g, row, cg, bad);
+      if (bad && lane == 0) atomicAdd(barrier + 2, 1u);
+      double* dst = pinv + static_cast<size_t>(k & 1) * 256;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dinvStore(dst + row * 16 + 4 * cg + e, g[e]);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   };
 
+#ifdef CVD_DINV_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tLast = __builtin_amdgcn_s_memtime();
+#endif
   publish(0);
+  CVD_DINV_T(0);
   const unsigned int nGroups = gridDim.x;
   bool alive = true;
   for (int k = 0; k < nT; ++k) {
     if (!dinvGridBarrier(barrier, static_cast<unsigned int>(k + 1) * nGroups, fail, &barrierOk)) { alive = false; break; }
-    // ---- the panel tiles of this super-tile's row and column blocks, and -P, into LDS
+    CVD_DINV_T(1);
+    // ---- the panel tiles of this super-tile's row and column blocks, and -P, into LDS.  ALL of a thread's loads are issued
+    // before the first is used: written as load-then-store per element the agent-scope loads ran one global round trip after
+    // the other (8 per step, most of a step's duration)
     {
       const double* pk = panel + static_cast<size_t>(k & 1) * nT * 256;
       const double* pp = pinv + static_cast<size_t>(k & 1) * 256;
       const int total = (2 * S + 1) * 256;
-      for (int e = threadIdx.x; e < total; e += kDinvNW * 64) {
+      double v[kPanelLoads];
+      int dstOff[kPanelLoads];
+#pragma unroll
+      for (int u = 0; u < kPanelLoads; ++u) {
+        const int e = threadIdx.x + u * (kDinvNW * 64);
         const int t = e >> 8, q = e & 255, rr = q >> 4, cc = q & 15;
-        if (t == 2 * S) {
-          piv[rr * kInvLd + cc] = dinvLoad(pp + q);
-        } else {
+        const double* src = pp + q;                         // (always a valid address: the loads are unconditional)
+        int off = (4 * S) * kInvTile + rr * kInvLd + cc;    // piv
+        bool zero = false;
+        if (t < 2 * S) {
           const int m = t < S ? t : t - S;
           const int blk = (t < S ? rowBase : colBase) + m;
-          double v = 0.0;
-          if (blk < nT && blk != k) v = dinvLoad(pk + static_cast<size_t>(blk) * 256 + q);
-          (t < S ? arow : acol)[m * kInvTile + rr * kInvLd + cc] = v;
+          off = (t < S ? 0 : S * kInvTile) + m * kInvTile + rr * kInvLd + cc;   // arow / acol
+          src = pk + static_cast<size_t>(min(blk, nT - 1)) * 256 + q;
+          zero = blk >= nT || blk == k;                     // (no such panel tile: its slot reads as zero)
         }
+        dstOff[u] = e < total ? off : -1;
+        const double raw = dinvLoad(src);
+        v[u] = zero ? 0.0 : raw;
       }
+#pragma unroll
+      for (int u = 0; u < kPanelLoads; ++u)
+        if (dstOff[u] >= 0) dinvSmem[dstOff[u]] = v[u];
     }
     __syncthreads();
+    CVD_DINV_T(2);
     // ---- -T_m = A(m, k) (-P): the row blocks, and the column blocks when block row k lies in this super-tile
     const bool hasRowK = k >= rowBase && k < rowBase + S;
     for (int m = w; m < (hasRowK ? 2 * S : S); m += kDinvNW) {
@@ -211,38 +247,39 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
       for (int r = 0; r < 4; ++r) dst[(r0 + 4 * r) * kInvLd + c] = t[r];
     }
     __syncthreads();
-    // ---- rank-16 update of every owned tile (tiles of block row / column k read zeroed panel slots; replaced below)
+    CVD_DINV_T(3);
+    // ---- rank-16 update G_ij += (-T_i) A(j, k)^T of every owned tile; tiles of block row / column k (they read zeroed panel
+    // slots) and the pivot tile are replaced
     const int laneOp = c * kInvLd + r0;
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
-      int oa = (tCode[s] < 0 ? 0 : DINV_LI(s)) * kInvTile, ob = (tCode[s] < 0 ? 0 : DINV_LJ(s)) * kInvTile;
-      asm volatile("" : "+s"(oa), "+s"(ob));
-      const double* ta = tneg + oa + laneOp;
-      const double* pb = acol + ob + laneOp;
+      const int I = DINV_I(s), J = DINV_J(s);
+      if (I < 0) continue;   // wave-uniform
+      const int oa = DINV_LI(s) * kInvTile, ob = DINV_LJ(s) * kInvTile;
+      if (I != k && J != k) {
+        const double* ta = tneg + oa + laneOp;
+        const double* pb = acol + ob + laneOp;
+        double a[4], b[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4 * kk], pb[4 * kk], acc[s], 0, 0, 0);
-    }
+        for (int kk = 0; kk < 4; ++kk) { a[kk] = ta[4 * kk]; b[kk] = pb[4 * kk]; }
 #pragma unroll
-    for (int s = 0; s < TPW; ++s) {
-      if (DINV_I(s) < 0 || (DINV_I(s) != k && DINV_J(s) != k)) continue;
-      if (DINV_I(s) == k && DINV_J(s) == k) {
+        for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc[s], 0, 0, 0);
+      } else if (I == k && J == k) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[s][r] = piv[(r0 + 4 * r) * kInvLd + c];
-      } else if (DINV_J(s) == k) {  // i > k: G_ik <- T_i
-        int o = (tCode[s] < 0 ? 0 : DINV_LI(s)) * kInvTile;
-        asm volatile("" : "+s"(o));
-        const double* src = tneg + o;
+      } else if (J == k) {  // i > k: G_ik <- T_i
+        const double* src = tneg + oa;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[s][r] = -src[(r0 + 4 * r) * kInvLd + c];
-      } else {                  // j < k: G_kj <- T_j^T
-        int o = (tCode[s] < 0 ? 0 : DINV_LJ(s)) * kInvTile;
-        asm volatile("" : "+s"(o));
-        const double* src = tnegc + o;
+      } else {              // j < k: G_kj <- T_j^T
+        const double* src = tnegc + ob;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[s][r] = -src[c * kInvLd + r0 + 4 * r];
       }
     }
+    CVD_DINV_T(4);
     if (k + 1 < nT) publish(k + 1);
+    CVD_DINV_T(5);
   }
   if (!alive) return;
   // (every pivot was inverted before the last barrier: the count is final)
@@ -277,6 +314,11 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
       __builtin_amdgcn_wave_barrier();
     }
   }
+#ifdef CVD_DINV_PROFILE
+  CVD_DINV_T(6);
+  if (lane == 0 && blockIdx.x < 256)
+    for (int q = 0; q < 8; ++q) g_dinvProf[(blockIdx.x * kDinvNW + w) * 8 + q] = prof[q];
+#endif
 }
 
 #undef DINV_LI

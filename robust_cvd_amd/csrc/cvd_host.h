@@ -509,6 +509,8 @@ void tapCounts(const Layout& L, int& KD, int& KS);
 bool fastLoss(const Layout& L);
 Table makeTable(cvd_handle* h);
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip);
+bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const cvd_xform_desc& sd, bool haveTriplets, int world,
+                        bool normalize);
 AsmPanels makePanels(int B, size_t capDoubles, int& panelCap);
 void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplets = false, bool ignoreStatic = false);
 double* pinnedStage(cvd_handle* h, int which, size_t n);

@@ -350,6 +350,29 @@ Table makeTable(cvd_handle* h) {
   T.invAspect = h->invAspect;
   return T;
 }
+// Scope of the dense mode as a function of the CALLER's parameters (cvd_dense_mode_supported: lib_python asks before it hands
+// a matchSeparation = 0 collection over as images instead of a list) -- the same conditions checkDenseScope
+// enforces at solve time, for every step of the schedule the parameters describe.
+bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const cvd_xform_desc& sd, bool haveTriplets, int world,
+                        bool normalize) {
+  if (world > 1) return false;
+  if (normalize) return p.normalize_depth_from_first_frame != 0;  // (the pair loop's DisparityDissimilarityCost is a generic-kernel loss)
+  if (sd.spatial_type != CVD_SPATIAL_IDENTITY || p.deferred_spatial_opt) return false;
+  if (p.static_loss_type != CVD_STATIC_REPRO_DISPARITY && p.static_loss_type != CVD_STATIC_REPRO_DEPTH_RATIO &&
+      p.static_loss_type != CVD_STATIC_REPRO_LOG_DEPTH)
+    return false;
+  if (dd.depth_type == CVD_DEPTH_IDENTITY) return true;
+  if (dd.value_xform != CVD_VALUE_SCALE) return false;
+  if (dd.depth_type == CVD_DEPTH_GRID && (dd.cubic_interpolation || dd.grid_size[2] > 1)) return false;
+  if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && haveTriplets) return false;
+  if (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) return false;
+  if (p.intr_opt == CVD_INTR_SHARED) return false;
+  // the largest frame block of the schedule must stay within the fast kernels' 256 unknowns
+  long long g = dd.depth_type == CVD_DEPTH_GRID ? static_cast<long long>(dd.grid_size[0]) * dd.grid_size[1] : 1;
+  if (p.coarse_to_fine && p.num_steps > 1) g = std::max(g, static_cast<long long>(p.ctf_long) * p.ctf_short);
+  return 7 + g <= 256;
+}
+
 // Dense mode runs on the specialised fast kernels only (the default residual configuration of the reference pipeline).
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
   if (!h->dense) return;

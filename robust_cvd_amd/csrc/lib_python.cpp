@@ -990,7 +990,9 @@ struct FlowConstraintsCollection {
     };
     const size_t px = static_cast<size_t>(w) * h;
     const size_t batch = std::max<size_t>(1, (512ull << 20) / (px * 18));  // ~512 MiB of flow + mask per call
-    const bool keepDense = params_.matchSeparation == 0 && !(haveDyn && params_.minDynamicDistance > 0);
+    // (with a dynamic mask the sampler rejects pixels whose distance is not > minDynamicDistance -- the pixels INSIDE the mask
+    // (distance 0) already at minDynamicDistance = 0 --: the kept images would then hold constraints the list does not)
+    const bool keepDense = params_.matchSeparation == 0 && !(haveDyn && params_.minDynamicDistance >= 0);
     denseFlow_.clear();
     denseMask_.clear();
     denseValid_ = false;
@@ -1320,7 +1322,7 @@ struct DepthVideoProcessor {
     c.normalize_depth_from_first_frame = p.normalizeDepthFromFirstFrame;
     return c;
   }
-  void upload(Session& s, const DvpParams& p, const FlowConstraintsCollection& fc) {
+  void upload(Session& s, const DvpParams& p, const FlowConstraintsCollection& fc, bool forNormalize) {
     DepthStream& ds = *video_->depthStreams_.at(p.depthStream);
     s.h = cvd_create(device_);
     if (!s.h) throw std::runtime_error(cvd_last_error(nullptr));
@@ -1369,8 +1371,15 @@ struct DepthVideoProcessor {
     }
     // matchSeparation = 0 collections whose flow images are at hand and match the depth stream's raster go to the solver as
     // images (dense mode: nothing materialised on the device); LIB_PYTHON_NO_DENSE forces the list (comparison / tests)
+    // -- and only when the solve these parameters describe lies within the dense mode's scope (the library fails outside it
+    // instead of falling back: the list path serves every configuration)
+    std::vector<int32_t> scopeRange;
+    const cvd_opt_params scopeParams = toC(p.poseOptimizer, scopeRange);
+    const cvd_xform_desc scopeDd = ds.depthXformDesc_.toC(), scopeSd = ds.spatialXformDesc_.toC();
     const bool denseHandOver = fc.denseValid_ && fc.denseW_ == w && fc.denseH_ == h && std::getenv("LIB_PYTHON_NO_DENSE") == nullptr &&
-                               fc.denseMask_.size() == fc.pairs_.size() * static_cast<size_t>(w) * h && fc.allPairConstraintsStatic();
+                               fc.denseMask_.size() == fc.pairs_.size() * static_cast<size_t>(w) * h && fc.allPairConstraintsStatic() &&
+                               cvd_dense_mode_supported(&scopeParams, &scopeDd, &scopeSd, fc.triplets_.empty() ? 0 : 1, 1,
+                                                        forNormalize ? 1 : 0) == 1;
     usedFlowImages_ = denseHandOver;
     if (denseHandOver) {
       std::vector<int32_t> pf;
@@ -1485,7 +1494,7 @@ struct DepthVideoProcessor {
   }
   void normalizeDepth(const DvpParams& p, const FlowConstraintsCollection& fc) {  // reference :1015-1019
     Session s;
-    upload(s, p, fc);
+    upload(s, p, fc, true);
     std::vector<int32_t> range;
     const cvd_opt_params c = toC(p.poseOptimizer, range);
     {
@@ -1496,7 +1505,7 @@ struct DepthVideoProcessor {
   }
   void optimizePoses(const DvpParams& p, const FlowConstraintsCollection& fc) {  // reference :1021-1025
     Session s;
-    upload(s, p, fc);
+    upload(s, p, fc, false);
     std::vector<int32_t> range;
     const cvd_opt_params c = toC(p.poseOptimizer, range);
     if (p.poseOptimizer.huberLoss) {

@@ -508,6 +508,44 @@ def test_match_separation_zero_goes_to_the_solver_as_images(lib, tmp_path, monke
 
 
 @pytest.mark.gpu
+def test_match_separation_zero_outside_the_dense_scope_takes_the_list(lib, tmp_path):
+    """A matchSeparation = 0 collection with a residual configuration the dense mode does not cover (here: the Euclidean loss; the
+    same holds for cubic grids, spatial transforms, smoothness, shared intrinsics, ScaleShift) must go to the solver as the
+    materialised LIST, as it did before the image hand-over existed -- not fail in the library's scope check
+    (cvd_dense_mode_supported)."""
+    import json
+    from tests.drop_in_caller import CV_32FC3, optimize_poses
+    v = synth.make_video(6, 64, 40, seed=72)
+    flows, masks = synth.make_dense_flows(v)
+    F, H, W = v.num_frames, v.height, v.width
+    colors = np.random.default_rng(6).uniform(0, 1, (F, H, W, 3)).astype(np.float32)
+    base = dataset_io.write_dataset(str(tmp_path / "v"), v)
+    os.remove(os.path.join(base, "flow_constraints.dat"))
+    with open(os.path.join(base, "flow_list.json"), "w") as f:
+        json.dump([["src", "dst"]] + v.pairs.tolist(), f)
+    dataset_io.write_flow_inputs(base, v.pairs, flows, masks, colors)
+    dv = lib.DepthVideo()
+    lib.DepthVideoImporter.importVideo(dv, base, False)
+    dv.createColorStream("full", "color_full", ".png", CV_32FC3)
+    dv.createColorStream("down", "color_down", ".raw", CV_32FC3)
+    dv.createDepthStream("depth_midas2", "depth_midas2", [-1, -1])
+    dv.save()
+    fcp = lib.FlowConstraintsParams()
+    fcp.frameRange.resolve(dv.numFrames(), True)
+    fcp.matchSeparation = 0
+    fc = lib.FlowConstraintsCollection(dv, fcp)
+    assert fc.holdsFlowImages()
+    opt = lib.DepthVideoPoseOptimizer.Params()
+    opt.ctfLong, opt.ctfShort = 4, 3
+    opt.staticLossType = lib.StaticLossType.Euclidean
+    proc = optimize_poses(lib, dv, fc, list(range(F)), opt)   # (raised "dense mode ... supports" before)
+    assert not proc.usedFlowImages
+    ds = dv.depthStream(dv.numDepthStreams() - 1)
+    assert ds.depthXformDesc().str() == "Grid(Scale, Linear, 4, 3, 1)"
+    assert np.isfinite(np.stack([np.asarray(ds.frame(f).extrinsics.position) for f in range(F)])).all()
+
+
+@pytest.mark.gpu
 def test_flow_guided_filter_op_matches_the_oracle(lib, tmp_path):
     """filter_depth() of the reference (pose_optimization.py:295-325): Op.Copy then Op.FlowGuidedFilter with
     frameRadius = radius, through the files of the dataset; result = the oracle's filter on the same arrays."""
