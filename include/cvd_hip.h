@@ -26,13 +26,14 @@ typedef struct cvd_handle_t cvd_handle;
 /* Inner linear solver / LM knobs that have no counterpart in the reference (Ceres' SPARSE_NORMAL_CHOLESKY
  * is replaced by a block-Jacobi preconditioned conjugate-gradient solve on the device). */
 typedef struct cvd_solver_options {
-  double pcg_relative_tolerance; /* eta: the PCG stops when sqrt(r^T M^-1 r) <= eta * its initial value.  Default 5e-3:
+  double pcg_relative_tolerance; /* eta: the PCG stops when sqrt(r^T M^-1 r) <= eta * its initial value.  Default 1e-3:
                                     the reference's SPARSE_NORMAL_CHOLESKY takes EXACT LM steps, and the iterate at which
-                                    function_tolerance stops them is only reproduced (to the 1e-3 pose tolerance of
-                                    BASELINE.json) when every step is this accurate -- measured on BASELINE configs[0..2]:
-                                    eta 0.1 (Ceres' own inexact-step default) ends 1.2e-3..2.8e-3 away from the exact-step
-                                    end state and may stop at a different iteration, 1e-2 within 5.2e-4, 3e-3 within 1.1e-4
-                                    (profiles/r02_parity_sweep.log) */
+                                    function_tolerance (1e-6 relative cost change) stops them is only reproduced -- to the
+                                    1e-3 pose tolerance of BASELINE.json -- when every step is this accurate.  On BASELINE
+                                    configs[0..2] 5e-3 sufficed (round 2's default); on the BENCHMARKED 4140-pair problem it
+                                    takes one LM iteration more than the exact-step solve and ends 2.0e-3 away, 2e-3 likewise,
+                                    1e-3 ends within 8.5e-5 (config0/1/2: 3.7e-5 / 6.1e-6 / 6.1e-6): profiles/r03_parity_probe.log,
+                                    DESIGN.md 4.  Ceres' own inexact-step default is 0.1. */
   int32_t pcg_max_iterations;    /* default 300 */
   int32_t pcg_check_every;       /* unused since the device mirrors its progress to the host (kept for layout) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */

@@ -39,6 +39,9 @@ def load_library():
     global _lib
     if _lib is None:
         path = _build.LIB
+        variant = os.environ.get("CVD_LIB_VARIANT")  # development: a profile build (robust_cvd_amd.build.build_variant)
+        if variant:
+            path = os.path.join(os.path.dirname(path), f"libcvd_hip_{variant}.so")
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -48,6 +48,26 @@ def _compile(unit, hipcc, verbose):
     subprocess.check_call(cmd)
 
 
+def build_variant(name, defines, units=None, verbose=False):
+    """Development: a second library lib/libcvd_hip_<name>.so with extra -D defines (profile stamps) in the given units; the other
+    units' objects are shared with the product build.  tools/ load it through CVD_LIB_VARIANT=<name>."""
+    from concurrent.futures import ThreadPoolExecutor
+    build(verbose=verbose)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    units = units or UNITS
+    objs = {u: os.path.join(OBJ, u + ".o") for u in UNITS}
+
+    def comp(u):
+        o = os.path.join(OBJ, f"{u}_{name}.o")
+        subprocess.check_call([hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, u + ".hip"), "-o", o])
+        objs[u] = o
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+        list(pool.map(comp, units))
+    out = os.path.join(_HERE, "lib", f"libcvd_hip_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [objs[u] for u in UNITS] + LINK)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

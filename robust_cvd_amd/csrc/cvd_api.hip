@@ -43,9 +43,9 @@ static void poseOptimization(cvd_handle* h, const cvd_opt_params& p) {
     h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
     h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);
     h->dQ.ensure(n + static_cast<size_t>(h->F) * kCB + 8); h->dHd.ensure(n); h->dMask.ensure(n);
-    h->dH.ensure(n * Bmax); h->dMinv.ensure(n * Bmax);
+    h->dH.ensure(n * Bmax); h->dMinv.ensure(n * Bmax + 4);
     // one undirected work item per ~768 constraints and pair: bounded by pairs + constraints / 768
-    h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / (h->dense ? kDenseChunk : kListChunk)) + 1) * 2 * Bmax);
+    h->dQPart.ensure((static_cast<size_t>(h->P) + static_cast<size_t>(h->C / (h->dense ? kDenseChunk : kListChunk)) + 1 + 3 * static_cast<size_t>(h->numCU)) * 2 * Bmax);
   }
   cvd_solve_summary total{};
   auto accumulate = [&](const cvd_solve_summary& s, bool first) {
@@ -197,7 +197,7 @@ void cvd_opt_params_default(cvd_opt_params* p) {
 }
 
 void cvd_solver_options_default(cvd_solver_options* o) {
-  o->pcg_relative_tolerance = 5e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
+  o->pcg_relative_tolerance = 1e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
   o->pcg_max_iterations = 300;
   o->pcg_check_every = 4;
   o->verbose = 0;

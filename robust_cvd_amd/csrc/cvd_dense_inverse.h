@@ -138,11 +138,45 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
     }
   }
 
-  // Publishes what step `k` will read: block column k (tiles I > k), block row k transposed (tiles J < k), and -P of the
-  // pivot tile (k, k), inverted in-wave by its owner.
+  // Slot of tile (kk, kk) in THIS wave, -1 when another wave or workgroup owns it.
+  auto pivotSlot = [&](int kk) -> int {
+    const int li = kk - rowBase;
+    if (SI != SJ || li < 0 || li >= S || kk >= nT) return -1;
+    const int l = li * S + li;
+    return (l % kDinvNW == w) ? l / kDinvNW : -1;
+  };
+  // The owner wave of pivot tile (kk, kk) inverts it in-wave (16 scalar symmetric sweeps) and publishes -P.  The 16 pivots
+  // exist ONCE in the code, not once per tile slot.
+  auto invertAndPublishPivot = [&](int kk, int slot) {
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+      if (s == slot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int row = lane & 15, cg = lane >> 4;
+    double g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = scratch[row * kInvLd + 4 * cg + e];
+    int bad = 0;
+    invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
+    invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
+    invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
+    invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
+    invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
+    invPivotStep<15>(g, row, cg, bad);
+    if (bad && lane == 0) atomicAdd(barrier + 2, 1u);
+    double* dst = pinv + static_cast<size_t>(kk & 1) * 256;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dinvStore(dst + row * 16 + 4 * cg + e, g[e]);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // Publishes the panel step `k` will read: block column k (tiles I > k) and block row k transposed (tiles J < k).
   auto publish = [&](int k) {
     double* pk = panel + static_cast<size_t>(k & 1) * nT * 256;
-    bool ownsPivot = false;
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       if (DINV_I(s) < 0) continue;
@@ -161,32 +195,7 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
         for (int r = 0; r < 4; ++r) dinvStore(dst + (r0 + 4 * r) * 16 + c, scratch[c * kInvLd + r0 + 4 * r]);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-      } else if (DINV_I(s) == k && DINV_J(s) == k) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
-        ownsPivot = true;
       }
-    }
-    if (ownsPivot) {  // wave-uniform; the 16 scalar pivots exist ONCE in the code, not once per tile slot
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int row = lane & 15, cg = lane >> 4;
-      double g[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = scratch[row * kInvLd + 4 * cg + e];
-      int bad = 0;
-      invPivotStep<0>(g, row, cg, bad);   invPivotStep<1>(g, row, cg, bad);   invPivotStep<2>(g, row, cg, bad);
-      invPivotStep<3>(g, row, cg, bad);   invPivotStep<4>(g, row, cg, bad);   invPivotStep<5>(g, row, cg, bad);
-      invPivotStep<6>(g, row, cg, bad);   invPivotStep<7>(g, row, cg, bad);   invPivotStep<8>(g, row, cg, bad);
-      invPivotStep<9>(g, row, cg, bad);   invPivotStep<10>(g, row, cg, bad);  invPivotStep<11>(g, row, cg, bad);
-      invPivotStep<12>(g, row, cg, bad);  invPivotStep<13>(g, row, cg, bad);  invPivotStep<14>(g, row, cg, bad);
-      invPivotStep<15>(g, row, cg, bad);
-      if (bad && lane == 0) atomicAdd(barrier + 2, 1u);
-      double* dst = pinv + static_cast<size_t>(k & 1) * 256;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dinvStore(dst + row * 16 + 4 * cg + e, g[e]);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   };
 
@@ -194,6 +203,10 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tLast = __builtin_amdgcn_s_memtime();
 #endif
+  {
+    const int ps = pivotSlot(0);
+    if (ps >= 0) invertAndPublishPivot(0, ps);
+  }
   publish(0);
   CVD_DINV_T(0);
   const unsigned int nGroups = gridDim.x;
@@ -251,10 +264,24 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
     // ---- rank-16 update G_ij += (-T_i) A(j, k)^T of every owned tile; tiles of block row / column k (they read zeroed panel
     // slots) and the pivot tile are replaced
     const int laneOp = c * kInvLd + r0;
+    // The next pivot tile FIRST: its owner wave updates it, inverts it and issues the -P stores before anything else, so
+    // that the stores' way to memory (~2.5 us until the drain in the grid barrier returns) overlaps this wave's other tiles.
+    const int ps = pivotSlot(k + 1);   // wave-uniform
+    if (ps >= 0) {
+#pragma unroll
+      for (int s = 0; s < TPW; ++s)
+        if (s == ps) {
+          const double* ta = tneg + DINV_LI(s) * kInvTile + laneOp;
+          const double* pb = acol + DINV_LJ(s) * kInvTile + laneOp;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4 * kk], pb[4 * kk], acc[s], 0, 0, 0);
+        }
+      invertAndPublishPivot(k + 1, ps);
+    }
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
       const int I = DINV_I(s), J = DINV_J(s);
-      if (I < 0) continue;   // wave-uniform
+      if (I < 0 || s == ps) continue;   // wave-uniform
       const int oa = DINV_LI(s) * kInvTile, ob = DINV_LJ(s) * kInvTile;
       if (I != k && J != k) {
         const double* ta = tneg + oa + laneOp;

@@ -181,6 +181,45 @@ __device__ __forceinline__ bool lastBlockArrives(unsigned int* counter, unsigned
   return *flag != 0;
 }
 
+// The same hand-off WITHOUT fences, for the three kernels of a PCG iteration (their workgroups exchange a handful of
+// doubles): the partials are published by write-through agent-scope stores (publishPartial), every storing wave drains
+// them (s_waitcnt vmcnt(0)) before the workgroup's ticket, and the last workgroup reads them back with agent-scope loads
+// (readPartial) -- cdna_hip_programming.md G16 recipe R1.  The release fence of lastBlockArrives is a buffer_wbl2 of the
+// XCD's whole L2 in EVERY workgroup and the acquire an invalidate, although nothing but the partials crosses workgroups.
+__device__ __forceinline__ void publishPartial(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double readPartial(const double* p) {
+  return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+__device__ __forceinline__ bool lastBlockArrivesLite(unsigned int* counter, unsigned int total, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its published partials have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (t == total - 1);
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+    *flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+// sum of n published partials by the whole (last) workgroup; `red` = 16 doubles of LDS
+__device__ __forceinline__ double blockSumPartials(const double* __restrict__ a, int n, double* red) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += readPartial(a + i);
+  acc = waveSum(acc);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (blockDim.x >> 6); ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
 // ---------------------------------------------------------------------------------------------------
 inline __global__ void k_frame_consts(Layout L, const double* __restrict__ x, FrameConst* __restrict__ fc) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1364,7 +1403,29 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
       xf[i] = x[base + i];
     }
   }
-  const int e0 = fiOff[f], e1 = fiOff[f + 1];  // (before the barrier: the row gather below depends on them)
+  const int e0 = fiOff[f], e1 = fiOff[f + 1];
+  // The frame's partial rows (contiguous; independent streaming loads, four in flight per thread) are summed BEFORE the
+  // barrier: they depend on nothing but the row range, so their way from L2 overlaps the vector loads above instead of
+  // following them (this kernel is a chain of dependent round trips, not a bandwidth problem).
+  double rowSum[2] = {0.0, 0.0};
+  if (L.includeStatic) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = tid + e * 256;
+      if (i >= B) continue;
+      const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int r = e0;
+      for (; r + 3 < e1; r += 4, rowp += 4 * B) {
+        a0 += rowp[0];
+        a1 += rowp[B];
+        a2 += rowp[2 * B];
+        a3 += rowp[3 * B];
+      }
+      for (; r < e1; ++r, rowp += B) a0 += rowp[0];
+      rowSum[e] = (a0 + a1) + (a2 + a3);
+    }
+  }
   __syncthreads();
   if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
 #pragma unroll
@@ -1376,22 +1437,8 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     pNew[base + i] = pv;
     pvReg[e] = pv;
     pf[i] = pv * vm[e];
-    double acc = 0.0;
-    if (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) {  // (stale partial buffer without a pair kernel)
-      // the frame's partial rows are contiguous: independent streaming loads, four in flight per thread
-      const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int e = e0;
-      for (; e + 3 < e1; e += 4, rowp += 4 * B) {
-        a0 += rowp[0];
-        a1 += rowp[B];
-        a2 += rowp[2 * B];
-        a3 += rowp[3 * B];
-      }
-      for (; e < e1; ++e, rowp += B) a0 += rowp[0];
-      acc = (a0 + a1) + (a2 + a3);
-    }
-    qf[i] = acc;
+    // (no pair kernel ran: the partial buffer is stale; shared focal: frame 0's slot collects every row's entry below)
+    qf[i] = (L.includeStatic && !(L.intrOpt == kIntrShared && i == 6)) ? rowSum[e] : 0.0;
   }
   __syncthreads();
   if (L.intrOpt == kIntrShared && f == 0 && L.includeStatic) {
@@ -1474,15 +1521,15 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
   dot = waveSum(dot);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
-  if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
+  if (tid == 0) publishPartial(fdot + f, red[0] + red[1] + red[2] + red[3]);
   if (qc != nullptr) {  // Z^T q and this frame's column of W (Z^T q) for the fused y update (CoarseStep)
     coarseRestrict(L, qf, f, tid, V.modeActive, qc);
     __syncthreads();
     coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
   }
   // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
-  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
-    const double pq = blockSumArray(fdot, L.F, red);
+  if (lastBlockArrivesLite(counter, L.F, reinterpret_cast<int*>(red + 6))) {
+    const double pq = blockSumPartials(fdot, L.F, red);
     if (tid == 0) {
       if (pqOut != nullptr) {
         *pqOut = pq;  // (this rank's share: reduced with q)
@@ -1513,9 +1560,9 @@ inline __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* _
   dot = waveSum(dot);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
-  if (tid == 0) fdot[f] = red[0] + red[1] + red[2] + red[3];
-  if (lastBlockArrives(counter, L.F, reinterpret_cast<int*>(red + 6))) {
-    const double pq = blockSumArray(fdot, L.F, red);
+  if (tid == 0) publishPartial(fdot + f, red[0] + red[1] + red[2] + red[3]);
+  if (lastBlockArrivesLite(counter, L.F, reinterpret_cast<int*>(red + 6))) {
+    const double pq = blockSumPartials(fdot, L.F, red);
     if (tid == 0) {
       scal[S_PQ] = pq;
       scal[S_ALPHA] = scal[S_RZ] / pq;
@@ -1548,13 +1595,18 @@ __device__ __forceinline__ void pcgFinishScalars(double* __restrict__ scal, int 
   scal[S_RZ] = rzs;
   scal[S_RR] = rrs;
   // Progress for the host in pinned, coherent memory, so that it can bound its run-ahead without any copy or event
-  // in the stream: [0] = iterations applied + 1 (0 = nothing yet), [1 + (iterations applied & 7)] = the done flag
-  // after exactly that many iterations (a ring: the host's decisions depend on the iteration count only, never on
-  // timing, which keeps the ranks of a multi-GPU run enqueuing the same collectives).
-  if (hostMirror != nullptr) {
-    __hip_atomic_store(hostMirror + 1 + (static_cast<int>(iters) & 7), done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(hostMirror, iters + 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  // in the stream: slot 1 + (iterations applied & 7) = 4 (iterations applied + 1) + the done flag after exactly that many
+  // iterations (a ring: the host's decisions depend on the iteration count only, never on timing, which keeps the ranks
+  // of a multi-GPU run enqueuing the same collectives).  ONE relaxed store carries both numbers: a release store after a
+  // separate flag store was a system-scope write-back of the XCD's L2 (buffer_wbl2 sc0 sc1) at the end of every iteration.
+  if (hostMirror != nullptr)
+    __hip_atomic_store(hostMirror + 1 + (static_cast<int>(iters) & 7), 4.0 * (iters + 1.0) + done, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// LDS doubles of k_cg_update's partial row sums (host and device agree on the layout)
+__host__ __device__ inline int cgUpdatePartDoubles(int B, int nThreads) {
+  return B > 256 ? nThreads : max(nThreads, 16 * ((B + 3) & ~3));
 }
 
 // alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
@@ -1577,8 +1629,8 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   const int B = L.B;
   const int nThreads = blockDim.x;
   double* rf = sm;                 // B
-  double* part = rf + B;           // nThreads partial row sums
-  double* red = part + nThreads;   // 2 * 16 wave partials + 10
+  double* part = rf + B;           // partial row sums: nThreads (B > 256) or 16 segments x 4 ceil(B / 4) rows
+  double* red = part + cgUpdatePartDoubles(B, nThreads);   // 2 * 16 wave partials + 10
   double* ypart = red + 48;        // 16 waves x kCB partial sums of the fused y update + kCB squares
   const bool fusedY = !init && cs.Wb != nullptr;
   const bool fusedDense = !init && ds.Ainv != nullptr;  // (the grid then has F extra workgroups)
@@ -1668,11 +1720,30 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
         t += __shfl_xor(t, 1, 64);
         t += __shfl_xor(t, 2, 64);
         t += __shfl_xor(t, 4, 64);
-        if (tid == 0) ds.dotPart[g] = t;
+        if (tid == 0) publishPartial(ds.dotPart + g, t);
       }
       __syncthreads();  // (psum is reused by the next frame)
     }
   } else {
+  // B <= 256: the thread's share of the f32 block M_f^-1 (see the mat-vec below) is requested FIRST -- it depends on nothing
+  // this launch computes, so its way from L2 / MALL overlaps the vector loads, the update and the barrier
+  struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+  constexpr int kMinvLoads = 8;   // rows j = sg, sg + nSeg, ...: the first 8 of up to ceil(256 / 16) = 16 (16 spill at the
+                                  // 128 registers a 1024-thread workgroup leaves a wave; the rest follows after the barrier)
+  const bool wide = B > 256;  // (two segments per row: blockDim = 128 * ceil(B / 64) <= 1024)
+  const float* Mf = minv + static_cast<size_t>(f) * B * B;
+  const int nQ = (B + 3) >> 2;
+  const int nSeg = min(16, nThreads / nQ);
+  const int q4 = tid % nQ, sg = tid / nQ;
+  F4u mreg[kMinvLoads];
+  if (!wide && sg < nSeg) {
+    const float* col = Mf + 4 * q4;
+#pragma unroll
+    for (int u = 0; u < kMinvLoads; ++u) {
+      const int j = sg + u * nSeg;
+      if (u * nSeg < B) mreg[u] = *reinterpret_cast<const F4u*>(col + static_cast<size_t>(min(j, B - 1)) * B);  // (uniform test)
+    }
+  }
   {
     // one element per thread (blockDim = 256 * ceil(B / 64) >= B).  The vector loads are issued together with the
     // scalars' and the convergence flag is tested once they are back: one dependent global round trip instead of two
@@ -1723,8 +1794,6 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   }
   // preconditioner blocks are stored in f32 (an SPD approximation is all PCG needs; halves the traffic),
   // applied with f64 accumulation.  Symmetric block: column access, coalesced over the row index.
-  const float* Mf = minv + static_cast<size_t>(f) * B * B;
-  const bool wide = B > 256;  // (two segments per row: blockDim = 128 * ceil(B / 64) <= 1024)
   const int chunk = wide ? tid >> 7 : tid >> 8, row = tid & 63, seg = wide ? (tid >> 6) & 1 : (tid >> 6) & 3;
   const int i = chunk * 64 + row;
   double acc = 0.0;
@@ -1742,37 +1811,70 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
       for (; j < B; j += 2) a0 += static_cast<double>(col[static_cast<size_t>(j) * B]) * rf[j];
       acc = (a0 + a1) + (a2 + a3);
     }
-  } else if (i < B) {
-    // eight independent column loads in flight per thread (the loop is latency-bound: 4 B per lane and load)
+  } else {
+    // Thread = (QUAD of rows 4 q .. 4 q + 3, j-segment): one 16-byte load fetches the quad's entries of block row j (the
+    // block is symmetric: row j = column j; consecutive lanes = consecutive quads, so a wave reads contiguous bytes of a
+    // row), up to 16 independent loads per thread all in flight.  4 B per lane and load (thread = one row) made this half of
+    // the launch latency-bound at 2.4 TB/s of L2/MALL-resident data.  The rows are only 4-byte aligned (B is odd in every
+    // level of the default schedule): global dwordx4 loads need no more.  A quad that reaches past the end of a row reads
+    // the head of the next one (past the last frame: the allocation's slack) into lanes whose sums are never used.
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const float* col = Mf + i;
-    int j = seg;
-    for (; j + 28 < B; j += 32) {
-      const float m0 = col[static_cast<size_t>(j) * B], m1 = col[static_cast<size_t>(j + 4) * B];
-      const float m2 = col[static_cast<size_t>(j + 8) * B], m3 = col[static_cast<size_t>(j + 12) * B];
-      const float m4 = col[static_cast<size_t>(j + 16) * B], m5 = col[static_cast<size_t>(j + 20) * B];
-      const float m6 = col[static_cast<size_t>(j + 24) * B], m7 = col[static_cast<size_t>(j + 28) * B];
-      a0 += static_cast<double>(m0) * rf[j];
-      a1 += static_cast<double>(m1) * rf[j + 4];
-      a2 += static_cast<double>(m2) * rf[j + 8];
-      a3 += static_cast<double>(m3) * rf[j + 12];
-      a0 += static_cast<double>(m4) * rf[j + 16];
-      a1 += static_cast<double>(m5) * rf[j + 20];
-      a2 += static_cast<double>(m6) * rf[j + 24];
-      a3 += static_cast<double>(m7) * rf[j + 28];
+    if (sg < nSeg) {
+#pragma unroll
+      for (int u = 0; u < kMinvLoads; ++u) {
+        const int j = sg + u * nSeg;
+        if (u * nSeg < B) {
+          const double rj = j < B ? rf[j] : 0.0;
+          a0 += static_cast<double>(mreg[u].x) * rj;
+          a1 += static_cast<double>(mreg[u].y) * rj;
+          a2 += static_cast<double>(mreg[u].z) * rj;
+          a3 += static_cast<double>(mreg[u].w) * rj;
+        }
+      }
+      if (kMinvLoads * nSeg < B) {  // (uniform: B > 128 at 16 segments) second batch, again all loads first
+        const float* col = Mf + 4 * q4;
+#pragma unroll
+        for (int u = 0; u < kMinvLoads; ++u) {
+          const int j = sg + (kMinvLoads + u) * nSeg;
+          if ((kMinvLoads + u) * nSeg < B) mreg[u] = *reinterpret_cast<const F4u*>(col + static_cast<size_t>(min(j, B - 1)) * B);
+        }
+#pragma unroll
+        for (int u = 0; u < kMinvLoads; ++u) {
+          const int j = sg + (kMinvLoads + u) * nSeg;
+          if ((kMinvLoads + u) * nSeg < B) {
+            const double rj = j < B ? rf[j] : 0.0;
+            a0 += static_cast<double>(mreg[u].x) * rj;
+            a1 += static_cast<double>(mreg[u].y) * rj;
+            a2 += static_cast<double>(mreg[u].z) * rj;
+            a3 += static_cast<double>(mreg[u].w) * rj;
+          }
+        }
+      }
+      double* dst = part + static_cast<size_t>(sg) * (4 * nQ) + 4 * q4;
+      dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
     }
-    for (; j < B; j += 4) a0 += static_cast<double>(col[static_cast<size_t>(j) * B]) * rf[j];
-    acc = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < B) {
+      double zv = 0.0;
+      for (int k2 = 0; k2 < nSeg; ++k2) zv += part[static_cast<size_t>(k2) * (4 * nQ) + tid];
+      acc = zv;
+    }
   }
-  part[tid] = acc;
+  if (wide) part[tid] = acc;
   __syncthreads();
   double rz = 0.0, rr = 0.0;
-  if (seg == 0 && i < B) {
-    const int b0 = wide ? chunk * 128 + row : chunk * 256 + row;
-    const double zv = wide ? part[b0] + part[b0 + 64] : part[b0] + part[b0 + 64] + part[b0 + 128] + part[b0 + 192];
-    z[base + i] = zv;
-    rz = rf[i] * zv;
-    rr = rf[i] * rf[i];
+  if (wide) {
+    if (seg == 0 && i < B) {
+      const int b0 = chunk * 128 + row;
+      const double zv = part[b0] + part[b0 + 64];
+      z[base + i] = zv;
+      rz = rf[i] * zv;
+      rr = rf[i] * rf[i];
+    }
+  } else if (tid < B) {
+    z[base + tid] = acc;
+    rz = rf[tid] * acc;
+    rr = rf[tid] * rf[tid];
   }
   rz = waveSum(rz);
   rr = waveSum(rr);
@@ -1781,8 +1883,8 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   if (tid == 0) {
     double a = 0.0, b = 0.0;
     for (int w = 0; w < nWaves; ++w) { a += red[w]; b += red[16 + w]; }
-    fdotRZ[f] = a;
-    fdotRR[f] = b;
+    publishPartial(fdotRZ + f, a);
+    publishPartial(fdotRR + f, b);
   }
   if (fusedY) {
     // y_f <- y_f - alpha (W Z^T q)_f (ypart is complete: two barriers since it was written); |y_f|^2 is this
@@ -1799,18 +1901,18 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < kCB; ++k) t += ypart[16 * kCB + k];
-      cs.fdotY[f] = t;
+      publishPartial(cs.fdotY + f, t);
     }
   }
   }  // frame workgroups
   // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
-  if (lastBlockArrives(counter, gridDim.x, reinterpret_cast<int*>(red + 40))) {
+  if (lastBlockArrivesLite(counter, gridDim.x, reinterpret_cast<int*>(red + 40))) {
     double a = 0.0, b = 0.0, cY = 0.0;
     for (int k = tid; k < L.F; k += nThreads) {
-      a += fdotRZ[k];
-      b += fdotRR[k];
-      if (fusedY) cY += cs.fdotY[k];
-      if (fusedDense) cY += ds.dotPart[k];
+      a += readPartial(fdotRZ + k);
+      b += readPartial(fdotRR + k);
+      if (fusedY) cY += readPartial(cs.fdotY + k);
+      if (fusedDense) cY += readPartial(ds.dotPart + k);
     }
     a = waveSum(a);
     b = waveSum(b);
@@ -2076,6 +2178,12 @@ __device__ __forceinline__ double uniformValue(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+#ifdef CVD_MV_PROFILE  // tools/mv_profile.py: wall-clock (100 MHz) stamps of the hot product's workgroups
+__device__ unsigned long long g_mvProf[4096 * 8];
+#define MV_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_mvProf[(blockIdx.x & 4095) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MV_STAMP(slot) do {} while (0)
+#endif
 constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
 constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 
@@ -2095,6 +2203,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
   constexpr double eps = 1e-6;
   const int B = L.B;
+  if (threadIdx.x == 0) MV_STAMP(0);
   double* xa = sm;
   double* xb = xa + B;
   double* pa = xb + B;
@@ -2179,6 +2288,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     E[tid] = pp[3] * f.dR[0][e] + pp[4] * f.dR[1][e] + pp[5] * f.dR[2][e];
   }
   __syncthreads();
+  if (threadIdx.x == 0) MV_STAMP(1);
 
   const int N = SPEC ? 1 : L.N;
   const int lossType = SPEC ? static_cast<int>(kLossDisparity) : L.lossType;
@@ -2389,6 +2499,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     }
   }
   }  // dir
+  MV_STAMP(4 + ((threadIdx.x >> 6) & 3));  // each wave's end of the constraint loop
   // ---- one workgroup reduction of the 27 accumulators (roles of direction 1: source = fb, target = fa).
   // Lane pairs store their values transposed into LDS (row = accumulator, column = lane pair, 33-padded 32-column
   // segments), then 4 threads per accumulator sum one segment each: ~45 LDS ops per thread instead of 27 x 6
@@ -2459,6 +2570,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0) MV_STAMP(2);
   { double* t = qa; qa = qb; qb = t; }  // undo the role swap
   if constexpr (DENSE) {
     // private copy [k][0] collected frame fa's grid columns (source of direction 0, target of direction 1), [k][1] fb's
@@ -2481,6 +2593,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     outA[i] = qa[i];
     outB[i] = qb[i];
   }
+  if (threadIdx.x == 0) MV_STAMP(3);
 }
 
 }  // namespace cvd

@@ -177,3 +177,10 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
 }
 
 }  // namespace cvd
+
+#ifdef CVD_MV_PROFILE
+extern "C" int32_t cvd_debug_mv_profile(unsigned long long* out) {  // (same translation unit as the launches: the symbol is per unit)
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cvd::g_mvProf), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -754,6 +754,10 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
   std::stable_sort(itemList.begin(), itemList.end(), [](const ItemDesc& a, const ItemDesc& b) {
       return (a.e0 - a.b0) + (a.e1 - a.b1) > (b.e0 - b.b0) + (b.e1 - b.b1);
     });
+  // (Measured and rejected, tools/mv_profile.py: the last, partly filled round of the 2070 items is 17 % of the hot product's
+  // launch, but neither a persistent workgroup per slot walking a balanced item list -- the item loop costs the kernel
+  // registers at its 170-VGPR budget: 52 -> 61 us -- nor halving the largest items up to a whole number of rounds -- 51.8 ->
+  // 50.9 us: the workgroups of a round do not finish together anyway -- pays.)
   for (const ItemDesc& d : itemList) {
     const int item = static_cast<int>(h->itemFa.size());
     h->itemFa.push_back(d.fa);
@@ -1065,7 +1069,7 @@ void ensureBuffers(Ctx& c) {
     // frames are zero and stay zero)
     const size_t nPad = static_cast<size_t>(h->framesPadded()) * B;
     const bool grow = h->dH.n < nPad * B;
-    h->dH.ensure(nPad * B); h->dMinv.ensure(nPad * B); h->dHd.ensure(nPad);
+    h->dH.ensure(nPad * B); h->dMinv.ensure(nPad * B + 4); h->dHd.ensure(nPad);  // (+4: k_cg_update's 16-byte loads at the last row's end)
     if (h->dist() && (grow || nPad > n)) {
       HIP_CHECK(hipMemsetAsync(h->dH.p, 0, nPad * B * sizeof(double), h->stream));
       HIP_CHECK(hipMemsetAsync(h->dMinv.p, 0, nPad * B * sizeof(float), h->stream));

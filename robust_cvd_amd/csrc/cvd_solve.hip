@@ -17,7 +17,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   const int nChunks = static_cast<int>((B + 63) / 64);
   const int nThreads = (B > 256 ? 128 : 256) * nChunks;  // (k_cg_update: four segments per row up to B = 256, two beyond)
   double* fd = h->dFdot.p;
-  size_t ldsU = (B + nThreads + 48 + 17 * kCB) * 8;
+  size_t ldsU = (B + cgUpdatePartDoubles(static_cast<int>(B), nThreads) + 48 + 17 * kCB) * 8;
   const double tol2 = c.h->opt.pcg_relative_tolerance * c.h->opt.pcg_relative_tolerance;
   for (int i = 0; i < 9; ++i) h->hPcg[i] = 0.0;  // device progress mirror (pcgFinishScalars): nothing applied yet
   const bool coarse = h->coarseOn;
@@ -99,18 +99,20 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   while (enq < maxIt) {
     if (enq >= kRunAhead - 1) {
       const int need = enq - kRunAhead + 1;
-      for (unsigned long long spins = 0; static_cast<int>(prog[0]) - 1 < need; ++spins) {
+      // slot 1 + (need & 7) = 4 (need + 1) + done flag once exactly `need` iterations have been applied
+      double v;
+      for (unsigned long long spins = 0; static_cast<long long>((v = prog[1 + (need & 7)]) * 0.25) != need + 1; ++spins) {
         if ((spins & 0xFFFFF) == 0xFFFFF) {
           // never spin forever on a mirror that cannot advance: a faulted stream reports here, and an idle stream
           // whose iterations did not publish progress is a logic error
           const hipError_t e = hipStreamQuery(s);
           if (e != hipErrorNotReady) {
             HIP_CHECK(e);
-            if (static_cast<int>(prog[0]) - 1 < need) throw std::runtime_error("PCG progress mirror stalled");
+            if (static_cast<long long>(prog[1 + (need & 7)] * 0.25) != need + 1) throw std::runtime_error("PCG progress mirror stalled");
           }
         }
       }
-      if (prog[1 + (need & 7)] != 0.0) break;
+      if (v - 4.0 * (need + 1) != 0.0) break;
     }
     enqueueIteration(enq, enq > 0 ? 1 : 0);
     ++enq;

@@ -1,4 +1,5 @@
-"""GPU parity (-m gpu) at the REAL sizes of BASELINE.json configs[0..2], with the DEFAULT (= benchmarked) solver options.
+"""GPU parity (-m gpu) at the REAL sizes of BASELINE.json configs[0..2] (+ the benchmarked 4140-pair variant of configs[2] and
+the evaluation of configs[4]), with the DEFAULT (= benchmarked) solver options.
 
 north_star: "results match the reference Ceres solve on identical inputs to a stated float tolerance on final poses and
 deformed depth maps ... converging to within 1e-3 relative pose error".  The reference solve is restated by the CPU oracle
@@ -45,8 +46,10 @@ def _oracle_with_solution(video, ref, desc):
     return o
 
 
-@pytest.mark.parametrize("name", ["config0", "config1", "config2"])
+@pytest.mark.parametrize("name", ["config0", "config1", "config2", "config2_4k"])
 def test_end_state_matches_the_oracle_solution(Solver, name):
+    """config2_4k is the BENCHMARKED problem (4140 directed pairs, 2.40 M constraints): its solves run the dense coarse level
+    (k_dense_spd_inverse in line) -- the configuration bench.py times, against the oracle's exact-Cholesky end state."""
     video = bc.make_video(name)
     ref = bc.load_solution(name)
     assert int(ref["num_pairs"]) == len(video.pairs) and int(ref["num_constraints"]) == video.num_constraints
@@ -104,6 +107,44 @@ def test_full_size_cost_gradient_and_blocks_match_the_oracle(Solver):
         out[k] = b.evaluate(p, p.depth_deform_reg_final, pose7, want_gradient=True, want_hdiag=True)
     h, o = out["hip"], out["oracle"]
     assert h["num_residual_blocks"] == o["num_residual_blocks"]
+    assert abs(h["cost"] - o["cost"]) <= 1e-9 * abs(o["cost"]), (h["cost"], o["cost"])
+    assert rel(h["gradient"], o["gradient"]) < 1e-9
+    assert rel(h["hdiag"], o["hdiag"]) < 1e-9
+
+
+@pytest.mark.parametrize("robust", ["cauchy", "huber"])
+def test_config4_full_size_cost_gradient_and_blocks_match_the_oracle(Solver, robust):
+    """BASELINE.json configs[4] at full size -- 1000 frames 640x384, hierarchical flow list (4318 directed pairs, 10.4 M
+    constraints), 16x12 bilinear grid (B = 199: the packed triangle of a frame block just fits the LDS), Cauchy 0.5 (what the
+    reference hard-wires) and Huber 0.5 (the stress variant BASELINE names): cost, gradient and every frame-diagonal J^T J
+    block of the HIP path against the oracle's block-sparse evaluation at a state away from the minimum."""
+    import bench
+    cfg = bench.CONFIGS[4]
+    video = synth.make_video(cfg["frames"], cfg["width"], cfg["height"], seed=bench.SEED, extra_offsets=1)
+    F = video.num_frames
+    rng = np.random.default_rng(17)
+    pose7 = np.zeros((F, 7))
+    pose7[:, :6] = rng.normal(0.0, 0.02, (F, 6))
+    pose7[:, 6] = 0.2 + rng.uniform(0.0, 0.02, F)
+    theta = 1.0 + rng.normal(0.0, 0.05, size=(F, 16 * 12))
+    from robust_cvd_amd.ctypes_types import OptParams
+    p = OptParams.defaults()
+    p.num_threads = 12
+    p.ctf_long, p.ctf_short = cfg["ctf"]
+    out = {}
+    for k, ctor in (("hip", lambda: Solver(0)), ("oracle", Oracle)):
+        b = ctor()
+        b.set_robust_loss(1 if robust == "huber" else 0)
+        synth.load_into(b, video)
+        b.reset_depth_xforms(XformDesc.grid_depth(16, 12))
+        b.reset_spatial_xforms(XformDesc.spatial())
+        b.set_xform_params(theta)
+        out[k] = b.evaluate(p, p.depth_deform_reg_final, pose7, want_gradient=True, want_hdiag=True)
+        if k == "hip":
+            assert b.block_size() == 199
+        del b
+    h, o = out["hip"], out["oracle"]
+    assert h["num_residual_blocks"] == o["num_residual_blocks"] and h["num_residual_blocks"] > 10_000_000
     assert abs(h["cost"] - o["cost"]) <= 1e-9 * abs(o["cost"]), (h["cost"], o["cost"])
     assert rel(h["gradient"], o["gradient"]) < 1e-9
     assert rel(h["hdiag"], o["hdiag"]) < 1e-9

@@ -424,10 +424,10 @@ def test_full_solve_reaches_the_oracle_minimum(Solver, cfg):
     assert list(out["hip"][3].grid_size) == list(out["oracle"][3].grid_size)
     perr, rerr = synth.relative_pose_error(out["hip"][0]["position"], out["hip"][0]["orientation"],
                                            out["oracle"][0]["position"], out["oracle"][0]["orientation"])
-    assert perr < 1e-2 and rerr < 1e-3, (perr, rerr)
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)   # BASELINE.json's tolerance
     assert np.abs(out["hip"][0]["vfov"] - out["oracle"][0]["vfov"]).max() < 1e-3
     # deformed depth (what DepthXform::apply consumes): per-vertex scale params agree
-    assert rel(out["hip"][1], out["oracle"][1]) < 1e-2
+    assert rel(out["hip"][1], out["oracle"][1]) < 1e-3
 
 
 @pytest.mark.parametrize("variant", ["deferred_spatial_default_grid", "graduate_deform_reg", "deferred_spatial_small_grid",
