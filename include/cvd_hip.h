@@ -117,7 +117,7 @@ int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair
 /* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
 /* 1 when a problem with these parameters / transform descriptors lies within the scope of the dense mode (identity spatial
  * transform, a reprojection loss, Scale value transform, Global or bilinear grid, per-frame or fixed intrinsics, no
- * smoothness triplets, one GPU, frame block <= 256); 0: hand the constraints over as a list (cvd_set_pair_constraints) --
+ * smoothness triplets, frame block <= 256); 0: hand the constraints over as a list (cvd_set_pair_constraints) --
  * a dense-mode solve outside the scope fails instead of falling back.  problem: 0 = poseOptimization, 1 = normalizeDepth.
  * What lib_python's FlowConstraintsCollection asks before it keeps a matchSeparation = 0 collection as images. */
 int32_t cvd_dense_mode_supported(const cvd_opt_params* params, const cvd_xform_desc* depth, const cvd_xform_desc* spatial,

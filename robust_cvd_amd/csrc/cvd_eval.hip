@@ -96,7 +96,7 @@ void enqueueStats(Ctx& c) {
 // problem is cheap to solve matrix-free.)
 bool crossScope(cvd_handle* h, const Ctx& c) {
   const bool off = h->opt.dense_matrix_free != 0;  // comparison variant
-  return h->dense && !off && !h->dist() && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
+  return h->dense && !off && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
          c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
          c.L.B <= 256;
 }

@@ -1367,7 +1367,8 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
                                                        int useBeta, double* __restrict__ q, double* __restrict__ fdot,
                                                        int distMode, int nRows, RegCache rc, CoarseView V,
                                                        double* __restrict__ qc, CoarseColumns cc,
-                                                       const double* __restrict__ Hdiag, double* __restrict__ pqOut) {
+                                                       const double* __restrict__ Hdiag, double* __restrict__ pqOut,
+                                                       int ownFirst, int ownCount) {
   // Hdiag != nullptr (explicit cross blocks, cvd_cross.h): the partial rows hold the OFF-diagonal blocks' products only;
   // the frame-diagonal part, regularisers included, is H_ff p_f with the assembled H_ff.
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
@@ -1450,7 +1451,9 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     if ((tid & 63) == 0) atomicAdd(&qf[6], a);
     __syncthreads();
   }
-  if (Hdiag != nullptr) {
+  // (pair-sharded run: the reduced H_ff lives on the frame's OWNER rank only -- the others contribute the cross blocks of
+  // their pairs and nothing else for this frame)
+  if (Hdiag != nullptr && f >= ownFirst && f < ownFirst + ownCount) {
     // symmetric block: column access, coalesced over the row index; four independent loads in flight
     const double* Hf = Hdiag + static_cast<size_t>(f) * B * B;
     for (int i = tid; i < B; i += 256) {
@@ -1466,7 +1469,7 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
       qf[i] += (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-  } else if (inRange[f]) {
+  } else if (Hdiag == nullptr && inRange[f]) {
     // J_reg^T (J_reg p) from the cached rows (k_reg_cache)
     for (int i = tid; i < rc.nr; i += 256) {
       const int n = rc.cnt[static_cast<size_t>(f) * rc.nr + i];

@@ -156,7 +156,8 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
                          h->dist() ? (h->rank == 0 ? 1 : 2) : 0, c.cross ? static_cast<int>(h->xFa.size()) * 2 : h->qRows,
                          h->regCache, cF,
                          fusedX ? (denseFused ? qcX : nullptr) : (((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr), cc,
-                         c.cross ? h->dH.p : nullptr, fusedX ? pqX : nullptr);
+                         c.cross ? h->dH.p : nullptr, fusedX ? pqX : nullptr, h->dist() ? h->ownFirst() : 0,
+                         h->dist() ? h->ownCount() : c.L.F);
     });
     HIP_CHECK(hipGetLastError());
     if (fusedX) {

@@ -355,7 +355,7 @@ Table makeTable(cvd_handle* h) {
 // enforces at solve time, for every step of the schedule the parameters describe.
 bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const cvd_xform_desc& sd, bool haveTriplets, int world,
                         bool normalize) {
-  if (world > 1) return false;
+  (void)world;  // (pair-sharded runs hand every rank the flow images of ITS pairs: same scope)
   if (normalize) return p.normalize_depth_from_first_frame != 0;  // (the pair loop's DisparityDissimilarityCost is a generic-kernel loss)
   if (sd.spatial_type != CVD_SPATIAL_IDENTITY || p.deferred_spatial_opt) return false;
   if (p.static_loss_type != CVD_STATIC_REPRO_DISPARITY && p.static_loss_type != CVD_STATIC_REPRO_DEPTH_RATIO &&
@@ -376,11 +376,10 @@ bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const
 // Dense mode runs on the specialised fast kernels only (the default residual configuration of the reference pipeline).
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
   if (!h->dense) return;
-  if (KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || h->dist() || L.cubic)
+  if (KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || L.cubic)
     throw std::runtime_error("dense mode (cvd_set_pair_flows) supports the fast kernels' residual configurations only: identity "
                              "spatial transform, a reprojection loss (ReproDisparity / ReproDepthRatio / ReproLogDepth), Scale "
-                             "value transform, Global or bilinear grid, per-frame or fixed intrinsics, no smoothness triplets, "
-                             "one GPU");
+                             "value transform, Global or bilinear grid, per-frame or fixed intrinsics, no smoothness triplets");
 }
 // Row panels of the packed lower triangle of a B x B frame block that fit `capDoubles` of LDS each (AsmPanels,
 // cvd_kernels.h): one panel up to B = 199, two at the reference's default deferred-spatial block B = 201.

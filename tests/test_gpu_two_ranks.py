@@ -140,3 +140,45 @@ def test_two_ranks_with_triplets_and_three_ranks():
     ranks3 = solve_sharded(v, 3, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25))
     compare(ranks3[:2], solve_single(v, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25)))
     assert np.array_equal(ranks3[0][2], ranks3[2][2])
+
+
+@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
+def test_two_ranks_dense_mode(product):
+    """Dense mode (flow / mask images of every pair instead of a constraint list) sharded over two ranks: every rank holds the
+    images of ITS pairs; the explicit cross blocks X_ab live on the pair's rank, the reduced H_ff (which carries the
+    frame-diagonal part of the product in this mode) on the frame's owner; coarse edge blocks from the local cross blocks are
+    all-reduced.  Against the single-rank dense solve."""
+    from robust_cvd_amd import api
+    v = synth.make_video(7, 96, 56, seed=55)
+    flow, mask = synth.make_dense_flows(v)
+    opts = {"dense_matrix_free": int(product == "matrix_free"), "coarse_update_budget": 0}
+
+    def run(world, rank, key):
+        s = api.Solver(0)
+        s.set_options(**opts)
+        idx = np.arange(len(v.pairs))
+        if world > 1:
+            s.comm_init_local_group(rank, world, key)
+            idx = sharding.shard_pairs(v.pairs, np.arange(len(v.pairs) + 1) * (v.width * v.height), world)[rank]
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.reset_poses()
+        s.set_pair_flows(v.pairs[idx], flow[idx], mask[idx])
+        if world > 1:
+            s.set_pair_graph(v.pairs)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        s.normalize_depth(p)
+        ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
+        s.pose_optimization(p)
+        res = (ev, s.get_poses(), s.get_xform_params().copy(), s.summary())
+        s.close()
+        return res
+
+    single = run(1, 0, 0)
+    _KEY[0] += 1
+    key = _KEY[0]
+    ranks = run_ranks(2, lambda r: run(2, r, key))
+    compare(ranks, single)
