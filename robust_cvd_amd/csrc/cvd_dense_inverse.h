@@ -124,11 +124,28 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
 #define DINV_J(s) (tCode[s] < 0 ? -1 : colBase + DINV_LJ(s))
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
+    // Tile l = w + 8 s of the super-tile.  Off-diagonal super-tiles: row-major (li, lj).  DIAGONAL super-tiles hold the lower
+    // triangle only and deal their S diagonal tiles -- the pivot tiles -- FIRST, one per wave (l = li < S), then the tiles
+    // below the diagonal: the wave that has to invert the next pivot carries one diagonal tile and its share of the others
+    // (row-major numbering put ALL diagonal tiles of an S = 7 super-tile on wave 0: l = 8 li).
     const int l = w + s * kDinvNW;
-    int li = l / S, lj = l - li * S;
+    int li, lj;
+    if (SI != SJ) {
+      li = l / S;
+      lj = l - li * S;
+    } else if (l < S) {
+      li = l;
+      lj = l;
+    } else {
+      const int m = l - S;  // strictly lower tiles: (1,0), (2,0), (2,1), (3,0) ...
+      li = static_cast<int>((1.f + sqrtf(1.f + 8.f * static_cast<float>(m))) * 0.5f);
+      while (li * (li - 1) / 2 > m) --li;
+      while ((li + 1) * li / 2 <= m) ++li;
+      lj = m - li * (li - 1) / 2;
+    }
     int I = rowBase + li, J = colBase + lj;
     int code = li | (lj << 8);
-    if (l >= S * S || I >= nT || J >= nT || I < J) { I = -1; J = -1; code = -1; }
+    if (l >= (SI != SJ ? S * S : S * (S + 1) / 2) || li >= S || I >= nT || J >= nT || I < J) { I = -1; J = -1; code = -1; }
     tCode[s] = __builtin_amdgcn_readfirstlane(code);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -142,8 +159,7 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   auto pivotSlot = [&](int kk) -> int {
     const int li = kk - rowBase;
     if (SI != SJ || li < 0 || li >= S || kk >= nT) return -1;
-    const int l = li * S + li;
-    return (l % kDinvNW == w) ? l / kDinvNW : -1;
+    return (li % kDinvNW == w) ? li / kDinvNW : -1;   // (diagonal tiles come first: l = li)
   };
   // The owner wave of pivot tile (kk, kk) inverts it in-wave (16 scalar symmetric sweeps) and publishes -P.  The 16 pivots
   // exist ONCE in the code, not once per tile slot.
@@ -156,6 +172,8 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
       }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (a non-inlined function for the 16 sweeps -- own register allocation, away from the ~100 live scalars of this kernel --
+    // was measured: no difference)
     const int row = lane & 15, cg = lane >> 4;
     double g[4];
 #pragma unroll

@@ -956,7 +956,7 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     }
     int activeFrames = 0;
     for (int f = 0; f < h->F; ++f) activeFrames += inRange[f] ? 1 : 0;
-    constexpr double partsPerCU = 1.0;
+    constexpr double partsPerCU = 1.0;  // (1.5 / 2 / 3 / 4 parts per CU measured on the 4140-pair set: 0.44 / 0.42 / 0.46 / 0.51 ms against 0.38)
     const long long denom = std::max<long long>(1, std::max<long long>(activeFrames, static_cast<long long>(partsPerCU * h->numCU)));
     const int capU = static_cast<int>(std::max<long long>(kAsmThreads / 64, (static_cast<long long>(units.size()) + denom - 1) / denom));
     std::vector<AsmPart> parts;
