@@ -152,6 +152,8 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
+    // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)
+    touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_solve(); touchModule_frontend();
     return h;
   } catch (const std::exception& e) {
     g_createError = e.what();

@@ -226,4 +226,11 @@ double evalFull(Ctx& c, const double* x, bool withStats) {
   return h->hScal[S_COST];
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_eval() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_sum2));
+}
+
 }  // namespace cvd

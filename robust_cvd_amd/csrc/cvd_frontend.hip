@@ -277,4 +277,11 @@ void flowGuidedFilter(cvd_handle* h, int n, int first, int count, int w, int hh,
   }
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_frontend() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_bgr_to_gray));
+}
+
 }  // namespace cvd

@@ -553,6 +553,12 @@ void sampleConstraints(cvd_handle* h, bool triplet, int num, const int32_t* keyF
                        int matchSeparation, float minDynamicDistance, int64_t* offsets);
 void denseMaps(cvd_handle* h, int kind, int first, int count, int w, int hh, void* out, double* kernelMs);
 void imageOps(cvd_handle* h, int kind, int n, int w, int hh, const void* in, float* out, double* kernelMs);
+void touchModule_setup();
+void touchModule_eval();
+void touchModule_matvec();
+void touchModule_precond();
+void touchModule_solve();
+void touchModule_frontend();
 void flowGuidedFilter(cvd_handle* h, int n, int first, int count, int w, int hh, int dw, int dh, float invAspect, const float* depth,
                       const float* cameras, const float* flowF, const uint8_t* maskF, const float* flowB, const uint8_t* maskB,
                       int frameRadius, int spatialRadius, int median, float* out, double* kernelMs);

@@ -177,6 +177,13 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
   }
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_matvec() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_dot_pq));
+}
+
 }  // namespace cvd
 
 #ifdef CVD_MV_PROFILE

@@ -238,4 +238,11 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
   HIP_CHECK(hipGetLastError());
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_precond() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_coarse_diag));
+}
+
 }  // namespace cvd

@@ -1133,4 +1133,11 @@ void refreshMedians(cvd_handle* h) {
   h->medianDirty = false;
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_setup() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_pick_median));
+}
+
 }  // namespace cvd

@@ -501,4 +501,11 @@ void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, con
   }
 }
 
+// One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
+// code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
+void touchModule_solve() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_cg_update));
+}
+
 }  // namespace cvd

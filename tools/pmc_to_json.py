@@ -31,9 +31,9 @@ out = {
     "kernel": kernel,
     "kernel_sources_sha256": bench.kernel_sources_digest(),
     "constraints": bench_line["config"]["constraints"], "pairs": bench_line["config"]["pairs"],
-    "command": "CVD_PCG_LOCKSTEP=1 rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-include-regex "
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-include-regex "
                "k_matvec_pairs_fast --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary "
-               "(lockstep: no early-exit launches in the average)",
+               "--pcg-lockstep (lockstep: no early-exit launches in the average)",
     "fetch_size_kb_per_launch_raw": f, "write_size_kb_per_launch_raw": w, "dispatches": nf,
     "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts a wide coalesced 16 B/lane stream at "
                   "half its bytes -> doubled; WRITE_SIZE uncalibrated, taken as is",
