@@ -231,7 +231,7 @@ def main():
                     help="dense mode (the reference's matchSeparation = 0): flow / mask images of every pair instead of the "
                          "sampled constraint list; the kernels read flow, mask and depth directly, 17 B per pixel pair")
     ap.add_argument("--pcg-tol", type=float, default=None, help="development: PCG forcing value (default: the library's)")
-    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="development: any integer field of cvd_solver_options (e.g. coarse_rebuild_excess=8, coarse_level=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figure on the reference sampler's 1766-pair list")
@@ -317,7 +317,7 @@ def main():
             solver.set_options(pcg_lockstep=1)
         for kv in args.opt:
             name, val = kv.split("=")
-            solver.set_options(**{name: int(val)})
+            solver.set_options(**{name: float(val) if "." in val or "e" in val else int(val)})
         t_prep = time.perf_counter()
         upload, grid, pipeline_first = prepare(solver, video, params, pair_graph=all_pairs)
         t_prep = time.perf_counter() - t_prep

@@ -57,6 +57,12 @@ typedef struct cvd_solver_options {
                                      right after the last rebuild add up to this many (about what a rebuild costs); default 16 */
   int64_t coarse_update_budget;   /* 8x8 block updates of the sparse elimination beyond which the coarse level goes dense
                                      (or, beyond coarse_dense_max_unknowns, is built on a sparsified graph); default 40000 */
+  double coarse_dense_shift;      /* dense coarse level: A_c + shift * diag(A_c) is what gets inverted (default 1e-5).  The level
+                                     applies an EXPLICIT inverse, whose rounding errors scale with cond(A_c) / lambda_min: beyond
+                                     cond ~ 1e8 (the damped matrix late in an LM run: the gauge directions carry only the
+                                     damping) the stored inverse stops being positive definite and PCG stalls.  The shift
+                                     bounds the condition number of the Jacobi-scaled matrix; as a preconditioner the level
+                                     loses nothing on directions that carry gradient */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -265,8 +271,8 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
  * from its blocks, a_c_inverse = the inverse the solver applied, failed = pivot failures of the factorisation.
  * Any output pointer may be NULL. */
 /* Test hook: the dense SPD inverse of the dense coarse level (cvd_dense_inverse.h) on one n x n f64 matrix (row-major,
- * symmetric); inverse = n x n f32; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
-int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, float* inverse, int32_t* failed);
+ * symmetric); inverse = n x n f64; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
+int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, double* inverse, int32_t* failed);
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 
 #ifdef __cplusplus

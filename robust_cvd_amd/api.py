@@ -31,6 +31,7 @@ class SolverOptions(C.Structure):
         ("coarse_dense_max_unknowns", C.c_int32),
         ("coarse_rebuild_excess", C.c_int32),
         ("coarse_update_budget", C.c_int64),
+        ("coarse_dense_shift", C.c_double),
     ]
 
 
@@ -105,7 +106,7 @@ class Solver(Binding):
         for k, v in variants.items():  # force_sharded_path, dense_matrix_free, block_inverse_variant, pcg_lockstep, coarse_*
             if k not in dict(SolverOptions._fields_):
                 raise TypeError(f"unknown solver option {k!r}")
-            setattr(o, k, int(v))
+            setattr(o, k, float(v) if k == "coarse_dense_shift" else int(v))
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
 
     def set_robust_loss(self, kind):
@@ -189,16 +190,16 @@ class Solver(Binding):
         return out, fl.value
 
     def dense_inverse_debug(self, a):
-        """f32 inverse of one dense SPD f64 matrix [n, n] through the dense coarse level's kernel (k_dense_spd_inverse) and
+        """f64 inverse of one dense SPD f64 matrix [n, n] through the dense coarse level's kernel (k_dense_spd_inverse) and
         its failure word (1: non-positive pivot, bit 30: barrier timeout)."""
         import numpy as np
         a = np.ascontiguousarray(a, dtype=np.float64)
         n = a.shape[0]
         assert a.shape == (n, n)
-        out = np.zeros((n, n), dtype=np.float32)
+        out = np.zeros((n, n), dtype=np.float64)
         fl = C.c_int32(0)
         self._check(self._fn("dense_inverse_debug")(self._h, C.c_int32(n), a.ctypes.data_as(C.POINTER(C.c_double)),
-                                                    out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(fl)))
+                                                    out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fl)))
         return out, fl.value
 
     def coarse_debug(self):

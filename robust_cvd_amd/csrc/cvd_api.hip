@@ -213,6 +213,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_dense_max_unknowns = 4096;
   o->coarse_rebuild_excess = 16;
   o->coarse_update_budget = 40000;
+  o->coarse_dense_shift = 1e-5;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
@@ -692,19 +693,19 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
   });
 }
 
-int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, float* inverse, int32_t* failed) {
+int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, double* inverse, int32_t* failed) {
   CVD_TRY(h, {
     if (n <= 0 || n > 8192) throw std::runtime_error("dense_inverse_debug: bad size");
     const size_t nn = static_cast<size_t>(n) * n;
     DevBuf<double> dA;
-    DevBuf<float> dM;
+    DevBuf<double> dM;
     DevBuf<int> dF;
     dA.ensure(nn);
     dM.ensure(nn);
     dF.ensure(2);
     hipStream_t s = h->stream;
     dA.upload(a, nn, s);
-    HIP_CHECK(hipMemsetAsync(dM.p, 0, nn * sizeof(float), s));
+    HIP_CHECK(hipMemsetAsync(dM.p, 0, nn * sizeof(double), s));
     HIP_CHECK(hipMemsetAsync(dF.p, 0, 2 * sizeof(int), s));
     launchDenseSpdInverse(h, n, dA.p, dM.p, dF.p, s, dF.p + 1);
     int fl[2] = {0, 0};

@@ -820,18 +820,26 @@ inline __global__ __launch_bounds__(256) void k_coarse_apply_wt(CoarseView V, in
 // from nearly every frame (the "~4k pairs" list of BASELINE.json: ~10^6 updates, 44 ms per factorisation).  For such
 // graphs the coarse matrix (8 F unknowns: 2400 at 300 frames) is simply treated as dense: assembled from the same
 // diagonal / edge blocks, inverted by ONE persistent kernel on the f64 matrix cores (k_dense_spd_inverse,
-// cvd_dense_inverse.h) and applied as an f32 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
-// r^T z, 23 MB streamed).  Unknowns in FRAME order (8 f + mode); inactive modes are identity rows.
+// cvd_dense_inverse.h) and applied as an f64 matrix-vector product per PCG iteration (k_coarse_dense_apply: c = A_c^-1 Z^T r and its share of
+// r^T z, 46 MB streamed).  Unknowns in FRAME order (8 f + mode); inactive modes are identity rows.
 // ---------------------------------------------------------------------------------------------------------
 inline __global__ __launch_bounds__(64) void k_coarse_dense_assemble(int F, int nEdges, const double* __restrict__ diag,
                                                               const double* __restrict__ edges,
                                                               const int* __restrict__ edgeFa, const int* __restrict__ edgeFb,
                                                               const unsigned char* __restrict__ modeActive,
-                                                              double* __restrict__ A) {
+                                                              double* __restrict__ A, double shift) {
   const size_t n = static_cast<size_t>(F) * kCB;
   const int b = blockIdx.x, t = threadIdx.x, i = t >> 3, j = t & 7;
   if (b < F) {
-    A[(static_cast<size_t>(b) * kCB + i) * n + b * kCB + j] = diag[static_cast<size_t>(b) * kCBB + t];
+    // (the diagonal carries a relative shift, cvd_solver_options::coarse_dense_shift: A_c is singular along the 7 gauge
+    // directions of the trajectory up to the LM damping, i.e. up to 1e-10 ... 1e-16 of its norm once the trust region has
+    // grown.  An explicit inverse of such a matrix is dominated by those directions and its rounding errors -- of relative
+    // size cond(A_c) eps -- swamp its small eigenvalues: the applied "inverse" is indefinite and PCG runs into its
+    // iteration cap, in which LM iteration depended on rounding.  f64 storage alone moves the limit from cond ~ 1e7 to
+    // ~ 1e8; the shift keeps cond of the Jacobi-scaled matrix below ~ 1e7.  The level is a preconditioner: the shift is
+    // invisible on every direction that carries gradient.)
+    const double v = diag[static_cast<size_t>(b) * kCBB + t];
+    A[(static_cast<size_t>(b) * kCB + i) * n + b * kCB + j] = (i == j) ? v * (1.0 + shift) : v;
   } else if (b - F < nEdges) {
     const int e = b - F, fa = edgeFa[e], fb = edgeFb[e];  // block stored rows = fa, columns = fb
     double v = edges[static_cast<size_t>(e) * kCBB + t];
@@ -879,7 +887,7 @@ inline __global__ __launch_bounds__(256) void k_blocks_pack(int B, size_t total,
 
 // c_f = (A_c^-1 Z^T r)_f for the 8 modes of frame f (one workgroup per frame: 8 rows x n, 32 threads per row) and this
 // frame's share of r^T Z A_c^-1 Z^T r; the last workgroup closes the PCG scalars exactly as k_coarse_apply_w does.
-inline __global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const float* __restrict__ Ainv,
+inline __global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const double* __restrict__ Ainv,
                                                             const double* __restrict__ rc, double* __restrict__ cOut,
                                                             const unsigned char* __restrict__ modeActive,
                                                             double* __restrict__ dotPart, double* __restrict__ scal,
@@ -892,27 +900,25 @@ inline __global__ __launch_bounds__(256) void k_coarse_dense_apply(int F, const 
   const int f = blockIdx.x, tid = threadIdx.x;
   const int m = tid >> 5, part = tid & 31;
   const size_t n = static_cast<size_t>(F) * kCB;
-  // 16-byte loads (n = 8 F: every row starts on a 16-byte boundary), four in flight per thread: the kernel streams 4 n^2
-  // bytes (23 MB at 300 frames) and is latency-bound otherwise
-  const float4* row = reinterpret_cast<const float4*>(Ainv + (static_cast<size_t>(f) * kCB + m) * n);
-  const size_t n4 = n / 4;
+  // 16-byte loads (n = 8 F: every row starts on a 16-byte boundary), four in flight per thread: the kernel streams 8 n^2
+  // bytes (46 MB at 300 frames) and is latency-bound otherwise
+  const double2* row = reinterpret_cast<const double2*>(Ainv + (static_cast<size_t>(f) * kCB + m) * n);
+  const double2* rc2 = reinterpret_cast<const double2*>(rc);
+  const size_t n2 = n / 2;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  auto dot4 = [&](size_t j) {
-    const float4 w = row[j];
-    const double* r = rc + 4 * j;
-    return (static_cast<double>(w.x) * r[0] + static_cast<double>(w.y) * r[1]) +
-           (static_cast<double>(w.z) * r[2] + static_cast<double>(w.w) * r[3]);
-  };
   size_t j = part;
-  for (; j + 96 < n4; j += 128) {
-    const float4 w0 = row[j], w1 = row[j + 32], w2 = row[j + 64], w3 = row[j + 96];
-    const double* r0 = rc + 4 * j;
-    a0 += (static_cast<double>(w0.x) * r0[0] + static_cast<double>(w0.y) * r0[1]) + (static_cast<double>(w0.z) * r0[2] + static_cast<double>(w0.w) * r0[3]);
-    a1 += (static_cast<double>(w1.x) * r0[128] + static_cast<double>(w1.y) * r0[129]) + (static_cast<double>(w1.z) * r0[130] + static_cast<double>(w1.w) * r0[131]);
-    a2 += (static_cast<double>(w2.x) * r0[256] + static_cast<double>(w2.y) * r0[257]) + (static_cast<double>(w2.z) * r0[258] + static_cast<double>(w2.w) * r0[259]);
-    a3 += (static_cast<double>(w3.x) * r0[384] + static_cast<double>(w3.y) * r0[385]) + (static_cast<double>(w3.z) * r0[386] + static_cast<double>(w3.w) * r0[387]);
+  for (; j + 96 < n2; j += 128) {
+    const double2 w0 = row[j], w1 = row[j + 32], w2 = row[j + 64], w3 = row[j + 96];
+    const double2 r0 = rc2[j], r1 = rc2[j + 32], r2 = rc2[j + 64], r3 = rc2[j + 96];
+    a0 += w0.x * r0.x + w0.y * r0.y;
+    a1 += w1.x * r1.x + w1.y * r1.y;
+    a2 += w2.x * r2.x + w2.y * r2.y;
+    a3 += w3.x * r3.x + w3.y * r3.y;
   }
-  for (; j < n4; j += 32) a0 += dot4(j);
+  for (; j < n2; j += 32) {
+    const double2 w0 = row[j], r0 = rc2[j];
+    a0 += w0.x * r0.x + w0.y * r0.y;
+  }
   double acc = (a0 + a1) + (a2 + a3);
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);

@@ -81,7 +81,7 @@ __device__ __forceinline__ bool dinvGridBarrier(unsigned int* counter, unsigned 
   return *ldsFlag != 0;
 }
 
-// A: n x n f64 row-major (lda = n), symmetric, only the lower triangle is read.  out: n x n f32, the full symmetric
+// A: n x n f64 row-major (lda = n), symmetric, only the lower triangle is read.  out: n x n f64, the full symmetric
 // inverse.  A non-positive pivot (the coarse matrix is singular along the gauge directions up to the damping) leaves `out`
 // untouched: when *outValid says it holds an earlier inverse that one stays in use -- any SPD approximation serves the
 // preconditioner -- otherwise *fail = 1 (the level is switched off by its consumers).  Success sets *outValid = 1.
@@ -90,7 +90,7 @@ __device__ __forceinline__ bool dinvGridBarrier(unsigned int* counter, unsigned 
 // *fail zeroed by the host.  gridDim.x = nS (nS + 1) / 2.
 template <int TPW>
 inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n, int S, int nS, const double* __restrict__ A,
-                                                                           float* __restrict__ out, int* __restrict__ fail,
+                                                                           double* __restrict__ out, int* __restrict__ fail,
                                                                            double* __restrict__ panel, double* __restrict__ pinv,
                                                                            unsigned int* __restrict__ barrier, int* __restrict__ outValid) {
   extern __shared__ __attribute__((aligned(16))) double dinvSmem[];
@@ -335,29 +335,27 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *outValid = 1;
 
-  // A^-1 = -G in f32: the tile as it lies and its mirror image (transposed through the private LDS tile)
+  // A^-1 = -G: the tile as it lies and its mirror image (transposed through the private LDS tile); a diagonal tile is
+  // averaged with its own transpose (its two halves were updated independently and differ in the last bits), so that the
+  // stored inverse is exactly symmetric
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     if (DINV_I(s) < 0) continue;
+    const bool diagTile = DINV_I(s) == DINV_J(s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = kInvTS * DINV_I(s) + r0 + 4 * r, j = kInvTS * DINV_J(s) + c;
-      if (i < n && j < n) out[static_cast<size_t>(i) * n + j] = static_cast<float>(-acc[s][r]);
+      const double t = scratch[c * kInvLd + r0 + 4 * r];  // element (c, r0 + 4 r) of the tile
+      if (i < n && j < n) out[static_cast<size_t>(i) * n + j] = diagTile ? -0.5 * (acc[s][r] + t) : -acc[s][r];
+      const int it = kInvTS * DINV_I(s) + c, jt = kInvTS * DINV_J(s) + r0 + 4 * r;  // element (it, jt) -> out[jt][it]
+      if (!diagTile && it < n && jt < n) out[static_cast<size_t>(jt) * n + it] = -t;
     }
-    if (DINV_I(s) != DINV_J(s)) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) scratch[(r0 + 4 * r) * kInvLd + c] = acc[s][r];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = kInvTS * DINV_I(s) + c, j = kInvTS * DINV_J(s) + r0 + 4 * r;  // element (i, j) of the tile -> out[j][i]
-        const double v = scratch[c * kInvLd + r0 + 4 * r];
-        if (i < n && j < n) out[static_cast<size_t>(j) * n + i] = static_cast<float>(-v);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 #ifdef CVD_DINV_PROFILE
   CVD_DINV_T(6);

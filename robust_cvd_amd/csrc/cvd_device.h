@@ -857,11 +857,11 @@ struct CoarseStep {
 // Dense coarse level fused into k_cg_update (Ainv == nullptr: off).  c = A_c^-1 Z^T r is linear in r, so with
 // r <- r - alpha q it obeys c <- c - alpha A_c^-1 (Z^T q): the product needs only qc = Z^T q, which the kernel that
 // completed q left behind, i.e. nothing k_cg_update's own frame workgroups produce -- F extra workgroups of the same
-// launch do it (8 rows of the f32 inverse each) and the separate k_coarse_dense_apply launch disappears from the
+// launch do it (8 rows of the inverse each) and the separate k_coarse_dense_apply launch disappears from the
 // iteration.  Z^T r is carried the same way (rc <- rc - alpha qc); both start from directly computed values at the
 // first residual of every PCG solve.
 struct DenseStep {
-  const float* Ainv;    // [8F][8F] f32
+  const double* Ainv;   // [8F][8F] f64 (f32 storage loses positive definiteness once cond(A_c) passes ~1e7)
   const double* qc;     // Z^T q, [F][kCB]
   double* rc;           // Z^T r, [F][kCB]
   double* c;            // A_c^-1 Z^T r, [F][kCB]

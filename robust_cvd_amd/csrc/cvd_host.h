@@ -293,12 +293,12 @@ struct cvd_handle_t {
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
     DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq, dropDiag;
     bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
-    // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f32 matrix, built in line by k_dense_spd_inverse
+    // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f64 matrix, built in line by k_dense_spd_inverse
     bool denseMode = false;
     int denseForB = 0;        // frame-block size of the problem the last build was for (a coarse-to-fine level)
     bool denseReady = false;  // a build for this plan has been launched: denseValid says whether denseInv holds an inverse
     DevBuf<double> denseA, densePanel;
-    DevBuf<float> denseInv;
+    DevBuf<double> denseInv;
     DevBuf<int> denseValid;
     int nW = 0;
     DevBuf<unsigned char> modeActive;
@@ -533,7 +533,7 @@ double evalFull(Ctx& c, const double* x, bool withStats = false);
 bool coarseFusedConsumers();
 bool fusedExchange(cvd_handle* h, bool withCoarse);
 size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
-void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, float* out, int* fail, hipStream_t s, int* outValid);
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);
 void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta, const double* lam,

@@ -1647,25 +1647,28 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   if (f >= L.F) {
     // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
     // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
-    // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the inverse are issued
+    // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the (f64) inverse are issued
     // at once, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in LDS
-    constexpr int kDenseLoads = 8;
+#ifndef CVD_DENSE_LOADS
+#define CVD_DENSE_LOADS 6
+#endif
+    constexpr int kDenseLoads = CVD_DENSE_LOADS;
     const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
     const size_t n = static_cast<size_t>(L.F) * kCB;
-    const int n4 = static_cast<int>(n / 4);
+    const int n2 = static_cast<int>(n / 2);
     double* qcs = sm;                       // n doubles (the frame workgroups' layout is not used here)
     double* psum = sm + n;                  // nThreads partial sums
     // kDenseFramesPerGroup frames per workgroup, one after the other: F + F / 2 workgroups of 768 threads still fit the
     // device in ONE round (two per CU), F + F do not
     const int g0 = (f - L.F) * kDenseFramesPerGroup;
-    float4 w[kDenseLoads];
+    double2 w[kDenseLoads];
     {
-      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + m) * n);
+      const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + m) * n);
 #pragma unroll
       for (int u = 0; u < kDenseLoads; ++u) {
         const int j = part + u * per;
-        w[u] = row[j < n4 ? j : 0];
-        if (j >= n4) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[u] = row[j < n2 ? j : 0];
+        if (j >= n2) w[u] = make_double2(0.0, 0.0);
       }
     }
     for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = ds.qc[i];
@@ -1675,32 +1678,33 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
     for (int rep = 0; rep < kDenseFramesPerGroup; ++rep) {
       const int g = g0 + rep;
       if (g >= L.F) break;
-      const float4* row = reinterpret_cast<const float4*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
+      const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
       if (rep > 0) {
 #pragma unroll
         for (int u = 0; u < kDenseLoads; ++u) {
           const int j = part + u * per;
-          w[u] = row[j < n4 ? j : 0];
-          if (j >= n4) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          w[u] = row[j < n2 ? j : 0];
+          if (j >= n2) w[u] = make_double2(0.0, 0.0);
         }
       }
       const int e = g * kCB + (tid < kCB ? tid : 0);
       const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
       const bool on = on0 && ds.modeActive[e];
-      double acc = 0.0;
+      double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
       for (int u = 0; u < kDenseLoads; ++u) {
         const int j = part + u * per;
-        const double* q4 = qcs + 4 * (j < n4 ? j : 0);
-        acc += (static_cast<double>(w[u].x) * q4[0] + static_cast<double>(w[u].y) * q4[1]) +
-               (static_cast<double>(w[u].z) * q4[2] + static_cast<double>(w[u].w) * q4[3]);
+        const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * (j < n2 ? j : 0));
+        acc0 += w[u].x * qq.x;
+        acc1 += w[u].y * qq.y;
       }
-      for (int j = part + kDenseLoads * per; j < n4; j += per) {  // (more than 8 x per float4 per row: F > 3 nThreads / 8)
-        const float4 ww = row[j];
-        const double* q4 = qcs + 4 * j;
-        acc += (static_cast<double>(ww.x) * q4[0] + static_cast<double>(ww.y) * q4[1]) +
-               (static_cast<double>(ww.z) * q4[2] + static_cast<double>(ww.w) * q4[3]);
+      for (int j = part + kDenseLoads * per; j < n2; j += per) {  // (more than 12 x per pairs per row: F > 3 nThreads / 8)
+        const double2 ww = row[j];
+        const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * j);
+        acc0 += ww.x * qq.x;
+        acc1 += ww.y * qq.y;
       }
+      const double acc = acc0 + acc1;
       psum[tid] = acc;
       __syncthreads();
       if (tid < kCB * 8) {  // 8 lanes per row fold its `per` partials, then three shuffle steps

@@ -108,9 +108,9 @@ void launchBlockInverse(Ctx& c) {
   h->tEnd(ct);
 }
 
-// out (f32, n x n) = A^-1 for one dense SPD f64 matrix (cvd_dense_inverse.h): one persistent launch, one workgroup per
+// out (f64, n x n) = A^-1 for one dense SPD f64 matrix (cvd_dense_inverse.h): one persistent launch, one workgroup per
 // super-tile of S x S 16-wide tiles, S the smallest for which the grid fits one workgroup per CU.
-void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, float* out, int* fail, hipStream_t s, int* outValid) {
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid) {
   auto& C = h->coarse;
   const int nT = (n + kInvTS - 1) / kInvTS;
   int S = 1;
@@ -219,7 +219,7 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     C.denseInv.ensure(static_cast<size_t>(n) * n);
     HIP_CHECK(hipMemsetAsync(C.denseA.p, 0, static_cast<size_t>(n) * n * sizeof(double), s));
     hipLaunchKernelGGL(k_coarse_dense_assemble, dim3(c.L.F + C.nEdges), dim3(64), 0, s, c.L.F, C.nEdges, C.diag.p, C.edges.p,
-                       C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p);
+                       C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.denseA.p, h->opt.coarse_dense_shift);
     HIP_CHECK(hipGetLastError());
     // (a rebuild that meets a non-positive pivot keeps the inverse in use when a build for this problem has succeeded)
     C.denseValid.ensure(1);

@@ -732,12 +732,31 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
   }
   struct ItemDesc { int fa, fb; long long b0, e0, b1, e1; };
   std::vector<ItemDesc> itemList;
+  // Constraints per direction and work item (list mode): 768 -- a whole pair of the sampled lists -- unless that would leave
+  // workgroup slots idle (three 256-thread workgroups per CU): a rank of a pair-sharded run holds 1 / world of the pairs (259
+  // of the benchmark's 2070 at 8 ranks: a third of the slots, every workgroup walking a whole pair), and small problems the
+  // same.  The pairs are then cut finer, down to 128 constraints, until the items fill the device once.
+  long long listChunk = kListChunk;
+  if (!h->dense) {
+    long long longest = 0;
+    for (const auto& e : edges) {
+      long long n0 = 0, n1 = 0;
+      if (e.second[0] >= 0) n0 = h->pairOff[e.second[0] + 1] - h->pairOff[e.second[0]];
+      if (e.second[1] >= 0) n1 = h->pairOff[e.second[1] + 1] - h->pairOff[e.second[1]];
+      longest += std::max(n0, n1);
+    }
+    const long long slots = 3ll * h->numCU;
+    if (longest / kListChunk + static_cast<long long>(edges.size()) < slots) {
+      const long long want = (longest + slots - 1) / slots;
+      listChunk = std::min<long long>(kListChunk, std::max<long long>(128, (want + 63) / 64 * 64));
+    }
+  }
   for (const auto& e : edges) {
     const int fa = e.first.first, fb = e.first.second;
     long long n0 = 0, n1 = 0, o0 = 0, o1 = 0;
     if (e.second[0] >= 0) { o0 = h->pairOff[e.second[0]]; n0 = h->pairOff[e.second[0] + 1] - o0; }
     if (e.second[1] >= 0) { o1 = h->pairOff[e.second[1]]; n1 = h->pairOff[e.second[1] + 1] - o1; }
-    const long long chunk = h->dense ? kDenseChunk : kListChunk;
+    const long long chunk = h->dense ? kDenseChunk : listChunk;
     const long long nItems = std::max<long long>(1, (std::max(n0, n1) + chunk - 1) / chunk);
     const long long c0 = (n0 + nItems - 1) / nItems, c1 = (n1 + nItems - 1) / nItems;
     for (long long k = 0; k < nItems; ++k) {

@@ -692,9 +692,9 @@ def test_dense_coarse_level_over_several_solves(Solver, tol):
 @pytest.mark.parametrize("variant", ["dense", "sparsified"])
 def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant):
     """Flow lists whose frame graph fills in under elimination (long-range pairs from nearly every frame) get the DENSE
-    coarse level (A_c inverted by k_dense_spd_inverse, applied as an f32 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
+    coarse level (A_c + coarse_dense_shift diag(A_c) inverted by k_dense_spd_inverse, applied as an f64 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
     (dropped pairs removed from the coarse operator).  Both are forced here on a small problem through the elimination
-    budget: A_c^-1 as applied really is the inverse (dense: to f32 accuracy), the operator stays SPD, and the solve
+    budget: A_c^-1 as applied really is the inverse (dense: of the shifted matrix) and is itself SPD, and the solve
     reaches the same minimum as with the exact sparse level."""
     F = 24
     v = synth.make_video(F, 128, 72, seed=12, extra_offsets=6)
@@ -720,8 +720,11 @@ def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant):
     assert dbg is not None and dbg["failed"] == 0
     A, Ai = dbg["a_c"], dbg["a_c_inverse"]
     assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max() and np.linalg.eigvalsh(A)[0] > 0.0
+    if variant == "dense":   # the level inverts A_c + shift diag(A_c) (cvd_solver_options::coarse_dense_shift, default 1e-5)
+        A = A + 1e-5 * np.diag(np.diag(A))
     err = np.abs(Ai @ A - np.eye(A.shape[0])).max()
-    assert err < (2e-2 if variant == "dense" else 1e-8), err   # (dense: f32 inverse of a badly scaled f64 matrix)
+    assert err < (1e-6 if variant == "dense" else 1e-8), err
+    assert np.linalg.eigvalsh(0.5 * (Ai + Ai.T))[0] > 0.0   # what is applied is positive definite
     if variant == "sparsified":   # fewer off-diagonal blocks than the full graph of the reference run
         Aref = ref.coarse_debug()["a_c"]
         nz = lambda M: int((np.abs(M.reshape(F, 8, F, 8)).max(axis=(1, 3)) > 0).sum())

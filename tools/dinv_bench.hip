@@ -14,7 +14,7 @@ using namespace cvd;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); std::exit(1); } } while (0)
 
 template <int TPW>
-static void launch(int groups, size_t lds, int n, int S, int nS, const double* A, float* out, int* fail, double* panel, double* pinv,
+static void launch(int groups, size_t lds, int n, int S, int nS, const double* A, double* out, int* fail, double* panel, double* pinv,
                    unsigned int* bar, int* valid) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_spd_inverse<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   hipLaunchKernelGGL((k_dense_spd_inverse<TPW>), dim3(groups), dim3(kDinvNW * 64), lds, 0, n, S, nS, A, out, fail, panel, pinv, bar, valid);
@@ -43,8 +43,8 @@ int main(int argc, char** argv) {
   const int nS = (nT + S - 1) / S, tpw = (S * S + kDinvNW - 1) / kDinvNW;
   const size_t lds = static_cast<size_t>(4 * S + 1 + kDinvNW) * kInvTile * sizeof(double);
   std::printf("n %d  tiles %d  S %d  workgroups %d  tiles/wave %d  LDS %zu B\n", n, nT, S, groups(S), tpw, lds);
-  double *dA, *dPanel; float* dOut; int* dFail; unsigned int* dBar;
-  CK(hipMalloc(&dA, nn * 8)); CK(hipMalloc(&dOut, nn * 4)); CK(hipMalloc(&dPanel, (static_cast<size_t>(2) * nT * 256 + 512) * 8));
+  double *dA, *dPanel; double* dOut; int* dFail; unsigned int* dBar;
+  CK(hipMalloc(&dA, nn * 8)); CK(hipMalloc(&dOut, nn * 8)); CK(hipMalloc(&dPanel, (static_cast<size_t>(2) * nT * 256 + 512) * 8));
   CK(hipMalloc(&dFail, 8)); CK(hipMalloc(&dBar, 16));
   CK(hipMemcpy(dA, h.data(), nn * 8, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
@@ -70,8 +70,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(fl, dFail, 8, hipMemcpyDeviceToHost));
   std::printf("k_dense_spd_inverse: %.1f us (best of 6), %.2f us per pivot step, fail %d valid %d\n", best * 1e3f, best * 1e3f / nT, fl[0], fl[1]);
   // residual of a few columns: A * out[:, j] = e_j
-  std::vector<float> out(nn);
-  CK(hipMemcpy(out.data(), dOut, nn * 4, hipMemcpyDeviceToHost));
+  std::vector<double> out(nn);
+  CK(hipMemcpy(out.data(), dOut, nn * 8, hipMemcpyDeviceToHost));
   double worst = 0;
   for (int j : {0, 1, n / 3, n / 2, n - 1}) {
     for (int i = 0; i < n; ++i) {
