@@ -5,19 +5,20 @@ TAG=${1:-r03a}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+exec < /dev/null
+# 1. HBM traffic of the hot kernel (separate passes per counter, MI355X_MICROARCH.md; lockstep PCG: no early-exit launches)
+#    -> profiles/pmc_matvec_pairs.json, which the bench line below reads for roofline.traffic (tied to the kernel sources by hash)
+bash $R/tools/pmc_refresh.sh $TAG > $OUT/pmc_refresh.log 2>&1
+mv $OUT/bench_full.json $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
 CMD_MAIN="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timing"
-python $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 $B --steps 20 --warmup 3 --time-all-kernels > $OUT/bench_allkernels.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 20 --warmup 3 --no-kernel-timing > $OUT/trace.log 2>&1
-# HBM traffic of the hot kernel: separate passes per counter (MI355X_MICROARCH.md), lockstep PCG (no early-exit launches)
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_matvec_pairs_fast" --output-format csv -d $OUT/pmc_fetch -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_matvec_pairs_fast" --output-format csv -d $OUT/pmc_write -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_write.log 2>&1
 # SQ counters of the PCG kernels and the dense inverse (wave cycles: parked / issue-stalled / active; VALU and LDS activity)
 K="k_matvec_pairs_fast|k_cg_update|k_matvec_finish|k_dense_spd_inverse"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_a -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_sq_a.log 2>&1
-# BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 60 and 300 frames)
+# BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 300 frames)
 python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
 python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_huber.json 2>> $OUT/bench.err
 python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300.json 2>> $OUT/bench.err
@@ -26,13 +27,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense -- pyth
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_cross_matvec" --output-format csv -d $OUT/pmc_fetch_dense -- python $R/bench.py --dense --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing --pcg-lockstep > $OUT/pmc_fetch_dense.log 2>&1
 python $R/tools/kernel_durations.py $OUT/trace_dense $TAG "$CMD_DENSE" > $OUT/kernel_durations_dense.txt 2>&1
 rm -rf $OUT/trace_dense
+# the dense inverse alone, what one rank of an N-rank run computes, run-to-run spread of the dense-level solve
+for n in 1000 2400 4096; do timeout 100 $R/tools/dinv_bench.bin $n >> $OUT/dinv_bench.log 2>&1; done
+timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
+timeout 200 python $R/tools/dense_coarse_probe.py 4 0 2>/dev/null | cut -c1-120 > $OUT/dense_coarse_probe.log
 # summaries (small, committed under profiles/)
 python $R/tools/kernel_durations.py $OUT/trace $TAG "$CMD_MAIN" > $OUT/kernel_durations.txt 2>&1
-python $R/tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_FETCH_SIZE.csv > /dev/null 2>&1
-python $R/tools/pmc_summary.py $OUT/pmc_write $OUT/pmc_WRITE_SIZE.csv > /dev/null 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc_sq_a $OUT/pmc_SQ_a.csv > /dev/null 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc_fetch_dense $OUT/pmc_FETCH_SIZE_dense.csv > /dev/null 2>&1
-python $R/tools/pmc_to_json.py $OUT $TAG > $OUT/pmc_matvec_pairs.json 2> $OUT/pmc_to_json.err
 cp $OUT/trace/*/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq_a $OUT/pmc_fetch_dense
-tail -c 300 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_300; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv
+rm -rf $OUT/trace $OUT/pmc_sq_a $OUT/pmc_fetch_dense
+tail -c 300 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_300; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv; cat $OUT/shard_sim.log $OUT/dense_coarse_probe.log $OUT/dinv_bench.log
