@@ -63,6 +63,9 @@ typedef struct cvd_solver_options {
                                      damping) the stored inverse stops being positive definite and PCG stalls.  The shift
                                      bounds the condition number of the Jacobi-scaled matrix; as a preconditioner the level
                                      loses nothing on directions that carry gradient */
+  int32_t constraint_order;       /* 1 (default): every pair's slice of the constraint table is re-ordered as a sweep over the
+                                     cells of the depth grid (consecutive lanes of a wave hit different grid vertices: the
+                                     LDS atomics of the pair-major kernels stop serialising); 0: the caller's order */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

@@ -32,6 +32,7 @@ class SolverOptions(C.Structure):
         ("coarse_rebuild_excess", C.c_int32),
         ("coarse_update_budget", C.c_int64),
         ("coarse_dense_shift", C.c_double),
+        ("constraint_order", C.c_int32),
     ]
 
 

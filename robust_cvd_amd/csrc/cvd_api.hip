@@ -214,11 +214,13 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_rebuild_excess = 16;
   o->coarse_update_budget = 40000;
   o->coarse_dense_shift = 1e-5;
+  o->constraint_order = 1;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
     if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
-      h->tableValid = false;  // (the coarse level's variant is chosen when the table is compiled)
+      h->tableValid = false;
+    if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
     h->opt = *o;
     h->distForced = h->world == 1 && (h->comm != nullptr || h->localGroup) && o->force_sharded_path != 0;
   });

@@ -188,8 +188,10 @@ struct cvd_handle_t {
   std::vector<long long> pairOff;
   DevBuf<int> dPairA, dPairB, dCPair;
   DevBuf<long long> dPairOff;
-  DevBuf<float4> dLoc, dNdc;
-  DevBuf<float2> dDsrc;
+  DevBuf<float4> dLoc, dNdc, dNdcOrd;   // (Ord: the table re-ordered for the current depth grid, orderTable)
+  DevBuf<float2> dDsrc, dDsrcOrd;
+  int orderGx = -1, orderGy = -1;       // grid the ordered copy was made for (0: input order in force, -1: stale)
+  bool tableOrdered = false;
   DevBuf<unsigned char> dStatic, dInRange, dRegOwner;
   // dense mode (cvd_set_pair_flows): flow / mask images of every directed pair instead of a constraint list
   bool dense = false;
@@ -513,6 +515,7 @@ bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const
                         bool normalize);
 AsmPanels makePanels(int B, size_t capDoubles, int& panelCap);
 void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplets = false, bool ignoreStatic = false);
+void orderTable(cvd_handle* h, const Layout& L, int KD);  // after compileTable: the table order for this problem's depth grid
 double* pinnedStage(cvd_handle* h, int which, size_t n);
 void uploadState(cvd_handle* h, const Layout& L, DevBuf<double>& dst);
 void downloadState(cvd_handle* h, const Layout& L, const DevBuf<double>& src);

@@ -335,8 +335,8 @@ bool fastLoss(const Layout& L) {
 }
 Table makeTable(cvd_handle* h) {
   Table T{};
-  T.ndc = h->dense ? nullptr : h->dNdc.p;
-  T.dsrc = h->dense ? nullptr : h->dDsrc.p;
+  T.ndc = h->dense ? nullptr : (h->tableOrdered ? h->dNdcOrd.p : h->dNdc.p);
+  T.dsrc = h->dense ? nullptr : (h->tableOrdered ? h->dDsrcOrd.p : h->dDsrc.p);
   T.pairA = h->dPairA.p;
   T.pairB = h->dPairB.p;
   T.pairOff = h->dPairOff.p;
@@ -699,6 +699,8 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     h->dNdc.ensure(std::max<long long>(h->C, 1));
     h->dDsrc.ensure(std::max<long long>(h->C, 1));
   }
+  h->orderGx = h->orderGy = -1;  // (the ordered copy, if any, is stale: orderTable)
+  h->tableOrdered = false;
   if (h->C > 0 && !h->dense) {
     const int bs = 256;
     const unsigned grid = static_cast<unsigned>((h->C + bs - 1) / bs);
@@ -1016,6 +1018,31 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
   h->tableRange = inRange;
   h->tableValid = true;
 }
+// The table in the order the pair-major kernels want for this problem's depth grid (k_order_table): a second copy of the
+// table, rebuilt when the table or the grid changes (coarse-to-fine levels refine the grid).  Grids only -- a Global
+// transform keeps its depth sums in registers -- and never the dense mode (no table).
+void orderTable(cvd_handle* h, const Layout& L, int KD) {
+  int gx = 0, gy = 0;
+  if (!h->dense && h->C > 0 && h->opt.constraint_order != 0 && L.depthType == kDepthGrid && L.gz <= 1 && (KD == 4 || KD == 16) &&
+      L.gx * L.gy <= kOrderMaxCells) {
+    gx = L.gx;
+    gy = L.gy;
+  }
+  if (h->orderGx == gx && h->orderGy == gy) return;
+  h->orderGx = gx;
+  h->orderGy = gy;
+  h->tableOrdered = false;
+  if (gx == 0) return;
+  h->dNdcOrd.ensure(h->C);
+  h->dDsrcOrd.ensure(h->C);
+  const size_t lds = static_cast<size_t>(gx * gy + 1) * sizeof(int) + 3 * kOrderCap * sizeof(unsigned short);
+  allowLds(k_order_table, lds);
+  hipLaunchKernelGGL(k_order_table, dim3(h->P), dim3(64), lds, h->stream, h->dPairOff.p, gx, gy, L.maxcx, L.maxcy, h->dNdc.p,
+                     h->dDsrc.p, h->dNdcOrd.p, h->dDsrcOrd.p);
+  HIP_CHECK(hipGetLastError());
+  h->tableOrdered = true;
+}
+
 // Pinned staging buffer `which` with room for n doubles (pageable transfers of the F x B vectors cost ~1 ms each).
 double* pinnedStage(cvd_handle* h, int which, size_t n) {
   if (h->hStageN[which] < n) {

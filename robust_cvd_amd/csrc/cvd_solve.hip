@@ -171,6 +171,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   tapCounts(c.L, c.KD, c.KS);
   phase("layout");
   compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
+  orderTable(h, c.L, c.KD);
   phase("table");
   refreshMedians(h);
   phase("medians");
@@ -443,6 +444,7 @@ void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, con
   c.L = makeLayout(h, p, depthDeformReg, PK_POSE_STEP);
   tapCounts(c.L, c.KD, c.KS);
   compileTable(h, range, wantsTriplets(p, PK_POSE_STEP));
+  orderTable(h, c.L, c.KD);
   refreshMedians(h);
   c.T = makeTable(h);
   c.nItems = static_cast<int>(h->itemFa.size());

@@ -113,6 +113,44 @@ def test_fast_and_generic_product_kernels_agree(Solver):
         assert rel(fast["hdiag"], gen["hdiag"]) < 1e-12
 
 
+@pytest.mark.parametrize("case", ["bilinear", "bicubic", "long_pairs", "one_cell"])
+def test_table_order_is_a_permutation_of_every_pairs_constraints(Solver, case):
+    """cvd_solver_options::constraint_order (k_order_table): the table re-ordered as a sweep over the cells of the depth grid
+    holds the SAME constraints, pair by pair -- cost, gradient, diagonal blocks, full J^T J and the product agree with the
+    caller's order to rounding.  Cases: the default bilinear grid; a bicubic grid; pairs longer than one window of the
+    kernel (4096 constraints; ragged last window); a 2 x 2 grid = every constraint in the one cell (the longest sweep)."""
+    ddesc = {"bilinear": XformDesc.grid_depth(6, 5), "bicubic": XformDesc.grid_depth(5, 4, cubic=True),
+             "long_pairs": XformDesc.grid_depth(9, 6), "one_cell": XformDesc.grid_depth(2, 2)}[case]
+    if case == "long_pairs":
+        v = synth.make_video(3, 192, 112, seed=41, spacing=2.0)   # ~6100 constraints per pair: two windows, the second ragged
+        assert np.diff(v.offsets).max() > 4096 + 500
+    else:
+        v = synth.make_video(5, 96, 56, seed=41, spacing=5)
+    rng = np.random.default_rng(3)
+    F = v.num_frames
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.03, (F, 6))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+    out = []
+    for order in (0, 1):
+        s = Solver(0)
+        s.set_options(constraint_order=order)
+        synth.load_into(s, v)
+        s.reset_depth_xforms(ddesc)
+        s.reset_spatial_xforms(XformDesc.spatial())
+        dx = 0.15 + np.random.default_rng(4).uniform(0, 0.05, s.get_xform_params().shape)
+        s.set_xform_params(dx)
+        p = OptParams.defaults()
+        out.append(s.evaluate(p, 0.1, pose, want_hdiag=True, want_hfull=True))
+        s.close()
+    a, b = out
+    assert a["num_residual_blocks"] == b["num_residual_blocks"]
+    assert abs(a["cost"] - b["cost"]) <= 1e-12 * abs(a["cost"])
+    assert rel(a["gradient"], b["gradient"]) < 1e-11
+    assert rel(a["hdiag"], b["hdiag"]) < 1e-11
+    assert rel(a["hfull"], b["hfull"]) < 1e-11   # (the matrix-free product, column by column)
+
+
 def test_fast_and_generic_candidate_cost_agree(Solver):
     """k_cost_items_fast (candidate-point cost of the default pipeline) vs the generic kernel: a few LM iterations from the
     same state, with the inner solve driven to 1e-10 so that both runs take the same steps; the accepted costs
