@@ -47,10 +47,11 @@ template <bool DENSE>
 __device__ __forceinline__ bool loadConstraint(const Table& T, long long c, long long pixBase, int fa, int fb, float4& n,
                                                float2& d) {
   if constexpr (!DENSE) {
+    // (both records are requested at once: testing d first made the 16-byte load a SECOND dependent round trip in every trip
+    // of the constraint loops; skipped entries are rare and the 16 bytes of one are free)
     d = T.dsrc[c];
-    if (!(d.x > 0.f)) return false;
     n = T.ndc[c];
-    return true;
+    return d.x > 0.f;
   } else {
     if (!T.fmask[c]) return false;
     const int pix = static_cast<int>(c - pixBase);
@@ -80,6 +81,37 @@ __device__ __forceinline__ bool loadConstraint(const Table& T, long long c, long
     return true;
   }
 }
+
+// Walk over table records c, c + step, ... < end with the NEXT record in flight (list mode; the dense mode's on-the-fly
+// constraints go through loadConstraint).  Loaded at the top of its own trip a record is a global round trip -- two,
+// dependent, where the compiler sinks the 16-byte half below the validity test of the 8-byte half -- that only the other
+// waves of the SIMD can hide; requested one trip ahead (6 registers) it is back before it is needed (hot product
+// 50.2 -> 48.6 us, 1000 frames: 213 -> 195 us).
+template <bool DENSE>
+struct RecordStream {
+  float4 ndNext;
+  float2 dNext;
+  // records base + i, base + i + step, ... (i < n); base is wave-uniform: 32-bit offsets from a scalar base address
+  __device__ __forceinline__ void prime(const Table& T, long long base, int i, int n) {
+    ndNext = make_float4(0.f, 0.f, 0.f, 0.f);
+    dNext = make_float2(0.f, 0.f);
+    if constexpr (!DENSE) {
+      if (i < n) { dNext = (T.dsrc + base)[i]; ndNext = (T.ndc + base)[i]; }
+    }
+  }
+  // record base + i (false: skipped); requests record base + i + step
+  __device__ __forceinline__ bool take(const Table& T, long long base, int i, int step, int n, long long pixBase, int fa, int fb,
+                                       float4& nd, float2& d) {
+    if constexpr (DENSE) {
+      return loadConstraint<true>(T, base + i, pixBase, fa, fb, nd, d);
+    } else {
+      nd = ndNext;
+      d = dNext;
+      if (i + step < n) { dNext = (T.dsrc + base)[i + step]; ndNext = (T.ndc + base)[i + step]; }
+      return d.x > 0.f;
+    }
+  }
+};
 
 // Valid constraints of the dense mode (what k_build_table counts for the list mode).
 inline __global__ void k_dense_count(Table T, int P, const unsigned char* __restrict__ inRange, unsigned long long* __restrict__ nValid) {
@@ -2205,10 +2237,13 @@ inline __global__ __launch_bounds__(256) void k_cost_items_fast(Layout L, Table 
     const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
     const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
     const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
-    for (long long c = cb + tid; c < ce; c += 256) {
+    RecordStream<DENSE> rs;
+    const int nDir = static_cast<int>(ce - cb);
+    rs.prime(T, cb, tid, nDir);
+    for (int ci = tid; ci < nDir; ci += 256) {
       float4 nd;
       float2 d;
-      if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
+      if (!rs.take(T, cb, ci, 256, nDir, pixBase, fsrc, ftgt, nd, d)) continue;
       const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
       double Da, Db;
       if (N == 0) {
@@ -2449,10 +2484,14 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // the wave after the one that took direction 0's last unit.  With ~9 units per direction and 4 waves the slowest wave
   // walks 5 units instead of 3 + 3 (both directions' remainders used to land on waves 0, 1).
   const int firstUnit = dir == 0 ? (tid >> 6) : static_cast<int>(((tid >> 6) - units0) & (NT / 64 - 1));
-  for (long long c = cb + firstUnit * 64 + (tid & 63); c < ce; c += NT) {
+  RecordStream<DENSE> rs;   // (list mode: the next trip's table record is in flight during this trip's arithmetic)
+  const int nDir = static_cast<int>(ce - cb);
+  const int iFirst = firstUnit * 64 + (tid & 63);
+  rs.prime(T, cb, iFirst, nDir);
+  for (int ci = iFirst; ci < nDir; ci += NT) {
     float4 nd;
     float2 d;
-    if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
+    if (!rs.take(T, cb, ci, NT, nDir, pixBase, fsrc, ftgt, nd, d)) continue;
     const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
     FastTaps<KD> ta, tb;
     fastGather<KD>(L, nd.x, nd.y, ta);
@@ -2569,6 +2608,11 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     if (N > 0) {
       const double ga = Rca[0] * yX[0] + Rca[1] * yX[1] + Rca[2] * yX[2];
       const double gb = dr2dDb * t2;
+      // (the source depths are converted again here instead of being kept as doubles across the trip: with the next record
+      // in flight the loop needs every register of its three-waves budget; the asm keeps the two conversions apart)
+      float dxLate = d.x, dyLate = d.y;
+      asm volatile("" : "+v"(dxLate), "+v"(dyLate));
+      const double da = static_cast<double>(dxLate), db = static_cast<double>(dyLate);
       if constexpr (KD == 1) {
         gDa[0] += ga * da; gDa[1] += ga;
         gDb[0] += gb * db; gDb[1] += gb;
@@ -2798,6 +2842,8 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
       const long long cFirst = DENSE ? cBegin + static_cast<long long>(lane) * kDenseRun : cBegin + lane;
       const long long cStop = DENSE ? (cFirst + kDenseRun < cEnd ? cFirst + kDenseRun : cEnd) : cEnd;
       constexpr long long cStep = DENSE ? 1 : 64;
+      // (no RecordStream here: a unit is two trips per lane and the kernel sits at its 256-register budget -- the six
+      // registers of a record in flight spill: 0.33 -> 0.35 ms)
       for (long long c = cFirst; c < cStop; c += cStep) {
         float4 nd;
         float2 d;
