@@ -1778,7 +1778,7 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
     // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the (f64) inverse are issued
     // at once, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in LDS
 #ifndef CVD_DENSE_LOADS
-#define CVD_DENSE_LOADS 6
+#define CVD_DENSE_LOADS 4
 #endif
     constexpr int kDenseLoads = CVD_DENSE_LOADS;
     const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
@@ -1807,30 +1807,28 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
       const int g = g0 + rep;
       if (g >= L.F) break;
       const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
-      if (rep > 0) {
-#pragma unroll
-        for (int u = 0; u < kDenseLoads; ++u) {
-          const int j = part + u * per;
-          w[u] = row[j < n2 ? j : 0];
-          if (j >= n2) w[u] = make_double2(0.0, 0.0);
-        }
-      }
       const int e = g * kCB + (tid < kCB ? tid : 0);
       const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
       const bool on = on0 && ds.modeActive[e];
       double acc0 = 0.0, acc1 = 0.0;
+      // the row in BATCHES of kDenseLoads loads per thread, every batch's loads issued together (a thread walks 12.5 pairs
+      // of a 2400-wide row: three round trips; a load-use loop over the part beyond the first batch was seven)
+      for (int base = 0; base < n2; base += kDenseLoads * per) {
+        if (rep > 0 || base > 0) {  // (the first batch of the first frame was requested before the barrier)
 #pragma unroll
-      for (int u = 0; u < kDenseLoads; ++u) {
-        const int j = part + u * per;
-        const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * (j < n2 ? j : 0));
-        acc0 += w[u].x * qq.x;
-        acc1 += w[u].y * qq.y;
-      }
-      for (int j = part + kDenseLoads * per; j < n2; j += per) {  // (more than 12 x per pairs per row: F > 3 nThreads / 8)
-        const double2 ww = row[j];
-        const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * j);
-        acc0 += ww.x * qq.x;
-        acc1 += ww.y * qq.y;
+          for (int u = 0; u < kDenseLoads; ++u) {
+            const int j = base + part + u * per;
+            w[u] = row[j < n2 ? j : 0];
+            if (j >= n2) w[u] = make_double2(0.0, 0.0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kDenseLoads; ++u) {
+          const int j = base + part + u * per;
+          const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * (j < n2 ? j : 0));
+          acc0 += w[u].x * qq.x;
+          acc1 += w[u].y * qq.y;
+        }
       }
       const double acc = acc0 + acc1;
       psum[tid] = acc;
