@@ -66,6 +66,10 @@ typedef struct cvd_solver_options {
   int32_t constraint_order;       /* 1 (default): every pair's slice of the constraint table is re-ordered as a sweep over the
                                      cells of the depth grid (consecutive lanes of a wave hit different grid vertices: the
                                      LDS atomics of the pair-major kernels stop serialising); 0: the caller's order */
+  int32_t coarse_rebuild_excess_dense; /* the same threshold for the DENSE coarse level (default 32): its rebuild is one
+                                     in-line 1.6 ms kernel (300 frames) = 22 PCG iterations, not a side-stream job, and the
+                                     PCG counts of an LM run grow by themselves as the trust region opens -- at 16 the level
+                                     was rebuilt every second LM iteration for 0.6 fewer PCG iterations per LM iteration */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

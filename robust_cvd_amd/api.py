@@ -33,6 +33,7 @@ class SolverOptions(C.Structure):
         ("coarse_update_budget", C.c_int64),
         ("coarse_dense_shift", C.c_double),
         ("constraint_order", C.c_int32),
+        ("coarse_rebuild_excess_dense", C.c_int32),
     ]
 
 

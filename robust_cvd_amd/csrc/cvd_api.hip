@@ -215,6 +215,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_update_budget = 40000;
   o->coarse_dense_shift = 1e-5;
   o->constraint_order = 1;
+  o->coarse_rebuild_excess_dense = 32;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {

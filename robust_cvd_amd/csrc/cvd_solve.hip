@@ -239,7 +239,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
   int invalid = 0, iteration = 0, termination = 1;
-  const int kCoarseRebuildIters = std::max(0, h->opt.coarse_rebuild_excess);
+  const int kCoarseRebuildIters = std::max(0, h->coarse.denseMode ? h->opt.coarse_rebuild_excess_dense : h->opt.coarse_rebuild_excess);
   int coarseAge = -1, cgAfterRefresh = 0, cgExcess = 0;  // coarse level: LM iterations since the last rebuild
   bool& coarsePending = pendingGuard.pending;  // a rebuild is running on the side stream
   int factorUses = 0;          // PCG solves done with the factor in use
