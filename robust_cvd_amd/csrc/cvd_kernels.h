@@ -1775,10 +1775,12 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   if (f >= L.F) {
     // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
     // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
-    // nThreads / 8 threads per row (96 at B = 177); a thread walks its share of the (f64) row in batches of kDenseLoads
-    // 16-byte loads issued together, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in
-    // LDS.  kDenseLoads = 4 keeps the kernel under 80 VGPRs, i.e. two 768-thread workgroups per CU (tests/test_codegen.py)
-    constexpr int kDenseLoads = 4;
+    // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the (f64) inverse are issued
+    // at once, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in LDS
+#ifndef CVD_DENSE_LOADS
+#define CVD_DENSE_LOADS 4
+#endif
+    constexpr int kDenseLoads = CVD_DENSE_LOADS;
     const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
     const size_t n = static_cast<size_t>(L.F) * kCB;
     const int n2 = static_cast<int>(n / 2);
