@@ -37,6 +37,36 @@ struct Table {
   float sx, sy, invAspect;      // loc = pixel * (1 / W, invAspect / H), float as in the reference (:371)
 };
 
+// Dense mode, the part of a constraint that follows its mask byte and flow vector `f` (both of which the kernels request
+// one trip ahead, RecordStream): bounds test of the rounded target, scaling, Observation constructor incl. the two depths.
+__device__ __forceinline__ bool denseConstraintFromFlow(const Table& T, long long c, long long pixBase, int fa, int fb, float2 f,
+                                                        float4& n, float2& d) {
+  const int pix = static_cast<int>(c - pixBase);
+  const int iy = pix / T.W, ix = pix - iy * T.W;
+  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
+  if (!(isfinite(fx1) && isfinite(fy1))) return false;
+  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
+  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
+  const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
+  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
+  n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
+  n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
+  n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
+  n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
+  int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
+  int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
+  int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
+  int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
+  ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
+  bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
+  const size_t fs = static_cast<size_t>(T.W) * T.H;
+  const float da = T.depth[fa * fs + static_cast<size_t>(ay) * T.W + ax];
+  const float db = T.depth[fb * fs + static_cast<size_t>(by) * T.W + bx];
+  if (!(isfinite(da) && da > 0.f && isfinite(db) && db > 0.f)) return false;
+  d = make_float2(da, db);
+  return true;
+}
+
 // One constraint of the pair-major / frame-major fast kernels: (ndc of both end points, the two source depths); false =
 // skipped.  DENSE = false: the compiled 24 B table entry.  DENSE = true: built on the fly from the flow / mask / depth
 // images with the reference's float arithmetic -- candidate test of FlowConstraintsCollection::compute (reference
@@ -54,31 +84,7 @@ __device__ __forceinline__ bool loadConstraint(const Table& T, long long c, long
     return d.x > 0.f;
   } else {
     if (!T.fmask[c]) return false;
-    const int pix = static_cast<int>(c - pixBase);
-    const int iy = pix / T.W, ix = pix - iy * T.W;
-    const float2 f = T.flow[c];
-    const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-    if (!(isfinite(fx1) && isfinite(fy1))) return false;
-    const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-    if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
-    const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
-    const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
-    n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
-    n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
-    n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
-    n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
-    int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
-    int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
-    int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
-    int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
-    ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
-    bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
-    const size_t fs = static_cast<size_t>(T.W) * T.H;
-    const float da = T.depth[fa * fs + static_cast<size_t>(ay) * T.W + ax];
-    const float db = T.depth[fb * fs + static_cast<size_t>(by) * T.W + bx];
-    if (!(isfinite(da) && da > 0.f && isfinite(db) && db > 0.f)) return false;
-    d = make_float2(da, db);
-    return true;
+    return denseConstraintFromFlow(T, c, pixBase, fa, fb, T.flow[c], n, d);
   }
 }
 
@@ -95,21 +101,36 @@ struct RecordStream {
   __device__ __forceinline__ void prime(const Table& T, long long base, int i, int n) {
     ndNext = make_float4(0.f, 0.f, 0.f, 0.f);
     dNext = make_float2(0.f, 0.f);
-    if constexpr (!DENSE) {
-      if (i < n) { dNext = (T.dsrc + base)[i]; ndNext = (T.ndc + base)[i]; }
-    }
+    if (i < n) { dNext = (T.dsrc + base)[i]; ndNext = (T.ndc + base)[i]; }
   }
   // record base + i (false: skipped); requests record base + i + step
+  __device__ __forceinline__ bool take(const Table& T, long long base, int i, int step, int n, long long, int, int, float4& nd,
+                                       float2& d) {
+    nd = ndNext;
+    d = dNext;
+    if (i + step < n) { dNext = (T.dsrc + base)[i + step]; ndNext = (T.ndc + base)[i + step]; }
+    return d.x > 0.f;
+  }
+};
+// Dense mode: a constraint is a chain mask byte -> flow vector -> the two depths (the target's address depends on the
+// flow).  Mask and flow of the NEXT pixel are requested one trip ahead (3 registers): one dependent round trip per pixel --
+// the depths -- instead of three.
+template <>
+struct RecordStream<true> {
+  float2 fNext;
+  unsigned int mNext;
+  __device__ __forceinline__ void prime(const Table& T, long long base, int i, int n) {
+    fNext = make_float2(0.f, 0.f);
+    mNext = 0u;
+    if (i < n) { mNext = (T.fmask + base)[i]; fNext = (T.flow + base)[i]; }
+  }
   __device__ __forceinline__ bool take(const Table& T, long long base, int i, int step, int n, long long pixBase, int fa, int fb,
                                        float4& nd, float2& d) {
-    if constexpr (DENSE) {
-      return loadConstraint<true>(T, base + i, pixBase, fa, fb, nd, d);
-    } else {
-      nd = ndNext;
-      d = dNext;
-      if (i + step < n) { dNext = (T.dsrc + base)[i + step]; ndNext = (T.ndc + base)[i + step]; }
-      return d.x > 0.f;
-    }
+    const unsigned int m = mNext;
+    const float2 f = fNext;
+    if (i + step < n) { mNext = (T.fmask + base)[i + step]; fNext = (T.flow + base)[i + step]; }
+    if (!m) return false;
+    return denseConstraintFromFlow(T, base + i, pixBase, fa, fb, f, nd, d);
   }
 };
 
@@ -2840,12 +2861,19 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
       const long long cFirst = DENSE ? cBegin + static_cast<long long>(lane) * kDenseRun : cBegin + lane;
       const long long cStop = DENSE ? (cFirst + kDenseRun < cEnd ? cFirst + kDenseRun : cEnd) : cEnd;
       constexpr long long cStep = DENSE ? 1 : 64;
-      // (no RecordStream here: a unit is two trips per lane and the kernel sits at its 256-register budget -- the six
-      // registers of a record in flight spill: 0.33 -> 0.35 ms)
+      // (list mode: no RecordStream -- a unit is two trips per lane and the kernel sits at its 256-register budget, the six
+      // registers of a record in flight spill: 0.33 -> 0.35 ms.  Dense mode: mask and flow of the lane's next pixel in flight)
+      RecordStream<true> rs;
+      const int iFirst = static_cast<int>(cFirst - cBegin), iStop = static_cast<int>(cStop - cBegin);
+      if constexpr (DENSE) rs.prime(T, cBegin, iFirst, iStop);
       for (long long c = cFirst; c < cStop; c += cStep) {
         float4 nd;
         float2 d;
-        if (!loadConstraint<DENSE>(T, c, T.pairOff[p], fsrc, ftgt, nd, d)) continue;
+        if constexpr (DENSE) {
+          if (!rs.take(T, cBegin, static_cast<int>(c - cBegin), 1, iStop, T.pairOff[p], fsrc, ftgt, nd, d)) continue;
+        } else {
+          if (!loadConstraint<false>(T, c, T.pairOff[p], fsrc, ftgt, nd, d)) continue;
+        }
         const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
         FastTaps<KD> ta, tb;
         fastGather<KD>(L, nd.x, nd.y, ta);
