@@ -209,13 +209,19 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_assemble(Layout 
     for (long long u0 = cb + wave * kUnit; u0 < ce; u0 += NW * kUnit) {
       const long long cFirst = u0 + static_cast<long long>(lane) * kCrossRun;
       const long long cStop = cFirst + kCrossRun < ce ? cFirst + kCrossRun : ce;
-      RecordStream<true> rs;   // (mask and flow of the lane's next pixel in flight)
+      // (GRID = 1: mask and flow of the lane's next pixel in flight; the pose half sits at its 256-register budget and
+      // loses with them: 14.4 -> 16.0 ms)
+      RecordStream<true> rs;
       const int iStop = static_cast<int>(cStop - u0);
-      rs.prime(T, u0, static_cast<int>(cFirst - u0), iStop);
+      if constexpr (GRID) rs.prime(T, u0, static_cast<int>(cFirst - u0), iStop);
       for (long long c = cFirst; c < cStop; ++c) {
         float4 nd;
         float2 d;
-        if (!rs.take(T, u0, static_cast<int>(c - u0), 1, iStop, cb, fs, ft, nd, d)) continue;
+        if constexpr (GRID) {
+          if (!rs.take(T, u0, static_cast<int>(c - u0), 1, iStop, cb, fs, ft, nd, d)) continue;
+        } else {
+          if (!loadConstraint<true>(T, c, cb, fs, ft, nd, d)) continue;
+        }
         CrossRows<KD> R;
         crossRows<KD>(L, Fs, Ft, xs, xt, nd, d, R);
         // row side = frame fa, column side = frame fb
