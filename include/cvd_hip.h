@@ -36,7 +36,8 @@ typedef struct cvd_solver_options {
                                     DESIGN.md 4.  Ceres' own inexact-step default is 0.1. */
   int32_t pcg_max_iterations;    /* default 300 */
   int32_t pcg_check_every;       /* unused since the device mirrors its progress to the host (kept for layout) */
-  int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout */
+  int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout; 2: + PCG scalars per iteration;
+                                    3: + setup phases and the shape of the coarse elimination (development) */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
   int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve
                                     (8 unknowns per frame), coarse factor rebuilt on demand; 2: rebuilt every LM

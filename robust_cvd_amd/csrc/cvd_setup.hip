@@ -572,7 +572,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.nLevels = nLevels;
   C.itemEdge = itemEdge;
   auto up = [&](DevBuf<int>& d, const std::vector<int>& v) { d.upload(v.data(), v.size(), s); };
-  if (std::getenv("CVD_COARSE_PLAN_STATS")) {  // development aid: shape of the elimination levels
+  if (h->opt.verbose >= 3) {  // development aid: shape of the elimination levels
     for (int lv = 0; lv < nLevels; ++lv) {
       long long nupd = 0, maxCol = 0, nblk = 0, maxChain = 0;
       for (int q = levelPtr[lv]; q < levelPtr[lv + 1]; ++q) {

@@ -70,7 +70,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
   // batches of `every` iterations and reads the control scalars of batch b only before enqueuing batch b + 2, so
   // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
-  // (profiling aid: CVD_PCG_LOCKSTEP=1 checks after every iteration and never runs ahead, so that per-launch
+  // (profiling aid: cvd_solver_options::pcg_lockstep checks after every iteration and never runs ahead, so that per-launch
   // counter averages contain no early-exit launches)
   const bool lockstep = h->opt.pcg_lockstep != 0;
   const size_t firstTimerSlot = h->evUsed;
@@ -156,7 +156,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
     bool pending = false;
     ~PendingGuard() { if (pending) (void)hipStreamWaitEvent(h->stream, h->evCoarseDone, 0); }
   } pendingGuard{h};
-  static const bool dbgSetup = std::getenv("CVD_DEBUG_SETUP") != nullptr;  // development: where a solve's fixed cost goes
+  const bool dbgSetup = h->opt.verbose >= 3;  // development: where a solve's fixed cost goes
   double tPhase = nowSeconds();
   auto phase = [&](const char* what) {
     if (!dbgSetup) return;

@@ -50,6 +50,7 @@ static bool dirExists(const std::string& p) {
   return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
 }
 static bool g_logStdout = false;
+static bool g_denseHandOver = true;  // setDenseHandOver(): matchSeparation = 0 collections may go to the solver as images
 static void logInfo(const std::string& s) {
   if (g_logStdout) { std::fputs(s.c_str(), stdout); std::fputc('\n', stdout); }
 }
@@ -1370,13 +1371,13 @@ struct DepthVideoProcessor {
       if (!masks.empty()) s.check(cvd_set_dynamic_masks(s.h, mh, mw, masks.data()));
     }
     // matchSeparation = 0 collections whose flow images are at hand and match the depth stream's raster go to the solver as
-    // images (dense mode: nothing materialised on the device); LIB_PYTHON_NO_DENSE forces the list (comparison / tests)
+    // images (dense mode: nothing materialised on the device); lib_python.setDenseHandOver(False) forces the list (comparison / tests)
     // -- and only when the solve these parameters describe lies within the dense mode's scope (the library fails outside it
     // instead of falling back: the list path serves every configuration)
     std::vector<int32_t> scopeRange;
     const cvd_opt_params scopeParams = toC(p.poseOptimizer, scopeRange);
     const cvd_xform_desc scopeDd = ds.depthXformDesc_.toC(), scopeSd = ds.spatialXformDesc_.toC();
-    const bool denseHandOver = fc.denseValid_ && fc.denseW_ == w && fc.denseH_ == h && std::getenv("LIB_PYTHON_NO_DENSE") == nullptr &&
+    const bool denseHandOver = fc.denseValid_ && fc.denseW_ == w && fc.denseH_ == h && g_denseHandOver &&
                                fc.denseMask_.size() == fc.pairs_.size() * static_cast<size_t>(w) * h && fc.allPairConstraintsStatic() &&
                                cvd_dense_mode_supported(&scopeParams, &scopeDd, &scopeSd, fc.triplets_.empty() ? 0 : 1, 1,
                                                         forNormalize ? 1 : 0) == 1;
@@ -1657,6 +1658,9 @@ PYBIND11_MODULE(lib_python, m) {
   m.doc() = "MI355X-native drop-in for robust_cvd's lib_python (optimizer path only)";
   m.def("initLib", []() {});
   m.def("logToStdout", []() { g_logStdout = true; });
+  // (not in the reference: matchSeparation = 0 collections go to the solver as flow images when the solve lies in the dense
+  // mode's scope; False keeps the materialised constraint list)
+  m.def("setDenseHandOver", [](bool on) { g_denseHandOver = on; }, py::arg("enabled"));
   m.def("computeDepthRange", [](const py::array_t<float, py::array::c_style | py::array::forcecast>& d) {
     float mn = std::numeric_limits<float>::max(), mx = std::numeric_limits<float>::min();  // reference lib/DepthMapTransform.cpp:20-34
     for (ssize_t i = 0; i < d.size(); ++i) {

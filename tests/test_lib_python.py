@@ -460,7 +460,7 @@ def test_match_separation_zero_goes_to_the_solver_as_images(lib, tmp_path, monke
     """FlowConstraintsParams.matchSeparation = 0 (reference lib/FlowConstraints.cpp:315-329, 381-395: every masked in-bounds
     pixel is a constraint): the collection keeps the flow / mask images it was computed from and DepthVideoProcessor hands
     THOSE to the solver (cvd_set_pair_flows, dense mode) instead of the materialised list.  Same optimize_poses() sequence
-    with the hand-over switched off (LIB_PYTHON_NO_DENSE: the list path) must end in the same state."""
+    with the hand-over switched off (lib_python.setDenseHandOver(False): the list path) must end in the same state."""
     import json
     from tests.drop_in_caller import build_pose_optimizer, optimize_poses
     v = synth.make_video(8, 96, 56, seed=71)
@@ -475,8 +475,7 @@ def test_match_separation_zero_goes_to_the_solver_as_images(lib, tmp_path, monke
         with open(os.path.join(base, "flow_list.json"), "w") as f:
             json.dump([["src", "dst"]] + v.pairs.tolist(), f)
         dataset_io.write_flow_inputs(base, v.pairs, flows, masks, colors)
-        if mode == "list":
-            monkeypatch.setenv("LIB_PYTHON_NO_DENSE", "1")
+        lib.setDenseHandOver(mode != "list")
         opt = lib.DepthVideoPoseOptimizer.Params()
         opt.ctfLong, opt.ctfShort = 6, 4
         # (tests/drop_in_caller.build_pose_optimizer with matchSeparation = 0 and no dynamic-mask flags)
@@ -501,6 +500,7 @@ def test_match_separation_zero_goes_to_the_solver_as_images(lib, tmp_path, monke
                      np.stack([np.asarray(ds.frame(f).extrinsics.orientation.coeffs()) for f in frames]),
                      np.stack([np.asarray(ds.frame(f).depthXform().params()) for f in frames]),
                      ds.depthXformDesc().str())
+        lib.setDenseHandOver(True)   # (module-wide switch: back to its default for the tests that follow)
     assert res["images"][3] == res["list"][3] == "Grid(Scale, Linear, 6, 4, 1)"
     perr, rerr = synth.relative_pose_error(res["images"][0], res["images"][1], res["list"][0], res["list"][1])
     assert perr < 1e-4 and rerr < 1e-4, (perr, rerr)
