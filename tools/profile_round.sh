@@ -28,6 +28,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_cross_matvec" --output-form
 python $R/tools/kernel_durations.py $OUT/trace_dense $TAG "$CMD_DENSE" > $OUT/kernel_durations_dense.txt 2>&1
 rm -rf $OUT/trace_dense
 # the dense inverse alone, what one rank of an N-rank run computes, run-to-run spread of the dense-level solve
+[ -x $R/tools/dinv_bench.bin ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Wno-cuda-compat -I$R/include -I$R/robust_cvd_amd/csrc $R/tools/dinv_bench.hip -o $R/tools/dinv_bench.bin
 for n in 1000 2400 4096; do timeout 100 $R/tools/dinv_bench.bin $n >> $OUT/dinv_bench.log 2>&1; done
 timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
 timeout 200 python $R/tools/dense_coarse_probe.py 4 0 2>/dev/null | cut -c1-120 > $OUT/dense_coarse_probe.log
