@@ -49,6 +49,23 @@ def test_default_params_match_reference_defaults():
     assert p.focal_long == 0.3461538376301239 and p.intr_opt == 2 and p.static_loss_type == 1
 
 
+def test_default_solver_options():
+    """The defaults bench.py times and the parity tests run with (include/cvd_hip.h cvd_solver_options); nothing is read from
+    the environment, in the library or in the drop-in module."""
+    lib = api.load_library()
+    o = api.SolverOptions()
+    lib.cvd_solver_options_default(C.byref(o))
+    assert o.pcg_relative_tolerance == 1e-3 and o.pcg_max_iterations == 300 and o.coarse_level == 1 and o.robust_loss == 0
+    assert o.coarse_rebuild_excess == 16 and o.coarse_rebuild_excess_dense == 32
+    assert o.coarse_dense_max_unknowns == 4096 and o.coarse_update_budget == 40000 and o.coarse_dense_shift == 1e-5
+    assert o.constraint_order == 1
+    assert (o.force_sharded_path, o.dense_matrix_free, o.block_inverse_variant, o.pcg_lockstep, o.force_iterations, o.verbose) == (0,) * 6
+    csrc = os.path.join(ROOT, "robust_cvd_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f} reads the environment"
+
+
 def test_no_cpu_fallback(have_gpu):
     """Without a GPU the product path must fail loudly (no CPU fallback, no oracle routing)."""
     if have_gpu:
