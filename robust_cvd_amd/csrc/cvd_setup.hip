@@ -361,12 +361,13 @@ bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const
   if (p.static_loss_type != CVD_STATIC_REPRO_DISPARITY && p.static_loss_type != CVD_STATIC_REPRO_DEPTH_RATIO &&
       p.static_loss_type != CVD_STATIC_REPRO_LOG_DEPTH)
     return false;
-  if (dd.depth_type == CVD_DEPTH_IDENTITY) return true;
+  (void)haveTriplets;
+  if (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) return false;  // (scene-flow triplets: generic kernels)
+  if (p.intr_opt == CVD_INTR_SHARED) return false;
+  // an Identity depth transform has no value parameter (N = 0): the fast kernels and checkDenseScope need N == 1
+  if (dd.depth_type == CVD_DEPTH_IDENTITY) return false;
   if (dd.value_xform != CVD_VALUE_SCALE) return false;
   if (dd.depth_type == CVD_DEPTH_GRID && (dd.cubic_interpolation || dd.grid_size[2] > 1)) return false;
-  if ((p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) && haveTriplets) return false;
-  if (p.smooth_static_weight > 0.0 || p.smooth_dynamic_weight > 0.0) return false;
-  if (p.intr_opt == CVD_INTR_SHARED) return false;
   // the largest frame block of the schedule must stay within the fast kernels' 256 unknowns
   long long g = dd.depth_type == CVD_DEPTH_GRID ? static_cast<long long>(dd.grid_size[0]) * dd.grid_size[1] : 1;
   if (p.coarse_to_fine && p.num_steps > 1) g = std::max(g, static_cast<long long>(p.ctf_long) * p.ctf_short);

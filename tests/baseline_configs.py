@@ -6,6 +6,8 @@
   config1: 100 frames 384x224, 4x4 bicubic spline grid (one LM solve from the normalised global scale)
   config2: 300 frames 384x224, hierarchical2 flow list (1766 directed pairs), the default pipeline of
            pose_optimization.py: normalizeDepth + coarse-to-fine Global -> 6x4 -> 12x7 -> 17x10
+  config4 / config4_huber: 1000 frames 640x384, 4318 directed pairs (10.4 M constraints), default pipeline ending at the 16x12
+           grid, Cauchy 0.5 resp. Huber 0.5 -- the problem `bench.py --config 4` times; sparsified coarse level on the device
   config2_4k: config2 with the "~4k pairs" flow list of BASELINE.json's north_star (extra_offsets = 6: 4140 directed pairs,
            2.40 M constraints) -- the problem bench.py times; its solves run the DENSE coarse level on the device
 """
@@ -26,6 +28,10 @@ CONFIGS = {
     "config2": dict(frames=300, width=384, height=224, seed=1237),
     # the BENCHMARKED problem (bench.py default): the same video with the flow list densified to 4140 directed pairs
     "config2_4k": dict(frames=300, width=384, height=224, seed=1237, extra_offsets=6),
+    # BASELINE.json configs[4] on one GPU (bench.py --config 4 [--robust huber]): 1000 frames 640x384, 4318 directed pairs,
+    # 10.4 M constraints, default pipeline with the 16x12 grid as its last level (B = 199); the sparsified coarse level
+    "config4": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12)),
+    "config4_huber": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12), robust=1),
 }
 
 
@@ -51,12 +57,16 @@ def params_for(name, threads=8):
     elif name == "config1":
         p.coarse_to_fine = 0
         p.num_steps = 1
+    if "ctf" in CONFIGS[name]:
+        p.ctf_long, p.ctf_short = CONFIGS[name]["ctf"]
     return p
 
 
 def run(binding, name, video, threads=8):
     """The solve of one config on `binding` (product Solver or test Oracle); returns the end state."""
     p = params_for(name, threads)
+    if CONFIGS[name].get("robust"):
+        binding.set_robust_loss(CONFIGS[name]["robust"])  # (1 = Huber: the stress variant BASELINE.json configs[4] names)
     synth.load_into(binding, video, p.focal_long)
     binding.reset_depth_xforms(XformDesc.global_depth())
     binding.reset_spatial_xforms(XformDesc.spatial())

@@ -543,6 +543,23 @@ def test_match_separation_zero_outside_the_dense_scope_takes_the_list(lib, tmp_p
     ds = dv.depthStream(dv.numDepthStreams() - 1)
     assert ds.depthXformDesc().str() == "Grid(Scale, Linear, 4, 3, 1)"
     assert np.isfinite(np.stack([np.asarray(ds.frame(f).extrinsics.position) for f in range(F)])).all()
+    # An Identity depth transform (the stream's state before any reset: no value parameter, N = 0) is outside the dense scope
+    # as well (cvd_dense_mode_supported answered 1 and the solve died in checkDenseScope): poses only, as a list.
+    params = lib.DepthVideoProcessor.Params()
+    params.depthStream = dv.numDepthStreams() - 1
+    params.frameRange.fromString(",".join(str(x) for x in range(F)))
+    params.poseOptimizer = lib.DepthVideoPoseOptimizer.Params()
+    params.poseOptimizer.frameRange.fromString(",".join(str(x) for x in range(F)))
+    params.poseOptimizer.coarseToFine = False
+    params.poseOptimizer.numSteps = 1
+    params.op = lib.DepthVideoProcessor.Op.ResetDepthXforms
+    params.depthXformDesc.type = lib.XformType.Depth
+    params.depthXformDesc.depthType = lib.DepthXformType.Identity
+    proc.process(params)
+    assert ds.depthXformDesc().str().startswith("Identity")
+    proc.optimizePoses(params, fc)
+    assert not proc.usedFlowImages
+    assert np.isfinite(np.stack([np.asarray(ds.frame(f).extrinsics.position) for f in range(F)])).all()
 
 
 @pytest.mark.gpu
