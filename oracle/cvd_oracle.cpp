@@ -2300,6 +2300,58 @@ struct Oracle {
           }
       }
   }
+
+  // Development hook (tools/pcg_lab.py: preconditioner experiments on the CPU): the block-sparse normal equations of the
+  // poseOptimizationStep problem at the given state, written to a file in the canonical per-frame layout --
+  // i32 F, i32 B, i64 numBlocks, f64 cost, f64 gradient[F B], then per block i32 I, i32 J (I >= J), f64 [B x B] = H_IJ.
+  void dumpBlocks(const cvd_opt_params& p, double depthDeformReg, const double* pose7, const char* path) {
+    if (pose7) {
+      poseParams.resize(F);
+      for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 7; ++i) poseParams[f][i] = pose7[f * 7 + i];
+    } else {
+      posesToParams();
+    }
+    Problem pb;
+    buildPoseProblem(pb, p, depthDeformReg);
+    pb.finalize();
+    Evaluation ev;
+    evaluateProblem(pb, p.num_threads, true, ev);
+    const int Bf = B();
+    const int n = pb.numActive;
+    std::vector<int> canon(n, -1);
+    for (const auto& b : pb.blocks)
+      if (b.offset >= 0)
+        for (int i = 0; i < b.size; ++i) canon[b.offset + i] = b.canon + i;
+    FILE* fp = std::fopen(path, "wb");
+    if (!fp) throw std::runtime_error("dumpBlocks: cannot open the output file");
+    const BlockSym& Hs = ev.H;
+    const int32_t hdr[2] = {F, Bf};
+    const int64_t nBlocks = static_cast<int64_t>(Hs.rowCol.size());
+    std::fwrite(hdr, sizeof(int32_t), 2, fp);
+    std::fwrite(&nBlocks, sizeof(int64_t), 1, fp);
+    std::fwrite(&ev.cost, sizeof(double), 1, fp);
+    std::vector<double> g(static_cast<size_t>(F) * Bf, 0.0);
+    for (int i = 0; i < n; ++i) g[canon[i]] = ev.g[i];
+    std::fwrite(g.data(), sizeof(double), g.size(), fp);
+    std::vector<double> blk(static_cast<size_t>(Bf) * Bf);
+    for (int I = 0; I < Hs.nb; ++I)
+      for (int e = Hs.rowPtr[I]; e < Hs.rowPtr[I + 1]; ++e) {
+        const int J = Hs.rowCol[e];
+        const int ni = Hs.size(I), nj = Hs.size(J);
+        if (ni == 0 || nj == 0) continue;
+        std::fill(blk.begin(), blk.end(), 0.0);
+        const double* Bv = Hs.val.data() + Hs.blkOff[e];
+        const int fI = canon[Hs.off[I]] / Bf, fJ = canon[Hs.off[J]] / Bf;
+        for (int a = 0; a < ni; ++a)
+          for (int b = 0; b < nj; ++b)
+            blk[static_cast<size_t>(canon[Hs.off[I] + a] % Bf) * Bf + canon[Hs.off[J] + b] % Bf] = Bv[static_cast<size_t>(a) * nj + b];
+        const int32_t ij[2] = {fI, fJ};
+        std::fwrite(ij, sizeof(int32_t), 2, fp);
+        std::fwrite(blk.data(), sizeof(double), blk.size(), fp);
+      }
+    std::fclose(fp);
+  }
 };
 
 }  // namespace cvdo
@@ -2504,6 +2556,9 @@ int cvdo_evaluate(void* h, const cvd_opt_params* p, double depthDeformReg, const
                   int* numResidualBlocks, double* gradient, double* hdiag, double* hfull) {
   CVDO_TRY(h, static_cast<Oracle*>(h)->evaluate(*p, depthDeformReg, pose7, cost, numResidualBlocks, gradient,
                                                 hdiag, hfull));
+}
+int cvdo_dump_blocks(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, const char* path) {
+  CVDO_TRY(h, static_cast<Oracle*>(h)->dumpBlocks(*p, depthDeformReg, pose7, path));
 }
 int cvdo_get_summary(void* h, cvd_solve_summary* s) {
   CVDO_TRY(h, *s = static_cast<Oracle*>(h)->lastSummary);

@@ -70,6 +70,9 @@ struct CoarsePlan {
   int nW;                // number of W blocks
   const int* updBlk;     // per update entry: the block id it belongs to (inverse of updPtr)
 };
+// *flag <- (*flag != 0): the dense level's fail word (bit 0 pivot failure, bit 30 barrier timeout) before it is summed over
+// the ranks of a sharded solve (a sum of bit-30 values could wrap to zero).
+inline __global__ void k_flag_to_bool(int* __restrict__ flag) { *flag = (*flag != 0) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Off-diagonal coarse blocks: C_e[i][j] = sum over the constraints between frames (fa, fb), both directions,

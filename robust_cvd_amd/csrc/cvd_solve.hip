@@ -417,6 +417,15 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
     }
   }
   phase("LM loop");
+  if (h->coarseOn && h->coarse.denseMode && h->coarse.fail.p != nullptr && !h->dist()) {
+    // a barrier timeout of the dense coarse inverse (bit 30) only costs PCG iterations -- but it should never pass unnoticed
+    int failWord = 0;
+    HIP_CHECK(hipMemcpyAsync(&failWord, h->coarse.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failWord & 0x40000000)
+      fprintf(stderr, "[cvd] warning: the dense coarse inverse timed out at its grid barrier (device shared with other work?); "
+                      "the coarse level was off for the last LM iteration(s)\n");
+  }
   downloadState(h, c.L, h->dX);
   phase("download");
   h->tCollect();

@@ -32,12 +32,16 @@ CONFIGS = {
     # 10.4 M constraints, default pipeline with the 16x12 grid as its last level (B = 199); the sparsified coarse level
     "config4": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12)),
     "config4_huber": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12), robust=1),
+    # DENSE mode at real resolution (matchSeparation = 0: every masked pixel of every directed pair, 13.3 M constraints): the
+    # HIP path reads the flow / mask images, the oracle the equivalent constraint list
+    "dense30": dict(frames=30, width=384, height=224, seed=1240, dense=True),
 }
 
 
 def make_video(name):
     c = CONFIGS[name]
-    return synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], extra_offsets=c.get("extra_offsets", 1))
+    return synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], extra_offsets=c.get("extra_offsets", 1),
+                            spacing=(1e9 if c.get("dense") else 12.5))  # (dense: the sampled list is not used)
 
 
 def input_digest(video):
@@ -45,6 +49,27 @@ def input_digest(video):
     for a in (video.depth, video.pairs, video.offsets, video.loc):
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+def dense_inputs(video):
+    """Flow / mask images of every directed pair and the constraint list the reference's compute() makes of them with
+    matchSeparation = 0 (cached on the video object)."""
+    if getattr(video, "dense_flow", None) is None:
+        video.dense_flow, video.dense_mask = synth.make_dense_flows(video)
+        video.dense_offsets, video.dense_loc = synth.dense_constraints_from_flows(video, video.dense_flow, video.dense_mask)
+    return video.dense_flow, video.dense_mask, video.dense_offsets, video.dense_loc
+
+
+def load_dense(binding, video, focal_long):
+    """Dense mode hand-over: images for the product Solver (cvd_set_pair_flows), the equivalent list for the Oracle."""
+    flow, mask, off, loc = dense_inputs(video)
+    binding.set_video(video.num_frames, video.width, video.height, video.aspect, video.inv_aspect)
+    binding.set_depth_all(video.depth)
+    if hasattr(binding, "set_pair_flows"):
+        binding.set_pair_flows(video.pairs, flow, mask)
+    else:
+        binding.set_pair_constraints(video.pairs, off, loc, None)
+    binding.reset_poses(focal_long)
 
 
 def params_for(name, threads=8):
@@ -67,7 +92,10 @@ def run(binding, name, video, threads=8):
     p = params_for(name, threads)
     if CONFIGS[name].get("robust"):
         binding.set_robust_loss(CONFIGS[name]["robust"])  # (1 = Huber: the stress variant BASELINE.json configs[4] names)
-    synth.load_into(binding, video, p.focal_long)
+    if CONFIGS[name].get("dense"):
+        load_dense(binding, video, p.focal_long)
+    else:
+        synth.load_into(binding, video, p.focal_long)
     binding.reset_depth_xforms(XformDesc.global_depth())
     binding.reset_spatial_xforms(XformDesc.spatial())
     binding.normalize_depth(p)

@@ -46,13 +46,15 @@ def main():
                  "final_cost": o.summary()["final_cost"], "iterations": o.summary()["num_iterations"]}
         perr, rerr = synth.relative_pose_error(sol["position"], sol["orientation"], tight["position"], tight["orientation"])
         s = sol["summary"]
-        print(f"{name}: {video.num_frames} frames, {len(video.pairs)} pairs, {video.num_constraints} constraints; oracle "
+        ncons = int(video.dense_offsets[-1]) if bc.CONFIGS[name].get("dense") else video.num_constraints
+        print(f"{name}: {video.num_frames} frames, {len(video.pairs)} pairs, {ncons} constraints; oracle "
               f"{dt:.1f} s, final cost {s['final_cost']:.9f} ({s['num_iterations']} LM iterations in the last level); tight "
               f"{tight['final_cost']:.9f} after {tight['iterations']} more; default-vs-tight pose err {perr:.2e} rot {rerr:.2e} "
               f"params {np.abs(sol['depth_params'] - tight['depth_params']).max() / np.abs(tight['depth_params']).max():.2e}")
         np.savez_compressed(
             bc.solution_path(name), input_sha256=np.frombuffer(bc.input_digest(video).encode(), np.uint8),
-            num_pairs=len(video.pairs), num_constraints=video.num_constraints,
+            num_pairs=len(video.pairs),
+            num_constraints=(int(video.dense_offsets[-1]) if bc.CONFIGS[name].get("dense") else video.num_constraints),
             pose7=sol["pose7"], position=sol["position"], orientation=sol["orientation"], vfov=sol["vfov"], hfov=sol["hfov"],
             depth_params=sol["depth_params"], grid_size=sol["grid_size"], final_cost=s["final_cost"],
             initial_cost_last_level=s["initial_cost"], iterations_last_level=s["num_iterations"], oracle_seconds=dt,

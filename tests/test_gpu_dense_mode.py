@@ -156,3 +156,49 @@ def test_dense_mode_rejects_configurations_outside_its_scope(Solver):
     hip.reset_spatial_xforms(XformDesc.spatial(SpatialXformType.BilinearGrid, 3, 2))
     with pytest.raises(RuntimeError, match="dense mode"):
         hip.evaluate(OptParams.defaults(), 0.1)
+
+
+def test_dense_mode_at_real_resolution_matches_the_oracle(Solver):
+    """Dense mode at the resolution of BASELINE.json configs[2] (VERDICT r3 Weak #2c: every other oracle comparison of this
+    mode is at 96x56): 30 frames 384x224, 156 directed pairs, 13.3 M pixel constraints.  (a) cost / gradient / every H_ff block
+    on the final 17x10 grid at a state away from the minimum against the oracle's evaluation of the equivalent
+    matchSeparation = 0 list, 1e-9; (b) the end state of the default pipeline (explicit cross blocks, default solver options)
+    against the oracle's committed exact-Cholesky solution (tests/golden/solutions/dense30.npz), the 1e-3 bar."""
+    from tests import baseline_configs as bc
+    video = bc.make_video("dense30")
+    flow, mask, off, loc = bc.dense_inputs(video)
+    assert int(off[-1]) > 13_000_000
+    p = bc.params_for("dense30", threads=12)
+    F = video.num_frames
+    rng = np.random.default_rng(21)
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.02, (F, 6))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+    theta = 1.0 + rng.normal(0.0, 0.05, size=(F, 17 * 10))
+    out = {}
+    for k, ctor in (("hip", lambda: Solver(0)), ("oracle", Oracle)):
+        b = ctor()
+        bc.load_dense(b, video, p.focal_long)
+        b.reset_depth_xforms(XformDesc.grid_depth(17, 10))
+        b.reset_spatial_xforms(XformDesc.spatial())
+        b.set_xform_params(theta)
+        out[k] = b.evaluate(p, p.depth_deform_reg_final, pose, want_gradient=True, want_hdiag=True)
+        if k == "hip":
+            assert b.num_active_constraints() == int(off[-1])
+        del b
+    h, o = out["hip"], out["oracle"]
+    assert h["num_residual_blocks"] == o["num_residual_blocks"]
+    assert abs(h["cost"] - o["cost"]) <= TOL * abs(o["cost"]), (h["cost"], o["cost"])
+    assert rel(h["gradient"], o["gradient"]) < TOL
+    assert rel(h["hdiag"], o["hdiag"]) < TOL
+    # (b) end state
+    ref = bc.load_solution("dense30")
+    assert int(ref["num_constraints"]) == int(off[-1])
+    s = Solver(0)
+    sol = bc.run(s, "dense30", video)
+    assert sol["summary"]["termination"] == 0 and list(sol["grid_size"]) == list(ref["grid_size"])
+    perr, rerr = synth.relative_pose_error(sol["position"], sol["orientation"], ref["position"], ref["orientation"])
+    assert perr <= 1e-3 and rerr <= 1e-3, (perr, rerr)
+    fc = float(ref["final_cost"])
+    assert abs(sol["summary"]["final_cost"] - fc) <= 1e-6 * fc, (sol["summary"]["final_cost"], fc)
+    assert rel(sol["depth_params"], ref["depth_params"]) <= 1e-3

@@ -182,3 +182,67 @@ def test_two_ranks_dense_mode(product):
     key = _KEY[0]
     ranks = run_ranks(2, lambda r: run(2, r, key))
     compare(ranks, single)
+
+
+# ---- the BENCHMARKED problem, sharded (BASELINE.json configs[3] through the local-group backend) ------------------------------
+_FULL = {}
+
+
+def _full_size_case():
+    """config2_4k (300 x 384x224, 4140 directed pairs, 2.40 M constraints): the video, the oracle's committed end state and the
+    single-rank solve of this build (default options), shared by the world sizes below."""
+    if not _FULL:
+        from robust_cvd_amd import api
+        from tests import baseline_configs as bc
+        video = bc.make_video("config2_4k")
+        s = api.Solver(0)
+        sol = bc.run(s, "config2_4k", video)
+        s.close()
+        _FULL.update(video=video, ref=bc.load_solution("config2_4k"), single=sol)
+    return _FULL["video"], _FULL["ref"], _FULL["single"]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_full_size_sharded_end_state(world):
+    """The problem bench.py times, pair-sharded over 2 / 4 / 8 ranks (every rank: its pairs' constraints, every frame's depth,
+    the whole problem's pair graph; dense coarse level inverted redundantly on every rank by the cooperative
+    k_dense_spd_inverse) -- default coarse-to-fine pipeline, default solver options: the end state against the ORACLE's
+    committed exact-Cholesky solution (the 1e-3 bar of BASELINE.json), the PCG effort against the single-rank solve (+-10 %),
+    and every rank bit-identical to rank 0."""
+    from robust_cvd_amd import api
+    from tests import baseline_configs as bc
+    v, ref, single = _full_size_case()
+    _KEY[0] += 1
+    key = _KEY[0]
+    shards = sharding.shard_pairs(v.pairs, v.offsets, world)
+    p = bc.params_for("config2_4k")
+
+    def body(rank):
+        s = api.Solver(0)
+        s.comm_init_local_group(rank, world, key)
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.set_pair_constraints(*sharding.take_pairs(v.pairs, v.offsets, v.loc, v.is_static, shards[rank]))
+        s.set_pair_graph(v.pairs)
+        s.reset_poses(p.focal_long)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        res = (s.get_poses(), s.get_xform_params().copy(), s.summary())
+        s.close()
+        return res
+
+    ranks = run_ranks(world, body)
+    fc = float(ref["final_cost"])
+    for poses, theta, summ in ranks:
+        assert summ["termination"] == 0
+        perr, rerr = synth.relative_pose_error(poses["position"], poses["orientation"], ref["position"], ref["orientation"])
+        assert perr <= 1e-3 and rerr <= 1e-3, (perr, rerr)
+        assert abs(summ["final_cost"] - fc) <= 1e-6 * fc, (summ["final_cost"], fc)
+        assert rel(theta, ref["depth_params"]) <= 1e-3
+        it_a, it_b = summ["total_linear_iterations"], single["summary"]["total_linear_iterations"]
+        assert abs(it_a - it_b) <= 0.1 * it_b, (it_a, it_b)
+        assert summ["num_iterations"] == single["summary"]["num_iterations"]
+    for r in range(1, world):
+        assert np.array_equal(ranks[0][1], ranks[r][1]) and np.array_equal(ranks[0][0]["position"], ranks[r][0]["position"])
