@@ -127,6 +127,11 @@ def mint(path):
     spread, worst = rr.depth_scale_spread(video, {**out, "param_map": ref["ref_scales"].astype(np.float64)})
     print(f"{len(err)} static constraints: reprojection error through the reference's geometry.py max {err.max():.4f} px, "
           f"mean {err.mean():.4f} px; per-frame scale spread {spread:.2e}, worst pixel {worst:.2e}")
+    # what the pin can see: the same state with paramMap's rows in the wrong order (row 0 = image bottom)
+    flipped = reference_outputs({**out, "param_map": out["param_map"][:, ::-1].copy()}, video)
+    err_flip = np.linalg.norm(flipped["ref_reprojected"] - flipped["target_pixel"], axis=1)
+    print(f"with paramMap flipped vertically the same check gives max {err_flip.max():.4f} px, mean {err_flip.mean():.4f} px")
+    ref["flipped_rows_error_px_max"] = np.float32(err_flip.max())
     keep = {k: out[k] for k in ("right", "up", "backward", "position", "orientation", "hfov", "vfov", "params", "width", "height",
                                 "depth_desc")}
     # (the full-resolution maps of three frames only: the fixture stays small; every constraint's scaled depth is kept)

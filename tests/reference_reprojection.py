@@ -23,14 +23,40 @@ from robust_cvd_amd import dataset_io, synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_py", "reprojection_golden.npz")
 
-CASE = dict(frames=16, width=192, height=112, seed=4242, ctf=(6, 4))
+CASE = dict(frames=16, width=192, height=112, seed=4242, ctf=(4, 3), field_amp=0.10, deform_reg=1e-4, scale_reg=1e-6)
+
+
+def grid_field(theta, W, H):
+    """theta [gy, gx] (row 0 = image BOTTOM) evaluated per pixel with the optimizer's own bilinear gather (reference
+    lib/DepthMapTransform.cpp:750-764, 823-840: s = (n + 1)(g - 1)/2 at the pixel-edge NDC n.x = -1 + 2 i / W,
+    n.y = 1 - 2 j / H of the constraints)."""
+    gy, gx = theta.shape
+    nx = -1.0 + 2.0 * np.arange(W) / W
+    ny = 1.0 - 2.0 * np.arange(H) / H
+    sx = np.clip((nx + 1.0) * (gx - 1) / 2.0, 0.0, np.nextafter(gx - 1.0, 0.0))
+    sy = np.clip((ny + 1.0) * (gy - 1) / 2.0, 0.0, np.nextafter(gy - 1.0, 0.0))
+    ix, iy = sx.astype(int), sy.astype(int)
+    rx, ry = (sx - ix)[None, :], (sy - iy)[:, None]
+    a, b = theta[iy][:, ix], theta[iy][:, ix + 1]
+    c, d = theta[iy + 1][:, ix], theta[iy + 1][:, ix + 1]
+    return (1 - ry) * ((1 - rx) * a + rx * b) + ry * ((1 - rx) * c + rx * d)
 
 
 def make_case():
-    """Zero-noise video whose per-frame depth error is a pure scale (field_amp = 0): an exact solution exists, so the
-    optimizer's end state reprojects every static constraint onto its flow target up to the regularisers' pull."""
+    """Zero-noise video whose per-frame depth error is EXACTLY what the final level of the case's schedule can undo: the depth
+    handed to the optimizer is the rendered depth divided by s_f * theta_f(x, y), theta_f a random 4 x 3 bilinear grid in the
+    optimizer's own gather convention.  An exact solution exists (the deformation regulariser, which pulls the vertices
+    together, and the scale regulariser, which pulls every vertex towards 1 / median depth, are set to 1e-4 / 1e-6 for this
+    case: at their defaults they outweigh the noise-free data term and the optimum is visibly not the true field), the end state reprojects every static constraint onto its flow target, and the scale
+    MAP varies by +-10 % over the image -- top to bottom too, so the row order of paramMap matters to the result."""
     c = CASE
-    return synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], flow_noise_px=0.0, field_amp=0.0)
+    v = synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], flow_noise_px=0.0, field_amp=0.0)
+    rng = np.random.default_rng(c["seed"] + 1)
+    gx, gy = c["ctf"]
+    v.true_theta = 1.0 + c["field_amp"] * rng.uniform(-1.0, 1.0, size=(v.num_frames, gy, gx))
+    for f in range(v.num_frames):
+        v.depth[f] = (v.depth[f].astype(np.float64) / grid_field(v.true_theta[f], v.width, v.height)).astype(np.float32)
+    return v
 
 
 def run_drop_in(lib, video, base_dir):
@@ -40,6 +66,8 @@ def run_drop_in(lib, video, base_dir):
     frames = list(range(video.num_frames))
     opt = lib.DepthVideoPoseOptimizer.Params()
     opt.ctfLong, opt.ctfShort = CASE["ctf"]
+    opt.depthDeformRegInitial = opt.depthDeformRegFinal = CASE["deform_reg"]
+    opt.scaleReg = CASE["scale_reg"]
     dv, fc = build_pose_optimizer(lib, base, "midas2", frames, opt)
     optimize_poses(lib, dv, fc, frames, opt)
     ds = dv.depthStream(dv.numDepthStreams() - 1)

@@ -20,10 +20,12 @@ from robust_cvd_amd import synth
 from tests import baseline_configs as bc
 from tests import reference_reprojection as rr
 
-# The case has an exact solution (zero flow noise, pure per-frame scale error); what remains is the pull of the scale /
-# focal regularisers (reference defaults) and the optimizer's stopping tolerance.  Measured at mint time: see the fixture's
-# `reprojection_error_px` (max 0.03 px).  A convention error (sign, row order, half-pixel, FOV axis) costs >= 0.5 px.
-REPROJ_TOL_PX = 0.05
+# The case has an exact solution (zero flow noise; the depth error is a per-frame scale times a field on the optimizer's own
+# 4 x 3 grid); what remains is the pull of the (reduced) regularisers, the stopping tolerance and the half-pixel between the
+# corner-aligned sampling of paramMap (reference lib/DepthMapTransform.cpp:428-449) and the pixel-edge NDC of the constraints.
+# Measured at mint time (fixture: `reprojection_error_px`): max 0.053 px, mean 0.0036 px.  The same check with paramMap's rows in
+# the wrong order: max 0.56 px, mean 0.025 px (`flipped_rows_error_px_max`); a sign / axis / FOV error costs pixels.
+REPROJ_TOL_PX, REPROJ_MEAN_TOL_PX = 0.1, 0.01
 
 
 def _golden():
@@ -46,7 +48,8 @@ def test_numpy_restatement_reproduces_the_reference_outputs():
     assert np.abs(rp - g["ref_reprojected"]).max() < 2e-3  # (float32 arithmetic in both; pixels)
     # the reference's own functions put the optimizer's end state onto the flow targets
     err = np.linalg.norm(g["ref_reprojected"] - g["target_pixel"], axis=1)
-    assert err.max() < REPROJ_TOL_PX, err.max()
+    assert err.max() < REPROJ_TOL_PX and err.mean() < REPROJ_MEAN_TOL_PX, (err.max(), err.mean())
+    assert float(g["flipped_rows_error_px_max"]) > 4 * err.max()  # (the check can tell the row order of paramMap)
     np.testing.assert_allclose(err, g["reprojection_error_px"], atol=1e-6)
 
 
@@ -68,9 +71,10 @@ def test_live_reference_functions_on_the_generators_ground_truth():
     R = synth.rodrigues(v.true_w)
     out = dict(right=R[:, :, 0], up=R[:, :, 1], backward=R[:, :, 2], position=v.true_t,
                hfov=np.full(F, 2 * np.arctan(v.true_fy * v.aspect)), vfov=np.full(F, 2 * np.arctan(v.true_fy)),
-               param_map=np.broadcast_to(v.frame_scale[:, None, None], (F, H, W)).copy(), params=v.frame_scale[:, None],
+               param_map=np.stack([v.frame_scale[f] * rr.grid_field(v.true_theta[f], W, H) for f in range(F)]),
+               params=v.frame_scale[:, None],
                warp=np.zeros((F, H, W, 2), np.float32), source_depth=v.depth, width=np.int32(W), height=np.int32(H),
-               depth_desc=np.frombuffer(b"Grid(Scale, Linear, 6, 4, 1)", np.uint8))
+               depth_desc=np.frombuffer(b"Grid(Scale, Linear, 4, 3, 1)", np.uint8))
     ref = mk.reference_outputs(out, v)
     err = np.linalg.norm(ref["ref_reprojected"] - ref["target_pixel"], axis=1)
     assert err.max() < 1e-3, err.max()
@@ -105,6 +109,9 @@ def test_drop_in_end_state_reprojects_through_the_reference_conventions(tmp_path
     ext, intr = rr.numpy_update_poses(out)
     fa, fb, pix, target, depth = rr.constraint_samples(video, out)
     err = np.linalg.norm(rr.numpy_reproject(ext, intr, fa, fb, pix, depth) - target, axis=1)
-    assert err.max() < REPROJ_TOL_PX, (err.max(), err.mean())
-    spread, worst = rr.depth_scale_spread(video, out)
-    assert spread < 2e-3 and worst < 1e-2, (spread, worst)  # depth x paramMap = rendered depth up to ONE global scale
+    assert err.max() < REPROJ_TOL_PX and err.mean() < REPROJ_MEAN_TOL_PX, (err.max(), err.mean())
+    # depth x paramMap against the rendered depth, up to ONE global scale: only to a few percent per frame -- with nearly
+    # parallel cameras and per-frame focal lengths the depth scale of a frame trades against its focal length (bas-relief
+    # ambiguity; measured spread 2.4e-2 while every constraint reprojects to 0.05 px)
+    spread, _worst = rr.depth_scale_spread(video, out)
+    assert spread < 5e-2, spread
