@@ -26,6 +26,9 @@ typedef struct cvd_handle_t cvd_handle;
 /* Inner linear solver / LM knobs that have no counterpart in the reference (Ceres' SPARSE_NORMAL_CHOLESKY
  * is replaced by a block-Jacobi preconditioned conjugate-gradient solve on the device). */
 typedef struct cvd_solver_options {
+  uint64_t struct_size;          /* sizeof(cvd_solver_options) of the header the CALLER was built with: set by
+                                    cvd_solver_options_default, checked by cvd_set_solver_options (a caller built against another
+                                    revision of this header is refused instead of being read out of bounds) */
   double pcg_relative_tolerance; /* eta: the PCG stops when sqrt(r^T M^-1 r) <= eta * its initial value.  Default 1e-3:
                                     the reference's SPARSE_NORMAL_CHOLESKY takes EXACT LM steps, and the iterate at which
                                     function_tolerance (1e-6 relative cost change) stops them is only reproduced -- to the
@@ -71,6 +74,10 @@ typedef struct cvd_solver_options {
                                      in-line 1.6 ms kernel (300 frames) = 22 PCG iterations, not a side-stream job, and the
                                      PCG counts of an LM run grow by themselves as the trust region opens -- at 16 the level
                                      was rebuilt every second LM iteration for 0.6 fewer PCG iterations per LM iteration */
+  int32_t pcg_fused_tail;         /* 1 (default): the two per-frame kernels of a PCG iteration (finish of the product, update) run
+                                     as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
+                                     one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
+                                     the two launches */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

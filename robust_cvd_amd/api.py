@@ -17,6 +17,7 @@ _lib = None
 
 class SolverOptions(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint64),
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
         ("pcg_check_every", C.c_int32),
@@ -34,6 +35,7 @@ class SolverOptions(C.Structure):
         ("coarse_dense_shift", C.c_double),
         ("constraint_order", C.c_int32),
         ("coarse_rebuild_excess_dense", C.c_int32),
+        ("pcg_fused_tail", C.c_int32),
     ]
 
 

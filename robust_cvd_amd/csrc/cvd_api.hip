@@ -126,6 +126,16 @@ static void normalizeDepth(cvd_handle* h, const cvd_opt_params& p) {
     return -1;                                 \
   }
 
+namespace cvd {
+static std::atomic<int> g_liveHandles[PersistentGate::kMaxDevices];
+int liveHandles(int device) { return (device >= 0 && device < PersistentGate::kMaxDevices) ? g_liveHandles[device].load() : 0; }
+PersistentGate::Slot& PersistentGate::slot(int device) {
+  static Slot slots[kMaxDevices];
+  if (device < 0 || device >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
+  return slots[device];
+}
+}  // namespace cvd
+
 extern "C" {
 
 static std::string g_createError;
@@ -154,13 +164,17 @@ cvd_handle* cvd_create(int32_t device) {
     cvd_solver_options_default(&h->opt);
     // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)
     touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_solve(); touchModule_frontend();
+    if (device < PersistentGate::kMaxDevices) ++g_liveHandles[device];
     return h;
   } catch (const std::exception& e) {
     g_createError = e.what();
     return nullptr;
   }
 }
-void cvd_destroy(cvd_handle* h) { delete h; }
+void cvd_destroy(cvd_handle* h) {
+  if (h && h->device >= 0 && h->device < PersistentGate::kMaxDevices) --g_liveHandles[h->device];
+  delete h;
+}
 const char* cvd_last_error(cvd_handle* h) { return h ? h->err.c_str() : g_createError.c_str(); }
 
 void cvd_abi_sizes(int32_t* out6) {
@@ -199,6 +213,7 @@ void cvd_opt_params_default(cvd_opt_params* p) {
 }
 
 void cvd_solver_options_default(cvd_solver_options* o) {
+  o->struct_size = sizeof(cvd_solver_options);
   o->pcg_relative_tolerance = 1e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
   o->pcg_max_iterations = 300;
   o->pcg_check_every = 4;
@@ -216,9 +231,27 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_dense_shift = 1e-5;
   o->constraint_order = 1;
   o->coarse_rebuild_excess_dense = 32;
+  o->pcg_fused_tail = 1;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
+    //  the struct is copied whole: refuse a caller built against another revision of the header, and values no
+    // code path is defined for, before anything is stored
+    if (o->struct_size != sizeof(cvd_solver_options))
+      throw std::runtime_error(fmt("cvd_solver_options: struct_size %llu != %zu (caller built against another cvd_hip.h; start "
+                                   "from cvd_solver_options_default)", static_cast<unsigned long long>(o->struct_size),
+                                   sizeof(cvd_solver_options)));
+    if (!(o->pcg_relative_tolerance > 0.0 && o->pcg_relative_tolerance < 1.0)) throw std::runtime_error("pcg_relative_tolerance must lie in (0, 1)");
+    if (o->pcg_max_iterations < 1) throw std::runtime_error("pcg_max_iterations must be >= 1");
+    if (!(o->coarse_dense_shift >= 0.0 && o->coarse_dense_shift < 1.0)) throw std::runtime_error("coarse_dense_shift must lie in [0, 1)");
+    if (o->coarse_rebuild_excess < 0 || o->coarse_rebuild_excess_dense < 0 || o->coarse_update_budget < 0)
+      throw std::runtime_error("coarse_rebuild_excess / coarse_rebuild_excess_dense / coarse_update_budget must be >= 0");
+    if (o->coarse_dense_max_unknowns < 0 || o->coarse_dense_max_unknowns > kDenseCoarseMaxUnknowns)
+      throw std::runtime_error(fmt("coarse_dense_max_unknowns must lie in [0, %d] (what k_dense_spd_inverse holds in registers)",
+                                   kDenseCoarseMaxUnknowns));
+    if (o->coarse_level < 0 || o->coarse_level > 2 || o->robust_loss < 0 || o->robust_loss > 1 || o->block_inverse_variant < 0 ||
+        o->block_inverse_variant > 2)
+      throw std::runtime_error("coarse_level in {0, 1, 2}, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
     if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)

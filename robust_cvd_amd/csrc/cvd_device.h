@@ -883,6 +883,8 @@ struct CoarseColumns {
 };
 // masked restriction Z_f^T v_f of one frame's vector (LDS or global) by the calling workgroup: threads 0..6 the
 // pose-like entries, wave 1 the sum over the depth-scale vertices
+// PUBLISH: the values are read by OTHER workgroups of the same launch (k_pcg_tail): write-through agent-scope stores.
+template <bool PUBLISH = false>
 __device__ __forceinline__ void coarseRestrict(const Layout& L, const double* __restrict__ vf, int f, int tid,
                                                const unsigned char* __restrict__ modeActive, double* __restrict__ out);
 
@@ -981,16 +983,24 @@ __device__ __forceinline__ double waveSum(double v) {
   return (readLane(v, 0) + readLane(v, 16)) + (readLane(v, 32) + readLane(v, 48));
 }
 
+__device__ __forceinline__ void storeMaybePublished(double* p, double v, bool publish) {
+  if (publish)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+template <bool PUBLISH>
 __device__ __forceinline__ void coarseRestrict(const Layout& L, const double* __restrict__ vf, int f, int tid,
                                                const unsigned char* __restrict__ modeActive, double* __restrict__ out) {
   // (inactive modes are identity rows of the coarse matrix: they must not feed the coarse solve)
-  if (tid < 7) out[f * kCB + tid] = modeActive[f * kCB + tid] ? vf[tid] : 0.0;
+  if (tid < 7) storeMaybePublished(out + f * kCB + tid, modeActive[f * kCB + tid] ? vf[tid] : 0.0, PUBLISH);
   if (tid >= 64 && tid < 128) {
     const int nV = (L.N >= 1 && L.depthType != kDepthIdentity) ? L.nD / L.N : 0;
     double a = 0.0;
     for (int v = tid - 64; v < nV; v += 64) a += vf[7 + v * L.N];
     a = waveSum(a);
-    if (tid == 64) out[f * kCB + 7] = modeActive[f * kCB + 7] ? a : 0.0;
+    if (tid == 64) storeMaybePublished(out + f * kCB + 7, modeActive[f * kCB + 7] ? a : 0.0, PUBLISH);
   }
 }
 

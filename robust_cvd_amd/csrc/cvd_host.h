@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -28,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/cvd_hip.h"
@@ -252,6 +254,7 @@ struct cvd_handle_t {
   DevBuf<long long> dXRange;
   DevBuf<double> dXBlocks;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
+  DevBuf<unsigned int> dTailBar;   // grid barrier of k_pcg_tail (tailArrive / tailWait)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
   bool tableValid = false;
   bool tableIgnoresStatic = false;  // compiled for normalizeDepth's pair loop (every constraint, dynamic ones included)
@@ -449,6 +452,9 @@ constexpr long long kListChunk = 768;    // constraints per direction and work i
 constexpr long long kDenseChunk = 8192;  // pixel slots per direction and work item (dense mode)
 
 constexpr int kMaxFrameBlock = 512;
+// k_dense_spd_inverse holds the lower triangle in registers, <= 25 tiles per wave of a 14 x 14 super-tile and <= 22 x 23 / 2
+// super-tiles on 256 CUs: 22 * 14 = 308 tiles of 16 (launchDenseSpdInverse checks the actual device)
+constexpr int kDenseCoarseMaxUnknowns = 4928;
 #define CVD_DISPATCH(KDv, KSv, ...)                                             \
   do {                                                                          \
     if (KDv == 1 && KSv == 0) { constexpr int KD = 1, KS = 0; __VA_ARGS__; }     \
@@ -491,6 +497,32 @@ void allowLds(K kernel, size_t bytes) {
     }
   }
 }
+
+// Per-device gate for kernels with a grid barrier: constructed right before the launch (the stream first waits for the
+// previous gated kernel of ANY handle of this process), destroyed right after it (records the completion the next one waits
+// for).  The event belongs to the process, not to a handle.
+int liveHandles(int device);  // handles of this process on the device (cvd_api.hip)
+struct PersistentGate {
+  static constexpr int kMaxDevices = 64;
+  struct Slot { std::mutex m; hipEvent_t ev = nullptr; bool recorded = false; };
+  static Slot& slot(int device);  // (cvd_api.hip: one table for all translation units)
+  Slot& sl;
+  hipStream_t s;
+  PersistentGate(int device, hipStream_t stream) : sl(slot(device)), s(stream) {
+    sl.m.lock();
+    try {
+      if (!sl.ev) HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+      if (sl.recorded) HIP_CHECK(hipStreamWaitEvent(s, sl.ev, 0));
+    } catch (...) {
+      sl.m.unlock();
+      throw;
+    }
+  }
+  ~PersistentGate() {
+    sl.recorded = hipEventRecord(sl.ev, s) == hipSuccess;
+    sl.m.unlock();
+  }
+};
 
 // ---- functions shared between the translation units (cvd_setup.hip, cvd_eval.hip, cvd_matvec.hip, cvd_precond.hip,
 // cvd_solve.hip, cvd_frontend.hip, cvd_api.hip) ---------------------------------------------------------------------
@@ -539,8 +571,12 @@ size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);
+// tailFused: only the partial products are launched; the caller follows with launchPcgTail (finish + update in one launch)
 void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta, const double* lam,
-                  double* q, bool withCoarse = false);
+                  double* q, bool withCoarse = false, bool tailFused = false);
+bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish, int& ldsScratch);
+void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, int useBeta, const double* lam, double* q,
+                   bool withCoarse, int nThreads, size_t lds, int ldsFinish, int ldsScratch, double tol2);
 void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv, int* dFail, int variant);
 void launchBlockInverse(Ctx& c);
 void launchCoarseSetup(Ctx& c, const double* x, int side = 0);

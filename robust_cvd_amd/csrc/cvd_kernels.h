@@ -1503,25 +1503,36 @@ inline __global__ __launch_bounds__(256) void k_reg_cache(Layout L, const double
   }
 }
 
-template <int KD>
-inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
-                                                       const double* __restrict__ mask,
-                                                       const double* __restrict__ lam, const float* __restrict__ median,
-                                                       const unsigned char* __restrict__ inRange,
-                                                       const unsigned char* __restrict__ rangeFlags,
-                                                       const int* __restrict__ fiOff, const int* __restrict__ fiList,
-                                                       const double* __restrict__ qPart, const double* __restrict__ z,
-                                                       const double* __restrict__ pOld, double* __restrict__ pNew,
-                                                       double* __restrict__ scal, unsigned int* __restrict__ counter,
-                                                       int useBeta, double* __restrict__ q, double* __restrict__ fdot,
-                                                       int distMode, int nRows, RegCache rc, CoarseView V,
-                                                       double* __restrict__ qc, CoarseColumns cc,
-                                                       const double* __restrict__ Hdiag, double* __restrict__ pqOut,
-                                                       int ownFirst, int ownCount) {
+// Direction and product element `tid` of the frame (B <= 256), handed from the finish half to the update half of the fused
+// tail kernel (k_pcg_tail) in registers.
+struct TailCarry {
+  double pv, qv;
+};
+
+// Body of k_matvec_finish.  FUSED = false: the kernel of that name (256 threads per frame).  FUSED = true: the first half of
+// k_pcg_tail -- the workgroup may be larger than 256 threads (threads beyond B idle through the barriers), nothing is handed to
+// a last workgroup (the caller's grid barrier follows), Z^T q is PUBLISHED (agent-scope stores: other workgroups of the same
+// launch read it), and the direction / product of element tid stay in registers (carry).  Returns false when the PCG has
+// converged already (uniform over the launch; nothing was written).
+template <int KD, bool FUSED>
+__device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* __restrict__ x,
+                                                 const double* __restrict__ mask,
+                                                 const double* __restrict__ lam, const float* __restrict__ median,
+                                                 const unsigned char* __restrict__ inRange,
+                                                 const unsigned char* __restrict__ rangeFlags,
+                                                 const int* __restrict__ fiOff, const int* __restrict__ fiList,
+                                                 const double* __restrict__ qPart, const double* __restrict__ z,
+                                                 const double* __restrict__ pOld, double* __restrict__ pNew,
+                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
+                                                 int useBeta, double* __restrict__ q, double* __restrict__ fdot,
+                                                 int distMode, int nRows, const RegCache& rc, const CoarseView& V,
+                                                 double* __restrict__ qc, const CoarseColumns& cc,
+                                                 const double* __restrict__ Hdiag, double* __restrict__ pqOut,
+                                                 int ownFirst, int ownCount, double* __restrict__ sm, TailCarry& carry) {
   // Hdiag != nullptr (explicit cross blocks, cvd_cross.h): the partial rows hold the OFF-diagonal blocks' products only;
   // the frame-diagonal part, regularisers included, is H_ff p_f with the assembled H_ff.
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int nT = FUSED ? static_cast<int>(blockDim.x) : 256;  // stride of the loops that are not bounded by B
   const int B = L.B;
   double* xf = sm;
   double* pf = xf + B;   // masked direction
@@ -1540,10 +1551,11 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
   } else if (tid < kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[f * kCB + tid] : 0.0;
   }
-  // (two elements per thread: B <= 512)
+  // (two elements per thread: B <= 512; the fused kernel's scope ends at B = 256: one)
+  constexpr int EPT = FUSED ? 1 : 2;
   double vz[2] = {0.0, 0.0}, vm[2] = {0.0, 0.0}, vp[2] = {0.0, 0.0}, vlam[2] = {0.0, 0.0}, pvReg[2] = {0.0, 0.0};
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * 256;
     if (i < B) {
       vz[e] = z[base + i];
@@ -1558,28 +1570,56 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
   // barrier: they depend on nothing but the row range, so their way from L2 overlaps the vector loads above instead of
   // following them (this kernel is a chain of dependent round trips, not a bandwidth problem).
   double rowSum[2] = {0.0, 0.0};
+  double* psum = cl + kCB;  // FUSED: (blockDim / 256 - 1) x 256 partial sums of the row walk
   if (L.includeStatic) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int i = tid + e * 256;
-      if (i >= B) continue;
-      const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int r = e0;
-      for (; r + 3 < e1; r += 4, rowp += 4 * B) {
-        a0 += rowp[0];
-        a1 += rowp[B];
-        a2 += rowp[2 * B];
-        a3 += rowp[3 * B];
+    if constexpr (FUSED) {
+      // every 256 threads of the (larger) workgroup walk their own residue class of the rows: the walk is a chain of dependent
+      // round trips -- 40 rows of a hub frame of the hierarchical flow list = 10 trips of 4 loads -- and that chain, not the
+      // bytes, was the fused kernel's critical path (the slowest frame reached the grid barrier after 25 us)
+      const int nParts = nT >> 8, part = tid >> 8, i = tid & 255;
+      if (i < B && part < nParts) {
+        const size_t step = static_cast<size_t>(nParts) * B;
+        const double* rowp = qPart + static_cast<size_t>(e0 + part) * B + i;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = e0 + part;
+        for (; r + 3 * nParts < e1; r += 4 * nParts, rowp += 4 * step) {
+          a0 += rowp[0];
+          a1 += rowp[step];
+          a2 += rowp[2 * step];
+          a3 += rowp[3 * step];
+        }
+        for (; r < e1; r += nParts, rowp += step) a0 += rowp[0];
+        const double t = (a0 + a1) + (a2 + a3);
+        if (part == 0) rowSum[0] = t;
+        else psum[(part - 1) * 256 + i] = t;
       }
-      for (; r < e1; ++r, rowp += B) a0 += rowp[0];
-      rowSum[e] = (a0 + a1) + (a2 + a3);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * 256;
+        if (i >= B) continue;
+        const double* rowp = qPart + static_cast<size_t>(e0) * B + i;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = e0;
+        for (; r + 3 < e1; r += 4, rowp += 4 * B) {
+          a0 += rowp[0];
+          a1 += rowp[B];
+          a2 += rowp[2 * B];
+          a3 += rowp[3 * B];
+        }
+        for (; r < e1; ++r, rowp += B) a0 += rowp[0];
+        rowSum[e] = (a0 + a1) + (a2 + a3);
+      }
     }
   }
   __syncthreads();
-  if (sDone != 0.0) return;  // uniform; nothing has been written to global memory yet
+  if (sDone != 0.0) return false;  // uniform; nothing has been written to global memory yet
+  if constexpr (FUSED) {
+    if (L.includeStatic && tid < B)
+      for (int k = 0; k + 1 < (nT >> 8); ++k) rowSum[0] += psum[k * 256 + tid];
+  }
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * 256;
     if (i >= B) continue;
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
@@ -1595,7 +1635,7 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     // shared focal: frame 0's slot collects the focal adjoint of EVERY partial row (both sides of every pair item, the
     // three rows of every triplet group)
     double a = 0.0;
-    for (int k = tid; k < nRows; k += 256) a += qPart[static_cast<size_t>(k) * B + 6];
+    for (int k = tid; k < nRows; k += nT) a += qPart[static_cast<size_t>(k) * B + 6];
     a = waveSum(a);
     if ((tid & 63) == 0) atomicAdd(&qf[6], a);
     __syncthreads();
@@ -1620,7 +1660,7 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     __syncthreads();
   } else if (Hdiag == nullptr && inRange[f]) {
     // J_reg^T (J_reg p) from the cached rows (k_reg_cache)
-    for (int i = tid; i < rc.nr; i += 256) {
+    for (int i = tid; i < rc.nr; i += nT) {
       const int n = rc.cnt[static_cast<size_t>(f) * rc.nr + i];
       const size_t e0 = static_cast<size_t>(f) * rc.stride * rc.nr + i;
       double t = 0.0;
@@ -1651,17 +1691,17 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
   // pqOut == nullptr: p.q / alpha are formed by k_dot_pq on the reduced vector.  pqOut != nullptr (FUSED exchange): the
   // product, its restriction Z^T q and p.q are all linear in q, so this rank's shares of the three travel in ONE
   // all-reduce ([q | Z^T q | p.q] contiguous) and k_cg_update forms alpha from the reduced p.q itself.
-  if (distMode && pqOut == nullptr) {
+  if (!FUSED && distMode && pqOut == nullptr) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int i = tid + e * 256;
       if (i < B) q[base + i] = qf[i] * vm[e] + (distMode == 1 ? vlam[e] * pvReg[e] : 0.0);
     }
-    return;
+    return true;
   }
   double dot = 0.0;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * 256;
     if (i >= B) continue;
     const double pv = pvReg[e];
@@ -1669,28 +1709,55 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
     q[base + i] = qv;
     qf[i] = qv;
     dot += pv * qv;
+    if (e == 0) { carry.pv = pv; carry.qv = qv; }
   }
   dot = waveSum(dot);
-  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  if ((tid & 63) == 0 && tid < 256) red[tid >> 6] = dot;  // (waves beyond the first four hold no element: B <= 256 when FUSED)
   __syncthreads();
   if (tid == 0) publishPartial(fdot + f, red[0] + red[1] + red[2] + red[3]);
   if (qc != nullptr) {  // Z^T q and this frame's column of W (Z^T q) for the fused y update (CoarseStep)
-    coarseRestrict(L, qf, f, tid, V.modeActive, qc);
-    __syncthreads();
-    coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
+    coarseRestrict<FUSED>(L, qf, f, tid, V.modeActive, qc);
+    if constexpr (!FUSED) {
+      __syncthreads();
+      coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
+    }
   }
-  // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
-  if (lastBlockArrivesLite(counter, L.F, reinterpret_cast<int*>(red + 6))) {
-    const double pq = blockSumPartials(fdot, L.F, red);
-    if (tid == 0) {
-      if (pqOut != nullptr) {
-        *pqOut = pq;  // (this rank's share: reduced with q)
-      } else {
-        scal[S_PQ] = pq;
-        scal[S_ALPHA] = scal[S_RZ] / pq;
+  if constexpr (!FUSED) {
+    // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
+    if (lastBlockArrivesLite(counter, L.F, reinterpret_cast<int*>(red + 6))) {
+      const double pq = blockSumPartials(fdot, L.F, red);
+      if (tid == 0) {
+        if (pqOut != nullptr) {
+          *pqOut = pq;  // (this rank's share: reduced with q)
+        } else {
+          scal[S_PQ] = pq;
+          scal[S_ALPHA] = scal[S_RZ] / pq;
+        }
       }
     }
   }
+  return true;
+}
+
+template <int KD>
+inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const double* __restrict__ x,
+                                                       const double* __restrict__ mask,
+                                                       const double* __restrict__ lam, const float* __restrict__ median,
+                                                       const unsigned char* __restrict__ inRange,
+                                                       const unsigned char* __restrict__ rangeFlags,
+                                                       const int* __restrict__ fiOff, const int* __restrict__ fiList,
+                                                       const double* __restrict__ qPart, const double* __restrict__ z,
+                                                       const double* __restrict__ pOld, double* __restrict__ pNew,
+                                                       double* __restrict__ scal, unsigned int* __restrict__ counter,
+                                                       int useBeta, double* __restrict__ q, double* __restrict__ fdot,
+                                                       int distMode, int nRows, RegCache rc, CoarseView V,
+                                                       double* __restrict__ qc, CoarseColumns cc,
+                                                       const double* __restrict__ Hdiag, double* __restrict__ pqOut,
+                                                       int ownFirst, int ownCount) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  TailCarry carry;
+  (void)matvecFinishBody<KD, false>(L, x, mask, lam, median, inRange, rangeFlags, fiOff, fiList, qPart, z, pOld, pNew, scal, counter,
+                                    useBeta, q, fdot, distMode, nRows, rc, V, qc, cc, Hdiag, pqOut, ownFirst, ownCount, sm, carry);
 }
 
 // p.q of the all-reduced product (multi-GPU only) + alpha, same last-workgroup pattern as k_matvec_finish.
@@ -1766,18 +1833,23 @@ __host__ __device__ inline int cgUpdatePartDoubles(int B, int nThreads) {
 // B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
 // 256 < B <= 512: 128 threads per chunk (two segments per row), same layout otherwise.
 // init != 0: dx = 0, r = -g (already masked), z = Minv r.
-inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
-                                                    const float* __restrict__ minv, const double* __restrict__ p,
-                                                    const double* __restrict__ q, double* __restrict__ scal,
-                                                    unsigned int* __restrict__ counter, double* __restrict__ dx,
-                                                    double* __restrict__ r, double* __restrict__ z,
-                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
-                                                    double tol2, double* __restrict__ rc,
-                                                    const unsigned char* __restrict__ modeActive,
-                                                    double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
-                                                    const double* __restrict__ pqReduced) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const double sDone = init ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
+// Body of k_cg_update.  FUSED = false: the kernel of that name.  FUSED = true: the second half of k_pcg_tail -- the caller's
+// `mid.first(pv, qv)` runs the finish half of the frame first (direction / product element handed over in registers; false =
+// converged already), then the loads that depend on nothing this launch computes are requested (the thread's share of M_f^-1
+// resp. of A_c^-1, r, dx) and `mid.second(alpha)` -- the grid barrier and alpha = r^T z / sum p.q -- runs while they are in
+// flight (held across the finish half as well they cost 32 spilled registers at the 80 a 768-thread workgroup pair allows).
+template <bool FUSED, typename Mid>
+__device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const double* __restrict__ g,
+                                             const float* __restrict__ minv, const double* __restrict__ p,
+                                             const double* __restrict__ q, double* __restrict__ scal,
+                                             unsigned int* __restrict__ counter, double* __restrict__ dx,
+                                             double* __restrict__ r, double* __restrict__ z,
+                                             double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
+                                             double tol2, double* __restrict__ rc,
+                                             const unsigned char* __restrict__ modeActive,
+                                             double* __restrict__ hostMirror, const CoarseStep& cs, const DenseStep& ds,
+                                             const double* __restrict__ pqReduced, double* __restrict__ sm, Mid& mid) {
+  const double sDone = (init || FUSED) ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
   const int B = L.B;
   const int nThreads = blockDim.x;
   double* rf = sm;                 // B
@@ -1792,7 +1864,13 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
   const size_t base = static_cast<size_t>(f) * B;
   // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
   // last workgroup to arrive, i.e. after every workgroup has read it here)
-  const double alpha = init ? 0.0 : (pqReduced != nullptr ? scal[S_RZ] / *pqReduced : scal[S_ALPHA]);
+  double alpha = (init || FUSED) ? 0.0 : (pqReduced != nullptr ? scal[S_RZ] / *pqReduced : scal[S_ALPHA]);
+  double pvCarry = 0.0, qvCarry = 0.0;
+  if constexpr (FUSED) {
+    // the finish half of this frame (dense-level workgroups: only the convergence flag); its registers are dead before the
+    // update half requests its operands below
+    if (!mid.first(pvCarry, qvCarry)) return;
+  }
   if (f >= L.F) {
     // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
     // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
@@ -1801,6 +1879,7 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
 #ifndef CVD_DENSE_LOADS
 #define CVD_DENSE_LOADS 4
 #endif
+    // (7 in the fused kernel -- two round trips per row instead of four -- spills at its 80-register budget: 12.9 -> 16.9 us)
     constexpr int kDenseLoads = CVD_DENSE_LOADS;
     const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
     const size_t n = static_cast<size_t>(L.F) * kCB;
@@ -1820,7 +1899,12 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
         if (j >= n2) w[u] = make_double2(0.0, 0.0);
       }
     }
-    for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = ds.qc[i];
+    if constexpr (FUSED) {  // (the first batch of the inverse's row is in flight across the grid barrier)
+      if (!mid.second(alpha)) return;
+      for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = readPartial(ds.qc + i);  // (published by the finish halves)
+    } else {
+      for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = ds.qc[i];
+    }
     const bool on0 = *ds.fail == 0;
     __syncthreads();
     if (sDone != 0.0) return;  // uniform; nothing written yet
@@ -1907,14 +1991,22 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
       if (init) {
         rv = -g[base + j];
       } else {
-        pv = p[base + j];
-        qv = q[base + j];
+        if constexpr (!FUSED) {
+          pv = p[base + j];
+          qv = q[base + j];
+        }
         rv = r[base + j];
         dv = dx[base + j];
       }
     }
-    asm volatile("" : "+v"(pv), "+v"(qv), "+v"(rv), "+v"(dv));  // (keeps the loads above the early exit)
-    if (sDone != 0.0) return;  // uniform; nothing written yet
+    if constexpr (!FUSED) asm volatile("" : "+v"(pv), "+v"(qv), "+v"(rv), "+v"(dv));  // (keeps the loads above the early exit)
+    if constexpr (FUSED) {
+      pv = pvCarry;
+      qv = qvCarry;
+      if (!mid.second(alpha)) return;  // grid barrier + alpha (the loads above are in flight meanwhile)
+    } else {
+      if (sDone != 0.0) return;  // uniform; nothing written yet
+    }
     if (j < B) {
       if (!init) {
         dv += alpha * pv;
@@ -2089,6 +2181,192 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
       }
     }
   }
+}
+
+inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, const double* __restrict__ g,
+                                                    const float* __restrict__ minv, const double* __restrict__ p,
+                                                    const double* __restrict__ q, double* __restrict__ scal,
+                                                    unsigned int* __restrict__ counter, double* __restrict__ dx,
+                                                    double* __restrict__ r, double* __restrict__ z,
+                                                    double* __restrict__ fdotRZ, double* __restrict__ fdotRR,
+                                                    double tol2, double* __restrict__ rc,
+                                                    const unsigned char* __restrict__ modeActive,
+                                                    double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
+                                                    const double* __restrict__ pqReduced) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  struct NoMid {
+    __device__ bool first(double&, double&) { return true; }
+    __device__ bool second(double&) { return true; }
+  } mid;
+  cgUpdateBody<false>(L, init, g, minv, p, q, scal, counter, dx, r, z, fdotRZ, fdotRR, tol2, rc, modeActive, hostMirror, cs, ds,
+                      pqReduced, sm, mid);
+}
+
+// ---- one kernel for the tail of a PCG iteration ------------------------------------------------------
+// k_matvec_finish and k_cg_update were two launches, two prologues and two last-workgroup hand-offs per iteration for
+// F (+ F / 2 dense-level) workgroups that are all co-resident, each a chain of dependent round trips.  k_pcg_tail runs both
+// halves in ONE launch: every workgroup first requests what its update half needs and nothing of this launch produces (its
+// share of the f32 block M_f^-1 resp. of the dense coarse inverse, r, dx), the frame workgroups then run the finish half
+// (partial rows -> q_f, p.q share, Z^T q published), ONE grid barrier, every workgroup sums the F shares of p.q itself
+// (alpha), and the update half follows with its operands already in registers.  The last workgroup to leave publishes beta /
+// the convergence flag exactly as k_cg_update does.  Single GPU, B <= 256, dense coarse level or none (the sparse level's
+// column products cross workgroups through plain stores; a sharded run has a collective between the halves).
+//
+// Grid barrier (tailArrive / tailWait): self-resetting (the last arriver zeroes the count and bumps the generation), one use per launch.  Payload crossing it is published with agent-scope stores and read with
+// agent-scope loads (publishPartial / readPartial, cdna_hip_programming.md G16 R1), every wave drains its stores first.
+// The spin is bounded: a launch whose workgroups are not all resident abandons (the host checks the occupancy and serialises
+// gated kernels of different handles, so this is a safety net) and the host's progress check reports the stalled PCG.
+// The barrier carries the one reduction the halves need: the LAST workgroup to arrive sums the nParts published partials
+// (p.q shares of the frames), publishes the sum and only then releases the others, which read that one double.
+// Split in two: tailArrive right after the finish half (the workgroup's payload is published; nothing it requests afterwards
+// delays its arrival), tailWait after the update half's operand requests.  Waiting costs MEMORY TRAFFIC: every poll is an
+// L2-bypassing load, and hundreds of workgroups polling one address saturate the memory channel that holds it -- the finish
+// halves still running slowed down 2x (measured with stamps, tools/tail_profile.py: 12.3 -> 7.6 us median when the poll
+// interval went from 4 to 32 sleep units).  The release word is therefore replicated over kTailBarCopies pages (different
+// channels), each workgroup polls the copy blockIdx % kTailBarCopies at a long interval.
+// bar: [0] arrivals, [1] abandon flag, generation copies at bar[kTailBarStride * (1 + k)].
+// scratch: 24 doubles of LDS ([0..15] wave partials, [16] role, [17] generation, [18] the sum).
+constexpr int kTailBarCopies = 16;
+constexpr int kTailBarStride = 1024;  // unsigned ints: 4 KB
+// (thread 0 reads its generation copy with tailGeneration at the START of the kernel and keeps the arrival ticket in a register
+// until tailWait: neither round trip sits between the finish half and the operand requests)
+__device__ __forceinline__ unsigned int tailGeneration(const unsigned int* bar) {
+  if (threadIdx.x != 0) return 0u;
+  return __hip_atomic_load(bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int tailArrive(unsigned int* bar) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its published payload has landed
+  __syncthreads();
+  if (threadIdx.x != 0) return 0u;
+  return __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups, unsigned int gen, unsigned int ticket,
+                                         const double* __restrict__ parts, int nParts, double* __restrict__ result,
+                                         double* __restrict__ scratch, double& sum) {
+  int* role = reinterpret_cast<int*>(scratch + 16);
+  if (threadIdx.x == 0) {
+    *role = (ticket == nGroups - 1) ? 2 : 1;
+    *reinterpret_cast<unsigned int*>(scratch + 17) = gen;
+  }
+  __syncthreads();
+  gen = *reinterpret_cast<unsigned int*>(scratch + 17);
+  if (*role == 2) {
+    const double v = blockSumPartials(parts, nParts, scratch);
+    if (threadIdx.x == 0) {
+      publishPartial(result, v);
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sum has landed before anybody is released
+    }
+    if (threadIdx.x < kTailBarCopies)
+      __hip_atomic_store(bar + kTailBarStride * (1 + threadIdx.x), gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum = v;
+    return true;
+  }
+  if (threadIdx.x == 0) {
+    const unsigned int* mine = bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1)));
+    int ok = 1;
+    unsigned int spins = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      __builtin_amdgcn_s_sleep(16);
+      ++spins;
+      if ((spins & 63u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (spins > (1u << 18)) {  // ~1 s
+        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    scratch[18] = ok ? readPartial(result) : 0.0;
+    *role = ok;
+  }
+  __syncthreads();
+  sum = scratch[18];
+  return *role != 0;
+}
+
+#ifdef CVD_TAIL_PROFILE  // tools/tail_profile.py: wall-clock (100 MHz) stamps of k_pcg_tail's workgroups
+__device__ unsigned long long g_tailProf[1024 * 8];
+#define TAIL_STAMP(slot) do { if (threadIdx.x == 0) g_tailProf[(blockIdx.x & 1023) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(slot) do {} while (0)
+#endif
+
+// what the update half needs beside the finish half's arguments
+struct TailUpdate {
+  const float* minv;
+  double* dx;
+  double* r;
+  double* z;
+  double* fdotRZ;
+  double* fdotRR;
+  double tol2;
+  const unsigned char* modeActive;
+  double* hostMirror;
+  unsigned int* counter;   // last-workgroup ticket of the update half
+  unsigned int* gridBar;   // kTailBarStride * (1 + kTailBarCopies) words, zeroed by the host before a PCG solve
+  double* pqSlot;          // where the barrier's last arriver publishes sum p.q (a line of its own)
+  int ldsFinish;           // offset (doubles) of the finish half's LDS region
+  int ldsScratch;          // offset of 24 doubles for the barrier flag and the p.q sum (beyond both kinds of workgroups' regions)
+  DenseStep ds;
+};
+
+template <int KD>
+inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_pcg_tail(Layout L, const double* __restrict__ x,
+                                                    const double* __restrict__ mask,
+                                                    const double* __restrict__ lam, const float* __restrict__ median,
+                                                    const unsigned char* __restrict__ inRange,
+                                                    const unsigned char* __restrict__ rangeFlags,
+                                                    const int* __restrict__ fiOff, const int* __restrict__ fiList,
+                                                    const double* __restrict__ qPart, const double* __restrict__ pOld,
+                                                    double* __restrict__ pNew, double* __restrict__ scal, int useBeta,
+                                                    double* __restrict__ q, double* __restrict__ fdot, int nRows, RegCache rc,
+                                                    CoarseView V, double* __restrict__ qc, const double* __restrict__ Hdiag,
+                                                    TailUpdate U) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int f = blockIdx.x;
+  const CoarseColumns ccOff{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const CoarseStep csOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  TAIL_STAMP(0);
+  const unsigned int barGen = tailGeneration(U.gridBar);
+  unsigned int barTicket = 0u;
+  auto first = [&](double& pv, double& qv) -> bool {
+    if (f < L.F) {
+      TailCarry carry{0.0, 0.0};
+      if (!matvecFinishBody<KD, true>(L, x, mask, lam, median, inRange, rangeFlags, fiOff, fiList, qPart, U.z, pOld, pNew, scal,
+                                      nullptr, useBeta, q, fdot, 0, nRows, rc, V, qc, ccOff, Hdiag, nullptr, 0, L.F,
+                                      sm + U.ldsFinish, carry))
+        return false;
+      pv = carry.pv;
+      qv = carry.qv;
+    } else if (scal[S_DONE] != 0.0) {
+      return false;  // (dense-level workgroup of a launch enqueued past convergence)
+    }
+    TAIL_STAMP(1);
+    barTicket = tailArrive(U.gridBar);
+    return true;
+  };
+  auto second = [&](double& alpha) -> bool {
+    double pq;
+    TAIL_STAMP(2);
+    if (!tailWait(U.gridBar, gridDim.x, barGen, barTicket, fdot, L.F, U.pqSlot, sm + U.ldsScratch, pq)) return false;
+    TAIL_STAMP(3);
+    // (S_RZ is rewritten only by the last workgroup to take the update half's ticket, i.e. after every workgroup has read it)
+    alpha = scal[S_RZ] / pq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      scal[S_PQ] = pq;
+      scal[S_ALPHA] = alpha;
+    }
+    return true;
+  };
+  struct Mid {
+    decltype(first)& f1;
+    decltype(second)& f2;
+    __device__ bool first(double& pv, double& qv) { return f1(pv, qv); }
+    __device__ bool second(double& alpha) { return f2(alpha); }
+  } mid{first, second};
+  cgUpdateBody<true>(L, 0, nullptr, U.minv, nullptr, nullptr, scal, U.counter, U.dx, U.r, U.z, U.fdotRZ, U.fdotRR, U.tol2, nullptr,
+                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid);
+  TAIL_STAMP(4);
 }
 
 // Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|.

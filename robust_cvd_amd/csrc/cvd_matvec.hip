@@ -43,7 +43,7 @@ void prepareMatvec(Ctx& c, const double* x) {
 }
 
 void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, double* pNew, int useBeta,
-                         const double* lam, double* q, bool withCoarse) {
+                         const double* lam, double* q, bool withCoarse, bool tailFused) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   const CoarseView cF = coarseView(h, withCoarse, coarseFusedConsumers());  // z + Z c: the coarse part of the preconditioned residual
@@ -134,7 +134,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     });
     HIP_CHECK(hipGetLastError());
   }
-  {
+  if (!tailFused) {
     if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_matvec_finish");
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8;  // xf, pf, qf + red[6] + flag + coarse correction
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
@@ -177,6 +177,73 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
   }
 }
 
+// ---- k_pcg_tail: finish + update of a PCG iteration in one launch (cvd_kernels.h) ----------------------------------------
+// Scope and launch geometry: one GPU, frame block <= 256, dense coarse level or none, and every workgroup of the launch
+// resident at once (the kernel has a grid barrier): checked against the kernel's occupancy on this device.
+bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish, int& ldsScratch) {
+  cvd_handle* h = c.h;
+  const int F = c.L.F, B = c.L.B;
+  if (!h->opt.pcg_fused_tail || h->dist() || B > 256 || h->forceGeneric) return false;
+  if (coarse && !h->coarse.denseMode) return false;
+  const int grid = F + (coarse ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
+  const int update = B + cgUpdatePartDoubles(B, nThreads) + 48 + 17 * kCB;  // k_cg_update's region (cvd_solve.hip: ldsU)
+  const int finish = 3 * B + 8 + kCB + (nThreads / 256 - 1) * 256;          // k_matvec_finish's + the partial sums of its row walk
+  const int denseEnd = coarse ? F * kCB + nThreads + 16 : 0;                // the dense-level workgroups' (Z^T q + partial sums)
+  ldsFinish = update;
+  ldsScratch = std::max(update + finish, denseEnd);
+  lds = static_cast<size_t>(ldsScratch + 24) * sizeof(double);
+  if (lds > kMaxLds) return false;
+  // occupancy of this (kernel, block size, LDS size) on this device: asked once
+  static std::map<std::tuple<int, int, int, size_t>, int> perCuCache;
+  static std::mutex cacheMutex;
+  int perCu = 0;
+  {
+    std::lock_guard<std::mutex> lock(cacheMutex);
+    const auto key = std::make_tuple(h->device, c.KD, nThreads, lds);
+    auto it = perCuCache.find(key);
+    if (it == perCuCache.end()) {
+      CVD_DISPATCH_KD(c.KD, {
+        allowLds((k_pcg_tail<KD>), lds);
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(&k_pcg_tail<KD>), nThreads, lds));
+      });
+      perCuCache[key] = perCu;
+    } else {
+      perCu = it->second;
+    }
+  }
+  return static_cast<long long>(perCu) * h->numCU >= grid;
+}
+
+void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, int useBeta, const double* lam, double* q,
+                   bool withCoarse, int nThreads, size_t lds, int ldsFinish, int ldsScratch, double tol2) {
+  cvd_handle* h = c.h;
+  hipStream_t s = h->stream;
+  const int F = c.L.F;
+  const CoarseView cF = coarseView(h, withCoarse, false);
+  const DenseStep ds = withCoarse ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p,
+                                               h->coarse.modeActive.p, h->coarse.fail.p}
+                                  : DenseStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* fd = h->dFdot.p;
+  const TailUpdate U{h->dMinv.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, h->coarse.modeActive.p, h->hPcg,
+                     h->dCounters.p + 1, h->dTailBar.p, h->dFdot.p + 4 * static_cast<size_t>(F) + 32, ldsFinish, ldsScratch, ds};
+  const int grid = F + (withCoarse ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
+  const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)
+  {
+    // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate)
+    std::unique_ptr<PersistentGate> gate;
+    if (liveHandles(h->device) > 1) gate.reset(new PersistentGate(h->device, s));
+    CVD_DISPATCH_KD(c.KD, {
+      hipLaunchKernelGGL((k_pcg_tail<KD>), dim3(grid), dim3(nThreads), lds, s, c.L, x, h->dMask.p, lam, h->dMedian.p, h->dRegOwner.p,
+                         h->dInRange.p, c.cross ? h->dXFiOff.p : h->dFiOff.p, h->dFiList.p, h->dQPart.p, pOld, pNew, h->dScal.p,
+                         useBeta, q, fd, c.cross ? static_cast<int>(h->xFa.size()) * 2 : h->qRows, h->regCache, cF,
+                         withCoarse ? h->coarse.qc.p : static_cast<double*>(nullptr),
+                         c.cross ? static_cast<const double*>(h->dH.p) : static_cast<const double*>(nullptr), U);
+    });
+    HIP_CHECK(hipGetLastError());
+  }
+  h->tEnd(slot);
+}
+
 // One kernel of this translation unit's code object is looked up at handle creation: the HIP runtime loads a unit's device
 // code at its first use, ~20 ms per unit that would otherwise land in the first solve of a process (cvd_create: loadDeviceCode).
 void touchModule_matvec() {
@@ -186,6 +253,12 @@ void touchModule_matvec() {
 
 }  // namespace cvd
 
+#ifdef CVD_TAIL_PROFILE
+extern "C" int32_t cvd_debug_tail_profile(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cvd::g_tailProf), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef CVD_MV_PROFILE
 extern "C" int32_t cvd_debug_mv_profile(unsigned long long* out) {  // (same translation unit as the launches: the symbol is per unit)
   (void)hipDeviceSynchronize();

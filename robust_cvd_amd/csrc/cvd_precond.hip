@@ -108,35 +108,6 @@ void launchBlockInverse(Ctx& c) {
   h->tEnd(ct);
 }
 
-// Per-device gate for kernels with a grid barrier: constructed right before the launch (the stream first waits for the
-// previous gated kernel of ANY handle of this process), destroyed right after it (records the completion the next one waits
-// for).  The event belongs to the process, not to a handle.
-struct PersistentGate {
-  static constexpr int kMaxDevices = 64;
-  struct Slot { std::mutex m; hipEvent_t ev = nullptr; bool recorded = false; };
-  static Slot& slot(int device) {
-    static Slot slots[kMaxDevices];
-    if (device < 0 || device >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
-    return slots[device];
-  }
-  Slot& sl;
-  hipStream_t s;
-  PersistentGate(int device, hipStream_t stream) : sl(slot(device)), s(stream) {
-    sl.m.lock();
-    try {
-      if (!sl.ev) HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-      if (sl.recorded) HIP_CHECK(hipStreamWaitEvent(s, sl.ev, 0));
-    } catch (...) {
-      sl.m.unlock();
-      throw;
-    }
-  }
-  ~PersistentGate() {
-    sl.recorded = hipEventRecord(sl.ev, s) == hipSuccess;
-    sl.m.unlock();
-  }
-};
-
 // out (f64, n x n) = A^-1 for one dense SPD f64 matrix (cvd_dense_inverse.h): one persistent launch, one workgroup per
 // super-tile of S x S 16-wide tiles, S the smallest for which the grid fits one workgroup per CU.
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid) {

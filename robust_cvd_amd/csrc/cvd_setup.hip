@@ -1123,7 +1123,7 @@ void ensureBuffers(Ctx& c) {
     }
   }
   h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(std::max(h->qRows, c.nItems * 2)) * B));
-  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4);
+  h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4 + 64);  // (+64: the published p.q sum of k_pcg_tail, in a line of its own)
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
   h->dFocal.ensure(static_cast<size_t>(c.L.F) * 2);

@@ -65,6 +65,14 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
   double* pNew = h->dP1.p;
+  // finish + update as ONE launch per iteration where the fused kernel's scope allows (k_pcg_tail, cvd_matvec.hip)
+  size_t ldsTail = 0;
+  int ldsFinish = 0, ldsScratch = 0;
+  const bool fusedTail = pcgTailScope(c, coarse, nThreads, ldsTail, ldsFinish, ldsScratch);
+  if (fusedTail) {  // (its grid barrier's words)
+    h->dTailBar.ensure(static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies));
+    HIP_CHECK(hipMemsetAsync(h->dTailBar.p, 0, static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies) * sizeof(unsigned int), s));
+  }
   const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
   const int every = std::max(1, c.h->opt.pcg_check_every);
   // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
@@ -77,6 +85,12 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   int enq = 0;
   auto enqueueIteration = [&](int it, int useBeta) {
     h->curPcgIter = it;
+    if (fusedTail) {
+      launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse, true);
+      launchPcgTail(c, x, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse, nThreads, ldsTail, ldsFinish, ldsScratch, tol2);
+      std::swap(pOld, pNew);
+      return;
+    }
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
     const int slot = h->tBegin(KC_CG_UPDATE);
     hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
@@ -108,7 +122,10 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
           const hipError_t e = hipStreamQuery(s);
           if (e != hipErrorNotReady) {
             HIP_CHECK(e);
-            if (static_cast<long long>(prog[1 + (need & 7)] * 0.25) != need + 1) throw std::runtime_error("PCG progress mirror stalled");
+            if (static_cast<long long>(prog[1 + (need & 7)] * 0.25) != need + 1)
+              throw std::runtime_error(fusedTail ? "PCG progress mirror stalled (k_pcg_tail's grid barrier abandoned: the device is shared "
+                                                   "with other work; cvd_solver_options::pcg_fused_tail = 0 selects the two-launch path)"
+                                                 : "PCG progress mirror stalled");
           }
         }
       }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Development aid (GPU): where the workgroups of k_pcg_tail (finish + update of a PCG iteration in one launch) spend their life.
+Library variant with wall-clock stamps (100 MHz):
+    python -c "from robust_cvd_amd import build; build.build_variant('tailprof', ['CVD_TAIL_PROFILE'], ['cvd_matvec'])"
+then  CVD_LIB_VARIANT=tailprof python tools/tail_profile.py [pairs_level]"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+torch.cuda.init()
+import bench
+from robust_cvd_amd import api, synth
+from robust_cvd_amd.ctypes_types import OptParams
+
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+v = synth.make_video(300, 384, 224, seed=bench.SEED, extra_offsets=level)
+s = api.Solver(0)
+p = OptParams.defaults()
+bench.prepare(s, v, p)
+s.set_options(pcg_lockstep=1)
+p.max_iterations = 2
+s.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=False)   # the stamps of the LAST tail launch stay
+lib = api.load_library()
+buf = (C.c_ulonglong * (1024 * 8))()
+assert lib.cvd_debug_tail_profile(buf) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+a = a[a[:, 0] > 0]
+F = v.num_frames
+t0 = a[:, 0].min()
+us = lambda x: x / 100.0
+print("workgroups", len(a), " launch span us %.1f" % us(a[:, 4].max() - t0))
+for name, rows in (("frame workgroups", a[:F]), ("dense-level workgroups", a[F:])):
+    if not len(rows):
+        continue
+    print(name, len(rows))
+    for label, x in (("start offset", us(rows[:, 0] - t0)), ("finish half", us(rows[:, 1] - rows[:, 0])),
+                     ("operand requests", us(rows[:, 2] - rows[:, 1])), ("grid barrier + alpha", us(rows[:, 3] - rows[:, 2])),
+                     ("update half", us(rows[:, 4] - rows[:, 3])), ("barrier release at", us(rows[:, 3] - t0)),
+                     ("end at", us(rows[:, 4] - t0))):
+        print(f"  {label:22s} min {x.min():6.2f}  median {np.median(x):6.2f}  mean {x.mean():6.2f}  max {x.max():6.2f}")
