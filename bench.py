@@ -340,7 +340,8 @@ def main():
         # sample of the timed region; the events of hipExtLaunchKernelGGL serialise the dispatch)
         sample_every = 1 if args.time_all_kernels else args.time_every
         if timing and not args.no_kernel_timing:
-            classes = None if args.time_all_kernels else (["matvec_pairs", "cost", "evaluate_assemble"] if args.dense else ["matvec_pairs"])
+            # every class, sampled (every --time-every-th launch of each class): the line carries SURVEY 8(d)'s per-phase split
+            classes = None
             solver.set_kernel_timing(True, classes=classes, sample_every=sample_every)
         barrier()
         t0 = time.perf_counter()
@@ -415,7 +416,7 @@ def main():
     if rank == 0:
         video, B, n_active = m["video"], m["B"], m["n_active"]
         mv = m["ktimes"]["matvec_pairs"]
-        dense_explicit = args.dense and not os.environ.get("CVD_DENSE_MATRIX_FREE")
+        dense_explicit = args.dense and not any(kv.replace(" ", "") == "dense_matrix_free=1" for kv in args.opt)
         if args.dense:
             npx = width * height
             slots = len(video.pairs) * npx

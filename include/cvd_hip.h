@@ -78,6 +78,10 @@ typedef struct cvd_solver_options {
                                      as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
                                      the two launches */
+  int32_t dist_owner_update;      /* pair-sharded multi-GPU solves, 1 (default): the per-frame update of a PCG iteration runs on the
+                                     frames' OWNER ranks only -- q reduce-scattered to the owners, z / c / the r^T z shares all-gathered
+                                     (two grouped collectives per iteration); 0: q all-reduced and the update replicated on every
+                                     rank (one collective per iteration; rounds 2-3) */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -107,6 +111,11 @@ int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t*
  * this is how the multi-rank code paths run with world > 1 on a single-GPU box (tests/test_gpu_two_ranks.py).
  * Host-synchronous; never used by a multi-GPU run. */
 int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, uint64_t group_key);
+/* Measurement aid (tools/shard_sim.py): this handle becomes rank `rank` of a `world`-rank run whose OTHER ranks do not exist --
+ * every collective returns at once and the other ranks' contributions are simply missing.  The sharded code path runs with the
+ * real owner chunks, offsets and launch geometry of that rank, so its kernels can be timed on one GPU; the numbers the solve
+ * produces mean nothing. */
+int32_t cvd_comm_init_phantom(cvd_handle* h, int32_t rank, int32_t world);
 /* Pair-sharded mode only: the frame pairs of the WHOLE problem (2 * num_pairs frame indices, direction and order
  * irrelevant), identical on every rank.  The coarse level of the preconditioner is built on this graph; without it
  * a multi-rank solve falls back to the block-Jacobi level alone.  Call after cvd_set_video. */

@@ -36,6 +36,7 @@ class SolverOptions(C.Structure):
         ("constraint_order", C.c_int32),
         ("coarse_rebuild_excess_dense", C.c_int32),
         ("pcg_fused_tail", C.c_int32),
+        ("dist_owner_update", C.c_int32),
     ]
 
 
@@ -63,7 +64,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
-    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
+    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_comm_init_phantom", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
     "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_dense_mode_supported", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
@@ -130,6 +131,10 @@ class Solver(Binding):
     def comm_init_local_group(self, rank, world, group_key):
         """Test backend of the exchange layer: `world` handles of this process (one host thread each) form a group."""
         self._check(self._fn("comm_init_local_group")(self._h, C.c_int32(rank), C.c_int32(world), C.c_uint64(group_key)))
+
+    def comm_init_phantom(self, rank, world):
+        """Measurement aid (tools/shard_sim.py): rank `rank` of a `world`-rank run whose other ranks do not exist."""
+        self._check(self._fn("comm_init_phantom")(self._h, C.c_int32(rank), C.c_int32(world)))
 
     def set_pair_graph(self, pair_frames):
         """Frame pairs of the whole problem (pair-sharded multi-GPU mode): same array on every rank."""

@@ -232,6 +232,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->constraint_order = 1;
   o->coarse_rebuild_excess_dense = 32;
   o->pcg_fused_tail = 1;
+  o->dist_owner_update = 1;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
@@ -256,7 +257,7 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
     h->opt = *o;
-    h->distForced = h->world == 1 && (h->comm != nullptr || h->localGroup) && o->force_sharded_path != 0;
+    h->distForced = h->world == 1 && (h->comm != nullptr || h->localGroup || h->phantom) && o->force_sharded_path != 0;
   });
 }
 void cvd_comm_unique_id(uint8_t* out128) {
@@ -288,6 +289,18 @@ int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, ui
     h->rank = rank;
     h->world = world;
     h->distForced = world == 1 && h->opt.force_sharded_path != 0;
+    h->tableValid = false;
+  });
+}
+int32_t cvd_comm_init_phantom(cvd_handle* h, int32_t rank, int32_t world) {
+  CVD_TRY(h, {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("invalid rank / world size");
+    if (h->comm) { NCCL_CHECK(ncclCommDestroy(h->comm)); h->comm = nullptr; }
+    if (h->localGroup) { leaveLocalGroup(*h->localGroup); h->localGroup.reset(); }
+    h->phantom = true;
+    h->rank = rank;
+    h->world = world;
+    h->distForced = world == 1;
     h->tableValid = false;
   });
 }
@@ -677,6 +690,7 @@ int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled) {
     // hipExtLaunchKernelGGL serialise the dispatch, ~3 % of the iteration rate when every launch carries them)
     h->timingStride = ((enabled >> 8) & 0xff) + 1;
     h->timingCounter = 0;
+    for (auto& k : h->timingCounterKc) k = 0;
     enabled &= 0xff;
     h->timing = enabled == 1 ? 0x3f : enabled;
     for (int k = 0; k < KC_TOTAL; ++k) { h->kcMs[k] = 0.0; h->kcN[k] = 0; }

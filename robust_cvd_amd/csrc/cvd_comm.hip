@@ -132,23 +132,36 @@ static void localCollective(cvd_handle* h, int kind, const void* send, void* rec
   groupBarrier(g);  // nobody restages before every rank has read
 }
 
+// Phantom rank (cvd_comm_init_phantom): the in-place forms leave the own contribution where it is; the out-of-place ones copy it.
+static void phantomCopy(const void* src, void* dst, size_t bytes, hipStream_t s) {
+  if (src != dst && bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+}
 void commAllReduce(cvd_handle* h, void* buf, size_t count, CommType t, hipStream_t s) {
+  if (h->phantom) return;
   if (h->localGroup) { localCollective(h, 0, buf, buf, count, t, s); return; }
   NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclType(t), ncclSum, h->comm, s));
 }
 void commReduceScatter(cvd_handle* h, const void* send, void* recv, size_t recvCount, CommType t, hipStream_t s) {
+  if (h->phantom) {
+    phantomCopy(static_cast<const unsigned char*>(send) + static_cast<size_t>(h->rank) * recvCount * typeSize(t), recv, recvCount * typeSize(t), s);
+    return;
+  }
   if (h->localGroup) { localCollective(h, 1, send, recv, recvCount, t, s); return; }
   NCCL_CHECK(ncclReduceScatter(send, recv, recvCount, ncclType(t), ncclSum, h->comm, s));
 }
 void commAllGather(cvd_handle* h, const void* send, void* recv, size_t sendCount, CommType t, hipStream_t s) {
+  if (h->phantom) {
+    phantomCopy(send, static_cast<unsigned char*>(recv) + static_cast<size_t>(h->rank) * sendCount * typeSize(t), sendCount * typeSize(t), s);
+    return;
+  }
   if (h->localGroup) { localCollective(h, 2, send, recv, sendCount, t, s); return; }
   NCCL_CHECK(ncclAllGather(send, recv, sendCount, ncclType(t), h->comm, s));
 }
 void commGroupStart(cvd_handle* h) {
-  if (!h->localGroup) NCCL_CHECK(ncclGroupStart());
+  if (!h->localGroup && !h->phantom) NCCL_CHECK(ncclGroupStart());
 }
 void commGroupEnd(cvd_handle* h) {
-  if (!h->localGroup) NCCL_CHECK(ncclGroupEnd());
+  if (!h->localGroup && !h->phantom) NCCL_CHECK(ncclGroupEnd());
 }
 
 }  // namespace cvd

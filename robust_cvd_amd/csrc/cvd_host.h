@@ -204,6 +204,7 @@ struct cvd_handle_t {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   std::shared_ptr<LocalGroup> localGroup;  // test backend of the exchange layer (cvd_comm_init_local_group)
+  bool phantom = false;                    // measurement aid (cvd_comm_init_phantom): the other ranks do not exist
   DevBuf<unsigned char> dCommStage;
   DevBuf<const unsigned char*> dCommPtrs;
   bool distForced = false;  // test hook (cvd_solver_options::force_sharded_path with a 1-rank communicator): run the multi-rank code path
@@ -255,6 +256,7 @@ struct cvd_handle_t {
   DevBuf<double> dXBlocks;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   DevBuf<unsigned int> dTailBar;   // grid barrier of k_pcg_tail (tailArrive / tailWait)
+  DevBuf<double> dOwnerScal;       // owner-sharded PCG iteration: {r^T z, r^T r} shares of every rank (all-gathered)
   std::vector<unsigned char> tableRange;  // range the table / items were compiled for
   bool tableValid = false;
   bool tableIgnoresStatic = false;  // compiled for normalizeDepth's pair loop (every constraint, dynamic ones included)
@@ -343,6 +345,7 @@ struct cvd_handle_t {
   int timing = 0;  // bit mask of KernelClass values to time with HIP events
   int timingStride = 1;        // hipExtLaunchKernelGGL event pairs (tReserve) on every timingStride-th launch only
   long long timingCounter = 0;
+  long long timingCounterKc[16] = {0};  // per class: tBegin samples every timingStride-th launch of a class as well
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
   std::vector<int> evClass;
   std::vector<int> evIter;  // PCG iteration the launch belongs to (-1 outside PCG): launches enqueued past
@@ -373,6 +376,7 @@ struct cvd_handle_t {
   // ---- timing helpers --------------------------------------------------------------------------------
   int tBegin(int kc) {
     if (kc >= KC_COUNT ? timing == 0 : !(timing & (1 << kc))) return -1;
+    if (timingStride > 1 && (timingCounterKc[kc]++ % timingStride) != 0) return -1;  // uniform sample of the class' launches
     if (evUsed == evPool.size()) {
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a));
@@ -567,7 +571,9 @@ void launchCrossAssemble(Ctx& c, const double* x);
 double evalFull(Ctx& c, const double* x, bool withStats = false);
 bool coarseFusedConsumers();
 bool fusedExchange(cvd_handle* h, bool withCoarse);
+size_t exchangeOffsetQc(const Ctx& c);
 size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
+bool ownerShardedUpdate(cvd_handle* h, bool withCoarse);
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);

@@ -1848,7 +1848,11 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
                                              double tol2, double* __restrict__ rc,
                                              const unsigned char* __restrict__ modeActive,
                                              double* __restrict__ hostMirror, const CoarseStep& cs, const DenseStep& ds,
-                                             const double* __restrict__ pqReduced, double* __restrict__ sm, Mid& mid) {
+                                             const double* __restrict__ pqReduced, double* __restrict__ sm, Mid& mid,
+                                             int f0, int nF, double* __restrict__ partOut) {
+  // [f0, f0 + nF): the frames this launch updates -- all of them, or (owner-sharded multi-GPU iteration) the calling rank's own
+  // chunk; workgroups beyond nF are the dense coarse level's, two frames of the window each.  partOut != nullptr: the last
+  // workgroup leaves THIS RANK's shares {r^T z, r^T r} there instead of finishing the PCG scalars (k_pcg_scalars_dist does).
   const double sDone = (init || FUSED) ? 0.0 : scal[S_DONE];  // converged earlier: the iterations enqueued ahead are no-ops (tested below)
   const int B = L.B;
   const int nThreads = blockDim.x;
@@ -1859,7 +1863,8 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   const bool fusedY = !init && cs.Wb != nullptr;
   const bool fusedDense = !init && ds.Ainv != nullptr;  // (the grid then has F extra workgroups)
   const int nWaves = nThreads >> 6;
-  const int f = blockIdx.x;
+  const bool denseWg = static_cast<int>(blockIdx.x) >= nF;
+  const int f = denseWg ? L.F + (static_cast<int>(blockIdx.x) - nF) : f0 + static_cast<int>(blockIdx.x);
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
@@ -1888,7 +1893,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     double* psum = sm + n;                  // nThreads partial sums
     // kDenseFramesPerGroup frames per workgroup, one after the other: F + F / 2 workgroups of 768 threads still fit the
     // device in ONE round (two per CU), F + F do not
-    const int g0 = (f - L.F) * kDenseFramesPerGroup;
+    const int g0 = f0 + (f - L.F) * kDenseFramesPerGroup;
     double2 w[kDenseLoads];
     {
       const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + m) * n);
@@ -1910,7 +1915,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     if (sDone != 0.0) return;  // uniform; nothing written yet
     for (int rep = 0; rep < kDenseFramesPerGroup; ++rep) {
       const int g = g0 + rep;
-      if (g >= L.F) break;
+      if (g >= f0 + nF) break;
       const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
       const int e = g * kCB + (tid < kCB ? tid : 0);
       const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
@@ -2154,7 +2159,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
   if (lastBlockArrivesLite(counter, gridDim.x, reinterpret_cast<int*>(red + 40))) {
     double a = 0.0, b = 0.0, cY = 0.0;
-    for (int k = tid; k < L.F; k += nThreads) {
+    for (int k = f0 + tid; k < f0 + nF; k += nThreads) {
       a += readPartial(fdotRZ + k);
       b += readPartial(fdotRR + k);
       if (fusedY) cY += readPartial(cs.fdotY + k);
@@ -2169,7 +2174,10 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     if (tid == 0) {
       double rzs = 0.0, rrs = 0.0, ys = 0.0;
       for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; ys += ypart[w]; }
-      if (fusedY) {  // two-level r^T z; a broken-down coarse factorisation switches the level off (consumers use c = 0)
+      if (partOut != nullptr) {  // owner-sharded iteration: this rank's shares, summed over the ranks by k_pcg_scalars_dist
+        partOut[0] = rzs + ((fusedY && *cs.fail != 0) ? 0.0 : ys);
+        partOut[1] = rrs;
+      } else if (fusedY) {  // two-level r^T z; a broken-down coarse factorisation switches the level off (consumers use c = 0)
         pcgFinishScalars(scal, 0, rzs + (*cs.fail == 0 ? ys : 0.0), rrs, tol2, hostMirror);
       } else if (fusedDense) {  // (a failed inverse left c = 0 and zero shares)
         pcgFinishScalars(scal, 0, rzs + ys, rrs, tol2, hostMirror);
@@ -2192,14 +2200,29 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
                                                     double tol2, double* __restrict__ rc,
                                                     const unsigned char* __restrict__ modeActive,
                                                     double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
-                                                    const double* __restrict__ pqReduced) {
+                                                    const double* __restrict__ pqReduced, int f0, int nF,
+                                                    double* __restrict__ partOut) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   struct NoMid {
     __device__ bool first(double&, double&) { return true; }
     __device__ bool second(double&) { return true; }
   } mid;
   cgUpdateBody<false>(L, init, g, minv, p, q, scal, counter, dx, r, z, fdotRZ, fdotRR, tol2, rc, modeActive, hostMirror, cs, ds,
-                      pqReduced, sm, mid);
+                      pqReduced, sm, mid, f0, nF, partOut);
+}
+
+// Owner-sharded PCG iteration (multi-GPU): every rank updated x, r, z of ITS frames and left {r^T z, r^T r} of those frames in
+// parts[2 rank]; after the all-gather of the shares one workgroup finishes the iteration's scalars (beta, convergence flag,
+// iteration count, host mirror) on every rank -- identically: the ranks sum the same numbers in the same order.
+inline __global__ void k_pcg_scalars_dist(const double* __restrict__ parts, int world, double* __restrict__ scal, double tol2,
+                                          double* __restrict__ hostMirror) {
+  if (threadIdx.x != 0 || scal[S_DONE] != 0.0) return;  // (iterations enqueued past convergence are no-ops)
+  double rz = 0.0, rr = 0.0;
+  for (int r = 0; r < world; ++r) {
+    rz += parts[2 * r];
+    rr += parts[2 * r + 1];
+  }
+  pcgFinishScalars(scal, 0, rz, rr, tol2, hostMirror);
 }
 
 // ---- one kernel for the tail of a PCG iteration ------------------------------------------------------
@@ -2365,7 +2388,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
     __device__ bool second(double& alpha) { return f2(alpha); }
   } mid{first, second};
   cgUpdateBody<true>(L, 0, nullptr, U.minv, nullptr, nullptr, scal, U.counter, U.dx, U.r, U.z, U.fdotRZ, U.fdotRR, U.tol2, nullptr,
-                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid);
+                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr);
   TAIL_STAMP(4);
 }
 

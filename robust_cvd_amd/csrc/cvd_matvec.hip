@@ -9,7 +9,18 @@ bool coarseFusedConsumers() {
 // Pair-sharded mode: the product's exchange carries [q | Z^T q | p.q] in one all-reduce unless the SPARSE coarse level is on
 // (its column products need the reduced Z^T q: k_dot_pq).  Layout: [q (F B) | Z^T q (8 F, dense coarse level only) | p.q].
 bool fusedExchange(cvd_handle* h, bool withCoarse) { return !withCoarse || h->coarse.denseMode; }
-size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse) { return c.n + (withDenseCoarse ? static_cast<size_t>(c.L.F) * kCB : 0); }
+// (sharded: the q part is padded to world x chunk frames, so that its reduce-scatter / all-gather chunks are equal)
+size_t exchangeOffsetQc(const Ctx& c) { return c.h->dist() ? static_cast<size_t>(c.h->framesPadded()) * c.L.B : c.n; }
+size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse) {
+  return exchangeOffsetQc(c) + (withDenseCoarse ? static_cast<size_t>(c.L.F) * kCB : 0);
+}
+// Owner-sharded PCG iteration: with the fused exchange the product's q is REDUCE-SCATTERED to
+// the frames' owners ([Z^T q | p.q] all-reduced beside it, one RCCL group), every rank updates x, r, z (and its rows of the dense
+// coarse level) for ITS frames only, and z / c / the r^T z shares are all-gathered (one group): two collectives per iteration,
+// the per-frame update work divided by the number of ranks.
+bool ownerShardedUpdate(cvd_handle* h, bool withCoarse) {
+  return h->dist() && fusedExchange(h, withCoarse) && h->opt.dist_owner_update != 0;
+}
 CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
   if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto& C = h->coarse;
@@ -144,7 +155,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     // q and travel in one all-reduce; k_cg_update forms alpha from the reduced p.q.  With the sparse coarse level the
     // column products need the REDUCED Z^T q: q alone is exchanged and k_dot_pq finishes the product.
     const bool fusedX = h->dist() && fusedExchange(h, withCoarse);
-    double* qcX = q + c.n;
+    double* qcX = q + exchangeOffsetQc(c);
     double* pqX = q + exchangeOffsetPq(c, denseFused);
     const CoarseColumns cc{h->coarse.pos.p, h->coarse.wPtr.p, h->coarse.wSlot.p, fusedCoarse ? h->coarse.Wb.p : nullptr,
                            h->coarse.wq.p};
@@ -160,7 +171,16 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
                          h->dist() ? h->ownCount() : c.L.F);
     });
     HIP_CHECK(hipGetLastError());
-    if (fusedX) {
+    if (fusedX && ownerShardedUpdate(h, withCoarse)) {
+      // q to the frames' owners (in place: the reduced chunk lands where the frames' q lives), [Z^T q | p.q] to everybody
+      const int ct = h->tBegin(KC_COMM_PRODUCT);
+      const size_t chunk = static_cast<size_t>(h->ownChunk()) * B;
+      commGroupStart(h);
+      commReduceScatter(h, q, q + static_cast<size_t>(h->rank) * chunk, chunk, CT_F64, s);
+      commAllReduce(h, qcX, exchangeOffsetPq(c, denseFused) - exchangeOffsetQc(c) + 1, CT_F64, s);
+      commGroupEnd(h);
+      h->tEnd(ct);
+    } else if (fusedX) {
       const int ct = h->tBegin(KC_COMM_PRODUCT);
       commAllReduce(h, q, exchangeOffsetPq(c, denseFused) + 1, CT_F64, s);
       h->tEnd(ct);

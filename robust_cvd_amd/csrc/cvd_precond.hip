@@ -103,8 +103,10 @@ void launchBlockInverse(Ctx& c) {
     launchBlockInverseRaw(h, own, h->dH.p + f0 * B * B, h->dLam.p + f0 * B, h->dMinv.p + f0 * B * B, h->dFail.p, variant);
   const int ct = h->tBegin(KC_COMM_EVAL);
   const size_t chunk = static_cast<size_t>(h->ownChunk()) * B * B;
+  commGroupStart(h);  // (one RCCL launch for both)
   commAllGather(h, h->dMinv.p + static_cast<size_t>(h->rank) * chunk, h->dMinv.p, chunk, CT_F32, h->stream);
   commAllReduce(h, h->dFail.p, 1, CT_I32, h->stream);
+  commGroupEnd(h);
   h->tEnd(ct);
 }
 

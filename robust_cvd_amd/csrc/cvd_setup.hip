@@ -617,7 +617,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.wq.ensure(static_cast<size_t>(nW) * kCB);
   C.fdotY.ensure(F);
   C.y.ensure(n);
-  C.c.ensure(n);
+  C.c.ensure(static_cast<size_t>(h->framesPadded()) * kCB);  // (all-gathered in place by the owner-sharded PCG iteration)
   C.dotPart.ensure(static_cast<size_t>(F));
   C.modeActive.ensure(n);
   C.fail.ensure(1);
@@ -1107,8 +1107,17 @@ void ensureBuffers(Ctx& c) {
   const size_t n = c.n;
   const size_t B = c.L.B;
   h->dX.ensure(n); h->dXc.ensure(n); h->dG.ensure(n); h->dLam.ensure(n); h->dScale.ensure(n);
-  h->dDx.ensure(n); h->dR.ensure(n); h->dR1.ensure(n); h->dZ.ensure(n); h->dP0.ensure(n); h->dP1.ensure(n);
-  h->dQ.ensure(n + static_cast<size_t>(c.L.F) * kCB + 8);  // (+ [Z^T q | p.q]: the fused exchange of the pair-sharded mode)
+  // (sharded: the vectors the owner-sharded PCG iteration reduce-scatters / all-gathers in place hold world x chunk frames)
+  const size_t nVec = static_cast<size_t>(h->framesPadded()) * B;
+  if (h->dist() && (h->dDx.n < nVec || h->dZ.n < nVec)) {
+    h->dDx.ensure(nVec); h->dR.ensure(nVec); h->dZ.ensure(nVec);
+    HIP_CHECK(hipMemsetAsync(h->dDx.p, 0, nVec * sizeof(double), h->stream));
+    HIP_CHECK(hipMemsetAsync(h->dR.p, 0, nVec * sizeof(double), h->stream));
+    HIP_CHECK(hipMemsetAsync(h->dZ.p, 0, nVec * sizeof(double), h->stream));
+  }
+  h->dDx.ensure(nVec); h->dR.ensure(nVec); h->dR1.ensure(n); h->dZ.ensure(nVec); h->dP0.ensure(n); h->dP1.ensure(n);
+  h->dQ.ensure(nVec + static_cast<size_t>(c.L.F) * kCB + 8);  // (+ [Z^T q | p.q]: the fused exchange of the pair-sharded mode)
+  h->dOwnerScal.ensure(2 * static_cast<size_t>(std::max(1, h->world)));
   h->dHd.ensure(n);
   {
     // (sharded mode: room for world x chunk frames so that the reduce-scatter / all-gather chunks are equal; the tail

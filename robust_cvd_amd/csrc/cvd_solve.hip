@@ -54,13 +54,14 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   // pair-sharded mode with the fused exchange (cvd_matvec.hip): Z^T q and p.q arrive all-reduced behind q
   const bool fusedX = h->dist() && fusedExchange(h, coarse);
   const double* pqReduced = fusedX ? h->dQ.p + exchangeOffsetPq(c, denseFused) : nullptr;
-  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + c.n : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
+  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + exchangeOffsetQc(c) : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
                                                 h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
                                     : dsOff;
   if (denseFused) ldsU = std::max(ldsU, (static_cast<size_t>(F) * kCB + nThreads + 16) * 8);  // (its workgroups: Z^T q + partial sums)
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
-                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr));
+                     h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr), 0, F,
+                     static_cast<double*>(nullptr));
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -73,6 +74,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
     h->dTailBar.ensure(static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies));
     HIP_CHECK(hipMemsetAsync(h->dTailBar.p, 0, static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies) * sizeof(unsigned int), s));
   }
+  const bool ownerMode = ownerShardedUpdate(h, coarse);
   const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
   const int every = std::max(1, c.h->opt.pcg_check_every);
   // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
@@ -92,10 +94,38 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       return;
     }
     launchMatvec(c, x, h->dZ.p, pOld, pNew, useBeta, h->dLam.p, h->dQ.p, coarse);
+    if (ownerMode) {
+      // ---- owner-sharded iteration: the exchange above left the reduced q of THIS rank's frames (and [Z^T q | p.q] everywhere);
+      // update the own frames, gather z / c / the r^T z shares, finish the scalars
+      const int f0 = h->ownFirst(), nOwn = h->ownCount();
+      const int slotO = h->tBegin(KC_CG_UPDATE);
+      if (nOwn > 0)
+        hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn),
+                           dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, h->dScal.p, h->dCounters.p + 1,
+                           h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, static_cast<double*>(nullptr),
+                           h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank);
+      else
+        HIP_CHECK(hipMemsetAsync(h->dOwnerScal.p + 2 * h->rank, 0, 2 * sizeof(double), s));
+      HIP_CHECK(hipGetLastError());
+      h->tEnd(slotO);
+      const int ct = h->tBegin(KC_COMM_PRODUCT);
+      const size_t chunkF = static_cast<size_t>(h->ownChunk());
+      commGroupStart(h);
+      commAllGather(h, h->dZ.p + h->rank * chunkF * B, h->dZ.p, chunkF * B, CT_F64, s);
+      if (denseFused) commAllGather(h, h->coarse.c.p + h->rank * chunkF * kCB, h->coarse.c.p, chunkF * kCB, CT_F64, s);
+      commAllGather(h, h->dOwnerScal.p + 2 * h->rank, h->dOwnerScal.p, 2, CT_F64, s);
+      commGroupEnd(h);
+      h->tEnd(ct);
+      hipLaunchKernelGGL(k_pcg_scalars_dist, dim3(1), dim3(64), 0, s, h->dOwnerScal.p, h->world, h->dScal.p, tol2, h->hPcg);
+      HIP_CHECK(hipGetLastError());
+      std::swap(pOld, pNew);
+      return;
+    }
     const int slot = h->tBegin(KC_CG_UPDATE);
     hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
-                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced);
+                       (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced,
+                       0, F, static_cast<double*>(nullptr));
     if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -140,6 +170,16 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
     }
   }
   h->curPcgIter = -1;
+  if (ownerMode) {
+    // the step and the residual of the frames live on their owners: everybody needs both (step statistics, candidate point)
+    const int ct = h->tBegin(KC_COMM_PRODUCT);
+    const size_t chunk = static_cast<size_t>(h->ownChunk()) * B;
+    commGroupStart(h);
+    commAllGather(h, h->dDx.p + h->rank * chunk, h->dDx.p, chunk, CT_F64, s);
+    commAllGather(h, h->dR.p + h->rank * chunk, h->dR.p, chunk, CT_F64, s);
+    commGroupEnd(h);
+    h->tEnd(ct);
+  }
   if (tail) tail();  // follow-up work that does not need the host's decision rides on the same read-back
   readScalars(c);    // drains the stream; S_DONE / S_ITERS are final
   if (h->hScal[S_DONE] == 2.0) throw std::runtime_error("PCG produced NaN");

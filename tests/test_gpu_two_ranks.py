@@ -120,12 +120,17 @@ def compare(ranks, single):
     assert ranks[0][3]["num_iterations"] == ranks[1][3]["num_iterations"]
 
 
-@pytest.mark.parametrize("coarse", ["sparse", "dense", "sparsified", "off"])
+@pytest.mark.parametrize("coarse", ["sparse", "dense", "sparsified", "off", "dense_replicated_update", "off_replicated_update"])
 def test_two_ranks_match_the_single_gpu_solve(coarse):
-    """Odd frame count (owner chunks of 5 + 4 frames, one padded frame), default coarse-to-fine pipeline on a small grid."""
+    """Odd frame count (owner chunks of 5 + 4 frames, one padded frame), default coarse-to-fine pipeline on a small grid.
+    dense / off run the OWNER-SHARDED PCG iteration (q reduce-scattered to the frames' owners, the update on the own frames only,
+    z / c / the r^T z shares all-gathered: two grouped collectives per iteration); *_replicated_update the round-3 scheme (q
+    all-reduced, the update replicated: cvd_solver_options::dist_owner_update = 0); sparse / sparsified the q-only exchange."""
     v = synth.make_video(9, 96, 56, seed=52, extra_offsets=4)
     options = {"sparse": {}, "dense": {"coarse_update_budget": 0},
-               "sparsified": {"coarse_update_budget": 0, "coarse_dense_max_unknowns": 0}, "off": {"coarse_level": 0}}[coarse]
+               "sparsified": {"coarse_update_budget": 0, "coarse_dense_max_unknowns": 0}, "off": {"coarse_level": 0},
+               "dense_replicated_update": {"coarse_update_budget": 0, "dist_owner_update": 0},
+               "off_replicated_update": {"coarse_level": 0, "dist_owner_update": 0}}[coarse]
     single = solve_single(v, options, (6, 4))
     ranks = solve_sharded(v, 2, options, (6, 4))
     compare(ranks, single)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid (GPU): end-state distance to the oracle's minted solutions (tests/golden/solutions) and PCG effort for a
-set of solver options.  usage: parity_probe.py "eta=5e-3" "eta=1e-3" ... [--configs=config2_4k,config2]"""
+set of solver options.  usage: parity_probe.py "eta=5e-3" "eta=1e-3,coarse_level=0" ... [--configs=config2_4k,config2]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,9 @@ for name in configs:
     for spec in args:
         kv = dict(x.split("=") for x in spec.split(","))
         s = api.Solver(0)
-        s.set_options(pcg_relative_tolerance=float(kv.get("eta", 1e-3)))
+        s.set_options(pcg_relative_tolerance=float(kv.pop("eta", 1e-3)))
+        if kv:  # any other cvd_solver_options field, e.g. coarse_level=0
+            s.set_options(**{k: (float(v) if "." in v or "e" in v else int(v)) for k, v in kv.items()})
         sol = bc.run(s, name, v)
         sm = sol["summary"]
         perr, rerr = synth.relative_pose_error(sol["position"], sol["orientation"], ref["position"], ref["orientation"])

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Development aid (one GPU): what ONE rank of an N-rank pair-sharded run computes per PCG iteration.  Rank 0's shard of the
-benchmark's pairs is solved on a 1-rank RCCL communicator with the sharded code path forced (the other ranks' contributions
-are simply missing: a smaller but valid problem), and the kernel classes are timed.  The collectives cost nothing here, so the
-figures are the COMPUTE side of an N-GPU iteration; the exchange (one all-reduce of [q | Z^T q | p.q], 445 KB, per product)
-comes on top.  usage: shard_sim.py [N ...]"""
+"""Development aid (one GPU): what ONE rank of an N-rank pair-sharded run computes per PCG iteration.  The handle becomes rank 0
+of a PHANTOM N-rank run (cvd_comm_init_phantom: the other ranks do not exist, every collective returns at once): it holds rank
+0's shard of the benchmark's pairs, owns rank 0's chunk of the frames and runs the sharded code path with that rank's real launch
+geometry -- product over its pairs, finish over all frames, update over ITS frames (owner-sharded iteration) -- while the kernel
+classes are timed.  The collectives cost nothing here, so the figures are the COMPUTE side of an N-GPU iteration; the numbers
+the solve produces mean nothing (the other ranks' contributions are missing), which is why the iteration counts are forced.
+usage: shard_sim.py [N ...] [--replicated]   (--replicated: cvd_solver_options::dist_owner_update = 0, the round-3 scheme)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,26 +16,47 @@ import bench
 from robust_cvd_amd import api, sharding, synth
 from robust_cvd_amd.ctypes_types import OptParams
 
-worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+replicated = "--replicated" in sys.argv
+worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
 full = synth.make_video(300, 384, 224, seed=bench.SEED, extra_offsets=6)
+# the state the timed iterations start from, from a REAL single-rank run (the phantom solve below cannot produce one)
+ref = api.Solver(0)
+p = OptParams.defaults()
+bench.prepare(ref, full, p)
+pose0, theta0 = ref.get_pose_params().copy(), ref.get_xform_params().copy()
+desc = ref.xform_desc()
+ref.close()
 for world in worlds:
     v = copy.copy(full)
     mine = sharding.shard_pairs(full.pairs, full.offsets, world)[0]
     v.pairs, v.offsets, v.loc, v.is_static = sharding.take_pairs(full.pairs, full.offsets, full.loc, full.is_static, mine)
     s = api.Solver(0)
-    s.set_options(force_sharded_path=1)
-    s.comm_init(0, 1, api.Solver.comm_unique_id())
-    p = OptParams.defaults()
-    bench.prepare(s, v, p, pair_graph=full.pairs)
-    pose0, theta0 = s.get_pose_params().copy(), s.get_xform_params().copy()
-    bench.run_iterations(s, p, pose0, theta0, 3)
+    s.comm_init_phantom(0, world)
+    # fixed work: 3 LM iterations of exactly 40 PCG iterations each (nothing converges with the other ranks missing)
+    s.set_options(force_sharded_path=1, dist_owner_update=int(not replicated), pcg_max_iterations=40, pcg_relative_tolerance=1e-12,
+                  force_iterations=1)
+    synth.load_into(s, v, p.focal_long)
+    s.set_pair_graph(full.pairs)
+    from robust_cvd_amd.ctypes_types import XformDesc
+    s.reset_depth_xforms(desc)
+    s.reset_spatial_xforms(XformDesc.spatial())
+
+    def run(n):
+        s.set_pose_params(pose0)
+        s.set_xform_params(theta0)
+        p.max_iterations = n
+        s.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=False)
+
+    run(2)
     s.set_kernel_timing(True)
-    done, cg, solves, last = bench.run_iterations(s, p, pose0, theta0, 12)
+    run(3)
     kt = s.kernel_times()
+    sm = s.summary()
     per_it = kt["matvec_pairs"]["avg_ms"] + kt["matvec_finish"]["avg_ms"] + kt["cg_update"]["avg_ms"]
-    print(f"world {world}: rank 0 holds {len(v.pairs)} pairs / {int(v.offsets[-1])} constraints; per PCG iteration (HIP events, "
-          f"incl. dispatch gaps): product {kt['matvec_pairs']['avg_ms'] * 1e3:.1f} us + finish (+ exchange call) "
-          f"{kt['matvec_finish']['avg_ms'] * 1e3:.1f} + update {kt['cg_update']['avg_ms'] * 1e3:.1f} = {per_it * 1e3:.1f} us; "
-          f"assembly {kt['evaluate_assemble']['avg_ms']:.3f} ms, preconditioner {kt['block_inverse']['avg_ms']:.3f} ms; "
-          f"{cg / done:.1f} PCG iterations per LM iteration", flush=True)
+    print(f"world {world}{' (replicated update)' if replicated else ''}: rank 0 holds {len(v.pairs)} pairs / {int(v.offsets[-1])} "
+          f"constraints and owns {-(-full.num_frames // world)} frames; per PCG iteration (HIP events, incl. dispatch gaps): product "
+          f"{kt['matvec_pairs']['avg_ms'] * 1e3:.1f} us + finish {kt['matvec_finish']['avg_ms'] * 1e3:.1f} + update "
+          f"{kt['cg_update']['avg_ms'] * 1e3:.1f} = {per_it * 1e3:.1f} us; assembly {kt['evaluate_assemble']['avg_ms']:.3f} ms, "
+          f"preconditioner {kt['block_inverse']['avg_ms']:.3f} ms; {sm['total_linear_iterations']} PCG iterations in "
+          f"{sm['num_iterations']} LM iterations", flush=True)
     s.close()
