@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figure on the reference sampler's 1766-pair list")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every kernel class (slower)")
-    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the hot kernel (1 = all)")
+    ap.add_argument("--time-every", type=int, default=16, help="HIP-event pair on every k-th launch of the hot kernel (1 = all)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="development: no HIP-event timing of the hot kernel (roofline fields are then empty)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="N > 1: pair-sharded (strong) or one video per GPU (weak)")
     ap.add_argument("--pcg-lockstep", action="store_true", help="profiling: no PCG run-ahead (clean per-launch counter averages)")

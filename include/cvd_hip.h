@@ -78,6 +78,9 @@ typedef struct cvd_solver_options {
                                      as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
                                      the two launches */
+  int32_t coarse_dense_row_split; /* dense coarse level, per PCG iteration: of a frame's 8 rows of A_c^-1 the first this-many are applied by
+                                     the dense-level workgroups (two frames each), the others by the frame's own workgroup after its
+                                     update (default 5; 8 = rounds 2-3: dense-level workgroups only; 0 = frame workgroups only) */
   int32_t dist_owner_update;      /* pair-sharded multi-GPU solves, 1 (default): the per-frame update of a PCG iteration runs on the
                                      frames' OWNER ranks only -- q reduce-scattered to the owners, z / c / the r^T z shares all-gathered
                                      (two grouped collectives per iteration); 0: q all-reduced and the update replicated on every

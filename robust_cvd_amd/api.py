@@ -36,6 +36,7 @@ class SolverOptions(C.Structure):
         ("constraint_order", C.c_int32),
         ("coarse_rebuild_excess_dense", C.c_int32),
         ("pcg_fused_tail", C.c_int32),
+        ("coarse_dense_row_split", C.c_int32),
         ("dist_owner_update", C.c_int32),
     ]
 

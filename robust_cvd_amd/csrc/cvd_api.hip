@@ -232,6 +232,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->constraint_order = 1;
   o->coarse_rebuild_excess_dense = 32;
   o->pcg_fused_tail = 1;
+  o->coarse_dense_row_split = 5;
   o->dist_owner_update = 1;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
@@ -253,6 +254,7 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
     if (o->coarse_level < 0 || o->coarse_level > 2 || o->robust_loss < 0 || o->robust_loss > 1 || o->block_inverse_variant < 0 ||
         o->block_inverse_variant > 2)
       throw std::runtime_error("coarse_level in {0, 1, 2}, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
+    if (o->coarse_dense_row_split < 0 || o->coarse_dense_row_split > 8) throw std::runtime_error("coarse_dense_row_split must lie in [0, 8]");
     if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)

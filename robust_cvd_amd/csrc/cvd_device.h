@@ -868,6 +868,12 @@ struct DenseStep {
   double* dotPart;      // [F] this frame's share of r^T Z A_c^-1 Z^T r
   const unsigned char* modeActive;
   const int* fail;
+  // Rows [0, rowSplit) of a frame's 8 belong to the dense-level workgroups (two frames each), rows [rowSplit, 8) to the frame's
+  // OWN workgroup, which walks them after its update: the dense-level workgroups alone were the kernel's long pole (12 us for
+  // 46 MB through 150 workgroups while the 300 frame workgroups had finished after 6).  rowSplit = 8: no split.
+  int rowSplit;
+  int ldsPsum;          // LDS offset (doubles) of the frame workgroups' partial sums for their rows
+  double* dotPart2;     // [F] the frame workgroup's rows' share
 };
 // Column half of y <- y - alpha W (Z^T q): the workgroup of frame f multiplies the blocks of ITS column of W (contiguous:
 // the elimination-tree path of the frame, <= tree depth blocks) with its restricted product and stores each 8-vector at

@@ -574,6 +574,7 @@ bool fusedExchange(cvd_handle* h, bool withCoarse);
 size_t exchangeOffsetQc(const Ctx& c);
 size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
 bool ownerShardedUpdate(cvd_handle* h, bool withCoarse);
+inline int denseRowSplit(const cvd_handle* h) { return std::min(kCB, std::max(0, h->opt.coarse_dense_row_split)); }
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);

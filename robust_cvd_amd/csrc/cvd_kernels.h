@@ -1876,39 +1876,96 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     // update half requests its operands below
     if (!mid.first(pvCarry, qvCarry)) return;
   }
-  if (f >= L.F) {
-    // ---- dense coarse level, frame g: d = (A_c^-1 Z^T q)_g (8 rows, one wave each, 16-byte loads all in flight),
-    // c_g <- c_g - alpha d, rc_g <- rc_g - alpha qc_g, and this frame's share of the coarse part of r^T z
-    // nThreads / 8 threads per row (96 at B = 177); every thread's <= kDenseLoads 16-byte loads of the (f64) inverse are issued
-    // at once, qc goes through LDS (coalesced, one round trip for both), the row sums are folded in LDS
 #ifndef CVD_DENSE_LOADS
 #define CVD_DENSE_LOADS 4
 #endif
-    // (7 in the fused kernel -- two round trips per row instead of four -- spills at its 80-register budget: 12.9 -> 16.9 us)
-    constexpr int kDenseLoads = CVD_DENSE_LOADS;
-    const int per = nThreads >> 3, m = tid / per, part = tid - m * per;
-    const size_t n = static_cast<size_t>(L.F) * kCB;
-    const int n2 = static_cast<int>(n / 2);
-    double* qcs = sm;                       // n doubles (the frame workgroups' layout is not used here)
-    double* psum = sm + n;                  // nThreads partial sums
-    // kDenseFramesPerGroup frames per workgroup, one after the other: F + F / 2 workgroups of 768 threads still fit the
-    // device in ONE round (two per CU), F + F do not
+  // (7 in the fused kernel -- two round trips per row instead of four -- spills at its 80-register budget: 12.9 -> 16.9 us)
+  constexpr int kDenseLoads = CVD_DENSE_LOADS;
+  const size_t nC = static_cast<size_t>(L.F) * kCB;   // coarse unknowns
+  const int n2 = static_cast<int>(nC / 2);
+  // ---- dense coarse level, rows [r0, r0 + nR) of frame g: d = (A_c^-1 Z^T q) (nThreads / nR threads per row; every thread's
+  // <= kDenseLoads 16-byte loads of the (f64) inverse are issued at once, qc comes from LDS, the row sums are folded in LDS),
+  // c <- c - alpha d, rc <- rc - alpha qc, and the rows' share of the coarse part of r^T z into *dotSlot.  All threads of the
+  // workgroup call it.  w: the first batch of the first row walk when preloaded.
+  auto denseRows = [&](int g, int r0, int nR, const double* qcs, double* psum, bool on0, double2 (&w)[kDenseLoads], bool preloaded,
+                       double* dotSlot) {
+    const int per = nThreads / nR, m = tid / per, part = tid - m * per;
+    const bool active = m < nR;
+    const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g) * kCB + r0 + (active ? m : 0)) * nC);
+    const int e = g * kCB + r0 + (tid < nR ? tid : 0);
+    const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
+    const bool on = on0 && ds.modeActive[e];
+    double acc0 = 0.0, acc1 = 0.0;
+    // the row in BATCHES of kDenseLoads loads per thread, every batch's loads issued together
+    for (int base = 0; base < n2; base += kDenseLoads * per) {
+      if (!preloaded || base > 0) {
+#pragma unroll
+        for (int u = 0; u < kDenseLoads; ++u) {
+          const int j = base + part + u * per;
+          w[u] = row[j < n2 ? j : 0];
+          if (j >= n2 || !active) w[u] = make_double2(0.0, 0.0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kDenseLoads; ++u) {
+        const int j = base + part + u * per;
+        const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * (j < n2 ? j : 0));
+        acc0 += w[u].x * qq.x;
+        acc1 += w[u].y * qq.y;
+      }
+    }
+    psum[tid] = active ? acc0 + acc1 : 0.0;
+    __syncthreads();
+    if (tid < nR * 8) {  // 8 lanes per row fold its `per` partials, then three shuffle steps
+      const int r = tid >> 3, l = tid & 7;
+      double t = 0.0;
+      for (int k = l; k < per; k += 8) t += psum[r * per + k];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if (l == 0) psum[nThreads + r] = t;
+    }
+    __syncthreads();
+    if (tid < 8) {  // (8 lanes shuffle together; rows beyond nR contribute nothing)
+      double t = 0.0;
+      if (tid < nR) {
+        const double d = psum[nThreads + tid];
+        const double rcn = rcOld - alpha * qcv;
+        const double cn = on ? cOld - alpha * d : 0.0;
+        ds.rc[e] = rcn;
+        ds.c[e] = cn;
+        t = cn * rcn;
+      }
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if (tid == 0) publishPartial(dotSlot, t);
+    }
+    __syncthreads();  // (psum is reused)
+  };
+  if (f >= L.F) {
+    // ---- dense-level workgroup: rows [0, rowSplit) of kDenseFramesPerGroup frames, one frame after the other (F + F / 2
+    // workgroups of 768 threads still fit the device in ONE round, two per CU; F + F do not)
+    const int nR = ds.rowSplit;
+    double* qcs = sm;                       // nC doubles (the frame workgroups' layout is not used here)
+    double* psum = sm + nC;                 // nThreads partial sums + 8 row sums
     const int g0 = f0 + (f - L.F) * kDenseFramesPerGroup;
     double2 w[kDenseLoads];
     {
-      const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + m) * n);
+      const int per = nThreads / nR, m = tid / per, part = tid - m * per;
+      const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g0) * kCB + (m < nR ? m : 0)) * nC);
 #pragma unroll
       for (int u = 0; u < kDenseLoads; ++u) {
         const int j = part + u * per;
         w[u] = row[j < n2 ? j : 0];
-        if (j >= n2) w[u] = make_double2(0.0, 0.0);
+        if (j >= n2 || m >= nR) w[u] = make_double2(0.0, 0.0);
       }
     }
     if constexpr (FUSED) {  // (the first batch of the inverse's row is in flight across the grid barrier)
       if (!mid.second(alpha)) return;
-      for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = readPartial(ds.qc + i);  // (published by the finish halves)
+      for (int i = tid; i < static_cast<int>(nC); i += nThreads) qcs[i] = readPartial(ds.qc + i);  // (published by the finish halves)
     } else {
-      for (int i = tid; i < static_cast<int>(n); i += nThreads) qcs[i] = ds.qc[i];
+      for (int i = tid; i < static_cast<int>(nC); i += nThreads) qcs[i] = ds.qc[i];
     }
     const bool on0 = *ds.fail == 0;
     __syncthreads();
@@ -1916,56 +1973,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     for (int rep = 0; rep < kDenseFramesPerGroup; ++rep) {
       const int g = g0 + rep;
       if (g >= f0 + nF) break;
-      const double2* row = reinterpret_cast<const double2*>(ds.Ainv + (static_cast<size_t>(g) * kCB + m) * n);
-      const int e = g * kCB + (tid < kCB ? tid : 0);
-      const double qcv = qcs[e], rcOld = ds.rc[e], cOld = ds.c[e];
-      const bool on = on0 && ds.modeActive[e];
-      double acc0 = 0.0, acc1 = 0.0;
-      // the row in BATCHES of kDenseLoads loads per thread, every batch's loads issued together (a thread walks 12.5 pairs
-      // of a 2400-wide row: three round trips; a load-use loop over the part beyond the first batch was seven)
-      for (int base = 0; base < n2; base += kDenseLoads * per) {
-        if (rep > 0 || base > 0) {  // (the first batch of the first frame was requested before the barrier)
-#pragma unroll
-          for (int u = 0; u < kDenseLoads; ++u) {
-            const int j = base + part + u * per;
-            w[u] = row[j < n2 ? j : 0];
-            if (j >= n2) w[u] = make_double2(0.0, 0.0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kDenseLoads; ++u) {
-          const int j = base + part + u * per;
-          const double2 qq = *reinterpret_cast<const double2*>(qcs + 2 * (j < n2 ? j : 0));
-          acc0 += w[u].x * qq.x;
-          acc1 += w[u].y * qq.y;
-        }
-      }
-      const double acc = acc0 + acc1;
-      psum[tid] = acc;
-      __syncthreads();
-      if (tid < kCB * 8) {  // 8 lanes per row fold its `per` partials, then three shuffle steps
-        const int r = tid >> 3, l = tid & 7;
-        double t = 0.0;
-        for (int k = l; k < per; k += 8) t += psum[r * per + k];
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        if (l == 0) psum[nThreads + r] = t;
-      }
-      __syncthreads();
-      if (tid < kCB) {
-        const double d = psum[nThreads + tid];
-        const double rcn = rcOld - alpha * qcv;
-        const double cn = on ? cOld - alpha * d : 0.0;
-        ds.rc[e] = rcn;
-        ds.c[e] = cn;
-        double t = cn * rcn;
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        if (tid == 0) publishPartial(ds.dotPart + g, t);
-      }
-      __syncthreads();  // (psum is reused by the next frame)
+      denseRows(g, 0, nR, qcs, psum, on0, w, rep == 0, ds.dotPart + g);
     }
   } else {
   // B <= 256: the thread's share of the f32 block M_f^-1 (see the mat-vec below) is requested FIRST -- it depends on nothing
@@ -2155,6 +2163,20 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
       publishPartial(cs.fdotY + f, t);
     }
   }
+  if (fusedDense && ds.rowSplit < kCB) {
+    // ---- this frame's rows [rowSplit, 8) of the dense coarse level (DenseStep::rowSplit), in an LDS region of their own
+    double* qcs = sm + ds.ldsPsum;
+    double* psum = qcs + nC;
+    if constexpr (FUSED) {
+      for (int i = tid; i < static_cast<int>(nC); i += nThreads) qcs[i] = readPartial(ds.qc + i);  // (published by the finish halves)
+    } else {
+      for (int i = tid; i < static_cast<int>(nC); i += nThreads) qcs[i] = ds.qc[i];
+    }
+    const bool on0 = *ds.fail == 0;
+    __syncthreads();
+    double2 w[kDenseLoads];
+    denseRows(f, ds.rowSplit, kCB - ds.rowSplit, qcs, psum, on0, w, false, ds.dotPart2 + f);
+  }
   }  // frame workgroups
   // last workgroup: rz_new = sum, beta = rz_new / rz_old (device-side scalars, no host round trip)
   if (lastBlockArrivesLite(counter, gridDim.x, reinterpret_cast<int*>(red + 40))) {
@@ -2163,7 +2185,8 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
       a += readPartial(fdotRZ + k);
       b += readPartial(fdotRR + k);
       if (fusedY) cY += readPartial(cs.fdotY + k);
-      if (fusedDense) cY += readPartial(ds.dotPart + k);
+      if (fusedDense && ds.rowSplit > 0) cY += readPartial(ds.dotPart + k);
+      if (fusedDense && ds.rowSplit < kCB) cY += readPartial(ds.dotPart2 + k);
     }
     a = waveSum(a);
     b = waveSum(b);

@@ -205,12 +205,14 @@ bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish
   const int F = c.L.F, B = c.L.B;
   if (!h->opt.pcg_fused_tail || h->dist() || B > 256 || h->forceGeneric) return false;
   if (coarse && !h->coarse.denseMode) return false;
-  const int grid = F + (coarse ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
+  const int split = denseRowSplit(h);
+  const int grid = F + (coarse && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
   const int update = B + cgUpdatePartDoubles(B, nThreads) + 48 + 17 * kCB;  // k_cg_update's region (cvd_solve.hip: ldsU)
   const int finish = 3 * B + 8 + kCB + (nThreads / 256 - 1) * 256;          // k_matvec_finish's + the partial sums of its row walk
   const int denseEnd = coarse ? F * kCB + nThreads + 16 : 0;                // the dense-level workgroups' (Z^T q + partial sums)
   ldsFinish = update;
-  ldsScratch = std::max(update + finish, denseEnd);
+  // (frame workgroups that walk rows of the dense level themselves: Z^T q + partial sums behind their two regions)
+  ldsScratch = std::max(update + finish + (coarse && split < kCB ? denseEnd : 0), denseEnd);
   lds = static_cast<size_t>(ldsScratch + 24) * sizeof(double);
   if (lds > kMaxLds) return false;
   // occupancy of this (kernel, block size, LDS size) on this device: asked once
@@ -240,13 +242,16 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
   hipStream_t s = h->stream;
   const int F = c.L.F;
   const CoarseView cF = coarseView(h, withCoarse, false);
+  const int split = denseRowSplit(h);
+  const int finishDoubles = 3 * static_cast<int>(c.L.B) + 8 + kCB + (nThreads / 256 - 1) * 256;  // (pcgTailScope)
   const DenseStep ds = withCoarse ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p,
-                                               h->coarse.modeActive.p, h->coarse.fail.p}
-                                  : DenseStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                                               h->coarse.modeActive.p, h->coarse.fail.p, split, ldsFinish + finishDoubles,
+                                               h->coarse.dotPart.p + F}
+                                  : DenseStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kCB, 0, nullptr};
   double* fd = h->dFdot.p;
   const TailUpdate U{h->dMinv.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, h->coarse.modeActive.p, h->hPcg,
                      h->dCounters.p + 1, h->dTailBar.p, h->dFdot.p + 4 * static_cast<size_t>(F) + 32, ldsFinish, ldsScratch, ds};
-  const int grid = F + (withCoarse ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
+  const int grid = F + (withCoarse && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0);
   const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)
   {
     // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate)

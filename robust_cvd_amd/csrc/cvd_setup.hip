@@ -618,7 +618,7 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
   C.fdotY.ensure(F);
   C.y.ensure(n);
   C.c.ensure(static_cast<size_t>(h->framesPadded()) * kCB);  // (all-gathered in place by the owner-sharded PCG iteration)
-  C.dotPart.ensure(static_cast<size_t>(F));
+  C.dotPart.ensure(static_cast<size_t>(F) * 2);  // (dense level: the dense-level workgroups' rows' shares, then the frame workgroups')
   C.modeActive.ensure(n);
   C.fail.ensure(1);
   HIP_CHECK(hipStreamSynchronize(s));

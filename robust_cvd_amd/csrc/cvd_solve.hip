@@ -48,16 +48,24 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
                               ? CoarseStep{h->coarse.wtPtr.p, h->coarse.wtBlk.p, h->coarse.wtFrame.p, h->coarse.Wb.p,
                                            h->coarse.qc.p, h->coarse.y.p, h->coarse.fdotY.p, h->coarse.fail.p, h->coarse.wq.p}
                               : csOff;
-  const DenseStep dsOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const DenseStep dsOff{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kCB, 0, nullptr};
   // dense level: c <- c - alpha A_c^-1 Z^T q inside k_cg_update (F extra workgroups) instead of a launch of its own
   const bool denseFused = denseCoarse;
   // pair-sharded mode with the fused exchange (cvd_matvec.hip): Z^T q and p.q arrive all-reduced behind q
   const bool fusedX = h->dist() && fusedExchange(h, coarse);
   const double* pqReduced = fusedX ? h->dQ.p + exchangeOffsetPq(c, denseFused) : nullptr;
   const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + exchangeOffsetQc(c) : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
-                                                h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p}
+                                                h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p,
+                                                // (two launches: the split costs 2 % -- the frame workgroups are this kernel's long
+                                                // pole already; it pays in k_pcg_tail, whose DenseStep launchPcgTail builds)
+                                                kCB, static_cast<int>(ldsU / 8), h->coarse.dotPart.p + F}
                                     : dsOff;
-  if (denseFused) ldsU = std::max(ldsU, (static_cast<size_t>(F) * kCB + nThreads + 16) * 8);  // (its workgroups: Z^T q + partial sums)
+  if (denseFused) {
+    // (dense-level workgroups: Z^T q + partial sums; frame workgroups walking rows of their own: the same again behind their region)
+    const size_t dense = static_cast<size_t>(F) * kCB + nThreads + 16;
+    ldsU = std::max((dsOn.rowSplit < kCB ? ldsU / 8 + dense : ldsU / 8), dense) * 8;
+  }
+  allowLds(k_cg_update, ldsU);
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
                      h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr), 0, F,
@@ -100,7 +108,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       const int f0 = h->ownFirst(), nOwn = h->ownCount();
       const int slotO = h->tBegin(KC_CG_UPDATE);
       if (nOwn > 0)
-        hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn),
+        hipLaunchKernelGGL(k_cg_update, dim3(denseFused && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn),
                            dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, h->dScal.p, h->dCounters.p + 1,
                            h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, static_cast<double*>(nullptr),
                            h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank);
@@ -122,7 +130,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       return;
     }
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(denseFused ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+    hipLaunchKernelGGL(k_cg_update, dim3(denseFused && dsOn.rowSplit > 0 ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
                        (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced,
                        0, F, static_cast<double*>(nullptr));

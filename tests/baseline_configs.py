@@ -32,7 +32,7 @@ CONFIGS = {
     # 10.4 M constraints, default pipeline with the 16x12 grid as its last level (B = 199); the sparsified coarse level
     "config4": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12)),
     "config4_huber": dict(frames=1000, width=640, height=384, seed=1237, ctf=(16, 12), robust=1),
-    # DENSE mode at real resolution (matchSeparation = 0: every masked pixel of every directed pair, 13.3 M constraints): the
+    # DENSE mode at real resolution (matchSeparation = 0: every masked pixel of every directed pair, 12.8 M constraints): the
     # HIP path reads the flow / mask images, the oracle the equivalent constraint list
     "dense30": dict(frames=30, width=384, height=224, seed=1240, dense=True),
 }

@@ -160,14 +160,14 @@ def test_dense_mode_rejects_configurations_outside_its_scope(Solver):
 
 def test_dense_mode_at_real_resolution_matches_the_oracle(Solver):
     """Dense mode at the resolution of BASELINE.json configs[2] (VERDICT r3 Weak #2c: every other oracle comparison of this
-    mode is at 96x56): 30 frames 384x224, 156 directed pairs, 13.3 M pixel constraints.  (a) cost / gradient / every H_ff block
+    mode is at 96x56): 30 frames 384x224, 156 directed pairs, 12.8 M pixel constraints.  (a) cost / gradient / every H_ff block
     on the final 17x10 grid at a state away from the minimum against the oracle's evaluation of the equivalent
     matchSeparation = 0 list, 1e-9; (b) the end state of the default pipeline (explicit cross blocks, default solver options)
     against the oracle's committed exact-Cholesky solution (tests/golden/solutions/dense30.npz), the 1e-3 bar."""
     from tests import baseline_configs as bc
     video = bc.make_video("dense30")
     flow, mask, off, loc = bc.dense_inputs(video)
-    assert int(off[-1]) > 13_000_000
+    assert int(off[-1]) > 12_500_000
     p = bc.params_for("dense30", threads=12)
     F = video.num_frames
     rng = np.random.default_rng(21)
