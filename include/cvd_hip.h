@@ -70,10 +70,13 @@ typedef struct cvd_solver_options {
   int32_t constraint_order;       /* 1 (default): every pair's slice of the constraint table is re-ordered as a sweep over the
                                      cells of the depth grid (consecutive lanes of a wave hit different grid vertices: the
                                      LDS atomics of the pair-major kernels stop serialising); 0: the caller's order */
-  int32_t coarse_rebuild_excess_dense; /* the same threshold for the DENSE coarse level (default 32): its rebuild is one
-                                     in-line 1.6 ms kernel (300 frames) = 22 PCG iterations, not a side-stream job, and the
-                                     PCG counts of an LM run grow by themselves as the trust region opens -- at 16 the level
-                                     was rebuilt every second LM iteration for 0.6 fewer PCG iterations per LM iteration */
+  int32_t coarse_rebuild_excess_dense; /* the same threshold for the DENSE coarse level, whose rebuild is one in-line kernel chain
+                                     (1.9 ms at 300 frames), not a side-stream job.  0 (default): 1.5 x the cost ratio MEASURED on
+                                     this handle (duration of a rebuild / duration of a PCG iteration of the running solves), in
+                                     steps of 8 -- 32 at 300 frames; the PCG counts of an LM run grow by themselves as the trust
+                                     region opens, and at the bare ratio (22) the level was rebuilt every second LM iteration for
+                                     0.6 fewer PCG iterations per LM iteration.  Sharded runs (every rank must decide alike) and
+                                     the first solves of a handle use 32.  > 0: that many */
   int32_t pcg_fused_tail;         /* 1 (default): the two per-frame kernels of a PCG iteration (finish of the product, update) run
                                      as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
@@ -104,9 +107,11 @@ int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
 
 /* ---- multi-GPU: one process per GPU, frame pairs sharded across ranks ---------------------
  * Every rank holds all frames (depth, parameters) but only ITS pairs (cvd_set_pair_constraints with the shard);
- * the regularisers of frame f belong to rank f % world.  The library all-reduces [g | H_ff | cost] once per
- * Jacobian evaluation and q once per PCG product over RCCL on its own stream.  The reference has no
- * counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
+ * the regularisers of frame f belong to rank f % world; frames are OWNED in contiguous chunks of ceil(F / world).  Per
+ * Jacobian evaluation the library all-reduces g and the per-frame costs, reduce-scatters H_ff to the frames' owners and
+ * all-gathers diag(H) and the owners' f32 block inverses; per PCG iteration it reduce-scatters q to the owners (with
+ * [Z^T q | p.q] all-reduced in the same group), updates the owners' frames and all-gathers z / c / the r^T z shares -- two
+ * grouped collectives over RCCL on the solver's stream.  The reference has no counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
 void cvd_comm_unique_id(uint8_t* out128);
 int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
 /* Test backend of the exchange layer: the `world` ranks are handles of THIS process on ONE device, each driven by its
@@ -147,7 +152,6 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t
  * list (cvd_set_pair_constraints switches back).  Supported for the default residual configuration (cvd_last_error says
  * which otherwise). */
 int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* flow, const uint8_t* mask);
-/* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
 /* 1 when a problem with these parameters / transform descriptors lies within the scope of the dense mode (identity spatial
  * transform, a reprojection loss, Scale value transform, Global or bilinear grid, per-frame or fixed intrinsics, no
  * smoothness triplets, frame block <= 256); 0: hand the constraints over as a list (cvd_set_pair_constraints) --
@@ -155,6 +159,7 @@ int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair
  * What lib_python's FlowConstraintsCollection asks before it keeps a matchSeparation = 0 collection as images. */
 int32_t cvd_dense_mode_supported(const cvd_opt_params* params, const cvd_xform_desc* depth, const cvd_xform_desc* spatial,
                                  int32_t have_triplets, int32_t world_size, int32_t problem);
+/* Triplet constraints (reference lib/FlowConstraints.h:109-111), keyed by centre frame; loc6[6*C]. */
 int32_t cvd_set_triplet_constraints(cvd_handle* h, int32_t num_triplets, const int32_t* centers,
                                     const int64_t* offsets, const float* loc6, const uint8_t* is_static);
 /* Dynamic masks of all frames, masks[F][height][width] u8 (the `dynamic_mask` colour stream; NULL forgets them):

@@ -7,6 +7,7 @@ library is missing, or no GPU is usable, construction raises.
 """
 import ctypes as C
 import os
+import sys
 
 from . import build as _build
 from .binding import Binding
@@ -41,14 +42,18 @@ class SolverOptions(C.Structure):
     ]
 
 
-def load_library():
-    """dlopen the in-tree libcvd_hip.so. Raises ImportError (never falls back) when it is not built."""
+def load_library(variant=None):
+    """dlopen the in-tree libcvd_hip.so. Raises ImportError (never falls back) when it is not built.  Nothing is read from the
+    environment.  `variant` (development tools only, before anything else loaded the library): a profile build
+    lib/libcvd_hip_<variant>.so made by robust_cvd_amd.build.build_variant; the chosen path is reported on stderr."""
     global _lib
+    if _lib is not None and variant:
+        raise RuntimeError("load_library(variant=...) must be the first load of the library in the process")
     if _lib is None:
         path = _build.LIB
-        variant = os.environ.get("CVD_LIB_VARIANT")  # development: a profile build (robust_cvd_amd.build.build_variant)
         if variant:
             path = os.path.join(os.path.dirname(path), f"libcvd_hip_{variant}.so")
+            sys.stderr.write(f"[robust_cvd_amd] loading the development variant {path}\n")
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -50,7 +50,7 @@ def _compile(unit, hipcc, verbose):
 
 def build_variant(name, defines, units=None, verbose=False):
     """Development: a second library lib/libcvd_hip_<name>.so with extra -D defines (profile stamps) in the given units; the other
-    units' objects are shared with the product build.  tools/ load it through CVD_LIB_VARIANT=<name>."""
+    units' objects are shared with the product build.  tools/ load it with api.load_library(variant=<name>)."""
     from concurrent.futures import ThreadPoolExecutor
     build(verbose=verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

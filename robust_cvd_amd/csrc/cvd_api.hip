@@ -230,7 +230,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_update_budget = 40000;
   o->coarse_dense_shift = 1e-5;
   o->constraint_order = 1;
-  o->coarse_rebuild_excess_dense = 32;
+  o->coarse_rebuild_excess_dense = 0;
   o->pcg_fused_tail = 1;
   o->coarse_dense_row_split = 5;
   o->dist_owner_update = 1;

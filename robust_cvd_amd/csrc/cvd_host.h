@@ -318,6 +318,10 @@ struct cvd_handle_t {
     CoarsePlan plan{};
   } coarse;
   bool coarseOn = false;  // this solve uses the coarse level
+  // measured on this handle (cvd_solve.hip: denseRebuildThreshold): an in-line rebuild of the dense coarse level and a PCG iteration
+  hipEvent_t evRebuild[2] = {nullptr, nullptr};
+  bool rebuildTimed = false;
+  double coarseRebuildMs = 0.0, pcgIterMs = 0.0;
   // frame-pair graph of the WHOLE problem (cvd_set_pair_graph): in the pair-sharded multi-GPU mode every rank must
   // build the same elimination plan although it only holds its own pairs
   std::vector<std::pair<int, int>> globalEdges;
@@ -363,6 +367,7 @@ struct cvd_handle_t {
     for (auto& p : hStage) if (p) (void)hipHostFree(p);
     if (hPcg) (void)hipHostFree(hPcg);
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
+    for (auto& e : evRebuild) if (e) (void)hipEventDestroy(e);
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
     if (stream2) (void)hipStreamDestroy(stream2);

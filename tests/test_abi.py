@@ -56,7 +56,7 @@ def test_default_solver_options():
     o = api.SolverOptions()
     lib.cvd_solver_options_default(C.byref(o))
     assert o.pcg_relative_tolerance == 1e-3 and o.pcg_max_iterations == 300 and o.coarse_level == 1 and o.robust_loss == 0
-    assert o.coarse_rebuild_excess == 16 and o.coarse_rebuild_excess_dense == 32
+    assert o.coarse_rebuild_excess == 16 and o.coarse_rebuild_excess_dense == 0   # (0 = measured on the handle)
     assert o.coarse_dense_max_unknowns == 4096 and o.coarse_update_budget == 40000 and o.coarse_dense_shift == 1e-5
     assert o.constraint_order == 1
     assert (o.force_sharded_path, o.dense_matrix_free, o.block_inverse_variant, o.pcg_lockstep, o.force_iterations, o.verbose) == (0,) * 6
@@ -83,3 +83,25 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(src), f"{f} references the oracle"
+
+
+@pytest.mark.gpu
+def test_solver_options_are_validated():
+    """cvd_set_solver_options copies the struct whole: a caller built against another revision of the header (struct_size) and
+    values no code path is defined for are refused before anything is stored."""
+    s = api.Solver(0)
+    lib = api.load_library()
+    o = api.SolverOptions()
+    lib.cvd_solver_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(api.SolverOptions)
+    assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) == 0
+    o.struct_size -= 8
+    assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) != 0
+    assert b"struct_size" in lib.cvd_last_error(C.c_void_p(s._h))
+    for field, bad in (("pcg_relative_tolerance", 0.0), ("pcg_relative_tolerance", float("nan")), ("pcg_max_iterations", 0),
+                       ("coarse_dense_shift", -1.0), ("coarse_rebuild_excess", -1), ("coarse_dense_max_unknowns", 1 << 20),
+                       ("coarse_level", 3), ("coarse_dense_row_split", 9)):
+        lib.cvd_solver_options_default(C.byref(o))
+        setattr(o, field, bad)
+        assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) != 0, field
+    s.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid (GPU): where a workgroup of the hot product k_matvec_pairs_fast spends its life.
 Library variant with wall-clock stamps (100 MHz):  python -c "from robust_cvd_amd import build; build.build_variant('mvprof', ['CVD_MV_PROFILE'], ['cvd_matvec'])"
-then  CVD_LIB_VARIANT=mvprof python tools/mv_profile.py [pairs_level]"""
+then  python tools/mv_profile.py [pairs_level]"""
 import ctypes as C
 import os
 import sys
@@ -9,8 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 torch.cuda.init()
-import bench
 from robust_cvd_amd import api, synth
+api.load_library(variant="mvprof")  # (before bench / Solver load the product library)
+import bench
 from robust_cvd_amd.ctypes_types import OptParams
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 6

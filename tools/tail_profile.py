@@ -2,7 +2,7 @@
 """Development aid (GPU): where the workgroups of k_pcg_tail (finish + update of a PCG iteration in one launch) spend their life.
 Library variant with wall-clock stamps (100 MHz):
     python -c "from robust_cvd_amd import build; build.build_variant('tailprof', ['CVD_TAIL_PROFILE'], ['cvd_matvec'])"
-then  CVD_LIB_VARIANT=tailprof python tools/tail_profile.py [pairs_level]"""
+then  python tools/tail_profile.py [pairs_level]"""
 import ctypes as C
 import os
 import sys
@@ -10,8 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 torch.cuda.init()
-import bench
 from robust_cvd_amd import api, synth
+api.load_library(variant="tailprof")  # (before bench / Solver load the product library)
+import bench
 from robust_cvd_amd.ctypes_types import OptParams
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 6
