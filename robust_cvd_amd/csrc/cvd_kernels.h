@@ -2278,7 +2278,7 @@ constexpr int kTailBarStride = 1024;  // unsigned ints: 4 KB
 // until tailWait: neither round trip sits between the finish half and the operand requests)
 __device__ __forceinline__ unsigned int tailGeneration(const unsigned int* bar) {
   if (threadIdx.x != 0) return 0u;
-  return __hip_atomic_load(bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *reinterpret_cast<const volatile unsigned int*>(bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1))));
 }
 __device__ __forceinline__ unsigned int tailArrive(unsigned int* bar) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its published payload has landed
@@ -2286,9 +2286,13 @@ __device__ __forceinline__ unsigned int tailArrive(unsigned int* bar) {
   if (threadIdx.x != 0) return 0u;
   return __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The release word of a copy is a 16-byte RECORD {generation, sum (2 words), generation}, written with ONE 16-byte store and read
+// with one 16-byte load: the sum travels with the flag, so the last arriver neither publishes it separately nor drains that store
+// before releasing (2.5 us of the 7 between the last arrival and the release).  A reader accepts a record whose two generation
+// words agree (a 16-byte access of one lane is one transaction; the second word guards against a torn one anyway).
+typedef unsigned int cvd_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups, unsigned int gen, unsigned int ticket,
-                                         const double* __restrict__ parts, int nParts, double* __restrict__ result,
-                                         double* __restrict__ scratch, double& sum) {
+                                         const double* __restrict__ parts, int nParts, double* __restrict__ scratch, double& sum) {
   int* role = reinterpret_cast<int*>(scratch + 16);
   if (threadIdx.x == 0) {
     *role = (ticket == nGroups - 1) ? 2 : 1;
@@ -2298,21 +2302,26 @@ __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups
   gen = *reinterpret_cast<unsigned int*>(scratch + 17);
   if (*role == 2) {
     const double v = blockSumPartials(parts, nParts, scratch);
-    if (threadIdx.x == 0) {
-      publishPartial(result, v);
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sum has landed before anybody is released
+    if (threadIdx.x == 0) __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kTailBarCopies) {
+      cvd_u32x4 rec;
+      rec.x = gen + 1u;
+      rec.y = static_cast<unsigned int>(__double2loint(v));
+      rec.z = static_cast<unsigned int>(__double2hiint(v));
+      rec.w = gen + 1u;
+      *reinterpret_cast<volatile cvd_u32x4*>(bar + kTailBarStride * (1 + threadIdx.x)) = rec;
     }
-    if (threadIdx.x < kTailBarCopies)
-      __hip_atomic_store(bar + kTailBarStride * (1 + threadIdx.x), gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sum = v;
     return true;
   }
   if (threadIdx.x == 0) {
-    const unsigned int* mine = bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1)));
+    const volatile cvd_u32x4* mine = reinterpret_cast<const volatile cvd_u32x4*>(bar + kTailBarStride * (1 + (blockIdx.x & (kTailBarCopies - 1))));
     int ok = 1;
     unsigned int spins = 0;
-    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+    cvd_u32x4 rec;
+    for (;;) {
+      rec = *mine;
+      if (rec.x == gen + 1u && rec.w == gen + 1u) break;
       __builtin_amdgcn_s_sleep(16);
       ++spins;
       if ((spins & 63u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
@@ -2322,7 +2331,7 @@ __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups
         break;
       }
     }
-    scratch[18] = ok ? readPartial(result) : 0.0;
+    scratch[18] = ok ? __hiloint2double(static_cast<int>(rec.z), static_cast<int>(rec.y)) : 0.0;
     *role = ok;
   }
   __syncthreads();
@@ -2394,7 +2403,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
   auto second = [&](double& alpha) -> bool {
     double pq;
     TAIL_STAMP(2);
-    if (!tailWait(U.gridBar, gridDim.x, barGen, barTicket, fdot, L.F, U.pqSlot, sm + U.ldsScratch, pq)) return false;
+    if (!tailWait(U.gridBar, gridDim.x, barGen, barTicket, fdot, L.F, sm + U.ldsScratch, pq)) return false;
     TAIL_STAMP(3);
     // (S_RZ is rewritten only by the last workgroup to take the update half's ticket, i.e. after every workgroup has read it)
     alpha = scal[S_RZ] / pq;

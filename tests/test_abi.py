@@ -94,14 +94,14 @@ def test_solver_options_are_validated():
     o = api.SolverOptions()
     lib.cvd_solver_options_default(C.byref(o))
     assert o.struct_size == C.sizeof(api.SolverOptions)
-    assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) == 0
+    assert lib.cvd_set_solver_options(s._h, C.byref(o)) == 0
     o.struct_size -= 8
-    assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) != 0
-    assert b"struct_size" in lib.cvd_last_error(C.c_void_p(s._h))
+    assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0
+    assert b"struct_size" in lib.cvd_last_error(s._h)
     for field, bad in (("pcg_relative_tolerance", 0.0), ("pcg_relative_tolerance", float("nan")), ("pcg_max_iterations", 0),
                        ("coarse_dense_shift", -1.0), ("coarse_rebuild_excess", -1), ("coarse_dense_max_unknowns", 1 << 20),
                        ("coarse_level", 3), ("coarse_dense_row_split", 9)):
         lib.cvd_solver_options_default(C.byref(o))
         setattr(o, field, bad)
-        assert lib.cvd_set_solver_options(C.c_void_p(s._h), C.byref(o)) != 0, field
+        assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0, field
     s.close()
