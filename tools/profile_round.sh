@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's committed evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC traffic passes, SQ counters.
 # usage (through gpurun): bash tools/profile_round.sh <tag>       (copy the summaries from gpurun_out/<tag> into profiles/)
-TAG=${1:-r03a}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -16,7 +16,7 @@ CMD_MAIN="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary
 $B --steps 20 --warmup 3 --time-all-kernels > $OUT/bench_allkernels.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 20 --warmup 3 --no-kernel-timing > $OUT/trace.log 2>&1
 # SQ counters of the PCG kernels and the dense inverse (wave cycles: parked / issue-stalled / active; VALU and LDS activity)
-K="k_matvec_pairs_fast|k_cg_update|k_matvec_finish|k_dense_spd_inverse"
+K="k_matvec_pairs_fast|k_pcg_tail|k_cg_update|k_matvec_finish|k_dense_spd_inverse"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_a -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_sq_a.log 2>&1
 # BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 300 frames)
 python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
@@ -31,6 +31,11 @@ rm -rf $OUT/trace_dense
 [ -x $R/tools/dinv_bench.bin ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Wno-cuda-compat -I$R/include -I$R/robust_cvd_amd/csrc $R/tools/dinv_bench.hip -o $R/tools/dinv_bench.bin
 for n in 1000 2400 4096; do timeout 100 $R/tools/dinv_bench.bin $n >> $OUT/dinv_bench.log 2>&1; done
 timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
+timeout 200 python $R/tools/shard_sim.py 8 --replicated 2>/dev/null | grep "^world" >> $OUT/shard_sim.log
+# where the workgroups of the fused PCG tail kernel spend their life (stamp variant of the library, built before the call)
+[ -f $R/robust_cvd_amd/lib/libcvd_hip_tailprof.so ] && timeout 200 python $R/tools/tail_profile.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/tail_profile.log
+# the two-launch tail for comparison (cvd_solver_options::pcg_fused_tail = 0)
+$B --steps 20 --warmup 3 --time-all-kernels --opt pcg_fused_tail=0 > $OUT/bench_allkernels_two_launch_tail.json 2>> $OUT/bench.err
 timeout 200 python $R/tools/dense_coarse_probe.py 4 0 2>/dev/null | cut -c1-120 > $OUT/dense_coarse_probe.log
 # summaries (small, committed under profiles/)
 python $R/tools/kernel_durations.py $OUT/trace $TAG "$CMD_MAIN" > $OUT/kernel_durations.txt 2>&1

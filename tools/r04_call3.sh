@@ -1,5 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04c; mkdir -p $OUT; cd $R
-timeout 300 python tools/tail_profile.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|development variant" | tee $OUT/tail_profile.log
-timeout 300 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3 2>> $OUT/bench.err | python tools/bench_line.py
-timeout 600 python -m pytest -q -m gpu -x tests/test_gpu_parity.py -k "fused_pcg_tail" tests/test_abi.py 2>&1 | tail -2
+for o in 1 0; do
+echo "== finish_in_product $o"; timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 --time-all-kernels --opt pcg_finish_in_product=$o 2>> $OUT/bench.err | tee $OUT/bfp$o.json | python tools/bench_line.py
+python -c "
+import json; d=json.loads(open('$OUT/bfp$o.json').read().strip().splitlines()[-1]); print(d['kernels_avg_ms']); print('secondary', d['secondary_1766_pairs']['value'], d['secondary_1766_pairs']['pcg_iterations_per_lm_iteration'])"
+done
+timeout 900 python -m pytest -q -m gpu -x tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -k "not config4" 2>&1 | tail -4
