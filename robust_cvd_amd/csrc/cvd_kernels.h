@@ -239,6 +239,12 @@ __device__ __forceinline__ bool lastBlockArrives(unsigned int* counter, unsigned
 // them (s_waitcnt vmcnt(0)) before the workgroup's ticket, and the last workgroup reads them back with agent-scope loads
 // (readPartial) -- cdna_hip_programming.md G16 recipe R1.  The release fence of lastBlockArrives is a buffer_wbl2 of the
 // XCD's whole L2 in EVERY workgroup and the acquire an invalidate, although nothing but the partials crosses workgroups.
+// The protocol leans on the gfx942 / gfx950 memory system (agent-scope relaxed atomics are write-through / L2-coherent accesses,
+// s_waitcnt vmcnt(0) drains them, workgroups of one launch are ordered by the ticket's data dependency) rather than on the HIP
+// memory model's release / acquire edges: this library is built for gfx950 only, and says so.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the fence-free inter-workgroup hand-off (publishPartial / readPartial / lastBlockArrivesLite) is written for gfx942 / gfx950"
+#endif
 __device__ __forceinline__ void publishPartial(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
