@@ -508,6 +508,12 @@ def main():
                                  "diag(H) and the f32 block inverses; per PCG product: all-reduce q (rank 0's timings)"}} if shard else {}),
             "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["ktimes"].items()},
             "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
+            "kernels_note": ("HIP events on a uniform sample of every class's launches (every --time-every-th); matvec_pairs: the "
+                             "kernel's own start / stop stamps, the other classes: event pairs around the launch (dispatch gap "
+                             "included).  With the fused PCG tail (k_pcg_tail: finish + update in one launch, the default where its "
+                             "scope allows) the finish class is empty and cg_update is the fused kernel; block_inverse includes the "
+                             "in-line rebuilds of the coarse level; SURVEY 8(d)'s split per LM iteration = evaluate_assemble + "
+                             "block_inverse + pcg_iterations_per_lm_iteration x (matvec_pairs + matvec_finish + cg_update) + cost"),
             "last_timed_solve": {k: m["summ"][k] for k in ("num_iterations", "num_successful_steps", "total_linear_iterations",
                                                            "initial_cost", "final_cost", "termination")},
             # every solve builds its coarse level in line (one persistent kernel) and carries nothing over from the solve before:

@@ -23,7 +23,7 @@ def test_pmc_traffic_file_was_measured_on_these_kernel_sources():
 
 
 def test_committed_bench_lines_follow_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]*_bench.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[234]*_bench.json")))
     assert lines, "no bench line under profiles/"
     d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
