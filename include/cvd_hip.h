@@ -88,6 +88,14 @@ typedef struct cvd_solver_options {
                                      frames' OWNER ranks only -- q reduce-scattered to the owners, z / c / the r^T z shares all-gathered
                                      (two grouped collectives per iteration); 0: q all-reduced and the update replicated on every
                                      rank (one collective per iteration; rounds 2-3) */
+  int32_t temporal_level;         /* third level of the preconditioner (cvd_temporal.h): temporal hat functions (one node every
+                                     temporal_step frames) x bilinear hats of a coarse grid on the depth grid, its Galerkin matrix
+                                     inverted densely, applied inside the PCG launches.  0: off; 1: rebuilt together with the dense
+                                     pose-graph level; 2: rebuilt every LM iteration.  Scope: one GPU, list mode, bilinear
+                                     one-parameter depth grid, dense pose-graph level in use; elsewhere the option is ignored */
+  int32_t temporal_step;          /* frames between two temporal nodes (default 32) */
+  int32_t temporal_grid_x;        /* coarse hats per axis; 0 (default): (grid + 1) / 2 */
+  int32_t temporal_grid_y;
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -306,6 +314,11 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
  * symmetric); inverse = n x n f64; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
 int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, double* inverse, int32_t* failed);
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
+/* Test hook for the third level of the preconditioner (cvd_solver_options::temporal_level; state of its last build in the last
+ * solve): dims6 = {NT unknowns (0: the level was off), S hats per node, nn nodes, step, Sx, Sy}; a_t = the assembled Galerkin
+ * matrix (NT x NT, unknown s * nn + a, diagonal shifted by coarse_dense_shift), a_t_inverse = the inverse in use, lam = the LM
+ * damping vector (frames x block) of the last LM iteration.  Any output pointer but dims6 may be NULL. */
+int32_t cvd_temporal_debug(cvd_handle* h, int32_t* dims6, double* a_t, double* a_t_inverse, double* lam, int32_t* failed);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,10 @@ class SolverOptions(C.Structure):
         ("pcg_fused_tail", C.c_int32),
         ("coarse_dense_row_split", C.c_int32),
         ("dist_owner_update", C.c_int32),
+        ("temporal_level", C.c_int32),
+        ("temporal_step", C.c_int32),
+        ("temporal_grid_x", C.c_int32),
+        ("temporal_grid_y", C.c_int32),
     ]
 
 
@@ -76,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug",
+    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug",
     "cvd_block_inverse_debug", "cvd_dense_inverse_debug",
 ]
 
@@ -216,6 +220,24 @@ class Solver(Binding):
         self._check(self._fn("dense_inverse_debug")(self._h, C.c_int32(n), a.ctypes.data_as(C.POINTER(C.c_double)),
                                                     out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(fl)))
         return out, fl.value
+
+    def temporal_debug(self):
+        """Third preconditioner level after the last solve: None when it was off, else its dimensions, Galerkin matrix, the inverse
+        in use and the damping vector of the last LM iteration."""
+        import numpy as np
+        dims = (C.c_int32 * 6)()
+        self._check(self._fn("temporal_debug")(self._h, dims, None, None, None, None))
+        if dims[0] == 0:
+            return None
+        n = dims[0]
+        a = np.zeros((n, n))
+        ai = np.zeros((n, n))
+        lam = np.zeros(self.num_frames * self.block_size())
+        fl = C.c_int32(0)
+        dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self._fn("temporal_debug")(self._h, dims, dp(a), dp(ai), dp(lam), C.byref(fl)))
+        return {"NT": n, "S": dims[1], "nn": dims[2], "step": dims[3], "Sx": dims[4], "Sy": dims[5], "a_t": a, "a_t_inverse": ai,
+                "lam": lam, "failed": fl.value}
 
     def coarse_debug(self):
         """(A_c, A_c^-1 as applied, pivot failures) of the coarse preconditioner level after the last solve."""

@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # translation units of libcvd_hip.so (compiled in parallel; every unit includes cvd_host.h + the kernel headers it launches)
-UNITS = ["cvd_api", "cvd_comm", "cvd_setup", "cvd_eval", "cvd_matvec", "cvd_precond", "cvd_solve", "cvd_frontend"]
+UNITS = ["cvd_api", "cvd_comm", "cvd_setup", "cvd_eval", "cvd_matvec", "cvd_precond", "cvd_temporal", "cvd_solve", "cvd_frontend"]
 LIB = os.path.join(_HERE, "lib", "libcvd_hip.so")
 OBJ = os.path.join(_HERE, "lib", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-cuda-compat"]

@@ -163,7 +163,7 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
     // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)
-    touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_solve(); touchModule_frontend();
+    touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_temporal(); touchModule_solve(); touchModule_frontend();
     if (device < PersistentGate::kMaxDevices) ++g_liveHandles[device];
     return h;
   } catch (const std::exception& e) {
@@ -234,6 +234,10 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->pcg_fused_tail = 1;
   o->coarse_dense_row_split = 5;
   o->dist_owner_update = 1;
+  o->temporal_level = 1;
+  o->temporal_step = 32;
+  o->temporal_grid_x = 0;
+  o->temporal_grid_y = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
@@ -255,6 +259,9 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
         o->block_inverse_variant > 2)
       throw std::runtime_error("coarse_level in {0, 1, 2}, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
     if (o->coarse_dense_row_split < 0 || o->coarse_dense_row_split > 8) throw std::runtime_error("coarse_dense_row_split must lie in [0, 8]");
+    if (o->temporal_level < 0 || o->temporal_level > 2 || o->temporal_step < 2 || o->temporal_grid_x < 0 || o->temporal_grid_y < 0 ||
+        o->temporal_grid_x == 1 || o->temporal_grid_y == 1)
+      throw std::runtime_error("temporal_level in {0, 1, 2}, temporal_step >= 2, temporal_grid_x / _y 0 (automatic) or >= 2");
     if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
@@ -768,6 +775,25 @@ int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, doubl
   });
 }
 
+int32_t cvd_temporal_debug(cvd_handle* h, int32_t* dims6, double* a_t, double* a_t_inverse, double* lam, int32_t* failed) {
+  CVD_TRY(h, {
+    auto& T = h->temporal;
+    hipStream_t s = h->stream;
+    const bool on = T.on && T.built;
+    const int dims[6] = {on ? T.NT : 0, T.S, T.nn, T.step, T.Sx, T.Sy};
+    for (int i = 0; i < 6; ++i) dims6[i] = dims[i];
+    if (on) {
+      const size_t n2 = static_cast<size_t>(T.NT) * T.NT;
+      if (a_t) T.A.download(a_t, n2, s);
+      if (a_t_inverse) T.Ainv.download(a_t_inverse, n2, s);
+      if (lam) h->dLam.download(lam, static_cast<size_t>(h->F) * h->Bsz(), s);
+      int fl = 0;
+      T.fail.download(&fl, 1, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (failed) *failed = fl;
+    }
+  });
+}
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed) {
   CVD_TRY(h, {
     auto& C = h->coarse;

@@ -908,6 +908,48 @@ struct CoarseView {
   const unsigned char* modeActive;
   const int* fail;
   const double* cF;
+  // third level (cvd_temporal.h: temporally coarse depth-grid level), tl == nullptr: off.  The level's workgroups leave the
+  // frame's S coefficients (its temporal hats already interpolated) in tl[f][S]; a consumer adds the spatial prolongation
+  // (P t)_i = sum_k tlW[v][k] tl[f][tlIdx[v] byte k] for depth vertex v = i - 7.
+  const double* tl;
+  const float4* tlW;         // [vertices] weights of the <= 4 coarse hats that are non-zero at the vertex
+  const unsigned int* tlIdx; // [vertices] their indices, one byte each
+  int tlS;
+};
+constexpr int kTlMaxS = 64;          // coarse hats per temporal node (LDS regions of the consumers: 2 x kTlMaxS doubles)
+constexpr int kTlMaxWidth = 32;      // vertices in the support of one coarse hat (transposed table, ELL)
+struct TlTaps {
+  float4 w;
+  unsigned int idx;
+};
+// (issued with the other loads of a consumer's prologue; i = unknown of the frame block, nV depth vertices)
+__device__ __forceinline__ void tlLoadTaps(const CoarseView& V, int i, int nV, TlTaps& t) {
+  const bool in = i >= 7 && i < 7 + nV;
+  const int v = in ? i - 7 : 0;
+  t.w = V.tlW[v];
+  t.idx = V.tlIdx[v];
+  if (!in) t.w = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ double tlAt(const double* __restrict__ tls, const TlTaps& t) {
+  return static_cast<double>(t.w.x) * tls[t.idx & 255u] + static_cast<double>(t.w.y) * tls[(t.idx >> 8) & 255u] +
+         static_cast<double>(t.w.z) * tls[(t.idx >> 16) & 255u] + static_cast<double>(t.w.w) * tls[t.idx >> 24];
+}
+// Per-iteration state of the third level inside the PCG kernels (Ainv == nullptr: off).  t = A_T^-1 P^T r is linear in r, so it
+// obeys t <- t - alpha A_T^-1 (P^T q) exactly as the dense pose-graph level's c does (DenseStep): the finish half of a frame
+// leaves the SPATIAL restriction of its product (sq[f][S]), S extra workgroups of the update launch -- one per coarse hat, the
+// hat's nn temporal nodes are its rows -- reduce over the frames of each node, walk their rows of the inverse and leave tl.
+// Unknown e = s * nn + a: hat s of temporal node a (node a sits at frame a * step, weight max(0, 1 - |f - a step| / step)).
+struct TlStep {
+  const double* Ainv;        // [NT][ld] f64
+  double* sq;                // [F][S]
+  double* rT;                // [NT] P^T r
+  double* t;                 // [NT] A_T^-1 P^T r
+  double* tl;                // [F][S] out (CoarseView::tl of the next product)
+  double* dotPart;           // [S] shares of r^T P t
+  const int* fail;
+  const float* elW;          // transposed vertex table of the restriction, ELL: entry k of hat s at [k * S + s]
+  const unsigned char* elV;  //   its vertex
+  int S, nn, step, NT, ld, width;
 };
 // One wave: out[0..7] = c_f (zero for inactive modes / a failed factorisation).  lane = (r, c) of the 8x8 block.
 __device__ __forceinline__ void coarseFrameCorrection(const CoarseView& V, int f, int lane, double* __restrict__ out) {

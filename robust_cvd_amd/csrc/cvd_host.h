@@ -35,6 +35,7 @@
 #include "../../include/cvd_hip.h"
 #include "cvd_kernels.h"
 #include "cvd_coarse.h"
+#include "cvd_temporal.h"
 #include "cvd_cross.h"
 #include "cvd_triplets.h"
 #include "cvd_dense.h"
@@ -318,6 +319,22 @@ struct cvd_handle_t {
     CoarsePlan plan{};
   } coarse;
   bool coarseOn = false;  // this solve uses the coarse level
+  // third level (cvd_temporal.h): temporal hats x coarse hats on the depth grid
+  struct TemporalHost {
+    bool on = false;        // this solve uses the level
+    bool built = false;     // A_T^-1 of this solve exists
+    int S = 0, Sx = 0, Sy = 0, nn = 0, step = 0, NT = 0, width = 0, nGroups = 0, nBlocks = 0;
+    int tabGx = 0, tabGy = 0, tabSx = 0, tabSy = 0;   // what the spatial tables were built for
+    int grpF = 0, grpStep = 0;                        // ... the groups / block lists
+    std::vector<int> grpFa, grpFb;
+    DevBuf<float> hx, hy, elW;
+    DevBuf<int> bx, by, gOff, gItems, blkA, blkB, gPtr, gather, fail, valid;
+    DevBuf<float4> vW;
+    DevBuf<unsigned int> vIdx, counter;
+    DevBuf<unsigned char> elV;
+    DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart;
+    DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
+  } temporal;
   // measured on this handle (cvd_solve.hip: denseRebuildThreshold): an in-line rebuild of the dense coarse level and a PCG iteration
   hipEvent_t evRebuild[2] = {nullptr, nullptr};
   bool rebuildTimed = false;
@@ -592,6 +609,13 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
 void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv, int* dFail, int variant);
 void launchBlockInverse(Ctx& c);
 void launchCoarseSetup(Ctx& c, const double* x, int side = 0);
+// third level (cvd_temporal.hip)
+bool temporalScope(const Ctx& c);
+void temporalPrepare(Ctx& c);                       // tables and work lists of this solve's problem
+void launchTemporalSetup(Ctx& c, const double* x);  // A_T for the current (H, lam, x) and its inverse
+void launchTemporalInit(Ctx& c);                    // first residual of a PCG solve: t, r_T, tl, the level's part of r^T z
+TlStep temporalStep(cvd_handle* h);                 // (Ainv == nullptr when the level is off)
+const TlStep* temporalStepDev(cvd_handle* h);       // its device copy for the kernels, nullptr when the level is off
 void coarseDebug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = nullptr);
 bool wantsTriplets(const cvd_opt_params& p, ProblemKind kind);
@@ -610,6 +634,7 @@ void touchModule_matvec();
 void touchModule_precond();
 void touchModule_solve();
 void touchModule_frontend();
+void touchModule_temporal();
 void flowGuidedFilter(cvd_handle* h, int n, int first, int count, int w, int hh, int dw, int dh, float invAspect, const float* depth,
                       const float* cameras, const float* flowF, const uint8_t* maskF, const float* flowB, const uint8_t* maskB,
                       int frameRadius, int spatialRadius, int median, float* out, double* kernelMs);

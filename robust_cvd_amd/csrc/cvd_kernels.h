@@ -1534,7 +1534,8 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
                                                  int distMode, int nRows, const RegCache& rc, const CoarseView& V,
                                                  double* __restrict__ qc, const CoarseColumns& cc,
                                                  const double* __restrict__ Hdiag, double* __restrict__ pqOut,
-                                                 int ownFirst, int ownCount, double* __restrict__ sm, TailCarry& carry) {
+                                                 int ownFirst, int ownCount, double* __restrict__ sm, TailCarry& carry,
+                                                 const TlStep* __restrict__ tsp, double* __restrict__ tlPart) {
   // Hdiag != nullptr (explicit cross blocks, cvd_cross.h): the partial rows hold the OFF-diagonal blocks' products only;
   // the frame-diagonal part, regularisers included, is H_ff p_f with the assembled H_ff.
   const double sDone = scal[S_DONE];  // PCG already converged (iterations enqueued ahead): tested after the input loads
@@ -1560,6 +1561,15 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
   // (two elements per thread: B <= 512; the fused kernel's scope ends at B = 256: one)
   constexpr int EPT = FUSED ? 1 : 2;
   double vz[2] = {0.0, 0.0}, vm[2] = {0.0, 0.0}, vp[2] = {0.0, 0.0}, vlam[2] = {0.0, 0.0}, pvReg[2] = {0.0, 0.0};
+  // third level (CoarseView::tl): the frame's coefficients to LDS (behind the row walk's partial sums), the vertex taps to registers
+  const bool tlOn = V.tl != nullptr;
+  double* tls = cl + kCB + (FUSED ? ((nT >> 8) - 1) * 256 : 0);
+  TlTaps tt[EPT];
+  if (tlOn) {
+    if (tid < V.tlS) tls[tid] = V.tl[static_cast<size_t>(f) * V.tlS + tid];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) tlLoadTaps(V, tid + e * 256, L.nD, tt[e]);
+  }
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * 256;
@@ -1629,7 +1639,7 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
     const int i = tid + e * 256;
     if (i >= B) continue;
     // search direction from the two-level preconditioned residual z + Z c (coarse part only on active unknowns)
-    const double pv = vz[e] + coarseAtLds(cl, L, i) * vm[e] + (useBeta ? beta * vp[e] : 0.0);
+    const double pv = vz[e] + (coarseAtLds(cl, L, i) + (tlOn ? tlAt(tls, tt[e]) : 0.0)) * vm[e] + (useBeta ? beta * vp[e] : 0.0);
     pNew[base + i] = pv;
     pvReg[e] = pv;
     pf[i] = pv * vm[e];
@@ -1728,6 +1738,20 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
       coarseColumnProducts(cc, qc + f * kCB, f, tid, 256);
     }
   }
+  if (tsp != nullptr) {
+    // third level: spatial restriction of this frame's product, sq[f][s] = sum_v Hs[v][s] q_f[7 + v], by the transposed vertex
+    // table (entry k of hat s; fixed summation order).  (The level's descriptor is read where it is used: as a kernel argument
+    // its 24 scalar registers stayed live through both halves of k_pcg_tail and cost the update half spilled operands.)
+    const TlStep ts = *tsp;
+    const int nE = ts.S * ts.width;
+    for (int e = tid; e < nE; e += nT) tlPart[e] = static_cast<double>(ts.elW[e]) * qf[7 + ts.elV[e]];
+    __syncthreads();
+    if (tid < ts.S) {
+      double a = 0.0;
+      for (int k = 0; k < ts.width; ++k) a += tlPart[k * ts.S + tid];
+      storeMaybePublished(ts.sq + static_cast<size_t>(f) * ts.S + tid, a, FUSED);
+    }
+  }
   if constexpr (!FUSED) {
     // the last workgroup to arrive reduces p.q over the frames and publishes alpha for k_cg_update
     if (lastBlockArrivesLite(counter, L.F, reinterpret_cast<int*>(red + 6))) {
@@ -1759,11 +1783,13 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
                                                        int distMode, int nRows, RegCache rc, CoarseView V,
                                                        double* __restrict__ qc, CoarseColumns cc,
                                                        const double* __restrict__ Hdiag, double* __restrict__ pqOut,
-                                                       int ownFirst, int ownCount) {
+                                                       int ownFirst, int ownCount, const TlStep* __restrict__ tsp) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   TailCarry carry;
+  // (third level: its coefficients behind the coarse corrections, the restriction's products behind those)
   (void)matvecFinishBody<KD, false>(L, x, mask, lam, median, inRange, rangeFlags, fiOff, fiList, qPart, z, pOld, pNew, scal, counter,
-                                    useBeta, q, fdot, distMode, nRows, rc, V, qc, cc, Hdiag, pqOut, ownFirst, ownCount, sm, carry);
+                                    useBeta, q, fdot, distMode, nRows, rc, V, qc, cc, Hdiag, pqOut, ownFirst, ownCount, sm, carry, tsp,
+                                    sm + 3 * L.B + 8 + kCB + kTlMaxS);
 }
 
 // p.q of the all-reduced product (multi-GPU only) + alpha, same last-workgroup pattern as k_matvec_finish.
@@ -1834,6 +1860,89 @@ __host__ __device__ inline int cgUpdatePartDoubles(int B, int nThreads) {
   return B > 256 ? nThreads : max(nThreads, 16 * ((B + 3) & ~3));
 }
 
+// Workgroup of the third level (TlStep) for coarse hat s: q_T = R_t sq over the frames of every temporal node (all NT entries: the
+// rows need them all), the hat's nn rows of the inverse (one wave per row), t <- t - alpha A_T^-1 q_T, r_T <- r_T - alpha q_T, the
+// hat's share of r^T P t, and the temporal interpolation of the new t for every frame (tl).  init: t = A_T^-1 q_T, r_T = q_T with
+// sq = the restriction of the first residual.  LDS: NT + 2 nn doubles at sm.  Returns false when nothing was written.
+struct NoMid {  // (the kernels that are not k_pcg_tail: nothing happens between the halves)
+  __device__ bool first(double&, double&) { return true; }
+  __device__ bool second(double&) { return true; }
+};
+template <bool FUSED, typename Mid>
+__device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int s, int F, double& alpha, int init, double sDone,
+                                            double* __restrict__ sm, Mid& mid) {
+  const TlStep ts = *tsp;
+  const int tid = threadIdx.x, nThreads = blockDim.x;
+  double* qT = sm;           // [S][nn]
+  double* tn = qT + ts.NT;   // nn new coefficients of this hat
+  double* red = tn + ts.nn;  // nn products t r_T
+  if constexpr (FUSED) {
+    if (!mid.second(alpha)) return false;
+  }
+  const double inv = 1.0 / static_cast<double>(ts.step);
+  for (int e = tid; e < ts.NT; e += nThreads) {  // e = a * S + s': neighbouring lanes read neighbouring words of a frame's row
+    const int a = e / ts.S, sp = e - a * ts.S;
+    const int fLo = max(0, (a - 1) * ts.step + 1), fHi = min(F - 1, (a + 1) * ts.step - 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    auto term = [&](int f) -> double {
+      const int fc = min(f, fHi);
+      const double* src = ts.sq + static_cast<size_t>(fc) * ts.S + sp;
+      const double v = FUSED ? readPartial(src) : *src;
+      const double w = 1.0 - fabs(static_cast<double>(fc - a * ts.step)) * inv;
+      return f <= fHi ? w * v : 0.0;
+    };
+    for (int f = fLo; f <= fHi; f += 4) {
+      a0 += term(f);
+      a1 += term(f + 1);
+      a2 += term(f + 2);
+      a3 += term(f + 3);
+    }
+    qT[sp * ts.nn + a] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (sDone != 0.0) return false;  // uniform; nothing written yet
+  const int wv = tid >> 6, lane = tid & 63, nW = nThreads >> 6;
+  const bool on = *ts.fail == 0;
+  for (int a = wv; a < ts.nn; a += nW) {
+    const int e = s * ts.nn + a;
+    const double* row = ts.Ainv + static_cast<size_t>(e) * ts.ld;
+    double acc0 = 0.0, acc1 = 0.0;
+    int c = lane;
+    for (; c + 64 < ts.NT; c += 128) {
+      acc0 += row[c] * qT[c];
+      acc1 += row[c + 64] * qT[c + 64];
+    }
+    if (c < ts.NT) acc0 += row[c] * qT[c];
+    const double d = waveSum(acc0 + acc1);
+    if (lane == 0) {
+      double rn, tv;
+      if (init) {
+        rn = qT[e];
+        tv = on ? d : 0.0;
+      } else {
+        rn = ts.rT[e] - alpha * qT[e];
+        tv = on ? ts.t[e] - alpha * d : 0.0;
+      }
+      ts.rT[e] = rn;
+      ts.t[e] = tv;
+      tn[a] = tv;
+      red[a] = tv * rn;
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < F; f += nThreads) {
+    const int a0 = f / ts.step;
+    const double tau = static_cast<double>(f - a0 * ts.step) * inv;
+    ts.tl[static_cast<size_t>(f) * ts.S + s] = (1.0 - tau) * tn[a0] + tau * tn[min(a0 + 1, ts.nn - 1)];
+  }
+  if (tid == 0) {
+    double d = 0.0;
+    for (int a = 0; a < ts.nn; ++a) d += red[a];
+    publishPartial(ts.dotPart + s, d);
+  }
+  return true;
+}
+
 // alpha = rz / sum(p.q) (published by k_matvec_finish); dx += alpha p; r -= alpha q; z = Minv_f r;
 // partial r.z and r.r.  One workgroup per frame with 256 threads per 64-row chunk (blockDim = 256 * ceil(B/64),
 // B <= 256): thread = (row, j-segment); the 4 segments of a row split the block mat-vec and are combined in LDS.
@@ -1855,7 +1964,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
                                              const unsigned char* __restrict__ modeActive,
                                              double* __restrict__ hostMirror, const CoarseStep& cs, const DenseStep& ds,
                                              const double* __restrict__ pqReduced, double* __restrict__ sm, Mid& mid,
-                                             int f0, int nF, double* __restrict__ partOut) {
+                                             int f0, int nF, double* __restrict__ partOut, const TlStep* __restrict__ tsp) {
   // [f0, f0 + nF): the frames this launch updates -- all of them, or (owner-sharded multi-GPU iteration) the calling rank's own
   // chunk; workgroups beyond nF are the dense coarse level's, two frames of the window each.  partOut != nullptr: the last
   // workgroup leaves THIS RANK's shares {r^T z, r^T r} there instead of finishing the PCG scalars (k_pcg_scalars_dist does).
@@ -1871,6 +1980,10 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   const int nWaves = nThreads >> 6;
   const bool denseWg = static_cast<int>(blockIdx.x) >= nF;
   const int f = denseWg ? L.F + (static_cast<int>(blockIdx.x) - nF) : f0 + static_cast<int>(blockIdx.x);
+  // (third level: its S workgroups follow the dense level's)
+  const int nDenseWg = (fusedDense && ds.rowSplit > 0) ? (nF + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0;
+  const bool tlOn = !init && tsp != nullptr;
+  const bool tlWg = tlOn && static_cast<int>(blockIdx.x) >= nF + nDenseWg;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
@@ -1950,6 +2063,9 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     __syncthreads();  // (psum is reused)
   };
   if (f >= L.F) {
+    if (tlWg) {  // third level's workgroup (one coarse hat)
+      if (!tlLevelRows<FUSED>(tsp, static_cast<int>(blockIdx.x) - nF - nDenseWg, L.F, alpha, 0, sDone, sm, mid)) return;
+    } else {
     // ---- dense-level workgroup: rows [0, rowSplit) of kDenseFramesPerGroup frames, one frame after the other (F + F / 2
     // workgroups of 768 threads still fit the device in ONE round, two per CU; F + F do not)
     const int nR = ds.rowSplit;
@@ -1981,6 +2097,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
       if (g >= f0 + nF) break;
       denseRows(g, 0, nR, qcs, psum, on0, w, rep == 0, ds.dotPart + g);
     }
+    }  // dense-level workgroup
   } else {
   // B <= 256: the thread's share of the f32 block M_f^-1 (see the mat-vec below) is requested FIRST -- it depends on nothing
   // this launch computes, so its way from L2 / MALL overlaps the vector loads, the update and the barrier
@@ -2194,15 +2311,19 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
       if (fusedDense && ds.rowSplit > 0) cY += readPartial(ds.dotPart + k);
       if (fusedDense && ds.rowSplit < kCB) cY += readPartial(ds.dotPart2 + k);
     }
+    double cT = 0.0;  // third level's part of r^T z (kept apart: a broken-down sparse factor switches ITS level off below, not this one)
+    if (tlOn)
+      for (int k = tid; k < tsp->S; k += nThreads) cT += readPartial(tsp->dotPart + k);
     a = waveSum(a);
     b = waveSum(b);
     cY = waveSum(cY);
+    cT = waveSum(cT);
     __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; ypart[tid >> 6] = cY; }
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; ypart[tid >> 6] = cY; ypart[16 + (tid >> 6)] = cT; }
     __syncthreads();
     if (tid == 0) {
       double rzs = 0.0, rrs = 0.0, ys = 0.0;
-      for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; ys += ypart[w]; }
+      for (int w = 0; w < nWaves; ++w) { rzs += red[w] + ypart[16 + w]; rrs += red[16 + w]; ys += ypart[w]; }
       if (partOut != nullptr) {  // owner-sharded iteration: this rank's shares, summed over the ranks by k_pcg_scalars_dist
         partOut[0] = rzs + ((fusedY && *cs.fail != 0) ? 0.0 : ys);
         partOut[1] = rrs;
@@ -2230,14 +2351,11 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
                                                     const unsigned char* __restrict__ modeActive,
                                                     double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
                                                     const double* __restrict__ pqReduced, int f0, int nF,
-                                                    double* __restrict__ partOut) {
+                                                    double* __restrict__ partOut, const TlStep* __restrict__ tsp) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  struct NoMid {
-    __device__ bool first(double&, double&) { return true; }
-    __device__ bool second(double&) { return true; }
-  } mid;
+  NoMid mid;
   cgUpdateBody<false>(L, init, g, minv, p, q, scal, counter, dx, r, z, fdotRZ, fdotRR, tol2, rc, modeActive, hostMirror, cs, ds,
-                      pqReduced, sm, mid, f0, nF, partOut);
+                      pqReduced, sm, mid, f0, nF, partOut, tsp);
 }
 
 // Owner-sharded PCG iteration (multi-GPU): every rank updated x, r, z of ITS frames and left {r^T z, r^T r} of those frames in
@@ -2369,6 +2487,7 @@ struct TailUpdate {
   int ldsFinish;           // offset (doubles) of the finish half's LDS region
   int ldsScratch;          // offset of 24 doubles for the barrier flag and the p.q sum (beyond both kinds of workgroups' regions)
   DenseStep ds;
+  const TlStep* ts;        // third level (device copy of its descriptor), nullptr: off
 };
 
 template <int KD>
@@ -2395,7 +2514,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
       TailCarry carry{0.0, 0.0};
       if (!matvecFinishBody<KD, true>(L, x, mask, lam, median, inRange, rangeFlags, fiOff, fiList, qPart, U.z, pOld, pNew, scal,
                                       nullptr, useBeta, q, fdot, 0, nRows, rc, V, qc, ccOff, Hdiag, nullptr, 0, L.F,
-                                      sm + U.ldsFinish, carry))
+                                      sm + U.ldsFinish, carry, U.ts, sm + L.B))  // (restriction products: the update half's partial-sum region)
         return false;
       pv = carry.pv;
       qv = carry.qv;
@@ -2426,7 +2545,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
     __device__ bool second(double& alpha) { return f2(alpha); }
   } mid{first, second};
   cgUpdateBody<true>(L, 0, nullptr, U.minv, nullptr, nullptr, scal, U.counter, U.dx, U.r, U.z, U.fdotRZ, U.fdotRR, U.tol2, nullptr,
-                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr);
+                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr, U.ts);
   TAIL_STAMP(4);
 }
 
@@ -2739,6 +2858,19 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   }
   constexpr int EPT = 256 / NT;  // elements of a frame block per thread (B <= 256)
   double vza[EPT], vzb[EPT], vpa[EPT], vpb[EPT], vma[EPT], vmb[EPT];
+  // third level (CoarseView::tl): the two frames' coefficients go to LDS behind the coarse corrections, the thread's vertex
+  // taps to registers -- same round trip as everything else here
+  const bool tlOn = V.tl != nullptr;
+  double* tls = cl + 2 * kCB;
+  TlTaps tt[EPT];
+  if (tlOn) {
+    for (int i = tid; i < 2 * V.tlS; i += NT) {
+      const int which = i >= V.tlS ? 1 : 0;
+      tls[i] = V.tl[static_cast<size_t>(which ? fb : fa) * V.tlS + (i - which * V.tlS)];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) tlLoadTaps(V, tid + e * NT, L.nD, tt[e]);
+  }
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * NT;
@@ -2764,8 +2896,13 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   for (int e = 0; e < EPT; ++e) {
     const int i = tid + e * NT;
     if (i < B) {
-      pa[i] = (vza[e] + coarseAtLds(cl, L, i) + (useBeta ? beta * vpa[e] : 0.0)) * vma[e];
-      pb[i] = (vzb[e] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * vpb[e] : 0.0)) * vmb[e];
+      double ca = coarseAtLds(cl, L, i), cb2 = coarseAtLds(cl + kCB, L, i);
+      if (tlOn) {
+        ca += tlAt(tls, tt[e]);
+        cb2 += tlAt(tls + V.tlS, tt[e]);
+      }
+      pa[i] = (vza[e] + ca + (useBeta ? beta * vpa[e] : 0.0)) * vma[e];
+      pb[i] = (vzb[e] + cb2 + (useBeta ? beta * vpb[e] : 0.0)) * vmb[e];
     }
   }
   if (L.intrOpt == kIntrShared) {

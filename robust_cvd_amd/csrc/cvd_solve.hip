@@ -65,11 +65,17 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
     const size_t dense = static_cast<size_t>(F) * kCB + nThreads + 16;
     ldsU = std::max((dsOn.rowSplit < kCB ? ldsU / 8 + dense : ldsU / 8), dense) * 8;
   }
+  // third level (cvd_temporal.h): S more workgroups of the update launch (q_T and the coefficients of one coarse hat in LDS)
+  const TlStep tsOff = temporalStep(nullptr);
+  const TlStep tsOn = coarse ? temporalStep(h) : tsOff;
+  const int nTlWg = tsOn.Ainv != nullptr ? tsOn.S : 0;
+  if (nTlWg) ldsU = std::max(ldsU, (static_cast<size_t>(tsOn.NT) + 2 * tsOn.nn) * 8);
   allowLds(k_cg_update, ldsU);
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
                      h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr), 0, F,
-                     static_cast<double*>(nullptr));
+                     static_cast<double*>(nullptr), static_cast<const TlStep*>(nullptr));
+  if (nTlWg) launchTemporalInit(c);  // (adds the level's part of r^T z before the dense level's kernel closes the scalars)
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -111,7 +117,8 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
         hipLaunchKernelGGL(k_cg_update, dim3(denseFused && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn),
                            dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, h->dScal.p, h->dCounters.p + 1,
                            h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, static_cast<double*>(nullptr),
-                           h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank);
+                           h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank,
+                           static_cast<const TlStep*>(nullptr));
       else
         HIP_CHECK(hipMemsetAsync(h->dOwnerScal.p + 2 * h->rank, 0, 2 * sizeof(double), s));
       HIP_CHECK(hipGetLastError());
@@ -130,10 +137,10 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       return;
     }
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3(denseFused && dsOn.rowSplit > 0 ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+    hipLaunchKernelGGL(k_cg_update, dim3((denseFused && dsOn.rowSplit > 0 ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F) + nTlWg), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
                        (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced,
-                       0, F, static_cast<double*>(nullptr));
+                       0, F, static_cast<double*>(nullptr), nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
     if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -251,6 +258,8 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
+  h->temporal.on = temporalScope(c);
+  if (h->temporal.on) temporalPrepare(c);
   phase("buffers");
   buildMask(h, c.L, p, kind, range);
   phase("mask");
@@ -402,6 +411,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
               HIP_CHECK(hipEventRecord(h->evRebuild[0], s));
             }
             launchCoarseSetup(c, h->dX.p);
+            if (h->temporal.on) launchTemporalSetup(c, h->dX.p);  // (third level: same linearisation point and damping)
             if (measure) {
               HIP_CHECK(hipEventRecord(h->evRebuild[1], s));
               h->rebuildTimed = true;
@@ -414,6 +424,11 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
           }
         } else {
           ++coarseAge;
+          if (h->temporal.on && h->opt.temporal_level == 2) {
+            const int slot = h->tBegin(KC_INVERSE);
+            launchTemporalSetup(c, h->dX.p);
+            h->tEnd(slot);
+          }
         }
       }
       // one read-back for the PCG result, the step statistics and the cost of the candidate point (the

@@ -1,0 +1,241 @@
+// cvd_temporal.hip -- host side of the third preconditioner level (cvd_temporal.h): scope, tables and work lists, the build of
+// A_T^-1 per (H, lam, x), the first residual of a PCG solve.  The per-iteration part lives inside the PCG launches.
+#include "cvd_host.h"
+
+namespace cvd {
+
+static int autoCoarse(int g, int wanted) {
+  const int s = wanted > 0 ? wanted : (g + 1) / 2;
+  return std::min(g, std::max(2, s));
+}
+
+// Static scope (see cvd_solver_options::temporal_level): everything the kernels of the level assume.
+bool temporalScope(const Ctx& c) {
+  cvd_handle* h = c.h;
+  const Layout& L = c.L;
+  if (h->opt.temporal_level == 0 || h->dist() || h->forceGeneric || h->dense || c.cross || c.trip) return false;
+  if (!h->coarseOn) return false;   // (the first residual's scalars are closed by the pose-graph level's kernel)
+  if (c.KD != 4 || c.KS != 0 || !fastLoss(L) || L.intrOpt == CVD_INTR_SHARED) return false;
+  if (L.N != 1 || L.gz != 1 || L.depthType != CVD_DEPTH_GRID || L.positionRegSqrt > 0.0 || !L.includeStatic) return false;
+  if (L.B > 256 || L.nD > 256 || L.gx < 3 || L.gy < 3 || L.nD != L.gx * L.gy) return false;
+  const int step = h->opt.temporal_step;
+  if (L.F <= 2 * step) return false;  // (fewer than three interior nodes: nothing temporal to coarsen)
+  const int Sx = autoCoarse(L.gx, h->opt.temporal_grid_x), Sy = autoCoarse(L.gy, h->opt.temporal_grid_y);
+  if (Sx * Sy > kTlMaxS) return false;
+  const int nn = (L.F - 1 + step - 1) / step + 1;
+  if (nn * Sx * Sy > kDenseCoarseMaxUnknowns) return false;
+  return true;
+}
+
+// 1-D hats of one axis: fine vertex i sits at i / ratio in coarse units
+static void axisTable(int g, int S, std::vector<float>& hv, std::vector<int>& bv) {
+  hv.assign(2 * static_cast<size_t>(g), 0.f);
+  bv.assign(g, 0);
+  const double ratio = static_cast<double>(g - 1) / static_cast<double>(S - 1);  // fine cells per coarse cell (>= 1)
+  for (int i = 0; i < g; ++i) {
+    const double pos = static_cast<double>(i) / ratio;
+    const int j0 = std::min(S - 2, std::max(0, static_cast<int>(std::floor(pos + 1e-12))));
+    const double fr = std::min(1.0, std::max(0.0, pos - j0));
+    bv[i] = j0;
+    hv[2 * i] = static_cast<float>(1.0 - fr);
+    hv[2 * i + 1] = static_cast<float>(fr);
+  }
+}
+
+void temporalPrepare(Ctx& c) {
+  cvd_handle* h = c.h;
+  auto& T = h->temporal;
+  const Layout& L = c.L;
+  hipStream_t s = h->stream;
+  const int step = h->opt.temporal_step;
+  const int Sx = autoCoarse(L.gx, h->opt.temporal_grid_x), Sy = autoCoarse(L.gy, h->opt.temporal_grid_y);
+  const int S = Sx * Sy, G = L.nD, F = L.F;
+  const int nn = (F - 1 + step - 1) / step + 1;
+  bool uploaded = false;
+  if (T.tabGx != L.gx || T.tabGy != L.gy || T.tabSx != Sx || T.tabSy != Sy) {
+    std::vector<float> hx, hy;
+    std::vector<int> bx, by;
+    axisTable(L.gx, Sx, hx, bx);
+    axisTable(L.gy, Sy, hy, by);
+    std::vector<float4> vW(G);
+    std::vector<unsigned int> vIdx(G);
+    std::vector<std::vector<std::pair<int, float>>> cols(S);
+    for (int vy = 0; vy < L.gy; ++vy)
+      for (int vx = 0; vx < L.gx; ++vx) {
+        const int v = vx + vy * L.gx;
+        float w[4];
+        unsigned int idx = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int i = k & 1, j = k >> 1;
+          const int hat = (bx[vx] + i) + (by[vy] + j) * Sx;
+          w[k] = hx[2 * vx + i] * hy[2 * vy + j];
+          idx |= static_cast<unsigned int>(hat) << (8 * k);
+          if (w[k] != 0.f) cols[hat].emplace_back(v, w[k]);
+        }
+        vW[v] = make_float4(w[0], w[1], w[2], w[3]);
+        vIdx[v] = idx;
+      }
+    size_t width = 1;
+    for (auto& col : cols) width = std::max(width, col.size());
+    if (width > static_cast<size_t>(kTlMaxWidth)) throw std::runtime_error("temporal level: a coarse hat covers too many depth vertices");
+    std::vector<float> elW(width * S, 0.f);
+    std::vector<unsigned char> elV(width * S, 0);
+    for (int hat = 0; hat < S; ++hat)
+      for (size_t k = 0; k < cols[hat].size(); ++k) {
+        elW[k * S + hat] = cols[hat][k].second;
+        elV[k * S + hat] = static_cast<unsigned char>(cols[hat][k].first);
+      }
+    T.hx.upload(hx.data(), hx.size(), s);
+    T.hy.upload(hy.data(), hy.size(), s);
+    T.bx.upload(bx.data(), bx.size(), s);
+    T.by.upload(by.data(), by.size(), s);
+    T.vW.upload(vW.data(), vW.size(), s);
+    T.vIdx.upload(vIdx.data(), vIdx.size(), s);
+    T.elW.upload(elW.data(), elW.size(), s);
+    T.elV.upload(elV.data(), elV.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));  // (the host vectors go out of scope)
+    T.tabGx = L.gx; T.tabGy = L.gy; T.tabSx = Sx; T.tabSy = Sy;
+    T.width = static_cast<int>(width);
+    uploaded = true;
+  }
+  T.S = S; T.Sx = Sx; T.Sy = Sy; T.nn = nn; T.step = step; T.NT = nn * S;
+  if (uploaded || T.grpF != F || T.grpStep != step || T.grpFa != h->itemFa || T.grpFb != h->itemFb) {
+    // groups of items by the pair of node intervals their frames fall into, <= kGroup items each
+    constexpr size_t kGroup = 48;
+    std::map<std::pair<int, int>, std::vector<int>> cells;
+    for (size_t i = 0; i < h->itemFa.size(); ++i) cells[{h->itemFa[i] / step, h->itemFb[i] / step}].push_back(static_cast<int>(i));
+    std::vector<int> gOff{0}, gItems;
+    std::map<std::pair<int, int>, std::vector<int>> blocks;  // (a, b), a <= b -> gather entries
+    for (int a = 0; a < nn; ++a) {
+      blocks[{a, a}];
+      if (a + 1 < nn) blocks[{a, a + 1}];
+    }
+    for (auto& cell : cells) {
+      const auto& items = cell.second;
+      for (size_t o = 0; o < items.size(); o += kGroup) {
+        const int g = static_cast<int>(gOff.size()) - 1;
+        gItems.insert(gItems.end(), items.begin() + o, items.begin() + std::min(items.size(), o + kGroup));
+        gOff.push_back(static_cast<int>(gItems.size()));
+        for (int k = 0; k < 4; ++k) {
+          const int na = cell.first.first + (k >> 1), nb = cell.first.second + (k & 1);
+          if (na >= nn || nb >= nn) continue;  // (its temporal weight is zero)
+          const int en = 2 * (g * 4 + k);
+          if (na < nb) blocks[{na, nb}].push_back(en);
+          else if (na > nb) blocks[{nb, na}].push_back(en + 1);
+          else { blocks[{na, na}].push_back(en); blocks[{na, na}].push_back(en + 1); }
+        }
+      }
+    }
+    std::vector<int> blkA, blkB, gPtr{0}, gather;
+    for (auto& b : blocks) {
+      blkA.push_back(b.first.first);
+      blkB.push_back(b.first.second);
+      gather.insert(gather.end(), b.second.begin(), b.second.end());
+      gPtr.push_back(static_cast<int>(gather.size()));
+    }
+    if (gather.empty()) gather.push_back(0);
+    if (gItems.empty()) gItems.push_back(0);
+    T.gOff.upload(gOff.data(), gOff.size(), s);
+    T.gItems.upload(gItems.data(), gItems.size(), s);
+    T.blkA.upload(blkA.data(), blkA.size(), s);
+    T.blkB.upload(blkB.data(), blkB.size(), s);
+    T.gPtr.upload(gPtr.data(), gPtr.size(), s);
+    T.gather.upload(gather.data(), gather.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    T.nGroups = static_cast<int>(gOff.size()) - 1;
+    T.nBlocks = static_cast<int>(blkA.size());
+    T.grpF = F; T.grpStep = step; T.grpFa = h->itemFa; T.grpFb = h->itemFb;
+  }
+  const size_t SS = static_cast<size_t>(S) * S, NT = static_cast<size_t>(T.NT);
+  T.Cf.ensure(static_cast<size_t>(F) * SS);
+  T.E.ensure(std::max<size_t>(1, h->itemFa.size()) * SS);
+  T.part.ensure(std::max<size_t>(1, static_cast<size_t>(T.nGroups)) * 4 * SS);
+  T.A.ensure(NT * NT);
+  T.Ainv.ensure(NT * NT);
+  T.sq.ensure(static_cast<size_t>(F) * S);
+  T.tl.ensure(static_cast<size_t>(F) * S);
+  T.rT.ensure(NT);
+  T.t.ensure(NT);
+  T.dotPart.ensure(S);
+  T.fail.ensure(1);
+  T.valid.ensure(1);
+  if (!T.counter.p) {
+    T.counter.ensure(4);
+    HIP_CHECK(hipMemsetAsync(T.counter.p, 0, 4 * sizeof(unsigned int), s));
+  }
+  HIP_CHECK(hipMemsetAsync(T.valid.p, 0, sizeof(int), s));  // (an inverse of another problem is never kept)
+  T.built = false;
+}
+
+static TlTables temporalTables(cvd_handle* h) {
+  auto& T = h->temporal;
+  return TlTables{T.hx.p, T.bx.p, T.hy.p, T.by.p, T.vW.p, T.vIdx.p, T.elW.p, T.elV.p, T.Sx, T.Sy, T.S, T.width};
+}
+
+TlStep temporalStep(cvd_handle* h) {
+  if (h == nullptr || !h->temporal.on || !h->temporal.built)
+    return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0};
+  auto& T = h->temporal;
+  return TlStep{T.Ainv.p, T.sq.p, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width};
+}
+
+const TlStep* temporalStepDev(cvd_handle* h) {
+  return (h != nullptr && h->temporal.on && h->temporal.built) ? h->temporal.stepDev.p : nullptr;
+}
+
+void launchTemporalSetup(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  auto& T = h->temporal;
+  const Layout& L = c.L;
+  hipStream_t s = h->stream;
+  const TlTables tb = temporalTables(h);
+  const size_t SS = static_cast<size_t>(T.S) * T.S;
+  launchFrameConsts(c, x);
+  const size_t ldsD = static_cast<size_t>(L.nD) * T.S * 8 + static_cast<size_t>(T.width) * T.S * 5 + 16;
+  allowLds(k_tl_diag, ldsD);
+  hipLaunchKernelGGL(k_tl_diag, dim3(L.F), dim3(256), ldsD, s, L, h->dH.p, h->dLam.p, h->dMask.p, tb, T.Cf.p);
+  HIP_CHECK(hipGetLastError());
+  if (c.nItems > 0) {
+    const size_t ldsE = 2 * static_cast<size_t>(L.B) * 8 + 2 * sizeof(FrameConst) + SS * 8 + 3 * static_cast<size_t>(L.gx + L.gy) * 4 + 16;
+    allowLds(k_tl_edges<false>, ldsE);
+    hipLaunchKernelGGL(k_tl_edges<false>, dim3(c.nItems), dim3(256), ldsE, s, L, c.T, c.it, x, h->dFc.p, h->dMask.p, tb, T.E.p);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_tl_reduce, dim3(T.nGroups), dim3(256), 0, s, T.S, T.step, T.gOff.p, T.gItems.p, h->dItemFa.p, h->dItemFb.p,
+                       T.E.p, T.part.p);
+    HIP_CHECK(hipGetLastError());
+  }
+  HIP_CHECK(hipMemsetAsync(T.A.p, 0, static_cast<size_t>(T.NT) * T.NT * sizeof(double), s));
+  hipLaunchKernelGGL(k_tl_assemble, dim3(T.nBlocks, static_cast<unsigned>((SS + 255) / 256)), dim3(256), 0, s, T.S, T.nn, T.step, L.F, T.NT, T.blkA.p, T.blkB.p, T.gPtr.p,
+                     T.gather.p, T.Cf.p, T.part.p, T.A.p, h->opt.coarse_dense_shift);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemsetAsync(T.fail.p, 0, sizeof(int), s));
+  launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p);
+  if (!T.built) {
+    T.built = true;
+    const TlStep ts = temporalStep(h);
+    T.stepDev.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(T.stepDev.p, &ts, sizeof(TlStep), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // (once per solve; `ts` is a local)
+  }
+}
+
+void launchTemporalInit(Ctx& c) {
+  cvd_handle* h = c.h;
+  auto& T = h->temporal;
+  hipStream_t s = h->stream;
+  const TlStep ts = temporalStep(h);
+  if (ts.Ainv == nullptr) return;
+  const size_t ldsR = (static_cast<size_t>(c.L.B) + static_cast<size_t>(T.S) * T.width) * 8;
+  hipLaunchKernelGGL(k_tl_restrict, dim3(c.L.F), dim3(256), ldsR, s, c.L, h->dR.p, temporalStepDev(h));
+  const size_t ldsI = (static_cast<size_t>(T.NT) + 2 * T.nn) * 8;
+  allowLds(k_tl_rows_init, ldsI);
+  hipLaunchKernelGGL(k_tl_rows_init, dim3(T.S), dim3(512), ldsI, s, temporalStepDev(h), c.L.F, h->dScal.p, T.counter.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+void touchModule_temporal() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_tl_reduce));
+}
+
+}  // namespace cvd

@@ -86,9 +86,9 @@ def test_huber_option_is_validated(Solver):
     synth.load_into(s, v)
     s.reset_depth_xforms(XformDesc.global_depth())
     s.reset_spatial_xforms(XformDesc.spatial())
-    s.set_robust_loss(5)
-    with pytest.raises(RuntimeError, match="robust_loss"):
-        s.evaluate(OptParams.defaults(), 0.1, np.zeros((3, 7)) + [0, 0, 0, 0, 0, 0, 0.2])
+    with pytest.raises(RuntimeError, match="robust_loss"):   # (refused where it is set: cvd_set_solver_options validates)
+        s.set_robust_loss(5)
+    s.evaluate(OptParams.defaults(), 0.1, np.zeros((3, 7)) + [0, 0, 0, 0, 0, 0, 0.2])   # the handle keeps its valid options
 
 
 @pytest.mark.parametrize("cfg", ["global", "grid6x4"])

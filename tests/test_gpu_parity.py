@@ -845,7 +845,7 @@ def test_two_level_preconditioner(Solver):
     assert a["total_linear_iterations"] * 1.5 <= b["total_linear_iterations"]   # (20 frames: 48 vs 87; 300 frames: ~5x)
 
 
-@pytest.mark.parametrize("case", ["dense_coarse", "no_coarse", "dense_coarse_triplets", "global_only"])
+@pytest.mark.parametrize("case", ["dense_coarse", "no_coarse", "dense_coarse_triplets", "global_only", "dense_coarse_temporal"])
 def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
     """k_pcg_tail (finish + update of a PCG iteration in ONE launch with a grid barrier between the halves: one GPU, frame block
     <= 256, dense coarse level or none) against the two launches it replaces (cvd_solver_options::pcg_fused_tail = 0): the same
@@ -865,6 +865,8 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
             opts["coarse_level"] = 0
         else:
             opts["coarse_update_budget"] = 0   # the dense coarse level
+        if case == "dense_coarse_temporal":    # + the third level (24 frames: a temporal node every 8)
+            opts["temporal_level"], opts["temporal_step"] = 2, 8
         s.set_options(**opts)
         s.reset_depth_xforms(XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())

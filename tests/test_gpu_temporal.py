@@ -1,0 +1,130 @@
+"""GPU (-m gpu): the third level of the PCG preconditioner (robust_cvd_amd/csrc/cvd_temporal.h; cvd_solver_options::temporal_level):
+temporal hat functions x bilinear hats of a coarse grid on the depth grid, Galerkin matrix assembled from the frame blocks and a
+per-constraint walk, inverted densely, applied inside the PCG launches.
+
+The level is a preconditioner: it cannot change where a solve converges to, only how many PCG iterations that takes.  Checked here:
+  * the device's Galerkin matrix against P_T^T (J^T J + diag(lam)) P_T formed in numpy from the matrix-free Hessian
+    (cvd_evaluate's hfull) and a prolongation built independently from the definition;
+  * the inverse in use is the inverse, and positive definite;
+  * on the BENCHMARKED problem the level saves PCG iterations and the end state stays within the parity tolerance of the oracle's
+    (tests/test_gpu_baseline_configs.py asserts the same for the default options, which include the level)."""
+import numpy as np
+import pytest
+
+from robust_cvd_amd import synth
+from robust_cvd_amd.ctypes_types import OptParams, XformDesc
+from tests import baseline_configs as bc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Solver():
+    from robust_cvd_amd import api
+    return api.Solver
+
+
+def axis_table(g, S):
+    """Coarse hats of one axis at the fine vertices (f32, as the device tables hold them): first hat and the two weights."""
+    ratio = (g - 1) / (S - 1)
+    b = np.zeros(g, dtype=int)
+    h = np.zeros((g, 2), dtype=np.float32)
+    for i in range(g):
+        pos = i / ratio
+        j0 = min(S - 2, max(0, int(np.floor(pos + 1e-12))))
+        fr = min(1.0, max(0.0, pos - j0))
+        b[i] = j0
+        h[i] = (np.float32(1.0 - fr), np.float32(fr))
+    return h, b
+
+
+def prolongation(F, B, gx, gy, Sx, Sy, step):
+    """P_T [F * B, S * nn]: column s * nn + a = (temporal hat of node a, at frame a * step) x (coarse hat s); depth-grid rows only."""
+    hx, bx = axis_table(gx, Sx)
+    hy, by = axis_table(gy, Sy)
+    S = Sx * Sy
+    nn = (F - 1 + step - 1) // step + 1
+    Hs = np.zeros((gx * gy, S))
+    for vy in range(gy):
+        for vx in range(gx):
+            for i in range(2):
+                for j in range(2):
+                    Hs[vx + vy * gx, (bx[vx] + i) + (by[vy] + j) * Sx] += float(np.float32(hx[vx, i] * hy[vy, j]))
+    assert np.allclose(Hs.sum(axis=1), 1.0, atol=1e-6)   # the hats are a partition of unity on the grid
+    P = np.zeros((F * B, S * nn))
+    for f in range(F):
+        for a in range(nn):
+            w = max(0.0, 1.0 - abs(f - a * step) / step)
+            if w > 0.0:
+                P[f * B + 7:f * B + 7 + gx * gy, a::nn] += w * Hs
+    return P, S, nn
+
+
+@pytest.mark.parametrize("grid,step", [((5, 4), 16), ((6, 5), 12)])
+def test_galerkin_matrix_and_inverse(Solver, grid, step):
+    """(5, 4) -> 3 x 2 hats: nested in x, not in y; (6, 5) -> 3 x 3: nested in neither (three hats per axis at some constraints)."""
+    F = 72
+    gx, gy = grid
+    v = synth.make_video(F, 128, 72, seed=12, extra_offsets=6)
+    s = Solver(0)
+    synth.load_into(s, v)
+    s.set_options(coarse_update_budget=0, temporal_level=2, temporal_step=step)   # (the dense pose-graph level: the third level's scope)
+    s.reset_depth_xforms(XformDesc.global_depth())
+    s.reset_spatial_xforms(XformDesc.spatial())
+    p = OptParams.defaults()
+    s.normalize_depth(p)
+    s.grid_xform_split(XformDesc.grid_depth(gx, gy))
+    reg = p.depth_deform_reg_final
+    p.max_iterations = 3
+    s.pose_optimization_step(p, reg, convert_poses=True)    # a state away from the start
+    H = s.evaluate(p, reg, None, want_hfull=True)["hfull"]
+    p.max_iterations = 1
+    s.pose_optimization_step(p, reg, convert_poses=False)   # ONE LM iteration: the level is built at the state just evaluated
+    dbg = s.temporal_debug()
+    assert dbg is not None and dbg["failed"] == 0
+    assert (dbg["Sx"], dbg["Sy"], dbg["step"]) == ((gx + 1) // 2, (gy + 1) // 2, step)
+    B = s.block_size()
+    P, S, nn = prolongation(F, B, gx, gy, dbg["Sx"], dbg["Sy"], step)
+    assert (S, nn, S * nn) == (dbg["S"], dbg["nn"], dbg["NT"])
+    ref = P.T @ (H + np.diag(dbg["lam"])) @ P
+    A = dbg["a_t"].copy()
+    assert np.array_equal(A, A.T)
+    A[np.diag_indices_from(A)] /= 1.0 + 1e-5   # (cvd_solver_options::coarse_dense_shift on the diagonal)
+    # the pair part alone is as large as the frame-diagonal part (they nearly cancel along the depth gauge): a wrong sign, a
+    # transposed block or a mis-weighted temporal node shows at the 1e-1 level.  Stated tolerance 1e-3 of the largest entry
+    # (measured 1.2e-4: the frame blocks come from k_assemble_fast, the reference from the matrix-free products).
+    err = np.abs(A - ref).max() / np.abs(ref).max()
+    assert err < 1e-3, err
+    Hd = np.zeros_like(H)
+    for f in range(F):
+        Hd[f * B:(f + 1) * B, f * B:(f + 1) * B] = H[f * B:(f + 1) * B, f * B:(f + 1) * B]
+    pair = P.T @ (H - Hd) @ P
+    assert np.abs(pair).max() > 0.05 * np.abs(ref).max()     # (the check above does see the pair part)
+    Ai = dbg["a_t_inverse"]
+    assert np.abs(Ai @ dbg["a_t"] - np.eye(S * nn)).max() < 1e-9
+    assert np.linalg.eigvalsh(0.5 * (Ai + Ai.T))[0] > 0.0
+    s.close()
+
+
+def test_level_saves_iterations_on_the_benchmarked_problem(Solver):
+    """BASELINE configs[2] with the 4140-pair list: the whole pipeline with and without the level (it is in scope at the
+    coarse-to-fine levels with a grid of at least 3 x 3 vertices).  Same minimum, fewer PCG iterations."""
+    name = "config2_4k"
+    v = bc.make_video(name)
+    ref = bc.load_solution(name)
+    out = {}
+    for lvl in (0, 1):
+        s = Solver(0)
+        s.set_options(temporal_level=lvl)
+        sol = bc.run(s, name, v)
+        perr, rerr = synth.relative_pose_error(sol["position"], sol["orientation"], ref["position"], ref["orientation"])
+        out[lvl] = (sol["summary"], perr, rerr, s.temporal_debug() is not None)
+        s.close()
+    assert not out[0][3] and out[1][3]
+    for lvl in (0, 1):
+        sm, perr, rerr, _ = out[lvl]
+        assert sm["termination"] == 0 and perr < 1e-3 and rerr < 1e-3, (lvl, perr, rerr)
+        assert abs(sm["final_cost"] - float(ref["final_cost"])) <= 1e-6 * float(ref["final_cost"])
+    assert out[0][0]["num_iterations"] == out[1][0]["num_iterations"]
+    # measured 1093 -> 888 over the whole pipeline, 50 -> 35 per LM iteration at the final level (profiles/r04_*)
+    assert out[1][0]["total_linear_iterations"] < 0.88 * out[0][0]["total_linear_iterations"], (out[0][0], out[1][0])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU check of the round: every -m gpu test, the default bench line, the all-kernels variant
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r04full}; mkdir -p $OUT; cd $R
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=12 > $OUT/t_all.log 2>&1; echo "all rc=$?"
+timeout 1500 python -m pytest tests -q -m gpu --durations=12 > $OUT/t_all.log 2>&1; echo "all rc=$?"
 tail -22 $OUT/t_all.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"
 timeout 400 python bench.py --steps 20 --warmup 3 2>> $OUT/bench.err | tee $OUT/b.json | python tools/bench_line.py
 python -c "
