@@ -334,6 +334,7 @@ struct cvd_handle_t {
     DevBuf<unsigned char> elV;
     DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart;
     DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
+    double* sqPtr = nullptr; // where the frames' restricted products live: sq, or (pair-sharded, fused exchange) behind [q | Z^T q | p.q]
   } temporal;
   // measured on this handle (cvd_solve.hip: denseRebuildThreshold): an in-line rebuild of the dense coarse level and a PCG iteration
   hipEvent_t evRebuild[2] = {nullptr, nullptr};
@@ -595,6 +596,7 @@ bool coarseFusedConsumers();
 bool fusedExchange(cvd_handle* h, bool withCoarse);
 size_t exchangeOffsetQc(const Ctx& c);
 size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
+size_t exchangeTemporalCount(cvd_handle* h, bool withCoarse);  // doubles the third level adds to the fused exchange (behind p.q)
 bool ownerShardedUpdate(cvd_handle* h, bool withCoarse);
 inline int denseRowSplit(const cvd_handle* h) { return std::min(kCB, std::max(0, h->opt.coarse_dense_row_split)); }
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);

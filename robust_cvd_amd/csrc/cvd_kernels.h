@@ -1796,11 +1796,24 @@ inline __global__ __launch_bounds__(256) void k_matvec_finish(Layout L, const do
 inline __global__ __launch_bounds__(256) void k_dot_pq(Layout L, const double* __restrict__ p, const double* __restrict__ q,
                                                 double* __restrict__ scal, unsigned int* __restrict__ counter,
                                                 double* __restrict__ fdot, double* __restrict__ qc,
-                                                const unsigned char* __restrict__ modeActive, CoarseColumns cc) {
+                                                const unsigned char* __restrict__ modeActive, CoarseColumns cc,
+                                                const TlStep* __restrict__ tsp) {
   if (scal[S_DONE] != 0.0) return;  // PCG already converged (iterations enqueued ahead)
   __shared__ double red[8];
+  __shared__ double prod[kTlMaxS * kTlMaxWidth];
   const int f = blockIdx.x, tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * L.B;
+  if (tsp != nullptr) {  // third level: spatial restriction of the all-reduced product (matvecFinishBody does it on the other paths)
+    const TlStep ts = *tsp;
+    const int nE = ts.S * ts.width;
+    for (int e = tid; e < nE; e += 256) prod[e] = static_cast<double>(ts.elW[e]) * q[base + 7 + ts.elV[e]];
+    __syncthreads();
+    if (tid < ts.S) {
+      double a = 0.0;
+      for (int k = 0; k < ts.width; ++k) a += prod[k * ts.S + tid];
+      ts.sq[static_cast<size_t>(f) * ts.S + tid] = a;
+    }
+  }
   if (qc != nullptr) {  // on the all-reduced q
     coarseRestrict(L, q + base, f, tid, modeActive, qc);
     __syncthreads();
@@ -2322,9 +2335,12 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; ypart[tid >> 6] = cY; ypart[16 + (tid >> 6)] = cT; }
     __syncthreads();
     if (tid == 0) {
-      double rzs = 0.0, rrs = 0.0, ys = 0.0;
-      for (int w = 0; w < nWaves; ++w) { rzs += red[w] + ypart[16 + w]; rrs += red[16 + w]; ys += ypart[w]; }
-      if (partOut != nullptr) {  // owner-sharded iteration: this rank's shares, summed over the ranks by k_pcg_scalars_dist
+      double rzs = 0.0, rrs = 0.0, ys = 0.0, tls = 0.0;
+      for (int w = 0; w < nWaves; ++w) { rzs += red[w]; rrs += red[16 + w]; ys += ypart[w]; tls += ypart[16 + w]; }
+      // (owner-sharded iteration: every rank walks ALL rows of the third level -- they are few -- so its part of r^T z counts once,
+      // on the first rank)
+      rzs += (partOut == nullptr || f0 == 0) ? tls : 0.0;
+      if (partOut != nullptr) {  // this rank's shares, summed over the ranks by k_pcg_scalars_dist
         partOut[0] = rzs + ((fusedY && *cs.fail != 0) ? 0.0 : ys);
         partOut[1] = rrs;
       } else if (fusedY) {  // two-level r^T z; a broken-down coarse factorisation switches the level off (consumers use c = 0)

@@ -18,6 +18,10 @@ size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse) {
 // the frames' owners ([Z^T q | p.q] all-reduced beside it, one RCCL group), every rank updates x, r, z (and its rows of the dense
 // coarse level) for ITS frames only, and z / c / the r^T z shares are all-gathered (one group): two collectives per iteration,
 // the per-frame update work divided by the number of ranks.
+size_t exchangeTemporalCount(cvd_handle* h, bool withCoarse) {
+  const TlStep ts = withCoarse ? temporalStep(h) : temporalStep(nullptr);
+  return (ts.Ainv != nullptr && h->dist() && fusedExchange(h, withCoarse)) ? static_cast<size_t>(h->F) * ts.S : 0;
+}
 bool ownerShardedUpdate(cvd_handle* h, bool withCoarse) {
   return h->dist() && fusedExchange(h, withCoarse) && h->opt.dist_owner_update != 0;
 }
@@ -186,12 +190,12 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
       const size_t chunk = static_cast<size_t>(h->ownChunk()) * B;
       commGroupStart(h);
       commReduceScatter(h, q, q + static_cast<size_t>(h->rank) * chunk, chunk, CT_F64, s);
-      commAllReduce(h, qcX, exchangeOffsetPq(c, denseFused) - exchangeOffsetQc(c) + 1, CT_F64, s);
+      commAllReduce(h, qcX, exchangeOffsetPq(c, denseFused) - exchangeOffsetQc(c) + 1 + exchangeTemporalCount(h, withCoarse), CT_F64, s);
       commGroupEnd(h);
       h->tEnd(ct);
     } else if (fusedX) {
       const int ct = h->tBegin(KC_COMM_PRODUCT);
-      commAllReduce(h, q, exchangeOffsetPq(c, denseFused) + 1, CT_F64, s);
+      commAllReduce(h, q, exchangeOffsetPq(c, denseFused) + 1 + exchangeTemporalCount(h, withCoarse), CT_F64, s);
       h->tEnd(ct);
     } else if (h->dist()) {
       // per-product exchange: q (F x B doubles) summed over the pair shards, then p.q / alpha on the reduced vector
@@ -199,7 +203,8 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
       commAllReduce(h, q, c.n, CT_F64, s);
       h->tEnd(ct);
       hipLaunchKernelGGL(k_dot_pq, dim3(c.L.F), dim3(256), 0, s, c.L, pNew, q, h->dScal.p, h->dCounters.p, h->dFdot.p,
-                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc);
+                         withCoarse ? h->coarse.qc.p : nullptr, h->coarse.modeActive.p, cc,
+                         ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
       HIP_CHECK(hipGetLastError());
     }
     h->tEnd(slot);

@@ -1116,7 +1116,8 @@ void ensureBuffers(Ctx& c) {
     HIP_CHECK(hipMemsetAsync(h->dZ.p, 0, nVec * sizeof(double), h->stream));
   }
   h->dDx.ensure(nVec); h->dR.ensure(nVec); h->dR1.ensure(n); h->dZ.ensure(nVec); h->dP0.ensure(n); h->dP1.ensure(n);
-  h->dQ.ensure(nVec + static_cast<size_t>(c.L.F) * kCB + 8);  // (+ [Z^T q | p.q]: the fused exchange of the pair-sharded mode)
+  // (+ [Z^T q | p.q | third level's restricted products]: the fused exchange of the pair-sharded mode)
+  h->dQ.ensure(nVec + static_cast<size_t>(c.L.F) * (kCB + kTlMaxS) + 8);
   h->dOwnerScal.ensure(2 * static_cast<size_t>(std::max(1, h->world)));
   h->dHd.ensure(n);
   {

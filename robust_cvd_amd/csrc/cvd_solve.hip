@@ -113,12 +113,12 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       // update the own frames, gather z / c / the r^T z shares, finish the scalars
       const int f0 = h->ownFirst(), nOwn = h->ownCount();
       const int slotO = h->tBegin(KC_CG_UPDATE);
-      if (nOwn > 0)
-        hipLaunchKernelGGL(k_cg_update, dim3(denseFused && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn),
+      if (nOwn > 0 || nTlWg)  // (a rank without frames still walks the third level's rows: every rank keeps its own copy of t / tl)
+        hipLaunchKernelGGL(k_cg_update, dim3((denseFused && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn) + nTlWg),
                            dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, h->dScal.p, h->dCounters.p + 1,
                            h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, static_cast<double*>(nullptr),
                            h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank,
-                           static_cast<const TlStep*>(nullptr));
+                           nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
       else
         HIP_CHECK(hipMemsetAsync(h->dOwnerScal.p + 2 * h->rank, 0, 2 * sizeof(double), s));
       HIP_CHECK(hipGetLastError());

@@ -61,15 +61,18 @@ __device__ __forceinline__ void tlAxis(const float* __restrict__ h, const int* _
 // ---- frame-diagonal part: C_f = Hs^T (H_ff restricted to the depth grid + diag(lam)) Hs, S x S per frame ---------------------
 // One workgroup per frame.  T1 = (H + lam) Hs in LDS ([G][S]; thread = row v, the <= 4 hats of every column vertex v' come from
 // the vertex table), then C = Hs^T T1 through the transposed table.  Frames whose depth unknowns are masked give zero.
+// (pair-sharded run: the reduced H_ff lives on the frame's owner rank -- frames outside [ownFirst, ownFirst + ownCount) give zero
+// here and the ranks' matrices are summed)
 inline __global__ __launch_bounds__(256) void k_tl_diag(Layout L, const double* __restrict__ hBlocks, const double* __restrict__ lam,
-                                                 const double* __restrict__ mask, TlTables T, double* __restrict__ Cf) {
+                                                 const double* __restrict__ mask, TlTables T, double* __restrict__ Cf, int ownFirst,
+                                                 int ownCount) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B, G = L.nD, S = T.S, f = blockIdx.x, tid = threadIdx.x;
   double* T1 = sm;                                              // [G][S]
   float* ew = reinterpret_cast<float*>(T1 + static_cast<size_t>(G) * S);   // [width][S]
   unsigned char* ev = reinterpret_cast<unsigned char*>(ew + T.width * S);
   double* out = Cf + static_cast<size_t>(f) * S * S;
-  if (mask[static_cast<size_t>(f) * B + 7] == 0.0) {
+  if (mask[static_cast<size_t>(f) * B + 7] == 0.0 || f < ownFirst || f >= ownFirst + ownCount) {
     for (int e = tid; e < S * S; e += 256) out[e] = 0.0;
     return;
   }
@@ -285,12 +288,13 @@ inline __global__ __launch_bounds__(256) void k_tl_reduce(int S, int step, const
 // ---- (node, node) blocks of A_T --------------------------------------------------------------------------------------------
 // Workgroup = block (a, b), a <= b <= a + 2 (blkA / blkB).  Its entries: the frames' C_f with w_a(f) w_b(f) (b <= a + 1) and the
 // group sums listed in gather[gPtr[blk] .. gPtr[blk + 1]): entry = 2 * part index + (1: transposed).  Written to both triangles
-// of the dense matrix (unknown e = s * nn + a, leading dimension ld; zeroed by the host), relative shift on the diagonal, empty
-// diagonal entries (no active frame under the node) become identity rows.
+// of the dense matrix (unknown e = s * nn + a, leading dimension ld; zeroed by the host).  k_tl_shift_diag follows (after the
+// ranks' matrices have been summed in a pair-sharded run): relative shift on the diagonal, empty diagonal entries (no active
+// frame under the node) become identity rows.
 inline __global__ __launch_bounds__(256) void k_tl_assemble(int S, int nn, int step, int F, int ld, const int* __restrict__ blkA,
                                                      const int* __restrict__ blkB, const int* __restrict__ gPtr,
                                                      const int* __restrict__ gather, const double* __restrict__ Cf,
-                                                     const double* __restrict__ part, double* __restrict__ Aout, double shift) {
+                                                     const double* __restrict__ part, double* __restrict__ Aout) {
   // grid (blocks, ceil(S^2 / 256)): one entry per thread, four independent sums in flight
   const int blk = blockIdx.x, SS = S * S;
   const int e = blockIdx.y * 256 + threadIdx.x;
@@ -328,11 +332,16 @@ inline __global__ __launch_bounds__(256) void k_tl_assemble(int S, int nn, int s
     v2 += gterm(k + 2);
     v3 += gterm(k + 3);
   }
-  double v = (v0 + v1) + (v2 + v3);
+  const double v = (v0 + v1) + (v2 + v3);
   const size_t r = static_cast<size_t>(s) * nn + a, c = static_cast<size_t>(sp) * nn + b;
-  if (r == c) v = v > 0.0 ? v * (1.0 + shift) : 1.0;
   Aout[r * ld + c] = v;
   if (r != c) Aout[c * ld + r] = v;
+}
+inline __global__ void k_tl_shift_diag(int n, int ld, double* __restrict__ A, double shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = A[static_cast<size_t>(i) * ld + i];
+  A[static_cast<size_t>(i) * ld + i] = v > 0.0 ? v * (1.0 + shift) : 1.0;
 }
 
 // ---- first residual of a PCG solve -------------------------------------------------------------------------------------------

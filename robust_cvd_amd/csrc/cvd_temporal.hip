@@ -13,7 +13,7 @@ static int autoCoarse(int g, int wanted) {
 bool temporalScope(const Ctx& c) {
   cvd_handle* h = c.h;
   const Layout& L = c.L;
-  if (h->opt.temporal_level == 0 || h->dist() || h->forceGeneric || h->dense || c.cross || c.trip) return false;
+  if (h->opt.temporal_level == 0 || h->forceGeneric || h->dense || c.cross || c.trip) return false;
   if (!h->coarseOn) return false;   // (the first residual's scalars are closed by the pose-graph level's kernel)
   if (c.KD != 4 || c.KS != 0 || !fastLoss(L) || L.intrOpt == CVD_INTR_SHARED) return false;
   if (L.N != 1 || L.gz != 1 || L.depthType != CVD_DEPTH_GRID || L.positionRegSqrt > 0.0 || !L.includeStatic) return false;
@@ -165,6 +165,8 @@ void temporalPrepare(Ctx& c) {
   }
   HIP_CHECK(hipMemsetAsync(T.valid.p, 0, sizeof(int), s));  // (an inverse of another problem is never kept)
   T.built = false;
+  // pair-sharded run with the fused exchange: the ranks' restricted products travel behind [q | Z^T q | p.q] in the same all-reduce
+  T.sqPtr = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetPq(c, h->coarse.denseMode) + 1 : T.sq.p;
 }
 
 static TlTables temporalTables(cvd_handle* h) {
@@ -176,7 +178,7 @@ TlStep temporalStep(cvd_handle* h) {
   if (h == nullptr || !h->temporal.on || !h->temporal.built)
     return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0};
   auto& T = h->temporal;
-  return TlStep{T.Ainv.p, T.sq.p, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width};
+  return TlStep{T.Ainv.p, T.sqPtr, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width};
 }
 
 const TlStep* temporalStepDev(cvd_handle* h) {
@@ -193,7 +195,8 @@ void launchTemporalSetup(Ctx& c, const double* x) {
   launchFrameConsts(c, x);
   const size_t ldsD = static_cast<size_t>(L.nD) * T.S * 8 + static_cast<size_t>(T.width) * T.S * 5 + 16;
   allowLds(k_tl_diag, ldsD);
-  hipLaunchKernelGGL(k_tl_diag, dim3(L.F), dim3(256), ldsD, s, L, h->dH.p, h->dLam.p, h->dMask.p, tb, T.Cf.p);
+  hipLaunchKernelGGL(k_tl_diag, dim3(L.F), dim3(256), ldsD, s, L, h->dH.p, h->dLam.p, h->dMask.p, tb, T.Cf.p,
+                     h->dist() ? h->ownFirst() : 0, h->dist() ? h->ownCount() : L.F);
   HIP_CHECK(hipGetLastError());
   if (c.nItems > 0) {
     const size_t ldsE = 2 * static_cast<size_t>(L.B) * 8 + 2 * sizeof(FrameConst) + SS * 8 + 3 * static_cast<size_t>(L.gx + L.gy) * 4 + 16;
@@ -206,10 +209,23 @@ void launchTemporalSetup(Ctx& c, const double* x) {
   }
   HIP_CHECK(hipMemsetAsync(T.A.p, 0, static_cast<size_t>(T.NT) * T.NT * sizeof(double), s));
   hipLaunchKernelGGL(k_tl_assemble, dim3(T.nBlocks, static_cast<unsigned>((SS + 255) / 256)), dim3(256), 0, s, T.S, T.nn, T.step, L.F, T.NT, T.blkA.p, T.blkB.p, T.gPtr.p,
-                     T.gather.p, T.Cf.p, T.part.p, T.A.p, h->opt.coarse_dense_shift);
+                     T.gather.p, T.Cf.p, T.part.p, T.A.p);
+  HIP_CHECK(hipGetLastError());
+  if (h->dist()) {  // every rank holds the blocks of ITS frames and pairs: the matrices add up
+    const int ct = h->tBegin(KC_COMM_COARSE);
+    commAllReduce(h, T.A.p, static_cast<size_t>(T.NT) * T.NT, CT_F64, s);
+    h->tEnd(ct);
+  }
+  hipLaunchKernelGGL(k_tl_shift_diag, dim3((T.NT + 255) / 256), dim3(256), 0, s, T.NT, T.NT, T.A.p, h->opt.coarse_dense_shift);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemsetAsync(T.fail.p, 0, sizeof(int), s));
   launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p);
+  if (h->dist()) {  // (the ranks must agree on "level on / off": see the dense pose-graph level, launchCoarseSetup)
+    hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, T.fail.p);
+    const int ct = h->tBegin(KC_COMM_COARSE);
+    commAllReduce(h, T.fail.p, 1, CT_I32, s);
+    h->tEnd(ct);
+  }
   if (!T.built) {
     T.built = true;
     const TlStep ts = temporalStep(h);

@@ -136,6 +136,24 @@ def test_two_ranks_match_the_single_gpu_solve(coarse):
     compare(ranks, single)
 
 
+@pytest.mark.parametrize("coarse", ["sparse", "dense", "dense_replicated_update"])
+def test_sharded_solves_with_the_temporal_level(coarse):
+    """The third preconditioner level (cvd_temporal.h) in a pair-sharded run: every rank adds the Galerkin blocks of ITS frames
+    and pairs (one all-reduce per build), the frames' restricted products travel behind [q | Z^T q | p.q] (dense pose-graph
+    level: fused exchange, owner-sharded or replicated update) or are restricted from the all-reduced q (sparse level: k_dot_pq),
+    every rank walks the level's rows itself.  13 frames, a temporal node every 3 (pairs reach further than a node interval);
+    two and three ranks against the single-GPU solve with the same options, which must also need fewer iterations than without."""
+    v = synth.make_video(13, 96, 56, seed=57, extra_offsets=4)
+    options = {"sparse": {}, "dense": {"coarse_update_budget": 0},
+               "dense_replicated_update": {"coarse_update_budget": 0, "dist_owner_update": 0}}[coarse]
+    options.update(temporal_level=2, temporal_step=3)
+    single = solve_single(v, options, (6, 4))
+    compare(solve_sharded(v, 2, options, (6, 4)), single)
+    ranks3 = solve_sharded(v, 3, options, (6, 4))
+    compare(ranks3[:2], single)
+    assert np.array_equal(ranks3[0][2], ranks3[2][2])
+
+
 def test_two_ranks_with_triplets_and_three_ranks():
     """Scene-flow smoothness triplets (groups sharded by index) on two ranks, and a world of three (chunks 4 + 4 + 2 of 10)."""
     v = synth.make_video(10, 96, 56, seed=53)
