@@ -334,6 +334,7 @@ struct cvd_handle_t {
     DevBuf<unsigned char> elV;
     DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart;
     DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
+    hipEvent_t evIn = nullptr, evDone = nullptr;  // fork / join of the assembly on the side stream
     double* sqPtr = nullptr; // where the frames' restricted products live: sq, or (pair-sharded, fused exchange) behind [q | Z^T q | p.q]
   } temporal;
   // measured on this handle (cvd_solve.hip: denseRebuildThreshold): an in-line rebuild of the dense coarse level and a PCG iteration
@@ -386,6 +387,8 @@ struct cvd_handle_t {
     if (hPcg) (void)hipHostFree(hPcg);
     for (auto& e : pcgEvent) if (e) (void)hipEventDestroy(e);
     for (auto& e : evRebuild) if (e) (void)hipEventDestroy(e);
+    if (temporal.evIn) (void)hipEventDestroy(temporal.evIn);
+    if (temporal.evDone) (void)hipEventDestroy(temporal.evDone);
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -614,7 +617,8 @@ void launchCoarseSetup(Ctx& c, const double* x, int side = 0);
 // third level (cvd_temporal.hip)
 bool temporalScope(const Ctx& c);
 void temporalPrepare(Ctx& c);                       // tables and work lists of this solve's problem
-void launchTemporalSetup(Ctx& c, const double* x);  // A_T for the current (H, lam, x) and its inverse
+void launchTemporalSetup(Ctx& c, const double* x, int half);  // A_T for the current (H, lam, x): 0 = its assembly (beside the
+                                                              // pose-graph level's build), 1 = its inverse
 void launchTemporalInit(Ctx& c);                    // first residual of a PCG solve: t, r_T, tl, the level's part of r^T z
 TlStep temporalStep(cvd_handle* h);                 // (Ainv == nullptr when the level is off)
 const TlStep* temporalStepDev(cvd_handle* h);       // its device copy for the kernels, nullptr when the level is off

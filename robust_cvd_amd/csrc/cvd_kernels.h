@@ -1565,10 +1565,20 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
   const bool tlOn = V.tl != nullptr;
   double* tls = cl + kCB + (FUSED ? ((nT >> 8) - 1) * 256 : 0);
   TlTaps tt[EPT];
+  // (... and the thread's first entry of the transposed table for the restriction at the end: no load left behind the product)
+  float tlW0 = 0.f;
+  int tlV0 = 0, tlEntries = 0;
   if (tlOn) {
     if (tid < V.tlS) tls[tid] = V.tl[static_cast<size_t>(f) * V.tlS + tid];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) tlLoadTaps(V, tid + e * 256, L.nD, tt[e]);
+  }
+  if (tsp != nullptr) {
+    tlEntries = tsp->S * tsp->width;
+    if (tid < tlEntries) {
+      tlW0 = tsp->elW[tid];
+      tlV0 = tsp->elV[tid];
+    }
   }
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
@@ -1743,8 +1753,8 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
     // table (entry k of hat s; fixed summation order).  (The level's descriptor is read where it is used: as a kernel argument
     // its 24 scalar registers stayed live through both halves of k_pcg_tail and cost the update half spilled operands.)
     const TlStep ts = *tsp;
-    const int nE = ts.S * ts.width;
-    for (int e = tid; e < nE; e += nT) tlPart[e] = static_cast<double>(ts.elW[e]) * qf[7 + ts.elV[e]];
+    if (tid < tlEntries) tlPart[tid] = static_cast<double>(tlW0) * qf[7 + tlV0];
+    for (int e = tid + nT; e < tlEntries; e += nT) tlPart[e] = static_cast<double>(ts.elW[e]) * qf[7 + ts.elV[e]];
     __syncthreads();
     if (tid < ts.S) {
       double a = 0.0;
@@ -1896,21 +1906,23 @@ __device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int 
   for (int e = tid; e < ts.NT; e += nThreads) {  // e = a * S + s': neighbouring lanes read neighbouring words of a frame's row
     const int a = e / ts.S, sp = e - a * ts.S;
     const int fLo = max(0, (a - 1) * ts.step + 1), fHi = min(F - 1, (a + 1) * ts.step - 1);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    auto term = [&](int f) -> double {
-      const int fc = min(f, fHi);
-      const double* src = ts.sq + static_cast<size_t>(fc) * ts.S + sp;
-      const double v = FUSED ? readPartial(src) : *src;
-      const double w = 1.0 - fabs(static_cast<double>(fc - a * ts.step)) * inv;
-      return f <= fHi ? w * v : 0.0;
-    };
-    for (int f = fLo; f <= fHi; f += 4) {
-      a0 += term(f);
-      a1 += term(f + 1);
-      a2 += term(f + 2);
-      a3 += term(f + 3);
+    // (a node has up to 2 step - 1 frames: eight independent loads per batch, the walk is latency, not bytes)
+    constexpr int kTlBatch = 8;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int f = fLo; f <= fHi; f += kTlBatch) {
+      double v[kTlBatch];
+#pragma unroll
+      for (int u = 0; u < kTlBatch; ++u) {
+        const double* src = ts.sq + static_cast<size_t>(min(f + u, fHi)) * ts.S + sp;
+        v[u] = FUSED ? readPartial(src) : *src;
+      }
+#pragma unroll
+      for (int u = 0; u < kTlBatch; ++u) {
+        const double w = 1.0 - fabs(static_cast<double>(f + u - a * ts.step)) * inv;
+        acc[u & 3] += (f + u <= fHi) ? w * v[u] : 0.0;
+      }
     }
-    qT[sp * ts.nn + a] = (a0 + a1) + (a2 + a3);
+    qT[sp * ts.nn + a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
   __syncthreads();
   if (sDone != 0.0) return false;  // uniform; nothing written yet

@@ -410,8 +410,10 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
               if (!h->evRebuild[0]) for (auto& e : h->evRebuild) HIP_CHECK(hipEventCreate(&e));
               HIP_CHECK(hipEventRecord(h->evRebuild[0], s));
             }
+            // (third level: same linearisation point and damping; its assembly runs beside the pose-graph level's build)
+            if (h->temporal.on) launchTemporalSetup(c, h->dX.p, 0);
             launchCoarseSetup(c, h->dX.p);
-            if (h->temporal.on) launchTemporalSetup(c, h->dX.p);  // (third level: same linearisation point and damping)
+            if (h->temporal.on) launchTemporalSetup(c, h->dX.p, 1);
             if (measure) {
               HIP_CHECK(hipEventRecord(h->evRebuild[1], s));
               h->rebuildTimed = true;
@@ -426,7 +428,8 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
           ++coarseAge;
           if (h->temporal.on && h->opt.temporal_level == 2) {
             const int slot = h->tBegin(KC_INVERSE);
-            launchTemporalSetup(c, h->dX.p);
+            launchTemporalSetup(c, h->dX.p, 0);
+            launchTemporalSetup(c, h->dX.p, 1);
             h->tEnd(slot);
           }
         }

@@ -169,6 +169,7 @@ void temporalPrepare(Ctx& c) {
   T.sqPtr = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetPq(c, h->coarse.denseMode) + 1 : T.sq.p;
 }
 
+static void temporalInverse(Ctx& c);
 static TlTables temporalTables(cvd_handle* h) {
   auto& T = h->temporal;
   return TlTables{T.hx.p, T.bx.p, T.hy.p, T.by.p, T.vW.p, T.vIdx.p, T.elW.p, T.elV.p, T.Sx, T.Sy, T.S, T.width};
@@ -185,14 +186,37 @@ const TlStep* temporalStepDev(cvd_handle* h) {
   return (h != nullptr && h->temporal.on && h->temporal.built) ? h->temporal.stepDev.p : nullptr;
 }
 
-void launchTemporalSetup(Ctx& c, const double* x) {
+// Two halves.  The first -- everything up to the assembled matrix -- reads only what a build of the pose-graph level reads
+// (H, lam, mask, x, the table) and writes the level's own buffers: on one GPU it runs on the side stream BESIDE that build (the
+// dense inverse of the pose-graph level is one latency-bound persistent kernel that leaves the CUs mostly idle; ~0.25 ms of
+// small kernels disappear behind it).  The second half -- the level's own inverse, a gated persistent kernel as well -- follows
+// on the solver's stream.  A pair-sharded run keeps everything on the solver's stream: its collectives must stay in one order.
+void launchTemporalSetup(Ctx& c, const double* x, int half) {
   cvd_handle* h = c.h;
   auto& T = h->temporal;
   const Layout& L = c.L;
-  hipStream_t s = h->stream;
+  const bool side = !h->dist() && h->stream2 != nullptr;
+  hipStream_t s = (half == 0 && side) ? h->stream2 : h->stream;
+  if (half == 1) {
+    if (side) HIP_CHECK(hipStreamWaitEvent(h->stream, T.evDone, 0));
+    temporalInverse(c);
+    return;
+  }
   const TlTables tb = temporalTables(h);
   const size_t SS = static_cast<size_t>(T.S) * T.S;
-  launchFrameConsts(c, x);
+  FrameConst* fcBuf = h->dFc.p;
+  if (side) {  // (its own frame constants: the solver's stream rewrites dFc; its own events: the sparse pose-graph level's
+               // asynchronous rebuild uses the handle's)
+    if (!T.evIn) {
+      HIP_CHECK(hipEventCreateWithFlags(&T.evIn, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&T.evDone, hipEventDisableTiming));
+    }
+    h->dFc2.ensure(L.F);
+    fcBuf = h->dFc2.p;
+    HIP_CHECK(hipEventRecord(T.evIn, h->stream));
+    HIP_CHECK(hipStreamWaitEvent(s, T.evIn, 0));
+  }
+  hipLaunchKernelGGL(k_frame_consts, dim3((L.F + 63) / 64), dim3(64), 0, s, L, x, fcBuf);
   const size_t ldsD = static_cast<size_t>(L.nD) * T.S * 8 + static_cast<size_t>(T.width) * T.S * 5 + 16;
   allowLds(k_tl_diag, ldsD);
   hipLaunchKernelGGL(k_tl_diag, dim3(L.F), dim3(256), ldsD, s, L, h->dH.p, h->dLam.p, h->dMask.p, tb, T.Cf.p,
@@ -201,7 +225,7 @@ void launchTemporalSetup(Ctx& c, const double* x) {
   if (c.nItems > 0) {
     const size_t ldsE = 2 * static_cast<size_t>(L.B) * 8 + 2 * sizeof(FrameConst) + SS * 8 + 3 * static_cast<size_t>(L.gx + L.gy) * 4 + 16;
     allowLds(k_tl_edges<false>, ldsE);
-    hipLaunchKernelGGL(k_tl_edges<false>, dim3(c.nItems), dim3(256), ldsE, s, L, c.T, c.it, x, h->dFc.p, h->dMask.p, tb, T.E.p);
+    hipLaunchKernelGGL(k_tl_edges<false>, dim3(c.nItems), dim3(256), ldsE, s, L, c.T, c.it, x, fcBuf, h->dMask.p, tb, T.E.p);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_tl_reduce, dim3(T.nGroups), dim3(256), 0, s, T.S, T.step, T.gOff.p, T.gItems.p, h->dItemFa.p, h->dItemFb.p,
                        T.E.p, T.part.p);
@@ -218,6 +242,13 @@ void launchTemporalSetup(Ctx& c, const double* x) {
   }
   hipLaunchKernelGGL(k_tl_shift_diag, dim3((T.NT + 255) / 256), dim3(256), 0, s, T.NT, T.NT, T.A.p, h->opt.coarse_dense_shift);
   HIP_CHECK(hipGetLastError());
+  if (side) HIP_CHECK(hipEventRecord(T.evDone, s));
+}
+
+static void temporalInverse(Ctx& c) {
+  cvd_handle* h = c.h;
+  auto& T = h->temporal;
+  hipStream_t s = h->stream;
   HIP_CHECK(hipMemsetAsync(T.fail.p, 0, sizeof(int), s));
   launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p);
   if (h->dist()) {  // (the ranks must agree on "level on / off": see the dense pose-graph level, launchCoarseSetup)

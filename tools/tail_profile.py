@@ -32,7 +32,8 @@ F = v.num_frames
 t0 = a[:, 0].min()
 us = lambda x: x / 100.0
 print("workgroups", len(a), " launch span us %.1f" % us(a[:, 4].max() - t0))
-for name, rows in (("frame workgroups", a[:F]), ("dense-level workgroups", a[F:])):
+nD = (F + 1) // 2   # dense-level workgroups (two frames each); the third level's workgroups follow
+for name, rows in (("frame workgroups", a[:F]), ("dense-level workgroups", a[F:F + nD]), ("third level's workgroups", a[F + nD:])):
     if not len(rows):
         continue
     print(name, len(rows))
