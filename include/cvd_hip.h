@@ -42,9 +42,13 @@ typedef struct cvd_solver_options {
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout; 2: + PCG scalars per iteration;
                                     3: + setup phases and the shape of the coarse elimination (development) */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
-  int32_t coarse_level;          /* 1 (default): two-level preconditioner, block-Jacobi + pose-graph coarse solve
-                                    (8 unknowns per frame), coarse factor rebuilt on demand; 2: rebuilt every LM
-                                    iteration; 0: block-Jacobi only */
+  int32_t coarse_level;          /* 1 (default): block-Jacobi + a pose-graph coarse solve (8 unknowns per frame) -- the EXACT
+                                    block-sparse factor while its elimination is cheap, else what coarse_over_budget names
+                                    (default: the temporal pose level); rebuilt on demand; 2: the same rebuilt every LM
+                                    iteration; 3: ALWAYS the TEMPORAL pose level -- the same 8 modes per frame x temporal hat
+                                    functions with a node every coarse_temporal_step frames (312 unknowns instead of 2400 at 300
+                                    frames), inverted densely, applied inside the PCG launches (cvd_temporal.h);
+                                    0: block-Jacobi only */
   int32_t robust_loss;           /* robust loss on the static flow constraints, parameter = cvd_opt_params::robustness:
                                     0 (default) ceres::CauchyLoss, what the reference hard-wires
                                     (lib/PoseOptimizer.cpp:1220); 1 ceres::HuberLoss, the stress variant of BASELINE.json
@@ -96,6 +100,11 @@ typedef struct cvd_solver_options {
   int32_t temporal_step;          /* frames between two temporal nodes (default 32) */
   int32_t temporal_grid_x;        /* coarse hats per axis; 0 (default): (grid + 1) / 2 */
   int32_t temporal_grid_y;
+  int32_t coarse_temporal_step;   /* temporal pose level: frames between two temporal nodes (default 8) */
+  int32_t coarse_over_budget;     /* coarse_level 1 / 2, what replaces the exact block-sparse factor when its elimination exceeds
+                                     coarse_update_budget (flow lists with long-range pairs from nearly every frame).  0 (default):
+                                     the TEMPORAL pose level (see coarse_level 3); 1: rounds 2-3 -- the exact level as ONE dense
+                                     inverse up to coarse_dense_max_unknowns, on a sparsified graph beyond */
 } cvd_solver_options;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

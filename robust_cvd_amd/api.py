@@ -43,6 +43,8 @@ class SolverOptions(C.Structure):
         ("temporal_step", C.c_int32),
         ("temporal_grid_x", C.c_int32),
         ("temporal_grid_y", C.c_int32),
+        ("coarse_temporal_step", C.c_int32),
+        ("coarse_over_budget", C.c_int32),
     ]
 
 

@@ -238,6 +238,8 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->temporal_step = 32;
   o->temporal_grid_x = 0;
   o->temporal_grid_y = 0;
+  o->coarse_temporal_step = 8;
+  o->coarse_over_budget = 0;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
@@ -255,14 +257,17 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
     if (o->coarse_dense_max_unknowns < 0 || o->coarse_dense_max_unknowns > kDenseCoarseMaxUnknowns)
       throw std::runtime_error(fmt("coarse_dense_max_unknowns must lie in [0, %d] (what k_dense_spd_inverse holds in registers)",
                                    kDenseCoarseMaxUnknowns));
-    if (o->coarse_level < 0 || o->coarse_level > 2 || o->robust_loss < 0 || o->robust_loss > 1 || o->block_inverse_variant < 0 ||
+    if (o->coarse_level < 0 || o->coarse_level > 3 || o->coarse_temporal_step < 2 || o->robust_loss < 0 || o->robust_loss > 1 || o->block_inverse_variant < 0 ||
         o->block_inverse_variant > 2)
-      throw std::runtime_error("coarse_level in {0, 1, 2}, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
+      throw std::runtime_error("coarse_level in {0, 1, 2, 3}, coarse_temporal_step >= 2, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
+    if (o->coarse_over_budget < 0 || o->coarse_over_budget > 1) throw std::runtime_error("coarse_over_budget in {0, 1}");
     if (o->coarse_dense_row_split < 0 || o->coarse_dense_row_split > 8) throw std::runtime_error("coarse_dense_row_split must lie in [0, 8]");
     if (o->temporal_level < 0 || o->temporal_level > 2 || o->temporal_step < 2 || o->temporal_grid_x < 0 || o->temporal_grid_y < 0 ||
         o->temporal_grid_x == 1 || o->temporal_grid_y == 1)
       throw std::runtime_error("temporal_level in {0, 1, 2}, temporal_step >= 2, temporal_grid_x / _y 0 (automatic) or >= 2");
-    if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns)
+    if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns ||
+        (o->coarse_level == 3) != (h->opt.coarse_level == 3) || o->coarse_temporal_step != h->opt.coarse_temporal_step ||
+        o->coarse_over_budget != h->opt.coarse_over_budget)
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
     h->opt = *o;
@@ -799,6 +804,17 @@ int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, doub
     auto& C = h->coarse;
     if (!C.valid || !h->coarseOn) {
       *num_unknowns = 0;
+    } else if (C.temporalPose) {
+      // temporal pose level (coarse_level 3): the node-reduced matrix (unknown = mode * nodes + node) and its inverse as stored
+      const size_t n = static_cast<size_t>(C.ptN);
+      *num_unknowns = static_cast<int32_t>(n);
+      hipStream_t s = h->stream;
+      int fl = 0;
+      C.fail.download(&fl, 1, s);
+      if (a_c) C.ptMat.download(a_c, n * n, s);
+      if (a_c_inverse) C.ptInv.download(a_c_inverse, n * n, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (failed) *failed = fl;
     } else {
       const int F = h->F;
       const size_t n = static_cast<size_t>(F) * kCB;

@@ -301,6 +301,15 @@ struct cvd_handle_t {
         updA, updB, edgeBlk, edgeFa, edgeFb, wPtr, wRow, wtPtr, wtBlk, wtCol, wtFrame, wuPtr, wuL, wuW, itemEdgeDev, wSlot;
     DevBuf<double> edges, diag, Lb, Linv, Wb, rc, qc, y, c, dotPart, fdotY, wq, dropDiag;
     bool sparsified = false;  // some frame pairs were left out of the coarse graph (sparsifyCoarseGraph)
+    // temporal pose level (coarse_level 3; cvd_temporal.h): denseMode is set as well -- same exchange layout, in-line build -- but
+    // the matrix is the node-reduced one (ptN = 8 nodes unknowns) and the PCG kernels walk it with tlLevelRows
+    bool temporalPose = false;
+    int ptNn = 0, ptStepFrames = 0, ptN = 0, ptBlocks = 0;
+    std::vector<int> edgeFaHost, edgeFbHost;
+    DevBuf<int> ptA, ptB, ptPtr, ptList;
+    DevBuf<double> ptMat, ptInv, ptR, ptT, ptDot;
+    DevBuf<TlStep> ptStepDev;   // [0]: per iteration (restricted products = Z^T q), [1]: first residual (= Z^T r)
+    DevBuf<unsigned int> ptCounter;
     // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f64 matrix, built in line by k_dense_spd_inverse
     bool denseMode = false;
     int denseForB = 0;        // frame-block size of the problem the last build was for (a coarse-to-fine level)
@@ -619,9 +628,15 @@ bool temporalScope(const Ctx& c);
 void temporalPrepare(Ctx& c);                       // tables and work lists of this solve's problem
 void launchTemporalSetup(Ctx& c, const double* x, int half);  // A_T for the current (H, lam, x): 0 = its assembly (beside the
                                                               // pose-graph level's build), 1 = its inverse
-void launchTemporalInit(Ctx& c);                    // first residual of a PCG solve: t, r_T, tl, the level's part of r^T z
+void launchTemporalInit(Ctx& c, bool closeScalars, double tol2);  // first residual of a PCG solve: t, r_T, tl, the level's part of r^T z
 TlStep temporalStep(cvd_handle* h);                 // (Ainv == nullptr when the level is off)
 const TlStep* temporalStepDev(cvd_handle* h);       // its device copy for the kernels, nullptr when the level is off
+// temporal pose level (coarse_level 3)
+void poseTemporalPlan(cvd_handle* h);                                   // node-pair lists for the compiled table's edge graph
+void poseTemporalPrepare(Ctx& c);                                       // buffers + descriptors of this solve
+void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut);      // from the coarse level's diag / edge blocks: matrix + inverse
+void launchPoseTemporalInit(Ctx& c, double tol2);                       // first residual: t, c, closes the PCG scalars
+const TlStep* poseTemporalStepDev(cvd_handle* h);                       // nullptr unless this solve uses the level
 void coarseDebug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 int runPcg(Ctx& c, const double* x, const std::function<void()>& tail = nullptr);
 bool wantsTriplets(const cvd_opt_params& p, ProblemKind kind);

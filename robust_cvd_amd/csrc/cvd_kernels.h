@@ -1989,7 +1989,8 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
                                              const unsigned char* __restrict__ modeActive,
                                              double* __restrict__ hostMirror, const CoarseStep& cs, const DenseStep& ds,
                                              const double* __restrict__ pqReduced, double* __restrict__ sm, Mid& mid,
-                                             int f0, int nF, double* __restrict__ partOut, const TlStep* __restrict__ tsp) {
+                                             int f0, int nF, double* __restrict__ partOut, const TlStep* __restrict__ tsp,
+                                             const TlStep* __restrict__ tpp) {
   // [f0, f0 + nF): the frames this launch updates -- all of them, or (owner-sharded multi-GPU iteration) the calling rank's own
   // chunk; workgroups beyond nF are the dense coarse level's, two frames of the window each.  partOut != nullptr: the last
   // workgroup leaves THIS RANK's shares {r^T z, r^T r} there instead of finishing the PCG scalars (k_pcg_scalars_dist does).
@@ -2007,8 +2008,9 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   const int f = denseWg ? L.F + (static_cast<int>(blockIdx.x) - nF) : f0 + static_cast<int>(blockIdx.x);
   // (third level: its S workgroups follow the dense level's)
   const int nDenseWg = (fusedDense && ds.rowSplit > 0) ? (nF + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0;
-  const bool tlOn = !init && tsp != nullptr;
-  const bool tlWg = tlOn && static_cast<int>(blockIdx.x) >= nF + nDenseWg;
+  // (... and the kCB of the temporal pose level, coarse_level 3, follow those: same rows routine, its own descriptor)
+  const bool tlOn = !init && tsp != nullptr, tpOn = !init && tpp != nullptr;
+  const bool tlWg = (tlOn || tpOn) && static_cast<int>(blockIdx.x) >= nF + nDenseWg;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
@@ -2088,8 +2090,9 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     __syncthreads();  // (psum is reused)
   };
   if (f >= L.F) {
-    if (tlWg) {  // third level's workgroup (one coarse hat)
-      if (!tlLevelRows<FUSED>(tsp, static_cast<int>(blockIdx.x) - nF - nDenseWg, L.F, alpha, 0, sDone, sm, mid)) return;
+    if (tlWg) {  // third level's workgroup (one coarse hat) or the temporal pose level's (one mode)
+      const int k = static_cast<int>(blockIdx.x) - nF - nDenseWg, nTl = tlOn ? tsp->S : 0;
+      if (!tlLevelRows<FUSED>(k < nTl ? tsp : tpp, k < nTl ? k : k - nTl, L.F, alpha, 0, sDone, sm, mid)) return;
     } else {
     // ---- dense-level workgroup: rows [0, rowSplit) of kDenseFramesPerGroup frames, one frame after the other (F + F / 2
     // workgroups of 768 threads still fit the device in ONE round, two per CU; F + F do not)
@@ -2339,6 +2342,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     double cT = 0.0;  // third level's part of r^T z (kept apart: a broken-down sparse factor switches ITS level off below, not this one)
     if (tlOn)
       for (int k = tid; k < tsp->S; k += nThreads) cT += readPartial(tsp->dotPart + k);
+    if (tpOn && tid < kCB) cT += readPartial(tpp->dotPart + tid);
     a = waveSum(a);
     b = waveSum(b);
     cY = waveSum(cY);
@@ -2359,7 +2363,8 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
         pcgFinishScalars(scal, 0, rzs + (*cs.fail == 0 ? ys : 0.0), rrs, tol2, hostMirror);
       } else if (fusedDense) {  // (a failed inverse left c = 0 and zero shares)
         pcgFinishScalars(scal, 0, rzs + ys, rrs, tol2, hostMirror);
-      } else if (rc != nullptr) {  // first residual: k_coarse_apply_w adds its part of r^T z and finishes the scalars
+      } else if (rc != nullptr || (init && (tsp != nullptr || tpp != nullptr))) {  // first residual: the coarse levels' kernels (k_coarse_apply_w /
+                                                               // k_coarse_dense_apply / k_tl_rows_init) add their parts of r^T z and finish the scalars
         scal[S_RZPART] = rzs;
         scal[S_RR] = rrs;
       } else {
@@ -2379,11 +2384,12 @@ inline __global__ __launch_bounds__(1024) void k_cg_update(Layout L, int init, c
                                                     const unsigned char* __restrict__ modeActive,
                                                     double* __restrict__ hostMirror, CoarseStep cs, DenseStep ds,
                                                     const double* __restrict__ pqReduced, int f0, int nF,
-                                                    double* __restrict__ partOut, const TlStep* __restrict__ tsp) {
+                                                    double* __restrict__ partOut, const TlStep* __restrict__ tsp,
+                                                    const TlStep* __restrict__ tpp) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   NoMid mid;
   cgUpdateBody<false>(L, init, g, minv, p, q, scal, counter, dx, r, z, fdotRZ, fdotRR, tol2, rc, modeActive, hostMirror, cs, ds,
-                      pqReduced, sm, mid, f0, nF, partOut, tsp);
+                      pqReduced, sm, mid, f0, nF, partOut, tsp, tpp);
 }
 
 // Owner-sharded PCG iteration (multi-GPU): every rank updated x, r, z of ITS frames and left {r^T z, r^T r} of those frames in
@@ -2516,6 +2522,7 @@ struct TailUpdate {
   int ldsScratch;          // offset of 24 doubles for the barrier flag and the p.q sum (beyond both kinds of workgroups' regions)
   DenseStep ds;
   const TlStep* ts;        // third level (device copy of its descriptor), nullptr: off
+  const TlStep* tp;        // temporal pose level (coarse_level 3), nullptr: off
 };
 
 template <int KD>
@@ -2573,7 +2580,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
     __device__ bool second(double& alpha) { return f2(alpha); }
   } mid{first, second};
   cgUpdateBody<true>(L, 0, nullptr, U.minv, nullptr, nullptr, scal, U.counter, U.dx, U.r, U.z, U.fdotRZ, U.fdotRR, U.tol2, nullptr,
-                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr, U.ts);
+                     U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr, U.ts, U.tp);
   TAIL_STAMP(4);
 }
 

@@ -19,16 +19,16 @@ size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse) {
 // coarse level) for ITS frames only, and z / c / the r^T z shares are all-gathered (one group): two collectives per iteration,
 // the per-frame update work divided by the number of ranks.
 size_t exchangeTemporalCount(cvd_handle* h, bool withCoarse) {
-  const TlStep ts = withCoarse ? temporalStep(h) : temporalStep(nullptr);
+  const TlStep ts = temporalStep(h);
   return (ts.Ainv != nullptr && h->dist() && fusedExchange(h, withCoarse)) ? static_cast<size_t>(h->F) * ts.S : 0;
 }
 bool ownerShardedUpdate(cvd_handle* h, bool withCoarse) {
   return h->dist() && fusedExchange(h, withCoarse) && h->opt.dist_owner_update != 0;
 }
 CoarseView coarseView(cvd_handle* h, bool on, bool walk) {
-  if (!on) return CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto& C = h->coarse;
-  CoarseView v{C.pos.p, C.wPtr.p, C.wRow.p, walk ? C.Wb.p : nullptr, C.y.p, C.modeActive.p, C.fail.p, C.c.p};
+  CoarseView v = on ? CoarseView{C.pos.p, C.wPtr.p, C.wRow.p, walk ? C.Wb.p : nullptr, C.y.p, C.modeActive.p, C.fail.p, C.c.p}
+                    : CoarseView{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (h->temporal.on && h->temporal.built) {  // third level: its per-frame coefficients and the vertex table of the prolongation
     v.tl = h->temporal.tl.p;
     v.tlW = h->temporal.vW.p;
@@ -158,7 +158,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
   }
   if (!tailFused) {
     if (B > 512) throw std::runtime_error("frame block larger than 512 unknowns is not supported by k_matvec_finish");
-    const TlStep ts = withCoarse ? temporalStep(h) : temporalStep(nullptr);
+    const TlStep ts = temporalStep(h);
     // xf, pf, qf + red[6] + flag + coarse correction (+ third level: its coefficients and the restriction's products)
     const size_t lds = 3 * B * 8 + (8 + kCB) * 8 + (ts.Ainv != nullptr ? (kTlMaxS + static_cast<size_t>(ts.S) * ts.width) * 8 : 0);
     // column half of the fused coarse update y <- y - alpha W (Z^T q) (the row half is in k_cg_update)
@@ -220,14 +220,17 @@ bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish
   if (!h->opt.pcg_fused_tail || h->dist() || B > 256 || h->forceGeneric) return false;
   if (coarse && !h->coarse.denseMode) return false;
   const int split = denseRowSplit(h);
-  const TlStep ts = coarse ? temporalStep(h) : temporalStep(nullptr);
+  const TlStep ts = temporalStep(h);
   // (third level: S more workgroups; the restriction's products of a frame use the update half's partial-sum region)
   if (ts.Ainv != nullptr && (ts.S * ts.width > cgUpdatePartDoubles(B, nThreads) || ts.NT + 2 * ts.nn > B + cgUpdatePartDoubles(B, nThreads)))
     return false;
-  const int grid = F + (coarse && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) + (ts.Ainv != nullptr ? ts.S : 0);
+  const bool poseT = coarse && h->coarse.temporalPose;  // (coarse_level 3: kCB workgroups walk the node-reduced inverse, no dense-level ones)
+  if (poseT && h->coarse.ptN + 2 * h->coarse.ptNn > B + cgUpdatePartDoubles(B, nThreads)) return false;
+  const int grid = F + (coarse && !poseT && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) +
+                   (ts.Ainv != nullptr ? ts.S : 0) + (poseT ? kCB : 0);
   const int update = B + cgUpdatePartDoubles(B, nThreads) + 48 + 17 * kCB;  // k_cg_update's region (cvd_solve.hip: ldsU)
   const int finish = 3 * B + 8 + kCB + (nThreads / 256 - 1) * 256 + kTlMaxS;  // k_matvec_finish's + the partial sums of its row walk + the third level's coefficients
-  const int denseEnd = coarse ? F * kCB + nThreads + 16 : 0;                // the dense-level workgroups' (Z^T q + partial sums)
+  const int denseEnd = (coarse && !poseT) ? F * kCB + nThreads + 16 : 0;    // the dense-level workgroups' (Z^T q + partial sums)
   ldsFinish = update;
   // (frame workgroups that walk rows of the dense level themselves: Z^T q + partial sums behind their two regions)
   ldsScratch = std::max(update + finish + (coarse && split < kCB ? denseEnd : 0), denseEnd);
@@ -262,16 +265,19 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
   const CoarseView cF = coarseView(h, withCoarse, false);
   const int split = denseRowSplit(h);
   const int finishDoubles = 3 * static_cast<int>(c.L.B) + 8 + kCB + (nThreads / 256 - 1) * 256 + kTlMaxS;  // (pcgTailScope)
-  const TlStep ts = withCoarse ? temporalStep(h) : temporalStep(nullptr);
-  const DenseStep ds = withCoarse ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p,
+  const TlStep ts = temporalStep(h);
+  const bool poseT = withCoarse && h->coarse.temporalPose;
+  const DenseStep ds = (withCoarse && !poseT) ? DenseStep{h->coarse.denseInv.p, h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p, h->coarse.dotPart.p,
                                                h->coarse.modeActive.p, h->coarse.fail.p, split, ldsFinish + finishDoubles,
                                                h->coarse.dotPart.p + F}
                                   : DenseStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kCB, 0, nullptr};
   double* fd = h->dFdot.p;
   const TailUpdate U{h->dMinv.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, h->coarse.modeActive.p, h->hPcg,
                      h->dCounters.p + 1, h->dTailBar.p, h->dFdot.p + 4 * static_cast<size_t>(F) + 32, ldsFinish, ldsScratch, ds,
-                     ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr)};
-  const int grid = F + (withCoarse && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) + (ts.Ainv != nullptr ? ts.S : 0);
+                     ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr),
+                     poseT ? poseTemporalStepDev(h) : static_cast<const TlStep*>(nullptr)};
+  const int grid = F + (withCoarse && !poseT && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) +
+                   (ts.Ainv != nullptr ? ts.S : 0) + (poseT ? kCB : 0);
   const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)
   {
     // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate)

@@ -230,6 +230,21 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     // dense level: A_c assembled from the same blocks and inverted by ONE persistent kernel on the f64 matrix cores
     // (cvd_dense_inverse.h), f32 inverse out; in line on the solver's stream
     if (side) throw std::logic_error("the dense coarse level is built in line");
+    if (C.temporalPose) {
+      // temporal pose level: the same blocks reduced over the temporal hats, n = 8 nodes instead of 8 frames unknowns
+      C.denseValid.ensure(1);
+      if (!(C.denseReady && C.denseForB == static_cast<int>(c.L.B))) HIP_CHECK(hipMemsetAsync(C.denseValid.p, 0, sizeof(int), s));
+      launchPoseTemporalBuild(c, s, failOut);
+      if (h->dist()) {
+        hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, failOut);
+        const int ct = h->tBegin(KC_COMM_COARSE);
+        commAllReduce(h, failOut, 1, CT_I32, s);
+        h->tEnd(ct);
+      }
+      C.denseReady = true;
+      C.denseForB = c.L.B;
+      return;
+    }
     const int n = c.L.F * kCB;
     C.denseA.ensure(static_cast<size_t>(n) * n);
     C.denseInv.ensure(static_cast<size_t>(n) * n);

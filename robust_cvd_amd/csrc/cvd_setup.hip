@@ -569,6 +569,8 @@ static void buildCoarsePlan(cvd_handle* h, const std::vector<std::pair<int, int>
     edgeFb.push_back(e.second);
   }
   C.nEdges = static_cast<int>(edgeList.size());
+  C.edgeFaHost = edgeFa;
+  C.edgeFbHost = edgeFb;
   C.nBlocks = nBlocks;
   C.nLevels = nLevels;
   C.itemEdge = itemEdge;
@@ -898,7 +900,15 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     h->coarse.denseMode = false;
     const int denseMaxUnknowns = h->opt.coarse_dense_max_unknowns;
     const bool overBudget = coarseEliminationUpdates(h->F, edgeList) > updateBudget;
-    if (overBudget && h->F * kCB <= denseMaxUnknowns) {
+    // coarse_level 3: the temporal pose level (cvd_temporal.h) -- every pair kept, the node-reduced matrix inverted densely
+    {
+      const int stepP = std::max(2, h->opt.coarse_temporal_step);
+      const bool fits = ((h->F - 1 + stepP - 1) / stepP + 1) * kCB <= kDenseCoarseMaxUnknowns;
+      h->coarse.temporalPose = fits && (h->opt.coarse_level == 3 || (overBudget && h->opt.coarse_over_budget == 0));
+    }
+    if (h->coarse.temporalPose) {
+      h->coarse.denseMode = true;  // (same exchange layout and in-line build as the dense exact level)
+    } else if (overBudget && h->F * kCB <= denseMaxUnknowns) {
       h->coarse.denseMode = true;  // small enough to invert as a dense matrix: keeps every pair (cvd_coarse.h)
     } else if (overBudget) {
       std::vector<int> newId(edgeList.size(), -1);
@@ -913,6 +923,7 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
       edgeList.swap(kept);
     }
     buildCoarsePlan(h, edgeList, itemEdge);
+    if (h->coarse.temporalPose) poseTemporalPlan(h);
     if (h->dense) {  // edge block of every cross pair (cvd_cross.h: k_coarse_edges_cross)
       std::map<std::pair<int, int>, int> edgeOfPair;
       for (size_t i = 0; i < h->itemFa.size(); ++i) edgeOfPair[{h->itemFa[i], h->itemFb[i]}] = itemEdge[i];

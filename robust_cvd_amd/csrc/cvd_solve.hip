@@ -31,7 +31,14 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       hipLaunchKernelGGL(k_coarse_apply_wt, dim3(F), dim3(256), 0, s, coarseView(h, true, true), F, h->coarse.c.p,
                          h->dScal.p, init);
   };
+  // coarse_level 3: the temporal pose level -- dense-mode plumbing (exchange layout, in-line build), but its rows are walked by
+  // kCB extra workgroups of the update launch (tlLevelRows) and no workgroup streams an 8F x 8F inverse
+  const bool poseT = denseCoarse && h->coarse.temporalPose;
   auto coarseApply = [&](int init) {
+    if (poseT) {
+      launchPoseTemporalInit(c, tol2);  // (first residual only: the iterations carry the level inside k_cg_update / k_pcg_tail)
+      return;
+    }
     if (denseCoarse) {
       hipLaunchKernelGGL(k_coarse_dense_apply, dim3(F), dim3(256), 0, s, F, h->coarse.denseInv.p, h->coarse.rc.p, h->coarse.c.p,
                          h->coarse.modeActive.p, h->coarse.dotPart.p, h->dScal.p, h->dCounters.p + 3, h->coarse.fail.p, init,
@@ -54,28 +61,33 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   // pair-sharded mode with the fused exchange (cvd_matvec.hip): Z^T q and p.q arrive all-reduced behind q
   const bool fusedX = h->dist() && fusedExchange(h, coarse);
   const double* pqReduced = fusedX ? h->dQ.p + exchangeOffsetPq(c, denseFused) : nullptr;
-  const DenseStep dsOn = denseFused ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + exchangeOffsetQc(c) : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
+  const bool denseRows = denseFused && !poseT;
+  const DenseStep dsOn = denseRows ? DenseStep{h->coarse.denseInv.p, fusedX ? h->dQ.p + exchangeOffsetQc(c) : h->coarse.qc.p, h->coarse.rc.p, h->coarse.c.p,
                                                 h->coarse.dotPart.p, h->coarse.modeActive.p, h->coarse.fail.p,
                                                 // (two launches: the split costs 2 % -- the frame workgroups are this kernel's long
                                                 // pole already; it pays in k_pcg_tail, whose DenseStep launchPcgTail builds)
                                                 kCB, static_cast<int>(ldsU / 8), h->coarse.dotPart.p + F}
                                     : dsOff;
-  if (denseFused) {
+  if (denseRows) {
     // (dense-level workgroups: Z^T q + partial sums; frame workgroups walking rows of their own: the same again behind their region)
     const size_t dense = static_cast<size_t>(F) * kCB + nThreads + 16;
     ldsU = std::max((dsOn.rowSplit < kCB ? ldsU / 8 + dense : ldsU / 8), dense) * 8;
   }
   // third level (cvd_temporal.h): S more workgroups of the update launch (q_T and the coefficients of one coarse hat in LDS)
-  const TlStep tsOff = temporalStep(nullptr);
-  const TlStep tsOn = coarse ? temporalStep(h) : tsOff;
+  const TlStep tsOn = temporalStep(h);
   const int nTlWg = tsOn.Ainv != nullptr ? tsOn.S : 0;
   if (nTlWg) ldsU = std::max(ldsU, (static_cast<size_t>(tsOn.NT) + 2 * tsOn.nn) * 8);
+  const int nPtWg = poseT ? kCB : 0;
+  if (poseT) ldsU = std::max(ldsU, (static_cast<size_t>(h->coarse.ptN) + 2 * h->coarse.ptNn) * 8);
+  const TlStep* tpDev = poseT ? poseTemporalStepDev(h) : nullptr;
   allowLds(k_cg_update, ldsU);
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
                      h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, rc,
                      h->coarse.modeActive.p, h->hPcg, csOff, dsOff, static_cast<const double*>(nullptr), 0, F,
-                     static_cast<double*>(nullptr), static_cast<const TlStep*>(nullptr));
-  if (nTlWg) launchTemporalInit(c);  // (adds the level's part of r^T z before the dense level's kernel closes the scalars)
+                     static_cast<double*>(nullptr), nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr),
+                     static_cast<const TlStep*>(nullptr));
+  // (adds the level's part of r^T z before the pose-graph level's kernel closes the scalars -- or closes them itself)
+  if (nTlWg) launchTemporalInit(c, !coarse, tol2);
   if (coarse) coarseApply(1);
   HIP_CHECK(hipGetLastError());
   double* pOld = h->dP0.p;
@@ -113,12 +125,12 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       // update the own frames, gather z / c / the r^T z shares, finish the scalars
       const int f0 = h->ownFirst(), nOwn = h->ownCount();
       const int slotO = h->tBegin(KC_CG_UPDATE);
-      if (nOwn > 0 || nTlWg)  // (a rank without frames still walks the third level's rows: every rank keeps its own copy of t / tl)
-        hipLaunchKernelGGL(k_cg_update, dim3((denseFused && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn) + nTlWg),
+      if (nOwn > 0 || nTlWg || nPtWg)  // (a rank without frames still walks the temporal levels' rows: every rank keeps its own copy of t / tl)
+        hipLaunchKernelGGL(k_cg_update, dim3((denseRows && dsOn.rowSplit > 0 ? nOwn + (nOwn + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : nOwn) + nTlWg + nPtWg),
                            dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew, h->dQ.p, h->dScal.p, h->dCounters.p + 1,
                            h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, static_cast<double*>(nullptr),
                            h->coarse.modeActive.p, h->hPcg, csOff, dsOn, pqReduced, f0, nOwn, h->dOwnerScal.p + 2 * h->rank,
-                           nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
+                           nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr), tpDev);
       else
         HIP_CHECK(hipMemsetAsync(h->dOwnerScal.p + 2 * h->rank, 0, 2 * sizeof(double), s));
       HIP_CHECK(hipGetLastError());
@@ -127,7 +139,7 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       const size_t chunkF = static_cast<size_t>(h->ownChunk());
       commGroupStart(h);
       commAllGather(h, h->dZ.p + h->rank * chunkF * B, h->dZ.p, chunkF * B, CT_F64, s);
-      if (denseFused) commAllGather(h, h->coarse.c.p + h->rank * chunkF * kCB, h->coarse.c.p, chunkF * kCB, CT_F64, s);
+      if (denseRows) commAllGather(h, h->coarse.c.p + h->rank * chunkF * kCB, h->coarse.c.p, chunkF * kCB, CT_F64, s);
       commAllGather(h, h->dOwnerScal.p + 2 * h->rank, h->dOwnerScal.p, 2, CT_F64, s);
       commGroupEnd(h);
       h->tEnd(ct);
@@ -137,10 +149,10 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
       return;
     }
     const int slot = h->tBegin(KC_CG_UPDATE);
-    hipLaunchKernelGGL(k_cg_update, dim3((denseFused && dsOn.rowSplit > 0 ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F) + nTlWg), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
+    hipLaunchKernelGGL(k_cg_update, dim3((denseRows && dsOn.rowSplit > 0 ? F + (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : F) + nTlWg + nPtWg), dim3(nThreads), ldsU, s, c.L, 0, h->dG.p, h->dMinv.p, pNew,
                        h->dQ.p, h->dScal.p, h->dCounters.p + 1, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2,
                        (coarse && unfusedY && !denseFused) ? rc : nullptr, h->coarse.modeActive.p, h->hPcg, csOn, dsOn, pqReduced,
-                       0, F, static_cast<double*>(nullptr), nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
+                       0, F, static_cast<double*>(nullptr), nTlWg ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr), tpDev);
     if (coarse && !denseFused) { if (unfusedY) coarseApply(0); else coarseC(0); }
     HIP_CHECK(hipGetLastError());
     h->tEnd(slot);
@@ -260,6 +272,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   ensureBuffers(c);
   h->temporal.on = temporalScope(c);
   if (h->temporal.on) temporalPrepare(c);
+  if (h->coarseOn && h->coarse.temporalPose) poseTemporalPrepare(c);
   phase("buffers");
   buildMask(h, c.L, p, kind, range);
   phase("mask");
@@ -432,6 +445,21 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
             launchTemporalSetup(c, h->dX.p, 1);
             h->tEnd(slot);
           }
+        }
+      }
+      if (!h->coarseOn && h->temporal.on) {
+        // third level without a pose-graph level (coarse_level 0): rebuilt by the same rule -- at the first iteration, then once
+        // the PCG iterations spent beyond the count seen right after the last build add up to the threshold (level 2: every iteration)
+        if (coarseAge < 0 || h->opt.temporal_level == 2 || cgExcess >= kCoarseRebuildIters) {
+          const int slot = h->tBegin(KC_INVERSE);
+          launchTemporalSetup(c, h->dX.p, 0);
+          launchTemporalSetup(c, h->dX.p, 1);
+          h->tEnd(slot);
+          coarseAge = 0;
+          cgExcess = 0;
+          freshFactor = true;
+        } else {
+          ++coarseAge;
         }
       }
       // one read-back for the PCG result, the step statistics and the cost of the candidate point (the

@@ -344,6 +344,46 @@ inline __global__ void k_tl_shift_diag(int n, int ld, double* __restrict__ A, do
   A[static_cast<size_t>(i) * ld + i] = v > 0.0 ? v * (1.0 + shift) : 1.0;
 }
 
+// ---- TEMPORAL POSE LEVEL (cvd_solver_options::coarse_level = 3) -----------------------------------------------------------------
+// The pose-graph level restricted to temporally smooth corrections: the frame's 8 modes (cvd_coarse.h: 7 pose-like unknowns + the
+// uniform depth-scale mode) x temporal hats with a node every `step` frames (default 8: 39 nodes, 312 unknowns at 300 frames,
+// against 2400 for the exact level).  Its Galerkin matrix is a weighted sum of the very 8 x 8 blocks the exact level is made of
+// (k_coarse_diag, k_coarse_edges*): block (a, b), a <= b, of node pairs = sum over frames under both hats of w_a w_b D_f + sum
+// over the listed edges (entry = 2 * edge + (1: the edge's block transposed, i.e. node a is the edge's SECOND frame)) of
+// w_a w_b E_e.  One wave per node pair, lane = (i, j); fixed order (the ranks of a sharded run build the same bits).  Unknown
+// e = mode * nn + node, as the third level's (tlLevelRows serves both).  Inactive modes contribute nothing; k_tl_shift_diag turns
+// their empty diagonal into identity rows.
+inline __global__ __launch_bounds__(64) void k_pt_assemble(int nn, int step, int F, int ld, const int* __restrict__ blkA,
+                                                    const int* __restrict__ blkB, const int* __restrict__ ptr,
+                                                    const int* __restrict__ list, const double* __restrict__ diag,
+                                                    const double* __restrict__ edges, const int* __restrict__ edgeFa,
+                                                    const int* __restrict__ edgeFb, const unsigned char* __restrict__ modeActive,
+                                                    double* __restrict__ A) {
+  const int blk = blockIdx.x, tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+  const int a = blkA[blk], b = blkB[blk];
+  if (a == b && i > j) return;  // (a diagonal block is symmetric: its upper triangle is computed and mirrored)
+  const double inv = 1.0 / static_cast<double>(step);
+  auto hat = [&](int node, int f) -> double { return fmax(0.0, 1.0 - fabs(static_cast<double>(f - node * step)) * inv); };
+  double v = 0.0;
+  if (b <= a + 1) {
+    const int fLo = max(0, (b - 1) * step + 1), fHi = min(F - 1, (a + 1) * step - 1);
+    for (int f = fLo; f <= fHi; ++f)
+      if (modeActive[f * kCB + i] && modeActive[f * kCB + j]) v += hat(a, f) * hat(b, f) * diag[static_cast<size_t>(f) * kCBB + tid];
+  }
+  for (int k = ptr[blk]; k < ptr[blk + 1]; ++k) {
+    const int en = list[k], e = en >> 1;
+    const int fa = edgeFa[e], fb = edgeFb[e];  // block stored rows = fa, columns = fb
+    if (en & 1) {
+      if (modeActive[fb * kCB + i] && modeActive[fa * kCB + j]) v += hat(a, fb) * hat(b, fa) * edges[static_cast<size_t>(e) * kCBB + j * kCB + i];
+    } else {
+      if (modeActive[fa * kCB + i] && modeActive[fb * kCB + j]) v += hat(a, fa) * hat(b, fb) * edges[static_cast<size_t>(e) * kCBB + tid];
+    }
+  }
+  const size_t r = static_cast<size_t>(i) * nn + a, c = static_cast<size_t>(j) * nn + b;
+  A[r * ld + c] = v;
+  if (r != c) A[c * ld + r] = v;
+}
+
 // ---- first residual of a PCG solve -------------------------------------------------------------------------------------------
 // sq[f][s] = spatial restriction of the (masked) residual of frame f
 inline __global__ __launch_bounds__(256) void k_tl_restrict(Layout L, const double* __restrict__ r, const TlStep* __restrict__ tsp) {
@@ -366,7 +406,8 @@ inline __global__ __launch_bounds__(256) void k_tl_restrict(Layout L, const doub
 // t = A_T^-1 P^T r, r_T = P^T r, tl, and the level's part of r^T z added to S_RZPART (k_cg_update(init) left the block-Jacobi part
 // there; the pose-graph level's kernel closes the scalars afterwards)
 inline __global__ __launch_bounds__(1024) void k_tl_rows_init(const TlStep* __restrict__ tsp, int F, double* __restrict__ scal,
-                                                       unsigned int* __restrict__ counter) {
+                                                       unsigned int* __restrict__ counter, int closeScalars, double tol2,
+                                                       double* __restrict__ hostMirror) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int flag;
   NoMid mid;
@@ -376,7 +417,8 @@ inline __global__ __launch_bounds__(1024) void k_tl_rows_init(const TlStep* __re
   if (threadIdx.x == 0) {
     double d = 0.0;
     for (int s = 0; s < tsp->S; ++s) d += readPartial(tsp->dotPart + s);
-    scal[S_RZPART] += d;
+    if (closeScalars) pcgFinishScalars(scal, 1, scal[S_RZPART] + d, scal[S_RR], tol2, hostMirror);
+    else scal[S_RZPART] += d;
   }
 }
 

@@ -14,7 +14,6 @@ bool temporalScope(const Ctx& c) {
   cvd_handle* h = c.h;
   const Layout& L = c.L;
   if (h->opt.temporal_level == 0 || h->forceGeneric || h->dense || c.cross || c.trip) return false;
-  if (!h->coarseOn) return false;   // (the first residual's scalars are closed by the pose-graph level's kernel)
   if (c.KD != 4 || c.KS != 0 || !fastLoss(L) || L.intrOpt == CVD_INTR_SHARED) return false;
   if (L.N != 1 || L.gz != 1 || L.depthType != CVD_DEPTH_GRID || L.positionRegSqrt > 0.0 || !L.includeStatic) return false;
   if (L.B > 256 || L.nD > 256 || L.gx < 3 || L.gy < 3 || L.nD != L.gx * L.gy) return false;
@@ -166,7 +165,7 @@ void temporalPrepare(Ctx& c) {
   HIP_CHECK(hipMemsetAsync(T.valid.p, 0, sizeof(int), s));  // (an inverse of another problem is never kept)
   T.built = false;
   // pair-sharded run with the fused exchange: the ranks' restricted products travel behind [q | Z^T q | p.q] in the same all-reduce
-  T.sqPtr = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetPq(c, h->coarse.denseMode) + 1 : T.sq.p;
+  T.sqPtr = (h->dist() && fusedExchange(h, h->coarseOn)) ? h->dQ.p + exchangeOffsetPq(c, h->coarseOn && h->coarse.denseMode) + 1 : T.sq.p;
 }
 
 static void temporalInverse(Ctx& c);
@@ -266,7 +265,8 @@ static void temporalInverse(Ctx& c) {
   }
 }
 
-void launchTemporalInit(Ctx& c) {
+// closeScalars: no pose-graph level follows whose kernel would finish the PCG scalars of the first residual
+void launchTemporalInit(Ctx& c, bool closeScalars, double tol2) {
   cvd_handle* h = c.h;
   auto& T = h->temporal;
   hipStream_t s = h->stream;
@@ -276,8 +276,111 @@ void launchTemporalInit(Ctx& c) {
   hipLaunchKernelGGL(k_tl_restrict, dim3(c.L.F), dim3(256), ldsR, s, c.L, h->dR.p, temporalStepDev(h));
   const size_t ldsI = (static_cast<size_t>(T.NT) + 2 * T.nn) * 8;
   allowLds(k_tl_rows_init, ldsI);
-  hipLaunchKernelGGL(k_tl_rows_init, dim3(T.S), dim3(512), ldsI, s, temporalStepDev(h), c.L.F, h->dScal.p, T.counter.p);
+  hipLaunchKernelGGL(k_tl_rows_init, dim3(T.S), dim3(512), ldsI, s, temporalStepDev(h), c.L.F, h->dScal.p, T.counter.p,
+                     closeScalars ? 1 : 0, tol2, h->hPcg);
   HIP_CHECK(hipGetLastError());
+}
+
+// ---- temporal pose level (coarse_level 3; k_pt_assemble in cvd_temporal.h) ------------------------------------------------------
+static int poseTemporalStep(const cvd_handle* h) { return std::max(2, h->opt.coarse_temporal_step); }
+
+// Node-pair lists for the edge graph of the compiled table (compileTable, after buildCoarsePlan): a frame lies under the hats of
+// node f / step and -- unless it sits on a node -- of the next one.
+void poseTemporalPlan(cvd_handle* h) {
+  auto& C = h->coarse;
+  hipStream_t s = h->stream;
+  const int step = poseTemporalStep(h), F = h->F;
+  const int nn = (F - 1 + step - 1) / step + 1;
+  std::map<std::pair<int, int>, std::vector<int>> blocks;  // (a, b), a <= b -> entries 2 * edge + transposed
+  for (int a = 0; a < nn; ++a) {
+    blocks[{a, a}];
+    if (a + 1 < nn) blocks[{a, a + 1}];
+  }
+  auto nodes = [&](int f, int out[2]) {
+    out[0] = f / step;
+    int n = 1;
+    if (f % step != 0 && out[0] + 1 < nn) out[n++] = out[0] + 1;
+    return n;
+  };
+  for (size_t e = 0; e < C.edgeFaHost.size(); ++e) {
+    int na[2], nb[2];
+    const int ca = nodes(C.edgeFaHost[e], na), cb = nodes(C.edgeFbHost[e], nb);
+    for (int x = 0; x < ca; ++x)
+      for (int y = 0; y < cb; ++y) {
+        const int en = 2 * static_cast<int>(e);
+        if (na[x] < nb[y]) blocks[{na[x], nb[y]}].push_back(en);
+        else if (na[x] > nb[y]) blocks[{nb[y], na[x]}].push_back(en + 1);
+        else { blocks[{na[x], na[x]}].push_back(en); blocks[{na[x], na[x]}].push_back(en + 1); }
+      }
+  }
+  std::vector<int> blkA, blkB, ptr{0}, list;
+  for (auto& b : blocks) {
+    blkA.push_back(b.first.first);
+    blkB.push_back(b.first.second);
+    list.insert(list.end(), b.second.begin(), b.second.end());
+    ptr.push_back(static_cast<int>(list.size()));
+  }
+  if (list.empty()) list.push_back(0);
+  C.ptA.upload(blkA.data(), blkA.size(), s);
+  C.ptB.upload(blkB.data(), blkB.size(), s);
+  C.ptPtr.upload(ptr.data(), ptr.size(), s);
+  C.ptList.upload(list.data(), list.size(), s);
+  HIP_CHECK(hipStreamSynchronize(s));
+  C.ptNn = nn;
+  C.ptStepFrames = step;
+  C.ptN = nn * kCB;
+  C.ptBlocks = static_cast<int>(blkA.size());
+}
+
+void poseTemporalPrepare(Ctx& c) {
+  cvd_handle* h = c.h;
+  auto& C = h->coarse;
+  hipStream_t s = h->stream;
+  const size_t n = static_cast<size_t>(C.ptN);
+  C.ptMat.ensure(n * n);
+  C.ptInv.ensure(n * n);
+  C.ptR.ensure(n);
+  C.ptT.ensure(n);
+  C.ptDot.ensure(kCB);
+  if (!C.ptCounter.p) {
+    C.ptCounter.ensure(4);
+    HIP_CHECK(hipMemsetAsync(C.ptCounter.p, 0, 4 * sizeof(unsigned int), s));
+  }
+  // restricted products: Z^T q where the finish half of the product leaves it (behind q in a pair-sharded run: the fused
+  // exchange), Z^T r of the first residual in rc; the frames' corrections go where the consumers of the exact level read them (c)
+  double* qc = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetQc(c) : C.qc.p;
+  TlStep st[2];
+  st[0] = TlStep{C.ptInv.p, qc, C.ptR.p, C.ptT.p, C.c.p, C.ptDot.p, C.fail.p, nullptr, nullptr, kCB, C.ptNn, C.ptStepFrames, C.ptN, C.ptN, 0};
+  st[1] = st[0];
+  st[1].sq = C.rc.p;
+  C.ptStepDev.ensure(2);
+  HIP_CHECK(hipMemcpyAsync(C.ptStepDev.p, st, sizeof(st), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut) {
+  cvd_handle* h = c.h;
+  auto& C = h->coarse;
+  HIP_CHECK(hipMemsetAsync(C.ptMat.p, 0, static_cast<size_t>(C.ptN) * C.ptN * sizeof(double), s));
+  hipLaunchKernelGGL(k_pt_assemble, dim3(C.ptBlocks), dim3(64), 0, s, C.ptNn, C.ptStepFrames, c.L.F, C.ptN, C.ptA.p, C.ptB.p, C.ptPtr.p,
+                     C.ptList.p, C.diag.p, C.edges.p, C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.ptMat.p);
+  hipLaunchKernelGGL(k_tl_shift_diag, dim3((C.ptN + 255) / 256), dim3(256), 0, s, C.ptN, C.ptN, C.ptMat.p, h->opt.coarse_dense_shift);
+  HIP_CHECK(hipGetLastError());
+  launchDenseSpdInverse(h, C.ptN, C.ptMat.p, C.ptInv.p, failOut, s, C.denseValid.p);
+}
+
+void launchPoseTemporalInit(Ctx& c, double tol2) {
+  cvd_handle* h = c.h;
+  auto& C = h->coarse;
+  const size_t lds = (static_cast<size_t>(C.ptN) + 2 * C.ptNn) * 8;
+  allowLds(k_tl_rows_init, lds);
+  hipLaunchKernelGGL(k_tl_rows_init, dim3(kCB), dim3(512), lds, h->stream, C.ptStepDev.p + 1, c.L.F, h->dScal.p, C.ptCounter.p, 1, tol2,
+                     h->hPcg);
+  HIP_CHECK(hipGetLastError());
+}
+
+const TlStep* poseTemporalStepDev(cvd_handle* h) {
+  return (h != nullptr && h->coarseOn && h->coarse.temporalPose && h->coarse.denseReady) ? h->coarse.ptStepDev.p : nullptr;
 }
 
 void touchModule_temporal() {

@@ -60,6 +60,7 @@ def test_default_solver_options():
     assert o.coarse_dense_max_unknowns == 4096 and o.coarse_update_budget == 40000 and o.coarse_dense_shift == 1e-5
     assert o.constraint_order == 1
     assert (o.temporal_level, o.temporal_step, o.temporal_grid_x, o.temporal_grid_y) == (1, 32, 0, 0)
+    assert (o.coarse_temporal_step, o.coarse_over_budget) == (8, 0)
     assert (o.force_sharded_path, o.dense_matrix_free, o.block_inverse_variant, o.pcg_lockstep, o.force_iterations, o.verbose) == (0,) * 6
     csrc = os.path.join(ROOT, "robust_cvd_amd", "csrc")
     for f in os.listdir(csrc):
@@ -101,7 +102,7 @@ def test_solver_options_are_validated():
     assert b"struct_size" in lib.cvd_last_error(s._h)
     for field, bad in (("pcg_relative_tolerance", 0.0), ("pcg_relative_tolerance", float("nan")), ("pcg_max_iterations", 0),
                        ("coarse_dense_shift", -1.0), ("coarse_rebuild_excess", -1), ("coarse_dense_max_unknowns", 1 << 20),
-                       ("coarse_level", 3), ("coarse_dense_row_split", 9), ("temporal_level", 3), ("temporal_step", 1), ("temporal_grid_x", 1)):
+                       ("coarse_level", 4), ("coarse_temporal_step", 1), ("coarse_over_budget", 2), ("coarse_dense_row_split", 9), ("temporal_level", 3), ("temporal_step", 1), ("temporal_grid_x", 1)):
         lib.cvd_solver_options_default(C.byref(o))
         setattr(o, field, bad)
         assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0, field

@@ -714,7 +714,7 @@ def test_dense_coarse_level_over_several_solves(Solver, tol):
         return out
 
     ref = run({}, 1)[0]   # (this small graph factorises exactly: the sparse level)
-    runs = run({"coarse_update_budget": 0}, 3)
+    runs = run({"coarse_update_budget": 0, "coarse_over_budget": 1}, 3)
     for sm, poses, theta in runs:
         assert sm["termination"] == 0
         if tol is None:
@@ -727,7 +727,7 @@ def test_dense_coarse_level_over_several_solves(Solver, tol):
             assert np.isfinite(sm["final_cost"]) and sm["final_cost"] <= sm["initial_cost"]
 
 
-@pytest.mark.parametrize("variant", ["dense", "sparsified"])
+@pytest.mark.parametrize("variant", ["dense", "sparsified", "temporal"])
 def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant):
     """Flow lists whose frame graph fills in under elimination (long-range pairs from nearly every frame) get the DENSE
     coarse level (A_c + coarse_dense_shift diag(A_c) inverted by k_dense_spd_inverse, applied as an f64 matrix) while 8 F <= 4096, a SPARSIFIED coarse graph beyond
@@ -750,18 +750,23 @@ def test_coarse_level_variants_for_dense_pair_graphs(Solver, variant):
         return s
 
     ref = run({})
-    options = {"coarse_update_budget": 0}
+    options = {"coarse_update_budget": 0, "coarse_over_budget": 1}
     if variant == "sparsified":
         options["coarse_dense_max_unknowns"] = 0
+    if variant == "temporal":   # the default for such graphs since round 4: the temporal pose level (cvd_temporal.h), here a node every 4 frames
+        options = {"coarse_update_budget": 0, "coarse_temporal_step": 4}
     s = run(options)
     dbg = s.coarse_debug()
     assert dbg is not None and dbg["failed"] == 0
     A, Ai = dbg["a_c"], dbg["a_c_inverse"]
     assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max() and np.linalg.eigvalsh(A)[0] > 0.0
+    if variant == "temporal":   # the node-reduced matrix (shift included): 8 modes x 7 nodes
+        assert A.shape == (8 * 7, 8 * 7)
     if variant == "dense":   # the level inverts A_c + shift diag(A_c) (cvd_solver_options::coarse_dense_shift, default 1e-5)
         A = A + 1e-5 * np.diag(np.diag(A))
     err = np.abs(Ai @ A - np.eye(A.shape[0])).max()
-    assert err < (1e-6 if variant == "dense" else 1e-8), err
+    # (explicit f64 inverses of matrices whose gauge directions carry only the damping: cond ~1e7)
+    assert err < (1e-8 if variant == "sparsified" else 1e-5), err
     assert np.linalg.eigvalsh(0.5 * (Ai + Ai.T))[0] > 0.0   # what is applied is positive definite
     if variant == "sparsified":   # fewer off-diagonal blocks than the full graph of the reference run
         Aref = ref.coarse_debug()["a_c"]
@@ -845,7 +850,8 @@ def test_two_level_preconditioner(Solver):
     assert a["total_linear_iterations"] * 1.5 <= b["total_linear_iterations"]   # (20 frames: 48 vs 87; 300 frames: ~5x)
 
 
-@pytest.mark.parametrize("case", ["dense_coarse", "no_coarse", "dense_coarse_triplets", "global_only", "dense_coarse_temporal"])
+@pytest.mark.parametrize("case", ["dense_coarse", "no_coarse", "dense_coarse_triplets", "global_only", "dense_coarse_temporal",
+                                  "temporal_pose", "temporal_pose_and_depth"])
 def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
     """k_pcg_tail (finish + update of a PCG iteration in ONE launch with a grid barrier between the halves: one GPU, frame block
     <= 256, dense coarse level or none) against the two launches it replaces (cvd_solver_options::pcg_fused_tail = 0): the same
@@ -864,9 +870,13 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
         if case == "no_coarse":
             opts["coarse_level"] = 0
         else:
-            opts["coarse_update_budget"] = 0   # the dense coarse level
+            opts["coarse_update_budget"], opts["coarse_over_budget"] = 0, 1   # the dense (exact) coarse level
         if case == "dense_coarse_temporal":    # + the third level (24 frames: a temporal node every 8)
             opts["temporal_level"], opts["temporal_step"] = 2, 8
+        if case.startswith("temporal_pose"):   # the temporal pose level instead of the dense exact one (a node every 4 frames)
+            opts["coarse_over_budget"], opts["coarse_temporal_step"] = 0, 4
+            if case.endswith("depth"):
+                opts["temporal_level"], opts["temporal_step"] = 2, 8
         s.set_options(**opts)
         s.reset_depth_xforms(XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())

@@ -126,5 +126,6 @@ def test_level_saves_iterations_on_the_benchmarked_problem(Solver):
         assert sm["termination"] == 0 and perr < 1e-3 and rerr < 1e-3, (lvl, perr, rerr)
         assert abs(sm["final_cost"] - float(ref["final_cost"])) <= 1e-6 * float(ref["final_cost"])
     assert out[0][0]["num_iterations"] == out[1][0]["num_iterations"]
-    # measured 1093 -> 888 over the whole pipeline, 50 -> 35 per LM iteration at the final level (profiles/r04_*)
-    assert out[1][0]["total_linear_iterations"] < 0.88 * out[0][0]["total_linear_iterations"], (out[0][0], out[1][0])
+    # measured over the whole pipeline: 1046 -> 932 with the temporal pose level (the default for this pair graph), 1093 -> 888 with
+    # the exact dense one; 50 -> 34 per LM iteration at the final level (profiles/r04_*)
+    assert out[1][0]["total_linear_iterations"] < 0.93 * out[0][0]["total_linear_iterations"], (out[0][0], out[1][0])

@@ -120,17 +120,21 @@ def compare(ranks, single):
     assert ranks[0][3]["num_iterations"] == ranks[1][3]["num_iterations"]
 
 
-@pytest.mark.parametrize("coarse", ["sparse", "dense", "sparsified", "off", "dense_replicated_update", "off_replicated_update"])
+@pytest.mark.parametrize("coarse", ["sparse", "dense", "sparsified", "off", "dense_replicated_update", "off_replicated_update",
+                                    "temporal", "temporal_replicated_update"])
 def test_two_ranks_match_the_single_gpu_solve(coarse):
     """Odd frame count (owner chunks of 5 + 4 frames, one padded frame), default coarse-to-fine pipeline on a small grid.
     dense / off run the OWNER-SHARDED PCG iteration (q reduce-scattered to the frames' owners, the update on the own frames only,
     z / c / the r^T z shares all-gathered: two grouped collectives per iteration); *_replicated_update the round-3 scheme (q
     all-reduced, the update replicated: cvd_solver_options::dist_owner_update = 0); sparse / sparsified the q-only exchange."""
     v = synth.make_video(9, 96, 56, seed=52, extra_offsets=4)
-    options = {"sparse": {}, "dense": {"coarse_update_budget": 0},
-               "sparsified": {"coarse_update_budget": 0, "coarse_dense_max_unknowns": 0}, "off": {"coarse_level": 0},
-               "dense_replicated_update": {"coarse_update_budget": 0, "dist_owner_update": 0},
-               "off_replicated_update": {"coarse_level": 0, "dist_owner_update": 0}}[coarse]
+    options = {"sparse": {}, "dense": {"coarse_update_budget": 0, "coarse_over_budget": 1},
+               "sparsified": {"coarse_update_budget": 0, "coarse_over_budget": 1, "coarse_dense_max_unknowns": 0}, "off": {"coarse_level": 0},
+               "dense_replicated_update": {"coarse_update_budget": 0, "coarse_over_budget": 1, "dist_owner_update": 0},
+               "off_replicated_update": {"coarse_level": 0, "dist_owner_update": 0},
+               # the temporal pose level (a node every 3 of the 9 frames): every rank walks its rows itself
+               "temporal": {"coarse_level": 3, "coarse_temporal_step": 3},
+               "temporal_replicated_update": {"coarse_level": 3, "coarse_temporal_step": 3, "dist_owner_update": 0}}[coarse]
     single = solve_single(v, options, (6, 4))
     ranks = solve_sharded(v, 2, options, (6, 4))
     compare(ranks, single)
@@ -144,8 +148,8 @@ def test_sharded_solves_with_the_temporal_level(coarse):
     every rank walks the level's rows itself.  13 frames, a temporal node every 3 (pairs reach further than a node interval);
     two and three ranks against the single-GPU solve with the same options, which must also need fewer iterations than without."""
     v = synth.make_video(13, 96, 56, seed=57, extra_offsets=4)
-    options = {"sparse": {}, "dense": {"coarse_update_budget": 0},
-               "dense_replicated_update": {"coarse_update_budget": 0, "dist_owner_update": 0}}[coarse]
+    options = {"sparse": {}, "dense": {"coarse_update_budget": 0, "coarse_over_budget": 1},
+               "dense_replicated_update": {"coarse_update_budget": 0, "coarse_over_budget": 1, "dist_owner_update": 0}}[coarse]
     options.update(temporal_level=2, temporal_step=3)
     single = solve_single(v, options, (6, 4))
     compare(solve_sharded(v, 2, options, (6, 4)), single)
@@ -160,8 +164,8 @@ def test_two_ranks_with_triplets_and_three_ranks():
     trip = synth.make_triplets(v, spacing=20.0)
     single = solve_single(v, {}, (6, 4), trip, (0.5, 0.25))
     compare(solve_sharded(v, 2, {}, (6, 4), trip, (0.5, 0.25)), single)
-    ranks3 = solve_sharded(v, 3, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25))
-    compare(ranks3[:2], solve_single(v, {"coarse_update_budget": 0}, (6, 4), trip, (0.5, 0.25)))
+    ranks3 = solve_sharded(v, 3, {"coarse_update_budget": 0, "coarse_over_budget": 1}, (6, 4), trip, (0.5, 0.25))
+    compare(ranks3[:2], solve_single(v, {"coarse_update_budget": 0, "coarse_over_budget": 1}, (6, 4), trip, (0.5, 0.25)))
     assert np.array_equal(ranks3[0][2], ranks3[2][2])
 
 
@@ -174,7 +178,7 @@ def test_two_ranks_dense_mode(product):
     from robust_cvd_amd import api
     v = synth.make_video(7, 96, 56, seed=55)
     flow, mask = synth.make_dense_flows(v)
-    opts = {"dense_matrix_free": int(product == "matrix_free"), "coarse_update_budget": 0}
+    opts = {"dense_matrix_free": int(product == "matrix_free"), "coarse_update_budget": 0, "coarse_over_budget": 1}
 
     def run(world, rank, key):
         s = api.Solver(0)

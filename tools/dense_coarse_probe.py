@@ -15,7 +15,7 @@ v = synth.make_video(7, 96, 56, seed=55)
 flow, mask = synth.make_dense_flows(v)
 for r in range(runs):
     s = api.Solver(0)
-    s.set_options(dense_matrix_free=mf, coarse_update_budget=0)
+    s.set_options(dense_matrix_free=mf, coarse_update_budget=0, coarse_over_budget=1)
     if shift is not None:
         s.set_options(coarse_dense_shift=shift)
     s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
