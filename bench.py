@@ -473,7 +473,8 @@ def main():
                              f"PerFrame intrinsics, default solver options"),
                 "pairs": int(m["full"]["pairs"]), "constraints": int(n_active), "unknowns": int(frames * B),
                 "parallelism": "single-gpu" if world == 1 else (f"pair-sharded dp{world} + RCCL" if shard else "video-per-gpu"),
-                "linear_solver": "PCG on matrix-free J^T J, two-level preconditioner (per-frame block-Jacobi + pose-graph coarse level)",
+                "linear_solver": ("PCG on matrix-free J^T J, additive three-level preconditioner: per-frame block-Jacobi + pose-graph level (8 modes per frame; exact "
+                             "sparse factor or, for this pair graph, its temporally coarse form) + temporally coarse depth-grid level"),
                 "pcg_iterations_per_lm_iteration": m["total_cg"] / max(1, args.steps),
                 "solves_in_timed_region": m["n_solves"],
             },

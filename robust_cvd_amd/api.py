@@ -45,6 +45,7 @@ class SolverOptions(C.Structure):
         ("temporal_grid_y", C.c_int32),
         ("coarse_temporal_step", C.c_int32),
         ("coarse_over_budget", C.c_int32),
+        ("temporal_weight", C.c_double),
     ]
 
 
@@ -123,7 +124,7 @@ class Solver(Binding):
         for k, v in variants.items():  # force_sharded_path, dense_matrix_free, block_inverse_variant, pcg_lockstep, coarse_*
             if k not in dict(SolverOptions._fields_):
                 raise TypeError(f"unknown solver option {k!r}")
-            setattr(o, k, float(v) if k == "coarse_dense_shift" else int(v))
+            setattr(o, k, float(v) if k in ("coarse_dense_shift", "temporal_weight") else int(v))
         self._check(self._fn("set_solver_options")(self._h, C.byref(o)))
 
     def set_robust_loss(self, kind):

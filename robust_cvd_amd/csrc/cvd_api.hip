@@ -240,6 +240,7 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->temporal_grid_y = 0;
   o->coarse_temporal_step = 8;
   o->coarse_over_budget = 0;
+  o->temporal_weight = 0.7;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
@@ -261,6 +262,7 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
         o->block_inverse_variant > 2)
       throw std::runtime_error("coarse_level in {0, 1, 2, 3}, coarse_temporal_step >= 2, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
     if (o->coarse_over_budget < 0 || o->coarse_over_budget > 1) throw std::runtime_error("coarse_over_budget in {0, 1}");
+    if (!(o->temporal_weight > 0.0 && o->temporal_weight <= 2.0)) throw std::runtime_error("temporal_weight must lie in (0, 2]");
     if (o->coarse_dense_row_split < 0 || o->coarse_dense_row_split > 8) throw std::runtime_error("coarse_dense_row_split must lie in [0, 8]");
     if (o->temporal_level < 0 || o->temporal_level > 2 || o->temporal_step < 2 || o->temporal_grid_x < 0 || o->temporal_grid_y < 0 ||
         o->temporal_grid_x == 1 || o->temporal_grid_y == 1)

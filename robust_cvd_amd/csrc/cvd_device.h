@@ -950,6 +950,7 @@ struct TlStep {
   const float* elW;          // transposed vertex table of the restriction, ELL: entry k of hat s at [k * S + s]
   const unsigned char* elV;  //   its vertex
   int S, nn, step, NT, ld, width;
+  double weight;             // the level enters the additive preconditioner as weight * P A^-1 P^T (cvd_solver_options::temporal_weight)
 };
 // One wave: out[0..7] = c_f (zero for inactive modes / a failed factorisation).  lane = (r, c) of the 8x8 block.
 __device__ __forceinline__ void coarseFrameCorrection(const CoarseView& V, int f, int lane, double* __restrict__ out) {

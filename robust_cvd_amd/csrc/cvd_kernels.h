@@ -1938,7 +1938,7 @@ __device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int 
       acc1 += row[c + 64] * qT[c + 64];
     }
     if (c < ts.NT) acc0 += row[c] * qT[c];
-    const double d = waveSum(acc0 + acc1);
+    const double d = ts.weight * waveSum(acc0 + acc1);
     if (lane == 0) {
       double rn, tv;
       if (init) {

@@ -176,9 +176,10 @@ static TlTables temporalTables(cvd_handle* h) {
 
 TlStep temporalStep(cvd_handle* h) {
   if (h == nullptr || !h->temporal.on || !h->temporal.built)
-    return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0};
+    return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 1.0};
   auto& T = h->temporal;
-  return TlStep{T.Ainv.p, T.sqPtr, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width};
+  return TlStep{T.Ainv.p, T.sqPtr, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width,
+                h->opt.temporal_weight};
 }
 
 const TlStep* temporalStepDev(cvd_handle* h) {
@@ -350,7 +351,8 @@ void poseTemporalPrepare(Ctx& c) {
   // exchange), Z^T r of the first residual in rc; the frames' corrections go where the consumers of the exact level read them (c)
   double* qc = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetQc(c) : C.qc.p;
   TlStep st[2];
-  st[0] = TlStep{C.ptInv.p, qc, C.ptR.p, C.ptT.p, C.c.p, C.ptDot.p, C.fail.p, nullptr, nullptr, kCB, C.ptNn, C.ptStepFrames, C.ptN, C.ptN, 0};
+  st[0] = TlStep{C.ptInv.p, qc, C.ptR.p, C.ptT.p, C.c.p, C.ptDot.p, C.fail.p, nullptr, nullptr, kCB, C.ptNn, C.ptStepFrames, C.ptN, C.ptN, 0,
+                 h->opt.temporal_weight};
   st[1] = st[0];
   st[1].sq = C.rc.p;
   C.ptStepDev.ensure(2);

@@ -16,7 +16,7 @@ CMD_MAIN="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary
 $B --steps 20 --warmup 3 --time-all-kernels > $OUT/bench_allkernels.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 20 --warmup 3 --no-kernel-timing > $OUT/trace.log 2>&1
 # SQ counters of the PCG kernels and the dense inverse (wave cycles: parked / issue-stalled / active; VALU and LDS activity)
-K="k_matvec_pairs_fast|k_pcg_tail|k_cg_update|k_matvec_finish|k_dense_spd_inverse"
+K="k_matvec_pairs_fast|k_pcg_tail|k_cg_update|k_matvec_finish|k_dense_spd_inverse|k_tl_edges|k_coarse_edges_fast"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_a -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_sq_a.log 2>&1
 # BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 300 frames)
 python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
@@ -36,6 +36,12 @@ timeout 200 python $R/tools/shard_sim.py 8 --replicated 2>/dev/null | grep "^wor
 [ -f $R/robust_cvd_amd/lib/libcvd_hip_tailprof.so ] && timeout 200 python $R/tools/tail_profile.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/tail_profile.log
 # the two-launch tail for comparison (cvd_solver_options::pcg_fused_tail = 0)
 $B --steps 20 --warmup 3 --time-all-kernels --opt pcg_fused_tail=0 > $OUT/bench_allkernels_two_launch_tail.json 2>> $OUT/bench.err
+# the preconditioner's levels one by one: round 3's (exact dense pose-graph level, no temporal depth-grid level), + the depth-grid level,
+# + the temporal pose level at weight 1 (the default adds temporal_weight = 0.7)
+$B --steps 20 --warmup 3 --opt coarse_over_budget=1 --opt temporal_level=0 > $OUT/bench_levels_round3.json 2>> $OUT/bench.err
+$B --steps 20 --warmup 3 --opt coarse_over_budget=1 --opt temporal_weight=1 > $OUT/bench_levels_depth_grid.json 2>> $OUT/bench.err
+$B --steps 20 --warmup 3 --opt temporal_weight=1 > $OUT/bench_levels_temporal_pose.json 2>> $OUT/bench.err
+timeout 300 python $R/tools/parity_probe.py "eta=1e-3" "eta=1e-3,temporal_weight=1" "eta=1e-3,coarse_over_budget=1,temporal_weight=1" "eta=1e-3,coarse_over_budget=1,temporal_level=0" 2>/dev/null | grep "^config" > $OUT/parity_probe_levels.log
 timeout 200 python $R/tools/dense_coarse_probe.py 4 0 2>/dev/null | cut -c1-120 > $OUT/dense_coarse_probe.log
 # summaries (small, committed under profiles/)
 python $R/tools/kernel_durations.py $OUT/trace $TAG "$CMD_MAIN" > $OUT/kernel_durations.txt 2>&1
@@ -43,4 +49,6 @@ python $R/tools/pmc_summary.py $OUT/pmc_sq_a $OUT/pmc_SQ_a.csv > /dev/null 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc_fetch_dense $OUT/pmc_FETCH_SIZE_dense.csv > /dev/null 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc_sq_a $OUT/pmc_fetch_dense
+for f in round3 depth_grid temporal_pose; do python -c "import json; d=json.loads(open('$OUT/bench_levels_$f.json').read().strip().splitlines()[-1]); print('levels_$f', round(d['value'],1), d['ms_per_step'], d['config']['pcg_iterations_per_lm_iteration'])"; done
+cat $OUT/parity_probe_levels.log
 tail -c 300 $OUT/bench.json; echo; for f in config4_cauchy config4_huber dense_300; do python -c "import sys,json; d=json.loads(open('$OUT/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['constraints'])"; done; head -12 $OUT/kernel_durations.txt | cut -c1-200; cat $OUT/pmc_matvec_pairs.json | head -12; head -6 $OUT/pmc_SQ_a.csv; cat $OUT/shard_sim.log $OUT/dense_coarse_probe.log $OUT/dinv_bench.log
