@@ -918,6 +918,9 @@ struct CoarseView {
 };
 constexpr int kTlMaxS = 64;          // coarse hats per temporal node (LDS regions of the consumers: 2 x kTlMaxS doubles)
 constexpr int kTlMaxWidth = 32;      // vertices in the support of one coarse hat (transposed table, ELL)
+constexpr int kTlSpan = 10;          // node intervals per workgroup of a temporal level (TlStep::span): 11 rows, one per wave
+__host__ __device__ inline int tlParts(int nn) { return nn > 1 ? (nn - 1 + kTlSpan - 1) / kTlSpan : 1; }
+__host__ __device__ inline int tlRowsLds(int NT) { return NT + 2 * (kTlSpan + 1) + 2; }  // doubles of LDS of such a workgroup
 struct TlTaps {
   float4 w;
   unsigned int idx;
@@ -943,13 +946,16 @@ struct TlStep {
   const double* Ainv;        // [NT][ld] f64
   double* sq;                // [F][S]
   double* rT;                // [NT] P^T r
-  double* t;                 // [NT] A_T^-1 P^T r
+  double* t;                 // [2][NT] A_T^-1 P^T r, double-buffered by the parity of the iteration count
   double* tl;                // [F][S] out (CoarseView::tl of the next product)
-  double* dotPart;           // [S] shares of r^T P t
+  double* dotPart;           // [S * parts] shares of r^T P t
   const int* fail;
   const float* elW;          // transposed vertex table of the restriction, ELL: entry k of hat s at [k * S + s]
   const unsigned char* elV;  //   its vertex
   int S, nn, step, NT, ld, width;
+  int parts, span;           // the hat's nodes are walked by `parts` workgroups, `span` node intervals each (rows per workgroup = span + 1)
+  double* rec;               // [NT] 16-byte records of the node sums' exchange inside k_pcg_tail (tlLevelRows), nullptr: every
+                             // workgroup sums all of sq itself
   double weight;             // the level enters the additive preconditioner as weight * P A^-1 P^T (cvd_solver_options::temporal_weight)
 };
 // One wave: out[0..7] = c_f (zero for inactive modes / a failed factorisation).  lane = (r, c) of the 8x8 block.

@@ -307,7 +307,7 @@ struct cvd_handle_t {
     int ptNn = 0, ptStepFrames = 0, ptN = 0, ptBlocks = 0;
     std::vector<int> edgeFaHost, edgeFbHost;
     DevBuf<int> ptA, ptB, ptPtr, ptList;
-    DevBuf<double> ptMat, ptInv, ptR, ptT, ptDot;
+    DevBuf<double> ptMat, ptInv, ptR, ptT, ptDot, ptRec;
     DevBuf<TlStep> ptStepDev;   // [0]: per iteration (restricted products = Z^T q), [1]: first residual (= Z^T r)
     DevBuf<unsigned int> ptCounter;
     // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f64 matrix, built in line by k_dense_spd_inverse
@@ -341,7 +341,7 @@ struct cvd_handle_t {
     DevBuf<float4> vW;
     DevBuf<unsigned int> vIdx, counter;
     DevBuf<unsigned char> elV;
-    DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart;
+    DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart, rec;
     DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
     hipEvent_t evIn = nullptr, evDone = nullptr;  // fork / join of the assembly on the side stream
     double* sqPtr = nullptr; // where the frames' restricted products live: sq, or (pair-sharded, fused exchange) behind [q | Z^T q | p.q]

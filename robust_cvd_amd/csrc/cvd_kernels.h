@@ -1887,52 +1887,136 @@ __host__ __device__ inline int cgUpdatePartDoubles(int B, int nThreads) {
 // rows need them all), the hat's nn rows of the inverse (one wave per row), t <- t - alpha A_T^-1 q_T, r_T <- r_T - alpha q_T, the
 // hat's share of r^T P t, and the temporal interpolation of the new t for every frame (tl).  init: t = A_T^-1 q_T, r_T = q_T with
 // sq = the restriction of the first residual.  LDS: NT + 2 nn doubles at sm.  Returns false when nothing was written.
+#ifdef CVD_TAIL_PROFILE  // tools/tail_profile.py: wall-clock (100 MHz) stamps of k_pcg_tail's workgroups
+__device__ unsigned long long g_tailProf[1024 * 8];
+#define TAIL_STAMP(slot) do { if (threadIdx.x == 0) g_tailProf[(blockIdx.x & 1023) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(slot) do {} while (0)
+#endif
+
 struct NoMid {  // (the kernels that are not k_pcg_tail: nothing happens between the halves)
   __device__ bool first(double&, double&) { return true; }
   __device__ bool second(double&) { return true; }
+  __device__ unsigned int generation() { return 0u; }
 };
+typedef unsigned int cvd_u32x4 __attribute__((ext_vector_type(4)));
 template <bool FUSED, typename Mid>
-__device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int s, int F, double& alpha, int init, double sDone,
-                                            double* __restrict__ sm, Mid& mid) {
+__device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int wg, int F, double& alpha, int init, double sDone,
+                                            const double* __restrict__ scal, double* __restrict__ sm, Mid& mid) {
   const TlStep ts = *tsp;
   const int tid = threadIdx.x, nThreads = blockDim.x;
-  double* qT = sm;           // [S][nn]
-  double* tn = qT + ts.NT;   // nn new coefficients of this hat
-  double* red = tn + ts.nn;  // nn products t r_T
+  const int wv = tid >> 6, lane = tid & 63, nW = nThreads >> 6;
+  // Workgroup = (hat s, node range): nodes [aLo, aHi] with aHi shared with the next range (both walk its row -- the frames between
+  // two nodes need both coefficients -- the next range OWNS it: writes it, counts it).  One row per wave: span + 1 <= waves.
+  const int s = wg / ts.parts, part = wg - s * ts.parts;
+  const int aLo = part * ts.span, aHi = min(ts.nn - 1, aLo + ts.span), nA = aHi - aLo + 1;
+  const bool ownsLast = part == ts.parts - 1;
+  // t is double-buffered (a shared row's old coefficient is read by two workgroups while its owner writes the new one): iteration
+  // k (S_ITERS = k - 1 applied) reads buffer (k - 1) & 1 and writes the other; the first residual writes buffer 0
+  const int par = init ? 1 : (static_cast<int>(scal[S_ITERS]) & 1);
+  const double* tin = ts.t + static_cast<size_t>(par) * ts.NT;
+  double* tout = ts.t + static_cast<size_t>(par ^ 1) * ts.NT;
+  double* qT = sm;                 // [S][nn]
+  double* tn = qT + ts.NT;         // span + 1 new coefficients of this hat
+  double* red = tn + ts.span + 1;  // span + 1 products t r_T, [span + 1 .. ]: flag
+  // (the coefficients the wave's first row updates depend on nothing this launch computes: requested before the grid barrier.
+  // The row itself as well -- 8 doubles per lane -- spills at the 80 registers of k_pcg_tail.)
+  double rOldPre = 0.0, tOldPre = 0.0;
+  if (lane == 0 && !init) {
+    const int e = s * ts.nn + aLo + (wv < nA ? wv : 0);
+    rOldPre = ts.rT[e];
+    tOldPre = tin[e];
+  }
   if constexpr (FUSED) {
     if (!mid.second(alpha)) return false;
   }
   const double inv = 1.0 / static_cast<double>(ts.step);
-  for (int e = tid; e < ts.NT; e += nThreads) {  // e = a * S + s': neighbouring lanes read neighbouring words of a frame's row
-    const int a = e / ts.S, sp = e - a * ts.S;
-    const int fLo = max(0, (a - 1) * ts.step + 1), fHi = min(F - 1, (a + 1) * ts.step - 1);
-    // (a node has up to 2 step - 1 frames: eight independent loads per batch, the walk is latency, not bytes)
-    constexpr int kTlBatch = 8;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int f = fLo; f <= fHi; f += kTlBatch) {
-      double v[kTlBatch];
-#pragma unroll
-      for (int u = 0; u < kTlBatch; ++u) {
-        const double* src = ts.sq + static_cast<size_t>(min(f + u, fHi)) * ts.S + sp;
-        v[u] = FUSED ? readPartial(src) : *src;
+  bool direct = true;
+  if constexpr (FUSED) {
+    if (ts.rec != nullptr) {
+      // Node sums through the other workgroups of the level: every hat's workgroup sums ITS hat over the frames of each node (one
+      // load per lane, one wave per node), the first range's publishes the nn sums as 16-byte records {generation, value,
+      // generation}, and everybody collects the NT records -- 1 + 1 round trips instead of (2 step - 1) / 8 batches of loads
+      // of the whole sq.  The generation is the grid barrier's (unique per launch; records zeroed with the barrier's words).
+      direct = false;
+      const unsigned int gen = mid.generation() + 1u;
+      cvd_u32x4* rec = reinterpret_cast<cvd_u32x4*>(ts.rec);
+      for (int a = wv; a < ts.nn; a += nW) {
+        const int f = (a - 1) * ts.step + 1 + lane;
+        const bool in = lane < 2 * ts.step - 1 && f >= 0 && f < F;
+        double v = in ? readPartial(ts.sq + static_cast<size_t>(f) * ts.S + s) : 0.0;
+        v *= 1.0 - fabs(static_cast<double>(f - a * ts.step)) * inv;
+        v = waveSum(in ? v : 0.0);
+        if (lane == 0 && part == 0) {
+          cvd_u32x4 r4;
+          r4.x = gen;
+          r4.y = static_cast<unsigned int>(__double2loint(v));
+          r4.z = static_cast<unsigned int>(__double2hiint(v));
+          r4.w = gen;
+          *reinterpret_cast<volatile cvd_u32x4*>(rec + s * ts.nn + a) = r4;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < kTlBatch; ++u) {
-        const double w = 1.0 - fabs(static_cast<double>(f + u - a * ts.step)) * inv;
-        acc[u & 3] += (f + u <= fHi) ? w * v[u] : 0.0;
+      int* bad = reinterpret_cast<int*>(red + ts.span + 1);
+      if (tid == 0) *bad = 0;
+      __syncthreads();
+      for (int e = tid; e < ts.NT; e += nThreads) {
+        const volatile cvd_u32x4* src = reinterpret_cast<const volatile cvd_u32x4*>(rec + e);
+        cvd_u32x4 r4;
+        unsigned int spins = 0;
+        for (;;) {
+          r4 = *src;
+          if (r4.x == gen && r4.w == gen) break;
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 20)) {  // (a workgroup of the level is not resident: give up, the host reports the stalled PCG)
+            *bad = 1;
+            break;
+          }
+        }
+        qT[e] = __hiloint2double(static_cast<int>(r4.z), static_cast<int>(r4.y));
       }
+      __syncthreads();
+      if (*bad) return false;
     }
-    qT[sp * ts.nn + a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
-  __syncthreads();
+  if (direct) {
+    for (int e = tid; e < ts.NT; e += nThreads) {  // e = a * S + s': neighbouring lanes read neighbouring words of a frame's row
+      const int a = e / ts.S, sp = e - a * ts.S;
+      const int fLo = max(0, (a - 1) * ts.step + 1), fHi = min(F - 1, (a + 1) * ts.step - 1);
+      // (a node has up to 2 step - 1 frames: eight independent loads per batch, the walk is latency, not bytes)
+      constexpr int kTlBatch = 8;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int f = fLo; f <= fHi; f += kTlBatch) {
+        double v[kTlBatch];
+#pragma unroll
+        for (int u = 0; u < kTlBatch; ++u) {
+          const double* src = ts.sq + static_cast<size_t>(min(f + u, fHi)) * ts.S + sp;
+          v[u] = FUSED ? readPartial(src) : *src;
+        }
+#pragma unroll
+        for (int u = 0; u < kTlBatch; ++u) {
+          const double w = 1.0 - fabs(static_cast<double>(f + u - a * ts.step)) * inv;
+          acc[u & 3] += (f + u <= fHi) ? w * v[u] : 0.0;
+        }
+      }
+      qT[sp * ts.nn + a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    __syncthreads();
+  }
   if (sDone != 0.0) return false;  // uniform; nothing written yet
-  const int wv = tid >> 6, lane = tid & 63, nW = nThreads >> 6;
+  if constexpr (FUSED) TAIL_STAMP(5);
   const bool on = *ts.fail == 0;
-  for (int a = wv; a < ts.nn; a += nW) {
-    const int e = s * ts.nn + a;
+  for (int k = wv; k < nA; k += nW) {
+    const int a = aLo + k, e = s * ts.nn + a;
     const double* row = ts.Ainv + static_cast<size_t>(e) * ts.ld;
+    const bool owned = ownsLast || a < aHi;
+    // (what the row's update needs besides the product: requested with the row)
+    double rOld = rOldPre, tOld = tOldPre;
     double acc0 = 0.0, acc1 = 0.0;
     int c = lane;
+    if (k != wv && lane == 0 && !init) {
+      rOld = ts.rT[e];
+      tOld = tin[e];
+    }
     for (; c + 64 < ts.NT; c += 128) {
       acc0 += row[c] * qT[c];
       acc1 += row[c + 64] * qT[c + 64];
@@ -1940,31 +2024,30 @@ __device__ __forceinline__ bool tlLevelRows(const TlStep* __restrict__ tsp, int 
     if (c < ts.NT) acc0 += row[c] * qT[c];
     const double d = ts.weight * waveSum(acc0 + acc1);
     if (lane == 0) {
-      double rn, tv;
-      if (init) {
-        rn = qT[e];
-        tv = on ? d : 0.0;
-      } else {
-        rn = ts.rT[e] - alpha * qT[e];
-        tv = on ? ts.t[e] - alpha * d : 0.0;
+      const double rn = init ? qT[e] : rOld - alpha * qT[e];
+      const double tv = on ? (init ? d : tOld - alpha * d) : 0.0;
+      if (owned) {
+        ts.rT[e] = rn;
+        tout[e] = tv;
       }
-      ts.rT[e] = rn;
-      ts.t[e] = tv;
-      tn[a] = tv;
-      red[a] = tv * rn;
+      tn[k] = tv;
+      red[k] = owned ? tv * rn : 0.0;
     }
   }
   __syncthreads();
-  for (int f = tid; f < F; f += nThreads) {
-    const int a0 = f / ts.step;
+  if constexpr (FUSED) TAIL_STAMP(6);
+  const int fLo = aLo * ts.step, fHi = ownsLast ? F : min(F, aHi * ts.step);
+  for (int f = fLo + tid; f < fHi; f += nThreads) {
+    const int a0 = f / ts.step, k0 = a0 - aLo;
     const double tau = static_cast<double>(f - a0 * ts.step) * inv;
-    ts.tl[static_cast<size_t>(f) * ts.S + s] = (1.0 - tau) * tn[a0] + tau * tn[min(a0 + 1, ts.nn - 1)];
+    ts.tl[static_cast<size_t>(f) * ts.S + s] = (1.0 - tau) * tn[k0] + tau * tn[min(k0 + 1, nA - 1)];
   }
   if (tid == 0) {
     double d = 0.0;
-    for (int a = 0; a < ts.nn; ++a) d += red[a];
-    publishPartial(ts.dotPart + s, d);
+    for (int k = 0; k < nA; ++k) d += red[k];
+    publishPartial(ts.dotPart + wg, d);
   }
+  if constexpr (FUSED) TAIL_STAMP(7);
   return true;
 }
 
@@ -2091,8 +2174,8 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   };
   if (f >= L.F) {
     if (tlWg) {  // third level's workgroup (one coarse hat) or the temporal pose level's (one mode)
-      const int k = static_cast<int>(blockIdx.x) - nF - nDenseWg, nTl = tlOn ? tsp->S : 0;
-      if (!tlLevelRows<FUSED>(k < nTl ? tsp : tpp, k < nTl ? k : k - nTl, L.F, alpha, 0, sDone, sm, mid)) return;
+      const int k = static_cast<int>(blockIdx.x) - nF - nDenseWg, nTl = tlOn ? tsp->S * tsp->parts : 0;
+      if (!tlLevelRows<FUSED>(k < nTl ? tsp : tpp, k < nTl ? k : k - nTl, L.F, alpha, 0, sDone, scal, sm, mid)) return;
     } else {
     // ---- dense-level workgroup: rows [0, rowSplit) of kDenseFramesPerGroup frames, one frame after the other (F + F / 2
     // workgroups of 768 threads still fit the device in ONE round, two per CU; F + F do not)
@@ -2341,8 +2424,9 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
     }
     double cT = 0.0;  // third level's part of r^T z (kept apart: a broken-down sparse factor switches ITS level off below, not this one)
     if (tlOn)
-      for (int k = tid; k < tsp->S; k += nThreads) cT += readPartial(tsp->dotPart + k);
-    if (tpOn && tid < kCB) cT += readPartial(tpp->dotPart + tid);
+      for (int k = tid; k < tsp->S * tsp->parts; k += nThreads) cT += readPartial(tsp->dotPart + k);
+    if (tpOn)
+      for (int k = tid; k < tpp->S * tpp->parts; k += nThreads) cT += readPartial(tpp->dotPart + k);
     a = waveSum(a);
     b = waveSum(b);
     cY = waveSum(cY);
@@ -2448,7 +2532,6 @@ __device__ __forceinline__ unsigned int tailArrive(unsigned int* bar) {
 // with one 16-byte load: the sum travels with the flag, so the last arriver neither publishes it separately nor drains that store
 // before releasing (2.5 us of the 7 between the last arrival and the release).  A reader accepts a record whose two generation
 // words agree (a 16-byte access of one lane is one transaction; the second word guards against a torn one anyway).
-typedef unsigned int cvd_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups, unsigned int gen, unsigned int ticket,
                                          const double* __restrict__ parts, int nParts, double* __restrict__ scratch, double& sum) {
   int* role = reinterpret_cast<int*>(scratch + 16);
@@ -2496,13 +2579,6 @@ __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups
   sum = scratch[18];
   return *role != 0;
 }
-
-#ifdef CVD_TAIL_PROFILE  // tools/tail_profile.py: wall-clock (100 MHz) stamps of k_pcg_tail's workgroups
-__device__ unsigned long long g_tailProf[1024 * 8];
-#define TAIL_STAMP(slot) do { if (threadIdx.x == 0) g_tailProf[(blockIdx.x & 1023) * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define TAIL_STAMP(slot) do {} while (0)
-#endif
 
 // what the update half needs beside the finish half's arguments
 struct TailUpdate {
@@ -2576,9 +2652,12 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
   struct Mid {
     decltype(first)& f1;
     decltype(second)& f2;
+    double* scratch;
     __device__ bool first(double& pv, double& qv) { return f1(pv, qv); }
     __device__ bool second(double& alpha) { return f2(alpha); }
-  } mid{first, second};
+    // (the barrier's generation at the start of this launch: tailWait left it in the scratch words for every thread)
+    __device__ unsigned int generation() { return *reinterpret_cast<unsigned int*>(scratch + 17); }
+  } mid{first, second, sm + U.ldsScratch};
   cgUpdateBody<true>(L, 0, nullptr, U.minv, nullptr, nullptr, scal, U.counter, U.dx, U.r, U.z, U.fdotRZ, U.fdotRR, U.tol2, nullptr,
                      U.modeActive, U.hostMirror, csOff, U.ds, nullptr, sm, mid, 0, L.F, nullptr, U.ts, U.tp);
   TAIL_STAMP(4);

@@ -222,12 +222,12 @@ bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish
   const int split = denseRowSplit(h);
   const TlStep ts = temporalStep(h);
   // (third level: S more workgroups; the restriction's products of a frame use the update half's partial-sum region)
-  if (ts.Ainv != nullptr && (ts.S * ts.width > cgUpdatePartDoubles(B, nThreads) || ts.NT + 2 * ts.nn > B + cgUpdatePartDoubles(B, nThreads)))
+  if (ts.Ainv != nullptr && (ts.S * ts.width > cgUpdatePartDoubles(B, nThreads) || tlRowsLds(ts.NT) > B + cgUpdatePartDoubles(B, nThreads)))
     return false;
   const bool poseT = coarse && h->coarse.temporalPose;  // (coarse_level 3: kCB workgroups walk the node-reduced inverse, no dense-level ones)
-  if (poseT && h->coarse.ptN + 2 * h->coarse.ptNn > B + cgUpdatePartDoubles(B, nThreads)) return false;
+  if (poseT && tlRowsLds(h->coarse.ptN) > B + cgUpdatePartDoubles(B, nThreads)) return false;
   const int grid = F + (coarse && !poseT && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) +
-                   (ts.Ainv != nullptr ? ts.S : 0) + (poseT ? kCB : 0);
+                   (ts.Ainv != nullptr ? ts.S * ts.parts : 0) + (poseT ? kCB * tlParts(h->coarse.ptNn) : 0);
   const int update = B + cgUpdatePartDoubles(B, nThreads) + 48 + 17 * kCB;  // k_cg_update's region (cvd_solve.hip: ldsU)
   const int finish = 3 * B + 8 + kCB + (nThreads / 256 - 1) * 256 + kTlMaxS;  // k_matvec_finish's + the partial sums of its row walk + the third level's coefficients
   const int denseEnd = (coarse && !poseT) ? F * kCB + nThreads + 16 : 0;    // the dense-level workgroups' (Z^T q + partial sums)
@@ -277,7 +277,7 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
                      ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr),
                      poseT ? poseTemporalStepDev(h) : static_cast<const TlStep*>(nullptr)};
   const int grid = F + (withCoarse && !poseT && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) +
-                   (ts.Ainv != nullptr ? ts.S : 0) + (poseT ? kCB : 0);
+                   (ts.Ainv != nullptr ? ts.S * ts.parts : 0) + (poseT ? kCB * tlParts(h->coarse.ptNn) : 0);
   const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)
   {
     // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate)

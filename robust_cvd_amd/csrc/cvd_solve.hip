@@ -75,10 +75,10 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   }
   // third level (cvd_temporal.h): S more workgroups of the update launch (q_T and the coefficients of one coarse hat in LDS)
   const TlStep tsOn = temporalStep(h);
-  const int nTlWg = tsOn.Ainv != nullptr ? tsOn.S : 0;
-  if (nTlWg) ldsU = std::max(ldsU, (static_cast<size_t>(tsOn.NT) + 2 * tsOn.nn) * 8);
-  const int nPtWg = poseT ? kCB : 0;
-  if (poseT) ldsU = std::max(ldsU, (static_cast<size_t>(h->coarse.ptN) + 2 * h->coarse.ptNn) * 8);
+  const int nTlWg = tsOn.Ainv != nullptr ? tsOn.S * tsOn.parts : 0;
+  if (nTlWg) ldsU = std::max(ldsU, static_cast<size_t>(tlRowsLds(tsOn.NT)) * 8);
+  const int nPtWg = poseT ? kCB * tlParts(h->coarse.ptNn) : 0;
+  if (poseT) ldsU = std::max(ldsU, static_cast<size_t>(tlRowsLds(h->coarse.ptN)) * 8);
   const TlStep* tpDev = poseT ? poseTemporalStepDev(h) : nullptr;
   allowLds(k_cg_update, ldsU);
   hipLaunchKernelGGL(k_cg_update, dim3(F), dim3(nThreads), ldsU, s, c.L, 1, h->dG.p, h->dMinv.p, h->dP0.p, h->dQ.p,
@@ -99,6 +99,8 @@ int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
   if (fusedTail) {  // (its grid barrier's words)
     h->dTailBar.ensure(static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies));
     HIP_CHECK(hipMemsetAsync(h->dTailBar.p, 0, static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies) * sizeof(unsigned int), s));
+    // (the temporal level's node-sum records carry the barrier's generation, which restarts with its words)
+    if (tsOn.rec != nullptr) HIP_CHECK(hipMemsetAsync(tsOn.rec, 0, 2 * static_cast<size_t>(tsOn.NT) * sizeof(double), s));
   }
   const bool ownerMode = ownerShardedUpdate(h, coarse);
   const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);

@@ -412,11 +412,11 @@ inline __global__ __launch_bounds__(1024) void k_tl_rows_init(const TlStep* __re
   __shared__ int flag;
   NoMid mid;
   double alpha = 0.0;
-  (void)tlLevelRows<false>(tsp, blockIdx.x, F, alpha, 1, 0.0, sm, mid);
+  (void)tlLevelRows<false>(tsp, blockIdx.x, F, alpha, 1, 0.0, scal, sm, mid);
   if (!lastBlockArrivesLite(counter, gridDim.x, &flag)) return;
   if (threadIdx.x == 0) {
     double d = 0.0;
-    for (int s = 0; s < tsp->S; ++s) d += readPartial(tsp->dotPart + s);
+    for (int s = 0; s < tsp->S * tsp->parts; ++s) d += readPartial(tsp->dotPart + s);
     if (closeScalars) pcgFinishScalars(scal, 1, scal[S_RZPART] + d, scal[S_RR], tol2, hostMirror);
     else scal[S_RZPART] += d;
   }

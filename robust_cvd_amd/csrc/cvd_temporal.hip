@@ -154,8 +154,9 @@ void temporalPrepare(Ctx& c) {
   T.sq.ensure(static_cast<size_t>(F) * S);
   T.tl.ensure(static_cast<size_t>(F) * S);
   T.rT.ensure(NT);
-  T.t.ensure(NT);
-  T.dotPart.ensure(S);
+  T.t.ensure(2 * NT);
+  T.dotPart.ensure(static_cast<size_t>(S) * tlParts(nn));
+  T.rec.ensure(2 * NT);
   T.fail.ensure(1);
   T.valid.ensure(1);
   if (!T.counter.p) {
@@ -176,9 +177,10 @@ static TlTables temporalTables(cvd_handle* h) {
 
 TlStep temporalStep(cvd_handle* h) {
   if (h == nullptr || !h->temporal.on || !h->temporal.built)
-    return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 1.0};
+    return TlStep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0, 0, 0, 1, kTlSpan, nullptr, 1.0};
   auto& T = h->temporal;
   return TlStep{T.Ainv.p, T.sqPtr, T.rT.p, T.t.p, T.tl.p, T.dotPart.p, T.fail.p, T.elW.p, T.elV.p, T.S, T.nn, T.step, T.NT, T.NT, T.width,
+                tlParts(T.nn), kTlSpan, (!h->dist() && T.step <= 32) ? T.rec.p : nullptr,  // (one wave's lanes cover a node's 2 step - 1 frames)
                 h->opt.temporal_weight};
 }
 
@@ -275,9 +277,9 @@ void launchTemporalInit(Ctx& c, bool closeScalars, double tol2) {
   if (ts.Ainv == nullptr) return;
   const size_t ldsR = (static_cast<size_t>(c.L.B) + static_cast<size_t>(T.S) * T.width) * 8;
   hipLaunchKernelGGL(k_tl_restrict, dim3(c.L.F), dim3(256), ldsR, s, c.L, h->dR.p, temporalStepDev(h));
-  const size_t ldsI = (static_cast<size_t>(T.NT) + 2 * T.nn) * 8;
+  const size_t ldsI = static_cast<size_t>(tlRowsLds(T.NT)) * 8;
   allowLds(k_tl_rows_init, ldsI);
-  hipLaunchKernelGGL(k_tl_rows_init, dim3(T.S), dim3(512), ldsI, s, temporalStepDev(h), c.L.F, h->dScal.p, T.counter.p,
+  hipLaunchKernelGGL(k_tl_rows_init, dim3(T.S * tlParts(T.nn)), dim3(768), ldsI, s, temporalStepDev(h), c.L.F, h->dScal.p, T.counter.p,
                      closeScalars ? 1 : 0, tol2, h->hPcg);
   HIP_CHECK(hipGetLastError());
 }
@@ -341,8 +343,9 @@ void poseTemporalPrepare(Ctx& c) {
   C.ptMat.ensure(n * n);
   C.ptInv.ensure(n * n);
   C.ptR.ensure(n);
-  C.ptT.ensure(n);
-  C.ptDot.ensure(kCB);
+  C.ptT.ensure(2 * n);
+  C.ptDot.ensure(static_cast<size_t>(kCB) * tlParts(C.ptNn));
+  C.ptRec.ensure(2 * n);
   if (!C.ptCounter.p) {
     C.ptCounter.ensure(4);
     HIP_CHECK(hipMemsetAsync(C.ptCounter.p, 0, 4 * sizeof(unsigned int), s));
@@ -352,6 +355,7 @@ void poseTemporalPrepare(Ctx& c) {
   double* qc = (h->dist() && fusedExchange(h, true)) ? h->dQ.p + exchangeOffsetQc(c) : C.qc.p;
   TlStep st[2];
   st[0] = TlStep{C.ptInv.p, qc, C.ptR.p, C.ptT.p, C.c.p, C.ptDot.p, C.fail.p, nullptr, nullptr, kCB, C.ptNn, C.ptStepFrames, C.ptN, C.ptN, 0,
+                 tlParts(C.ptNn), kTlSpan, nullptr,  // (few frames per node: every workgroup sums them itself)
                  h->opt.temporal_weight};
   st[1] = st[0];
   st[1].sq = C.rc.p;
@@ -374,9 +378,9 @@ void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut) {
 void launchPoseTemporalInit(Ctx& c, double tol2) {
   cvd_handle* h = c.h;
   auto& C = h->coarse;
-  const size_t lds = (static_cast<size_t>(C.ptN) + 2 * C.ptNn) * 8;
+  const size_t lds = static_cast<size_t>(tlRowsLds(C.ptN)) * 8;
   allowLds(k_tl_rows_init, lds);
-  hipLaunchKernelGGL(k_tl_rows_init, dim3(kCB), dim3(512), lds, h->stream, C.ptStepDev.p + 1, c.L.F, h->dScal.p, C.ptCounter.p, 1, tol2,
+  hipLaunchKernelGGL(k_tl_rows_init, dim3(kCB * tlParts(C.ptNn)), dim3(768), lds, h->stream, C.ptStepDev.p + 1, c.L.F, h->dScal.p, C.ptCounter.p, 1, tol2,
                      h->hPcg);
   HIP_CHECK(hipGetLastError());
 }

@@ -32,8 +32,17 @@ F = v.num_frames
 t0 = a[:, 0].min()
 us = lambda x: x / 100.0
 print("workgroups", len(a), " launch span us %.1f" % us(a[:, 4].max() - t0))
-nD = (F + 1) // 2   # dense-level workgroups (two frames each); the third level's workgroups follow
-for name, rows in (("frame workgroups", a[:F]), ("dense-level workgroups", a[F:F + nD]), ("third level's workgroups", a[F + nD:])):
+# workgroups behind the frames': the exact dense level's (two frames each; none with the temporal pose level), then the temporal
+# levels' (45 hats of the depth-grid level, 8 modes of the temporal pose level)
+nExtra = len(a) - F
+nD = (F + 1) // 2 if nExtra >= (F + 1) // 2 else 0
+groups = [("frame workgroups", a[:F]), ("dense-level workgroups", a[F:F + nD])]
+rest = a[F + nD:]
+if len(rest) > 8:
+    groups += [("depth-grid level's workgroups", rest[:len(rest) - 8]), ("temporal pose level's workgroups", rest[len(rest) - 8:])]
+else:
+    groups += [("temporal levels' workgroups", rest)]
+for name, rows in groups:
     if not len(rows):
         continue
     print(name, len(rows))
@@ -42,3 +51,7 @@ for name, rows in (("frame workgroups", a[:F]), ("dense-level workgroups", a[F:F
                      ("update half", us(rows[:, 4] - rows[:, 3])), ("barrier release at", us(rows[:, 3] - t0)),
                      ("end at", us(rows[:, 4] - t0))):
         print(f"  {label:22s} min {x.min():6.2f}  median {np.median(x):6.2f}  mean {x.mean():6.2f}  max {x.max():6.2f}")
+    if "level's" in name and rows[:, 5].min() > 0:   # (tlLevelRows' own stamps)
+        for label, x in (("  node sums (q_T)", us(rows[:, 5] - rows[:, 3])), ("  rows + update", us(rows[:, 6] - rows[:, 5])),
+                         ("  interpolation + share", us(rows[:, 7] - rows[:, 6])), ("  ticket", us(rows[:, 4] - rows[:, 7]))):
+            print(f"  {label:22s} min {x.min():6.2f}  median {np.median(x):6.2f}  mean {x.mean():6.2f}  max {x.max():6.2f}")
