@@ -38,10 +38,9 @@ nExtra = len(a) - F
 nD = (F + 1) // 2 if nExtra >= (F + 1) // 2 else 0
 groups = [("frame workgroups", a[:F]), ("dense-level workgroups", a[F:F + nD])]
 rest = a[F + nD:]
-if len(rest) > 8:
-    groups += [("depth-grid level's workgroups", rest[:len(rest) - 8]), ("temporal pose level's workgroups", rest[len(rest) - 8:])]
-else:
-    groups += [("temporal levels' workgroups", rest)]
+dbg = s.temporal_debug()
+nTl = dbg["S"] * max(1, (dbg["nn"] - 1 + 9) // 10) if dbg else 0   # (hats x node ranges of 10 intervals: TlStep::parts)
+groups += [("depth-grid level's workgroups", rest[:nTl]), ("temporal pose level's workgroups", rest[nTl:])]
 for name, rows in groups:
     if not len(rows):
         continue
