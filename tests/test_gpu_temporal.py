@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from robust_cvd_amd import synth
-from robust_cvd_amd.ctypes_types import OptParams, XformDesc
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, XformDesc
 from tests import baseline_configs as bc
 
 pytestmark = pytest.mark.gpu
@@ -129,3 +129,48 @@ def test_level_saves_iterations_on_the_benchmarked_problem(Solver):
     # measured over the whole pipeline: 1046 -> 932 with the temporal pose level (the default for this pair graph), 1093 -> 888 with
     # the exact dense one; 50 -> 34 per LM iteration at the final level (profiles/r04_*)
     assert out[1][0]["total_linear_iterations"] < 0.93 * out[0][0]["total_linear_iterations"], (out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("intr", ["per_frame", "fixed"])
+def test_temporal_levels_with_frames_out_of_range(Solver, intr):
+    """A frame range with holes and a cut tail (whole frames masked: their modes are inactive, some temporal nodes see few or no
+    active frames -> identity rows), intrinsics fixed in one variant (mode 6 inactive everywhere): both temporal levels against
+    the exact sparse level without the depth-grid level.  Same minimum; the levels' matrices are SPD and their inverses correct."""
+    F = 72
+    v = synth.make_video(F, 128, 72, seed=21, extra_offsets=6)
+    frames = [f for f in range(4, 61) if f not in (17, 18, 19, 40)]
+    out = {}
+    for name, opts in (("reference", {"temporal_level": 0}),
+                       ("temporal", {"coarse_level": 3, "coarse_temporal_step": 4, "temporal_level": 2, "temporal_step": 16})):
+        s = Solver(0)
+        synth.load_into(s, v)
+        s.set_options(**opts)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        p.set_frame_range(frames)
+        if intr == "fixed":
+            p.intr_opt = IntrinsicsOptimization.Fixed
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[name] = (s.summary(), s.get_poses(), s.get_xform_params().copy())
+        if name == "temporal":
+            dbg, cdbg = s.temporal_debug(), s.coarse_debug()
+            assert dbg is not None and dbg["failed"] == 0 and cdbg is not None and cdbg["failed"] == 0
+            for A, Ai in ((dbg["a_t"], dbg["a_t_inverse"]), (cdbg["a_c"], cdbg["a_c_inverse"])):
+                assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max() and np.linalg.eigvalsh(A)[0] > 0.0
+                assert np.abs(Ai @ A - np.eye(A.shape[0])).max() < 1e-5
+            if intr == "fixed":   # the focal mode of every node is an identity row
+                n = cdbg["a_c"].shape[0] // 8
+                assert np.array_equal(cdbg["a_c"][6 * n:7 * n, 6 * n:7 * n], np.eye(n))
+        s.close()
+    a, b = out["temporal"], out["reference"]
+    assert a[0]["termination"] == 0 and b[0]["termination"] == 0
+    assert abs(a[0]["final_cost"] - b[0]["final_cost"]) <= 1e-6 * abs(b[0]["final_cost"])
+    sel = np.array(frames)
+    perr, rerr = synth.relative_pose_error(a[1]["position"][sel], a[1]["orientation"][sel], b[1]["position"][sel], b[1]["orientation"][sel])
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+    # frames outside the range are untouched
+    rest = np.setdiff1d(np.arange(F), sel)
+    assert np.array_equal(a[1]["position"][rest], b[1]["position"][rest]) and np.array_equal(a[2][rest], b[2][rest])
