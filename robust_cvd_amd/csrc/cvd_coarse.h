@@ -1,4 +1,6 @@
-// Coarse (pose-graph) level of the two-level preconditioner of the PCG solve.
+// Coarse (pose-graph) level of the additive preconditioner of the PCG solve.  (Round 4: cvd_temporal.h adds a temporally coarse
+// level for the depth grid and a temporally coarse FORM of this level -- the same 8 modes per frame x hat functions in time, built
+// from the very blocks below -- which replaces the dense inverse wherever the exact factor's elimination is over budget.)
 //
 // The block-Jacobi preconditioner inverts every frame's own block exactly, but the slowly converging error of
 // this problem lives BETWEEN frames: low-frequency drift of the camera trajectory and of the per-frame depth

@@ -1,7 +1,9 @@
 // cvd_dense_inverse.h -- inverse of ONE dense symmetric positive definite f64 matrix (the dense coarse level of the
 // two-level preconditioner: A_c = Z^T (J^T J + D) Z, 8 unknowns per frame, n = 2400 at 300 frames) on the f64 matrix cores
 // of the WHOLE device, as one persistent kernel.  Replaces rocSOLVER's potrf + potri (~250 dependent micro-kernels,
-// 6.5 ms) on the product path.
+// 6.5 ms) on the product path.  Since round 4 the default path inverts the temporal levels' matrices with
+// it (cvd_temporal.h: n = 8 x nodes = 312 and n = nodes x hats = 495 at 300 frames, 0.12 ms each); the 2400-unknown exact level
+// remains as cvd_solver_options::coarse_over_budget = 1.
 //
 // Algorithm: the symmetric sweep operator of k_block_inverse_mfma (cvd_kernels.h), blocked with 16-wide pivot tiles, spread
 // over the device.  Sweeping pivot tile k (P = G_kk^-1) maps
