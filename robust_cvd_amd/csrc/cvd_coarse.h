@@ -390,7 +390,7 @@ inline __global__ __launch_bounds__(256) void k_coarse_diag(Layout L, const doub
     double a = 0.0;
     for (int v = 0; v < nV; ++v) {
       const int cidx = 7 + v * N;
-      a += hf[static_cast<size_t>(r) * B + cidx] + (r == cidx ? lamScale * lf[r] : 0.0);
+      a += hf[static_cast<size_t>(cidx) * B + r] + (r == cidx ? lamScale * lf[r] : 0.0);  // (symmetric block: coalesced over r)
     }
     u[r] = a;
     if (r >= 7 && r < 7 + L.nD && ((r - 7) % (N > 0 ? N : 1)) == 0 && mf[r] != 0.0) anyScale = 1;

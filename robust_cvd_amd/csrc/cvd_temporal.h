@@ -353,32 +353,38 @@ inline __global__ void k_tl_shift_diag(int n, int ld, double* __restrict__ A, do
 // w_a w_b E_e.  One wave per node pair, lane = (i, j); fixed order (the ranks of a sharded run build the same bits).  Unknown
 // e = mode * nn + node, as the third level's (tlLevelRows serves both).  Inactive modes contribute nothing; k_tl_shift_diag turns
 // their empty diagonal into identity rows.
-inline __global__ __launch_bounds__(64) void k_pt_assemble(int nn, int step, int F, int ld, const int* __restrict__ blkA,
-                                                    const int* __restrict__ blkB, const int* __restrict__ ptr,
-                                                    const int* __restrict__ list, const double* __restrict__ diag,
-                                                    const double* __restrict__ edges, const int* __restrict__ edgeFa,
-                                                    const int* __restrict__ edgeFb, const unsigned char* __restrict__ modeActive,
-                                                    double* __restrict__ A) {
-  const int blk = blockIdx.x, tid = threadIdx.x, i = tid >> 3, j = tid & 7;
+inline __global__ __launch_bounds__(256) void k_pt_assemble(int nn, int step, int F, int ld, const int* __restrict__ blkA,
+                                                     const int* __restrict__ blkB, const int* __restrict__ ptr,
+                                                     const int* __restrict__ list, const double* __restrict__ diag,
+                                                     const double* __restrict__ edges, const int* __restrict__ edgeFa,
+                                                     const int* __restrict__ edgeFb, const unsigned char* __restrict__ modeActive,
+                                                     double* __restrict__ A) {
+  // four waves per node pair: wave w takes every fourth frame / list entry (lane = (i, j)), the four partial blocks are added in
+  // wave order -- the walk is a chain of dependent loads, ~200 list entries for a diagonal node pair
+  __shared__ double part[4][kCBB];
+  const int blk = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l >> 3, j = l & 7;
   const int a = blkA[blk], b = blkB[blk];
-  if (a == b && i > j) return;  // (a diagonal block is symmetric: its upper triangle is computed and mirrored)
   const double inv = 1.0 / static_cast<double>(step);
   auto hat = [&](int node, int f) -> double { return fmax(0.0, 1.0 - fabs(static_cast<double>(f - node * step)) * inv); };
   double v = 0.0;
   if (b <= a + 1) {
     const int fLo = max(0, (b - 1) * step + 1), fHi = min(F - 1, (a + 1) * step - 1);
-    for (int f = fLo; f <= fHi; ++f)
-      if (modeActive[f * kCB + i] && modeActive[f * kCB + j]) v += hat(a, f) * hat(b, f) * diag[static_cast<size_t>(f) * kCBB + tid];
+    for (int f = fLo + w; f <= fHi; f += 4)
+      if (modeActive[f * kCB + i] && modeActive[f * kCB + j]) v += hat(a, f) * hat(b, f) * diag[static_cast<size_t>(f) * kCBB + l];
   }
-  for (int k = ptr[blk]; k < ptr[blk + 1]; ++k) {
+  for (int k = ptr[blk] + w; k < ptr[blk + 1]; k += 4) {
     const int en = list[k], e = en >> 1;
     const int fa = edgeFa[e], fb = edgeFb[e];  // block stored rows = fa, columns = fb
     if (en & 1) {
       if (modeActive[fb * kCB + i] && modeActive[fa * kCB + j]) v += hat(a, fb) * hat(b, fa) * edges[static_cast<size_t>(e) * kCBB + j * kCB + i];
     } else {
-      if (modeActive[fa * kCB + i] && modeActive[fb * kCB + j]) v += hat(a, fa) * hat(b, fb) * edges[static_cast<size_t>(e) * kCBB + tid];
+      if (modeActive[fa * kCB + i] && modeActive[fb * kCB + j]) v += hat(a, fa) * hat(b, fb) * edges[static_cast<size_t>(e) * kCBB + l];
     }
   }
+  part[w][l] = v;
+  __syncthreads();
+  if (w != 0 || (a == b && i > j)) return;  // (a diagonal block is symmetric: its upper triangle is computed and mirrored)
+  v = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
   const size_t r = static_cast<size_t>(i) * nn + a, c = static_cast<size_t>(j) * nn + b;
   A[r * ld + c] = v;
   if (r != c) A[c * ld + r] = v;

@@ -368,7 +368,7 @@ void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut) {
   cvd_handle* h = c.h;
   auto& C = h->coarse;
   HIP_CHECK(hipMemsetAsync(C.ptMat.p, 0, static_cast<size_t>(C.ptN) * C.ptN * sizeof(double), s));
-  hipLaunchKernelGGL(k_pt_assemble, dim3(C.ptBlocks), dim3(64), 0, s, C.ptNn, C.ptStepFrames, c.L.F, C.ptN, C.ptA.p, C.ptB.p, C.ptPtr.p,
+  hipLaunchKernelGGL(k_pt_assemble, dim3(C.ptBlocks), dim3(256), 0, s, C.ptNn, C.ptStepFrames, c.L.F, C.ptN, C.ptA.p, C.ptB.p, C.ptPtr.p,
                      C.ptList.p, C.diag.p, C.edges.p, C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.ptMat.p);
   hipLaunchKernelGGL(k_tl_shift_diag, dim3((C.ptN + 255) / 256), dim3(256), 0, s, C.ptN, C.ptN, C.ptMat.p, h->opt.coarse_dense_shift);
   HIP_CHECK(hipGetLastError());
