@@ -625,7 +625,7 @@ void launchBlockInverse(Ctx& c);
 void launchCoarseSetup(Ctx& c, const double* x, int side = 0);
 // third level (cvd_temporal.hip)
 bool temporalScope(const Ctx& c);
-void temporalPrepare(Ctx& c);                       // tables and work lists of this solve's problem
+bool temporalPrepare(Ctx& c);                       // tables and work lists of this solve's problem (false: outside the kernels' limits)
 void launchTemporalSetup(Ctx& c, const double* x, int half);  // A_T for the current (H, lam, x): 0 = its assembly (beside the
                                                               // pose-graph level's build), 1 = its inverse
 void launchTemporalInit(Ctx& c, bool closeScalars, double tol2);  // first residual of a PCG solve: t, r_T, tl, the level's part of r^T z

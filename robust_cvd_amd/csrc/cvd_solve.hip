@@ -273,7 +273,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
   h->temporal.on = temporalScope(c);
-  if (h->temporal.on) temporalPrepare(c);
+  if (h->temporal.on) h->temporal.on = temporalPrepare(c);
   if (h->coarseOn && h->coarse.temporalPose) poseTemporalPrepare(c);
   phase("buffers");
   buildMask(h, c.L, p, kind, range);

@@ -41,7 +41,9 @@ static void axisTable(int g, int S, std::vector<float>& hv, std::vector<int>& bv
   }
 }
 
-void temporalPrepare(Ctx& c) {
+// false: the chosen coarse grid is outside what the kernels hold (a hat covering more than kTlMaxWidth depth vertices) -- the
+// solve runs without the level
+bool temporalPrepare(Ctx& c) {
   cvd_handle* h = c.h;
   auto& T = h->temporal;
   const Layout& L = c.L;
@@ -76,7 +78,7 @@ void temporalPrepare(Ctx& c) {
       }
     size_t width = 1;
     for (auto& col : cols) width = std::max(width, col.size());
-    if (width > static_cast<size_t>(kTlMaxWidth)) throw std::runtime_error("temporal level: a coarse hat covers too many depth vertices");
+    if (width > static_cast<size_t>(kTlMaxWidth)) return false;
     std::vector<float> elW(width * S, 0.f);
     std::vector<unsigned char> elV(width * S, 0);
     for (int hat = 0; hat < S; ++hat)
@@ -167,6 +169,7 @@ void temporalPrepare(Ctx& c) {
   T.built = false;
   // pair-sharded run with the fused exchange: the ranks' restricted products travel behind [q | Z^T q | p.q] in the same all-reduce
   T.sqPtr = (h->dist() && fusedExchange(h, h->coarseOn)) ? h->dQ.p + exchangeOffsetPq(c, h->coarseOn && h->coarse.denseMode) + 1 : T.sq.p;
+  return true;
 }
 
 static void temporalInverse(Ctx& c);

@@ -174,3 +174,28 @@ def test_temporal_levels_with_frames_out_of_range(Solver, intr):
     # frames outside the range are untouched
     rest = np.setdiff1d(np.arange(F), sel)
     assert np.array_equal(a[1]["position"][rest], b[1]["position"][rest]) and np.array_equal(a[2][rest], b[2][rest])
+
+
+def test_coarse_grid_beyond_the_kernels_limits_switches_the_level_off(Solver):
+    """A hand-picked coarse grid whose hats cover more depth vertices than the transposed vertex table holds (5 x 4 hats on the
+    17 x 10 grid: 7 x 5 = 35 > 32): the solve runs without the level instead of failing."""
+    v = synth.make_video(72, 128, 72, seed=12, extra_offsets=6)
+    out = {}
+    for name, opts in (("auto", {}), ("too_coarse", {"temporal_grid_x": 5, "temporal_grid_y": 4})):
+        s = Solver(0)
+        synth.load_into(s, v)
+        s.set_options(temporal_step=16, **opts)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        s.normalize_depth(p)
+        s.grid_xform_split(XformDesc.grid_depth(17, 10))
+        s.pose_optimization_step(p, p.depth_deform_reg_final, convert_poses=True)
+        out[name] = (s.summary(), s.temporal_debug())
+        s.close()
+    assert out["auto"][1] is not None and (out["auto"][1]["Sx"], out["auto"][1]["Sy"]) == (9, 5)
+    assert out["too_coarse"][1] is None
+    a, b = out["auto"][0], out["too_coarse"][0]
+    assert a["termination"] == 0 and b["termination"] == 0
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-6 * abs(b["final_cost"])
+    assert a["total_linear_iterations"] < b["total_linear_iterations"]
