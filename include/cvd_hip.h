@@ -105,6 +105,13 @@ typedef struct cvd_solver_options {
                                      coarse_update_budget (flow lists with long-range pairs from nearly every frame).  0 (default):
                                      the TEMPORAL pose level (see coarse_level 3); 1: rounds 2-3 -- the exact level as ONE dense
                                      inverse up to coarse_dense_max_unknowns, on a sparsified graph beyond */
+  int32_t coarse_temporal_min_frames; /* coarse_level 1 / 2 on ONE GPU with frame blocks <= 256: from this many frames on (default 128;
+                                     0: never) the temporal pose level is used even where the exact factor is cheap -- it brings
+                                     the PCG iteration inside k_pcg_tail's scope (one launch for finish + update), which the exact
+                                     sparse level is not: 1766-pair list at 300 frames 296 -> 331 LM iterations/s at 37.6 -> 39.8
+                                     PCG iterations.  Beyond ~400 frames the fused kernel's workgroups are no longer co-resident
+                                     and the exact factor stays (configs[4]: 52.9 against 47 iterations/s) */
+  int32_t reserved0;              /* (keeps the double below aligned the same way in every binding) */
   double temporal_weight;         /* the temporal levels (depth-grid level, temporal pose level) enter the additive preconditioner
                                      as weight x P A^-1 P^T: their spaces overlap each other's and the per-frame blocks', and an
                                      additive combination of overlapping exact corrections overshoots (default 0.7: 5 - 8 % fewer

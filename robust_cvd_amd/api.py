@@ -45,6 +45,8 @@ class SolverOptions(C.Structure):
         ("temporal_grid_y", C.c_int32),
         ("coarse_temporal_step", C.c_int32),
         ("coarse_over_budget", C.c_int32),
+        ("coarse_temporal_min_frames", C.c_int32),
+        ("reserved0", C.c_int32),
         ("temporal_weight", C.c_double),
     ]
 

@@ -240,6 +240,8 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->temporal_grid_y = 0;
   o->coarse_temporal_step = 8;
   o->coarse_over_budget = 0;
+  o->coarse_temporal_min_frames = 128;
+  o->reserved0 = 0;
   o->temporal_weight = 0.7;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
@@ -262,6 +264,7 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
         o->block_inverse_variant > 2)
       throw std::runtime_error("coarse_level in {0, 1, 2, 3}, coarse_temporal_step >= 2, robust_loss in {0, 1}, block_inverse_variant in {0, 1, 2}");
     if (o->coarse_over_budget < 0 || o->coarse_over_budget > 1) throw std::runtime_error("coarse_over_budget in {0, 1}");
+    if (o->coarse_temporal_min_frames < 0) throw std::runtime_error("coarse_temporal_min_frames must be >= 0");
     if (!(o->temporal_weight > 0.0 && o->temporal_weight <= 2.0)) throw std::runtime_error("temporal_weight must lie in (0, 2]");
     if (o->coarse_dense_row_split < 0 || o->coarse_dense_row_split > 8) throw std::runtime_error("coarse_dense_row_split must lie in [0, 8]");
     if (o->temporal_level < 0 || o->temporal_level > 2 || o->temporal_step < 2 || o->temporal_grid_x < 0 || o->temporal_grid_y < 0 ||
@@ -269,7 +272,8 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
       throw std::runtime_error("temporal_level in {0, 1, 2}, temporal_step >= 2, temporal_grid_x / _y 0 (automatic) or >= 2");
     if (o->coarse_update_budget != h->opt.coarse_update_budget || o->coarse_dense_max_unknowns != h->opt.coarse_dense_max_unknowns ||
         (o->coarse_level == 3) != (h->opt.coarse_level == 3) || o->coarse_temporal_step != h->opt.coarse_temporal_step ||
-        o->coarse_over_budget != h->opt.coarse_over_budget)
+        o->coarse_over_budget != h->opt.coarse_over_budget || o->coarse_temporal_min_frames != h->opt.coarse_temporal_min_frames ||
+        o->pcg_fused_tail != h->opt.pcg_fused_tail)
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
     h->opt = *o;

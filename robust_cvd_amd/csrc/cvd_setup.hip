@@ -904,7 +904,12 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     {
       const int stepP = std::max(2, h->opt.coarse_temporal_step);
       const bool fits = ((h->F - 1 + stepP - 1) / stepP + 1) * kCB <= kDenseCoarseMaxUnknowns;
-      h->coarse.temporalPose = fits && (h->opt.coarse_level == 3 || (overBudget && h->opt.coarse_over_budget == 0));
+      // (... and where it brings the PCG iteration inside the fused tail kernel's scope: cvd_solver_options::coarse_temporal_min_frames)
+      const bool fusedScope = !h->dist() && h->opt.pcg_fused_tail != 0 && !h->forceGeneric && h->Bsz() <= 256 &&
+                              h->opt.coarse_temporal_min_frames > 0 && h->F >= h->opt.coarse_temporal_min_frames &&
+                              h->F + 2 * kTlMaxS <= 2 * h->numCU;
+      h->coarse.temporalPose = fits && (h->opt.coarse_level == 3 || (overBudget && h->opt.coarse_over_budget == 0) ||
+                                        (h->opt.coarse_over_budget == 0 && fusedScope));
     }
     if (h->coarse.temporalPose) {
       h->coarse.denseMode = true;  // (same exchange layout and in-line build as the dense exact level)

@@ -60,7 +60,7 @@ def test_default_solver_options():
     assert o.coarse_dense_max_unknowns == 4096 and o.coarse_update_budget == 40000 and o.coarse_dense_shift == 1e-5
     assert o.constraint_order == 1
     assert (o.temporal_level, o.temporal_step, o.temporal_grid_x, o.temporal_grid_y) == (1, 32, 0, 0)
-    assert (o.coarse_temporal_step, o.coarse_over_budget) == (8, 0)
+    assert (o.coarse_temporal_step, o.coarse_over_budget, o.coarse_temporal_min_frames, o.temporal_weight) == (8, 0, 128, 0.7)
     assert (o.force_sharded_path, o.dense_matrix_free, o.block_inverse_variant, o.pcg_lockstep, o.force_iterations, o.verbose) == (0,) * 6
     csrc = os.path.join(ROOT, "robust_cvd_amd", "csrc")
     for f in os.listdir(csrc):
