@@ -307,15 +307,29 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L,
   double* ya = pb + B;
   double* ybw = ya + B;          // NW x B partial column sums
   double* cl = ybw + NW * B;     // 2 x kCB coarse corrections
+  double* tls = cl + 2 * kCB;    // third level (CoarseView::tl): the two frames' coefficients, 2 x tlS
   const int fa = cp.fa[pair], fb = cp.fb[pair];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
+  const bool tlOn = V.tl != nullptr;
   if (tid < 2 * kCB) cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
+  if (tlOn)
+    for (int i = tid; i < 2 * V.tlS; i += kCrossThreads) {
+      const int which = i >= V.tlS ? 1 : 0;
+      tls[i] = V.tl[static_cast<size_t>(which ? fb : fa) * V.tlS + (i - which * V.tlS)];
+    }
   __syncthreads();
   if (sDone != 0.0) return;
   for (int i = tid; i < B; i += kCrossThreads) {
     const size_t ia = static_cast<size_t>(fa) * B + i, ib = static_cast<size_t>(fb) * B + i;
-    pa[i] = (z[ia] + coarseAtLds(cl, L, i) + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
-    pb[i] = (z[ib] + coarseAtLds(cl + kCB, L, i) + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
+    double ca = coarseAtLds(cl, L, i), cb2 = coarseAtLds(cl + kCB, L, i);
+    if (tlOn) {
+      TlTaps tt;
+      tlLoadTaps(V, i, L.nD, tt);
+      ca += tlAt(tls, tt);
+      cb2 += tlAt(tls + V.tlS, tt);
+    }
+    pa[i] = (z[ia] + ca + (useBeta ? beta * pOld[ia] : 0.0)) * mask[ia];
+    pb[i] = (z[ib] + cb2 + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
   }
   __syncthreads();
   const double* Xp = X + static_cast<size_t>(pair) * B * B;

@@ -74,7 +74,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     // explicit cross blocks (dense mode): one workgroup per undirected pair streams its B x B block
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
-    const size_t ldsX = (3 * B + (kCrossThreads / 64) * B + 2 * kCB) * 8;
+    const size_t ldsX = (3 * B + (kCrossThreads / 64) * B + 2 * kCB + 2 * kTlMaxS) * 8;
     const unsigned nP = static_cast<unsigned>(h->xFa.size());
     if (evStart)
       hipExtLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, evStart, evStop, 0, c.L, crossPairs(h),

@@ -15,6 +15,7 @@
 //   * pair part            E_item[s][s'] = sum over the item's constraints  rho' (dr2/dtheta_fa . dr2/dtheta_fb) u_s v_s'
 //     (only the disparity row of a flow constraint depends on BOTH frames' depth grids; u, v = the constraint's bilinear taps
 //     composed with the hats: separable, <= 3 x 3 hats per side)                                          k_tl_edges
+//     (dense mode with explicit cross blocks: a projection of the pair's block instead                     k_tl_edges_cross)
 //   * temporal reduction   groups of items whose frames lie in the same pair of node intervals are summed with the four
 //     products of their temporal weights (k_tl_reduce), the (node, node) blocks gather the groups' sums and the frames'
 //     C_f (k_tl_assemble); A_T is block-banded in the node index (|a - b| <= 2), stored dense, unknown e = s * nn + a.
@@ -246,6 +247,44 @@ inline __global__ __launch_bounds__(256) void k_tl_edges(Layout L, Table T, Item
   }
   __syncthreads();
   for (int e = tid; e < S * S; e += 256) out[e] = E[e];
+}
+
+// Dense mode with explicit cross blocks (cvd_cross.h): the pair part is a projection of the pair's B x B block X_ab (rows = fa's
+// unknowns) -- E = Hs^T X|grid Hs in two gather stages through the transposed vertex table, no walk over the pixels.
+inline __global__ __launch_bounds__(256) void k_tl_edges_cross(Layout L, const int* __restrict__ pairFa, const int* __restrict__ pairFb,
+                                                        const double* __restrict__ X, const double* __restrict__ mask, TlTables T,
+                                                        double* __restrict__ Eout) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B, G = L.nD, S = T.S, pair = blockIdx.x, tid = threadIdx.x;
+  double* T1 = sm;                                                        // [G][S]
+  float* ew = reinterpret_cast<float*>(T1 + static_cast<size_t>(G) * S);  // [width][S]
+  unsigned char* ev = reinterpret_cast<unsigned char*>(ew + T.width * S);
+  double* out = Eout + static_cast<size_t>(pair) * S * S;
+  const int fa = pairFa[pair], fb = pairFb[pair];
+  if (mask[static_cast<size_t>(fa) * B + 7] == 0.0 || mask[static_cast<size_t>(fb) * B + 7] == 0.0) {
+    for (int e = tid; e < S * S; e += 256) out[e] = 0.0;
+    return;
+  }
+  for (int e = tid; e < T.width * S; e += 256) {
+    ew[e] = T.elW[e];
+    ev[e] = T.elV[e];
+  }
+  __syncthreads();
+  const double* Xp = X + static_cast<size_t>(pair) * B * B;
+  for (int e = tid; e < G * S; e += 256) {  // T1[v][s'] = sum_k w_k X[7 + v][7 + vertex k of hat s']
+    const int v = e / S, sp = e - v * S;
+    const double* row = Xp + static_cast<size_t>(7 + v) * B + 7;
+    double a = 0.0;
+    for (int k = 0; k < T.width; ++k) a += static_cast<double>(ew[k * S + sp]) * row[ev[k * S + sp]];
+    T1[e] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < S * S; e += 256) {
+    const int s = e / S, sp = e - s * S;
+    double a = 0.0;
+    for (int k = 0; k < T.width; ++k) a += static_cast<double>(ew[k * S + s]) * T1[static_cast<size_t>(ev[k * S + s]) * S + sp];
+    out[e] = a;
+  }
 }
 
 // ---- temporal reduction of the pair parts ---------------------------------------------------------------------------------

@@ -13,7 +13,9 @@ static int autoCoarse(int g, int wanted) {
 bool temporalScope(const Ctx& c) {
   cvd_handle* h = c.h;
   const Layout& L = c.L;
-  if (h->opt.temporal_level == 0 || h->forceGeneric || h->dense || c.cross || c.trip) return false;
+  // (dense mode: with the explicit cross blocks only -- the pair part is then a projection of the blocks; the matrix-free dense
+  // product would need the per-pixel walk with 64 lanes hitting the same hats)
+  if (h->opt.temporal_level == 0 || h->forceGeneric || (h->dense && !c.cross) || c.trip) return false;
   if (c.KD != 4 || c.KS != 0 || !fastLoss(L) || L.intrOpt == CVD_INTR_SHARED) return false;
   if (L.N != 1 || L.gz != 1 || L.depthType != CVD_DEPTH_GRID || L.positionRegSqrt > 0.0 || !L.includeStatic) return false;
   if (L.B > 256 || L.nD > 256 || L.gx < 3 || L.gy < 3 || L.nD != L.gx * L.gy) return false;
@@ -100,11 +102,14 @@ bool temporalPrepare(Ctx& c) {
     uploaded = true;
   }
   T.S = S; T.Sx = Sx; T.Sy = Sy; T.nn = nn; T.step = step; T.NT = nn * S;
-  if (uploaded || T.grpF != F || T.grpStep != step || T.grpFa != h->itemFa || T.grpFb != h->itemFb) {
+  // (the units of the pair part: the work items of the constraint walk, or -- explicit cross blocks -- the undirected pairs)
+  const std::vector<int>& unitFa = c.cross ? h->xFa : h->itemFa;
+  const std::vector<int>& unitFb = c.cross ? h->xFb : h->itemFb;
+  if (uploaded || T.grpF != F || T.grpStep != step || T.grpFa != unitFa || T.grpFb != unitFb) {
     // groups of items by the pair of node intervals their frames fall into, <= kGroup items each
     constexpr size_t kGroup = 48;
     std::map<std::pair<int, int>, std::vector<int>> cells;
-    for (size_t i = 0; i < h->itemFa.size(); ++i) cells[{h->itemFa[i] / step, h->itemFb[i] / step}].push_back(static_cast<int>(i));
+    for (size_t i = 0; i < unitFa.size(); ++i) cells[{unitFa[i] / step, unitFb[i] / step}].push_back(static_cast<int>(i));
     std::vector<int> gOff{0}, gItems;
     std::map<std::pair<int, int>, std::vector<int>> blocks;  // (a, b), a <= b -> gather entries
     for (int a = 0; a < nn; ++a) {
@@ -145,11 +150,11 @@ bool temporalPrepare(Ctx& c) {
     HIP_CHECK(hipStreamSynchronize(s));
     T.nGroups = static_cast<int>(gOff.size()) - 1;
     T.nBlocks = static_cast<int>(blkA.size());
-    T.grpF = F; T.grpStep = step; T.grpFa = h->itemFa; T.grpFb = h->itemFb;
+    T.grpF = F; T.grpStep = step; T.grpFa = unitFa; T.grpFb = unitFb;
   }
   const size_t SS = static_cast<size_t>(S) * S, NT = static_cast<size_t>(T.NT);
   T.Cf.ensure(static_cast<size_t>(F) * SS);
-  T.E.ensure(std::max<size_t>(1, h->itemFa.size()) * SS);
+  T.E.ensure(std::max<size_t>(1, unitFa.size()) * SS);
   T.part.ensure(std::max<size_t>(1, static_cast<size_t>(T.nGroups)) * 4 * SS);
   T.A.ensure(NT * NT);
   T.Ainv.ensure(NT * NT);
@@ -227,7 +232,16 @@ void launchTemporalSetup(Ctx& c, const double* x, int half) {
   hipLaunchKernelGGL(k_tl_diag, dim3(L.F), dim3(256), ldsD, s, L, h->dH.p, h->dLam.p, h->dMask.p, tb, T.Cf.p,
                      h->dist() ? h->ownFirst() : 0, h->dist() ? h->ownCount() : L.F);
   HIP_CHECK(hipGetLastError());
-  if (c.nItems > 0) {
+  if (c.cross) {
+    if (!h->xFa.empty()) {
+      allowLds(k_tl_edges_cross, ldsD);
+      hipLaunchKernelGGL(k_tl_edges_cross, dim3(static_cast<unsigned>(h->xFa.size())), dim3(256), ldsD, s, L, h->dXFa.p, h->dXFb.p,
+                         h->dXBlocks.p, h->dMask.p, tb, T.E.p);
+      hipLaunchKernelGGL(k_tl_reduce, dim3(T.nGroups), dim3(256), 0, s, T.S, T.step, T.gOff.p, T.gItems.p, h->dXFa.p, h->dXFb.p, T.E.p,
+                         T.part.p);
+      HIP_CHECK(hipGetLastError());
+    }
+  } else if (c.nItems > 0) {
     const size_t ldsE = 2 * static_cast<size_t>(L.B) * 8 + 2 * sizeof(FrameConst) + SS * 8 + 3 * static_cast<size_t>(L.gx + L.gy) * 4 + 16;
     allowLds(k_tl_edges<false>, ldsE);
     hipLaunchKernelGGL(k_tl_edges<false>, dim3(c.nItems), dim3(256), ldsE, s, L, c.T, c.it, x, fcBuf, h->dMask.p, tb, T.E.p);
