@@ -344,6 +344,7 @@ struct cvd_handle_t {
     DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart, rec;
     DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
     hipEvent_t evIn = nullptr, evDone = nullptr;  // fork / join of the assembly on the side stream
+    bool sidePending = false;                     // ... forked and not yet joined (a solve that throws in between joins on its way out)
     double* sqPtr = nullptr; // where the frames' restricted products live: sq, or (pair-sharded, fused exchange) behind [q | Z^T q | p.q]
   } temporal;
   // measured on this handle (cvd_solve.hip: denseRebuildThreshold): an in-line rebuild of the dense coarse level and a PCG iteration

@@ -240,7 +240,13 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   struct PendingGuard {
     cvd_handle* h;
     bool pending = false;
-    ~PendingGuard() { if (pending) (void)hipStreamWaitEvent(h->stream, h->evCoarseDone, 0); }
+    ~PendingGuard() {
+      if (pending) (void)hipStreamWaitEvent(h->stream, h->evCoarseDone, 0);
+      if (h->temporal.sidePending) {  // (the third level's assembly was forked and the solve left before its join)
+        (void)hipStreamWaitEvent(h->stream, h->temporal.evDone, 0);
+        h->temporal.sidePending = false;
+      }
+    }
   } pendingGuard{h};
   const bool dbgSetup = h->opt.verbose >= 3;  // development: where a solve's fixed cost goes
   double tPhase = nowSeconds();

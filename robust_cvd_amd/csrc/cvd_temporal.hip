@@ -208,7 +208,10 @@ void launchTemporalSetup(Ctx& c, const double* x, int half) {
   const bool side = !h->dist() && h->stream2 != nullptr;
   hipStream_t s = (half == 0 && side) ? h->stream2 : h->stream;
   if (half == 1) {
-    if (side) HIP_CHECK(hipStreamWaitEvent(h->stream, T.evDone, 0));
+    if (side && T.sidePending) {
+      HIP_CHECK(hipStreamWaitEvent(h->stream, T.evDone, 0));
+      T.sidePending = false;
+    }
     temporalInverse(c);
     return;
   }
@@ -261,7 +264,10 @@ void launchTemporalSetup(Ctx& c, const double* x, int half) {
   }
   hipLaunchKernelGGL(k_tl_shift_diag, dim3((T.NT + 255) / 256), dim3(256), 0, s, T.NT, T.NT, T.A.p, h->opt.coarse_dense_shift);
   HIP_CHECK(hipGetLastError());
-  if (side) HIP_CHECK(hipEventRecord(T.evDone, s));
+  if (side) {
+    HIP_CHECK(hipEventRecord(T.evDone, s));
+    T.sidePending = true;
+  }
 }
 
 static void temporalInverse(Ctx& c) {
