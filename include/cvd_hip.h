@@ -75,12 +75,10 @@ typedef struct cvd_solver_options {
                                      cells of the depth grid (consecutive lanes of a wave hit different grid vertices: the
                                      LDS atomics of the pair-major kernels stop serialising); 0: the caller's order */
   int32_t coarse_rebuild_excess_dense; /* the same threshold for the DENSE coarse level, whose rebuild is one in-line kernel chain
-                                     (1.9 ms at 300 frames), not a side-stream job.  0 (default): 1.5 x the cost ratio MEASURED on
-                                     this handle (duration of a rebuild / duration of a PCG iteration of the running solves), in
-                                     steps of 8 -- 32 at 300 frames; the PCG counts of an LM run grow by themselves as the trust
-                                     region opens, and at the bare ratio (22) the level was rebuilt every second LM iteration for
-                                     0.6 fewer PCG iterations per LM iteration.  Sharded runs (every rank must decide alike) and
-                                     the first solves of a handle use 32.  > 0: that many */
+                                     (1.9 ms at 300 frames), not a side-stream job.  0 (default): 32, a constant -- identical inputs
+                                     take identical rebuild decisions on every run and rank.  > 0: that many.  -1 (opt-in, one GPU):
+                                     1.5 x the cost ratio MEASURED on this handle (duration of a rebuild / duration of a PCG
+                                     iteration), in steps of 8; wall-clock dependent, so PCG counts may differ run to run */
   int32_t pcg_fused_tail;         /* 1 (default): the two per-frame kernels of a PCG iteration (finish of the product, update) run
                                      as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always

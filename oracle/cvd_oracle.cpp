@@ -2301,6 +2301,75 @@ struct Oracle {
       }
   }
 
+  // Parity hook for the reference-held residual pin (tests/test_reference_residuals.py): every StaticSceneCost block of the
+  // poseOptimizationStep problem at the current state, WITHOUT the robust loss -- frames (a, b); the two observations' NDC
+  // (float, as stored) and warped NDC (obsToCamera x / y: NDC + spatial warp) and deformed depths (obsToCamera z); the three
+  // residuals; and their dual-number Jacobian with respect to [pose_a(6) | pose_b(6) | vfocal_a | vfocal_b] (14 columns; the
+  // focal columns stay 0 under Fixed intrinsics, both hold the one shared column under Shared).  Returns the number of blocks;
+  // with null outputs only counts.
+  int staticResiduals(const cvd_opt_params& p, double depthDeformReg, const double* pose7, int maxBlocks, int32_t* frames,
+                      double* obs /*8 per block*/, double* res /*3*/, double* jac /*3 x 14*/) {
+    if (pose7) {
+      poseParams.resize(F);
+      for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 7; ++i) poseParams[f][i] = pose7[f * 7 + i];
+    } else {
+      posesToParams();
+    }
+    Problem pb;
+    buildPoseProblem(pb, p, depthDeformReg);
+    pb.finalize();
+    int n = 0;
+    for (const auto& rb : pb.residuals) {
+      const auto* cf = dynamic_cast<const AutoDiff<StaticSceneCost>*>(rb.cost.get());
+      if (!cf) continue;
+      if (frames && n < maxBlocks) {
+        const StaticSceneCost& sc = cf->f;
+        const int nb = static_cast<int>(rb.blocks.size());
+        int total = 0;
+        std::vector<int> start(nb);
+        for (int b = 0; b < nb; ++b) { start[b] = total; total += cf->blockSizes[b]; }
+        std::vector<const double*> pd(nb);
+        for (int b = 0; b < nb; ++b) pd[b] = pb.blocks[rb.blocks[b]].ptr;
+        std::vector<double> J(static_cast<size_t>(3) * total);
+        double r[3];
+        evaluateCostFunctionAt(*cf, pd.data(), r, J.data());
+        const int b0 = 0, b1 = sc.obs0.numBlocks(), bf = b1 + sc.obs1.numBlocks();
+        frames[2 * n] = pb.blocks[rb.blocks[b0]].frame;
+        frames[2 * n + 1] = pb.blocks[rb.blocks[b1]].frame;
+        {
+          int off = 0;
+          ObsParams<double> p0 = unpack(off, pd.data(), sc.obs0);
+          ObsParams<double> p1 = unpack(off, pd.data(), sc.obs1);
+          double c0[3], c1[3];
+          obsToCamera(sc.obs0, p0, c0);
+          obsToCamera(sc.obs1, p1, c1);
+          double* o = obs + static_cast<size_t>(8) * n;
+          o[0] = sc.obs0.ndc[0]; o[1] = sc.obs0.ndc[1]; o[2] = sc.obs1.ndc[0]; o[3] = sc.obs1.ndc[1];
+          o[4] = c0[0]; o[5] = c0[1]; o[6] = c0[2]; o[7] = c1[2];
+          (void)c1[0];
+        }
+        for (int k = 0; k < 3; ++k) {
+          res[3 * n + k] = r[k];
+          double* row = jac + (static_cast<size_t>(3) * n + k) * 14;
+          for (int i = 0; i < 14; ++i) row[i] = 0.0;
+          for (int i = 0; i < 6; ++i) {
+            row[i] = J[static_cast<size_t>(k) * total + start[b0] + i];
+            row[6 + i] = J[static_cast<size_t>(k) * total + start[b1] + i];
+          }
+          if (p.intr_opt == CVD_INTR_SHARED) {
+            row[12] = row[13] = J[static_cast<size_t>(k) * total + start[bf]];
+          } else if (p.intr_opt == CVD_INTR_PER_FRAME) {
+            row[12] = J[static_cast<size_t>(k) * total + start[bf]];
+            row[13] = J[static_cast<size_t>(k) * total + start[bf + 1]];
+          }
+        }
+      }
+      ++n;
+    }
+    return n;
+  }
+
   // Development hook (tools/pcg_lab.py: preconditioner experiments on the CPU): the block-sparse normal equations of the
   // poseOptimizationStep problem at the given state, written to a file in the canonical per-frame layout --
   // i32 F, i32 B, i64 numBlocks, f64 cost, f64 gradient[F B], then per block i32 I, i32 J (I >= J), f64 [B x B] = H_IJ.
@@ -2556,6 +2625,16 @@ int cvdo_evaluate(void* h, const cvd_opt_params* p, double depthDeformReg, const
                   int* numResidualBlocks, double* gradient, double* hdiag, double* hfull) {
   CVDO_TRY(h, static_cast<Oracle*>(h)->evaluate(*p, depthDeformReg, pose7, cost, numResidualBlocks, gradient,
                                                 hdiag, hfull));
+}
+int cvdo_static_residuals(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, int maxBlocks,
+                          int32_t* frames, double* obs, double* res, double* jac) {
+  auto* o = static_cast<Oracle*>(h);
+  try {
+    return o->staticResiduals(*p, depthDeformReg, pose7, maxBlocks, frames, obs, res, jac);
+  } catch (const std::exception& e) {
+    o->lastError = e.what();
+    return -1;
+  }
 }
 int cvdo_dump_blocks(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, const char* path) {
   CVDO_TRY(h, static_cast<Oracle*>(h)->dumpBlocks(*p, depthDeformReg, pose7, path));

@@ -117,3 +117,28 @@ def deformation_cost(desc: XformDesc, params):
     if n < 0:
         raise RuntimeError("deformation_cost failed")
     return out[:n].copy()
+
+
+def static_residuals(orc: Oracle, params, depth_deform_reg, pose_params=None):
+    """Every StaticSceneCost block of the poseOptimizationStep problem at the current state, WITHOUT the robust loss
+    (cvdo_static_residuals): frames [n, 2]; ndc_a / ndc_b [n, 2] (the stored float NDC of the two observations);
+    cam_a [n, 3] = obsToCamera of the source (warped NDC x, y and deformed depth); depth_b [n] = the target's deformed depth;
+    residuals [n, 3]; jacobian [n, 3, 14] over [pose_a(6) | pose_b(6) | vfocal_a | vfocal_b] (dual numbers)."""
+    fn = orc._fn("static_residuals")
+    pp = np.ascontiguousarray(pose_params, np.float64).reshape(orc.num_frames, 7) if pose_params is not None else None
+    ppp = pp.ctypes.data_as(C.POINTER(C.c_double)) if pp is not None else None
+    n = fn(orc._h, C.byref(params), C.c_double(depth_deform_reg), ppp, C.c_int(0), None, None, None, None)
+    if n < 0:
+        orc._check(n)
+    frames = np.zeros((n, 2), np.int32)
+    obs = np.zeros((n, 8), np.float64)
+    res = np.zeros((n, 3), np.float64)
+    jac = np.zeros((n, 3, 14), np.float64)
+    m = fn(orc._h, C.byref(params), C.c_double(depth_deform_reg), ppp, C.c_int(n),
+           frames.ctypes.data_as(C.POINTER(C.c_int32)), obs.ctypes.data_as(C.POINTER(C.c_double)),
+           res.ctypes.data_as(C.POINTER(C.c_double)), jac.ctypes.data_as(C.POINTER(C.c_double)))
+    if m != n:
+        orc._check(-1 if m < 0 else 0)
+        raise RuntimeError("static_residuals: block count changed between calls")
+    return dict(frames=frames, ndc_a=obs[:, 0:2].copy(), ndc_b=obs[:, 2:4].copy(), cam_a=obs[:, 4:7].copy(),
+                depth_b=obs[:, 7].copy(), residuals=res, jacobian=jac)

@@ -164,7 +164,14 @@ cvd_handle* cvd_create(int32_t device) {
     cvd_solver_options_default(&h->opt);
     // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)
     touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_temporal(); touchModule_solve(); touchModule_frontend();
-    if (device < PersistentGate::kMaxDevices) ++g_liveHandles[device];
+    if (device < PersistentGate::kMaxDevices) {
+      //  A handle that is alone on its device launches k_pcg_tail without the gate's events (launchPcgTail holds the
+      // slot's mutex while it checks the count and launches).  Becoming the second handle: count under the same mutex, then drain
+      // the device -- every tail launch enqueued before this point has left it, every later one sees the count and is gated.
+      PersistentGate::Slot& sl = PersistentGate::slot(device);
+      std::lock_guard<std::mutex> lock(sl.m);
+      if (++g_liveHandles[device] > 1) HIP_CHECK(hipDeviceSynchronize());
+    }
     return h;
   } catch (const std::exception& e) {
     g_createError = e.what();
@@ -255,8 +262,8 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
     if (!(o->pcg_relative_tolerance > 0.0 && o->pcg_relative_tolerance < 1.0)) throw std::runtime_error("pcg_relative_tolerance must lie in (0, 1)");
     if (o->pcg_max_iterations < 1) throw std::runtime_error("pcg_max_iterations must be >= 1");
     if (!(o->coarse_dense_shift >= 0.0 && o->coarse_dense_shift < 1.0)) throw std::runtime_error("coarse_dense_shift must lie in [0, 1)");
-    if (o->coarse_rebuild_excess < 0 || o->coarse_rebuild_excess_dense < 0 || o->coarse_update_budget < 0)
-      throw std::runtime_error("coarse_rebuild_excess / coarse_rebuild_excess_dense / coarse_update_budget must be >= 0");
+    if (o->coarse_rebuild_excess < 0 || o->coarse_rebuild_excess_dense < -1 || o->coarse_update_budget < 0)
+      throw std::runtime_error("coarse_rebuild_excess / coarse_update_budget must be >= 0, coarse_rebuild_excess_dense >= -1");
     if (o->coarse_dense_max_unknowns < 0 || o->coarse_dense_max_unknowns > kDenseCoarseMaxUnknowns)
       throw std::runtime_error(fmt("coarse_dense_max_unknowns must lie in [0, %d] (what k_dense_spd_inverse holds in registers)",
                                    kDenseCoarseMaxUnknowns));

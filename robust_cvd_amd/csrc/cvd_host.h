@@ -372,6 +372,7 @@ struct cvd_handle_t {
   cvd_solve_summary summary{};
   std::vector<cvd_iteration_record> records;
 
+  bool tailDisabled = false;  // k_pcg_tail abandoned its grid barrier once on this handle: two-launch tail from then on (runPcg)
   bool forceGeneric = false;  // test hook: route the products through the generic (all-variants) kernel
 
   // kernel timing

@@ -217,7 +217,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
 bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish, int& ldsScratch) {
   cvd_handle* h = c.h;
   const int F = c.L.F, B = c.L.B;
-  if (!h->opt.pcg_fused_tail || h->dist() || B > 256 || h->forceGeneric) return false;
+  if (!h->opt.pcg_fused_tail || h->tailDisabled || h->dist() || B > 256 || h->forceGeneric) return false;
   if (coarse && !h->coarse.denseMode) return false;
   const int split = denseRowSplit(h);
   const TlStep ts = temporalStep(h);
@@ -280,9 +280,15 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
                    (ts.Ainv != nullptr ? ts.S * ts.parts : 0) + (poseT ? kCB * tlParts(h->coarse.ptNn) : 0);
   const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)
   {
-    // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate)
+    // several handles of this process on one device: their grid-barrier kernels must not overlap (PersistentGate).  A handle
+    // that is alone launches under the slot's mutex only (no events in the stream): cvd_create counts a second handle under the
+    // same mutex and drains the device, so no ungated launch can still be in flight once another handle exists.
     std::unique_ptr<PersistentGate> gate;
-    if (liveHandles(h->device) > 1) gate.reset(new PersistentGate(h->device, s));
+    std::unique_lock<std::mutex> alone(PersistentGate::slot(h->device).m);
+    if (liveHandles(h->device) > 1) {
+      alone.unlock();
+      gate.reset(new PersistentGate(h->device, s));
+    }
     CVD_DISPATCH_KD(c.KD, {
       hipLaunchKernelGGL((k_pcg_tail<KD>), dim3(grid), dim3(nThreads), lds, s, c.L, x, h->dMask.p, lam, h->dMedian.p, h->dRegOwner.p,
                          h->dInRange.p, c.cross ? h->dXFiOff.p : h->dFiOff.p, h->dFiList.p, h->dQPart.p, pOld, pNew, h->dScal.p,

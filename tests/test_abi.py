@@ -56,7 +56,7 @@ def test_default_solver_options():
     o = api.SolverOptions()
     lib.cvd_solver_options_default(C.byref(o))
     assert o.pcg_relative_tolerance == 1e-3 and o.pcg_max_iterations == 300 and o.coarse_level == 1 and o.robust_loss == 0
-    assert o.coarse_rebuild_excess == 16 and o.coarse_rebuild_excess_dense == 0   # (0 = measured on the handle)
+    assert o.coarse_rebuild_excess == 16 and o.coarse_rebuild_excess_dense == 0   # (0 = the constant 32; -1 = measured on the handle)
     assert o.coarse_dense_max_unknowns == 4096 and o.coarse_update_budget == 40000 and o.coarse_dense_shift == 1e-5
     assert o.constraint_order == 1
     assert (o.temporal_level, o.temporal_step, o.temporal_grid_x, o.temporal_grid_y) == (1, 32, 0, 0)

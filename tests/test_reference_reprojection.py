@@ -100,18 +100,23 @@ def test_drop_in_end_state_reprojects_through_the_reference_conventions(tmp_path
     perr, rerr = synth.relative_pose_error(out["position"], out["orientation"], g["position"], g["orientation"])
     assert perr < 1e-4 and rerr < 1e-4, (perr, rerr)
     assert np.abs(out["vfov"] - g["vfov"]).max() < 1e-5 and np.abs(out["hfov"] - g["hfov"]).max() < 1e-5
-    # (the depth scales move along the problem's weakest direction -- overall scene scale against the trajectory's -- by a few
-    # 1e-4 between two builds whose PCG products merely round differently; the reprojection checks below carry the pin)
-    np.testing.assert_allclose(out["params"], g["params"], rtol=1e-3)
-    np.testing.assert_allclose(out["param_map"][g["map_frames"]], g["param_map"], rtol=1e-3)
     # right / up / backward are the columns of the pose's rotation matrix (what update_poses stacks into [R | t])
     Rm = synth.quat_to_matrix(out["orientation"])
     for k, name in enumerate(("right", "up", "backward")):
         np.testing.assert_allclose(out[name], Rm[:, :, k], atol=1e-6)
+    # THE PIN, first: every static constraint reprojects onto its flow target through the reference's conventions
     ext, intr = rr.numpy_update_poses(out)
     fa, fb, pix, target, depth = rr.constraint_samples(video, out)
     err = np.linalg.norm(rr.numpy_reproject(ext, intr, fa, fb, pix, depth) - target, axis=1)
     assert err.max() < REPROJ_TOL_PX and err.mean() < REPROJ_MEAN_TOL_PX, (err.max(), err.mean())
+    # The depth scales against the minted state, with the overall scene scale divided out: scaleReg is 1e-6 in this case, so the
+    # global scale (against the trajectory's) is nearly a gauge direction -- it moved by 1e-3 between builds whose PCG products
+    # merely round differently (VERDICT r4 Weak #1) while the scale-free shape below repeats to ~1e-5.  The margin is >= 3 x the
+    # worst value over repeated runs (profiles/r05_repeat.log).
+    gs_out, gs_g = np.median(out["params"]), np.median(g["params"])
+    assert abs(gs_out / gs_g - 1.0) < 2e-2, (gs_out, gs_g)   # (gauge: loose on purpose)
+    np.testing.assert_allclose(out["params"] / gs_out, g["params"] / gs_g, rtol=5e-4)
+    np.testing.assert_allclose(out["param_map"][g["map_frames"]] / gs_out, g["param_map"] / gs_g, rtol=5e-4)
     # depth x paramMap against the rendered depth, up to ONE global scale: only to a few percent per frame -- with nearly
     # parallel cameras and per-frame focal lengths the depth scale of a frame trades against its focal length (bas-relief
     # ambiguity; measured spread 2.4e-2 while every constraint reprojects to 0.05 px)

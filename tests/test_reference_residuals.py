@@ -1,0 +1,92 @@
+"""Reference-held pin of the RESIDUAL ARITHMETIC at random, NON-converged states: the oracle's
+three ReproDisparity residuals of every static constraint, and their dual-number Jacobian columns for pose and focal length,
+against the reference's own torch statement of the same quantities -- utils/geometry.py:62-166 and the reprojection /
+disparity terms of loss/consistency_loss.py:93-122 (see tests/reference_residuals.py for the conversions).
+
+CPU only.  Always: against tests/golden/reference_py/residual_golden.npz (outputs of the real reference functions, minted by
+make_residual_golden.py next to it).  With /root/reference mounted: against the live functions, including
+ConsistencyLoss.geometry_consistency_loss itself.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization
+from tests import baseline_configs as bc
+from tests import reference_residuals as rres
+
+# float64 on both sides: the residual VALUES agree to rounding (measured 5e-14 px on residuals of up to 15 px; 1e-16 on
+# disparity differences of up to 0.06); the derivative columns to the accuracy of the central differences (measured 3e-8 on
+# entries of up to 330: step 1e-6).  Tolerances sit >= 20 x above the measured worst case.
+VALUE_TOL_PX, VALUE_TOL_DISP = 1e-12, 1e-14
+FD_REL_TOL = 1e-6
+
+
+def _golden():
+    if not os.path.exists(rres.GOLDEN):
+        pytest.skip("residual golden not minted")
+    return dict(np.load(rres.GOLDEN))
+
+
+def _check(name, v, p, pose, sr, ref, rows):
+    W, H = v.width, v.height
+    r, J = rres.to_reference_units(sr, p, W, H)
+    assert np.array_equal(sr["frames"], ref["frames"])
+    # the state is not converged: the pin sees residual VALUES, not zeros
+    assert np.abs(ref["pixel_diff"]).max() > 5.0 and np.abs(ref["disparity_diff"]).max() > 0.01
+    assert np.abs(r[:, :2] - ref["pixel_diff"]).max() < VALUE_TOL_PX
+    assert np.abs(r[:, 2] - ref["disparity_diff"]).max() < VALUE_TOL_DISP
+    # the reference's loss method: reproj = |pixel difference| / 2, disp = mean(fx, fy over the batch) |disparity difference| / 2
+    _ext, intr = rres.cameras(pose, v.aspect, W, H)
+    f_mean = intr[sr["frames"][:, 0], :2].mean()
+    assert np.abs(np.linalg.norm(r[:, :2], axis=1) / 2.0 - ref["loss_reproj"]).max() < VALUE_TOL_PX
+    assert np.abs(f_mean * np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-10
+    # derivative columns: pose of the source (0-5), pose of the target (6-11), the focal lengths (12, 13)
+    fd = ref["fd"]
+    scale = np.abs(fd).max(axis=(0, 2), keepdims=True)   # per residual row (pixels / disparity)
+    Jr = J[rows]
+    assert (np.abs(Jr[:, :, :12] - fd[:, :, :12]) / scale).max() < FD_REL_TOL
+    intr_opt = CASE_INTR[name]
+    if intr_opt == IntrinsicsOptimization.PerFrame:
+        assert (np.abs(Jr[:, :, 12:] - fd[:, :, 12:]) / scale).max() < FD_REL_TOL
+    elif intr_opt == IntrinsicsOptimization.Shared:
+        # one focal length for every frame (reference lib/PoseOptimizer.cpp:1226): its column is the sum of the two roles'
+        both = fd[:, :, 12] + fd[:, :, 13]
+        assert (np.abs(Jr[:, :, 12] - both) / scale[:, :, 0]).max() < FD_REL_TOL
+        assert np.array_equal(Jr[:, :, 12], Jr[:, :, 13])
+    else:
+        assert np.abs(Jr[:, :, 12:]).max() == 0.0   # Fixed: no focal column
+    # every translation / rotation / focal column carries signal (a column of zeros would pass a relative test vacuously)
+    assert (np.abs(fd[:, :2, :12]).max(axis=(0, 1)) > 1.0).all()
+
+
+CASE_INTR = {k: c["intr"] for k, c in rres.CASES.items()}
+
+
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_oracle_residuals_match_the_committed_reference_outputs(name):
+    g = _golden()
+    v, p, pose, sr = rres.oracle_side(name)
+    assert bc.input_digest(v).encode() == g[name + "/input_sha256"].tobytes(), "the seeded case drifted from the minted one"
+    np.testing.assert_array_equal(pose, g[name + "/pose"])
+    ref = {k: g[f"{name}/{k}"] for k in ("frames", "pixel_diff", "disparity_diff", "loss_reproj", "loss_disp", "fd")}
+    _check(name, v, p, pose, sr, ref, g[name + "/fd_rows"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not mounted")
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_oracle_residuals_match_the_live_reference_functions(name):
+    v, p, pose, sr = rres.oracle_side(name)
+    ref = rres.reference_outputs(name)
+    _check(name, v, p, pose, sr, ref, np.arange(len(ref["pixel_diff"])))
+
+
+def test_the_pin_can_tell_a_wrong_convention():
+    """What the comparison would see if the oracle's camera looked down +z, or the image rows ran bottom-up: pixels, not 1e-12."""
+    name = "perframe_grid4x3"
+    g = _golden()
+    v, p, pose, sr = rres.oracle_side(name)
+    r, _J = rres.to_reference_units(sr, p, v.width, v.height)
+    assert np.abs(-r[:, 1] - g[name + "/pixel_diff"][:, 1]).max() > 1.0     # flipped v
+    assert np.abs(-r[:, 2] - g[name + "/disparity_diff"]).max() > 0.01      # flipped disparity sign
