@@ -2774,13 +2774,30 @@ struct FastTaps<16> {
   __device__ __forceinline__ double Wt(int k) const { return s.fx[k & 3] * s.fy[k >> 2]; }
 };
 
+// gridCell (cvd_device.h) in 6 instructions instead of 9, bit-identical: (loc + 1) is exact in double, so one FMA rounds the same
+// real number as the product (loc + 1) * ((g - 1) / 2) does ((g - 1) / 2 is a half-integer: exact), and for the clamped s >= 0
+// v_fract_f64 is s - trunc(s).  For the hot product's loop (four cells per constraint).
+__device__ __forceinline__ void gridCellFast(float loc, double hg, double maxc, int& i, double& r) {
+  double s = __builtin_fma(static_cast<double>(loc), hg, hg);
+  s = fmin(fmax(s, 0.0), maxc);
+  i = static_cast<int>(s);
+  r = __builtin_amdgcn_fract(s);
+}
 template <int KD>
 __device__ __forceinline__ void fastGather(const Layout& L, float lx, float ly, FastTaps<KD>& t) {
   if constexpr (KD == 16) {
     bicubicSeparable(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.s);
     t.gx = L.gx;
   } else if constexpr (KD == 4) {
-    bilinearTaps(lx, ly, L.gx, L.gy, L.maxcx, L.maxcy, t.idx, t.w);
+    int ix, iy;
+    double rx, ry;
+    gridCellFast(lx, 0.5 * static_cast<double>(L.gx - 1), L.maxcx, ix, rx);
+    gridCellFast(ly, 0.5 * static_cast<double>(L.gy - 1), L.maxcy, iy, ry);
+    const int i0 = ix + iy * L.gx;
+    t.idx[0] = i0;            t.w[0] = (1.0 - rx) * (1.0 - ry);
+    t.idx[1] = i0 + 1;        t.w[1] = rx * (1.0 - ry);
+    t.idx[2] = i0 + L.gx;     t.w[2] = (1.0 - rx) * ry;
+    t.idx[3] = i0 + L.gx + 1; t.w[3] = rx * ry;
   } else {
     t.idx[0] = 0;
     t.w[0] = 1.0;
@@ -2913,13 +2930,18 @@ __device__ unsigned long long g_mvProf[4096 * 8];
 #else
 #define MV_STAMP(slot) do {} while (0)
 #endif
-constexpr int kRedVals = 27;               // accumulators of k_matvec_pairs_fast reduced per workgroup
+constexpr int kRedVals = 15;               // accumulators of k_matvec_pairs_fast reduced per workgroup (11 + the 4 depth-block sums of KD = 1)
+constexpr int kMvPose = 24;                // LDS doubles of its rotation constants: J_l (9) and e = J_l p_w (3) of both frames
 constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 
 // SPEC = 1: the default pipeline's variant fixed at compile time (one value parameter per vertex, ReproDisparity loss,
 // Cauchy robustifier): the branches on the runtime Layout fields drop out of the constraint loop.
+#ifndef CVD_MV_WAVES
+#define CVD_MV_WAVES 4   // waves per SIMD the specialised list-mode product (Global / bilinear) is compiled for (round 5: 129 -> 128
+                         // VGPRs; 3 = rounds 2-4 and still the bicubic and dense variants, which spill at 128)
+#endif
 template <int KD, int NT, int SPEC = 0, bool DENSE = false>
-inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? 3 : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
+inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? ((KD <= 4 && !DENSE) ? CVD_MV_WAVES : 3) : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc,
                                                            const double* __restrict__ mask,
                                                            const double* __restrict__ z, const double* __restrict__ pOld,
@@ -2929,7 +2951,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // that the flag does not cost a dependent global round trip of its own in every working launch)
   const double sDone = scal[S_DONE];
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int NV = KD == 1 ? kRedVals : 23;  // the depth-block sums exist only with one tap per side
+  constexpr int NV = KD == 1 ? kRedVals : 11;  // the depth-block sums exist only with one tap per side
   constexpr double eps = 1e-6;
   const int B = L.B;
   if (threadIdx.x == 0) MV_STAMP(0);
@@ -2940,8 +2962,8 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   double* qa = pb + B;
   double* qb = qa + B;
   FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
-  double* E = reinterpret_cast<double*>(fcs + 2);  // E_a[9], E_b[9]
-  double* red = E + 18;                            // 27 reduced accumulators
+  double* JL = reinterpret_cast<double*>(fcs + 2); // per frame: J_l[9] (row i = a_i, dR/dw_i = [a_i]x R) and e[3] = sum_i p_w,i a_i
+  double* red = JL + kMvPose;                      // the reduced accumulators
   double* W = red + 32;                            // transposed reduction scratch: kRedVals rows x kRedStride
   // Dense mode: neighbouring lanes are neighbouring pixels and hit the SAME grid vertices -- 64-way same-address LDS
   // atomics.  The grid columns are therefore accumulated into kPriv lane-keyed private copies (after W) and folded
@@ -3029,11 +3051,28 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     }
   }
   __syncthreads();
-  if (tid < 18) {
-    const int which = tid / 9, e = tid % 9;
+  // Rotation derivatives in CROSS-PRODUCT form (round 5).  R(w) = exp([w]x)  =>  dR/dw_i = [a_i]x R with a_i the i-th column of
+  // the left Jacobian of SO(3); a_i is read off the frame constants as the axial vector of dR_i R^T.  With e = sum_i p_w,i a_i
+  //   forward   source: sum_i p_w,i dR_i c = e x (R c);   target: sum_i p_w,i dR_i^T v = R^T (v x e)
+  //   adjoint   source: y . dR_i (D c)   = a_i . ((D R c) x y);   target: y_q . dR_i^T v = -a_i . (v x R y_q)
+  // so a constraint contributes ONE cross product v x y_X to the rotation rows of both frames (3 accumulators and 6
+  // instructions instead of the two 3 x 3 outer products: 18 accumulators, 21 instructions), the 18 E entries of a trip's LDS
+  // broadcast reads become 6 scalars, and the workgroup reduction carries 11 values instead of 23.
+  if (tid < 6) {
+    const int which = tid / 3, k = tid % 3;
+    const int r = (k + 2) % 3, cc = (k + 1) % 3;   // axial component k of M = dR_i R^T: (M[r][cc] - M[cc][r]) / 2
     const double* pp = which ? pb : pa;
     const FrameConst& f = fcs[which];
-    E[tid] = pp[3] * f.dR[0][e] + pp[4] * f.dR[1][e] + pp[5] * f.dR[2][e];
+    double e = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double* D = f.dR[i];
+      const double m = 0.5 * ((D[r * 3] * f.R[cc * 3] + D[r * 3 + 1] * f.R[cc * 3 + 1] + D[r * 3 + 2] * f.R[cc * 3 + 2]) -
+                              (D[cc * 3] * f.R[r * 3] + D[cc * 3 + 1] * f.R[r * 3 + 1] + D[cc * 3 + 2] * f.R[r * 3 + 2]));
+      JL[which * 12 + i * 3 + k] = m;
+      e += pp[3 + i] * m;
+    }
+    JL[which * 12 + 9 + k] = e;
   }
   __syncthreads();
   if (threadIdx.x == 0) MV_STAMP(1);
@@ -3041,14 +3080,12 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   const int N = SPEC ? 1 : L.N;
   const int lossType = SPEC ? static_cast<int>(kLossDisparity) : L.lossType;
   const double A = L.aspect;
-  // The pose-level accumulators are kept per ROLE (source / target) and swapped between the two directions, so
-  // that one reduction serves both: O_src of direction 0 and O_tgt of direction 1 both contract with dR of frame
-  // `fa` (q_w,i = <dR_i, O> for either role), the translation adjoint changes sign, the focal sums swap.
-  double aT[3] = {0, 0, 0};  // sum y_X  (q_t,src = +aT, q_t,tgt = -aT)
-  double Oa[9], Ob[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { Oa[i] = 0.0; Ob[i] = 0.0; }
-  double aFa = 0.0, aFb = 0.0;
+  // The pose-level accumulators serve both directions through ONE reduction: aT = sum y_X of the running direction (the
+  // translation adjoint: q_t,src = +aT, q_t,tgt = -aT; direction 0's sum is parked in aT0, the rotation rows need both),
+  // Cx = sum v x y_X (negated between the directions: source and target swap), the focal sums per ROLE (swapped).
+  double aT[3] = {0, 0, 0}, aT0[3] = {0, 0, 0};
+  double Cx[3] = {0, 0, 0};
+  double aFa = 0.0, aFb = 0.0;  // (unnormalised: x 1 / fy of the frame in the epilogue)
   double gDa[2] = {0.0, 0.0}, gDb[2] = {0.0, 0.0};  // KD == 1: every sample hits the one depth block -> registers
   const long long units0 = (it.range[item * 4 + 1] - it.range[item * 4] + 63) >> 6;  // wave-units of direction 0
   for (int dir = 0; dir < 2; ++dir) {
@@ -3056,17 +3093,15 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // role swap for the reverse pair (source = fb, target = fa): swap every per-frame pointer
   const FrameConst& Fa = fcs[dir];
   const FrameConst& Fb = fcs[dir ^ 1];
-  const double* Esrc = E + 9 * dir;
-  const double* Eb = E + 9 * (dir ^ 1);
+  const double* JLa = JL + 12 * dir;
+  const double* JLb = JL + 12 * (dir ^ 1);
   if (dir) {
     double* t;
     t = xa; xa = xb; xb = t;
     t = pa; pa = pb; pb = t;
     t = qa; qa = qb; qb = t;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { const double o = Oa[i]; Oa[i] = Ob[i]; Ob[i] = o; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) aT[i] = -aT[i];
+    for (int i = 0; i < 3; ++i) { aT0[i] = aT[i]; aT[i] = 0.0; Cx[i] = -Cx[i]; }
     { const double o = aFa; aFa = aFb; aFb = o; }
 #pragma unroll
     for (int n = 0; n < 2; ++n) { const double o = gDa[n]; gDa[n] = gDb[n]; gDb[n] = o; }
@@ -3074,16 +3109,25 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // The frame constants are the same for every lane: hand them to the loop as SCALAR values (v_readfirstlane of the
   // LDS copy -> SGPRs; a VALU instruction takes one scalar operand).  Rotations and translations of both frames are
   // 24 doubles = 48 VGPRs less per lane: 193 -> 14x VGPRs, three waves per SIMD instead of two.
-  double RaU[9], RbU[9], taU[3], tbU[3];
+  double RaU[9], RbU[9], dTU[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { RaU[i] = uniformValue(Fa.R[i]); RbU[i] = uniformValue(Fb.R[i]); }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { taU[i] = uniformValue(Fa.t[i]); tbU[i] = uniformValue(Fb.t[i]); }
-  // (E and the pose part of p stay LDS broadcast reads inside the loop: as scalars too they overflow the SGPR file --
-  // 80 spills -- and hoisted into VGPRs they cost the third wave)
+  for (int i = 0; i < 3; ++i) dTU[i] = uniformValue(Fa.t[i] - Fb.t[i]);
+  // (round 5: the rotation parts of the search direction are 3 + 3 scalars -- e of both frames -- and its translation / focal
+  // parts another 5; as 18 + 14 values they overflowed the SGPR file and were LDS broadcast reads inside the loop)
+  double eaU[3], ebU[3], dptU[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    eaU[i] = uniformValue(JLa[9 + i]);
+    ebU[i] = uniformValue(JLb[9 + i]);
+    dptU[i] = uniformValue(pa[i] - pb[i]);
+  }
   const double fya = uniformValue(Fa.fy), fxa = fya * A;
   const double fyb = uniformValue(Fb.fy);
   const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
+  const double pfaU = uniformValue(pa[6]) / fya;          // p_f,src / fy_src: the focal column of the source is D R (c + e_z) / fy
+  const double pfrU = L.ws * uniformValue(pb[6]) * ifyb;   // ws p_f,tgt / fy_tgt
 
   const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
   const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
@@ -3119,9 +3163,9 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
           if (N == 2) {
             Da += (da * xa[7 + ia * 2] + xa[7 + ia * 2 + 1]) * wa;
             sDa += (da * pa[7 + ia * 2] + pa[7 + ia * 2 + 1]) * wa;
-          } else {
-            Da += da * xa[7 + ia] * wa;
-            sDa += da * pa[7 + ia] * wa;
+          } else {  // (one value parameter: the source depth multiplies the interpolated scale once, below)
+            Da += xa[7 + ia] * wa;
+            sDa += pa[7 + ia] * wa;
           }
         }
         if (tb.ok(k)) {
@@ -3131,18 +3175,18 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
             Db += (db * xb[7 + ib * 2] + xb[7 + ib * 2 + 1]) * wb;
             sDb += (db * pb[7 + ib * 2] + pb[7 + ib * 2 + 1]) * wb;
           } else {
-            Db += db * xb[7 + ib] * wb;
-            sDb += db * pb[7 + ib] * wb;
+            Db += xb[7 + ib] * wb;
+            sDb += pb[7 + ib] * wb;
           }
         }
       }
+      if (N != 2) { Da *= da; sDa *= da; Db *= db; sDb *= db; }
     }
     const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
     const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
     const double ca[3] = {pax * fxa, pay * fya, -1.0};
     const double Rca[3] = {dot3(RaU, ca), dot3(RaU + 3, ca), dot3(RaU + 6, ca)};
-    const double v[3] = {taU[0] + Rca[0] * Da - tbU[0], taU[1] + Rca[1] * Da - tbU[1],
-                         taU[2] + Rca[2] * Da - tbU[2]};
+    const double v[3] = {dTU[0] + Rca[0] * Da, dTU[1] + Rca[1] * Da, dTU[2] + Rca[2] * Da};
     const double q0 = RbU[0] * v[0] + RbU[3] * v[1] + RbU[6] * v[2];
     const double q1 = RbU[1] * v[0] + RbU[4] * v[1] + RbU[7] * v[2];
     const double q2 = RbU[2] * v[0] + RbU[5] * v[1] + RbU[8] * v[2];
@@ -3179,40 +3223,33 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     const double rho1 = SPEC ? rcpFast(1.0 + sq * L.cauchyC) : robustRho1(L, sq);
 
     // ---- forward: dX, dq, t
-    const double cf[3] = {pax * A, pay, 0.0};
-    const double Rcf[3] = {RaU[0] * cf[0] + RaU[1] * cf[1], RaU[3] * cf[0] + RaU[4] * cf[1],
-                           RaU[6] * cf[0] + RaU[7] * cf[1]};
-    const double Eca[3] = {dot3(Esrc, ca), dot3(Esrc + 3, ca), dot3(Esrc + 6, ca)};
-    const double pfa = pa[6], pfb = pb[6];
+    // R c_f, c_f = d c_a / d fy = (c_a + e_z) / fy: the rotated ray plus R's third column (the 1 / fy sits in pfaU and, for the
+    // adjoint, in the epilogue)
+    const double Rcf[3] = {Rca[0] + RaU[2], Rca[1] + RaU[5], Rca[2] + RaU[8]};
+    const double Eca[3] = {eaU[1] * Rca[2] - eaU[2] * Rca[1], eaU[2] * Rca[0] - eaU[0] * Rca[2], eaU[0] * Rca[1] - eaU[1] * Rca[0]};
+    const double vxe[3] = {v[1] * ebU[2] - v[2] * ebU[1], v[2] * ebU[0] - v[0] * ebU[2], v[0] * ebU[1] - v[1] * ebU[0]};
     double w3[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) w3[i] = pa[i] + Da * (Eca[i] + pfa * Rcf[i]) + sDa * Rca[i] - pb[i];
-    const double dq0 = RbU[0] * w3[0] + RbU[3] * w3[1] + RbU[6] * w3[2] + Eb[0] * v[0] + Eb[3] * v[1] + Eb[6] * v[2];
-    const double dq1 = RbU[1] * w3[0] + RbU[4] * w3[1] + RbU[7] * w3[2] + Eb[1] * v[0] + Eb[4] * v[1] + Eb[7] * v[2];
-    const double dq2 = RbU[2] * w3[0] + RbU[5] * w3[1] + RbU[8] * w3[2] + Eb[2] * v[0] + Eb[5] * v[1] + Eb[8] * v[2];
+    for (int i = 0; i < 3; ++i) w3[i] = dptU[i] + Da * (Eca[i] + pfaU * Rcf[i]) + sDa * Rca[i] + vxe[i];
+    const double dq0 = RbU[0] * w3[0] + RbU[3] * w3[1] + RbU[6] * w3[2];
+    const double dq1 = RbU[1] * w3[0] + RbU[4] * w3[1] + RbU[7] * w3[2];
+    const double dq2 = RbU[2] * w3[0] + RbU[5] * w3[1] + RbU[8] * w3[2];
     const double wiz = L.ws * iz;
     const double m00 = wiz * ifxb, m11 = wiz * ifyb, m02 = wiz * u, m12 = wiz * vv;
-    const double pfr = pfb * ifyb;
-    double t0 = (m00 * dq0 + m02 * dq2 - L.ws * u * pfr) * rho1;
-    double t1 = (m11 * dq1 + m12 * dq2 - L.ws * vv * pfr) * rho1;
+    double t0 = (m00 * dq0 + m02 * dq2 - u * pfrU) * rho1;
+    double t1 = (m11 * dq1 + m12 * dq2 - vv * pfrU) * rho1;
     double t2 = (-dr2dA * dq2 + dr2dDb * sDb) * rho1;
 
     // ---- backward
     const double yq0 = m00 * t0, yq1 = m11 * t1, yq2 = m02 * t0 + m12 * t1 - dr2dA * t2;
-    aFb -= (L.ws * u * t0 + L.ws * vv * t1) * ifyb;
+    aFb -= L.ws * (u * t0 + vv * t1);
     const double yX[3] = {RbU[0] * yq0 + RbU[1] * yq1 + RbU[2] * yq2, RbU[3] * yq0 + RbU[4] * yq1 + RbU[5] * yq2,
                           RbU[6] * yq0 + RbU[7] * yq1 + RbU[8] * yq2};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      aT[i] += yX[i];
-      const double dy = Da * yX[i];
-      Oa[i * 3 + 0] += dy * ca[0];
-      Oa[i * 3 + 1] += dy * ca[1];
-      Oa[i * 3 + 2] += dy * ca[2];
-      Ob[i * 3 + 0] += v[i] * yq0;
-      Ob[i * 3 + 1] += v[i] * yq1;
-      Ob[i * 3 + 2] += v[i] * yq2;
-    }
+    for (int i = 0; i < 3; ++i) aT[i] += yX[i];
+    Cx[0] += v[1] * yX[2] - v[2] * yX[1];
+    Cx[1] += v[2] * yX[0] - v[0] * yX[2];
+    Cx[2] += v[0] * yX[1] - v[1] * yX[0];
     aFa += Da * (Rcf[0] * yX[0] + Rcf[1] * yX[1] + Rcf[2] * yX[2]);
     if (N > 0) {
       const double ga = Rca[0] * yX[0] + Rca[1] * yX[1] + Rca[2] * yX[2];
@@ -3230,26 +3267,27 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
       const int pkey = (DENSE ? tid : (tid ^ (tid >> 5))) & (kPriv - 1);
       double* qaw = kUsePriv ? qpriv + (static_cast<size_t>(pkey) * 2 + dir) * B : qa;
       double* qbw = kUsePriv ? qpriv + (static_cast<size_t>(pkey) * 2 + (dir ^ 1)) * B : qb;
+      const double gad = ga * da, gbd = gb * db;
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
         if (ta.ok(k)) {
           const int ia = ta.I(k);
           const double wa = ta.Wt(k);
           if (N == 2) {
-            atomicAdd(&qaw[7 + ia * 2], ga * wa * da);
+            atomicAdd(&qaw[7 + ia * 2], gad * wa);
             atomicAdd(&qaw[7 + ia * 2 + 1], ga * wa);
           } else {
-            atomicAdd(&qaw[7 + ia], ga * wa * da);
+            atomicAdd(&qaw[7 + ia], gad * wa);
           }
         }
         if (tb.ok(k)) {
           const int ib = tb.I(k);
           const double wb = tb.Wt(k);
           if (N == 2) {
-            atomicAdd(&qbw[7 + ib * 2], gb * wb * db);
+            atomicAdd(&qbw[7 + ib * 2], gbd * wb);
             atomicAdd(&qbw[7 + ib * 2 + 1], gb * wb);
           } else {
-            atomicAdd(&qbw[7 + ib], gb * wb * db);
+            atomicAdd(&qbw[7 + ib], gbd * wb);
           }
         }
       }
@@ -3258,23 +3296,20 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   }
   }  // dir
   MV_STAMP(4 + ((threadIdx.x >> 6) & 3));  // each wave's end of the constraint loop
-  // ---- one workgroup reduction of the 27 accumulators (roles of direction 1: source = fb, target = fa).
+  // ---- one workgroup reduction of the 11 (15) accumulators (roles of direction 1: source = fb, target = fa).
   // Lane pairs store their values transposed into LDS (row = accumulator, column = lane pair, 33-padded 32-column
-  // segments), then 4 threads per accumulator sum one segment each: ~45 LDS ops per thread instead of 27 x 6
+  // segments), then 4 threads per accumulator sum one segment each: ~25 LDS ops per thread instead of 11 x 6
   // cross-lane butterfly steps.
   const FrameConst& Fa = fcs[1];
   const FrameConst& Fb = fcs[0];
   {
     double vals[NV];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vals[i] = aT[i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { vals[3 + i] = Oa[i]; vals[12 + i] = Ob[i]; }
-    vals[21] = aFa;
-    vals[22] = aFb;
-    if constexpr (KD == 1) { vals[23] = gDa[0]; vals[24] = gDa[1]; vals[25] = gDb[0]; vals[26] = gDb[1]; }
+    for (int i = 0; i < 3; ++i) { vals[i] = aT[i]; vals[3 + i] = aT0[i]; vals[6 + i] = Cx[i]; }
+    vals[9] = aFa;
+    vals[10] = aFb;
+    if constexpr (KD == 1) { vals[11] = gDa[0]; vals[12] = gDa[1]; vals[13] = gDb[0]; vals[14] = gDb[1]; }
     // neighbouring lanes are summed in registers first (one DPP swap), so only the even lanes store: half the LDS
-    // (29 KB instead of 57 KB: the workgroup's footprint drops below a quarter of the CU's 160 KB)
     const int half = tid >> 1;
     const int colw = (half >> 5) * 33 + (half & 31);
 #pragma unroll
@@ -3301,30 +3336,33 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     if (tid % SEG == 0) red[tid / SEG] = sacc;
   }
   __syncthreads();
+  // red: [0..2] aT of direction 1 (source fb), [3..5] aT of direction 0 (source fa), [6..8] C = C_1 - C_0, [9] / [10] focal sums of
+  // the source / target ROLE of direction 1, [11..14] the depth-block sums (KD == 1).  With dT = t_src - t_tgt of direction 1:
+  //   q_t,src = aT_1 - aT_0 = -q_t,tgt;   q_w,src,i = a_src,i . (C - dT x aT_1);   q_w,tgt,i = a_tgt,i . (dT x aT_0 - C)
   if (tid < 3) {
-    qa[tid] += red[tid];
-    qb[tid] -= red[tid];
-  } else if (tid < 6) {
-    const int i = tid - 3;  // q_w,src,i = <dR_src,i, O_a>  (O_a[r][c] = sum D y_X[r] c_a[c])
-    double s = 0.0;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) s += Fa.dR[i][e] * red[3 + e];
-    qa[3 + i] += s;
+    const double d = red[tid] - red[3 + tid];
+    qa[tid] += d;
+    qb[tid] -= d;
   } else if (tid < 9) {
-    const int i = tid - 6;  // q_w,tgt,i = <dR_tgt,i, O_b>  (O_b[r][c] = sum v[r] y_q[c]; dq/dw_i = dR_i^T v)
-    double s = 0.0;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) s += Fb.dR[i][e] * red[12 + e];
-    qb[3 + i] += s;
+    const bool tgt = tid >= 6;
+    const int i = tgt ? tid - 6 : tid - 3;
+    const double dT[3] = {Fa.t[0] - Fb.t[0], Fa.t[1] - Fb.t[1], Fa.t[2] - Fb.t[2]};
+    const double* y = red + (tgt ? 3 : 0);
+    const double m[3] = {red[6] - (dT[1] * y[2] - dT[2] * y[1]), red[7] - (dT[2] * y[0] - dT[0] * y[2]),
+                         red[8] - (dT[0] * y[1] - dT[1] * y[0])};
+    const double* a = JL + (tgt ? 0 : 12) + 3 * i;   // (frame fb = fcs[1] is the source of direction 1)
+    const double sdot = a[0] * m[0] + a[1] * m[1] + a[2] * m[2];
+    if (tgt) qb[3 + i] -= sdot;
+    else qa[3 + i] += sdot;
   } else if (tid == 9) {
-    qa[6] += red[21];
+    qa[6] += red[9] / Fa.fy;
   } else if (tid == 10) {
-    qb[6] += red[22];
+    qb[6] += red[10] / Fb.fy;
   } else if (KD == 1 && tid < 15) {
     const int n = (tid - 11) & 1;
     if (n < N) {
-      if (tid < 13) qa[7 + n] += red[23 + n];
-      else qb[7 + n] += red[25 + n];
+      if (tid < 13) qa[7 + n] += red[11 + n];
+      else qb[7 + n] += red[13 + n];
     }
   }
   __syncthreads();
