@@ -47,10 +47,10 @@ if _ROOT not in sys.path:
 SEED = 1234 + 3
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_TFLOPS = 78.6  # MI355X f64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
-# f64 operations per constraint of k_matvec_pairs_fast<4> counted from the kernel source (FMA = 2): gathers 36, depths
-# and their directional derivatives 48, geometry + residual + robust weight 76, forward product 101, adjoint 97
-# 
-FLOPS_PER_CONSTRAINT = 358.0
+# f64 operations per constraint of k_matvec_pairs_fast<4, 256, 1> counted from the COMPILED loop body (FMA = 2): 75 v_mul_f64 +
+# 20 v_add_f64 + 93 fused multiply-adds = 281 (round 5, the cross-product form of the rotation derivatives; rounds 2-4: 358 for
+# the same product -- the fraction below prices the arithmetic the kernel executes, not the arithmetic an older form needed)
+FLOPS_PER_CONSTRAINT = 281.0
 
 CONFIGS = {
     2: dict(frames=300, width=384, height=224, ctf=(17, 10), label="configs[2]"),
@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="development: no HIP-event timing of the hot kernel (roofline fields are then empty)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="N > 1: pair-sharded (strong) or one video per GPU (weak)")
     ap.add_argument("--pcg-lockstep", action="store_true", help="profiling: no PCG run-ahead (clean per-launch counter averages)")
+    ap.add_argument("--lib-variant", default=None, help="development: load lib/libcvd_hip_<name>.so (robust_cvd_amd.build.build_variant)")
     ap.add_argument("--verify", action="store_true",
                     help="N = 1: the oracle runs the SAME number of LM iterations as the last timed solve from the same state and the "
                          "final costs must agree to 1e-6 (minutes of CPU time)")
@@ -261,6 +262,8 @@ def main():
     import torch
     from robust_cvd_amd import api, synth
     from robust_cvd_amd.ctypes_types import OptParams
+    if args.lib_variant:
+        api.load_library(variant=args.lib_variant)
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)

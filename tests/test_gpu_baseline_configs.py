@@ -23,6 +23,7 @@ from oracle.oracle import Oracle
 from robust_cvd_amd import synth
 from robust_cvd_amd.ctypes_types import XformDesc
 from tests import baseline_configs as bc
+from tests import margins
 from tests.helpers import rel
 
 pytestmark = pytest.mark.gpu
@@ -64,11 +65,13 @@ def test_end_state_matches_the_oracle_solution(Solver, name):
     assert list(sol["grid_size"]) == list(ref["grid_size"])
     ctx = f"(inputs {'identical to' if bc.input_digest(video).encode() == ref['input_sha256'].tobytes() else 'DIFFER from'} the minted ones)"
     perr, rerr = synth.relative_pose_error(sol["position"], sol["orientation"], ref["position"], ref["orientation"])
-    assert perr <= POS_TOL and rerr <= ROT_TOL, (perr, rerr, ctx)
+    # (tests/margins.py: every tolerance is logged with its value; policy: worst value over repeated runs <= limit / 3)
+    margins.below("position", perr, POS_TOL, ctx)
+    margins.below("rotation", rerr, ROT_TOL, ctx)
     fc = float(ref["final_cost"])
-    assert abs(sm["final_cost"] - fc) <= COST_TOL * fc, (sm["final_cost"], fc, ctx)
-    assert np.abs(sol["vfov"] - ref["vfov"]).max() <= FOV_TOL and np.abs(sol["hfov"] - ref["hfov"]).max() <= FOV_TOL
-    assert rel(sol["depth_params"], ref["depth_params"]) <= THETA_TOL, ctx
+    margins.below("final cost", abs(sm["final_cost"] - fc) / fc, COST_TOL, ctx)
+    margins.below("fov", max(np.abs(sol["vfov"] - ref["vfov"]).max(), np.abs(sol["hfov"] - ref["hfov"]).max()), FOV_TOL, ctx)
+    margins.below("depth parameters", rel(sol["depth_params"], ref["depth_params"]), THETA_TOL, ctx)
     # deformed depth maps: DepthXform::apply of the HIP end state (device kernel) against the oracle's apply of ITS end
     # state, every frame at config0/1, every 10th frame at config2
     frames = range(video.num_frames) if video.num_frames <= 100 else range(0, video.num_frames, 10)
@@ -78,7 +81,7 @@ def test_end_state_matches_the_oracle_solution(Solver, name):
         dh = s.apply_depth_xforms(f, 1)[0].astype(np.float64)
         do = o.apply_depth_xforms(f, 1)[0].astype(np.float64)
         worst = max(worst, float((np.abs(dh - do) / np.maximum(np.abs(do), 1e-12)).max()))
-    assert worst <= DEPTH_TOL, (worst, ctx)
+    margins.below("deformed depth maps", worst, DEPTH_TOL, ctx)
 
 
 def test_config0_live_oracle_agrees_with_its_fixture():

@@ -14,6 +14,7 @@ import pytest
 from robust_cvd_amd import synth
 from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, XformDesc
 from tests import baseline_configs as bc
+from tests import margins
 
 pytestmark = pytest.mark.gpu
 
@@ -123,12 +124,15 @@ def test_level_saves_iterations_on_the_benchmarked_problem(Solver):
     assert not out[0][3] and out[1][3]
     for lvl in (0, 1):
         sm, perr, rerr, _ = out[lvl]
-        assert sm["termination"] == 0 and perr < 1e-3 and rerr < 1e-3, (lvl, perr, rerr)
-        assert abs(sm["final_cost"] - float(ref["final_cost"])) <= 1e-6 * float(ref["final_cost"])
-    assert out[0][0]["num_iterations"] == out[1][0]["num_iterations"]
+        assert sm["termination"] == 0
+        margins.below(f"level {lvl} position", perr, 1e-3)
+        margins.below(f"level {lvl} rotation", rerr, 1e-3)
+        margins.below(f"level {lvl} final cost", abs(sm["final_cost"] - float(ref["final_cost"])) / float(ref["final_cost"]), 1e-6)
+    margins.same_count("LM iterations with / without the level", out[0][0]["num_iterations"], out[1][0]["num_iterations"])
     # measured over the whole pipeline: 1046 -> 932 with the temporal pose level (the default for this pair graph), 1093 -> 888 with
     # the exact dense one; 50 -> 34 per LM iteration at the final level (profiles/r04_*)
-    assert out[1][0]["total_linear_iterations"] < 0.93 * out[0][0]["total_linear_iterations"], (out[0][0], out[1][0])
+    # (>= 10 % margin on an iteration-count comparison: measured ratio 0.85 - 0.89, asserted < 0.97)
+    margins.below("PCG iterations with / without the level", out[1][0]["total_linear_iterations"] / out[0][0]["total_linear_iterations"], 0.97)
 
 
 @pytest.mark.parametrize("intr", ["per_frame", "fixed"])

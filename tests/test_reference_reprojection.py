@@ -18,6 +18,7 @@ import pytest
 
 from robust_cvd_amd import synth
 from tests import baseline_configs as bc
+from tests import margins
 from tests import reference_reprojection as rr
 
 # The case has an exact solution (zero flow noise; the depth error is a per-frame scale times a field on the optimizer's own
@@ -98,8 +99,9 @@ def test_drop_in_end_state_reprojects_through_the_reference_conventions(tmp_path
     assert bytes(out["depth_desc"]) == bytes(g["depth_desc"])
     # the state the reference code was run on is the state this build produces
     perr, rerr = synth.relative_pose_error(out["position"], out["orientation"], g["position"], g["orientation"])
-    assert perr < 1e-4 and rerr < 1e-4, (perr, rerr)
-    assert np.abs(out["vfov"] - g["vfov"]).max() < 1e-5 and np.abs(out["hfov"] - g["hfov"]).max() < 1e-5
+    margins.below("position vs minted state", perr, 1e-4)
+    margins.below("rotation vs minted state", rerr, 1e-4)
+    margins.below("fov vs minted state", max(np.abs(out["vfov"] - g["vfov"]).max(), np.abs(out["hfov"] - g["hfov"]).max()), 1e-5)
     # right / up / backward are the columns of the pose's rotation matrix (what update_poses stacks into [R | t])
     Rm = synth.quat_to_matrix(out["orientation"])
     for k, name in enumerate(("right", "up", "backward")):
@@ -108,15 +110,17 @@ def test_drop_in_end_state_reprojects_through_the_reference_conventions(tmp_path
     ext, intr = rr.numpy_update_poses(out)
     fa, fb, pix, target, depth = rr.constraint_samples(video, out)
     err = np.linalg.norm(rr.numpy_reproject(ext, intr, fa, fb, pix, depth) - target, axis=1)
-    assert err.max() < REPROJ_TOL_PX and err.mean() < REPROJ_MEAN_TOL_PX, (err.max(), err.mean())
+    margins.below("reprojection max px", err.max(), REPROJ_TOL_PX)
+    margins.below("reprojection mean px", err.mean(), REPROJ_MEAN_TOL_PX)
     # The depth scales against the minted state, with the overall scene scale divided out: scaleReg is 1e-6 in this case, so the
-    # global scale (against the trajectory's) is nearly a gauge direction -- it moved by 1e-3 between builds whose PCG products
-    # merely round differently (VERDICT r4 Weak #1) while the scale-free shape below repeats to ~1e-5.  The margin is >= 3 x the
-    # worst value over repeated runs (profiles/r05_repeat.log).
+    # global scale (against the trajectory's) is nearly a gauge direction.  Five repeated runs of ONE build
+    # (profiles/r05_reproj_repeat.log): the gauge moves by up to 9.3e-4 run to run (this is what turned the round-4 record red:
+    # absolute scales compared at 1e-3), the scale-free shape by 8.9e-5, positions by 2.5e-5.
     gs_out, gs_g = np.median(out["params"]), np.median(g["params"])
-    assert abs(gs_out / gs_g - 1.0) < 2e-2, (gs_out, gs_g)   # (gauge: loose on purpose)
-    np.testing.assert_allclose(out["params"] / gs_out, g["params"] / gs_g, rtol=5e-4)
-    np.testing.assert_allclose(out["param_map"][g["map_frames"]] / gs_out, g["param_map"] / gs_g, rtol=5e-4)
+    margins.below("gauge (overall scale) vs minted state", abs(gs_out / gs_g - 1.0), 2e-2)   # (gauge: loose on purpose)
+    margins.below("scale-free depth scales vs minted state", np.abs(out["params"] / gs_out / (g["params"] / gs_g) - 1.0).max(), 5e-4)
+    margins.below("scale-free paramMap vs minted state",
+                  np.abs(out["param_map"][g["map_frames"]] / gs_out / (g["param_map"] / gs_g) - 1.0).max(), 5e-4)
     # depth x paramMap against the rendered depth, up to ONE global scale: only to a few percent per frame -- with nearly
     # parallel cameras and per-frame focal lengths the depth scale of a frame trades against its focal length (bas-relief
     # ambiguity; measured spread 2.4e-2 while every constraint reprojects to 0.05 px)
