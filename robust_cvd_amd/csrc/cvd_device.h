@@ -94,12 +94,14 @@ __device__ __forceinline__ double robustRho1(const Layout& L, double sq) {
   return 1.0 / (1.0 + sq * L.cauchyC);
 }
 
-// Per-frame constants of one evaluation point (40 doubles).
+// Per-frame constants of one evaluation point (49 doubles).
 struct FrameConst {
   double R[9];      // row-major R(w): ceres::AngleAxisRotatePoint as a matrix (I + [w]x below eps)
   double dR[3][9];  // dR/dw_i, differentiated through the SAME branch
   double t[3];
   double fy;        // vertical focal actually used (vFocal when intrinsics are fixed)
+  double Jl[9];     // row i = a_i, the axial vector of dR_i R^T: dR/dw_i = [a_i]x R (columns of the left Jacobian of SO(3)); the
+                    // pair-major product uses the rotation derivatives in this cross-product form (k_matvec_pairs_fast)
 };
 
 __device__ __forceinline__ void frameConstFromParams(const double* __restrict__ x, int intrOpt, double vFocal,
@@ -150,6 +152,17 @@ __device__ __forceinline__ void frameConstFromParams(const double* __restrict__ 
     fc.dR[0][5] = -1.0; fc.dR[0][7] = 1.0;
     fc.dR[1][2] = 1.0;  fc.dR[1][6] = -1.0;
     fc.dR[2][1] = -1.0; fc.dR[2][3] = 1.0;
+  }
+  // a_i = axial vector of M = dR_i R^T (antisymmetric up to rounding: the antisymmetric part is taken)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double* D = fc.dR[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = (k + 2) % 3, cc = (k + 1) % 3;
+      fc.Jl[i * 3 + k] = 0.5 * ((D[r * 3] * fc.R[cc * 3] + D[r * 3 + 1] * fc.R[cc * 3 + 1] + D[r * 3 + 2] * fc.R[cc * 3 + 2]) -
+                                (D[cc * 3] * fc.R[r * 3] + D[cc * 3 + 1] * fc.R[r * 3 + 1] + D[cc * 3 + 2] * fc.R[r * 3 + 2]));
+    }
   }
 }
 

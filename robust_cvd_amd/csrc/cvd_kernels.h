@@ -2931,7 +2931,6 @@ __device__ unsigned long long g_mvProf[4096 * 8];
 #define MV_STAMP(slot) do {} while (0)
 #endif
 constexpr int kRedVals = 15;               // accumulators of k_matvec_pairs_fast reduced per workgroup (11 + the 4 depth-block sums of KD = 1)
-constexpr int kMvPose = 24;                // LDS doubles of its rotation constants: J_l (9) and e = J_l p_w (3) of both frames
 constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed) in 33-padded segments of 32, +1 skew
 
 // SPEC = 1: the default pipeline's variant fixed at compile time (one value parameter per vertex, ReproDisparity loss,
@@ -2939,6 +2938,13 @@ constexpr int kRedStride = 4 * 33 + 1;     // 128 columns (lane pairs pre-summed
 #ifndef CVD_MV_WAVES
 #define CVD_MV_WAVES 4   // waves per SIMD the specialised list-mode product (Global / bilinear) is compiled for (round 5: 129 -> 128
                          // VGPRs; 3 = rounds 2-4 and still the bicubic and dense variants, which spill at 128)
+#endif
+#ifndef CVD_MV_SLOAD
+#define CVD_MV_SLOAD 1   // 1: frame constants by scalar loads from global memory; 0: staged in LDS, v_readfirstlane per direction
+                         // (same box, 4140-pair set: 39.6 us against 41.4 / 41.9; without the early request below 40.8)
+#endif
+#ifndef CVD_MV_EARLY
+#define CVD_MV_EARLY 1   // 1: direction 0's first table record is requested at the top of the kernel
 #endif
 template <int KD, int NT, int SPEC = 0, bool DENSE = false>
 inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC ? ((KD <= 4 && !DENSE) ? CVD_MV_WAVES : 3) : 2))) void k_matvec_pairs_fast(Layout L, Table T, Items it, const double* __restrict__ x,
@@ -2961,9 +2967,8 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   double* pb = pa + B;
   double* qa = pb + B;
   double* qb = qa + B;
-  FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);
-  double* JL = reinterpret_cast<double*>(fcs + 2); // per frame: J_l[9] (row i = a_i, dR/dw_i = [a_i]x R) and e[3] = sum_i p_w,i a_i
-  double* red = JL + kMvPose;                      // the reduced accumulators
+  FrameConst* fcs = reinterpret_cast<FrameConst*>(qb + B);   // (CVD_MV_SLOAD = 0: both frames' constants)
+  double* red = reinterpret_cast<double*>(fcs + 2);          // the reduced accumulators
   double* W = red + 32;                            // transposed reduction scratch: kRedVals rows x kRedStride
   // Dense mode: neighbouring lanes are neighbouring pixels and hit the SAME grid vertices -- 64-way same-address LDS
   // atomics.  The grid columns are therefore accumulated into kPriv lane-keyed private copies (after W) and folded
@@ -2976,21 +2981,36 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   const int tid = threadIdx.x;
   const int fa = it.fa[item], fb = it.fb[item];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
+  // The frame constants (R, t, fy, J_l of both frames) are wave-uniform READ-ONLY global data at an address that depends on
+  // blockIdx only: the compiler fetches them with scalar loads straight into SGPRs (round 5; rounds 2-4 staged the two structs in
+  // LDS and moved 26 doubles per direction into SGPRs through v_readfirstlane: ~200 instructions per wave and direction).
+#if CVD_MV_SLOAD
+  const FrameConst* __restrict__ fcF[2] = {fc + fa, fc + fb};
+#else
+  const FrameConst* fcF[2] = {fcs, fcs + 1};
+  {
+    constexpr int FCW = sizeof(FrameConst) / 8;
+    if (tid >= NT - 2 * FCW) {  // (the last waves: the first ones carry the coarse loads)
+      const int t = tid - (NT - 2 * FCW);
+      const int which = t / FCW, k = t % FCW;
+      reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
+    }
+  }
+#endif
+  // The first table record of direction 0 is requested before anything else: it is back when the prologue's barriers are.
+  const long long cb0 = it.range[item * 4], ce0 = it.range[item * 4 + 1];
+  // (not the bicubic variant: six more live registers through the prologue spill at its budget)
+  constexpr bool kEarlyPrime = KD <= 4 && CVD_MV_EARLY;
+  RecordStream<DENSE> rs;   // (list mode: the next trip's table record is in flight during this trip's arithmetic)
+  if constexpr (kEarlyPrime) rs.prime(T, cb0, (tid >> 6) * 64 + (tid & 63), static_cast<int>(ce0 - cb0));
   // Prologue in ONE global round trip (the workgroup lives ~5 us, a dependent load costs ~1 us of it): every thread
-  // issues its loads of x / z / p_old / mask for both frames, the coarse correction c_f (see CoarseView) and the
-  // frame constants go to LDS in the same phase, and the search direction is formed after the barrier.  B <= 256:
-  // one element per thread.
-  constexpr int FCW = sizeof(FrameConst) / 8;
+  // issues its loads of x / z / p_old / mask for both frames and the coarse correction c_f (see CoarseView) in the same phase,
+  // and the search direction is formed after the barrier.  B <= 256: one element per thread.
   if (V.Wb != nullptr) {  // (fused coarse variant: the correction is gathered here, one wave per frame)
     if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
     else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
   } else if (tid < 2 * kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
-  }
-  if (tid >= NT - 2 * FCW) {  // (the last waves: the first ones carry the coarse loads)
-    const int t = tid - (NT - 2 * FCW);
-    const int which = t / FCW, k = t % FCW;
-    reinterpret_cast<double*>(fcs + which)[k] = reinterpret_cast<const double*>(fc + (which ? fb : fa))[k];
   }
   constexpr int EPT = 256 / NT;  // elements of a frame block per thread (B <= 256)
   double vza[EPT], vzb[EPT], vpa[EPT], vpb[EPT], vma[EPT], vmb[EPT];
@@ -3052,29 +3072,12 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   }
   __syncthreads();
   // Rotation derivatives in CROSS-PRODUCT form (round 5).  R(w) = exp([w]x)  =>  dR/dw_i = [a_i]x R with a_i the i-th column of
-  // the left Jacobian of SO(3); a_i is read off the frame constants as the axial vector of dR_i R^T.  With e = sum_i p_w,i a_i
+  // the left Jacobian of SO(3) (FrameConst::Jl, read off dR_i R^T by k_frame_consts).  With e = sum_i p_w,i a_i
   //   forward   source: sum_i p_w,i dR_i c = e x (R c);   target: sum_i p_w,i dR_i^T v = R^T (v x e)
   //   adjoint   source: y . dR_i (D c)   = a_i . ((D R c) x y);   target: y_q . dR_i^T v = -a_i . (v x R y_q)
   // so a constraint contributes ONE cross product v x y_X to the rotation rows of both frames (3 accumulators and 6
   // instructions instead of the two 3 x 3 outer products: 18 accumulators, 21 instructions), the 18 E entries of a trip's LDS
   // broadcast reads become 6 scalars, and the workgroup reduction carries 11 values instead of 23.
-  if (tid < 6) {
-    const int which = tid / 3, k = tid % 3;
-    const int r = (k + 2) % 3, cc = (k + 1) % 3;   // axial component k of M = dR_i R^T: (M[r][cc] - M[cc][r]) / 2
-    const double* pp = which ? pb : pa;
-    const FrameConst& f = fcs[which];
-    double e = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double* D = f.dR[i];
-      const double m = 0.5 * ((D[r * 3] * f.R[cc * 3] + D[r * 3 + 1] * f.R[cc * 3 + 1] + D[r * 3 + 2] * f.R[cc * 3 + 2]) -
-                              (D[cc * 3] * f.R[r * 3] + D[cc * 3 + 1] * f.R[r * 3 + 1] + D[cc * 3 + 2] * f.R[r * 3 + 2]));
-      JL[which * 12 + i * 3 + k] = m;
-      e += pp[3 + i] * m;
-    }
-    JL[which * 12 + 9 + k] = e;
-  }
-  __syncthreads();
   if (threadIdx.x == 0) MV_STAMP(1);
 
   const int N = SPEC ? 1 : L.N;
@@ -3091,10 +3094,8 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   for (int dir = 0; dir < 2; ++dir) {
   const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
   // role swap for the reverse pair (source = fb, target = fa): swap every per-frame pointer
-  const FrameConst& Fa = fcs[dir];
-  const FrameConst& Fb = fcs[dir ^ 1];
-  const double* JLa = JL + 12 * dir;
-  const double* JLb = JL + 12 * (dir ^ 1);
+  const FrameConst& Fa = *fcF[dir];
+  const FrameConst& Fb = *fcF[dir ^ 1];
   if (dir) {
     double* t;
     t = xa; xa = xb; xb = t;
@@ -3106,28 +3107,36 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
 #pragma unroll
     for (int n = 0; n < 2; ++n) { const double o = gDa[n]; gDa[n] = gDb[n]; gDb[n] = o; }
   }
-  // The frame constants are the same for every lane: hand them to the loop as SCALAR values (v_readfirstlane of the
-  // LDS copy -> SGPRs; a VALU instruction takes one scalar operand).  Rotations and translations of both frames are
-  // 24 doubles = 48 VGPRs less per lane: 193 -> 14x VGPRs, three waves per SIMD instead of two.
+  const int firstUnit = dir == 0 ? (tid >> 6) : static_cast<int>(((tid >> 6) - units0) & (NT / 64 - 1));
+  const int nDir = static_cast<int>(ce - cb);
+  const int iFirst = firstUnit * 64 + (tid & 63);
+  if (dir || !kEarlyPrime) rs.prime(T, cb, iFirst, nDir);   // (direction 0: requested at the top of the kernel; here: before the scalar set-up)
+  // The frame constants are the same for every lane and reach the loop as SCALAR values (scalar loads; a VALU instruction
+  // takes one scalar operand).  Rotations and translations of both frames are 24 doubles = 48 VGPRs less per lane.
   double RaU[9], RbU[9], dTU[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { RaU[i] = uniformValue(Fa.R[i]); RbU[i] = uniformValue(Fb.R[i]); }
 #pragma unroll
   for (int i = 0; i < 3; ++i) dTU[i] = uniformValue(Fa.t[i] - Fb.t[i]);
-  // (round 5: the rotation parts of the search direction are 3 + 3 scalars -- e of both frames -- and its translation / focal
-  // parts another 5; as 18 + 14 values they overflowed the SGPR file and were LDS broadcast reads inside the loop)
+  // (round 5: the rotation parts of the search direction are 3 + 3 scalars -- e = J_l^T p_w of both frames -- and its
+  // translation / focal parts another 5; as 18 + 14 values they overflowed the SGPR file and were LDS broadcast reads inside
+  // the loop.  Every wave forms them itself from the LDS copy of p: 18 multiply-adds instead of a barrier)
   double eaU[3], ebU[3], dptU[3];
+  {
+    const double pwa[3] = {uniformValue(pa[3]), uniformValue(pa[4]), uniformValue(pa[5])};
+    const double pwb[3] = {uniformValue(pb[3]), uniformValue(pb[4]), uniformValue(pb[5])};
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    eaU[i] = uniformValue(JLa[9 + i]);
-    ebU[i] = uniformValue(JLb[9 + i]);
-    dptU[i] = uniformValue(pa[i] - pb[i]);
+    for (int k = 0; k < 3; ++k) {
+      eaU[k] = uniformValue(pwa[0] * Fa.Jl[k] + pwa[1] * Fa.Jl[3 + k] + pwa[2] * Fa.Jl[6 + k]);
+      ebU[k] = uniformValue(pwb[0] * Fb.Jl[k] + pwb[1] * Fb.Jl[3 + k] + pwb[2] * Fb.Jl[6 + k]);
+      dptU[k] = uniformValue(pa[k] - pb[k]);
+    }
   }
   const double fya = uniformValue(Fa.fy), fxa = fya * A;
   const double fyb = uniformValue(Fb.fy);
-  const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
-  const double pfaU = uniformValue(pa[6]) / fya;          // p_f,src / fy_src: the focal column of the source is D R (c + e_z) / fy
-  const double pfrU = L.ws * uniformValue(pb[6]) * ifyb;   // ws p_f,tgt / fy_tgt
+  const double ifyb = uniformValue(1.0 / fyb), ifxb = uniformValue(1.0 / (fyb * A));
+  const double pfaU = uniformValue(pa[6] / fya);          // p_f,src / fy_src: the focal column of the source is D R (c + e_z) / fy
+  const double pfrU = uniformValue(L.ws * pb[6] * ifyb);   // ws p_f,tgt / fy_tgt
 
   const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
   const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
@@ -3136,11 +3145,6 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // Wave-units of 64 constraints are dealt round-robin over the waves ACROSS the two directions: direction 1 starts with
   // the wave after the one that took direction 0's last unit.  With ~9 units per direction and 4 waves the slowest wave
   // walks 5 units instead of 3 + 3 (both directions' remainders used to land on waves 0, 1).
-  const int firstUnit = dir == 0 ? (tid >> 6) : static_cast<int>(((tid >> 6) - units0) & (NT / 64 - 1));
-  RecordStream<DENSE> rs;   // (list mode: the next trip's table record is in flight during this trip's arithmetic)
-  const int nDir = static_cast<int>(ce - cb);
-  const int iFirst = firstUnit * 64 + (tid & 63);
-  rs.prime(T, cb, iFirst, nDir);
   for (int ci = iFirst; ci < nDir; ci += NT) {
     float4 nd;
     float2 d;
@@ -3300,8 +3304,8 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // Lane pairs store their values transposed into LDS (row = accumulator, column = lane pair, 33-padded 32-column
   // segments), then 4 threads per accumulator sum one segment each: ~25 LDS ops per thread instead of 11 x 6
   // cross-lane butterfly steps.
-  const FrameConst& Fa = fcs[1];
-  const FrameConst& Fb = fcs[0];
+  const FrameConst& Fa = *fcF[1];
+  const FrameConst& Fb = *fcF[0];
   {
     double vals[NV];
 #pragma unroll
@@ -3350,7 +3354,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
     const double* y = red + (tgt ? 3 : 0);
     const double m[3] = {red[6] - (dT[1] * y[2] - dT[2] * y[1]), red[7] - (dT[2] * y[0] - dT[0] * y[2]),
                          red[8] - (dT[0] * y[1] - dT[1] * y[0])};
-    const double* a = JL + (tgt ? 0 : 12) + 3 * i;   // (frame fb = fcs[1] is the source of direction 1)
+    const double* a = (tgt ? Fb.Jl : Fa.Jl) + 3 * i;   // (frame fb is the source of direction 1)
     const double sdot = a[0] * m[0] + a[1] * m[1] + a[2] * m[2];
     if (tgt) qb[3 + i] -= sdot;
     else qa[3 + i] += sdot;

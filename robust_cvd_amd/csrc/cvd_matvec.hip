@@ -85,7 +85,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     HIP_CHECK(hipGetLastError());
   } else if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
-    const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (kMvPose + 32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;
+    const size_t ldsFast = 6 * B * 8 + 2 * sizeof(FrameConst) + (32 + static_cast<size_t>(kRedVals) * kRedStride) * 8;  // (the two FrameConst: CVD_MV_SLOAD = 0 only)
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
     const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L);
