@@ -332,6 +332,11 @@ int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block
  * symmetric); inverse = n x n f64; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
 int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, double* inverse, int32_t* failed);
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
+/* Diagnostics (no counterpart in the reference): which variant of the linear solver the LAST solve of the handle ran --
+ * out8 = { pose-graph level on, its form (0 exact sparse factor, 1 exact dense inverse, 2 temporal pose level), depth-grid
+ * temporal level on, PCG tail fused into one launch (k_pcg_tail), fused tail disabled after an abandoned barrier, depth taps per
+ * sample (1 / 4 / 16), work items of the pair-major kernels, explicit cross blocks (dense mode) }.  tools/defaults_sweep.py. */
+int32_t cvd_path_info(cvd_handle* h, int32_t* out8);
 /* Test hook for the third level of the preconditioner (cvd_solver_options::temporal_level; state of its last build in the last
  * solve): dims6 = {NT unknowns (0: the level was off), S hats per node, nn nodes, step, Sx, Sy}; a_t = the assembled Galerkin
  * matrix (NT x NT, unknown s * nn + a, diagonal shifted by coarse_dense_shift), a_t_inverse = the inverse in use, lam = the LM

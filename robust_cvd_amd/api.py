@@ -85,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug",
+    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug", "cvd_path_info",
     "cvd_block_inverse_debug", "cvd_dense_inverse_debug",
 ]
 
@@ -243,6 +243,14 @@ class Solver(Binding):
         self._check(self._fn("temporal_debug")(self._h, dims, dp(a), dp(ai), dp(lam), C.byref(fl)))
         return {"NT": n, "S": dims[1], "nn": dims[2], "step": dims[3], "Sx": dims[4], "Sy": dims[5], "a_t": a, "a_t_inverse": ai,
                 "lam": lam, "failed": fl.value}
+
+    def path_info(self):
+        """Which variant of the linear solver the last solve ran (cvd_path_info)."""
+        out = (C.c_int32 * 8)()
+        self._check(self._fn("path_info")(self._h, out))
+        form = {-1: "none", 0: "exact sparse factor", 1: "exact dense inverse", 2: "temporal pose level"}[out[1]]
+        return {"pose_graph_level": form, "depth_grid_level": bool(out[2]), "fused_tail": bool(out[3]), "tail_disabled": bool(out[4]),
+                "taps": out[5], "work_items": out[6], "cross_blocks": bool(out[7])}
 
     def coarse_debug(self):
         """(A_c, A_c^-1 as applied, pivot failures) of the coarse preconditioner level after the last solve."""

@@ -812,6 +812,18 @@ int32_t cvd_temporal_debug(cvd_handle* h, int32_t* dims6, double* a_t, double* a
     }
   });
 }
+int32_t cvd_path_info(cvd_handle* h, int32_t* out8) {
+  CVD_TRY(h, {
+    out8[0] = h->coarseOn ? 1 : 0;
+    out8[1] = !h->coarseOn ? -1 : (h->coarse.temporalPose ? 2 : (h->coarse.denseMode ? 1 : 0));
+    out8[2] = h->temporal.on ? 1 : 0;
+    out8[3] = h->lastFusedTail ? 1 : 0;
+    out8[4] = h->tailDisabled ? 1 : 0;
+    out8[5] = h->lastKD;
+    out8[6] = static_cast<int32_t>(h->itemFa.size());
+    out8[7] = h->lastCross ? 1 : 0;
+  });
+}
 int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed) {
   CVD_TRY(h, {
     auto& C = h->coarse;

@@ -372,6 +372,8 @@ struct cvd_handle_t {
   cvd_solve_summary summary{};
   std::vector<cvd_iteration_record> records;
 
+  bool lastFusedTail = false, lastCross = false;  // cvd_path_info: what the last PCG solve ran
+  int lastKD = 0;
   bool tailDisabled = false;  // k_pcg_tail abandoned its grid barrier once on this handle: two-launch tail from then on (runPcg)
   bool forceGeneric = false;  // test hook: route the products through the generic (all-variants) kernel
 

@@ -116,6 +116,9 @@ static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& t
   size_t ldsTail = 0;
   int ldsFinish = 0, ldsScratch = 0;
   const bool fusedTail = pcgTailScope(c, coarse, nThreads, ldsTail, ldsFinish, ldsScratch);
+  h->lastFusedTail = fusedTail;
+  h->lastKD = c.KD;
+  h->lastCross = c.cross;
   if (fusedTail) {  // (its grid barrier's words)
     h->dTailBar.ensure(static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies));
     HIP_CHECK(hipMemsetAsync(h->dTailBar.p, 0, static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies) * sizeof(unsigned int), s));

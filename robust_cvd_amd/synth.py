@@ -144,7 +144,8 @@ def _field(rng, H, W, gh=3, gw=4):
 
 def make_video(num_frames, width, height, seed=1234, pairs=None, spacing=12.5, flow_noise_px=0.25,
                field_amp=0.10, trans_sigma=0.02, rot_sigma_deg=0.5, focal_long=0.3461538376301239,
-               scale_range=(0.5, 2.0), dense=False, max_pairs=None, extra_offsets=False):
+               scale_range=(0.5, 2.0), dense=False, max_pairs=None, extra_offsets=False, outlier_fraction=0.0,
+               outlier_px=20.0):
     """Build a SyntheticVideo. `spacing` ~ 12.5 px reproduces the density of the reference's greedy disk
     sampling with matchSeparation = 10 (about 590 constraints per pair at 384x224). dense=True emits every
     in-bounds pixel (the reference's matchSeparation = 0 regime)."""
@@ -223,6 +224,10 @@ def make_video(num_frames, width, height, seed=1234, pairs=None, spacing=12.5, f
             v = q[..., 1] / z / fy
         x1 = (u + 1.0) * 0.5 * W + rng.normal(0.0, flow_noise_px, size=u.shape)
         y1 = (1.0 - v) * 0.5 * H + rng.normal(0.0, flow_noise_px, size=v.shape)
+        if outlier_fraction > 0.0:  # gross flow errors (what the robust loss is for); no draw at the default 0: seeds keep their videos
+            bad = rng.uniform(size=u.shape) < outlier_fraction
+            x1 = x1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
+            y1 = y1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
         # reference lib/FlowConstraints.cpp:446-449: rounded target pixel must be in bounds
         fx1 = x1.astype(np.float32)
         fy1 = y1.astype(np.float32)
@@ -277,6 +282,10 @@ def make_dense_flows(video: SyntheticVideo, flow_noise_px=0.25, seed=99, invalid
             v = q[..., 1] / z / fy
         x1 = (u + 1.0) * 0.5 * W + rng.normal(0.0, flow_noise_px, size=u.shape)
         y1 = (1.0 - v) * 0.5 * H + rng.normal(0.0, flow_noise_px, size=v.shape)
+        if outlier_fraction > 0.0:  # gross flow errors (what the robust loss is for); no draw at the default 0: seeds keep their videos
+            bad = rng.uniform(size=u.shape) < outlier_fraction
+            x1 = x1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
+            y1 = y1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
         ok = (z > 1e-3) & np.isfinite(x1) & np.isfinite(y1) & (x1 > -0.5) & (x1 < W - 0.5) & (y1 > -0.5) & (y1 < H - 0.5)
         ok &= rng.uniform(size=ok.shape) >= invalid_fraction
         flow[k, ..., 0] = np.where(ok, x1 - gx, 0.0)
