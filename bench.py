@@ -509,7 +509,9 @@ def main():
                          "exchange_counts": {k: v["count"] for k, v in m["comm"].items()},
                          "n1_equivalence": m["equivalence"],
                          "note": "per Jacobian evaluation: all-reduce g + cost, reduce-scatter H_ff to the frames' owners, all-gather "
-                                 "diag(H) and the f32 block inverses; per PCG product: all-reduce q (rank 0's timings)"}} if shard else {}),
+                                 "diag(H) and the f32 block inverses; per PCG iteration (owner-sharded update, the default): reduce-scatter q + "
+                                 "all-reduce [Z^T q | p.q] after the product, all-gather z / c / r^T z shares after the update -- two "
+                                 "grouped collectives (rank 0's timings)"}} if shard else {}),
             "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["ktimes"].items()},
             "kernels_launches": {k: v["launches"] for k, v in m["ktimes"].items()},
             "kernels_note": ("HIP events on a uniform sample of every class's launches (every --time-every-th); matvec_pairs: the "

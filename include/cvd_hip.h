@@ -38,7 +38,6 @@ typedef struct cvd_solver_options {
                                     1e-3 ends within 8.5e-5 (config0/1/2: 3.7e-5 / 6.1e-6 / 6.1e-6): profiles/r03_parity_probe.log,
                                     DESIGN.md 4.  Ceres' own inexact-step default is 0.1. */
   int32_t pcg_max_iterations;    /* default 300 */
-  int32_t pcg_check_every;       /* unused since the device mirrors its progress to the host (kept for layout) */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout; 2: + PCG scalars per iteration;
                                     3: + setup phases and the shape of the coarse elimination (development) */
   int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
@@ -92,9 +91,14 @@ typedef struct cvd_solver_options {
                                      rank (one collective per iteration; rounds 2-3) */
   int32_t temporal_level;         /* third level of the preconditioner (cvd_temporal.h): temporal hat functions (one node every
                                      temporal_step frames) x bilinear hats of a coarse grid on the depth grid, its Galerkin matrix
-                                     inverted densely, applied inside the PCG launches.  0: off; 1: rebuilt together with the dense
-                                     pose-graph level; 2: rebuilt every LM iteration.  Scope: one GPU, list mode, bilinear
-                                     one-parameter depth grid, dense pose-graph level in use; elsewhere the option is ignored */
+                                     inverted densely, applied inside the PCG launches.  0: off; 1: rebuilt whenever the pose-graph
+                                     level is (in line or on the side stream) -- without a pose-graph level (coarse_level 0) by the
+                                     same excess-iterations rule; 2: rebuilt every LM iteration.  Scope (temporalScope,
+                                     cvd_temporal.hip): list mode or dense mode with explicit cross blocks, one GPU or pair-sharded,
+                                     any form of the pose-graph level or none; fast-path problems only -- bilinear one-parameter
+                                     depth grid of at least 3 x 3 vertices, identity spatial transform, reprojection losses, Fixed /
+                                     PerFrame intrinsics, no triplets, no position regulariser, more than 2 temporal_step frames;
+                                     elsewhere the option is ignored */
   int32_t temporal_step;          /* frames between two temporal nodes (default 32) */
   int32_t temporal_grid_x;        /* coarse hats per axis; 0 (default): (grid + 1) / 2 */
   int32_t temporal_grid_y;
@@ -307,8 +311,10 @@ int32_t cvd_flow_guided_filter(cvd_handle* h, int32_t num_frames, int32_t first_
 int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6);
 /* Exchange steps of the pair-sharded mode (RCCL on the solver stream), timed with HIP events whenever kernel timing is on:
  * fills {evaluation exchange: all-reduce g / cost, reduce-scatter H_ff, all-gather diag(H) and the f32 block inverses;
- * product exchange: all-reduce q per PCG product; coarse exchange: edge blocks, diagonal blocks} -- average ms per
- * occurrence and counts. */
+ * product exchange: per PCG iteration, owner-sharded update (default): reduce-scatter q to the frames' owners + all-reduce
+ * [Z^T q | p.q] after the product, all-gather z / c / the r^T z shares after the update (two grouped collectives per iteration);
+ * replicated update (dist_owner_update = 0): ONE all-reduce of [q | Z^T q | p.q]; coarse exchange: edge blocks, diagonal blocks}
+ * -- average ms per occurrence and counts. */
 int32_t cvd_get_comm_times(cvd_handle* h, double* avg_ms3, int64_t* counts3);
 /* Per-launch HIP-event timing: 0 = off (default), 1 = every class, otherwise a bit mask (bit k = class k in the
  * order of cvd_get_kernel_times). Two event records per timed launch. Bits 8..15 = sampling stride - 1 for the hot

@@ -21,7 +21,6 @@ class SolverOptions(C.Structure):
         ("struct_size", C.c_uint64),
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
-        ("pcg_check_every", C.c_int32),
         ("verbose", C.c_int32),
         ("force_iterations", C.c_int32),
         ("coarse_level", C.c_int32),
@@ -101,7 +100,7 @@ class Solver(Binding):
         super().__init__(lib, "cvd_", handle)
         self._options = None
 
-    def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, pcg_check_every=None, verbose=None,
+    def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, verbose=None,
                     force_iterations=None, coarse_level=None, robust_loss=None, **variants):
         """Options persist per handle: only the fields given change (robust_loss: 0 Cauchy = reference, 1 Huber)."""
         o = self._options
@@ -113,8 +112,6 @@ class Solver(Binding):
             o.pcg_relative_tolerance = pcg_relative_tolerance
         if pcg_max_iterations is not None:
             o.pcg_max_iterations = pcg_max_iterations
-        if pcg_check_every is not None:
-            o.pcg_check_every = pcg_check_every
         if verbose is not None:
             o.verbose = int(verbose)
         if force_iterations is not None:

@@ -223,7 +223,6 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->struct_size = sizeof(cvd_solver_options);
   o->pcg_relative_tolerance = 1e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
   o->pcg_max_iterations = 300;
-  o->pcg_check_every = 4;
   o->verbose = 0;
   o->force_iterations = 0;
   o->coarse_level = 1;

@@ -2568,6 +2568,10 @@ __device__ __forceinline__ bool tailWait(unsigned int* bar, unsigned int nGroups
       if ((spins & 63u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
       if (spins > (1u << 18)) {  // ~1 s
         __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        //  ... and poison the arrival count: no later arriver of this solve can draw the LAST ticket any more, so an
+        // abandoned barrier is never released behind the workgroups that left it (x / r stay consistent; the host's progress
+        // check reports the stall and falls back to the two-launch tail)
+        __hip_atomic_fetch_add(bar, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
       }

@@ -127,10 +127,8 @@ static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& t
   }
   const bool ownerMode = ownerShardedUpdate(h, coarse);
   const int maxIt = std::max(1, c.h->opt.pcg_max_iterations);
-  const int every = std::max(1, c.h->opt.pcg_check_every);
-  // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); the host enqueues
-  // batches of `every` iterations and reads the control scalars of batch b only before enqueuing batch b + 2, so
-  // the stream never drains while the host waits.  Iterations enqueued past convergence return immediately.
+  // Convergence is decided on the device (S_DONE, set by the last workgroup of k_cg_update); how far the host runs ahead of it
+  // is described at the loop below.
   // (profiling aid: cvd_solver_options::pcg_lockstep checks after every iteration and never runs ahead, so that per-launch
   // counter averages contain no early-exit launches)
   const bool lockstep = h->opt.pcg_lockstep != 0;
@@ -450,6 +448,14 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
             HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));
             coarsePending = true;
             cgExcess = 0;
+            //  the third level is "rebuilt together with the pose-graph level": also when that rebuild runs on the
+            // side stream -- in line, at this linearisation point (it is small: two launches and a 0.1 ms inverse)
+            if (h->temporal.on) {
+              const int slot = h->tBegin(KC_INVERSE);
+              launchTemporalSetup(c, h->dX.p, 0);
+              launchTemporalSetup(c, h->dX.p, 1);
+              h->tEnd(slot);
+            }
           } else {
             const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
             const bool measure = h->coarse.denseMode && !h->dist() && h->opt.coarse_rebuild_excess_dense < 0;
