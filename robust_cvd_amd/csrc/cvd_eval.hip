@@ -130,7 +130,9 @@ void launchCrossAssemble(Ctx& c, const double* x) {
   HIP_CHECK(hipGetLastError());
 }
 
-double evalFull(Ctx& c, const double* x, bool withStats) {
+// noReadBack: everything is enqueued and the host does not wait (the LM loop reads |g|_max / |x| of the new point with the next
+// PCG solve's scalars, which recompute them: cvd_solve.hip); returns 0.
+double evalFull(Ctx& c, const double* x, bool withStats, bool noReadBack) {
   cvd_handle* h = c.h;
   hipStream_t s = h->stream;
   launchFrameConsts(c, x);
@@ -218,6 +220,7 @@ double evalFull(Ctx& c, const double* x, bool withStats) {
   }
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, s, h->dCostFrame.p, c.L.F, h->dCostFrame.p, 0, h->dScal.p, S_COST);
   HIP_CHECK(hipGetLastError());
+  if (noReadBack) return 0.0;
   if (withStats) {  // |g|_max and |x| of the new point in the same read-back (lam = 0: only those two are used)
     HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
     enqueueStats(c);

@@ -607,7 +607,7 @@ void enqueueStats(Ctx& c);
 bool crossScope(cvd_handle* h, const Ctx& c);
 CrossPairs crossPairs(cvd_handle* h);
 void launchCrossAssemble(Ctx& c, const double* x);
-double evalFull(Ctx& c, const double* x, bool withStats = false);
+double evalFull(Ctx& c, const double* x, bool withStats = false, bool noReadBack = false);
 bool coarseFusedConsumers();
 bool fusedExchange(cvd_handle* h, bool withCoarse);
 size_t exchangeOffsetQc(const Ctx& c);

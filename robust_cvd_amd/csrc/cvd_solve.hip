@@ -357,6 +357,12 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
 
   double radius = Ceres::initial_radius;
   double decrease = 2.0;
+  // After an accepted step the host does not wait for the new point's |g|_max / |x| (one idle round trip of ~60 us per LM
+  // iteration, round 5): the step statistics of the NEXT PCG solve recompute both for the same point (k_step_stats) and arrive
+  // with its read-back.  gradPending: the gradient-tolerance test of the last accepted step and its record's gradient norm are
+  // still open.  (verbose runs keep the immediate read: the table prints the norm with its iteration)
+  bool gradPending = false;
+  const bool deferStats = h->opt.verbose == 0;
   int invalid = 0, iteration = 0, termination = 1;
   // Rebuild threshold of the coarse level in PCG iterations.  Sparse factor (side stream): the option.  DENSE level, built in
   // line: coarse_rebuild_excess_dense > 0 fixes it; 0 (default) = 32, a constant: identical inputs must take identical
@@ -534,6 +540,19 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
       ++factorUses;
       installPendingCoarse();
       tLin += nowSeconds() - tl;
+      if (gradPending) {
+        gradPending = false;
+        gmax = h->hScal[S_GMAX];
+        xNorm = std::sqrt(h->hScal[S_XX]);
+        h->records.back().gradient_max_norm = gmax;
+        if (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) {
+          // the previous iteration ended the solve (Ceres tests the gradient right after a successful step): this iteration's
+          // linear solve was speculative and is dropped -- x, the cost and the records are those of the previous iteration
+          --iteration;
+          termination = 0;
+          break;
+        }
+      }
       rec.linear_iterations = cgIters;
       sum.total_linear_iterations += cgIters;
       const double dg = h->hScal[S_DG], dr = h->hScal[S_DR], dld = h->hScal[S_DLD], dd = h->hScal[S_DD];
@@ -575,11 +594,16 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
         lastRelChange = std::abs(xCost - candCost) / std::max(std::abs(xCost), 1e-300);
         xCost = candCost;
         te = nowSeconds();
-        const double chk = evalFull(c, h->dX.p, true);
-        (void)chk;
+        // (the last iteration allowed reads at once: nothing follows that would bring the statistics)
+        const bool defer = deferStats && iteration < p.max_iterations;
+        (void)evalFull(c, h->dX.p, true, defer);
         tEval += nowSeconds() - te;
-        gmax = h->hScal[S_GMAX];
-        xNorm = std::sqrt(h->hScal[S_XX]);
+        if (defer) {
+          gradPending = true;   // (gmax / xNorm keep the previous point's values until the next solve's read-back)
+        } else {
+          gmax = h->hScal[S_GMAX];
+          xNorm = std::sqrt(h->hScal[S_XX]);
+        }
         ++sum.num_successful_steps;
         rec.step_is_successful = 1;
         const double q = rec.relative_decrease;
@@ -593,7 +617,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
         if (h->opt.verbose)
           printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
                  stepNorm, rec.relative_decrease, radius, cgIters);
-        if (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) { termination = 0; break; }
+        if (!gradPending && gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) { termination = 0; break; }
       } else {
         radius /= decrease;
         decrease *= 2.0;
@@ -605,6 +629,13 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
                  stepNorm, rec.relative_decrease, radius, cgIters);
       }
     }
+  }
+  if (gradPending) {  // (the loop left before another solve brought the last accepted point's statistics)
+    HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
+    enqueueStats(c);
+    readScalars(c);
+    h->records.back().gradient_max_norm = h->hScal[S_GMAX];
+    gradPending = false;
   }
   phase("LM loop");
   if (h->coarseOn && h->coarse.denseMode && h->coarse.fail.p != nullptr && !h->dist()) {

@@ -282,10 +282,6 @@ def make_dense_flows(video: SyntheticVideo, flow_noise_px=0.25, seed=99, invalid
             v = q[..., 1] / z / fy
         x1 = (u + 1.0) * 0.5 * W + rng.normal(0.0, flow_noise_px, size=u.shape)
         y1 = (1.0 - v) * 0.5 * H + rng.normal(0.0, flow_noise_px, size=v.shape)
-        if outlier_fraction > 0.0:  # gross flow errors (what the robust loss is for); no draw at the default 0: seeds keep their videos
-            bad = rng.uniform(size=u.shape) < outlier_fraction
-            x1 = x1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
-            y1 = y1 + bad * rng.uniform(-outlier_px, outlier_px, size=u.shape)
         ok = (z > 1e-3) & np.isfinite(x1) & np.isfinite(y1) & (x1 > -0.5) & (x1 < W - 0.5) & (y1 > -0.5) & (y1 < H - 0.5)
         ok &= rng.uniform(size=ok.shape) >= invalid_fraction
         flow[k, ..., 0] = np.where(ok, x1 - gx, 0.0)

@@ -13,29 +13,30 @@ import json
 import os
 
 
-def _log(name, value, limit):
+def _log(name, value, limit, kind="tolerance"):
     path = os.environ.get("CVD_MARGIN_LOG")
     if not path:
         return
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
     with open(path, "a") as f:
-        f.write(json.dumps({"test": test, "name": name, "value": float(value), "limit": float(limit)}) + "\n")
+        f.write(json.dumps({"test": test, "name": name, "value": float(value), "limit": float(limit), "kind": kind}) + "\n")
 
 
-def below(name, value, limit, info=None):
-    """value < limit (a tolerance): logged with its margin."""
-    _log(name, value, limit)
+def below(name, value, limit, info=None, kind="tolerance"):
+    """value < limit: logged with its margin.  kind "tolerance": the 1/3 policy applies; "ratio": a ratio of two iteration counts
+    (>= 10 % between the measured value and the limit)."""
+    _log(name, value, limit, kind)
     assert value < limit, (name, value, limit, info)
 
 
 def close_count(name, a, b, rel=0.1, slack=2):
     """Two iteration counts agree to rel (>= 10 %) + slack."""
     lim = rel * max(a, b) + slack
-    _log(name, abs(a - b), lim)
+    _log(name, abs(a - b), lim, "count")
     assert abs(a - b) <= lim, (name, a, b)
 
 
 def same_count(name, a, b, slack=1):
     """LM-iteration counts of two solver paths: equal up to one iteration (a stopping test decided in the last digits)."""
-    _log(name, abs(a - b), slack + 1)
+    _log(name, abs(a - b), slack + 1, "count")
     assert abs(a - b) <= slack, (name, a, b)

@@ -902,5 +902,5 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
     perr, rerr = synth.relative_pose_error(a[1]["position"], a[1]["orientation"], b[1]["position"], b[1]["orientation"])
     # (two eta = 1e-3 solves whose products round differently end ~1e-6 apart)
     margins.below("position fused vs two-launch", perr, 3e-5)
-    margins.below("rotation fused vs two-launch", rerr, 1e-4)
+    margins.below("rotation fused vs two-launch", rerr, 2e-4)   # (metric floor ~5e-5: arccos of float-quaternion matrices)
     margins.below("depth parameters fused vs two-launch", rel(a[2], b[2]), 3e-5)

@@ -26,7 +26,8 @@ from tests import reference_reprojection as rr
 # corner-aligned sampling of paramMap (reference lib/DepthMapTransform.cpp:428-449) and the pixel-edge NDC of the constraints.
 # Measured at mint time (fixture: `reprojection_error_px`): max 0.053 px, mean 0.0036 px.  The same check with paramMap's rows in
 # the wrong order: max 0.56 px, mean 0.025 px (`flipped_rows_error_px_max`); a sign / axis / FOV error costs pixels.
-REPROJ_TOL_PX, REPROJ_MEAN_TOL_PX = 0.1, 0.01
+# (3 x the measured values; the flipped-rows state still fails both by a factor of 3.3 / 2.2)
+REPROJ_TOL_PX, REPROJ_MEAN_TOL_PX = 0.17, 0.011
 
 
 def _golden():

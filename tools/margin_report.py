@@ -9,13 +9,16 @@ rows = collections.defaultdict(list)
 for path in sys.argv[1:]:
     for line in open(path):
         r = json.loads(line)
-        rows[(r["test"], r["name"])].append((r["value"], r["limit"]))
+        rows[(r["test"], r["name"], r.get("kind", "tolerance"))].append((r["value"], r["limit"]))
 bad = 0
-print(f"# {len(sys.argv) - 1} run(s), {len(rows)} logged assertions; policy: worst value / limit <= 0.333")
-for (test, name), vals in sorted(rows.items(), key=lambda kv: -max(v / l if l else 0.0 for v, l in kv[1])):
+print(f"# {len(sys.argv) - 1} run(s), {len(rows)} logged assertions; policy: tolerances -- worst value / limit <= 0.333; iteration-count "
+      f"comparisons (count: |a - b| against 10 - 20 % + slack; ratio: measured ratio at least 10 % inside its limit) -- must hold")
+LIMIT = {"tolerance": 1.0 / 3.0, "count": 1.0, "ratio": 0.9}
+for (test, name, kind), vals in sorted(rows.items(), key=lambda kv: -max(v / l if l else 0.0 for v, l in kv[1])):
     worst = max(v / l if l else 0.0 for v, l in vals)
     vs = [v for v, _ in vals]
-    flag = "  <-- over 1/3" if worst > 1.0 / 3.0 else ""
-    bad += worst > 1.0 / 3.0
-    print(f"{worst:7.3f}  n={len(vals):2d}  min {min(vs):.3e}  max {max(vs):.3e}  limit {vals[0][1]:.3e}  {test} :: {name}{flag}")
+    over = worst > LIMIT[kind] + 1e-12
+    flag = f"  <-- over {LIMIT[kind]:.2f}" if over else ""
+    bad += over
+    print(f"{worst:7.3f}  {kind:9s} n={len(vals):2d}  min {min(vs):.3e}  max {max(vs):.3e}  limit {vals[0][1]:.3e}  {test} :: {name}{flag}")
 sys.exit(1 if bad else 0)
