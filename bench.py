@@ -502,7 +502,11 @@ def main():
                          "frac_hbm": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
                 "assemble": {"avg_ms": m["ktimes"]["evaluate_assemble"]["avg_ms"],
                              "GB/s": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6,
-                             "frac_hbm": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
+                             "frac_hbm": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS,
+                             # the roof that binds it: ~1600 f64 flop per pixel constraint (Jacobian chain of both sides 600 +
+                             # the rank-structured outer products of the diagonal and cross blocks 1000; DESIGN_LOG.md, round 3)
+                             "TFLOP/s": 1600.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9,
+                             "frac_valu": 1600.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9 / F64_PEAK_TFLOPS},
             }} if args.dense else {}),
             **({"rccl": {"ranks": world, "frames_owned_per_rank": -(-frames // world),
                          "exchange_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["comm"].items()},
