@@ -155,17 +155,19 @@ inline __global__ __launch_bounds__(256) void k_coarse_edges(Layout L, Table T, 
       }
     }
   }
-  if (tid < kCBB) Cs[tid] = 0.0;
   __syncthreads();
+  // (one slot per wave, folded in wave order: the block does not depend on which wave finishes first)
 #pragma unroll
   for (int i = 0; i < kCBB; ++i) {
     const double v = waveSum(Cacc[i]);
-    if ((tid & 63) == 0) atomicAdd(&Cs[i], v);
+    if ((tid & 63) == 0) Cs[(tid >> 6) * kCBB + i] = v;
   }
   __syncthreads();
   // several chunk items may share one frame pair: the outputs are zeroed by the host before the launch
+  // (two items at most for a kept pair -- a two-term sum is order-free; the self blocks of DROPPED pairs collect many items in
+  // arrival order: the sparsified level is outside the deterministic build's scope)
   double* out = mode == 0 ? edgeOut + static_cast<size_t>(edge) * kCBB : dropDiag + static_cast<size_t>(mode == 1 ? fa : fb) * kCBB;
-  if (tid < kCBB) atomicAdd(&out[tid], Cs[tid]);
+  if (tid < kCBB) atomicAdd(&out[tid], (Cs[tid] + Cs[kCBB + tid]) + (Cs[2 * kCBB + tid] + Cs[3 * kCBB + tid]));
   __syncthreads();
   }  // mode
 }
@@ -352,17 +354,19 @@ inline __global__ __launch_bounds__(256) void k_coarse_edges_fast(Layout L, Tabl
       }
     }
   }
-  if (tid < kCBB) Cs[tid] = 0.0;
   __syncthreads();
+  // (one slot per wave, folded in wave order: the block does not depend on which wave finishes first)
 #pragma unroll
   for (int i = 0; i < kCBB; ++i) {
     const double v = waveSum(Cacc[i]);
-    if ((tid & 63) == 0) atomicAdd(&Cs[i], v);
+    if ((tid & 63) == 0) Cs[(tid >> 6) * kCBB + i] = v;
   }
   __syncthreads();
   // several chunk items may share one frame pair: the outputs are zeroed by the host before the launch
+  // (two items at most for a kept pair -- a two-term sum is order-free; the self blocks of DROPPED pairs collect many items in
+  // arrival order: the sparsified level is outside the deterministic build's scope)
   double* out = mode == 0 ? edgeOut + static_cast<size_t>(edge) * kCBB : dropDiag + static_cast<size_t>(mode == 1 ? fa : fb) * kCBB;
-  if (tid < kCBB) atomicAdd(&out[tid], Cs[tid]);
+  if (tid < kCBB) atomicAdd(&out[tid], (Cs[tid] + Cs[kCBB + tid]) + (Cs[2 * kCBB + tid] + Cs[3 * kCBB + tid]));
   __syncthreads();
   }  // mode
 }

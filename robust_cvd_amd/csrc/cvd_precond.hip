@@ -175,7 +175,7 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     hipLaunchKernelGGL(k_frame_consts, dim3((c.L.F + 63) / 64), dim3(64), 0, s, c.L, x, fcBuf);
     HIP_CHECK(hipMemsetAsync(C.edges.p, 0, static_cast<size_t>(std::max(C.nEdges, 1)) * kCBB * sizeof(double), s));
     if (C.sparsified) HIP_CHECK(hipMemsetAsync(C.dropDiag.p, 0, static_cast<size_t>(c.L.F) * kCBB * sizeof(double), s));
-    const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + kCBB * 8;
+    const size_t ldsE = 2 * B * 8 + 2 * sizeof(FrameConst) + 4 * kCBB * 8;  // (x of both frames, their constants, one 8 x 8 slot per wave)
     if (c.cross && !C.sparsified) {
       // explicit cross blocks exist for this linearisation point: the edge blocks are reductions of them
       hipLaunchKernelGGL(k_coarse_edges_cross, dim3(static_cast<unsigned>(h->xFa.size())), dim3(256), 0, s, c.L, crossPairs(h),

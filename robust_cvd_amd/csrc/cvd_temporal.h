@@ -158,7 +158,8 @@ inline __global__ __launch_bounds__(256) void k_tl_edges(Layout L, Table T, Item
     const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
     const int fsrc = dir ? fb : fa, ftgt = dir ? fa : fb;
     const long long pixBase = DENSE ? (cb / (static_cast<long long>(T.W) * T.H)) * (static_cast<long long>(T.W) * T.H) : 0;
-    for (long long c = cb + tid; c < ce; c += 256) {
+    // (deterministic build: the first wave alone walks the constraints -- its LDS atomics land in program order)
+    for (long long c = cb + tid; c < ce && tid < kAtomicWalkers256; c += kAtomicWalkers256) {
       float4 nd;
       float2 d;
       if (!loadConstraint<DENSE>(T, c, pixBase, fsrc, ftgt, nd, d)) continue;
