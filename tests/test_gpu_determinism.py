@@ -17,11 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_deterministic_build_repeats_a_solve_bit_for_bit():
+@pytest.mark.parametrize("what", ["final_level_solve", "whole_pipeline"])
+def test_deterministic_build_repeats_a_solve_bit_for_bit(what):
     from robust_cvd_amd import build as b
     b.build_deterministic()
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_check.py"), "--variant", "det", "--frames", "100", "--reps", "4",
-                          "--iterations", "6"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    extra = ["--pipeline"] if what == "whole_pipeline" else ["--iterations", "6"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_check.py"), "--variant", "det", "--frames", "100", "--reps", "4"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     reps = [l.split(" ", 2)[2] for l in out.stdout.splitlines() if l.startswith("rep ")]
     assert len(reps) == 4, out.stdout

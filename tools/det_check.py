@@ -18,6 +18,7 @@ ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--level", type=int, default=6)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--iterations", type=int, default=8)
+ap.add_argument("--pipeline", action="store_true", help="repeat the WHOLE default pipeline (normalizeDepth + coarse-to-fine) on fresh handles instead")
 args = ap.parse_args()
 if args.variant:
     api.load_library(variant=args.variant)
@@ -25,6 +26,22 @@ import bench  # noqa: E402
 from robust_cvd_amd.ctypes_types import OptParams  # noqa: E402
 
 v = synth.make_video(args.frames, 384, 224, seed=bench.SEED, extra_offsets=args.level)
+if args.pipeline:
+    from robust_cvd_amd.ctypes_types import XformDesc
+    for r in range(args.reps):
+        s = api.Solver(0)
+        p = OptParams.defaults()
+        synth.load_into(s, v, p.focal_long)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        sm = s.summary()
+        print("rep", r, "LM", sm["num_iterations"], "pcg", sm["total_linear_iterations"], "cost", float(sm["final_cost"]).hex(),
+              "pose-digest", hex(hash(s.get_pose_params().tobytes()) & 0xFFFFFFFFFFFF),
+              "theta-digest", hex(hash(s.get_xform_params().tobytes()) & 0xFFFFFFFFFFFF), flush=True)
+        s.close()
+    sys.exit(0)
 s = api.Solver(0)
 p = OptParams.defaults()
 bench.prepare(s, v, p)
