@@ -18,7 +18,13 @@
 //   ceres/loss_function.cc  CauchyLoss, ScaledLoss;  ceres/corrector.cc  Corrector
 //   ceres/trust_region_minimizer.cc + levenberg_marquardt_strategy.cc  (default Solver::Options)
 // The oracle is pinned instead by independent cross-checks in tests/ (central finite differences,
-// closed forms, zero-noise ground-truth recovery, scipy least_squares on the same residuals).
+// closed forms, zero-noise ground-truth recovery, scipy least_squares on the same residuals) and, where the
+// reference holds a second statement of the same arithmetic in Python, by running THAT: the ReproDisparity
+// residuals of every constraint and their Jacobian columns for pose and focal length against
+// utils/geometry.py:62-166 + loss/consistency_loss.py:27-199 at random non-converged states
+// (tests/test_reference_residuals.py, cvdo_static_residuals), the output conventions against
+// VideoDataset.update_poses (tests/test_reference_reprojection.py), the pair sampler against
+// utils/frame_sampling.py (tests/test_synth.py).  What stays unpinned is the Ceres SOLVE.
 //
 // Build: oracle/Makefile -> oracle/_build/libcvd_oracle.so  (g++ -O2 -ffp-contract=off -fopenmp)
 
