@@ -141,7 +141,7 @@ int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
  * Jacobian evaluation the library all-reduces g and the per-frame costs, reduce-scatters H_ff to the frames' owners and
  * all-gathers diag(H) and the owners' f32 block inverses; per PCG iteration it reduce-scatters q to the owners (with
  * [Z^T q | p.q] all-reduced in the same group), updates the owners' frames and all-gathers z / c / the r^T z shares -- two
- * grouped collectives over RCCL on the solver's stream (DESIGN.md 5).  The reference has no counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
+ * grouped collectives over RCCL on the solver's stream (DESIGN.md 6).  The reference has no counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
 void cvd_comm_unique_id(uint8_t* out128);
 int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
 /* Test backend of the exchange layer: the `world` ranks are handles of THIS process on ONE device, each driven by its
