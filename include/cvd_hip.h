@@ -81,7 +81,10 @@ typedef struct cvd_solver_options {
   int32_t pcg_fused_tail;         /* 1 (default): the two per-frame kernels of a PCG iteration (finish of the product, update) run
                                      as ONE launch with a grid barrier between their halves (k_pcg_tail) where its scope allows --
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
-                                     the two launches */
+                                     the two launches.  A handle whose fused tail ever abandons its barrier (device shared with
+                                     other work) falls back to the two launches for good and repeats the solve (a warning on
+                                     stderr); 2 = test hook: as 1, and the host treats the first solve's third iteration as such
+                                     a stall */
   int32_t coarse_dense_row_split; /* dense coarse level, per PCG iteration: of a frame's 8 rows of A_c^-1 the first this-many are applied by
                                      the dense-level workgroups (two frames each), the others by the frame's own workgroup after its
                                      update (default 5; 8 = rounds 2-3: dense-level workgroups only; 0 = frame workgroups only) */
@@ -119,6 +122,13 @@ typedef struct cvd_solver_options {
                                      additive combination of overlapping exact corrections overshoots (default 0.7: 5 - 8 % fewer
                                      PCG iterations than 1.0 on the benchmarked problem) */
 } cvd_solver_options;
+
+/* Revision of this header's binary interface: bumped whenever a struct layout or an entry point's meaning changes (round 4: 4 --
+ * cvd_solver_options gained struct_size as its FIRST field; round 5: 5 -- pcg_check_every removed, cvd_path_info added).
+ * cvd_abi_revision() returns the revision the LIBRARY was built with; bindings compare it with the header they were written
+ * against before any struct crosses the boundary (robust_cvd_amd/api.py does at load). */
+#define CVD_ABI_REVISION 5
+int32_t cvd_abi_revision(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 /* One optimizer per DepthVideo + depth stream (reference: DepthVideoPoseOptimizer ctor,

@@ -50,6 +50,9 @@ class SolverOptions(C.Structure):
     ]
 
 
+ABI_REVISION = 5  # include/cvd_hip.h: CVD_ABI_REVISION
+
+
 def load_library(variant=None):
     """dlopen the in-tree libcvd_hip.so. Raises ImportError (never falls back) when it is not built.  Nothing is read from the
     environment.  `variant` (development tools only, before anything else loaded the library): a profile build
@@ -72,6 +75,10 @@ def load_library(variant=None):
         lib.cvd_last_error.restype = C.c_char_p
         lib.cvd_last_error.argtypes = [C.c_void_p]
         lib.cvd_num_active_constraints.restype = C.c_int64
+        lib.cvd_abi_revision.restype = C.c_int32
+        if lib.cvd_abi_revision() != ABI_REVISION:
+            raise ImportError(f"{path} was built with ABI revision {lib.cvd_abi_revision()}, this binding is written against "
+                              f"{ABI_REVISION} (include/cvd_hip.h: CVD_ABI_REVISION): rebuild the library")
         _lib = lib
     return _lib
 
@@ -84,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug", "cvd_path_info",
+    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug", "cvd_path_info", "cvd_abi_revision",
     "cvd_block_inverse_debug", "cvd_dense_inverse_debug",
 ]
 

@@ -184,6 +184,7 @@ void cvd_destroy(cvd_handle* h) {
 }
 const char* cvd_last_error(cvd_handle* h) { return h ? h->err.c_str() : g_createError.c_str(); }
 
+int32_t cvd_abi_revision(void) { return CVD_ABI_REVISION; }
 void cvd_abi_sizes(int32_t* out6) {
   out6[0] = sizeof(cvd_xform_desc);
   out6[1] = sizeof(cvd_opt_params);

@@ -213,6 +213,9 @@ static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& t
     }
     enqueueIteration(enq, enq > 0 ? 1 : 0);
     ++enq;
+    // (test hook, pcg_fused_tail = 2: the host behaves as if the fused tail's barrier had been abandoned in the middle of the
+    // first solve it is used in -- exercises the recovery path above without needing a second tenant on the device)
+    if (fusedTail && h->opt.pcg_fused_tail == 2 && enq == 3) throw TailStalled{};
     if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
       readScalars(c);
       std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq - 1, h->hScal[S_RZ],

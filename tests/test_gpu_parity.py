@@ -904,3 +904,66 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
     margins.below("position fused vs two-launch", perr, 3e-5)
     margins.below("rotation fused vs two-launch", rerr, 2e-4)   # (metric floor ~5e-5: arccos of float-quaternion matrices)
     margins.below("depth parameters fused vs two-launch", rel(a[2], b[2]), 3e-5)
+
+
+def test_a_stalled_fused_tail_falls_back_to_the_two_launches(Solver, capfd):
+    """an abandoned grid barrier of k_pcg_tail is not an error.  pcg_fused_tail = 2 makes the host treat the third
+    iteration of the first fused solve as such a stall: the handle must switch to the two-launch tail for good, repeat the solve from
+    its start (state vectors and tickets re-initialised) and end where a handle that never used the fused kernel ends."""
+    v = synth.make_video(24, 128, 72, seed=14, extra_offsets=6)
+
+    def run(mode):
+        s = Solver(0)
+        synth.load_into(s, v)
+        s.set_options(pcg_fused_tail=mode, coarse_update_budget=0, coarse_over_budget=1)   # (the dense exact level: inside the fused scope)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        p.ctf_long, p.ctf_short = 6, 4
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out = (s.summary(), s.get_poses(), s.get_xform_params().copy(), s.path_info())
+        s.close()
+        return out
+
+    a, b = run(2), run(0)
+    err = capfd.readouterr().err
+    assert "two-launch PCG tail from here on" in err
+    assert a[3]["tail_disabled"] and not a[3]["fused_tail"] and not b[3]["tail_disabled"]
+    assert a[0]["termination"] == 0 and b[0]["termination"] == 0
+    margins.same_count("LM iterations stalled-and-recovered vs two-launch", a[0]["num_iterations"], b[0]["num_iterations"])
+    margins.below("final cost stalled-and-recovered vs two-launch", abs(a[0]["final_cost"] - b[0]["final_cost"]) / abs(b[0]["final_cost"]), 1e-8)
+    perr, rerr = synth.relative_pose_error(a[1]["position"], a[1]["orientation"], b[1]["position"], b[1]["orientation"])
+    margins.below("position stalled-and-recovered vs two-launch", perr, 3e-5)
+    margins.below("rotation stalled-and-recovered vs two-launch", rerr, 2e-4)
+
+
+@pytest.mark.parametrize("frames,fused", [(330, True), (440, False)])
+def test_default_options_on_both_sides_of_the_fused_tails_scope(Solver, frames, fused):
+    """The fused PCG tail needs every workgroup resident: at the 17 x 10 grid (B = 177) that holds up to ~400 frames, beyond it the
+    two launches run (VERDICT r4 Next #8: a parity test on both sides of that boundary).  Small images keep it short; the frame
+    count, not the resolution, decides the path.  End state against the same pipeline with near-exact LM steps."""
+    v = synth.make_video(frames, 96, 56, seed=5, extra_offsets=6)
+
+    def run(**opts):
+        s = Solver(0)
+        if opts:
+            s.set_options(**opts)
+        synth.load_into(s, v)
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        p = OptParams.defaults()
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out = (s.summary(), s.get_poses(), s.path_info())
+        s.close()
+        return out
+
+    a = run()
+    b = run(pcg_relative_tolerance=1e-6, coarse_level=2, temporal_level=2)
+    assert a[2]["fused_tail"] == fused, a[2]
+    assert a[0]["termination"] == 0 and b[0]["termination"] == 0
+    perr, rerr = synth.relative_pose_error(a[1]["position"], a[1]["orientation"], b[1]["position"], b[1]["orientation"])
+    margins.below("position vs near-exact steps", perr, 1e-3)
+    margins.below("rotation vs near-exact steps", rerr, 1e-3)
+    margins.below("final cost vs near-exact steps", abs(a[0]["final_cost"] - b[0]["final_cost"]) / b[0]["final_cost"], 1e-6)
