@@ -8,8 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--lib-variant", default=None,
+                     help="development: run the suite against lib/libcvd_hip_<name>.so (e.g. `det`, the deterministic build) "
+                          "instead of the product library")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    variant = config.getoption("--lib-variant")
+    if variant:
+        import torch  # (first, as the tests do: the process then holds ONE HIP runtime -- torch's)
+        if torch.cuda.is_available():
+            torch.cuda.init()
+        from robust_cvd_amd import api, build as b
+        if variant == "det":
+            b.build_deterministic()
+        api.load_library(variant=variant)  # (must be the first load of the library in the process)
 
 
 def _has_gpu():
