@@ -98,9 +98,19 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
       // waves per SIMD, i.e. 2 x CUs slots of 256 threads or 4 x CUs slots of 128.  When the items need more than one
       // round at 256 threads but fit into one round of 128-thread workgroups the launch has no ragged second round
       // (benchmark: 883 items, 44 -> 39.5 us).
-      const int nt = (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
-      // SPEC = 1: the default pipeline's variant (one value parameter, ReproDisparity, Cauchy) fixed at compile time
-      const bool spec = c.L.N == 1 && c.L.lossType == CVD_STATIC_REPRO_DISPARITY && c.L.robustKind == 0;
+      // SPEC = 1 / 2: the default pipeline's variant (one value parameter, ReproDisparity; Cauchy / Huber) fixed at compile time
+      const int spec = (c.L.N == 1 && c.L.lossType == CVD_STATIC_REPRO_DISPARITY) ? (c.L.robustKind == 0 ? 1 : 2) : 0;
+      // Slots of 256-thread workgroups on the device: waves per SIMD the variant is compiled for (cvd_kernels.h) x CUs; 128-thread
+      // workgroups: twice as many, as far as the LDS of a CU holds them.  One round of 256 when the items fit; one round of 128
+      // when only that fits; else 256 (rounds 2-4 assumed two waves per SIMD for every variant).
+      const int wavesPerSimd = spec ? ((c.KD <= 4) ? CVD_MV_WAVES : 3) : 2;
+      const long long slots256 = static_cast<long long>(wavesPerSimd) * h->numCU;
+      const long long slots128 = std::min<long long>(2 * slots256, static_cast<long long>(kMaxLds / std::max<size_t>(ldsFast, 1)) * h->numCU);
+#ifndef CVD_MV_NT_RULE
+#define CVD_MV_NT_RULE 1   // 0: the rule of rounds 2-4 (2 x CUs slots assumed)
+#endif
+      const int nt = CVD_MV_NT_RULE ? ((c.nItems <= slots256 || c.nItems > slots128) ? 256 : 128)
+                                    : (c.nItems > 2 * h->numCU && c.nItems <= 4 * h->numCU ? 128 : 256);
 #define CVD_LAUNCH_PAIRS_FAST_S(NTV, SPECV)                                                                              \
       CVD_DISPATCH_KD(c.KD, {                                                                                            \
         allowLds((k_matvec_pairs_fast<KD, NTV, SPECV>), ldsFast);                                                        \
@@ -111,7 +121,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
           hipLaunchKernelGGL((k_matvec_pairs_fast<KD, NTV, SPECV>), dim3(c.nItems), dim3(NTV), ldsFast, s, c.L, c.T, c.it, x, \
                              fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                                      \
       })
-#define CVD_LAUNCH_PAIRS_FAST(NTV) do { if (spec) CVD_LAUNCH_PAIRS_FAST_S(NTV, 1); else CVD_LAUNCH_PAIRS_FAST_S(NTV, 0); } while (0)
+#define CVD_LAUNCH_PAIRS_FAST(NTV) do { if (spec == 1) CVD_LAUNCH_PAIRS_FAST_S(NTV, 1); else if (spec == 2) CVD_LAUNCH_PAIRS_FAST_S(NTV, 2); else CVD_LAUNCH_PAIRS_FAST_S(NTV, 0); } while (0)
       if (h->dense) {
         // dense mode: flow / mask / depth read directly (17 B per pixel pair), grid columns in 8 lane-keyed private copies
         const size_t ldsDense = ldsFast + 8 * 2 * B * 8;
@@ -127,8 +137,9 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
                                  c.it, x, fcp, maskp, z, pOld, scalp, useBeta, h->dQPart.p, cF);                         \
           }                                                                                                              \
         })
-        if (spec) CVD_LAUNCH_PAIRS_DENSE(1);
-        else CVD_LAUNCH_PAIRS_DENSE(0);  // (the other reprojection losses / the Huber robustifier: runtime branches)
+        if (spec == 1) CVD_LAUNCH_PAIRS_DENSE(1);
+        else if (spec == 2) CVD_LAUNCH_PAIRS_DENSE(2);
+        else CVD_LAUNCH_PAIRS_DENSE(0);  // (the other reprojection losses: runtime branches)
 #undef CVD_LAUNCH_PAIRS_DENSE
       }
 #if CVD_DETERMINISTIC
