@@ -31,7 +31,7 @@ import types
 import numpy as np
 
 from robust_cvd_amd import synth
-from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, XformDesc
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, OptParams, StaticLossType, XformDesc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_py", "residual_golden.npz")
 
@@ -40,6 +40,10 @@ CASES = {
     "perframe_grid4x3": dict(frames=8, width=96, height=56, seed=515, intr=IntrinsicsOptimization.PerFrame, grid=(4, 3)),
     "fixed_global": dict(frames=6, width=64, height=48, seed=516, intr=IntrinsicsOptimization.Fixed, grid=None),
     "shared_grid3x3_portrait": dict(frames=6, width=48, height=80, seed=517, intr=IntrinsicsOptimization.Shared, grid=(3, 3)),
+    # ReproLogDepth: third residual = log(min / max) of the reprojected and the target's depth -- the reference's "depth ratio"
+    # term (loss/consistency_loss.py:124-140), the second of the optimizer's four static losses the reference's Python states
+    "perframe_logdepth": dict(frames=6, width=64, height=48, seed=518, intr=IntrinsicsOptimization.PerFrame, grid=(4, 3),
+                              loss=StaticLossType.ReproLogDepth),
 }
 FD_STEP = 1e-6   # central differences of the torch functions (float64)
 
@@ -70,6 +74,7 @@ def make_state(name):
     p.intr_opt = int(c["intr"])
     p.static_spatial_weight = 1.3   # (not 1: the weights must not hide in the comparison)
     p.static_depth_weight = 0.7
+    p.static_loss_type = int(c.get("loss", StaticLossType.ReproDisparity))
     if c["intr"] == IntrinsicsOptimization.Fixed:
         pose[:, 6] = v.true_fy      # (what the optimizer uses there: vFocal(params), reference lib/PoseOptimizer.cpp:1155-1157)
     return v, o, p, pose
@@ -116,24 +121,31 @@ def _reference_modules():
     return geometry, ConsistencyLoss
 
 
-def reference_terms(geometry, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b):
+def reference_terms(geometry, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b, log_depth=False, ext_b=None, intr_b=None):
     """The reference's functions, one constraint per batch entry as (n, C, 1, 1) float64 tensors: returns the pixel difference
     `project(reproject_points(pixels_to_points(..)))  - (pixels + flow)` [n, 2] and the disparity difference
     `1 / z_tgt - 1 / z_warped` [n] (consistency_loss.py:99-103, :117-118; `sample` of the target's point map at the matched pixel
     is the target observation's own camera-space point)."""
     import torch
     n = len(fa)
+    ext_b = ext if ext_b is None else ext_b      # (the target's camera tensors from another state: one-sided differences)
+    intr_b = intr if intr_b is None else intr_b
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)
     points_ref = geometry.pixels_to_points(t(intr[fa]), t(depth_a).view(n, 1, 1, 1), t(pix_a).view(n, 2, 1, 1).clone())
-    points_tgt = geometry.reproject_points(points_ref, t(ext[fa]), t(ext[fb]))
-    pixels_tgt = geometry.project(points_tgt, t(intr[fb]))
+    points_tgt = geometry.reproject_points(points_ref, t(ext[fa]), t(ext_b[fb]))
+    pixels_tgt = geometry.project(points_tgt, t(intr_b[fb]))
     matched = t(pix_b).view(n, 2, 1, 1)
-    warped_tgt = geometry.pixels_to_points(t(intr[fb]), t(depth_b).view(n, 1, 1, 1), matched.clone())
-    disp_diff = 1.0 / points_tgt[:, -1:, ...] - 1.0 / warped_tgt[:, -1:, ...]
-    return (pixels_tgt - matched).view(n, 2).numpy(), disp_diff.view(n).numpy()
+    warped_tgt = geometry.pixels_to_points(t(intr_b[fb]), t(depth_b).view(n, 1, 1, 1), matched.clone())
+    if log_depth:
+        # loss/consistency_loss.py:130-137: log(min / max) of |z| of the warped target point and of the reprojected point
+        dw, dt = torch.abs(warped_tgt[:, -1:, ...]), torch.abs(points_tgt[:, -1:, ...])
+        third = torch.log(torch.min(dw, dt) / torch.max(dw, dt))
+    else:
+        third = 1.0 / points_tgt[:, -1:, ...] - 1.0 / warped_tgt[:, -1:, ...]
+    return (pixels_tgt - matched).view(n, 2).numpy(), third.view(n).numpy()
 
 
-def reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b):
+def reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b, log_depth=False):
     """`ConsistencyLoss.geometry_consistency_loss` ITSELF (loss/consistency_loss.py:27-199) with the l1 distance, one
     constraint per batch entry as a constant 2 x 2 image pair; the reverse direction is masked out, so the method returns
     per constraint  reproj = |pixel difference| / 2  and  disp = mean(fx, fy) |disparity difference| / 2."""
@@ -141,7 +153,7 @@ def reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, depth_a, pix
     import utils.torch_helpers as th
     n = len(fa)
     opt = types.SimpleNamespace(distance_type_static="l1", distance_scale=1.0, lambda_static_reprojection=1.0,
-                                lambda_static_disparity=1.0, lambda_static_depth_ratio=0.0)
+                                lambda_static_disparity=0.0 if log_depth else 1.0, lambda_static_depth_ratio=1.0 if log_depth else 0.0)
     loss = ConsistencyLoss(opt)
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)
     img = lambda a, c: t(a).view(n, c, 1, 1).expand(n, c, 2, 2).contiguous()
@@ -155,7 +167,7 @@ def reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, depth_a, pix
                                                torch.zeros(n, 1, 2, 2, dtype=torch.float64))}}
     assert th._device.type == "cpu"
     _total, batch = loss.geometry_consistency_loss(pts, meta, pix)
-    return batch["reproj"].numpy(), batch["disp"].numpy()
+    return batch["reproj"].numpy(), batch["depth ratio" if log_depth else "disp"].numpy()
 
 
 def reference_outputs(name):
@@ -168,13 +180,10 @@ def reference_outputs(name):
     pix_b = to_pixels(sr["ndc_b"], W, H)
     Da, Db = sr["cam_a"][:, 2], sr["depth_b"]
 
-    def terms(ps):
-        ext, intr = cameras(ps, v.aspect, W, H)
-        return reference_terms(geometry, ext, intr, fa, fb, pix_a, Da, pix_b, Db)
-
-    dpx, ddisp = terms(pose)
+    log_depth = CASES[name].get("loss") == StaticLossType.ReproLogDepth
     ext, intr = cameras(pose, v.aspect, W, H)
-    l_reproj, l_disp = reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, Da, pix_b, Db)
+    dpx, ddisp = reference_terms(geometry, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
+    l_reproj, l_disp = reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
     # central differences of the torch functions along the 7 parameters of frame a resp. frame b, per constraint:
     # perturbing parameter k of EVERY frame that is a constraint's source (resp. target) at once is not the same thing when a
     # frame is both, so source and target are perturbed through two copies of the camera tensors
@@ -189,16 +198,7 @@ def reference_outputs(name):
             e1, i1 = cameras(ps, v.aspect, W, H)
             ea, ia = (e1, i1) if which == 0 else (ext, intr)
             eb, ib = (e1, i1) if which == 1 else (ext, intr)
-            # (two-camera form of reference_terms: the source's tensors from one state, the target's from the other)
-            import torch
-            t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)
-            pr = geometry.pixels_to_points(t(ia[fa]), t(Da).view(n, 1, 1, 1), t(pix_a).view(n, 2, 1, 1).clone())
-            pt = geometry.reproject_points(pr, t(ea[fa]), t(eb[fb]))
-            px = geometry.project(pt, t(ib[fb]))
-            m = t(pix_b).view(n, 2, 1, 1)
-            wt = geometry.pixels_to_points(t(ib[fb]), t(Db).view(n, 1, 1, 1), m.clone())
-            dd = 1.0 / pt[:, -1:, ...] - 1.0 / wt[:, -1:, ...]
-            out.append((( px - m).view(n, 2).numpy(), dd.view(n).numpy()))
+            out.append(reference_terms(geometry, ea, ia, fa, fb, pix_a, Da, pix_b, Db, log_depth, ext_b=eb, intr_b=ib))
         fd[:, 0, col] = (out[0][0][:, 0] - out[1][0][:, 0]) / (2 * FD_STEP)
         fd[:, 1, col] = (out[0][0][:, 1] - out[1][0][:, 1]) / (2 * FD_STEP)
         fd[:, 2, col] = (out[0][1] - out[1][1]) / (2 * FD_STEP)
@@ -207,7 +207,9 @@ def reference_outputs(name):
 
 
 def to_reference_units(sr, p, W, H):
-    """The oracle's residuals / Jacobian rows in the reference's units (pixels, disparity): see the module docstring."""
+    """The oracle's residuals / Jacobian rows in the reference's units (pixels, disparity): see the module docstring.
+    (ReproLogDepth: the third residual IS log(min / max) times the depth weight -- no sign change.)"""
     ws, wd = p.static_spatial_weight, p.static_depth_weight
-    s = np.array([(W / 2.0) / ws, -(H / 2.0) / ws, -1.0 / wd])
+    third = 1.0 / wd if p.static_loss_type == StaticLossType.ReproLogDepth else -1.0 / wd
+    s = np.array([(W / 2.0) / ws, -(H / 2.0) / ws, third])
     return sr["residuals"] * s[None, :], sr["jacobian"] * s[None, :, None]

@@ -1,7 +1,8 @@
 """Reference-held pin of the RESIDUAL ARITHMETIC at random, NON-converged states: the oracle's
-three ReproDisparity residuals of every static constraint, and their dual-number Jacobian columns for pose and focal length,
-against the reference's own torch statement of the same quantities -- utils/geometry.py:62-166 and the reprojection /
-disparity terms of loss/consistency_loss.py:93-122 (see tests/reference_residuals.py for the conversions).
+three residuals of every static constraint -- ReproDisparity (the default loss) and ReproLogDepth --, and their dual-number
+Jacobian columns for pose and focal length, against the reference's own torch statement of the same quantities --
+utils/geometry.py:62-166 and the reprojection / disparity / depth-ratio terms of loss/consistency_loss.py:93-140 (see
+tests/reference_residuals.py for the conversions).
 
 CPU only.  Always: against tests/golden/reference_py/residual_golden.npz (outputs of the real reference functions, minted by
 make_residual_golden.py next to it).  With /root/reference mounted: against the live functions, including
@@ -12,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from robust_cvd_amd.ctypes_types import IntrinsicsOptimization
+from robust_cvd_amd.ctypes_types import IntrinsicsOptimization, StaticLossType
 from tests import baseline_configs as bc
 from tests import reference_residuals as rres
 
@@ -41,7 +42,12 @@ def _check(name, v, p, pose, sr, ref, rows):
     _ext, intr = rres.cameras(pose, v.aspect, W, H)
     f_mean = intr[sr["frames"][:, 0], :2].mean()
     assert np.abs(np.linalg.norm(r[:, :2], axis=1) / 2.0 - ref["loss_reproj"]).max() < VALUE_TOL_PX
-    assert np.abs(f_mean * np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-10
+    if rres.CASES[name].get("loss") == StaticLossType.ReproLogDepth:
+        # "depth ratio" term: |log(min / max)| / 2 per constraint (lambda = 1, no focal factor: loss/consistency_loss.py:124-140)
+        assert np.abs(np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-12
+        assert (r[:, 2] <= 0.0).all()
+    else:
+        assert np.abs(f_mean * np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-10
     # derivative columns: pose of the source (0-5), pose of the target (6-11), the focal lengths (12, 13)
     fd = ref["fd"]
     scale = np.abs(fd).max(axis=(0, 2), keepdims=True)   # per residual row (pixels / disparity)
