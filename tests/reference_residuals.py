@@ -48,13 +48,16 @@ CASES = {
 FD_STEP = 1e-6   # central differences of the torch functions (float64)
 
 
-def make_state(name):
+def make_state(name, binding=None):
     """A seeded NON-converged state of a small synthetic problem: the true cameras perturbed by centimetres / degrees /
-    10 % in focal length, flow noise 1 px, random depth scales -- residuals of O(0.01 .. 1) NDC units."""
-    from oracle.oracle import Oracle
+    10 % in focal length, flow noise 1 px, random depth scales -- residuals of O(0.01 .. 1) NDC units.  `binding`: the object
+    to load it into (default: a fresh Oracle; the GPU test passes the product Solver)."""
     c = CASES[name]
     v = synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], flow_noise_px=1.0, spacing=9.0)
-    o = Oracle()
+    if binding is None:
+        from oracle.oracle import Oracle
+        binding = Oracle()
+    o = binding
     synth.load_into(o, v)
     o.reset_depth_xforms(XformDesc.grid_depth(*c["grid"]) if c["grid"] else XformDesc.global_depth())
     o.reset_spatial_xforms(XformDesc.spatial())
@@ -213,3 +216,24 @@ def to_reference_units(sr, p, W, H):
     third = 1.0 / wd if p.static_loss_type == StaticLossType.ReproLogDepth else -1.0 / wd
     s = np.array([(W / 2.0) / ws, -(H / 2.0) / ws, third])
     return sr["residuals"] * s[None, :], sr["jacobian"] * s[None, :, None]
+
+
+def cost_from_reference_terms(pixel_diff, third, p, W, H, log_depth=False):
+    """The static part of the optimizer's cost, 0.5 sum rho_Cauchy(|r|^2) (ceres::CauchyLoss(robustness): rho(s) = b^2 log(1 + s / b^2),
+    reference lib/PoseOptimizer.cpp:1220), from the REFERENCE's per-constraint pixel / disparity (or log-depth) terms."""
+    ws, wd, b2 = p.static_spatial_weight, p.static_depth_weight, p.robustness ** 2
+    r0 = pixel_diff[:, 0] * ws / (W / 2.0)
+    r1 = -pixel_diff[:, 1] * ws / (H / 2.0)
+    r2 = third * wd * (1.0 if log_depth else -1.0)
+    s = r0 * r0 + r1 * r1 + r2 * r2
+    return 0.5 * float(np.sum(b2 * np.log1p(s / b2)))
+
+
+def without_regularisers(p):
+    """The same problem with every regulariser switched off: the cost is then the static constraints' alone."""
+    p.scale_reg = 0.0
+    p.focal_reg = 0.0
+    p.depth_deform_reg_initial = p.depth_deform_reg_final = 0.0
+    p.spatial_deform_reg = 0.0
+    p.position_reg = 0.0
+    return p

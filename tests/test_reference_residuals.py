@@ -96,3 +96,40 @@ def test_the_pin_can_tell_a_wrong_convention():
     r, _J = rres.to_reference_units(sr, p, v.width, v.height)
     assert np.abs(-r[:, 1] - g[name + "/pixel_diff"][:, 1]).max() > 1.0     # flipped v
     assert np.abs(-r[:, 2] - g[name + "/disparity_diff"]).max() > 0.01      # flipped disparity sign
+
+
+def _reference_cost(name, p, v, g):
+    logd = rres.CASES[name].get("loss") == StaticLossType.ReproLogDepth
+    return rres.cost_from_reference_terms(g[name + "/pixel_diff"], g[name + "/disparity_diff"], p, v.width, v.height, logd)
+
+
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_oracle_cost_equals_the_cost_of_the_reference_terms(name):
+    """With every regulariser off the problem's cost is 0.5 sum rho_Cauchy(|r|^2) over the static constraints: the oracle's evaluation
+    hook against that sum formed from the REFERENCE's per-constraint terms (committed outputs of its torch functions)."""
+    g = _golden()
+    v, o, p, pose = rres.make_state(name)
+    rres.without_regularisers(p)
+    ev = o.evaluate(p, 0.0, pose, want_gradient=False)
+    assert ev["num_residual_blocks"] == len(g[name + "/pixel_diff"])
+    ref = _reference_cost(name, p, v, g)
+    assert abs(ev["cost"] - ref) <= 1e-13 * ref, (ev["cost"], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_hip_cost_equals_the_cost_of_the_reference_terms(name):
+    """The same for the HIP path, with no oracle in between: cvd_evaluate at a random non-converged state against the cost formed
+    from what the reference's own geometry.py / consistency_loss.py return for every constraint (fast and generic kernels)."""
+    from robust_cvd_amd import api
+    g = _golden()
+    for generic in (False, True):
+        s = api.Solver(0)
+        s.set_generic_kernels(generic)
+        v, _s, p, pose = rres.make_state(name, s)
+        rres.without_regularisers(p)
+        ev = s.evaluate(p, 0.0, pose, want_gradient=False)
+        ref = _reference_cost(name, p, v, g)
+        assert ev["num_residual_blocks"] == len(g[name + "/pixel_diff"])
+        assert abs(ev["cost"] - ref) <= 1e-12 * ref, (generic, ev["cost"], ref)
+        s.close()
