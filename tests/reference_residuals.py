@@ -237,3 +237,39 @@ def without_regularisers(p):
     p.spatial_deform_reg = 0.0
     p.position_reg = 0.0
     return p
+
+
+def reference_cost_gradient(name):
+    """Central differences (step FD_STEP) of the REFERENCE cost -- 0.5 sum rho_Cauchy(|r|^2) with r from the reference's torch
+    functions -- along every frame's pose parameters [t(3) w(3)] and focal length: [F, 7].  Shared intrinsics: the one focal length
+    is perturbed in every frame at once and its derivative is stored in frame 0's slot; Fixed: the focal column stays 0.
+    (needs /root/reference)"""
+    geometry, _cl = _reference_modules()
+    v, p, pose, sr = oracle_side(name)
+    without_regularisers(p)
+    W, H = v.width, v.height
+    fa, fb = sr["frames"][:, 0], sr["frames"][:, 1]
+    pix_a, pix_b = to_pixels(sr["cam_a"][:, :2], W, H), to_pixels(sr["ndc_b"], W, H)
+    Da, Db = sr["cam_a"][:, 2], sr["depth_b"]
+    log_depth = CASES[name].get("loss") == StaticLossType.ReproLogDepth
+
+    def cost(ps):
+        ext, intr = cameras(ps, v.aspect, W, H)
+        d, t = reference_terms(geometry, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
+        return cost_from_reference_terms(d, t, p, W, H, log_depth)
+
+    F = v.num_frames
+    g = np.zeros((F, 7))
+    intr_mode = CASES[name]["intr"]
+    for f in range(F):
+        for k in range(7 if intr_mode == IntrinsicsOptimization.PerFrame else 6):
+            a, b = pose.copy(), pose.copy()
+            a[f, k] += FD_STEP
+            b[f, k] -= FD_STEP
+            g[f, k] = (cost(a) - cost(b)) / (2 * FD_STEP)
+    if intr_mode == IntrinsicsOptimization.Shared:
+        a, b = pose.copy(), pose.copy()
+        a[:, 6] += FD_STEP
+        b[:, 6] -= FD_STEP
+        g[0, 6] = (cost(a) - cost(b)) / (2 * FD_STEP)
+    return g

@@ -133,3 +133,46 @@ def test_hip_cost_equals_the_cost_of_the_reference_terms(name):
         assert ev["num_residual_blocks"] == len(g[name + "/pixel_diff"])
         assert abs(ev["cost"] - ref) <= 1e-12 * ref, (generic, ev["cost"], ref)
         s.close()
+
+
+def _check_gradient(name, grad, g):
+    """grad [F, B] (layout [t w f | theta]) of the regulariser-free problem against the central differences of the reference cost."""
+    fd = g[name + "/cost_gradient_fd"]
+    scale = np.abs(fd).max()
+    assert scale > 10.0   # (the state is far from a minimum: the gradient carries signal)
+    G = grad[:, :7].copy()
+    intr = rres.CASES[name]["intr"]
+    if intr == IntrinsicsOptimization.Shared:
+        G[0, 6] = G[:, 6].sum()   # (one focal length: the canonical layout keeps it in frame 0's slot)
+        G[1:, 6] = 0.0
+    elif intr == IntrinsicsOptimization.Fixed:
+        assert np.abs(G[:, 6]).max() == 0.0
+    # central differences with step 1e-6 of a cost of O(100): ~1e-8 absolute; measured 5e-8 on entries of up to 785
+    assert np.abs(G - fd).max() < 1e-9 * scale + 1e-6, (np.abs(G - fd).max(), scale)
+
+
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_oracle_gradient_equals_the_differences_of_the_reference_cost(name):
+    g = _golden()
+    v, o, p, pose = rres.make_state(name)
+    rres.without_regularisers(p)
+    ev = o.evaluate(p, 0.0, pose, want_gradient=True)
+    _check_gradient(name, ev["gradient"], g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_hip_gradient_equals_the_differences_of_the_reference_cost(name):
+    """J^T (rho' r) of the device's assembly kernels (fast and generic), pose and focal part, against central differences of the
+    cost formed from the reference's own per-constraint terms: analytic Jacobians, robust weights and the frame-major accumulation
+    of the HIP path held by reference code without the oracle in between."""
+    from robust_cvd_amd import api
+    g = _golden()
+    for generic in (False, True):
+        s = api.Solver(0)
+        s.set_generic_kernels(generic)
+        v, _s, p, pose = rres.make_state(name, s)
+        rres.without_regularisers(p)
+        ev = s.evaluate(p, 0.0, pose, want_gradient=True)
+        _check_gradient(name, ev["gradient"], g)
+        s.close()
