@@ -35,13 +35,18 @@ CONFIGS = {
     # DENSE mode at real resolution (matchSeparation = 0: every masked pixel of every directed pair, 12.8 M constraints): the
     # HIP path reads the flow / mask images, the oracle the equivalent constraint list
     "dense30": dict(frames=30, width=384, height=224, seed=1240, dense=True),
+    # OFF the tuning set (VERDICT r4 Next #8: the defaults of cvd_solver_options were chosen on seed 1237 at 300 frames): another
+    # seed at 150 frames, and a third seed with 1 px flow noise and 5 % gross outliers -- default options against the oracle
+    "sweep150": dict(frames=150, width=384, height=224, seed=1, extra_offsets=6),
+    "sweep150_noisy": dict(frames=150, width=384, height=224, seed=3, extra_offsets=6, flow_noise_px=1.0, outlier_fraction=0.05),
 }
 
 
 def make_video(name):
     c = CONFIGS[name]
     return synth.make_video(c["frames"], c["width"], c["height"], seed=c["seed"], extra_offsets=c.get("extra_offsets", 1),
-                            spacing=(1e9 if c.get("dense") else 12.5))  # (dense: the sampled list is not used)
+                            spacing=(1e9 if c.get("dense") else 12.5),  # (dense: the sampled list is not used)
+                            flow_noise_px=c.get("flow_noise_px", 0.25), outlier_fraction=c.get("outlier_fraction", 0.0))
 
 
 def input_digest(video):
