@@ -147,19 +147,22 @@ double evalFull(Ctx& c, const double* x, bool withStats, bool noReadBack) {
   if (fast && fastFits) {
     h->dAsmScratch.ensure(static_cast<size_t>(h->nAsmSlots) * (B * (B + 1) / 2 + B + 4));
     const AsmWork work{h->dAsmParts.p, h->dAsmUnits.p, h->dAsmScratch.p, h->dAsmCount.p};
-    CVD_DISPATCH_KD(c.KD, {
-      if (h->dense) {
-        allowLds((k_assemble_fast<KD, true>), ldsFast);
-        hipLaunchKernelGGL((k_assemble_fast<KD, true>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
-                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
-                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
-      } else {
-        allowLds((k_assemble_fast<KD, false>), ldsFast);
-        hipLaunchKernelGGL((k_assemble_fast<KD, false>), dim3(h->nAsmParts), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
-                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,
-                           h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);
-      }
-    });
+    // STAGE: the other frame's parameters in a per-wave LDS buffer whenever the LDS holds 8 B doubles more (cvd_kernels.h)
+    const size_t ldsStage = ldsFast + static_cast<size_t>(kAsmThreads / 64) * B * 8;
+    const bool stage = ldsStage <= kMaxLds;
+#define CVD_LAUNCH_ASM(DENSEV, STAGEV)                                                                                     \
+    CVD_DISPATCH_KD(c.KD, {                                                                                              \
+      allowLds((k_assemble_fast<KD, DENSEV, STAGEV>), STAGEV ? ldsStage : ldsFast);                                        \
+      hipLaunchKernelGGL((k_assemble_fast<KD, DENSEV, STAGEV>), dim3(h->nAsmParts), dim3(kAsmThreads), STAGEV ? ldsStage : ldsFast, s, \
+                         c.L, c.T, x, h->dFc.p, h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p,  \
+                         h->dCostFrame.p, h->dFocal.p, h->dFocal.p + c.L.F);                                             \
+    })
+#ifndef CVD_ASM_STAGE
+#define CVD_ASM_STAGE 1
+#endif
+    if (h->dense) { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(true, true); else CVD_LAUNCH_ASM(true, false); }
+    else { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(false, true); else CVD_LAUNCH_ASM(false, false); }
+#undef CVD_LAUNCH_ASM
   } else {
     const AsmPanels panels = makePanels(static_cast<int>(B), (kMaxLds - ldsRest) / 8, panelCap);
     const size_t lds = static_cast<size_t>(panelCap) * 8 + ldsRest;

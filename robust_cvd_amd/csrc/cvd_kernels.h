@@ -3452,7 +3452,11 @@ __device__ unsigned long long g_asmProf[2048 * 16];
 #else
 #define ASM_STAMP(slot) do {} while (0)
 #endif
-template <int KD, bool DENSE = false>
+// STAGE (round 5): the OTHER frame's parameters of the unit a wave walks are copied into a per-wave LDS buffer first.  Without it
+// the taps of the other side are 4-tap gathers from global memory -- a dependent round trip in every trip of a kernel that runs
+// two waves per SIMD -- and, since `side` selects between an LDS and a global pointer at run time, every parameter read of the
+// loop is a FLAT load.  With it both sides are LDS reads.  Needs 8 B more doubles of LDS: on whenever that fits (cvd_eval.hip).
+template <int KD, bool DENSE = false, bool STAGE = false>
 inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
@@ -3473,6 +3477,7 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
   double* gs = Hs + npk;
   double* xf = gs + B;
   double* red = xf + B;  // 36 workgroup sums (LDS atomics, one set per wave) + scratch
+  double* xstage = red + 4 * 36;  // STAGE: kAsmThreads / 64 x B doubles
   const AsmPart me = work.parts[blockIdx.x];
   const int f = me.frame;
   const int tid = threadIdx.x;
@@ -3517,8 +3522,15 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
       const double* __restrict__ xo = x + static_cast<size_t>(o) * B;
       const FrameConst& Fa = side ? fc[o] : fc[f];
       const FrameConst& Fb = side ? fc[f] : fc[o];
-      const double* xa = side ? xo : xf;
-      const double* xb = side ? xf : xo;
+      double* xw = xstage + wv * B;
+      if constexpr (STAGE) {
+        // (a wave's LDS operations execute in order: its own earlier reads of the buffer are done before these writes land, and
+        // the reads below see them -- no workgroup barrier, the waves walk their units independently)
+        for (int i = lane; i < B; i += 64) xw[i] = xo[i];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      const double* xa = STAGE ? (side ? xw : xf) : (side ? xo : xf);
+      const double* xb = STAGE ? (side ? xf : xw) : (side ? xf : xo);
       const double fya = Fa.fy, fxa = Fa.fy * A;
       const double fyb = Fb.fy;
       const double ifyb = 1.0 / fyb, ifxb = 1.0 / (fyb * A);
