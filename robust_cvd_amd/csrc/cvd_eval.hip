@@ -98,35 +98,49 @@ bool crossScope(cvd_handle* h, const Ctx& c) {
   const bool off = h->opt.dense_matrix_free != 0;  // comparison variant
   return h->dense && !off && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
          c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
-         c.L.B <= 256;
+         c.L.B <= 256 && (static_cast<size_t>(c.L.B) * (c.L.B + 1) / 2 + 2 * c.L.B + 4 * 36) * 8 <= kMaxLds &&  // (the fold's packed block)
+         dwLdsBytes(c.L.nD, c.L.B, kDwThreads) <= kMaxLds;
 }
 CrossPairs crossPairs(cvd_handle* h) {
   return CrossPairs{h->dXFa.p, h->dXFb.p, h->dXRange.p, h->dXSlot.p, static_cast<int>(h->xFa.size())};
 }
-// X_ab of every undirected pair at the linearisation point x (frame constants in dFc are those of x)
+// Dense mode, explicit-block scope: the ONE walk over the pixels (cvd_dense_walk.h) -- every directed pair's record and the
+// per-pixel grid x grid scalars at the linearisation point x (frame constants in dFc are those of x).
+DenseRecords denseRecords(cvd_handle* h) {
+  return DenseRecords{h->dDwRecords.p, h->dDwRecOff.p, h->dFpOff.p, h->dFpList.p};
+}
+void launchDenseWalk(Ctx& c, const double* x) {
+  cvd_handle* h = c.h;
+  const int G = c.L.nD, B = c.L.B;
+  h->dDwRecords.ensure(static_cast<size_t>(std::max(1, h->nDwRecords)) * dwRecordDoubles(G));
+  h->dDwGg.ensure(static_cast<size_t>(std::max<long long>(1, h->C)));
+  if (h->nDwRecords == 0) return;
+  const size_t lds = dwLdsBytes(G, B, kDwThreads);
+  const DenseWalkList wl{h->dDwPair.p, h->dDwRange.p, h->nDwRecords};
+  allowLds((k_dense_walk<4>), lds);
+  hipLaunchKernelGGL((k_dense_walk<4>), dim3(h->nDwRecords), dim3(kDwThreads), lds, h->stream, c.L, c.T, wl, x, h->dFc.p,
+                     h->dDwRecords.p, h->dDwGg.p);
+  HIP_CHECK(hipGetLastError());
+}
+// X_ab of every undirected pair from the walk's records (pose rows / columns) and scalars (grid x grid, in column panels of the
+// largest width that fits the LDS)
 void launchCrossAssemble(Ctx& c, const double* x) {
+  (void)x;
   cvd_handle* h = c.h;
   const size_t B = c.L.B, G = c.L.nD;
   h->dXBlocks.ensure(h->xFa.size() * B * B);
-  // pose rows / columns: one workgroup per pair; grid x grid: column panels of the largest width that fits the LDS
-  const size_t fixedDoubles = 2 * B + 2 * sizeof(FrameConst) / 8;
-  int panelW = static_cast<int>(((kMaxLds - 8192) / 8 - fixedDoubles) / G);
+  const unsigned nP = static_cast<unsigned>(h->xFa.size());
+  if (nP == 0) return;
+  hipLaunchKernelGGL(k_dense_fold_cross, dim3(nP), dim3(256), 0, h->stream, c.L, crossPairs(h), h->dXDir.p, h->dDwRecOff.p,
+                     h->dDwRecords.p, h->dXBlocks.p);
+  int panelW = static_cast<int>(((kMaxLds - 4096) / 8) / G);
   panelW = std::max(1, std::min<int>(panelW, static_cast<int>(G)));
   const int nPanels = static_cast<int>((G + panelW - 1) / panelW);
   panelW = static_cast<int>((G + nPanels - 1) / nPanels);  // (even panels)
-  const size_t ldsPose = (fixedDoubles + 56 + 14 * G) * 8;
-  const size_t ldsGrid = (fixedDoubles + static_cast<size_t>(panelW) * G) * 8;
-  const unsigned nP = static_cast<unsigned>(h->xFa.size());
-  CVD_DISPATCH_KD(c.KD, {
-    if constexpr (KD == 4) {
-      allowLds((k_cross_assemble<KD, false>), ldsPose);
-      hipLaunchKernelGGL((k_cross_assemble<KD, false>), dim3(nP), dim3(kCrossThreads), ldsPose, h->stream, c.L, c.T, crossPairs(h),
-                         x, h->dFc.p, static_cast<int>(G), h->dXBlocks.p);
-      allowLds((k_cross_assemble<KD, true>), ldsGrid);
-      hipLaunchKernelGGL((k_cross_assemble<KD, true>), dim3(nP, nPanels), dim3(kCrossThreads), ldsGrid, h->stream, c.L, c.T,
-                         crossPairs(h), x, h->dFc.p, panelW, h->dXBlocks.p);
-    }
-  });
+  const size_t ldsGrid = static_cast<size_t>(panelW) * G * 8;
+  allowLds((k_dense_gg<4>), ldsGrid);
+  hipLaunchKernelGGL((k_dense_gg<4>), dim3(nP, nPanels), dim3(kGgThreads), ldsGrid, h->stream, c.L, c.T, crossPairs(h), h->dXDir.p,
+                     h->dDwGg.p, panelW, h->dXBlocks.p);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -160,7 +174,14 @@ double evalFull(Ctx& c, const double* x, bool withStats, bool noReadBack) {
 #ifndef CVD_ASM_STAGE
 #define CVD_ASM_STAGE 1
 #endif
-    if (h->dense) { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(true, true); else CVD_LAUNCH_ASM(true, false); }
+    if (c.cross) {
+      // explicit-block scope of the dense mode: one walk over the pixels, then a per-frame fold of the pairs' records
+      launchDenseWalk(c, x);
+      allowLds((k_assemble_fast<4, true, false, true>), ldsFast);
+      hipLaunchKernelGGL((k_assemble_fast<4, true, false, true>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                         h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p, h->dCostFrame.p,
+                         h->dFocal.p, h->dFocal.p + c.L.F, denseRecords(h));
+    } else if (h->dense) { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(true, true); else CVD_LAUNCH_ASM(true, false); }
     else { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(false, true); else CVD_LAUNCH_ASM(false, false); }
 #undef CVD_LAUNCH_ASM
   } else {

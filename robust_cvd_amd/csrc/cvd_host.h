@@ -37,6 +37,7 @@
 #include "cvd_coarse.h"
 #include "cvd_temporal.h"
 #include "cvd_cross.h"
+#include "cvd_dense_walk.h"
 #include "cvd_triplets.h"
 #include "cvd_dense.h"
 #include "cvd_sampling.h"
@@ -255,6 +256,11 @@ struct cvd_handle_t {
   DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff, dXPairEdge;
   DevBuf<long long> dXRange;
   DevBuf<double> dXBlocks;
+  // one-walk assembly of the dense mode (cvd_dense_walk.h): records of the directed pairs, per-pixel grid x grid scalars
+  DevBuf<int> dDwPair, dDwRecOff, dXDir;
+  DevBuf<long long> dDwRange;
+  DevBuf<double> dDwRecords, dDwGg;
+  int nDwRecords = 0;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   DevBuf<unsigned int> dTailBar;   // grid barrier of k_pcg_tail (tailArrive / tailWait)
   DevBuf<double> dOwnerScal;       // owner-sharded PCG iteration: {r^T z, r^T r} shares of every rank (all-gathered)

@@ -202,6 +202,16 @@ struct AsmWork {
   unsigned int* counters;    // one per frame, zero between launches
 };
 
+// Dense mode, one-walk assembly (cvd_dense_walk.h): k_dense_walk leaves one compact RECORD per directed pair (layout: that
+// header); k_assemble_fast<.., FOLD> sums a frame's records into H_ff / g / cost through this view.
+__host__ __device__ inline int dwRecordDoubles(int G) { return 256 + 40 * G + 8; }
+struct DenseRecords {
+  const double* records;
+  const int* recOff;     // per directed pair: its records [recOff[p], recOff[p + 1])
+  const int* fpOff;      // per frame: entries of fpList
+  const int* fpList;     // directed pair * 2 + side (0: the frame is the pair's source, 1: its target)
+};
+
 // scalar slots kept on the device during PCG
 enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5, S_RZ0 = 6, S_COST = 7,
              S_DG = 8, S_DR = 9, S_DLD = 10, S_DD = 11, S_XX = 12, S_NVALID = 13, S_GMAX = 14,
@@ -3456,7 +3466,10 @@ __device__ unsigned long long g_asmProf[2048 * 16];
 // the taps of the other side are 4-tap gathers from global memory -- a dependent round trip in every trip of a kernel that runs
 // two waves per SIMD -- and, since `side` selects between an LDS and a global pointer at run time, every parameter read of the
 // loop is a FLAT load.  With it both sides are LDS reads.  Needs 8 B more doubles of LDS: on whenever that fits (cvd_eval.hip).
-template <int KD, bool DENSE = false, bool STAGE = false>
+// FOLD (round 6, dense mode inside the explicit-block scope): the constraints were walked by k_dense_walk (cvd_dense_walk.h); a
+// frame's workgroup sums its records -- a gather over (pair, side) entries, no atomics -- in place of the walk, and continues with
+// the regularisers and the write-out as ever.  One workgroup per frame (blockIdx.x = frame; the work list is not used).
+template <int KD, bool DENSE = false, bool STAGE = false, bool FOLD = false>
 inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, Table T, const double* __restrict__ x,
                                                        const FrameConst* __restrict__ fc,
                                                        const double* __restrict__ mask, const float* __restrict__ median,
@@ -3465,7 +3478,7 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
                                                        AsmWork work,
                                                        double* __restrict__ gOut, double* __restrict__ hOut,
                                                        double* __restrict__ costFrame, double* __restrict__ focalG,
-                                                       double* __restrict__ focalH) {
+                                                       double* __restrict__ focalH, DenseRecords dr = DenseRecords{}) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr double eps = 1e-6;
   const int B = L.B;
@@ -3478,7 +3491,7 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
   double* xf = gs + B;
   double* red = xf + B;  // 36 workgroup sums (LDS atomics, one set per wave) + scratch
   double* xstage = red + 4 * 36;  // STAGE: kAsmThreads / 64 x B doubles
-  const AsmPart me = work.parts[blockIdx.x];
+  const AsmPart me = FOLD ? AsmPart{static_cast<int>(blockIdx.x), 0, 0, 0, 1, 0} : work.parts[blockIdx.x];
   const int f = me.frame;
   const int tid = threadIdx.x;
   constexpr int NT = kAsmThreads;
@@ -3510,6 +3523,54 @@ inline __global__ __launch_bounds__(kAsmThreads) void k_assemble_fast(Layout L, 
   const int N = L.N;
   const double A = L.aspect;
 
+  if constexpr (FOLD) {
+    if (L.includeStatic) {
+      // output o: [0, 28) pose x pose (lower), [28, 35) pose gradient, 35 cost, then 36 + c G + v: c < 7 theta[v] x pose[c],
+      // c = 7 gradient of theta[v], c = 8 + d band d of theta x theta.  Side 0 (source) / 1 (target) read different parts of a record.
+      const int G = L.nD;
+      const int recN = dwRecordDoubles(G);
+      const int e0 = dr.fpOff[f], e1 = dr.fpOff[f + 1];
+      const int nOut = 36 + 13 * G;
+      for (int o = tid; o < nOut; o += NT) {
+        int off0, off1, c = -1, v = 0;
+        if (o < 28) {
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= o) ++i;
+          const int j = o - i * (i + 1) / 2;
+          off0 = i * 16 + j;
+          off1 = (7 + i) * 16 + 7 + j;
+        } else if (o < 35) {
+          off0 = (o - 28) * 16 + 14;
+          off1 = (7 + o - 28) * 16 + 14;
+        } else if (o == 35) {
+          off0 = 256 + 40 * G;
+          off1 = -1;
+        } else {
+          const int e = o - 36;
+          c = e / G;
+          v = e - c * G;
+          if (c < 7) { off0 = 256 + c * G + v; off1 = 256 + 15 * G + (7 + c) * G + v; }
+          else if (c == 7) { off0 = 256 + 14 * G + v; off1 = 256 + 29 * G + v; }
+          else { off0 = 256 + 30 * G + (c - 8) * G + v; off1 = 256 + 35 * G + (c - 8) * G + v; }
+        }
+        double s = 0.0;
+        for (int e = e0; e < e1; ++e) {
+          const int code = dr.fpList[e];
+          const int off = (code & 1) ? off1 : off0;
+          if (off < 0) continue;
+          for (int q = dr.recOff[code >> 1]; q < dr.recOff[(code >> 1) + 1]; ++q) s += dr.records[static_cast<size_t>(q) * recN + off];
+        }
+        if (o < 36) atomicAdd(&red[o], s);
+        else if (c < 7) Hs[packedIdx(7 + v, c)] = s;
+        else if (c == 7) gs[7 + v] = s;
+        else {
+          const int d = c - 8;
+          const int v2 = v + (d == 0 ? 0 : (d == 1 ? 1 : L.gx + d - 3));
+          if (v2 < G) atomicAdd(&Hs[packedIdx(7 + v2, 7 + v)], s);  // (gx = 2: bands 1 and 2 are the same vertex pair)
+        }
+      }
+    }
+  } else
   if (L.includeStatic) {
     // one unit (slice of a (pair, side) entry) per WAVE at a time: the waves run through their units independently
     // (no barrier until the end), 64 lanes over the slice's constraints

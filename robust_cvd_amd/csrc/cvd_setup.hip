@@ -809,6 +809,37 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
       frameRows[fa].push_back(k * 2 + 0);
       frameRows[fb].push_back(k * 2 + 1);
     }
+    // one-walk assembly (cvd_dense_walk.h): one record per directed pair of the pair graph, and the two directions of every block
+    {
+      std::vector<int> dwPair, recOff(h->P + 1, 0), xDir;
+      std::vector<long long> dwRange;
+      for (const auto& e : edges) {
+        bool any = false;
+        for (int dir = 0; dir < 2; ++dir) any = any || (e.second[dir] >= 0 && h->pairOff[e.second[dir] + 1] > h->pairOff[e.second[dir]]);
+        if (!any) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+          const int p = e.second[dir];
+          const bool has = p >= 0 && h->pairOff[p + 1] > h->pairOff[p];
+          xDir.push_back(has ? p : -1);
+        }
+      }
+      for (int p = 0; p < h->P; ++p) {
+        const int a = h->pairA[p], b = h->pairB[p];
+        const long long n = h->pairOff[p + 1] - h->pairOff[p];
+        recOff[p] = static_cast<int>(dwPair.size());
+        if (!inRange[a] || !inRange[b] || a == b || n <= 0) continue;
+        dwPair.push_back(p);
+        dwRange.insert(dwRange.end(), {0ll, n});
+      }
+      recOff[h->P] = static_cast<int>(dwPair.size());
+      h->nDwRecords = static_cast<int>(dwPair.size());
+      if (xDir.empty()) xDir.push_back(-1);
+      if (dwPair.empty()) { dwPair.push_back(0); dwRange.insert(dwRange.end(), {0ll, 0ll}); }
+      h->dDwPair.upload(dwPair.data(), dwPair.size(), s);
+      h->dDwRange.upload(dwRange.data(), dwRange.size(), s);
+      h->dDwRecOff.upload(recOff.data(), recOff.size(), s);
+      h->dXDir.upload(xDir.data(), xDir.size(), s);
+    }
     std::vector<int> xFiOff(h->F + 1, 0), xSlot(std::max<size_t>(1, h->xFa.size() * 2), 0);
     int row = 0;
     for (int f = 0; f < h->F; ++f) {
