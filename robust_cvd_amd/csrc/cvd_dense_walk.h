@@ -38,19 +38,42 @@
 namespace cvd {
 
 constexpr int kDwThreads = CVD_DETERMINISTIC ? 64 : 512;
-constexpr int kDwRun = 16;           // consecutive pixels per lane (kDenseRun: lanes of a wave touch different cells)
 constexpr int kDwLd = 17;            // row stride (doubles) of the per-wave MFMA staging tile [64 constraints][16 columns]
-constexpr int kDwCols = 15;          // side-block columns
 // (dwRecordDoubles, DenseRecords: cvd_kernels.h, beside the frame-major kernel that folds the records)
-__host__ __device__ inline size_t dwLdsBytes(int G, int B, int threads) {
-  return (static_cast<size_t>(dwRecordDoubles(G)) + 2 * B + 2 * (sizeof(FrameConst) / 8) + static_cast<size_t>(threads / 64) * 64 * kDwLd) * 8;
+constexpr int kDwCols = 15;          // side-block columns of a record
+
+// Lane map of the walks.  A lane's LDS atomics go to the vertices of the cell its pixel lies in: lanes of one wave instruction that
+// sit in the same cell hit the same addresses and are serialised (SQ_LDS_BANK_CONFLICT was 62 % of the LDS time with lanes 16
+// pixels apart along a row and 2.7 rows per wave: ~4 lanes per cell of the 17 x 10 grid).  Here a wave works on `rowGroups` image
+// rows that lie a band height (H / rowGroups) apart, `lanesPerRow` lanes per row, each walking its own run of `run` consecutive
+// pixels: at 384 x 224 that is 16 x 4 lanes with runs of 24 pixels -- one lane per cell column, the row groups 56 rows (> 2 cells)
+// apart.  A unit = one such set of rows; a pair has `bandH` units.
+struct DenseLaneMap {
+  int run, lanesPerRow, rowGroups, bandH;
+};
+inline DenseLaneMap denseLaneMap(int W, int H) {
+  DenseLaneMap m;
+  m.run = (W + 15) / 16;
+  m.lanesPerRow = (W + m.run - 1) / m.run;
+  m.rowGroups = 64 / m.lanesPerRow;
+  if (m.rowGroups > H) m.rowGroups = H;
+  m.bandH = (H + m.rowGroups - 1) / m.rowGroups;
+  return m;
+}
+// first pixel of the lane's run in unit u (row-major index within the image) and the run's length (0: the lane idles)
+__device__ __forceinline__ int denseLaneRun(const DenseLaneMap& m, int W, int H, int lane, int u, int& len) {
+  const int rg = lane / m.lanesPerRow, cb = lane - rg * m.lanesPerRow;
+  const int row = rg * m.bandH + u, col = cb * m.run;
+  const int rowEnd = (rg + 1) * m.bandH < H ? (rg + 1) * m.bandH : H;
+  len = (rg < m.rowGroups && row < rowEnd) ? (col + m.run <= W ? m.run : W - col) : 0;
+  return row * W + col;
 }
 
-// Work list: one record per entry.
+// Work list: one record per directed pair.
 struct DenseWalkList {
   const int* pair;          // directed pair of the record
-  const long long* range;   // 2 per record: pixel slots [begin, end) (within the pair)
   int count;
+  DenseLaneMap map;
 };
 
 // ndc of both end points of a dense-mode constraint from its flow vector, WITHOUT the depth fetch (k_dense_gg: taps only).  The same
@@ -95,11 +118,18 @@ __device__ __forceinline__ void dwGather(const Layout& L, float lx, float ly, Dw
   t.i0 = ix + iy * L.gx;
 }
 
-__device__ __forceinline__ void dwChain(const Layout& L, const FrameConst& Fs, const FrameConst& Ft, const double* __restrict__ xs,
+// Constants of the directed pair, wave-uniform (SGPRs: a VALU instruction takes one scalar operand).
+struct DwPairConst {
+  double Rs[9], Rt[9];
+  double dT[3];            // t_s - t_t
+  double fxs, fys, ifys;   // source focal lengths
+  double ifxt, ifyt;       // 1 / target focal lengths
+};
+
+__device__ __forceinline__ void dwChain(const Layout& L, const DwPairConst& P, const double* __restrict__ xs,
                                         const double* __restrict__ xt, const float4& nd, double da, double db, const DwTaps& ts,
                                         const DwTaps& tt, DwState& o) {
   constexpr double eps = 1e-6;
-  const double A = L.aspect;
   const int gx = L.gx;
   // (the same tap order and summation order as fastGather / the other fast kernels)
   double Da = 0.0, Db = 0.0;
@@ -109,25 +139,22 @@ __device__ __forceinline__ void dwChain(const Layout& L, const FrameConst& Fs, c
     Db += db * xt[7 + tt.i0 + (k & 1) + (k >> 1) * gx] * tt.Wt(k);
   }
   o.Da = Da;
-  const double fys = Fs.fy, fxs = Fs.fy * A;
-  const double fyt = Ft.fy;
-  const double ifyt = 1.0 / fyt, ifxt = 1.0 / (fyt * A);
   const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
   const double pbx = static_cast<double>(nd.z), pby = static_cast<double>(nd.w);
-  const double ca[3] = {pax * fxs, pay * fys, -1.0};
+  const double ca[3] = {pax * P.fxs, pay * P.fys, -1.0};
   double v[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    o.Rca[i] = dot3(Fs.R + 3 * i, ca);
-    v[i] = Fs.t[i] + o.Rca[i] * Da - Ft.t[i];
+    o.Rca[i] = dot3(P.Rs + 3 * i, ca);
+    v[i] = P.dT[i] + o.Rca[i] * Da;
   }
-  const double q0 = Ft.R[0] * v[0] + Ft.R[3] * v[1] + Ft.R[6] * v[2];
-  const double q1 = Ft.R[1] * v[0] + Ft.R[4] * v[1] + Ft.R[7] * v[2];
-  const double q2 = Ft.R[2] * v[0] + Ft.R[5] * v[1] + Ft.R[8] * v[2];
+  const double q0 = P.Rt[0] * v[0] + P.Rt[3] * v[1] + P.Rt[6] * v[2];
+  const double q1 = P.Rt[1] * v[0] + P.Rt[4] * v[1] + P.Rt[7] * v[2];
+  const double q2 = P.Rt[2] * v[0] + P.Rt[5] * v[1] + P.Rt[8] * v[2];
   const double zz = -q2;
   const double iz = 1.0 / zz;
-  const double u = q0 * iz * ifxt;
-  const double vv = q1 * iz * ifyt;
+  const double u = q0 * iz * P.ifxt;
+  const double vv = q1 * iz * P.ifyt;
   o.zz = zz;
   o.r[0] = (u - pbx) * L.ws;
   o.r[1] = (vv - pby) * L.ws;
@@ -155,42 +182,53 @@ __device__ __forceinline__ void dwChain(const Layout& L, const FrameConst& Fs, c
   }
   robustRho(L, o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2], o.rho0, o.w);
   const double wiz = L.ws * iz;
-  o.m00 = wiz * ifxt;
-  o.m11 = wiz * ifyt;
+  o.m00 = wiz * P.ifxt;
+  o.m11 = wiz * P.ifyt;
   o.m02 = wiz * u;
   o.m12 = wiz * vv;
   o.m22 = -dr2dA;
   o.JDT2 = dr2dDb;
 }
 
-// The 15 columns [Jp_s (7) | Jp_t (7) | r] contracted with a vector mu over the components of q (g = R_t mu over those of X): with
-// mu = row r of M this is row r of the Jacobian (c13, c14 = its focal-of-target entry and its residual); with
-// mu = sum_r rho' (d r_r / d D_s) M_r it is the pose x theta_s column block, with mu = rho' (d r_2 / d D_t) M_2 the pose x theta_t
-// one -- the columns are LINEAR in mu, so the side blocks need no accumulators beside the staging of the rows for the matrix pipe.
-// jds = g . R_s c, the same contraction of d r / d D_s.
-__device__ __forceinline__ void dwColumns(const DwState& c, const FrameConst& Fs, const FrameConst& Ft, double mu0, double mu1,
-                                          double mu2, double c13, double c14, double (&J)[15], double& jds) {
-  double g[3], y[3], v[3];
+// The Jacobian row that d r / d q = mu stands for, in FEATURE form.  With g = R_t mu, y = D_s R_s c, n = y x g, v = dT + y the 15
+// columns [Jp_s (7) | Jp_t (7) | r] are
+//   J[0..2] = g, J[3 + i] = a_s,i . n, J[6] = (g . y + D_s g . R_s e_z) / fy_s, J[7..9] = -g,
+//   J[10 + i] = a_t,i . (g x v) = (dT x a_t,i) . g - a_t,i . n, J[13] = d r / d fy_t, J[14] = r:
+// linear, with coefficients that are constants of the frame pair, in the NINE features  g (3) | n (3) | J[6] | J[13] | J[14].
+// The matrix pipe accumulates the Gram matrix of the features; the workgroup maps it to the 15 columns once, at the end
+// (dwFeatureMap) -- 9 staged values per row instead of 15, and the rotation Jacobians a_i never enter the pixel loop.
+constexpr int kDwFeat = 9;
+__device__ __forceinline__ void dwFeatures(const DwState& c, const DwPairConst& P, const double (&y)[3], double mu0, double mu1,
+                                           double mu2, double j13, double rr, double (&F)[kDwFeat], double& jds) {
+  double g[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    g[i] = Ft.R[3 * i] * mu0 + Ft.R[3 * i + 1] * mu1 + Ft.R[3 * i + 2] * mu2;
-    y[i] = c.Rca[i] * c.Da;
-    v[i] = (Fs.t[i] + y[i]) - Ft.t[i];
-  }
-  const double n0 = y[1] * g[2] - y[2] * g[1], n1 = y[2] * g[0] - y[0] * g[2], n2 = y[0] * g[1] - y[1] * g[0];   // y x g
-  const double m0 = g[1] * v[2] - g[2] * v[1], m1 = g[2] * v[0] - g[0] * v[2], m2 = g[0] * v[1] - g[1] * v[0];   // g x v
-  J[0] = g[0]; J[1] = g[1]; J[2] = g[2];
-  J[7] = -g[0]; J[8] = -g[1]; J[9] = -g[2];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    J[3 + i] = Fs.Jl[3 * i] * n0 + Fs.Jl[3 * i + 1] * n1 + Fs.Jl[3 * i + 2] * n2;
-    J[10 + i] = Ft.Jl[3 * i] * m0 + Ft.Jl[3 * i + 1] * m1 + Ft.Jl[3 * i + 2] * m2;
-  }
+  for (int i = 0; i < 3; ++i) g[i] = P.Rt[3 * i] * mu0 + P.Rt[3 * i + 1] * mu1 + P.Rt[3 * i + 2] * mu2;
+  F[0] = g[0]; F[1] = g[1]; F[2] = g[2];
+  F[3] = y[1] * g[2] - y[2] * g[1];
+  F[4] = y[2] * g[0] - y[0] * g[2];
+  F[5] = y[0] * g[1] - y[1] * g[0];
   jds = dot3(g, c.Rca);
-  // d X / d fy_s = D_s R_s (p_x A, p_y, 0) = D_s (R_s c + R_s e_z) / fy_s
-  J[6] = (c.Da / Fs.fy) * (jds + g[0] * Fs.R[2] + g[1] * Fs.R[5] + g[2] * Fs.R[8]);
-  J[13] = c13;
-  J[14] = c14;
+  F[6] = (c.Da * P.ifys) * (jds + g[0] * P.Rs[2] + g[1] * P.Rs[5] + g[2] * P.Rs[8]);
+  F[7] = j13;
+  F[8] = rr;
+}
+// column n of the 15 as a combination of the 9 features: coefficient of feature a
+__device__ __forceinline__ double dwFeatureMap(const FrameConst& Fs, const FrameConst& Ft, const double (&dT)[3], int a, int n) {
+  if (n < 3) return a == n ? 1.0 : 0.0;
+  if (n < 6) return (a >= 3 && a < 6) ? Fs.Jl[3 * (n - 3) + (a - 3)] : 0.0;
+  if (n == 6) return a == 6 ? 1.0 : 0.0;
+  if (n < 10) return a == n - 7 ? -1.0 : 0.0;
+  if (n < 13) {
+    const double* at = Ft.Jl + 3 * (n - 10);
+    if (a < 3) {  // (dT x a_t)[a]
+      const int i1 = (a + 1) % 3, i2 = (a + 2) % 3;
+      return dT[i1] * at[i2] - dT[i2] * at[i1];
+    }
+    return a < 6 ? -at[a - 3] : 0.0;
+  }
+  if (n == 13) return a == 7 ? 1.0 : 0.0;
+  if (n == 14) return a == 8 ? 1.0 : 0.0;
+  return 0.0;
 }
 
 #ifdef CVD_DW_PROFILE
@@ -200,96 +238,223 @@ __device__ unsigned long long g_dwProf[4096 * 8];
 #define DW_STAMP(slot) do {} while (0)
 #endif
 
+// LDS accumulators of k_dense_walk (doubles): the Gram tile, then MOMENT blocks instead of the 15-column side blocks.  The columns
+// [Jp_s | Jp_t | r] contracted with a vector mu are linear in a few per-pixel FEATURES with coefficients that are constants of the
+// frame pair (dwColumns spelled out):
+//   g = R_t mu, y = D_s R_s c, n = y x g:   J[0..2] = g, J[3 + i] = a_s,i . n, J[6] = (g . y + D_s g . R_s e_z) / fy_s, J[7..9] = -g,
+//                                           J[10 + i] = a_t,i . (g x v) = g . (dT x a_t,i) - a_t,i . n   (v = dT + y), J[13], J[14]
+//   side S (mu = sum_r rho' (d r_r / d D_s) M_r, any direction):  the 9 features of dwFeatures
+//   side T (mu = rho' (d r_2 / d D_t) m22 e_z, i.e. g = s rho with rho = R_t e_z a constant of the pair):
+//                                                                  6 features   s | s y (3) | s D_s | gradient
+// so a pixel sends 6 x 4 atomics to its target vertices instead of 14 x 4, and the source side -- whose cell and vertical tap
+// weights are the same along a lane's run of pixels of one image row -- accumulates 2 x 9 feature sums in REGISTERS and flushes
+// them once per run (36 atomics per run instead of 60 per pixel).  The workgroup expands the moments into the record's side blocks
+// when it writes the record.
+constexpr int kDwFeatS = kDwFeat, kDwFeatT = 6;
+__host__ __device__ inline int dwAccDoubles(int G) { return 256 + (kDwFeatS + kDwFeatT + 10) * G + 8; }
+__host__ __device__ inline size_t dwLdsBytes(int G, int B, int threads) {
+  return (static_cast<size_t>(dwAccDoubles(G)) + 2 * B + static_cast<size_t>(threads / 64) * 64 * kDwLd) * 8;
+}
+
+#ifndef DW_WAVES
+#define DW_WAVES 2
+#endif
 template <int KD>
-inline __global__ __launch_bounds__(kDwThreads) void k_dense_walk(Layout L, Table T, DenseWalkList wl, const double* __restrict__ x,
+inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_eu(DW_WAVES))) void k_dense_walk(Layout L, Table T, DenseWalkList wl, const double* __restrict__ x,
                                                            const FrameConst* __restrict__ fc, double* __restrict__ records,
                                                            double* __restrict__ ggOut) {
   static_assert(KD == 4, "bilinear depth grids (the explicit-block scope of the dense mode)");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B, G = L.nD, gx = L.gx;
-  const int recN = dwRecordDoubles(G);
+  const int accN = dwAccDoubles(G);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = kDwThreads / 64;
-  double* acc = sm;
-  double* xs = acc + recN;
+  double* acc = sm;                       // [0, 256) Gram tile
+  double* MS = acc + 256;                 // [12][G] source-side moments
+  double* MT = MS + kDwFeatS * G;         // [6][G]  target-side moments
+  double* bandS = MT + kDwFeatT * G;      // [5][G]
+  double* bandT = bandS + 5 * G;          // [5][G], then the cost
+  double* xs = acc + accN;
   double* xt = xs + B;
-  FrameConst* fcs = reinterpret_cast<FrameConst*>(xt + B);
-  double* scr = reinterpret_cast<double*>(fcs + 2) + wave * (64 * kDwLd);
-  double* sideS = acc + 256;
-  double* sideT = sideS + kDwCols * G;
-  double* bandS = acc + 256 + 30 * G;
-  double* bandT = bandS + 5 * G;
+  double* scr = xt + B + wave * (64 * kDwLd);
   const int rec = blockIdx.x;
   const int p = wl.pair[rec];
   const int fs = T.pairA[p], ft = T.pairB[p];
   DW_STAMP(0);
-  for (int i = tid; i < recN; i += kDwThreads) acc[i] = 0.0;
+  for (int i = tid; i < accN; i += kDwThreads) acc[i] = 0.0;
   for (int i = tid; i < B; i += kDwThreads) {
     xs[i] = x[static_cast<size_t>(fs) * B + i];
     xt[i] = x[static_cast<size_t>(ft) * B + i];
   }
-  constexpr int FCW = sizeof(FrameConst) / 8;
-  for (int i = tid; i < 2 * FCW; i += kDwThreads)
-    reinterpret_cast<double*>(fcs)[i] = reinterpret_cast<const double*>(fc + (i < FCW ? fs : ft))[i % FCW];
-  scr[lane * kDwLd + 15] = 0.0;   // (the 16th column of the staging tile: never written again)
+#pragma unroll
+  for (int c = kDwFeat; c < 16; ++c) scr[lane * kDwLd + c] = 0.0;   // (the unused columns of the staging tile: never written again)
   __syncthreads();
   DW_STAMP(1);
   // (wave-uniform read-only global data at an address that depends on blockIdx only: scalar loads, as in the hot product)
   const FrameConst& Fs = fc[fs];
   const FrameConst& Ft = fc[ft];
+  DwPairConst P;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { P.Rs[i] = uniformValue(Fs.R[i]); P.Rt[i] = uniformValue(Ft.R[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) P.dT[i] = uniformValue(Fs.t[i] - Ft.t[i]);
+  P.fys = uniformValue(Fs.fy);
+  P.fxs = uniformValue(Fs.fy * L.aspect);
+  P.ifys = uniformValue(1.0 / Fs.fy);
+  P.ifyt = uniformValue(1.0 / Ft.fy);
+  P.ifxt = uniformValue(1.0 / (Ft.fy * L.aspect));
   const long long pixBase = T.pairOff[p];
-  const long long cb = pixBase + wl.range[rec * 2], ce = pixBase + wl.range[rec * 2 + 1];
+  const bool havePixels = T.pairOff[p + 1] > pixBase;
 
-  cvd_d4 tile0 = {0.0, 0.0, 0.0, 0.0}, tile1 = {0.0, 0.0, 0.0, 0.0};
+  cvd_d4 tile0 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   const int mk = lane >> 4, mc = lane & 15;  // MFMA operand element [k = lane >> 4][column = lane & 15]
-  constexpr long long kUnit = 64LL * kDwRun;
-  for (long long u0 = cb + wave * kUnit; u0 < ce; u0 += NW * kUnit) {
-    const long long cFirst = u0 + static_cast<long long>(lane) * kDwRun;
-    const int iFirst = lane * kDwRun;
-    const long long rem = ce - u0;
-    const int iStop = static_cast<int>(rem < (iFirst + kDwRun) ? (rem < iFirst ? iFirst : rem) : (iFirst + kDwRun));
+  const DenseLaneMap map = wl.map;
+  for (int u = wave; u < (havePixels ? map.bandH : 0); u += NW) {
+    int len;
+    const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
+    const int iStop = iFirst + len;
+    const long long cFirst = pixBase + iFirst;
+    const int iy = iFirst / T.W, ix0 = iFirst - iy * T.W;
     RecordStream<true> rs;
-    rs.prime(T, u0, iFirst, iStop);
-    for (int t = 0; t < kDwRun; ++t) {
+    rs.prime(T, pixBase, iFirst, iStop);
+    // source-side sums of the lane's run (one image row: one cell row, one pair of vertical tap weights)
+    double AS[2][kDwFeatS], BS[3];
+#pragma unroll
+    for (int f = 0; f < kDwFeatS; ++f) { AS[0][f] = 0.0; AS[1][f] = 0.0; }
+    BS[0] = BS[1] = BS[2] = 0.0;
+    int curI0 = -1;
+    double curRy = 0.0;
+    // (one trip past the run: the flush of the last cell's sums has ONE copy, at the top of the trip)
+#pragma unroll 1
+    for (int t = 0; t <= map.run; ++t) {
       const int i = iFirst + t;
+      const bool inRun = i < iStop;
+      // the source end point's cell follows from the pixel alone (the float arithmetic of denseConstraintFromFlow)
+      DwTaps ts;
+      ts.i0 = -2; ts.rx = 0.0; ts.ry = 0.0;
+      if (inRun) {
+        const float lx0 = __fmul_rn(static_cast<float>(ix0 + t), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
+        dwGather(L, __fadd_rn(-1.f, __fmul_rn(2.f, lx0)), __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect)), ts);
+      }
+      if (curI0 >= 0 && ts.i0 != curI0) {
+        // ---- flush the sums of the cell the lane has left: 4 taps x 12 features, 10 vertex pairs
+        const double wy0 = 1.0 - curRy, wy1 = curRy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double* col = MS + curI0 + (k & 1) + (k >> 1) * gx;
+          const double wy = (k >> 1) ? wy1 : wy0;
+#pragma unroll
+          for (int f = 0; f < kDwFeatS; ++f) atomicAdd(&col[f * G], AS[k & 1][f] * wy);
+        }
+        // vertex pairs of the cell, lower vertex first: offsets {0, 1, gx - 1, gx, gx + 1} -> band index {0, 1, 2, 3, 4}
+        const double y00 = wy0 * wy0, y01 = wy0 * wy1, y11 = wy1 * wy1;
+        atomicAdd(&bandS[0 * G + curI0], BS[0] * y00);
+        atomicAdd(&bandS[1 * G + curI0], BS[1] * y00);
+        atomicAdd(&bandS[3 * G + curI0], BS[0] * y01);
+        atomicAdd(&bandS[4 * G + curI0], BS[1] * y01);
+        atomicAdd(&bandS[0 * G + curI0 + 1], BS[2] * y00);
+        atomicAdd(&bandS[2 * G + curI0 + 1], BS[1] * y01);
+        atomicAdd(&bandS[3 * G + curI0 + 1], BS[2] * y01);
+        atomicAdd(&bandS[0 * G + curI0 + gx], BS[0] * y11);
+        atomicAdd(&bandS[1 * G + curI0 + gx], BS[1] * y11);
+        atomicAdd(&bandS[0 * G + curI0 + gx + 1], BS[2] * y11);
+#pragma unroll
+        for (int f = 0; f < kDwFeatS; ++f) { AS[0][f] = 0.0; AS[1][f] = 0.0; }
+        BS[0] = BS[1] = BS[2] = 0.0;
+        curI0 = -1;
+      }
       float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
       float2 d = make_float2(0.f, 0.f);
       bool valid = false;
-      if (i < iStop) valid = rs.take(T, u0, i, 1, iStop, pixBase, fs, ft, nd, d);
+      if (inRun) valid = rs.take(T, pixBase, i, 1, iStop, pixBase, fs, ft, nd, d);
       if (__builtin_amdgcn_readfirstlane(__ballot(valid) == 0ull ? 1 : 0)) {
-        if (i < iStop) ggOut[cFirst + t] = 0.0;
+        if (inRun) ggOut[cFirst + t] = 0.0;
         continue;  // (wave-uniform)
       }
       DwState ch;
-      DwTaps ts, tt;
-      const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
-      double sw = 0.0;
+      double sw = 0.0, zf = 0.0;
+      double y[3] = {0.0, 0.0, 0.0};
       if (valid) {
-        dwGather(L, nd.x, nd.y, ts);
+        DwTaps tt;
+        const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
         dwGather(L, nd.z, nd.w, tt);
-        dwChain(L, Fs, Ft, xs, xt, nd, da, db, ts, tt, ch);
+        dwChain(L, P, xs, xt, nd, da, db, ts, tt, ch);
         sw = sqrt(ch.w);
         cost += ch.rho0;
-      }
-      // d r_0,1 / d fy_t = -ws (u, v) / fy_t = -(m02, m12) z' / fy_t
-      const double zf = valid ? -ch.zz / Ft.fy : 0.0;
-      // ---- the three residual rows sqrt(rho') [Jp_s | Jp_t | r] through the wave's staging tile into the Gram tile
-      double wj[3] = {0.0, 0.0, 0.0};  // rho' d r_r / d D_s
+        zf = -ch.zz * P.ifyt;   // d r_0,1 / d fy_t = -ws (u, v) / fy_t = -(m02, m12) z' / fy_t
 #pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2) y[i2] = ch.Rca[i2] * ch.Da;
+        // rho' d r_r / d D_s = rho' M_r . (R_t^T R_s c)
+        const double k0 = P.Rt[0] * ch.Rca[0] + P.Rt[3] * ch.Rca[1] + P.Rt[6] * ch.Rca[2];
+        const double k1 = P.Rt[1] * ch.Rca[0] + P.Rt[4] * ch.Rca[1] + P.Rt[7] * ch.Rca[2];
+        const double k2 = P.Rt[2] * ch.Rca[0] + P.Rt[5] * ch.Rca[1] + P.Rt[8] * ch.Rca[2];
+        const double wj0 = ch.w * (ch.m00 * k0 + ch.m02 * k2), wj1 = ch.w * (ch.m11 * k1 + ch.m12 * k2), wj2 = ch.w * ch.m22 * k2;
+        const double wt = ch.w * ch.JDT2;   // rho' d r_2 / d D_t
+        ggOut[cFirst + t] = wj2 * ch.JDT2 * da * db;
+        {  // ---- source side: features of mu = sum_r wj_r M_r into the run's sums
+          const double mu0 = wj0 * ch.m00, mu1 = wj1 * ch.m11, mu2 = wj0 * ch.m02 + wj1 * ch.m12 + wj2 * ch.m22;
+          double ft12[kDwFeatS], sSS;   // sSS = sum_r rho' (d r_r / d D_s)^2
+          dwFeatures(ch, P, y, mu0, mu1, mu2, (wj0 * ch.m02 + wj1 * ch.m12) * zf, wj0 * ch.r[0] + wj1 * ch.r[1] + wj2 * ch.r[2], ft12, sSS);
+          curI0 = ts.i0;
+          curRy = ts.ry;
+          const double fa0 = da * (1.0 - ts.rx), fa1 = da * ts.rx;
+#pragma unroll
+          for (int f = 0; f < kDwFeatS; ++f) {
+            AS[0][f] += ft12[f] * fa0;
+            AS[1][f] += ft12[f] * fa1;
+          }
+          BS[0] += sSS * fa0 * fa0;
+          BS[1] += sSS * fa0 * fa1;
+          BS[2] += sSS * fa1 * fa1;
+        }
+        {  // ---- target side: d r / d D_t has the one row 2, g = s R_t e_z
+          const double s = wt * ch.m22;
+          const double mt[kDwFeatT] = {s, s * y[0], s * y[1], s * y[2], s * ch.Da, wt * ch.r[2]};
+          double fb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) fb[k] = tt.Wt(k) * db;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double* col = MT + tt.i0 + (k & 1) + (k >> 1) * gx;
+#pragma unroll
+            for (int f = 0; f < kDwFeatT; ++f) atomicAdd(&col[f * G], mt[f] * fb[k]);
+          }
+          const double sTT = wt * ch.JDT2;
+          const int j0 = tt.i0;
+          const double b0 = sTT * fb[0], b1 = sTT * fb[1], b2 = sTT * fb[2], b3 = sTT * fb[3];
+          atomicAdd(&bandT[0 * G + j0], b0 * fb[0]);
+          atomicAdd(&bandT[1 * G + j0], b0 * fb[1]);
+          atomicAdd(&bandT[3 * G + j0], b0 * fb[2]);
+          atomicAdd(&bandT[4 * G + j0], b0 * fb[3]);
+          atomicAdd(&bandT[0 * G + j0 + 1], b1 * fb[1]);
+          atomicAdd(&bandT[2 * G + j0 + 1], b1 * fb[2]);
+          atomicAdd(&bandT[3 * G + j0 + 1], b1 * fb[3]);
+          atomicAdd(&bandT[0 * G + j0 + gx], b2 * fb[2]);
+          atomicAdd(&bandT[1 * G + j0 + gx], b2 * fb[3]);
+          atomicAdd(&bandT[0 * G + j0 + gx + 1], b3 * fb[3]);
+        }
+      } else if (inRun) {
+        ggOut[cFirst + t] = 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- the three residual rows sqrt(rho') x features through the wave's staging tile into the Gram tile.  A REAL loop: unrolled,
+      // the three rows' features are all formed before the first one is staged (their arithmetic moves freely across the fences).
+#pragma unroll 1
       for (int r = 0; r < 3; ++r) {
         if (valid) {
-          double J[15], jds;
-          if (r == 0) dwColumns(ch, Fs, Ft, ch.m00, 0.0, ch.m02, ch.m02 * zf, ch.r[0], J, jds);
-          else if (r == 1) dwColumns(ch, Fs, Ft, 0.0, ch.m11, ch.m12, ch.m12 * zf, ch.r[1], J, jds);
-          else dwColumns(ch, Fs, Ft, 0.0, 0.0, ch.m22, 0.0, ch.r[2], J, jds);
+          const double mu0 = r == 0 ? ch.m00 : 0.0, mu1 = r == 1 ? ch.m11 : 0.0;
+          const double mu2 = r == 0 ? ch.m02 : (r == 1 ? ch.m12 : ch.m22);
+          const double j13 = r == 2 ? 0.0 : mu2 * zf;
+          const double rr = r == 0 ? ch.r[0] : (r == 1 ? ch.r[1] : ch.r[2]);
+          double F[kDwFeat], jds;
+          dwFeatures(ch, P, y, mu0, mu1, mu2, j13, rr, F, jds);
 #pragma unroll
-          for (int c = 0; c < 15; ++c) scr[lane * kDwLd + c] = sw * J[c];
-          wj[r] = ch.w * jds;
+          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLd + c] = sw * F[c];
         } else {
 #pragma unroll
-          for (int c = 0; c < 15; ++c) scr[lane * kDwLd + c] = 0.0;
+          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLd + c] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -299,84 +464,73 @@ inline __global__ __launch_bounds__(kDwThreads) void k_dense_walk(Layout L, Tabl
           const double a0 = scr[(4 * j + mk) * kDwLd + mc];
           const double a1 = scr[(4 * j + 4 + mk) * kDwLd + mc];
           tile0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, tile0, 0, 0, 0);
-          tile1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, tile1, 0, 0, 0);
+          tile0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, tile0, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (valid) {
-        const double wt = ch.w * ch.JDT2;   // rho' d r_2 / d D_t
-        ggOut[cFirst + t] = wj[2] * ch.JDT2 * da * db;
-        double fa[4], fb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { fa[k] = ts.Wt(k) * da; fb[k] = tt.Wt(k) * db; }
-        double sSS;
-        {  // theta_s x {pose_s, pose_t, gradient}: mu = sum_r wj_r M_r
-          double vS[15], jds;
-          dwColumns(ch, Fs, Ft, wj[0] * ch.m00, wj[1] * ch.m11, wj[0] * ch.m02 + wj[1] * ch.m12 + wj[2] * ch.m22,
-                    (wj[0] * ch.m02 + wj[1] * ch.m12) * zf, wj[0] * ch.r[0] + wj[1] * ch.r[1] + wj[2] * ch.r[2], vS, jds);
-          sSS = jds;   // sum_r rho' (d r_r / d D_s)^2
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            double* col = sideS + ts.i0 + (k & 1) + (k >> 1) * gx;
-#pragma unroll
-            for (int c = 0; c < 15; ++c) atomicAdd(&col[c * G], vS[c] * fa[k]);
-            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise forms all products before the first atomic)
-          }
-        }
-        {  // theta_t x {pose_s, pose_t, gradient}: d r / d D_t has the one row 2
-          double vT[15], jds;
-          dwColumns(ch, Fs, Ft, 0.0, 0.0, wt * ch.m22, 0.0, wt * ch.r[2], vT, jds);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            double* col = sideT + tt.i0 + (k & 1) + (k >> 1) * gx;
-#pragma unroll
-            for (int c = 0; c < 15; ++c)
-              if (c != 13) atomicAdd(&col[c * G], vT[c] * fb[k]);  // (d r_2 / d fy_t = 0)
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // vertex pairs of the cell, lower vertex first: offsets {0, 1, gx - 1, gx, gx + 1} -> band index {0, 1, 2, 3, 4}
-        const double sTT = wt * ch.JDT2;
-        const int i0 = ts.i0, j0 = tt.i0;
-        const double a0 = sSS * fa[0], a1 = sSS * fa[1], a2 = sSS * fa[2], a3 = sSS * fa[3];
-        atomicAdd(&bandS[0 * G + i0], a0 * fa[0]);
-        atomicAdd(&bandS[1 * G + i0], a0 * fa[1]);
-        atomicAdd(&bandS[3 * G + i0], a0 * fa[2]);
-        atomicAdd(&bandS[4 * G + i0], a0 * fa[3]);
-        atomicAdd(&bandS[0 * G + i0 + 1], a1 * fa[1]);
-        atomicAdd(&bandS[2 * G + i0 + 1], a1 * fa[2]);
-        atomicAdd(&bandS[3 * G + i0 + 1], a1 * fa[3]);
-        atomicAdd(&bandS[0 * G + i0 + gx], a2 * fa[2]);
-        atomicAdd(&bandS[1 * G + i0 + gx], a2 * fa[3]);
-        atomicAdd(&bandS[0 * G + i0 + gx + 1], a3 * fa[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        const double b0 = sTT * fb[0], b1 = sTT * fb[1], b2 = sTT * fb[2], b3 = sTT * fb[3];
-        atomicAdd(&bandT[0 * G + j0], b0 * fb[0]);
-        atomicAdd(&bandT[1 * G + j0], b0 * fb[1]);
-        atomicAdd(&bandT[3 * G + j0], b0 * fb[2]);
-        atomicAdd(&bandT[4 * G + j0], b0 * fb[3]);
-        atomicAdd(&bandT[0 * G + j0 + 1], b1 * fb[1]);
-        atomicAdd(&bandT[2 * G + j0 + 1], b1 * fb[2]);
-        atomicAdd(&bandT[3 * G + j0 + 1], b1 * fb[3]);
-        atomicAdd(&bandT[0 * G + j0 + gx], b2 * fb[2]);
-        atomicAdd(&bandT[1 * G + j0 + gx], b2 * fb[3]);
-        atomicAdd(&bandT[0 * G + j0 + gx + 1], b3 * fb[3]);
-      } else if (i < iStop) {
-        ggOut[cFirst + t] = 0.0;
-      }
     }
   }
   DW_STAMP(2);
-  // ---- the waves' Gram tiles and cost into the record (D: column = lane & 15, row = (lane >> 4) + 4 reg)
+  // ---- the waves' Gram tiles and cost (D: column = lane & 15, row = (lane >> 4) + 4 reg)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) atomicAdd(&acc[((lane >> 4) + 4 * q) * 16 + (lane & 15)], tile0[q] + tile1[q]);
+  for (int q = 0; q < 4; ++q) atomicAdd(&acc[((lane >> 4) + 4 * q) * 16 + (lane & 15)], tile0[q]);
   cost = waveSum(cost);
-  if (lane == 0) atomicAdd(&acc[256 + 40 * G], cost);
+  if (lane == 0) atomicAdd(&bandT[5 * G], cost);
   __syncthreads();
+  // ---- the record: tile, the side blocks expanded from the moments with the pair's constants, bands, cost
+  const int recN = dwRecordDoubles(G);
   double* out = records + static_cast<size_t>(rec) * recN;
-  for (int i = tid; i < recN; i += kDwThreads) out[i] = acc[i];
+  const double rho[3] = {Ft.R[2], Ft.R[5], Ft.R[8]};          // R_t e_z
+  const double rs2[3] = {Fs.R[2], Fs.R[5], Fs.R[8]};          // R_s e_z
+  const double dT[3] = {Fs.t[0] - Ft.t[0], Fs.t[1] - Ft.t[1], Fs.t[2] - Ft.t[2]};
+  const double ifys = 1.0 / Fs.fy;
+  for (int i = tid; i < 256; i += kDwThreads) {
+    // D[m][n] = sum_ab C[a][m] Gram9[a][b] C[b][n]
+    const int m = i >> 4, n = i & 15;
+    double v = 0.0;
+    if (m < 15 && n < 15) {
+      for (int a = 0; a < kDwFeat; ++a) {
+        const double cm = dwFeatureMap(Fs, Ft, dT, a, m);
+        if (cm == 0.0) continue;
+        double row = 0.0;
+        for (int b = 0; b < kDwFeat; ++b) row += acc[a * 16 + b] * dwFeatureMap(Fs, Ft, dT, b, n);
+        v += cm * row;
+      }
+    }
+    out[i] = v;
+  }
+  for (int i = tid; i < 10 * G; i += kDwThreads) out[256 + 30 * G + i] = bandS[i];
+  if (tid == 0) out[256 + 40 * G] = bandT[5 * G];
+  for (int idx = tid; idx < 2 * kDwCols * G; idx += kDwThreads) {
+    const int side = idx >= kDwCols * G ? 1 : 0;
+    const int e = idx - side * kDwCols * G;
+    const int c = e / G, v = e - c * G;
+    double val;
+    if (side == 0) {
+      const double* m = MS + v;   // m[f * G]
+      val = 0.0;
+      for (int a = 0; a < kDwFeat; ++a) val += dwFeatureMap(Fs, Ft, dT, a, c) * m[a * G];
+    } else {
+      const double* m = MT + v;
+      if (c < 3) val = rho[c] * m[0];
+      else if (c < 6) {
+        const double* a = Fs.Jl + 3 * (c - 3);
+        const double b0 = rho[1] * a[2] - rho[2] * a[1], b1 = rho[2] * a[0] - rho[0] * a[2], b2 = rho[0] * a[1] - rho[1] * a[0];  // rho x a
+        val = b0 * m[G] + b1 * m[2 * G] + b2 * m[3 * G];
+      } else if (c == 6) val = (rho[0] * m[G] + rho[1] * m[2 * G] + rho[2] * m[3 * G] + dot3(rho, rs2) * m[4 * G]) * ifys;
+      else if (c < 10) val = -rho[c - 7] * m[0];
+      else if (c < 13) {
+        const double* a = Ft.Jl + 3 * (c - 10);
+        const double b0 = a[1] * rho[2] - a[2] * rho[1], b1 = a[2] * rho[0] - a[0] * rho[2], b2 = a[0] * rho[1] - a[1] * rho[0];  // a x rho
+        const double q0 = rho[1] * dT[2] - rho[2] * dT[1], q1 = rho[2] * dT[0] - rho[0] * dT[2], q2 = rho[0] * dT[1] - rho[1] * dT[0];  // rho x dT
+        val = (a[0] * q0 + a[1] * q1 + a[2] * q2) * m[0] + b0 * m[G] + b1 * m[2 * G] + b2 * m[3 * G];
+      } else if (c == 13) val = 0.0;
+      else val = m[5 * G];
+    }
+    out[256 + idx] = val;
+  }
   DW_STAMP(3);
 }
 
@@ -419,10 +573,11 @@ inline __global__ __launch_bounds__(256) void k_dense_fold_cross(Layout L, Cross
 // Grid x grid part of X_ab: sum over the pixels of both directions of gg fac-free tap products,
 //   X[7 + v_a][7 + v_b] += gg * w_a[k] * w_b[l]        (gg = rho' JD_s,2 JD_t,2 d_s d_t of k_dense_walk; 0 = no constraint)
 // One workgroup per (pair, panel of columns); lane = run of pixels as in the walk.
-constexpr int kGgThreads = CVD_DETERMINISTIC ? 64 : 512;
+constexpr int kGgThreads = CVD_DETERMINISTIC ? 64 : 1024;
 template <int KD>
 inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table T, CrossPairs cp, const int* __restrict__ xDir,
-                                                        const double* __restrict__ gg, int panelW, double* __restrict__ X) {
+                                                        const double* __restrict__ gg, int panelW, DenseLaneMap map,
+                                                        double* __restrict__ X) {
   static_assert(KD == 4, "bilinear depth grids");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B, G = L.nD;
@@ -436,16 +591,22 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
   for (int dir = 0; dir < 2; ++dir) {
     const int p = xDir[pair * 2 + dir];
     if (p < 0) continue;
-    const long long cb = T.pairOff[p], ce = T.pairOff[p + 1];
-    constexpr long long kUnit = 64LL * kDwRun;
-    for (long long u0 = cb + wave * kUnit; u0 < ce; u0 += NW * kUnit) {
-      const long long cFirst = u0 + static_cast<long long>(lane) * kDwRun;
-      const long long cStop = cFirst + kDwRun < ce ? cFirst + kDwRun : ce;
-      for (long long c = cFirst; c < cStop; ++c) {
-        const double g = gg[c];
+    const long long cb = T.pairOff[p];
+    if (T.pairOff[p + 1] <= cb) continue;
+    for (int u = wave; u < map.bandH; u += NW) {
+      int len;
+      const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
+      // (gg and flow of the lane's next pixel in flight)
+      double gNext = 0.0;
+      float2 fNext = make_float2(0.f, 0.f);
+      if (len > 0) { gNext = gg[cb + iFirst]; fNext = T.flow[cb + iFirst]; }
+      for (int t = 0; t < len; ++t) {
+        const double g = gNext;
+        const float2 f = fNext;
+        if (t + 1 < len) { gNext = gg[cb + iFirst + t + 1]; fNext = T.flow[cb + iFirst + t + 1]; }
         if (g == 0.0) continue;
         float4 nd;
-        if (!denseNdcFromFlow(T, static_cast<int>(c - cb), T.flow[c], nd)) continue;
+        if (!denseNdcFromFlow(T, iFirst + t, f, nd)) continue;
         FastTaps<KD> ts, tt;
         fastGather<KD>(L, nd.x, nd.y, ts);
         fastGather<KD>(L, nd.z, nd.w, tt);

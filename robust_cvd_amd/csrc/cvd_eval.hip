@@ -116,7 +116,7 @@ void launchDenseWalk(Ctx& c, const double* x) {
   h->dDwGg.ensure(static_cast<size_t>(std::max<long long>(1, h->C)));
   if (h->nDwRecords == 0) return;
   const size_t lds = dwLdsBytes(G, B, kDwThreads);
-  const DenseWalkList wl{h->dDwPair.p, h->dDwRange.p, h->nDwRecords};
+  const DenseWalkList wl{h->dDwPair.p, h->nDwRecords, denseLaneMap(h->W, h->H)};
   allowLds((k_dense_walk<4>), lds);
   hipLaunchKernelGGL((k_dense_walk<4>), dim3(h->nDwRecords), dim3(kDwThreads), lds, h->stream, c.L, c.T, wl, x, h->dFc.p,
                      h->dDwRecords.p, h->dDwGg.p);
@@ -140,7 +140,7 @@ void launchCrossAssemble(Ctx& c, const double* x) {
   const size_t ldsGrid = static_cast<size_t>(panelW) * G * 8;
   allowLds((k_dense_gg<4>), ldsGrid);
   hipLaunchKernelGGL((k_dense_gg<4>), dim3(nP, nPanels), dim3(kGgThreads), ldsGrid, h->stream, c.L, c.T, crossPairs(h), h->dXDir.p,
-                     h->dDwGg.p, panelW, h->dXBlocks.p);
+                     h->dDwGg.p, panelW, denseLaneMap(h->W, h->H), h->dXBlocks.p);
   HIP_CHECK(hipGetLastError());
 }
 

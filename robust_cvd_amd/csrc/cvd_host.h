@@ -258,7 +258,6 @@ struct cvd_handle_t {
   DevBuf<double> dXBlocks;
   // one-walk assembly of the dense mode (cvd_dense_walk.h): records of the directed pairs, per-pixel grid x grid scalars
   DevBuf<int> dDwPair, dDwRecOff, dXDir;
-  DevBuf<long long> dDwRange;
   DevBuf<double> dDwRecords, dDwGg;
   int nDwRecords = 0;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)

@@ -812,7 +812,6 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
     // one-walk assembly (cvd_dense_walk.h): one record per directed pair of the pair graph, and the two directions of every block
     {
       std::vector<int> dwPair, recOff(h->P + 1, 0), xDir;
-      std::vector<long long> dwRange;
       for (const auto& e : edges) {
         bool any = false;
         for (int dir = 0; dir < 2; ++dir) any = any || (e.second[dir] >= 0 && h->pairOff[e.second[dir] + 1] > h->pairOff[e.second[dir]]);
@@ -829,14 +828,12 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
         recOff[p] = static_cast<int>(dwPair.size());
         if (!inRange[a] || !inRange[b] || a == b || n <= 0) continue;
         dwPair.push_back(p);
-        dwRange.insert(dwRange.end(), {0ll, n});
       }
       recOff[h->P] = static_cast<int>(dwPair.size());
       h->nDwRecords = static_cast<int>(dwPair.size());
       if (xDir.empty()) xDir.push_back(-1);
-      if (dwPair.empty()) { dwPair.push_back(0); dwRange.insert(dwRange.end(), {0ll, 0ll}); }
+      if (dwPair.empty()) dwPair.push_back(0);
       h->dDwPair.upload(dwPair.data(), dwPair.size(), s);
-      h->dDwRange.upload(dwRange.data(), dwRange.size(), s);
       h->dDwRecOff.upload(recOff.data(), recOff.size(), s);
       h->dXDir.upload(xDir.data(), xDir.size(), s);
     }

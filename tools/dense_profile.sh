@@ -1,0 +1,20 @@
+#!/bin/bash
+# Dense-mode evidence on the GPU box: per-kernel durations (rocprofv3 --kernel-trace) and the SQ counters of the one-walk assembly.
+# usage (through gpurun): bash tools/dense_profile.sh <tag> [frames]
+TAG=${1:-dense}
+FR=${2:-300}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+exec < /dev/null
+cd /tmp && export TMPDIR=/tmp
+CMD="python bench.py --dense --frames $FR --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense -- python $R/bench.py --dense --frames $FR --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/trace_dense.log 2>&1
+python $R/tools/kernel_durations.py $OUT/trace_dense $TAG "$CMD" > $OUT/kernel_durations_dense.txt 2>&1
+rm -rf $OUT/trace_dense
+K="k_dense_walk|k_dense_gg|k_dense_fold_cross|k_assemble_fast"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_sq.log 2>&1
+python $R/tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_SQ_dense.csv > /dev/null 2>&1
+rm -rf $OUT/pmc_sq
+head -14 $OUT/kernel_durations_dense.txt | cut -c1-180
+cat $OUT/pmc_SQ_dense.csv

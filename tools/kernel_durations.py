@@ -16,6 +16,9 @@ for r in csv.DictReader(open(fn)):
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     d[name].append(dur)
     grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+    lds = r.get("LDS_Block_Size") or r.get("LDS_Block_Size_v") or ""
+    if lds and int(lds) > 65536:   # (the dense mode's walks launch one grid at every coarse-to-fine level: their LDS size tells the levels apart)
+        grid = f"{grid}/lds{lds}"
     bygrid[(name, grid)].append(dur)
 print(f"# per-kernel durations from rocprofv3 --kernel-trace of `{cmdline}`")
 print(f"# (the --stats averages in {tag}_bench_kernel_stats.csv include the early-exit PCG launches enqueued past convergence;")
@@ -30,4 +33,4 @@ for name, _ in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:5]:
     for (n2, grid), v in sorted(((k, v) for k, v in bygrid.items() if k[0] == name), key=lambda kv: -sum(kv[1]))[:4]:
         med = statistics.median(v)
         w = [x for x in v if x > med / 2]
-        print(f"{name:34s} grid {grid:>9s} launches {len(v):5d}  total {sum(v) / 1e3:8.3f} ms  median {med:8.1f} us  working mean {sum(w) / len(w):8.1f} us")
+        print(f"{name:34s} grid {grid:>18s} launches {len(v):5d}  total {sum(v) / 1e3:8.3f} ms  median {med:8.1f} us  working mean {sum(w) / len(w):8.1f} us")
