@@ -118,6 +118,32 @@ __device__ __forceinline__ void dwGather(const Layout& L, float lx, float ly, Dw
   t.i0 = ix + iy * L.gx;
 }
 
+// The walk's loads run two pixels ahead: mask byte and flow vector of pixel t + 2 are requested while the two depths of pixel
+// t + 1 -- whose target address follows from its flow vector -- are, and pixel t is worked on with everything in registers.
+// (RecordStream<true> keeps one pixel's mask and flow in flight and takes the depth round trip, an L2 / HBM latency, in every
+// trip: waves parked 32 % of their cycles at two waves per SIMD.)  A masked-out or out-of-bounds candidate is encoded as d.x = 0.
+__device__ __forceinline__ float2 denseDepthsAhead(const Table& T, int pix, bool ok, unsigned int m, float2 f, int fa, int fb) {
+  float2 d = make_float2(0.f, 0.f);
+  if (!ok || !m) return d;
+  const int iy = pix / T.W, ix = pix - iy * T.W;
+  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
+  if (!(isfinite(fx1) && isfinite(fy1))) return d;
+  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
+  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return d;
+  const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
+  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
+  int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
+  int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
+  int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
+  int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
+  ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
+  bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
+  const size_t fsz = static_cast<size_t>(T.W) * T.H;
+  d.x = T.depth[fa * fsz + static_cast<size_t>(ay) * T.W + ax];
+  d.y = T.depth[fb * fsz + static_cast<size_t>(by) * T.W + bx];
+  return d;
+}
+
 // Constants of the directed pair, wave-uniform (SGPRs: a VALU instruction takes one scalar operand).
 struct DwPairConst {
   double Rs[9], Rt[9];
@@ -317,8 +343,15 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
     const int iStop = iFirst + len;
     const long long cFirst = pixBase + iFirst;
     const int iy = iFirst / T.W, ix0 = iFirst - iy * T.W;
-    RecordStream<true> rs;
-    rs.prime(T, pixBase, iFirst, iStop);
+    // loads in flight: (mask, flow) of pixel t + 1, the depths of pixel t
+    unsigned int mNext = 0u;
+    float2 fCur = make_float2(0.f, 0.f), fNext = make_float2(0.f, 0.f), dCur;
+    {
+      unsigned int m0 = 0u;
+      if (len > 0) { m0 = (T.fmask + pixBase)[iFirst]; fCur = (T.flow + pixBase)[iFirst]; }
+      if (len > 1) { mNext = (T.fmask + pixBase)[iFirst + 1]; fNext = (T.flow + pixBase)[iFirst + 1]; }
+      dCur = denseDepthsAhead(T, iFirst, len > 0, m0, fCur, fs, ft);
+    }
     // source-side sums of the lane's run (one image row: one cell row, one pair of vertical tap weights)
     double AS[2][kDwFeatS], BS[3];
 #pragma unroll
@@ -365,10 +398,16 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         BS[0] = BS[1] = BS[2] = 0.0;
         curI0 = -1;
       }
+      // pixel t: flow and depths are here; request the depths of t + 1 and (mask, flow) of t + 2
+      const float2 fl = fCur, d = dCur;
+      {
+        const unsigned int m1 = mNext;
+        fCur = fNext;
+        if (i + 2 < iStop) { mNext = (T.fmask + pixBase)[i + 2]; fNext = (T.flow + pixBase)[i + 2]; }
+        dCur = denseDepthsAhead(T, i + 1, i + 1 < iStop, m1, fCur, fs, ft);
+      }
       float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
-      float2 d = make_float2(0.f, 0.f);
-      bool valid = false;
-      if (inRun) valid = rs.take(T, pixBase, i, 1, iStop, pixBase, fs, ft, nd, d);
+      const bool valid = inRun && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f && denseNdcFromFlow(T, i, fl, nd);
       if (__builtin_amdgcn_readfirstlane(__ballot(valid) == 0ull ? 1 : 0)) {
         if (inRun) ggOut[cFirst + t] = 0.0;
         continue;  // (wave-uniform)
@@ -596,14 +635,32 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
     for (int u = wave; u < map.bandH; u += NW) {
       int len;
       const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
-      // (gg and flow of the lane's next pixel in flight)
-      double gNext = 0.0;
-      float2 fNext = make_float2(0.f, 0.f);
-      if (len > 0) { gNext = gg[cb + iFirst]; fNext = T.flow[cb + iFirst]; }
-      for (int t = 0; t < len; ++t) {
-        const double g = gNext;
-        const float2 f = fNext;
-        if (t + 1 < len) { gNext = gg[cb + iFirst + t + 1]; fNext = T.flow[cb + iFirst + t + 1]; }
+      // (gg and flow of the lane's next FOUR pixels in flight: the trip is short -- taps and 16 atomics -- and the kernel waits on
+      // its loads otherwise)
+      constexpr int kBatch = 4;
+      double gN[kBatch];
+      float2 fN[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        gN[q] = 0.0;
+        fN[q] = make_float2(0.f, 0.f);
+        if (q < len) { gN[q] = gg[cb + iFirst + q]; fN[q] = T.flow[cb + iFirst + q]; }
+      }
+      for (int t0 = 0; t0 < len; t0 += kBatch) {
+        double gC[kBatch];
+        float2 fC[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+          gC[q] = gN[q];
+          fC[q] = fN[q];
+          gN[q] = 0.0;
+          if (t0 + kBatch + q < len) { gN[q] = gg[cb + iFirst + t0 + kBatch + q]; fN[q] = T.flow[cb + iFirst + t0 + kBatch + q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+        const int t = t0 + q;
+        const double g = gC[q];
+        const float2 f = fC[q];
         if (g == 0.0) continue;
         float4 nd;
         if (!denseNdcFromFlow(T, iFirst + t, f, nd)) continue;
@@ -621,6 +678,7 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
             const int jc = tc.I(l) - v0;
             if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], fr * tc.Wt(l));
           }
+        }
         }
       }
     }

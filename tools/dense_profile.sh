@@ -16,5 +16,10 @@ K="k_dense_walk|k_dense_gg|k_dense_fold_cross|k_assemble_fast"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_sq.log 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_SQ_dense.csv > /dev/null 2>&1
 rm -rf $OUT/pmc_sq
+# second SQ pass: where the issue stalls of the walk come from (LDS queue, matrix pipe, scalar unit)
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL --kernel-include-regex "k_dense_walk|k_dense_gg" --output-format csv -d $OUT/pmc_sq_b -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_sq_b.log 2>&1
+python $R/tools/pmc_summary.py $OUT/pmc_sq_b $OUT/pmc_SQ_dense_b.csv > /dev/null 2>&1
+rm -rf $OUT/pmc_sq_b
 head -14 $OUT/kernel_durations_dense.txt | cut -c1-180
 cat $OUT/pmc_SQ_dense.csv
+cat $OUT/pmc_SQ_dense_b.csv
