@@ -78,8 +78,7 @@ struct DenseWalkList {
 
 // ndc of both end points of a dense-mode constraint from its flow vector, WITHOUT the depth fetch (k_dense_gg: taps only).  The same
 // float arithmetic as denseConstraintFromFlow; false: target out of bounds.
-__device__ __forceinline__ bool denseNdcFromFlow(const Table& T, int pix, float2 f, float4& n) {
-  const int iy = pix / T.W, ix = pix - iy * T.W;
+__device__ __forceinline__ bool denseNdcFromFlow(const Table& T, int ix, int iy, float2 f, float4& n) {
   const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
   if (!(isfinite(fx1) && isfinite(fy1))) return false;
   const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
@@ -101,7 +100,7 @@ struct DwState {
   double m00, m02, m11, m12, m22;
   double zz;
   double r[3];
-  double w, rho0, JDT2, Da;
+  double w, sw, rho0, JDT2, Da;   // rho', sqrt(rho'), rho
   double Rca[3];
 };
 
@@ -122,10 +121,9 @@ __device__ __forceinline__ void dwGather(const Layout& L, float lx, float ly, Dw
 // t + 1 -- whose target address follows from its flow vector -- are, and pixel t is worked on with everything in registers.
 // (RecordStream<true> keeps one pixel's mask and flow in flight and takes the depth round trip, an L2 / HBM latency, in every
 // trip: waves parked 32 % of their cycles at two waves per SIMD.)  A masked-out or out-of-bounds candidate is encoded as d.x = 0.
-__device__ __forceinline__ float2 denseDepthsAhead(const Table& T, int pix, bool ok, unsigned int m, float2 f, int fa, int fb) {
+__device__ __forceinline__ float2 denseDepthsAhead(const Table& T, int ix, int iy, bool ok, unsigned int m, float2 f, int fa, int fb) {
   float2 d = make_float2(0.f, 0.f);
   if (!ok || !m) return d;
-  const int iy = pix / T.W, ix = pix - iy * T.W;
   const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
   if (!(isfinite(fx1) && isfinite(fy1))) return d;
   const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
@@ -178,7 +176,7 @@ __device__ __forceinline__ void dwChain(const Layout& L, const DwPairConst& P, c
   const double q1 = P.Rt[1] * v[0] + P.Rt[4] * v[1] + P.Rt[7] * v[2];
   const double q2 = P.Rt[2] * v[0] + P.Rt[5] * v[1] + P.Rt[8] * v[2];
   const double zz = -q2;
-  const double iz = 1.0 / zz;
+  const double iz = rcpFast(zz);   // (1 - 2 ulp: cvd_kernels.h; the IEEE division sequence is twice the instructions)
   const double u = q0 * iz * P.ifxt;
   const double vv = q1 * iz * P.ifyt;
   o.zz = zz;
@@ -187,7 +185,7 @@ __device__ __forceinline__ void dwChain(const Layout& L, const DwPairConst& P, c
   double dr2dA, dr2dDb;
   if (L.lossType == kLossDisparity) {
     const bool zo = !(zz < eps), bo = !(Db < eps);
-    const double izc = zo ? iz : 1.0 / eps, ibc = 1.0 / (bo ? Db : eps);
+    const double izc = zo ? iz : 1.0 / eps, ibc = rcpFast(bo ? Db : eps);
     o.r[2] = (izc - ibc) * L.wd;
     dr2dA = zo ? (-L.wd * izc * izc) : 0.0;
     dr2dDb = bo ? (L.wd * ibc * ibc) : 0.0;
@@ -206,7 +204,18 @@ __device__ __forceinline__ void dwChain(const Layout& L, const DwPairConst& P, c
       dr2dDb = ((zIsMax ? 0.0 : dmx) + (zIsMin ? 0.0 : dmn)) * L.wd;
     }
   }
-  robustRho(L, o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2], o.rho0, o.w);
+  {
+    const double sq = o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2];
+    if (L.robustKind == kRobustCauchy) {   // (robustRho with the reciprocal and the square root of rho' in their fast forms)
+      const double sum = 1.0 + sq * L.cauchyC;
+      o.rho0 = L.cauchyB * log(sum);
+      o.sw = rsqrtFast(sum);
+      o.w = o.sw * o.sw;
+    } else {
+      robustRho(L, sq, o.rho0, o.w);
+      o.sw = sqrt(o.w);
+    }
+  }
   const double wiz = L.ws * iz;
   o.m00 = wiz * P.ifxt;
   o.m11 = wiz * P.ifyt;
@@ -350,7 +359,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
       unsigned int m0 = 0u;
       if (len > 0) { m0 = (T.fmask + pixBase)[iFirst]; fCur = (T.flow + pixBase)[iFirst]; }
       if (len > 1) { mNext = (T.fmask + pixBase)[iFirst + 1]; fNext = (T.flow + pixBase)[iFirst + 1]; }
-      dCur = denseDepthsAhead(T, iFirst, len > 0, m0, fCur, fs, ft);
+      dCur = denseDepthsAhead(T, ix0, iy, len > 0, m0, fCur, fs, ft);
     }
     // source-side sums of the lane's run (one image row: one cell row, one pair of vertical tap weights)
     double AS[2][kDwFeatS], BS[3];
@@ -404,10 +413,10 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         const unsigned int m1 = mNext;
         fCur = fNext;
         if (i + 2 < iStop) { mNext = (T.fmask + pixBase)[i + 2]; fNext = (T.flow + pixBase)[i + 2]; }
-        dCur = denseDepthsAhead(T, i + 1, i + 1 < iStop, m1, fCur, fs, ft);
+        dCur = denseDepthsAhead(T, ix0 + t + 1, iy, i + 1 < iStop, m1, fCur, fs, ft);
       }
       float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool valid = inRun && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f && denseNdcFromFlow(T, i, fl, nd);
+      const bool valid = inRun && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f && denseNdcFromFlow(T, ix0 + t, iy, fl, nd);
       if (__builtin_amdgcn_readfirstlane(__ballot(valid) == 0ull ? 1 : 0)) {
         if (inRun) ggOut[cFirst + t] = 0.0;
         continue;  // (wave-uniform)
@@ -420,7 +429,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         const double da = static_cast<double>(d.x), db = static_cast<double>(d.y);
         dwGather(L, nd.z, nd.w, tt);
         dwChain(L, P, xs, xt, nd, da, db, ts, tt, ch);
-        sw = sqrt(ch.w);
+        sw = ch.sw;
         cost += ch.rho0;
         zf = -ch.zz * P.ifyt;   // d r_0,1 / d fy_t = -ws (u, v) / fy_t = -(m02, m12) z' / fy_t
 #pragma unroll
@@ -635,6 +644,7 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
     for (int u = wave; u < map.bandH; u += NW) {
       int len;
       const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
+      const int iy = iFirst / T.W, ix0 = iFirst - iy * T.W;
       // (gg and flow of the lane's next FOUR pixels in flight: the trip is short -- taps and 16 atomics -- and the kernel waits on
       // its loads otherwise)
       constexpr int kBatch = 4;
@@ -663,7 +673,7 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
         const float2 f = fC[q];
         if (g == 0.0) continue;
         float4 nd;
-        if (!denseNdcFromFlow(T, iFirst + t, f, nd)) continue;
+        if (!denseNdcFromFlow(T, ix0 + t, iy, f, nd)) continue;
         FastTaps<KD> ts, tt;
         fastGather<KD>(L, nd.x, nd.y, ts);
         fastGather<KD>(L, nd.z, nd.w, tt);
