@@ -359,6 +359,8 @@ def main():
             dt = float(tt.item())
         comm = solver.comm_times() if shard else None
         ktimes = solver.kernel_times()
+        if args.dense:
+            ktimes.update(solver.dense_times())
         solver.set_kernel_timing(False)
         # the whole pipeline again on the warm handle (steady state of a process that optimises video after video)
         from robust_cvd_amd.ctypes_types import XformDesc
@@ -425,9 +427,13 @@ def main():
             slots = len(video.pairs) * npx
             und = {(min(a, b), max(a, b)) for a, b in video.pairs.tolist()}
             if dense_explicit:
-                # explicit cross blocks (cvd_cross.h, the default at the bilinear levels): a product streams one B x B f64 block
-                # per undirected pair + per pair the two frames' z, p_old, mask blocks in and two partial rows out
-                bytes_launch = len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0)
+                # The dominant kernel of a dense-mode step is the ONE walk over the pixels of the Jacobian evaluation
+                # (k_dense_walk, cvd_dense_walk.h): SURVEY.md 8d's 17 B per pixel pair -- flow 8 B + mask 1 B + d_src0 4 B +
+                # gathered d_src1 4 B, every slot of every directed pair read once -- + the 8 B per slot it leaves for the
+                # grid x grid kernel + one record per directed pair.  (The PCG product streams the assembled blocks: dense_kernels.)
+                mv = m["ktimes"]["dense_walk"]
+                G = B - 7
+                bytes_launch = 17.0 * slots + 8.0 * slots + len(video.pairs) * (256 + 40 * G + 8) * 8.0
             else:
                 # flow 8 B + mask 1 B + d_src0 4 B + gathered d_src1 4 B = 17 B per pixel pair (every pixel slot
                 # of every pair is read) + per work item (8192 slots per direction) the frame blocks as in the list mode
@@ -436,7 +442,10 @@ def main():
             bytes_launch = matvec_bytes_per_launch(m["local_video"], n_active, B)
         achieved = (bytes_launch / (mv["avg_ms"] * 1e-3)) / 1e9 if mv["avg_ms"] > 0 else 0.0
         # (explicit blocks: y_a = X p_b and y_b = X^T p_a, 4 B^2 flop per pair)
-        flops_launch = (len(und) * 4.0 * B * B) if (args.dense and dense_explicit) else FLOPS_PER_CONSTRAINT * n_active
+        # dense walk: ~780 f64 VALU flop per pixel constraint counted from the compiled loop (mul 209 + add 102 + 2 x 172 fma, the
+        # row loop three times), beside 48 v_mfma_f64_16x16x4 per 64 constraints on the matrix pipe (1536 flop per constraint issued)
+        DENSE_WALK_FLOPS = 780.0
+        flops_launch = (DENSE_WALK_FLOPS * n_active) if (args.dense and dense_explicit) else FLOPS_PER_CONSTRAINT * n_active
         tflops = (flops_launch / (mv["avg_ms"] * 1e-3)) / 1e12 if mv["avg_ms"] > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot happen inside this
         # process): only when profiles/pmc_matvec_pairs.json was produced from the kernel sources benchmarked here and
@@ -482,16 +491,18 @@ def main():
                 "solves_in_timed_region": m["n_solves"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_cross_matvec" if (args.dense and dense_explicit) else "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_dense_walk" if (args.dense and dense_explicit) else "k_matvec_pairs", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "bytes_per_launch": bytes_launch, "avg_launch_ms": mv["avg_ms"], "launches": mv["launches"],
                 "timed": f"HIP start/stop events on every {m['sample_every']}. launch of the timed region ({mv['launches']} launches timed)",
                 "valu": {"achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_PEAK_TFLOPS,
                          "flops_per_launch": flops_launch,
-                         "note": ("4 B^2 flop per undirected pair (y_a = X p_b, y_b = X^T p_a)" if (args.dense and dense_explicit) else
+                         "note": (f"{DENSE_WALK_FLOPS:.0f} f64 VALU flop per pixel constraint counted from the compiled loop; the pose Gram "
+                                  "tile runs beside it on the matrix pipe (48 v_mfma_f64_16x16x4 per 64 constraints)" if (args.dense and dense_explicit) else
                                   f"{FLOPS_PER_CONSTRAINT:.0f} f64 flop per constraint counted from the kernel source (DESIGN.md 3)")},
-                "note": ("dense mode, explicit cross blocks: the product streams the assembled blocks (HBM-bound); the step is "
-                         "dominated by the block ASSEMBLY, see dense_kernels (f64 VALU / LDS-atomic bound)" if (args.dense and dense_explicit)
+                "note": ("dense mode: the Jacobian evaluation's one walk over the pixels (flow / mask / depth read once per evaluation); "
+                         "f64 VALU / matrix-pipe / LDS-atomic bound, not HBM-bound: both fractions are reported; the PCG product of "
+                         "this mode streams the assembled cross blocks (dense_kernels.product)" if (args.dense and dense_explicit)
                          else "f64 VALU/latency-bound, not HBM-bound (DESIGN.md 3): both fractions are reported"),
             },
             **({"dense_kernels": {
@@ -500,13 +511,22 @@ def main():
                 # and, with explicit cross blocks, 1 + panels more times for X_ab: reported against the two diagonal passes)
                 "cost": {"avg_ms": m["ktimes"]["cost"]["avg_ms"], "GB/s": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6,
                          "frac_hbm": 17.0 * slots / max(m["ktimes"]["cost"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS},
+                # the whole Jacobian evaluation: walk + per-frame fold + cross-block fold + grid x grid kernel (+ the small launches)
                 "assemble": {"avg_ms": m["ktimes"]["evaluate_assemble"]["avg_ms"],
-                             "GB/s": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6,
-                             "frac_hbm": 2 * 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS,
-                             # the roof that binds it: ~1600 f64 flop per pixel constraint (Jacobian chain of both sides 600 +
-                             # the rank-structured outer products of the diagonal and cross blocks 1000; DESIGN_LOG.md, round 3)
-                             "TFLOP/s": 1600.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9,
-                             "frac_valu": 1600.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9 / F64_PEAK_TFLOPS},
+                             "GB/s": 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6,
+                             "frac_hbm": 17.0 * slots / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS,
+                             "TFLOP/s": 780.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9,
+                             "frac_valu": 780.0 * n_active / max(m["ktimes"]["evaluate_assemble"]["avg_ms"], 1e-9) * 1e-9 / F64_PEAK_TFLOPS,
+                             "note": "rounds 2-5: three walks, ~1600 flop per constraint (the chain re-derived per side and per cross block), "
+                                     "38.2 ms; round 6: one walk, ~780 VALU flop per constraint + the Gram tile on the matrix pipe"},
+                **({"walk": {"avg_ms": m["ktimes"]["dense_walk"]["avg_ms"], "launches": m["ktimes"]["dense_walk"]["launches"]},
+                    "grid_x_grid": {"avg_ms": m["ktimes"]["dense_gg"]["avg_ms"], "launches": m["ktimes"]["dense_gg"]["launches"],
+                                    "GB/s": 16.0 * slots * 2 / max(m["ktimes"]["dense_gg"]["avg_ms"], 1e-9) * 1e-6,
+                                    "note": "8 B scalar + 8 B flow per pixel slot, read once per column panel (two panels at 17 x 10)"},
+                    "product": {"kernel": "k_cross_matvec", "avg_ms": m["ktimes"]["matvec_pairs"]["avg_ms"],
+                                "GB/s": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6,
+                                "frac_hbm": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS}}
+                   if dense_explicit else {}),
             }} if args.dense else {}),
             **({"rccl": {"ranks": world, "frames_owned_per_rank": -(-frames // world),
                          "exchange_avg_ms": {k: round(v["avg_ms"], 5) for k, v in m["comm"].items()},

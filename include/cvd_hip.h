@@ -326,6 +326,11 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avg_ms6, int64_t* launches6)
  * replicated update (dist_owner_update = 0): ONE all-reduce of [q | Z^T q | p.q]; coarse exchange: edge blocks, diagonal blocks}
  * -- average ms per occurrence and counts. */
 int32_t cvd_get_comm_times(cvd_handle* h, double* avg_ms3, int64_t* counts3);
+/* Dense mode (cvd_set_pair_flows) inside the explicit-block scope: the two kernels of the Jacobian evaluation that walk the pixels,
+ * timed on their own whenever kernel timing is on -- {k_dense_walk: flow / mask / depth read once, every contribution of a pixel
+ * constraint formed once (replaces the reference's per-constraint residual blocks, lib/PoseOptimizer.cpp:1185-1232, for
+ * matchSeparation = 0, lib/FlowConstraints.cpp:381-395); k_dense_gg: grid x grid part of the cross blocks} -- average ms, launches. */
+int32_t cvd_get_dense_times(cvd_handle* h, double* avg_ms2, int64_t* launches2);
 /* Per-launch HIP-event timing: 0 = off (default), 1 = every class, otherwise a bit mask (bit k = class k in the
  * order of cvd_get_kernel_times). Two event records per timed launch. Bits 8..15 = sampling stride - 1 for the hot
  * kernel's start/stop events (0: every launch, 3: every 4th launch of k_matvec_pairs carries an event pair). */

@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
     "cvd_get_pose_params", "cvd_set_pose_params", "cvd_block_size", "cvd_normalize_depth", "cvd_pose_optimization",
     "cvd_pose_optimization_step", "cvd_evaluate", "cvd_sample_pair_constraints", "cvd_get_sampled_constraints", "cvd_sample_triplet_constraints", "cvd_get_sampled_triplet_constraints", "cvd_set_dynamic_masks", "cvd_corner_min_eigenval", "cvd_dynamic_distance", "cvd_apply_depth_xforms", "cvd_depth_param_maps", "cvd_spatial_warp_maps", "cvd_flow_guided_filter", "cvd_get_summary", "cvd_num_records", "cvd_get_records",
-    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug", "cvd_path_info", "cvd_abi_revision",
+    "cvd_get_kernel_times", "cvd_get_comm_times", "cvd_get_dense_times", "cvd_set_kernel_timing", "cvd_num_active_constraints", "cvd_coarse_debug", "cvd_temporal_debug", "cvd_path_info", "cvd_abi_revision",
     "cvd_block_inverse_debug", "cvd_dense_inverse_debug",
 ]
 
@@ -193,6 +193,13 @@ class Solver(Binding):
         n = (C.c_int64 * 6)()
         self._check(self._fn("get_kernel_times")(self._h, ms, n))
         return {k: {"avg_ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def dense_times(self):
+        """Average ms / launches of the dense mode's two pixel-walking kernels of a Jacobian evaluation (see cvd_get_dense_times)."""
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        self._check(self._fn("get_dense_times")(self._h, ms, n))
+        return {k: {"avg_ms": ms[i], "launches": n[i]} for i, k in enumerate(("dense_walk", "dense_gg"))}
 
     def comm_times(self):
         """Average ms / counts of the sharded mode's exchange steps (see cvd_get_comm_times)."""

@@ -702,6 +702,14 @@ int32_t cvd_get_kernel_times(cvd_handle* h, double* avgMs6, int64_t* launches6) 
     }
   });
 }
+int32_t cvd_get_dense_times(cvd_handle* h, double* avgMs2, int64_t* launches2) {
+  CVD_TRY(h, {
+    for (int k = 0; k < 2; ++k) {
+      avgMs2[k] = h->kcN[KC_DENSE_WALK + k] ? h->kcMs[KC_DENSE_WALK + k] / h->kcN[KC_DENSE_WALK + k] : 0.0;
+      launches2[k] = h->kcN[KC_DENSE_WALK + k];
+    }
+  });
+}
 int32_t cvd_get_comm_times(cvd_handle* h, double* avgMs3, int64_t* counts3) {
   CVD_TRY(h, {
     for (int k = 0; k < 3; ++k) {

@@ -118,8 +118,10 @@ void launchDenseWalk(Ctx& c, const double* x) {
   const size_t lds = dwLdsBytes(G, B, kDwThreads);
   const DenseWalkList wl{h->dDwPair.p, h->nDwRecords, denseLaneMap(h->W, h->H)};
   allowLds((k_dense_walk<4>), lds);
+  const int slot = h->tBegin(KC_DENSE_WALK);
   hipLaunchKernelGGL((k_dense_walk<4>), dim3(h->nDwRecords), dim3(kDwThreads), lds, h->stream, c.L, c.T, wl, x, h->dFc.p,
                      h->dDwRecords.p, h->dDwGg.p);
+  h->tEnd(slot);
   HIP_CHECK(hipGetLastError());
 }
 // X_ab of every undirected pair from the walk's records (pose rows / columns) and scalars (grid x grid, in column panels of the
@@ -139,8 +141,10 @@ void launchCrossAssemble(Ctx& c, const double* x) {
   panelW = static_cast<int>((G + nPanels - 1) / nPanels);  // (even panels)
   const size_t ldsGrid = static_cast<size_t>(panelW) * G * 8;
   allowLds((k_dense_gg<4>), ldsGrid);
+  const int slot = h->tBegin(KC_DENSE_GG);
   hipLaunchKernelGGL((k_dense_gg<4>), dim3(nP, nPanels), dim3(kGgThreads), ldsGrid, h->stream, c.L, c.T, crossPairs(h), h->dXDir.p,
                      h->dDwGg.p, panelW, denseLaneMap(h->W, h->H), h->dXBlocks.p);
+  h->tEnd(slot);
   HIP_CHECK(hipGetLastError());
 }
 

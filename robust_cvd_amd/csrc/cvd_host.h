@@ -147,7 +147,9 @@ inline int xformNumBlocks(const cvd_xform_desc& d) {
 
 enum KernelClass { KC_ASSEMBLE = 0, KC_MATVEC_PAIRS, KC_MATVEC_FINISH, KC_CG_UPDATE, KC_INVERSE, KC_COST, KC_COUNT,
                    // exchange steps of the pair-sharded multi-GPU mode (cvd_get_comm_times): timed whenever any class is
-                   KC_COMM_EVAL = KC_COUNT, KC_COMM_PRODUCT, KC_COMM_COARSE, KC_TOTAL };
+                   KC_COMM_EVAL = KC_COUNT, KC_COMM_PRODUCT, KC_COMM_COARSE,
+                   // kernels timed on their own beside their class (cvd_get_dense_times): the dense mode's pixel walk and grid x grid kernel
+                   KC_DENSE_WALK, KC_DENSE_GG, KC_TOTAL };
 
 struct Ceres {  // ceres::Solver::Options defaults used on this path
   static constexpr double initial_radius = 1e4, max_radius = 1e16, min_radius = 1e-32;
