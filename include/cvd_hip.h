@@ -26,9 +26,11 @@ typedef struct cvd_handle_t cvd_handle;
 /* Inner linear solver / LM knobs that have no counterpart in the reference (Ceres' SPARSE_NORMAL_CHOLESKY
  * is replaced by a block-Jacobi preconditioned conjugate-gradient solve on the device). */
 typedef struct cvd_solver_options {
-  uint64_t struct_size;          /* sizeof(cvd_solver_options) of the header the CALLER was built with: set by
-                                    cvd_solver_options_default, checked by cvd_set_solver_options (a caller built against another
-                                    revision of this header is refused instead of being read out of bounds) */
+  uint64_t struct_size;          /* CVD_STRUCT_STAMP(cvd_solver_options) of the header the CALLER was built with -- sizeof in the low
+                                    32 bits, CVD_ABI_REVISION in the high 32 (round 6, ADVICE r5: removing one int32 left sizeof
+                                    unchanged behind the padding, so the size alone could not tell the revisions apart) -- set by
+                                    cvd_solver_options_default, checked by cvd_set_solver_options: a caller built against another
+                                    revision of this header is refused instead of being read with shifted fields */
   double pcg_relative_tolerance; /* eta: the PCG stops when sqrt(r^T M^-1 r) <= eta * its initial value.  Default 1e-3:
                                     the reference's SPARSE_NORMAL_CHOLESKY takes EXACT LM steps, and the iterate at which
                                     function_tolerance (1e-6 relative cost change) stops them is only reproduced -- to the
@@ -40,7 +42,6 @@ typedef struct cvd_solver_options {
   int32_t pcg_max_iterations;    /* default 300 */
   int32_t verbose;               /* 1: print a Ceres-like per-iteration table to stdout; 2: + PCG scalars per iteration;
                                     3: + setup phases and the shape of the coarse elimination (development) */
-  int32_t force_iterations;      /* measurement only: ignore the convergence tests, run exactly max_iterations */
   int32_t coarse_level;          /* 1 (default): block-Jacobi + a pose-graph coarse solve (8 unknowns per frame) -- the EXACT
                                     block-sparse factor while its elimination is cheap, else what coarse_over_budget names
                                     (default: the temporal pose level); rebuilt on demand; 2: the same rebuilt every LM
@@ -52,12 +53,11 @@ typedef struct cvd_solver_options {
                                     0 (default) ceres::CauchyLoss, what the reference hard-wires
                                     (lib/PoseOptimizer.cpp:1220); 1 ceres::HuberLoss, the stress variant of BASELINE.json
                                     configs[4] (no counterpart in the reference) */
-  /* ---- variant selection for tests / measurements (per handle; all default 0 = the product path) ---- */
-  int32_t force_sharded_path;     /* 1: a 1-rank communicator runs the multi-rank code path (owner chunks, exchange calls) */
+  /* ---- POLICY: which of the library's variants a solve uses.  The defaults are the product path (chosen on the benchmarked video,
+   * held off it by tools/defaults_sweep.py: DESIGN.md 8); a caller has no reason to touch anything below this line.  Test and
+   * measurement hooks are NOT here: include/cvd_hip_debug.h ---- */
   int32_t dense_matrix_free;      /* dense mode: 1 = matrix-free products everywhere (no explicit cross blocks) */
   int32_t block_inverse_variant;  /* 0: MFMA blocked sweep (default); 1: scalar register-resident sweep */
-  int32_t pcg_lockstep;           /* profiling: 1 = the host never enqueues a PCG iteration ahead of the convergence flag, so
-                                     that per-launch counter averages contain no early-exit launches */
   int32_t coarse_dense_max_unknowns; /* the coarse level is inverted as ONE dense matrix up to this many unknowns
                                      (8 per frame) when its sparse elimination is too expensive; default 4096 */
   int32_t coarse_rebuild_excess;  /* coarse_level 1: the coarse level is rebuilt once the PCG iterations spent beyond the count seen
@@ -83,8 +83,7 @@ typedef struct cvd_solver_options {
                                      one GPU, frame block <= 256, dense coarse level or none, every workgroup resident; 0: always
                                      the two launches.  A handle whose fused tail ever abandons its barrier (device shared with
                                      other work) falls back to the two launches for good and repeats the solve (a warning on
-                                     stderr); 2 = test hook: as 1, and the host treats the first solve's third iteration as such
-                                     a stall */
+                                     stderr) */
   int32_t coarse_dense_row_split; /* dense coarse level, per PCG iteration: of a frame's 8 rows of A_c^-1 the first this-many are applied by
                                      the dense-level workgroups (two frames each), the others by the frame's own workgroup after its
                                      update (default 5; 8 = rounds 2-3: dense-level workgroups only; 0 = frame workgroups only) */
@@ -116,7 +115,6 @@ typedef struct cvd_solver_options {
                                      sparse level is not: 1766-pair list at 300 frames 296 -> 331 LM iterations/s at 37.6 -> 39.8
                                      PCG iterations.  Beyond ~400 frames the fused kernel's workgroups are no longer co-resident
                                      and the exact factor stays (configs[4]: 52.9 against 47 iterations/s) */
-  int32_t reserved0;              /* (keeps the double below aligned the same way in every binding) */
   double temporal_weight;         /* the temporal levels (depth-grid level, temporal pose level) enter the additive preconditioner
                                      as weight x P A^-1 P^T: their spaces overlap each other's and the per-frame blocks', and an
                                      additive combination of overlapping exact corrections overshoots (default 0.7: 5 - 8 % fewer
@@ -124,10 +122,12 @@ typedef struct cvd_solver_options {
 } cvd_solver_options;
 
 /* Revision of this header's binary interface: bumped whenever a struct layout or an entry point's meaning changes (round 4: 4 --
- * cvd_solver_options gained struct_size as its FIRST field; round 5: 5 -- pcg_check_every removed, cvd_path_info added).
- * cvd_abi_revision() returns the revision the LIBRARY was built with; bindings compare it with the header they were written
- * against before any struct crosses the boundary (robust_cvd_amd/api.py does at load). */
-#define CVD_ABI_REVISION 5
+ * cvd_solver_options gained struct_size as its FIRST field; round 5: 5 -- pcg_check_every removed, cvd_path_info added; round 6: 6 --
+ * the test / measurement hooks left cvd_solver_options for cvd_debug_options (cvd_hip_debug.h), struct_size carries the revision,
+ * cvd_get_dense_times added).  cvd_abi_revision() returns the revision the LIBRARY was built with; bindings compare it with the
+ * header they were written against before any struct crosses the boundary (robust_cvd_amd/api.py does at load). */
+#define CVD_ABI_REVISION 6
+#define CVD_STRUCT_STAMP(T) ((uint64_t)sizeof(T) | ((uint64_t)CVD_ABI_REVISION << 32))
 int32_t cvd_abi_revision(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
@@ -142,8 +142,6 @@ void cvd_abi_sizes(int32_t* out6);
 void cvd_opt_params_default(cvd_opt_params* p);       /* reference lib/PoseOptimizer.h:55-103 defaults */
 void cvd_solver_options_default(cvd_solver_options* o);
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o);
-/* Test hook: 1 = run the generic all-variants kernels even where a specialised fast kernel exists. */
-int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
 
 /* ---- multi-GPU: one process per GPU, frame pairs sharded across ranks ---------------------
  * Every rank holds all frames (depth, parameters) but only ITS pairs (cvd_set_pair_constraints with the shard);
@@ -154,16 +152,6 @@ int32_t cvd_set_generic_kernels(cvd_handle* h, int32_t enabled);
  * grouped collectives over RCCL on the solver's stream.  The reference has no counterpart (single process).  Rank 0 creates the id, the caller broadcasts the 128 bytes (any transport). */
 void cvd_comm_unique_id(uint8_t* out128);
 int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t* id128);
-/* Test backend of the exchange layer: the `world` ranks are handles of THIS process on ONE device, each driven by its
- * own host thread; handles that pass the same `group_key` form one group.  RCCL refuses two ranks on one device, so
- * this is how the multi-rank code paths run with world > 1 on a single-GPU box (tests/test_gpu_two_ranks.py).
- * Host-synchronous; never used by a multi-GPU run. */
-int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, uint64_t group_key);
-/* Measurement aid (tools/shard_sim.py): this handle becomes rank `rank` of a `world`-rank run whose OTHER ranks do not exist --
- * every collective returns at once and the other ranks' contributions are simply missing.  The sharded code path runs with the
- * real owner chunks, offsets and launch geometry of that rank, so its kernels can be timed on one GPU; the numbers the solve
- * produces mean nothing. */
-int32_t cvd_comm_init_phantom(cvd_handle* h, int32_t rank, int32_t world);
 /* Pair-sharded mode only: the frame pairs of the WHOLE problem (2 * num_pairs frame indices, direction and order
  * irrelevant), identical on every rank.  The coarse level of the preconditioner is built on this graph; without it
  * a multi-rank solve falls back to the block-Jacobi level alone.  Call after cvd_set_video. */
@@ -337,32 +325,11 @@ int32_t cvd_get_dense_times(cvd_handle* h, double* avg_ms2, int64_t* launches2);
 int32_t cvd_set_kernel_timing(cvd_handle* h, int32_t enabled);
 /* Number of (valid static) constraints in the compiled table of the last solve. */
 int64_t cvd_num_active_constraints(cvd_handle* h);
-/* Parity hook for the per-frame dense solve of the block-Jacobi preconditioner (no reference counterpart: Ceres'
- * SPARSE_NORMAL_CHOLESKY, lib/PoseOptimizer.cpp:956, is replaced by PCG): inverts `num_blocks` symmetric positive
- * definite block_size x block_size f64 matrices `a` (row-major, block after block) with the very kernel the solver uses
- * and returns the f32 inverses.  variant 0: blocked sweep on the f64 matrix cores (the default path), 1: scalar
- * register-tile sweep, 2: LDS Cholesky.  failed = number of non-positive pivots met. */
-int32_t cvd_block_inverse_debug(cvd_handle* h, int32_t num_blocks, int32_t block_size, const double* a, int32_t variant,
-                                float* inverse, int32_t* failed);
-
-/* Test hook for the coarse level of the preconditioner (state of the last LM iteration of the last solve):
- * n = 8 * frames (0 when the level was off), a_c = Z^T (J^T J + diag(lam)) Z as a dense n x n matrix assembled
- * from its blocks, a_c_inverse = the inverse the solver applied, failed = pivot failures of the factorisation.
- * Any output pointer may be NULL. */
-/* Test hook: the dense SPD inverse of the dense coarse level (cvd_dense_inverse.h) on one n x n f64 matrix (row-major,
- * symmetric); inverse = n x n f64; failed = 1 on a non-positive pivot (inverse untouched), bit 30 = barrier timeout. */
-int32_t cvd_dense_inverse_debug(cvd_handle* h, int32_t n, const double* a, double* inverse, int32_t* failed);
-int32_t cvd_coarse_debug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);
 /* Diagnostics (no counterpart in the reference): which variant of the linear solver the LAST solve of the handle ran --
  * out8 = { pose-graph level on, its form (0 exact sparse factor, 1 exact dense inverse, 2 temporal pose level), depth-grid
  * temporal level on, PCG tail fused into one launch (k_pcg_tail), fused tail disabled after an abandoned barrier, depth taps per
  * sample (1 / 4 / 16), work items of the pair-major kernels, explicit cross blocks (dense mode) }.  tools/defaults_sweep.py. */
 int32_t cvd_path_info(cvd_handle* h, int32_t* out8);
-/* Test hook for the third level of the preconditioner (cvd_solver_options::temporal_level; state of its last build in the last
- * solve): dims6 = {NT unknowns (0: the level was off), S hats per node, nn nodes, step, Sx, Sy}; a_t = the assembled Galerkin
- * matrix (NT x NT, unknown s * nn + a, diagonal shifted by coarse_dense_shift), a_t_inverse = the inverse in use, lam = the LM
- * damping vector (frames x block) of the last LM iteration.  Any output pointer but dims6 may be NULL. */
-int32_t cvd_temporal_debug(cvd_handle* h, int32_t* dims6, double* a_t, double* a_t_inverse, double* lam, int32_t* failed);
 
 #ifdef __cplusplus
 }

@@ -22,13 +22,10 @@ class SolverOptions(C.Structure):
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
         ("verbose", C.c_int32),
-        ("force_iterations", C.c_int32),
         ("coarse_level", C.c_int32),
         ("robust_loss", C.c_int32),
-        ("force_sharded_path", C.c_int32),
         ("dense_matrix_free", C.c_int32),
         ("block_inverse_variant", C.c_int32),
-        ("pcg_lockstep", C.c_int32),
         ("coarse_dense_max_unknowns", C.c_int32),
         ("coarse_rebuild_excess", C.c_int32),
         ("coarse_update_budget", C.c_int64),
@@ -45,12 +42,22 @@ class SolverOptions(C.Structure):
         ("coarse_temporal_step", C.c_int32),
         ("coarse_over_budget", C.c_int32),
         ("coarse_temporal_min_frames", C.c_int32),
-        ("reserved0", C.c_int32),
         ("temporal_weight", C.c_double),
     ]
 
 
-ABI_REVISION = 5  # include/cvd_hip.h: CVD_ABI_REVISION
+class DebugOptions(C.Structure):
+    """include/cvd_hip_debug.h cvd_debug_options: test / measurement hooks, not part of the product interface."""
+    _fields_ = [
+        ("struct_size", C.c_uint64),
+        ("force_iterations", C.c_int32),
+        ("force_sharded_path", C.c_int32),
+        ("pcg_lockstep", C.c_int32),
+        ("stall_fused_tail_once", C.c_int32),
+    ]
+
+
+ABI_REVISION = 6  # include/cvd_hip.h: CVD_ABI_REVISION
 
 
 def load_library(variant=None):
@@ -85,7 +92,7 @@ def load_library(variant=None):
 
 EXPORTED_SYMBOLS = [
     "cvd_create", "cvd_destroy", "cvd_last_error", "cvd_abi_sizes", "cvd_opt_params_default",
-    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_comm_init_phantom", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
+    "cvd_solver_options_default", "cvd_set_solver_options", "cvd_debug_options_default", "cvd_set_debug_options", "cvd_set_generic_kernels", "cvd_comm_unique_id", "cvd_comm_init", "cvd_comm_init_local_group", "cvd_comm_init_phantom", "cvd_set_pair_graph", "cvd_set_video", "cvd_set_depth", "cvd_set_depth_all",
     "cvd_set_pair_constraints", "cvd_set_pair_flows", "cvd_dense_mode_supported", "cvd_set_triplet_constraints", "cvd_set_poses", "cvd_get_poses",
     "cvd_reset_poses", "cvd_reset_depth_xforms", "cvd_reset_spatial_xforms", "cvd_grid_xform_split",
     "cvd_get_xform_desc", "cvd_num_xform_params", "cvd_get_xform_params", "cvd_set_xform_params",
@@ -106,10 +113,23 @@ class Solver(Binding):
             raise RuntimeError("cvd_create failed: " + (lib.cvd_last_error(None) or b"").decode())
         super().__init__(lib, "cvd_", handle)
         self._options = None
+        self._debug = None
 
     def set_options(self, pcg_relative_tolerance=None, pcg_max_iterations=None, verbose=None,
-                    force_iterations=None, coarse_level=None, robust_loss=None, **variants):
-        """Options persist per handle: only the fields given change (robust_loss: 0 Cauchy = reference, 1 Huber)."""
+                    coarse_level=None, robust_loss=None, **variants):
+        """Options persist per handle: only the fields given change (robust_loss: 0 Cauchy = reference, 1 Huber).  Names of
+        cvd_debug_options (force_iterations, force_sharded_path, pcg_lockstep, stall_fused_tail_once: test / measurement hooks,
+        include/cvd_hip_debug.h) are routed to cvd_set_debug_options."""
+        debug = {k: variants.pop(k) for k in list(variants) if k in dict(DebugOptions._fields_) and k != "struct_size"}
+        if debug:
+            d = self._debug
+            if d is None:
+                d = DebugOptions()
+                self._lib.cvd_debug_options_default(C.byref(d))
+                self._debug = d
+            for k, v in debug.items():
+                setattr(d, k, int(v))
+            self._check(self._fn("set_debug_options")(self._h, C.byref(d)))
         o = self._options
         if o is None:
             o = SolverOptions()
@@ -121,13 +141,11 @@ class Solver(Binding):
             o.pcg_max_iterations = pcg_max_iterations
         if verbose is not None:
             o.verbose = int(verbose)
-        if force_iterations is not None:
-            o.force_iterations = int(force_iterations)
         if coarse_level is not None:
             o.coarse_level = int(coarse_level)
         if robust_loss is not None:
             o.robust_loss = int(robust_loss)
-        for k, v in variants.items():  # force_sharded_path, dense_matrix_free, block_inverse_variant, pcg_lockstep, coarse_*
+        for k, v in variants.items():  # dense_matrix_free, block_inverse_variant, coarse_*, temporal_*, ...
             if k not in dict(SolverOptions._fields_):
                 raise TypeError(f"unknown solver option {k!r}")
             setattr(o, k, float(v) if k in ("coarse_dense_shift", "temporal_weight") else int(v))

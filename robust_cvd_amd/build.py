@@ -73,7 +73,7 @@ def build_deterministic(verbose=False):
     ONE wave, folds in index order -- bit-reproducible solves, several times slower).  tests/test_gpu_determinism.py and
     tools/det_check.py load it with api.load_library(variant="det").  Rebuilt when a source is newer than the library."""
     out = os.path.join(_HERE, "lib", "libcvd_hip_det.so")
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(_HERE, "..", "include", "cvd_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [os.path.join(_HERE, "..", "include", "cvd_hip.h"), os.path.join(_HERE, "..", "include", "cvd_hip_debug.h")]
     if os.path.exists(out) and all(os.path.getmtime(f) <= os.path.getmtime(out) for f in srcs if os.path.exists(f)):
         return out
     return build_variant("det", ["CVD_DETERMINISTIC=1"], verbose=verbose)

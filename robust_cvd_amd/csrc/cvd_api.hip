@@ -162,6 +162,7 @@ cvd_handle* cvd_create(int32_t device) {
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
+    cvd_debug_options_default(&h->dbg);
     // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)
     touchModule_setup(); touchModule_eval(); touchModule_matvec(); touchModule_precond(); touchModule_temporal(); touchModule_solve(); touchModule_frontend();
     if (device < PersistentGate::kMaxDevices) {
@@ -221,17 +222,14 @@ void cvd_opt_params_default(cvd_opt_params* p) {
 }
 
 void cvd_solver_options_default(cvd_solver_options* o) {
-  o->struct_size = sizeof(cvd_solver_options);
+  o->struct_size = CVD_STRUCT_STAMP(cvd_solver_options);
   o->pcg_relative_tolerance = 1e-3;  // near-exact LM steps: what reproducing the reference's exact-step end state takes (cvd_hip.h)
   o->pcg_max_iterations = 300;
   o->verbose = 0;
-  o->force_iterations = 0;
   o->coarse_level = 1;
   o->robust_loss = 0;
-  o->force_sharded_path = 0;
   o->dense_matrix_free = 0;
   o->block_inverse_variant = 0;
-  o->pcg_lockstep = 0;
   o->coarse_dense_max_unknowns = 4096;
   o->coarse_rebuild_excess = 16;
   o->coarse_update_budget = 40000;
@@ -248,17 +246,18 @@ void cvd_solver_options_default(cvd_solver_options* o) {
   o->coarse_temporal_step = 8;
   o->coarse_over_budget = 0;
   o->coarse_temporal_min_frames = 128;
-  o->reserved0 = 0;
   o->temporal_weight = 0.7;
 }
 int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
   CVD_TRY(h, {
     //  the struct is copied whole: refuse a caller built against another revision of the header, and values no
     // code path is defined for, before anything is stored
-    if (o->struct_size != sizeof(cvd_solver_options))
-      throw std::runtime_error(fmt("cvd_solver_options: struct_size %llu != %zu (caller built against another cvd_hip.h; start "
-                                   "from cvd_solver_options_default)", static_cast<unsigned long long>(o->struct_size),
-                                   sizeof(cvd_solver_options)));
+    if (o->struct_size != CVD_STRUCT_STAMP(cvd_solver_options))
+      throw std::runtime_error(fmt("cvd_solver_options: struct_size %#llx != %#llx = sizeof | revision << 32 (caller built against "
+                                   "another cvd_hip.h; start from cvd_solver_options_default)",
+                                   static_cast<unsigned long long>(o->struct_size),
+                                   static_cast<unsigned long long>(CVD_STRUCT_STAMP(cvd_solver_options))));
+    if (o->pcg_fused_tail < 0 || o->pcg_fused_tail > 1) throw std::runtime_error("pcg_fused_tail in {0, 1}");
     if (!(o->pcg_relative_tolerance > 0.0 && o->pcg_relative_tolerance < 1.0)) throw std::runtime_error("pcg_relative_tolerance must lie in (0, 1)");
     if (o->pcg_max_iterations < 1) throw std::runtime_error("pcg_max_iterations must be >= 1");
     if (!(o->coarse_dense_shift >= 0.0 && o->coarse_dense_shift < 1.0)) throw std::runtime_error("coarse_dense_shift must lie in [0, 1)");
@@ -284,6 +283,20 @@ int32_t cvd_set_solver_options(cvd_handle* h, const cvd_solver_options* o) {
       h->tableValid = false;
     if (o->constraint_order != h->opt.constraint_order) h->orderGx = h->orderGy = -1;  // (the coarse level's variant is chosen when the table is compiled)
     h->opt = *o;
+  });
+}
+void cvd_debug_options_default(cvd_debug_options* o) {
+  o->struct_size = CVD_STRUCT_STAMP(cvd_debug_options);
+  o->force_iterations = 0;
+  o->force_sharded_path = 0;
+  o->pcg_lockstep = 0;
+  o->stall_fused_tail_once = 0;
+}
+int32_t cvd_set_debug_options(cvd_handle* h, const cvd_debug_options* o) {
+  CVD_TRY(h, {
+    if (o->struct_size != CVD_STRUCT_STAMP(cvd_debug_options))
+      throw std::runtime_error("cvd_debug_options: struct_size does not match this library's cvd_hip_debug.h (start from cvd_debug_options_default)");
+    h->dbg = *o;
     h->distForced = h->world == 1 && (h->comm != nullptr || h->localGroup || h->phantom) && o->force_sharded_path != 0;
   });
 }
@@ -304,7 +317,7 @@ int32_t cvd_comm_init(cvd_handle* h, int32_t rank, int32_t world, const uint8_t*
     h->world = world;
     h->localGroup.reset();
     // test hook: with one rank the collectives are no-ops, but the sharded-mode kernels and call sequence still run
-    h->distForced = world == 1 && h->opt.force_sharded_path != 0;
+    h->distForced = world == 1 && h->dbg.force_sharded_path != 0;
     h->tableValid = false;
   });
 }
@@ -315,7 +328,7 @@ int32_t cvd_comm_init_local_group(cvd_handle* h, int32_t rank, int32_t world, ui
     h->localGroup = joinLocalGroup(group_key, world);
     h->rank = rank;
     h->world = world;
-    h->distForced = world == 1 && h->opt.force_sharded_path != 0;
+    h->distForced = world == 1 && h->dbg.force_sharded_path != 0;
     h->tableValid = false;
   });
 }

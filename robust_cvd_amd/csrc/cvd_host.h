@@ -32,7 +32,7 @@
 #include <tuple>
 #include <vector>
 
-#include "../../include/cvd_hip.h"
+#include "../../include/cvd_hip_debug.h"
 #include "cvd_kernels.h"
 #include "cvd_coarse.h"
 #include "cvd_temporal.h"
@@ -178,6 +178,7 @@ struct cvd_handle_t {
   hipStream_t stream = nullptr;
   std::string err;
   cvd_solver_options opt{};
+  cvd_debug_options dbg{};   // test / measurement hooks (cvd_hip_debug.h)
 
   // video
   int F = 0, W = 0, H = 0;

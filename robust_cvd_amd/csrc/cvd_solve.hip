@@ -131,7 +131,7 @@ static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& t
   // is described at the loop below.
   // (profiling aid: cvd_solver_options::pcg_lockstep checks after every iteration and never runs ahead, so that per-launch
   // counter averages contain no early-exit launches)
-  const bool lockstep = h->opt.pcg_lockstep != 0;
+  const bool lockstep = h->dbg.pcg_lockstep != 0;
   const size_t firstTimerSlot = h->evUsed;
   int enq = 0;
   auto enqueueIteration = [&](int it, int useBeta) {
@@ -213,9 +213,9 @@ static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& t
     }
     enqueueIteration(enq, enq > 0 ? 1 : 0);
     ++enq;
-    // (test hook, pcg_fused_tail = 2: the host behaves as if the fused tail's barrier had been abandoned in the middle of the
+    // (test hook, cvd_debug_options::stall_fused_tail_once: the host behaves as if the fused tail's barrier had been abandoned in the middle of the
     // first solve it is used in -- exercises the recovery path above without needing a second tenant on the device)
-    if (fusedTail && h->opt.pcg_fused_tail == 2 && enq == 3) throw TailStalled{};
+    if (fusedTail && h->dbg.stall_fused_tail_once != 0 && enq == 3) throw TailStalled{};
     if (h->opt.verbose >= 2) {  // development trace: per-iteration scalars (synchronises every iteration)
       readScalars(c);
       std::printf("    pcg %3d  rz %.6e  rzpart %.6e  alpha %.6e  beta %.6e  pq %.6e  done %g\n", enq - 1, h->hScal[S_RZ],
@@ -411,7 +411,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
     printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n"
            "%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", 0, xCost, 0.0, gmax, 0.0, 0.0, radius, 0);
 
-  if (sum.num_parameters == 0 || (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations)) {
+  if (sum.num_parameters == 0 || (gmax <= Ceres::gradient_tolerance && !h->dbg.force_iterations)) {
     termination = 0;
   } else {
     while (true) {
@@ -548,7 +548,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
         gmax = h->hScal[S_GMAX];
         xNorm = std::sqrt(h->hScal[S_XX]);
         h->records.back().gradient_max_norm = gmax;
-        if (gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) {
+        if (gmax <= Ceres::gradient_tolerance && !h->dbg.force_iterations) {
           // the previous iteration ended the solve (Ceres tests the gradient right after a successful step): this iteration's
           // linear solve was speculative and is dropped -- x, the cost and the records are those of the previous iteration
           --iteration;
@@ -580,7 +580,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
       bool stop = false;
       if (stepNorm <= Ceres::parameter_tolerance * (xNorm + Ceres::parameter_tolerance)) stop = true;
       if (!stop && std::abs(xCost - candCost) <= Ceres::function_tolerance * xCost) stop = true;
-      if (h->opt.force_iterations) stop = false;
+      if (h->dbg.force_iterations) stop = false;
       if (stop) {
         rec.cost = xCost;
         rec.trust_region_radius = radius;
@@ -620,7 +620,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
         if (h->opt.verbose)
           printf("%4d % .6e    % .2e   % .2e   % .2e  % .2e % .2e   %5d\n", iteration, xCost, rec.cost_change, gmax,
                  stepNorm, rec.relative_decrease, radius, cgIters);
-        if (!gradPending && gmax <= Ceres::gradient_tolerance && !h->opt.force_iterations) { termination = 0; break; }
+        if (!gradPending && gmax <= Ceres::gradient_tolerance && !h->dbg.force_iterations) { termination = 0; break; }
       } else {
         radius /= decrease;
         decrease *= 2.0;

@@ -1,7 +1,13 @@
 """Pair sharding for the multi-GPU path: directed pairs are split across ranks so that
 (i, j) and (j, i) stay on one rank and constraint counts balance (greedy bin packing); per-frame
-regularisers are owned by rank (frame % world).  After local assembly, gradient / frame-diagonal blocks /
-cost are summed with ONE all-reduce per LM iteration (and one per PCG product for the matrix-free q).
+regularisers are owned by rank (frame % world); frames are OWNED in contiguous chunks of ceil(F / world).
+The exchange steps run inside the library over RCCL (cvd_comm.hip):
+  per Jacobian evaluation   all-reduce g and the per-frame costs, reduce-scatter H_ff to the frames' owners,
+                            all-gather diag(H) and the owners' f32 block inverses
+  per PCG iteration         reduce-scatter q to the owners + all-reduce [Z^T q | p.q] after the product, all-gather z / c /
+                            the r^T z shares after the owners' update -- two grouped collectives per iteration
+(dense mode: the pixel walk of a Jacobian evaluation is per pair and divides by the ranks; its per-pair records are folded on
+the rank that walked the pair, the sums above follow).
 
 Pure index bookkeeping: no optimizer arithmetic here.
 """

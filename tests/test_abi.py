@@ -1,4 +1,5 @@
-"""C-ABI library: loads without a GPU, exports every symbol include/cvd_hip.h declares, struct sizes agree."""
+"""C-ABI library: loads without a GPU, exports every symbol include/cvd_hip.h (the drop-in boundary) and include/cvd_hip_debug.h (test /
+measurement hooks) declare, struct sizes agree."""
 import ctypes as C
 import os
 import re
@@ -11,10 +12,13 @@ from robust_cvd_amd.ctypes_types import FramePose, IterationRecord, OptParams, S
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cvd_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cvd_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("cvd_hip.h", "cvd_hip_debug.h")):
+    names = set()
+    for hname in headers:
+        text = open(os.path.join(ROOT, "include", hname)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(cvd_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_symbols_are_exported():
@@ -22,8 +26,16 @@ def test_header_symbols_are_exported():
     names = declared_symbols()
     assert len(names) >= 30
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/cvd_hip.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert sorted(api.EXPORTED_SYMBOLS) == names
+    # the product header holds no test hook: debug options, simulated ranks and parity hooks of internal solves live in cvd_hip_debug.h
+    product = declared_symbols(("cvd_hip.h",))
+    for n in ("cvd_set_debug_options", "cvd_comm_init_local_group", "cvd_comm_init_phantom", "cvd_set_generic_kernels",
+              "cvd_block_inverse_debug", "cvd_dense_inverse_debug", "cvd_coarse_debug", "cvd_temporal_debug"):
+        assert n not in product and n in names
+    text = open(os.path.join(ROOT, "include", "cvd_hip.h")).read()
+    for hook in ("force_iterations", "force_sharded_path", "pcg_lockstep", "stall_fused_tail_once"):
+        assert not re.search(r"int32_t\s+" + hook, text), hook
 
 
 def test_struct_sizes_match_compiled_library():
@@ -61,7 +73,11 @@ def test_default_solver_options():
     assert o.constraint_order == 1
     assert (o.temporal_level, o.temporal_step, o.temporal_grid_x, o.temporal_grid_y) == (1, 32, 0, 0)
     assert (o.coarse_temporal_step, o.coarse_over_budget, o.coarse_temporal_min_frames, o.temporal_weight) == (8, 0, 128, 0.7)
-    assert (o.force_sharded_path, o.dense_matrix_free, o.block_inverse_variant, o.pcg_lockstep, o.force_iterations, o.verbose) == (0,) * 6
+    assert (o.dense_matrix_free, o.block_inverse_variant, o.verbose) == (0,) * 3
+    d = api.DebugOptions()
+    lib.cvd_debug_options_default(C.byref(d))
+    assert (d.force_sharded_path, d.pcg_lockstep, d.force_iterations, d.stall_fused_tail_once) == (0,) * 4
+    assert d.struct_size == C.sizeof(api.DebugOptions) | (api.ABI_REVISION << 32)
     csrc = os.path.join(ROOT, "robust_cvd_amd", "csrc")
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".h", ".cpp")):
@@ -95,11 +111,16 @@ def test_solver_options_are_validated():
     lib = api.load_library()
     o = api.SolverOptions()
     lib.cvd_solver_options_default(C.byref(o))
-    assert o.struct_size == C.sizeof(api.SolverOptions)
+    # sizeof in the low half, the header's revision in the high half (a removed int32 can hide behind the padding)
+    assert o.struct_size == C.sizeof(api.SolverOptions) | (api.ABI_REVISION << 32)
     assert lib.cvd_set_solver_options(s._h, C.byref(o)) == 0
-    o.struct_size -= 8
-    assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0
-    assert b"struct_size" in lib.cvd_last_error(s._h)
+    for stale in (o.struct_size - 8, C.sizeof(api.SolverOptions), C.sizeof(api.SolverOptions) | ((api.ABI_REVISION - 1) << 32)):
+        o.struct_size = stale
+        assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0
+        assert b"struct_size" in lib.cvd_last_error(s._h)
+    lib.cvd_solver_options_default(C.byref(o))
+    o.pcg_fused_tail = 2
+    assert lib.cvd_set_solver_options(s._h, C.byref(o)) != 0   # (the stall hook moved to cvd_debug_options)
     for field, bad in (("pcg_relative_tolerance", 0.0), ("pcg_relative_tolerance", float("nan")), ("pcg_max_iterations", 0),
                        ("coarse_dense_shift", -1.0), ("coarse_rebuild_excess", -1), ("coarse_dense_max_unknowns", 1 << 20),
                        ("coarse_level", 4), ("coarse_temporal_step", 1), ("coarse_over_budget", 2), ("coarse_dense_row_split", 9), ("temporal_level", 3), ("temporal_step", 1), ("temporal_grid_x", 1)):

@@ -21,8 +21,10 @@ SOURCE = f'''
 #include "{CSRC}/cvd_kernels.h"
 #include "{CSRC}/cvd_coarse.h"
 #include "{CSRC}/cvd_cross.h"
+#include "{CSRC}/cvd_dense_walk.h"
 namespace cvd {{
-template __global__ void k_cross_assemble<4, true>(Layout, Table, CrossPairs, const double*, const FrameConst*, int, double*);
+template __global__ void k_dense_walk<4>(Layout, Table, DenseWalkList, const double*, const FrameConst*, double*, double*);
+template __global__ void k_dense_gg<4>(Layout, Table, CrossPairs, const int*, const double*, int, DenseLaneMap, double*);
 template __global__ void k_cost_items_fast<4>(Layout, Table, Items, const double*, const FrameConst*, double*);
 template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*, double*);
 template __global__ void k_matvec_pairs_fast<4, 128>(Layout, Table, Items, const double*, const FrameConst*, const double*,
@@ -105,9 +107,18 @@ def test_update_kernel_register_budget(asm):
 
 def test_dense_mode_block_kernels(asm):
     """Explicit cross blocks (cvd_cross.h): the streaming product is light (no scratch, <= 64 VGPRs: latency is hidden by
-    occupancy); the grid-panel half of the assembly must not drag the pose Jacobians along (they are dead code there:
-    no scratch, well below the 256 VGPRs of the pose half)."""
+    occupancy)."""
     fields, _ = kernel_info(asm, "14k_cross_matvec")
     assert fields["private_segment_fixed_size"] == 0 and fields["next_free_vgpr"] <= 64, fields
-    fields, _ = kernel_info(asm, "16k_cross_assembleILi4ELb1")
-    assert fields["private_segment_fixed_size"] == 0 and fields["next_free_vgpr"] <= 168, fields
+
+
+def test_dense_walk_uses_the_matrix_pipe_and_stays_in_registers(asm):
+    """The dense mode's one-walk assembly (cvd_dense_walk.h): the pose Gram tile is accumulated by v_mfma_f64_16x16x4 (not by
+    per-lane accumulators: 45 of them would not fit), everything with a grid vertex by ds_add_f64; two waves per SIMD (<= 256 VGPRs)
+    with at most a handful of spilled values; the grid x grid kernel is small enough for sixteen waves per CU."""
+    fields, body = kernel_info(asm, "12k_dense_walk")
+    assert "v_mfma_f64_16x16x4" in body and "ds_add_f64" in body
+    assert fields["next_free_vgpr"] <= 256, fields
+    assert fields["private_segment_fixed_size"] <= 128, fields
+    fields, body = kernel_info(asm, "10k_dense_gg")
+    assert fields["next_free_vgpr"] <= 128 and fields["private_segment_fixed_size"] == 0, fields

@@ -907,7 +907,7 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
 
 
 def test_a_stalled_fused_tail_falls_back_to_the_two_launches(Solver, capfd):
-    """an abandoned grid barrier of k_pcg_tail is not an error.  pcg_fused_tail = 2 makes the host treat the third
+    """ADVICE r4: an abandoned grid barrier of k_pcg_tail is not an error.  cvd_debug_options::stall_fused_tail_once makes the host treat the third
     iteration of the first fused solve as such a stall: the handle must switch to the two-launch tail for good, repeat the solve from
     its start (state vectors and tickets re-initialised) and end where a handle that never used the fused kernel ends."""
     v = synth.make_video(24, 128, 72, seed=14, extra_offsets=6)
@@ -915,7 +915,7 @@ def test_a_stalled_fused_tail_falls_back_to_the_two_launches(Solver, capfd):
     def run(mode):
         s = Solver(0)
         synth.load_into(s, v)
-        s.set_options(pcg_fused_tail=mode, coarse_update_budget=0, coarse_over_budget=1)   # (the dense exact level: inside the fused scope)
+        s.set_options(pcg_fused_tail=min(mode, 1), stall_fused_tail_once=int(mode == 2), coarse_update_budget=0, coarse_over_budget=1)   # (the dense exact level: inside the fused scope)
         s.reset_depth_xforms(XformDesc.global_depth())
         s.reset_spatial_xforms(XformDesc.spatial())
         p = OptParams.defaults()
