@@ -294,7 +294,6 @@ def main():
                                  spacing=(1e9 if args.dense else 12.5))  # (dense: the sampled list is not used)
         solver = api.Solver(local_rank)
         if args.dense:
-            assert world == 1, "dense mode runs on one GPU"
             t_flow = time.perf_counter()
             video.dense_flow, video.dense_mask = synth.make_dense_flows(video)
             print(f"[bench] dense flows of {len(video.pairs)} pairs generated in {time.perf_counter() - t_flow:.1f} s", file=sys.stderr)
@@ -310,10 +309,18 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             solver.comm_init(rank, world, ids[0])
             all_pairs = video.pairs.copy()
-            mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
             video = copy.copy(video)
-            video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
-                full_video.pairs, full_video.offsets, full_video.loc, full_video.is_static, mine)
+            if args.dense:
+                # dense mode shards by pairs as well: every pair is width x height pixel slots, its walk is independent of the others'
+                mine = sharding.shard_pairs(full_video.pairs, sharding.uniform_offsets(len(full_video.pairs), width * height), world)[rank]
+                _, video.dense_flow, video.dense_mask = sharding.take_pair_flows(
+                    full_video.pairs, full_video.dense_flow, full_video.dense_mask, mine)
+                video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(   # (the sampled list: not used)
+                    full_video.pairs, full_video.offsets, full_video.loc, full_video.is_static, mine)
+            else:
+                mine = sharding.shard_pairs(video.pairs, video.offsets, world)[rank]
+                video.pairs, video.offsets, video.loc, video.is_static = sharding.take_pairs(
+                    full_video.pairs, full_video.offsets, full_video.loc, full_video.is_static, mine)
         if args.pcg_tol is not None:
             solver.set_options(pcg_relative_tolerance=args.pcg_tol)
         if args.pcg_lockstep:
@@ -395,6 +402,8 @@ def main():
                 if args.pcg_tol is not None:
                     single.set_options(pcg_relative_tolerance=args.pcg_tol)
                 synth.load_into(single, full_video, params.focal_long)
+                if args.dense:
+                    single.set_pair_flows(full_video.pairs, full_video.dense_flow, full_video.dense_mask)
                 from robust_cvd_amd.ctypes_types import XformDesc
                 single.reset_depth_xforms(XformDesc.grid_depth(*grid))
                 single.reset_spatial_xforms(XformDesc.spatial())

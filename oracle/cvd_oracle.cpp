@@ -2314,7 +2314,7 @@ struct Oracle {
   // focal columns stay 0 under Fixed intrinsics, both hold the one shared column under Shared).  Returns the number of blocks;
   // with null outputs only counts.
   int staticResiduals(const cvd_opt_params& p, double depthDeformReg, const double* pose7, int maxBlocks, int32_t* frames,
-                      double* obs /*8 per block*/, double* res /*3*/, double* jac /*3 x 14*/) {
+                      double* obs /*10 per block*/, double* res /*3*/, double* jac /*3 x 14*/) {
     if (pose7) {
       poseParams.resize(F);
       for (int f = 0; f < F; ++f)
@@ -2350,10 +2350,10 @@ struct Oracle {
           double c0[3], c1[3];
           obsToCamera(sc.obs0, p0, c0);
           obsToCamera(sc.obs1, p1, c1);
-          double* o = obs + static_cast<size_t>(8) * n;
+          double* o = obs + static_cast<size_t>(10) * n;
           o[0] = sc.obs0.ndc[0]; o[1] = sc.obs0.ndc[1]; o[2] = sc.obs1.ndc[0]; o[3] = sc.obs1.ndc[1];
           o[4] = c0[0]; o[5] = c0[1]; o[6] = c0[2]; o[7] = c1[2];
-          (void)c1[0];
+          o[8] = c1[0]; o[9] = c1[1];   // (the target's WARPED NDC: differs from ndc_b under a spatial transform)
         }
         for (int k = 0; k < 3; ++k) {
           res[3 * n + k] = r[k];
@@ -2368,6 +2368,79 @@ struct Oracle {
           } else if (p.intr_opt == CVD_INTR_PER_FRAME) {
             row[12] = J[static_cast<size_t>(k) * total + start[bf]];
             row[13] = J[static_cast<size_t>(k) * total + start[bf + 1]];
+          }
+        }
+      }
+      ++n;
+    }
+    return n;
+  }
+
+  // The depth-parameter columns of every StaticSceneCost block in a form code held by the reference can check
+  // (tests/test_reference_residuals.py: central differences of utils/geometry.py along the two deformed depths).  The depth functor
+  // is D = sum_k w_k V(d, theta_k) (reference lib/DepthMapTransform.cpp:597-606, lib/ValueTransform.h:59-81), so the dual-number
+  // column of theta_k[0] is (d r / d D) w_k d and that of theta_k[1] (ScaleShift) is (d r / d D) w_k.  Per block and side
+  // (0 = source, 1 = target):  jd[3] = column of the tap with the largest weight divided by that factor = d r / d D;
+  // euler[3] = sum over the side's depth columns of column x parameter (Scale: = (d r / d D) D); tapdev = largest deviation of any
+  // other tap's quotient from jd, relative to |jd|_max (0 when the columns are exactly rank one in (residual, tap)).
+  int staticResidualsDepth(const cvd_opt_params& p, double depthDeformReg, const double* pose7, int maxBlocks, double* jd /*3 x 2*/,
+                           double* euler /*3 x 2*/, double* tapdev /*2*/) {
+    if (pose7) {
+      poseParams.resize(F);
+      for (int f = 0; f < F; ++f)
+        for (int i = 0; i < 7; ++i) poseParams[f][i] = pose7[f * 7 + i];
+    } else {
+      posesToParams();
+    }
+    Problem pb;
+    buildPoseProblem(pb, p, depthDeformReg);
+    pb.finalize();
+    int n = 0;
+    for (const auto& rb : pb.residuals) {
+      const auto* cf = dynamic_cast<const AutoDiff<StaticSceneCost>*>(rb.cost.get());
+      if (!cf) continue;
+      if (jd && n < maxBlocks) {
+        const StaticSceneCost& sc = cf->f;
+        const int nb = static_cast<int>(rb.blocks.size());
+        int total = 0;
+        std::vector<int> start(nb);
+        for (int b = 0; b < nb; ++b) { start[b] = total; total += cf->blockSizes[b]; }
+        std::vector<const double*> pd(nb);
+        for (int b = 0; b < nb; ++b) pd[b] = pb.blocks[rb.blocks[b]].ptr;
+        std::vector<double> J(static_cast<size_t>(3) * total);
+        double r[3];
+        evaluateCostFunctionAt(*cf, pd.data(), r, J.data());
+        const Obs* obs[2] = {&sc.obs0, &sc.obs1};
+        const int first[2] = {1, sc.obs0.numBlocks() + 1};   // (block 0 of a side is its pose)
+        for (int side = 0; side < 2; ++side) {
+          const Obs& o = *obs[side];
+          double* q = jd + (static_cast<size_t>(n) * 3) * 2;
+          double* e = euler + (static_cast<size_t>(n) * 3) * 2;
+          for (int k = 0; k < 3; ++k) { q[k * 2 + side] = 0.0; e[k * 2 + side] = 0.0; }
+          tapdev[static_cast<size_t>(n) * 2 + side] = 0.0;
+          if (o.depthType == CVD_DEPTH_IDENTITY || o.dg.n == 0) continue;
+          const double d = static_cast<double>(o.sourceDepth);
+          int best = 0;
+          for (int i = 1; i < o.dg.n; ++i) if (o.dg.w[i] > o.dg.w[best]) best = i;
+          auto weightOf = [&](int i) { return o.depthType == CVD_DEPTH_GLOBAL ? 1.0 : static_cast<double>(o.dg.w[i]); };
+          double scale = 0.0;
+          for (int k = 0; k < 3; ++k) {
+            q[k * 2 + side] = J[static_cast<size_t>(k) * total + start[first[side] + best]] / (weightOf(best) * d);
+            scale = std::max(scale, std::abs(q[k * 2 + side]));
+          }
+          for (int i = 0; i < o.dg.n; ++i) {
+            const int b = first[side] + i;
+            for (int k = 0; k < 3; ++k) {
+              for (int a = 0; a < cf->blockSizes[b]; ++a) {
+                const double col = J[static_cast<size_t>(k) * total + start[b] + a];
+                e[k * 2 + side] += col * pd[b][a];
+                if (weightOf(i) > 1e-9) {
+                  const double quot = col / (weightOf(i) * (a == 0 ? d : 1.0));
+                  tapdev[static_cast<size_t>(n) * 2 + side] =
+                      std::max(tapdev[static_cast<size_t>(n) * 2 + side], std::abs(quot - q[k * 2 + side]) / std::max(scale, 1e-300));
+                }
+              }
+            }
           }
         }
       }
@@ -2637,6 +2710,16 @@ int cvdo_static_residuals(void* h, const cvd_opt_params* p, double depthDeformRe
   auto* o = static_cast<Oracle*>(h);
   try {
     return o->staticResiduals(*p, depthDeformReg, pose7, maxBlocks, frames, obs, res, jac);
+  } catch (const std::exception& e) {
+    o->lastError = e.what();
+    return -1;
+  }
+}
+int cvdo_static_residuals_depth(void* h, const cvd_opt_params* p, double depthDeformReg, const double* pose7, int maxBlocks,
+                                double* jd, double* euler, double* tapdev) {
+  auto* o = static_cast<Oracle*>(h);
+  try {
+    return o->staticResidualsDepth(*p, depthDeformReg, pose7, maxBlocks, jd, euler, tapdev);
   } catch (const std::exception& e) {
     o->lastError = e.what();
     return -1;

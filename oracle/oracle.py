@@ -123,6 +123,7 @@ def static_residuals(orc: Oracle, params, depth_deform_reg, pose_params=None):
     """Every StaticSceneCost block of the poseOptimizationStep problem at the current state, WITHOUT the robust loss
     (cvdo_static_residuals): frames [n, 2]; ndc_a / ndc_b [n, 2] (the stored float NDC of the two observations);
     cam_a [n, 3] = obsToCamera of the source (warped NDC x, y and deformed depth); depth_b [n] = the target's deformed depth;
+    cam_b [n, 3] = obsToCamera of the target (its warped NDC and deformed depth);
     residuals [n, 3]; jacobian [n, 3, 14] over [pose_a(6) | pose_b(6) | vfocal_a | vfocal_b] (dual numbers)."""
     fn = orc._fn("static_residuals")
     pp = np.ascontiguousarray(pose_params, np.float64).reshape(orc.num_frames, 7) if pose_params is not None else None
@@ -131,7 +132,7 @@ def static_residuals(orc: Oracle, params, depth_deform_reg, pose_params=None):
     if n < 0:
         orc._check(n)
     frames = np.zeros((n, 2), np.int32)
-    obs = np.zeros((n, 8), np.float64)
+    obs = np.zeros((n, 10), np.float64)
     res = np.zeros((n, 3), np.float64)
     jac = np.zeros((n, 3, 14), np.float64)
     m = fn(orc._h, C.byref(params), C.c_double(depth_deform_reg), ppp, C.c_int(n),
@@ -141,4 +142,26 @@ def static_residuals(orc: Oracle, params, depth_deform_reg, pose_params=None):
         orc._check(-1 if m < 0 else 0)
         raise RuntimeError("static_residuals: block count changed between calls")
     return dict(frames=frames, ndc_a=obs[:, 0:2].copy(), ndc_b=obs[:, 2:4].copy(), cam_a=obs[:, 4:7].copy(),
-                depth_b=obs[:, 7].copy(), residuals=res, jacobian=jac)
+                depth_b=obs[:, 7].copy(), cam_b=np.stack([obs[:, 8], obs[:, 9], obs[:, 7]], 1), residuals=res, jacobian=jac)
+
+
+def static_residuals_depth(orc: Oracle, params, depth_deform_reg, pose_params=None):
+    """The depth-parameter columns of every StaticSceneCost block, reduced to what a reference-held check can see
+    (cvdo_static_residuals_depth): d_r_d_depth [n, 3, 2] = d r / d D of the source (.., 0) and target (.., 1) deformed depth, recovered
+    from the dual-number column of the heaviest tap; euler [n, 3, 2] = sum over the side's depth columns of column x parameter;
+    tap_deviation [n, 2] = how far any other tap's column is from rank one in (residual, tap), relative."""
+    fn = orc._fn("static_residuals_depth")
+    pp = np.ascontiguousarray(pose_params, np.float64).reshape(orc.num_frames, 7) if pose_params is not None else None
+    ppp = pp.ctypes.data_as(C.POINTER(C.c_double)) if pp is not None else None
+    n = fn(orc._h, C.byref(params), C.c_double(depth_deform_reg), ppp, C.c_int(0), None, None, None)
+    if n < 0:
+        orc._check(n)
+    jd = np.zeros((n, 3, 2), np.float64)
+    eu = np.zeros((n, 3, 2), np.float64)
+    dev = np.zeros((n, 2), np.float64)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    m = fn(orc._h, C.byref(params), C.c_double(depth_deform_reg), ppp, C.c_int(n), dp(jd), dp(eu), dp(dev))
+    if m != n:
+        orc._check(-1 if m < 0 else 0)
+        raise RuntimeError("static_residuals_depth: block count changed between calls")
+    return dict(d_r_d_depth=jd, euler=eu, tap_deviation=dev)

@@ -44,3 +44,17 @@ def take_pairs(pairs, offsets, loc, is_static, idx):
     loc_o = np.concatenate(locs) if locs else np.zeros((0, loc.shape[1]), loc.dtype)
     st_o = np.concatenate(stat) if stat else np.zeros((0,), np.uint8)
     return pairs[idx], np.asarray(new_off, dtype=np.int64), loc_o, st_o
+
+
+def take_pair_flows(pairs, flow, mask, idx):
+    """Dense mode: the flow / mask images of the pairs in idx (kept in map order).  A pair's pixel walk is independent of every other
+    pair's (reference: one residual block per masked pixel of a pair, lib/FlowConstraints.cpp:381-395, lib/PoseOptimizer.cpp:1185-1232),
+    so the images shard with the pairs; every pair carries width x height candidate constraints, hence shard_pairs with uniform
+    offsets balances them."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    return pairs[idx], np.ascontiguousarray(flow[idx]), np.ascontiguousarray(mask[idx])
+
+
+def uniform_offsets(num_pairs, per_pair):
+    """offsets of a collection whose pairs all hold per_pair constraints (dense mode: width x height pixel slots)."""
+    return np.arange(num_pairs + 1, dtype=np.int64) * int(per_pair)

@@ -8,8 +8,9 @@ tests/reference_residuals.py.  Runs in the build container only (needs /root/ref
 Per case `<name>/...`: frames [n, 2], pose [F, 7] (the state), pixel_diff [n, 2] (pixels), disparity_diff [n],
 loss_reproj / loss_disp [n] (what ConsistencyLoss.geometry_consistency_loss returns per constraint), cost_gradient_fd [F, 7] (central
 differences of the cost formed from the reference terms along every pose parameter and focal length), fd_rows (indices of the
-constraints whose derivative rows are kept) and fd [len(fd_rows), 3, 14] (central differences of the torch functions along
-[pose_a(6) | pose_b(6) | vfocal_a | vfocal_b]).  The oracle-side inputs (NDC, deformed depths) are recomputed by the test
+constraints whose derivative rows are kept), fd [len(fd_rows), 3, 14] (central differences of the torch functions along
+[pose_a(6) | pose_b(6) | vfocal_a | vfocal_b]), fd_depth [len(fd_rows), 3, 2] (along the deformed depths D_a, D_b) and
+cost_gradient_theta_fd [F, nD] (central differences of the reference cost along every depth-transform parameter).  The oracle-side inputs (NDC, deformed depths) are recomputed by the test
 from the same seed; the input digest of every case's video is stored so that a drifted generator is noticed.
 """
 import os
@@ -36,8 +37,10 @@ def main():
         for k in ("frames", "pose", "pixel_diff", "disparity_diff", "loss_reproj", "loss_disp"):
             out[f"{name}/{k}"] = ref[k]
         out[name + "/cost_gradient_fd"] = rres.reference_cost_gradient(name)
+        out[name + "/cost_gradient_theta_fd"] = rres.reference_cost_gradient_theta(name)
         out[name + "/fd_rows"] = rows.astype(np.int32)
         out[name + "/fd"] = ref["fd"][rows]
+        out[name + "/fd_depth"] = ref["fd_depth"][rows]
         print(f"{name}: {len(ref['pixel_diff'])} constraints, |pixel diff| up to {np.abs(ref['pixel_diff']).max():.2f} px, "
               f"|disparity diff| up to {np.abs(ref['disparity_diff']).max():.4f}")
     np.savez_compressed(rres.GOLDEN, **out)

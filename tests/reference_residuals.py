@@ -20,9 +20,12 @@ Conversions (derived from the two statements, checked by the test itself):
     r_x / ws =  (pixels_tgt - matched).x / (W/2),   r_y / ws = -(pixels_tgt - matched).y / (H/2)
     r_z / wd = -(1 / z_tgt - 1 / z_warped)          (the reference's camera looks down -z: z = -depth)
 
-What the pin covers: a6 / a7 of SURVEY.md 8 -- the camera model, pose and projection conventions, the disparity term --
-as VALUES and first derivatives away from the optimum.  What it takes as given: the deformed depths D_a, D_b of the two
-observations (the depth functors are pinned by the goldens of tests/golden/, the reference samples a network output there).
+What the pin covers: a6 / a7 of SURVEY.md 8 -- the camera model, pose and projection conventions, the three depth terms
+(disparity, log depth, depth ratio) -- as VALUES and first derivatives away from the optimum: along pose (12), focal lengths (2)
+and, since round 6, along the two deformed depths D_a, D_b (2), which is what every depth-transform column of the optimizer's
+Jacobian is made of (d r / d theta_k = (d r / d D) w_k d_src); one case runs under a non-trivial bilinear spatial transform.  What it
+takes as given: the gather weights w_k of the depth / spatial functors (pinned by the goldens of tests/golden/; the reference samples
+a network output there).
 """
 import os
 import sys
@@ -44,6 +47,14 @@ CASES = {
     # term (loss/consistency_loss.py:124-140), the second of the optimizer's four static losses the reference's Python states
     "perframe_logdepth": dict(frames=6, width=64, height=48, seed=518, intr=IntrinsicsOptimization.PerFrame, grid=(4, 3),
                               loss=StaticLossType.ReproLogDepth),
+    # ReproDepthRatio (round 6): third residual = max / min - 1 of the same two depths (reference lib/PoseOptimizer.cpp:294-297); the
+    # Python reference has no term of this form, but the two depths it is made of are outputs of its functions
+    "perframe_ratio": dict(frames=6, width=64, height=48, seed=519, intr=IntrinsicsOptimization.PerFrame, grid=(4, 3),
+                           loss=StaticLossType.ReproDepthRatio),
+    # a bilinear SPATIAL transform with random non-zero parameters (round 6): both observations' warped NDC enter the camera model
+    # (reference lib/PoseOptimizer.cpp:162-175, lib/DepthMapTransform.cpp:1253-1343), i.e. the reference's functions see shifted pixels
+    "perframe_spatial3x2": dict(frames=6, width=64, height=48, seed=520, intr=IntrinsicsOptimization.PerFrame, grid=(4, 3),
+                                spatial=(3, 2)),
 }
 FD_STEP = 1e-6   # central differences of the torch functions (float64)
 
@@ -60,7 +71,11 @@ def make_state(name, binding=None):
     o = binding
     synth.load_into(o, v)
     o.reset_depth_xforms(XformDesc.grid_depth(*c["grid"]) if c["grid"] else XformDesc.global_depth())
-    o.reset_spatial_xforms(XformDesc.spatial())
+    if c.get("spatial"):
+        from robust_cvd_amd.ctypes_types import SpatialXformType
+        o.reset_spatial_xforms(XformDesc.spatial(SpatialXformType.BilinearGrid, *c["spatial"]))
+    else:
+        o.reset_spatial_xforms(XformDesc.spatial())
     rng = np.random.default_rng(c["seed"] + 7)
     F = v.num_frames
     pose = np.zeros((F, 7))
@@ -72,6 +87,9 @@ def make_state(name, binding=None):
     dx = o.get_xform_params(False)
     dx = v.frame_scale[:, None] * (1.0 + rng.uniform(-0.15, 0.15, dx.shape))
     o.set_xform_params(dx, False)
+    if c.get("spatial"):
+        sx = o.get_xform_params(True)
+        o.set_xform_params(rng.normal(0.0, 0.02, sx.shape), True)    # NDC units: ~1 px at 64 x 48
     p = OptParams.defaults()
     p.num_threads = 1
     p.intr_opt = int(c["intr"])
@@ -124,6 +142,12 @@ def _reference_modules():
     return geometry, ConsistencyLoss
 
 
+def loss_kind(name):
+    """False: ReproDisparity; True: ReproLogDepth; "ratio": ReproDepthRatio (the `log_depth` argument of the functions below)."""
+    loss = CASES[name].get("loss")
+    return "ratio" if loss == StaticLossType.ReproDepthRatio else (loss == StaticLossType.ReproLogDepth)
+
+
 def reference_terms(geometry, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b, log_depth=False, ext_b=None, intr_b=None):
     """The reference's functions, one constraint per batch entry as (n, C, 1, 1) float64 tensors: returns the pixel difference
     `project(reproject_points(pixels_to_points(..)))  - (pixels + flow)` [n, 2] and the disparity difference
@@ -139,7 +163,11 @@ def reference_terms(geometry, ext, intr, fa, fb, pix_a, depth_a, pix_b, depth_b,
     pixels_tgt = geometry.project(points_tgt, t(intr_b[fb]))
     matched = t(pix_b).view(n, 2, 1, 1)
     warped_tgt = geometry.pixels_to_points(t(intr_b[fb]), t(depth_b).view(n, 1, 1, 1), matched.clone())
-    if log_depth:
+    if isinstance(log_depth, str) and log_depth == "ratio":
+        # ReproDepthRatio, lib/PoseOptimizer.cpp:294-297: max / min - 1 of the same two depths (formed here from the functions' outputs)
+        dw, dt = torch.abs(warped_tgt[:, -1:, ...]), torch.abs(points_tgt[:, -1:, ...])
+        third = torch.max(dw, dt) / torch.min(dw, dt) - 1.0
+    elif log_depth:
         # loss/consistency_loss.py:130-137: log(min / max) of |z| of the warped target point and of the reprojected point
         dw, dt = torch.abs(warped_tgt[:, -1:, ...]), torch.abs(points_tgt[:, -1:, ...])
         third = torch.log(torch.min(dw, dt) / torch.max(dw, dt))
@@ -179,14 +207,17 @@ def reference_outputs(name):
     v, p, pose, sr = oracle_side(name)
     W, H = v.width, v.height
     fa, fb = sr["frames"][:, 0], sr["frames"][:, 1]
-    pix_a = to_pixels(sr["cam_a"][:, :2], W, H)      # (identity spatial transform: the warped NDC is the NDC)
-    pix_b = to_pixels(sr["ndc_b"], W, H)
+    pix_a = to_pixels(sr["cam_a"][:, :2], W, H)      # the WARPED NDC of both observations (identity spatial transform: the NDC)
+    pix_b = to_pixels(sr["cam_b"][:, :2], W, H)
     Da, Db = sr["cam_a"][:, 2], sr["depth_b"]
 
-    log_depth = CASES[name].get("loss") == StaticLossType.ReproLogDepth
+    log_depth = loss_kind(name)
     ext, intr = cameras(pose, v.aspect, W, H)
     dpx, ddisp = reference_terms(geometry, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
-    l_reproj, l_disp = reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
+    if log_depth == "ratio":   # (no term of this form in the Python reference: the loss method is not called)
+        l_reproj, l_disp = np.linalg.norm(dpx, axis=1) / 2.0, np.zeros(len(fa))
+    else:
+        l_reproj, l_disp = reference_loss_terms(ConsistencyLoss, ext, intr, fa, fb, pix_a, Da, pix_b, Db, log_depth)
     # central differences of the torch functions along the 7 parameters of frame a resp. frame b, per constraint:
     # perturbing parameter k of EVERY frame that is a constraint's source (resp. target) at once is not the same thing when a
     # frame is both, so source and target are perturbed through two copies of the camera tensors
@@ -205,7 +236,20 @@ def reference_outputs(name):
         fd[:, 0, col] = (out[0][0][:, 0] - out[1][0][:, 0]) / (2 * FD_STEP)
         fd[:, 1, col] = (out[0][0][:, 1] - out[1][0][:, 1]) / (2 * FD_STEP)
         fd[:, 2, col] = (out[0][1] - out[1][1]) / (2 * FD_STEP)
-    return dict(pixel_diff=dpx, disparity_diff=ddisp, loss_reproj=l_reproj, loss_disp=l_disp, fd=fd,
+    # ... and along the two deformed depths (round 6: what the theta columns of the optimizer's Jacobian are made of,
+    # d r / d theta_k = (d r / d D) w_k d_src): relative steps, one constraint per batch entry
+    fd_depth = np.zeros((n, 3, 2))
+    for side in range(2):
+        out = []
+        for sgn in (+1.0, -1.0):
+            da = Da * (1.0 + sgn * FD_STEP) if side == 0 else Da
+            db = Db * (1.0 + sgn * FD_STEP) if side == 1 else Db
+            out.append(reference_terms(geometry, ext, intr, fa, fb, pix_a, da, pix_b, db, log_depth))
+        h = 2 * FD_STEP * (Da if side == 0 else Db)
+        fd_depth[:, 0, side] = (out[0][0][:, 0] - out[1][0][:, 0]) / h
+        fd_depth[:, 1, side] = (out[0][0][:, 1] - out[1][0][:, 1]) / h
+        fd_depth[:, 2, side] = (out[0][1] - out[1][1]) / h
+    return dict(pixel_diff=dpx, disparity_diff=ddisp, loss_reproj=l_reproj, loss_disp=l_disp, fd=fd, fd_depth=fd_depth,
                 frames=sr["frames"], pose=pose)
 
 
@@ -213,7 +257,7 @@ def to_reference_units(sr, p, W, H):
     """The oracle's residuals / Jacobian rows in the reference's units (pixels, disparity): see the module docstring.
     (ReproLogDepth: the third residual IS log(min / max) times the depth weight -- no sign change.)"""
     ws, wd = p.static_spatial_weight, p.static_depth_weight
-    third = 1.0 / wd if p.static_loss_type == StaticLossType.ReproLogDepth else -1.0 / wd
+    third = 1.0 / wd if p.static_loss_type in (StaticLossType.ReproLogDepth, StaticLossType.ReproDepthRatio) else -1.0 / wd
     s = np.array([(W / 2.0) / ws, -(H / 2.0) / ws, third])
     return sr["residuals"] * s[None, :], sr["jacobian"] * s[None, :, None]
 
@@ -224,7 +268,7 @@ def cost_from_reference_terms(pixel_diff, third, p, W, H, log_depth=False):
     ws, wd, b2 = p.static_spatial_weight, p.static_depth_weight, p.robustness ** 2
     r0 = pixel_diff[:, 0] * ws / (W / 2.0)
     r1 = -pixel_diff[:, 1] * ws / (H / 2.0)
-    r2 = third * wd * (1.0 if log_depth else -1.0)
+    r2 = third * wd * (1.0 if log_depth else -1.0)   # (log depth and ratio enter as they are; the disparity term changes sign)
     s = r0 * r0 + r1 * r1 + r2 * r2
     return 0.5 * float(np.sum(b2 * np.log1p(s / b2)))
 
@@ -249,9 +293,9 @@ def reference_cost_gradient(name):
     without_regularisers(p)
     W, H = v.width, v.height
     fa, fb = sr["frames"][:, 0], sr["frames"][:, 1]
-    pix_a, pix_b = to_pixels(sr["cam_a"][:, :2], W, H), to_pixels(sr["ndc_b"], W, H)
+    pix_a, pix_b = to_pixels(sr["cam_a"][:, :2], W, H), to_pixels(sr["cam_b"][:, :2], W, H)
     Da, Db = sr["cam_a"][:, 2], sr["depth_b"]
-    log_depth = CASES[name].get("loss") == StaticLossType.ReproLogDepth
+    log_depth = loss_kind(name)
 
     def cost(ps):
         ext, intr = cameras(ps, v.aspect, W, H)
@@ -272,4 +316,38 @@ def reference_cost_gradient(name):
         a[:, 6] += FD_STEP
         b[:, 6] -= FD_STEP
         g[0, 6] = (cost(a) - cost(b)) / (2 * FD_STEP)
+    return g
+
+
+def reference_cost_gradient_theta(name):
+    """Central differences of the REFERENCE cost along every depth-transform parameter: [F, nD].  The deformed depths D_a, D_b that the
+    reference's functions are fed come from the oracle's depth functor at the perturbed parameters (the gathers are pinned by the goldens
+    of tests/golden/); everything downstream of them -- back-projection, re-projection, the three residual terms, the robust loss --
+    is the reference's own arithmetic.  (needs /root/reference)"""
+    from oracle import oracle as om
+    geometry, _cl = _reference_modules()
+    v, o, p, pose = make_state(name)
+    without_regularisers(p)
+    W, H = v.width, v.height
+    log_depth = loss_kind(name)
+    ext, intr = cameras(pose, v.aspect, W, H)
+    theta0 = o.get_xform_params(False).copy()
+
+    def cost(theta):
+        o.set_xform_params(theta, False)
+        sr = om.static_residuals(o, p, 0.0, pose)
+        fa, fb = sr["frames"][:, 0], sr["frames"][:, 1]
+        pix_a, pix_b = to_pixels(sr["cam_a"][:, :2], W, H), to_pixels(sr["cam_b"][:, :2], W, H)
+        d, t = reference_terms(geometry, ext, intr, fa, fb, pix_a, sr["cam_a"][:, 2], pix_b, sr["depth_b"], log_depth)
+        return cost_from_reference_terms(d, t, p, W, H, log_depth)
+
+    g = np.zeros_like(theta0)
+    for f in range(theta0.shape[0]):
+        for k in range(theta0.shape[1]):
+            a, b = theta0.copy(), theta0.copy()
+            h = FD_STEP * max(1.0, abs(theta0[f, k]))
+            a[f, k] += h
+            b[f, k] -= h
+            g[f, k] = (cost(a) - cost(b)) / (2 * h)
+    o.set_xform_params(theta0, False)
     return g

@@ -1,8 +1,10 @@
 """Reference-held pin of the RESIDUAL ARITHMETIC at random, NON-converged states: the oracle's
-three residuals of every static constraint -- ReproDisparity (the default loss) and ReproLogDepth --, and their dual-number
-Jacobian columns for pose and focal length, against the reference's own torch statement of the same quantities --
+three residuals of every static constraint -- ReproDisparity (the default loss), ReproLogDepth and ReproDepthRatio, one case under a
+bilinear spatial transform --, and their dual-number Jacobian columns for pose (12), focal lengths (2) and, through d r / d D of the
+two deformed depths (2), every depth-transform parameter, against the reference's own torch statement of the same quantities --
 utils/geometry.py:62-166 and the reprojection / disparity / depth-ratio terms of loss/consistency_loss.py:93-140 (see
-tests/reference_residuals.py for the conversions).
+tests/reference_residuals.py for the conversions).  The HIP path's cost and gradient (pose, focal and depth-transform rows) are held
+against the same reference outputs with no oracle in between (GPU tests at the end).
 
 CPU only.  Always: against tests/golden/reference_py/residual_golden.npz (outputs of the real reference functions, minted by
 make_residual_golden.py next to it).  With /root/reference mounted: against the live functions, including
@@ -46,6 +48,8 @@ def _check(name, v, p, pose, sr, ref, rows):
         # "depth ratio" term: |log(min / max)| / 2 per constraint (lambda = 1, no focal factor: loss/consistency_loss.py:124-140)
         assert np.abs(np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-12
         assert (r[:, 2] <= 0.0).all()
+    elif rres.CASES[name].get("loss") == StaticLossType.ReproDepthRatio:
+        assert (r[:, 2] >= 0.0).all()   # max / min - 1 (no term of this form in the reference's loss method)
     else:
         assert np.abs(f_mean * np.abs(r[:, 2]) / 2.0 - ref["loss_disp"]).max() < 1e-10
     # derivative columns: pose of the source (0-5), pose of the target (6-11), the focal lengths (12, 13)
@@ -65,6 +69,31 @@ def _check(name, v, p, pose, sr, ref, rows):
         assert np.abs(Jr[:, :, 12:]).max() == 0.0   # Fixed: no focal column
     # every translation / rotation / focal column carries signal (a column of zeros would pass a relative test vacuously)
     assert (np.abs(fd[:, :2, :12]).max(axis=(0, 1)) > 1.0).all()
+    if rres.CASES[name].get("spatial"):
+        assert np.abs(sr["cam_a"][:, :2] - sr["ndc_a"]).max() > 0.01   # (the spatial transform really moves the observations)
+
+
+def _check_depth_columns(name, v, p, pose, sr, sd, fd_depth, rows):
+    """The depth-transform columns of the oracle's dual-number Jacobian (round 6): every column of a side is (d r / d D) x the tap's
+    factor -- rank one in (residual, tap) to rounding -- and d r / d D of both sides equals the central differences of the
+    REFERENCE's functions along the deformed depth they are fed."""
+    W, H = v.width, v.height
+    ws, wd = p.static_spatial_weight, p.static_depth_weight
+    third = 1.0 / wd if p.static_loss_type in (StaticLossType.ReproLogDepth, StaticLossType.ReproDepthRatio) else -1.0 / wd
+    unit = np.array([(W / 2.0) / ws, -(H / 2.0) / ws, third])
+    J = sd["d_r_d_depth"] * unit[None, :, None]
+    assert sd["tap_deviation"].max() < 1e-10, sd["tap_deviation"].max()
+    Jr = J[rows]
+    scale = np.abs(fd_depth).max(axis=(0, 2), keepdims=True)
+    assert (scale > 0).all()
+    assert (np.abs(Jr - fd_depth) / scale).max() < FD_REL_TOL, (np.abs(Jr - fd_depth) / scale).max()
+    # the source depth moves the re-projected point (all three rows), the target depth only the third residual
+    assert np.abs(fd_depth[:, :2, 1]).max() < 1e-6 * scale[:, :2].max() and np.abs(fd_depth[:, 2, 1]).max() > 1e-3
+    assert np.abs(fd_depth[:, :2, 0]).max() > 1e-2
+    # Scale value transform: D is linear-homogeneous in the side's parameters, so sum_k theta_k d r / d theta_k = D d r / d D
+    D = np.stack([sr["cam_a"][:, 2], sr["depth_b"]], 1)
+    eul = sd["euler"] * unit[None, :, None]
+    assert np.abs(eul - J * D[:, None, :]).max() <= 1e-12 * np.abs(J * D[:, None, :]).max()
 
 
 CASE_INTR = {k: c["intr"] for k, c in rres.CASES.items()}
@@ -80,12 +109,26 @@ def test_oracle_residuals_match_the_committed_reference_outputs(name):
     _check(name, v, p, pose, sr, ref, g[name + "/fd_rows"])
 
 
+@pytest.mark.parametrize("name", sorted(rres.CASES))
+def test_oracle_depth_columns_match_the_committed_reference_differences(name):
+    from oracle import oracle as om
+    g = _golden()
+    v, o, p, pose = rres.make_state(name)
+    sr = om.static_residuals(o, p, 0.1, pose)
+    sd = om.static_residuals_depth(o, p, 0.1, pose)
+    _check_depth_columns(name, v, p, pose, sr, sd, g[name + "/fd_depth"], g[name + "/fd_rows"])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not mounted")
 @pytest.mark.parametrize("name", sorted(rres.CASES))
 def test_oracle_residuals_match_the_live_reference_functions(name):
     v, p, pose, sr = rres.oracle_side(name)
     ref = rres.reference_outputs(name)
     _check(name, v, p, pose, sr, ref, np.arange(len(ref["pixel_diff"])))
+    from oracle import oracle as om
+    _v, o, _p, _pose = rres.make_state(name)
+    sd = om.static_residuals_depth(o, p, 0.1, pose)
+    _check_depth_columns(name, v, p, pose, sr, sd, ref["fd_depth"], np.arange(len(ref["pixel_diff"])))
 
 
 def test_the_pin_can_tell_a_wrong_convention():
@@ -99,7 +142,7 @@ def test_the_pin_can_tell_a_wrong_convention():
 
 
 def _reference_cost(name, p, v, g):
-    logd = rres.CASES[name].get("loss") == StaticLossType.ReproLogDepth
+    logd = rres.loss_kind(name)
     return rres.cost_from_reference_terms(g[name + "/pixel_diff"], g[name + "/disparity_diff"], p, v.width, v.height, logd)
 
 
@@ -136,7 +179,13 @@ def test_hip_cost_equals_the_cost_of_the_reference_terms(name):
 
 
 def _check_gradient(name, grad, g):
-    """grad [F, B] (layout [t w f | theta]) of the regulariser-free problem against the central differences of the reference cost."""
+    """grad [F, B] (layout [t w f | theta | phi]) of the regulariser-free problem against the central differences of the reference cost:
+    pose and focal rows, and (round 6) the depth-transform rows."""
+    ft = g[name + "/cost_gradient_theta_fd"]
+    st = np.abs(ft).max()
+    assert st > 0.05   # (the depth rows carry signal as well)
+    Gt = grad[:, 7:7 + ft.shape[1]]
+    assert np.abs(Gt - ft).max() < 1e-9 * st + 1e-6, (np.abs(Gt - ft).max(), st)
     fd = g[name + "/cost_gradient_fd"]
     scale = np.abs(fd).max()
     assert scale > 10.0   # (the state is far from a minimum: the gradient carries signal)
