@@ -376,6 +376,7 @@ int32_t cvd_set_video(cvd_handle* h, int32_t numFrames, int32_t width, int32_t h
     h->P = 0;
     h->C = 0;
     h->dense = false;
+    h->denseListValid = false;
     // everything keyed by frame index belongs to the previous video (stale triplet centres / pair graph
     // indexed past a smaller F)
     h->haveTriplets = false;
@@ -438,6 +439,7 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t numPairs, const int32_t*
       if (pairFrames[2 * k] < 0 || pairFrames[2 * k] >= h->F || pairFrames[2 * k + 1] < 0 || pairFrames[2 * k + 1] >= h->F)
         throw std::runtime_error("pair frame out of range");
     h->dense = false;
+    h->denseListValid = false;
     h->dFlow.release();
     h->dFMask.release();
     h->P = numPairs;
@@ -517,6 +519,7 @@ int32_t cvd_set_pair_flows(cvd_handle* h, int32_t numPairs, const int32_t* pairF
     h->P = numPairs;
     h->C = static_cast<long long>(numPairs) * npx;
     h->dense = true;
+    h->denseListValid = false;
     h->tableValid = false;
   });
 }

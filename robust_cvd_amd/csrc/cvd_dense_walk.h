@@ -701,4 +701,60 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Dense mode OUTSIDE the scope of the kernels above (spatial transforms, Shared intrinsics, ScaleShift, bicubic grids, smoothness
+// triplets, the pair loop of normalizeDepth): the constraint LIST the images stand for -- what the reference's
+// FlowConstraintsCollection::compute builds with matchSeparation = 0 (lib/FlowConstraints.cpp:436-460: mask, target int(x + flow + 0.5)
+// in bounds; scaling :371) -- is materialised ON THE DEVICE, in row-major pixel order per pair, and the solve runs on the list-mode
+// kernels (every residual configuration).  24 B per constraint of table + 20 B of list: 6.4 GB for the 144 M constraints of the
+// benchmarked video -- what 288 GB of HBM are for; until round 5 such a solve was refused and lib_python built the list on the host.
+constexpr int kDlChunk = 4096;   // pixels per workgroup
+__device__ __forceinline__ bool denseCandidate(const Table& T, int pix, unsigned int m, float2 f, float4& loc) {
+  if (!m) return false;
+  const int iy = pix / T.W, ix = pix - iy * T.W;
+  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
+  if (!(isfinite(fx1) && isfinite(fy1))) return false;
+  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
+  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
+  loc = make_float4(__fmul_rn(static_cast<float>(ix), T.sx), __fmul_rn(static_cast<float>(iy), T.sy), __fmul_rn(fx1, T.sx), __fmul_rn(fy1, T.sy));
+  return true;
+}
+// pass 1: candidates per (pair, chunk); pass 2 (offsets != nullptr): write them at the chunk's offset in pixel order
+inline __global__ __launch_bounds__(256) void k_dense_list(Table T, int chunksPerPair, int* __restrict__ counts,
+                                                    const long long* __restrict__ offsets, float4* __restrict__ loc,
+                                                    int* __restrict__ cpair, unsigned char* __restrict__ isStatic) {
+  __shared__ int waveCount[4];
+  __shared__ int base;
+  const int p = blockIdx.x / chunksPerPair, ch = blockIdx.x - p * chunksPerPair;
+  const int npx = T.W * T.H;
+  const long long pixBase = static_cast<long long>(p) * npx;
+  const int p0 = ch * kDlChunk, p1 = min(npx, p0 + kDlChunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int total = 0;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int q0 = p0; q0 < p1; q0 += 256) {
+    const int pix = q0 + threadIdx.x;
+    float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool ok = false;
+    if (pix < p1) ok = denseCandidate(T, pix, (T.fmask + pixBase)[pix], (T.flow + pixBase)[pix], l);
+    const unsigned long long b = __ballot(ok);
+    if (lane == 0) waveCount[wave] = __popcll(b);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += waveCount[w];
+    if (offsets != nullptr && ok) {
+      const long long at = offsets[blockIdx.x] + before + __popcll(b & ((1ull << lane) - 1ull));
+      loc[at] = l;
+      cpair[at] = p;
+      isStatic[at] = 1;
+    }
+    total = base + waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+    __syncthreads();
+    if (threadIdx.x == 0) base = total;
+    __syncthreads();
+  }
+  if (offsets == nullptr && threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
 }  // namespace cvd

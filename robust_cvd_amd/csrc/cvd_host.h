@@ -263,6 +263,12 @@ struct cvd_handle_t {
   DevBuf<int> dDwPair, dDwRecOff, dXDir;
   DevBuf<double> dDwRecords, dDwGg;
   int nDwRecords = 0;
+  // dense mode outside the fast scope: the list the images stand for, materialised on the device (denseListEnter / Leave)
+  bool denseAsList = false;            // the handle currently runs a solve on the materialised list
+  bool denseListValid = false;         // dLoc / dCPair / dStatic / denseListOff hold the list of the current images
+  std::vector<long long> denseListOff; // pair offsets of the list
+  DevBuf<int> dDlCounts;
+  DevBuf<long long> dDlOffsets;
   DevBuf<unsigned int> dCounters;  // [0] k_matvec_finish, [1] k_cg_update (last-workgroup tickets)
   DevBuf<unsigned int> dTailBar;   // grid barrier of k_pcg_tail (tailArrive / tailWait)
   DevBuf<double> dOwnerScal;       // owner-sharded PCG iteration: {r^T z, r^T r} shares of every rank (all-gathered)
@@ -594,6 +600,14 @@ void tapCounts(const Layout& L, int& KD, int& KS);
 bool fastLoss(const Layout& L);
 Table makeTable(cvd_handle* h);
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip);
+bool denseFastScope(const cvd_handle* h, const Layout& L, int KS, bool trip);
+// RAII: a solve whose configuration lies outside the dense fast scope runs on the device-materialised list (cvd_dense_walk.h)
+struct DenseListScope {
+  cvd_handle* h;
+  bool entered = false;
+  DenseListScope(cvd_handle* h, bool needList);
+  ~DenseListScope();
+};
 bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const cvd_xform_desc& sd, bool haveTriplets, int world,
                         bool normalize);
 AsmPanels makePanels(int B, size_t capDoubles, int& panelCap);

@@ -374,13 +374,70 @@ bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const
   return 7 + g <= 256;
 }
 
-// Dense mode runs on the specialised fast kernels only (the default residual configuration of the reference pipeline).
+// Dense mode: the specialised kernels (pixel walk, image-reading product / cost) cover the default residual configuration of the
+// reference pipeline; every other configuration runs on the list the images stand for, materialised on the device (DenseListScope).
+bool denseFastScope(const cvd_handle* h, const Layout& L, int KS, bool trip) {
+  return !(KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || L.cubic);
+}
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
   if (!h->dense) return;
-  if (KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || L.cubic)
-    throw std::runtime_error("dense mode (cvd_set_pair_flows) supports the fast kernels' residual configurations only: identity "
-                             "spatial transform, a reprojection loss (ReproDisparity / ReproDepthRatio / ReproLogDepth), Scale "
-                             "value transform, Global or bilinear grid, per-frame or fixed intrinsics, no smoothness triplets");
+  if (!denseFastScope(h, L, KS, trip))
+    throw std::logic_error("dense mode: a configuration outside the fast kernels' scope reached them (DenseListScope should have taken it)");
+}
+DenseListScope::DenseListScope(cvd_handle* hh, bool needList) : h(hh) {
+  if (!h->dense || !needList) return;
+  hipStream_t s = h->stream;
+  const int npx = h->W * h->H;
+  const int chunks = (npx + kDlChunk - 1) / kDlChunk;
+  const size_t nwg = static_cast<size_t>(h->P) * chunks;
+  if (!h->denseListValid) {
+    const Table T = makeTable(h);
+    h->dDlCounts.ensure(std::max<size_t>(1, nwg));
+    h->dDlOffsets.ensure(std::max<size_t>(1, nwg));
+    std::vector<int> counts(nwg, 0);
+    if (nwg > 0) {
+      hipLaunchKernelGGL(k_dense_list, dim3(static_cast<unsigned>(nwg)), dim3(256), 0, s, T, chunks, h->dDlCounts.p, nullptr, nullptr, nullptr, nullptr);
+      HIP_CHECK(hipGetLastError());
+      h->dDlCounts.download(counts.data(), nwg, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+    std::vector<long long> offs(std::max<size_t>(1, nwg), 0);
+    h->denseListOff.assign(h->P + 1, 0);
+    long long o = 0;
+    for (int p = 0; p < h->P; ++p) {
+      h->denseListOff[p] = o;
+      for (int c = 0; c < chunks; ++c) { offs[static_cast<size_t>(p) * chunks + c] = o; o += counts[static_cast<size_t>(p) * chunks + c]; }
+    }
+    h->denseListOff[h->P] = o;
+    h->dLoc.ensure(std::max<long long>(o, 1));
+    h->dCPair.ensure(std::max<long long>(o, 1));
+    h->dStatic.ensure(std::max<long long>(o, 1));
+    if (nwg > 0) {
+      h->dDlOffsets.upload(offs.data(), offs.size(), s);
+      hipLaunchKernelGGL(k_dense_list, dim3(static_cast<unsigned>(nwg)), dim3(256), 0, s, T, chunks, h->dDlCounts.p, h->dDlOffsets.p, h->dLoc.p,
+                         h->dCPair.p, h->dStatic.p);
+      HIP_CHECK(hipGetLastError());
+    }
+    h->denseListValid = true;
+  }
+  // the handle runs this solve as a list-mode handle
+  h->dense = false;
+  h->denseAsList = true;
+  h->pairOff = h->denseListOff;
+  h->C = h->denseListOff[h->P];
+  h->dPairOff.upload(h->pairOff.data(), h->pairOff.size(), s);
+  h->tableValid = false;
+  entered = true;
+}
+DenseListScope::~DenseListScope() {
+  if (!entered) return;
+  const long long npx = static_cast<long long>(h->W) * h->H;
+  h->dense = true;
+  h->denseAsList = false;
+  for (int p = 0; p <= h->P; ++p) h->pairOff[p] = static_cast<long long>(p) * npx;
+  h->C = static_cast<long long>(h->P) * npx;
+  try { h->dPairOff.upload(h->pairOff.data(), h->pairOff.size(), h->stream); } catch (...) {}
+  h->tableValid = false;
 }
 // Row panels of the packed lower triangle of a B x B frame block that fit `capDoubles` of LDS each (AsmPanels,
 // cvd_kernels.h): one panel up to B = 199, two at the reference's default deferred-spatial block B = 201.

@@ -289,6 +289,8 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   checkFrameBlock(static_cast<size_t>(c.L.B), "solve");
   tapCounts(c.L, c.KD, c.KS);
   phase("layout");
+  // dense mode outside the fast kernels' scope: this solve runs on the device-materialised list (flipped back when the solve ends)
+  DenseListScope denseList(h, h->dense && c.L.includeStatic && !denseFastScope(h, c.L, c.KS, wantsTriplets(p, kind)));
   compileTable(h, range, wantsTriplets(p, kind), kind == PK_NORMALIZE && c.L.includeStatic);
   orderTable(h, c.L, c.KD);
   phase("table");
@@ -676,6 +678,7 @@ void evaluate(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, con
   c.h = h;
   c.L = makeLayout(h, p, depthDeformReg, PK_POSE_STEP);
   tapCounts(c.L, c.KD, c.KS);
+  DenseListScope denseList(h, h->dense && !denseFastScope(h, c.L, c.KS, wantsTriplets(p, PK_POSE_STEP)));
   compileTable(h, range, wantsTriplets(p, PK_POSE_STEP));
   orderTable(h, c.L, c.KD);
   refreshMedians(h);

