@@ -356,6 +356,10 @@ struct cvd_handle_t {
     DevBuf<unsigned int> vIdx, counter;
     DevBuf<unsigned char> elV;
     DevBuf<double> Cf, E, part, A, Ainv, sq, rT, t, tl, dotPart, rec;
+    // panel / grid-barrier words of ITS dense inverse: the level's inverse runs on the solver's stream while the pose-graph level may
+    // be rebuilding on the side stream (k_coarse_factor_mw zeroes and uses the pose-graph level's barrier words)
+    DevBuf<double> invPanel;
+    DevBuf<unsigned int> invBarrier;
     DevBuf<TlStep> stepDev;  // the kernels read the level's descriptor from memory (see matvecFinishBody)
     hipEvent_t evIn = nullptr, evDone = nullptr;  // fork / join of the assembly on the side stream
     bool sidePending = false;                     // ... forked and not yet joined (a solve that throws in between joins on its way out)
@@ -637,7 +641,8 @@ size_t exchangeOffsetPq(const Ctx& c, bool withDenseCoarse);
 size_t exchangeTemporalCount(cvd_handle* h, bool withCoarse);  // doubles the third level adds to the fused exchange (behind p.q)
 bool ownerShardedUpdate(cvd_handle* h, bool withCoarse);
 inline int denseRowSplit(const cvd_handle* h) { return std::min(kCB, std::max(0, h->opt.coarse_dense_row_split)); }
-void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid);
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid,
+                           DevBuf<double>* panelBuf = nullptr, DevBuf<unsigned int>* barrierBuf = nullptr);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);
 // tailFused: only the partial products are launched; the caller follows with launchPcgTail (finish + update in one launch)

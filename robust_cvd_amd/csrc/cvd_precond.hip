@@ -112,8 +112,12 @@ void launchBlockInverse(Ctx& c) {
 
 // out (f64, n x n) = A^-1 for one dense SPD f64 matrix (cvd_dense_inverse.h): one persistent launch, one workgroup per
 // super-tile of S x S 16-wide tiles, S the smallest for which the grid fits one workgroup per CU.
-void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid) {
-  auto& C = h->coarse;
+void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid,
+                           DevBuf<double>* panelBuf, DevBuf<unsigned int>* barrierBuf) {
+  // (scratch of the caller's level: two levels' inverses / factors may run on different streams at once -- the gate below orders the
+  // persistent kernels, not the memsets of their barrier words)
+  DevBuf<double>& densePanel = panelBuf ? *panelBuf : h->coarse.densePanel;
+  DevBuf<unsigned int>& barrier = barrierBuf ? *barrierBuf : h->coarse.barrier;
   const int nT = (n + kInvTS - 1) / kInvTS;
   int S = 1;
   auto groups = [&](int sv) { const int nS = (nT + sv - 1) / sv; return nS * (nS + 1) / 2; };
@@ -122,10 +126,10 @@ void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, i
   const int tpw = (S * S + kDinvNW - 1) / kDinvNW;
   const size_t lds = static_cast<size_t>(4 * S + 1 + kDinvNW) * kInvTile * sizeof(double);
   if (tpw > 25 || lds > kMaxLds) throw std::runtime_error(fmt("dense coarse level: %d unknowns are too many for the dense inverse", n));
-  C.densePanel.ensure(static_cast<size_t>(2) * nT * 256 + 2 * 256);
-  C.barrier.ensure(4);
-  HIP_CHECK(hipMemsetAsync(C.barrier.p, 0, 4 * sizeof(unsigned int), s));
-  double* panel = C.densePanel.p;
+  densePanel.ensure(static_cast<size_t>(2) * nT * 256 + 2 * 256);
+  barrier.ensure(4);
+  HIP_CHECK(hipMemsetAsync(barrier.p, 0, 4 * sizeof(unsigned int), s));
+  double* panel = densePanel.p;
   double* pinv = panel + static_cast<size_t>(2) * nT * 256;
   // The kernel's grid barrier needs every workgroup RESIDENT (ADVICE r3 / VERDICT r3 Weak #8).  (i) The grid is checked
   // against the kernel's occupancy on this device.  (ii) Persistent kernels of different handles of this process (the
@@ -145,7 +149,7 @@ void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, i
                                    "(%d per CU x %d CUs at %zu B of LDS)", groups(S), perCu_, h->numCU, lds));            \
     PersistentGate gate(h->device, s);                                                                                   \
     hipLaunchKernelGGL((k_dense_spd_inverse<TPWV>), dim3(groups(S)), dim3(kDinvNW * 64), lds, s, n, S, nS, A, out, fail, panel, \
-                       pinv, C.barrier.p, outValid);                                                                    \
+                       pinv, barrier.p, outValid);                                                                      \
   } while (0)
   if (tpw <= 2) CVD_LAUNCH_DINV(2);
   else if (tpw <= 5) CVD_LAUNCH_DINV(5);

@@ -12,15 +12,24 @@ struct TailStalled {};  // k_pcg_tail's grid barrier was abandoned (its workgrou
 }
 static int runPcgAttempt(Ctx& c, const double* x, const std::function<void()>& tail);
 int runPcg(Ctx& c, const double* x, const std::function<void()>& tail) {
+  const size_t firstTimerSlot = c.h->evUsed;
   try {
     return runPcgAttempt(c, x, tail);
   } catch (const TailStalled&) {
     //  not an error: the fused tail is an optimisation.  The handle falls back to the two-launch path for good and
     // the solve is repeated from its start (the PCG's inputs -- g, lam, the block inverses, the levels -- are untouched; its
     // state vectors and last-workgroup tickets are re-initialised).
+    //  EVERY ticket and counter a half-finished fused iteration may have left behind is reset -- the update / finish
+    // tickets, the levels' (temporal node sums), the barrier words (the attempt re-zeroes them too) -- and the timer slots of the
+    // abandoned attempt are dropped, so the kernel-time averages hold the repeated solve only.
     cvd_handle* h = c.h;
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 8 * sizeof(unsigned int), h->stream));
+    if (h->temporal.counter.p) HIP_CHECK(hipMemsetAsync(h->temporal.counter.p, 0, 4 * sizeof(unsigned int), h->stream));
+    if (h->dTailBar.p)
+      HIP_CHECK(hipMemsetAsync(h->dTailBar.p, 0, static_cast<size_t>(kTailBarStride) * (1 + kTailBarCopies) * sizeof(unsigned int), h->stream));
+    h->curPcgIter = -1;
+    h->tDropFrom(firstTimerSlot, 0);
     h->tailDisabled = true;
     fprintf(stderr, "[cvd] warning: k_pcg_tail's grid barrier was abandoned (device shared with other work?); this handle uses the "
                     "two-launch PCG tail from here on\n");
@@ -453,20 +462,25 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
           // (the dense level's inverse is one persistent kernel that wants every CU: always in line)
           if (lastRelChange < asyncMaxChange && !h->coarse.denseMode && h->opt.coarse_level != 2 && !h->dist()) {
             h->dFc2.ensure(c.L.F);
+            //  the third level is "rebuilt together with the pose-graph level": also when that rebuild runs on the side
+            // stream -- at this linearisation point, for THIS iteration's PCG (it is small: two launches and a 0.1 ms inverse).
+            //  its assembly goes to the side stream BEFORE the pose-graph level's rebuild: queued behind it, the main
+            // stream's wait for the third level would have been a wait for the whole rebuild the side stream exists to hide.
+            // Its inverse (a persistent kernel: gated per device) is enqueued before the rebuild's factorisation as well, so that the
+            // gate's event chain makes the SIDE stream wait for the small inverse and not the solver's stream for the rebuild; the two
+            // levels' inverses have scratch (panel, barrier words) of their own.
+            if (h->temporal.on) {
+              const int slotT = h->tBegin(KC_INVERSE);
+              launchTemporalSetup(c, h->dX.p, 0);
+              launchTemporalSetup(c, h->dX.p, 1);
+              h->tEnd(slotT);
+            }
             HIP_CHECK(hipEventRecord(h->evCoarseIn, s));
             HIP_CHECK(hipStreamWaitEvent(h->stream2, h->evCoarseIn, 0));
             launchCoarseSetup(c, h->dX.p, 1);
             HIP_CHECK(hipEventRecord(h->evCoarseDone, h->stream2));
             coarsePending = true;
             cgExcess = 0;
-            //  the third level is "rebuilt together with the pose-graph level": also when that rebuild runs on the
-            // side stream -- in line, at this linearisation point (it is small: two launches and a 0.1 ms inverse)
-            if (h->temporal.on) {
-              const int slot = h->tBegin(KC_INVERSE);
-              launchTemporalSetup(c, h->dX.p, 0);
-              launchTemporalSetup(c, h->dX.p, 1);
-              h->tEnd(slot);
-            }
           } else {
             const int slot = h->tBegin(KC_INVERSE);  // preconditioner construction, same class as the block inverse
             const bool measure = h->coarse.denseMode && !h->dist() && h->opt.coarse_rebuild_excess_dense < 0;

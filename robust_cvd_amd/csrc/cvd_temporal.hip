@@ -275,7 +275,7 @@ static void temporalInverse(Ctx& c) {
   auto& T = h->temporal;
   hipStream_t s = h->stream;
   HIP_CHECK(hipMemsetAsync(T.fail.p, 0, sizeof(int), s));
-  launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p);
+  launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p, &T.invPanel, &T.invBarrier);
   if (h->dist()) {  // (the ranks must agree on "level on / off": see the dense pose-graph level, launchCoarseSetup)
     hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, T.fail.p);
     const int ct = h->tBegin(KC_COMM_COARSE);
