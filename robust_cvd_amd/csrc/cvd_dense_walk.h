@@ -757,4 +757,129 @@ inline __global__ __launch_bounds__(256) void k_dense_list(Table T, int chunksPe
   if (offsets == nullptr && threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LIST MODE: the off-diagonal blocks of the pose-graph level, E_ab = Z_a^T X_ab Z_b with Z = [I_7 0; 0 1] (cvd_coarse.h), on the
+// matrix pipe.  k_coarse_edges_fast keeps the 8 x 8 block in 64 per-lane accumulators (128 VGPRs) beside both sides' projected
+// Jacobians: 288 us per build of the level on the benchmarked list, on the critical path of every solve's first iteration.  The 16
+// projected columns [J_s Z (8) | J_t Z (8)] of a constraint's three residual rows are exactly one v_mfma_f64_16x16x4 tile wide: the
+// rows sqrt(rho') [..] go through the wave's staging tile and the Gram tile's off-diagonal quadrant IS the block (dir 0: rows = modes
+// of the source; dir 1, source = fb: transposed).  Scope: bilinear depth grid with one value parameter (KD = 4, N = 1), every pair
+// kept; elsewhere k_coarse_edges_fast / k_coarse_edges.
+inline __global__ __launch_bounds__(256) void k_coarse_edges_mfma(Layout L, Table T, Items it, const double* __restrict__ x,
+                                                           const FrameConst* __restrict__ fc, const int* __restrict__ itemEdge,
+                                                           double* __restrict__ edgeOut) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int B = L.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* xa = sm;
+  double* xb = xa + B;
+  double* Es = xb + B;                        // [2][256] the two directions' Gram tiles, summed over the waves
+  double* scr = Es + 512 + wave * (64 * kDwLd);
+  const int item = blockIdx.x;
+  const int fa = it.fa[item], fb = it.fb[item];
+  for (int i = tid; i < B; i += 256) {
+    xa[i] = x[static_cast<size_t>(fa) * B + i];
+    xb[i] = x[static_cast<size_t>(fb) * B + i];
+  }
+  for (int i = tid; i < 512; i += 256) Es[i] = 0.0;
+  __syncthreads();
+  const int mk = lane >> 4, mc = lane & 15;
+  for (int dir = 0; dir < 2; ++dir) {
+    const long long cb = it.range[item * 4 + dir * 2], ce = it.range[item * 4 + dir * 2 + 1];
+    if (cb >= ce) continue;   // (workgroup-uniform)
+    const FrameConst& Fs = fc[dir ? fb : fa];
+    const FrameConst& Ft = fc[dir ? fa : fb];
+    const double* xs = dir ? xb : xa;
+    const double* xt = dir ? xa : xb;
+    DwPairConst P;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { P.Rs[i] = uniformValue(Fs.R[i]); P.Rt[i] = uniformValue(Ft.R[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.dT[i] = uniformValue(Fs.t[i] - Ft.t[i]);
+    P.fys = uniformValue(Fs.fy);
+    P.fxs = uniformValue(Fs.fy * L.aspect);
+    P.ifys = uniformValue(1.0 / Fs.fy);
+    P.ifyt = uniformValue(1.0 / Ft.fy);
+    P.ifxt = uniformValue(1.0 / (Ft.fy * L.aspect));
+    cvd_d4 tile = {0.0, 0.0, 0.0, 0.0};
+    const int n = static_cast<int>(ce - cb);
+    for (int k0 = 0; k0 < n; k0 += 256) {
+      const int k = k0 + tid;
+      float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
+      float2 d = make_float2(0.f, 0.f);
+      bool valid = false;
+      if (k < n) valid = loadConstraint<false>(T, cb + k, 0, 0, 0, nd, d);
+      if (__builtin_amdgcn_readfirstlane(__ballot(valid) == 0ull ? 1 : 0)) continue;
+      DwState ch;
+      double sw = 0.0, zf = 0.0, da = 0.0, db = 0.0;
+      double y[3] = {0.0, 0.0, 0.0};
+      if (valid) {
+        DwTaps ts, tt;
+        da = static_cast<double>(d.x);
+        db = static_cast<double>(d.y);
+        dwGather(L, nd.x, nd.y, ts);
+        dwGather(L, nd.z, nd.w, tt);
+        dwChain(L, P, xs, xt, nd, da, db, ts, tt, ch);
+        sw = ch.sw;
+        zf = -ch.zz * P.ifyt;
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2) y[i2] = ch.Rca[i2] * ch.Da;
+      }
+#pragma unroll 1
+      for (int r = 0; r < 3; ++r) {
+        if (valid) {
+          const double mu0 = r == 0 ? ch.m00 : 0.0, mu1 = r == 1 ? ch.m11 : 0.0;
+          const double mu2 = r == 0 ? ch.m02 : (r == 1 ? ch.m12 : ch.m22);
+          double F[kDwFeat], jds;
+          dwFeatures(ch, P, y, mu0, mu1, mu2, r == 2 ? 0.0 : mu2 * zf, 0.0, F, jds);
+          const double* g = F;
+          const double* nn = F + 3;   // y x g
+          double J[16];
+          J[0] = g[0]; J[1] = g[1]; J[2] = g[2];
+          J[8] = -g[0]; J[9] = -g[1]; J[10] = -g[2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double* as = Fs.Jl + 3 * i;
+            const double* at = Ft.Jl + 3 * i;
+            J[3 + i] = as[0] * nn[0] + as[1] * nn[1] + as[2] * nn[2];
+            // a_t . (g x v) = g . (dT x a_t) - a_t . (y x g)
+            const double c0 = P.dT[1] * at[2] - P.dT[2] * at[1], c1 = P.dT[2] * at[0] - P.dT[0] * at[2], c2 = P.dT[0] * at[1] - P.dT[1] * at[0];
+            J[11 + i] = (g[0] * c0 + g[1] * c1 + g[2] * c2) - (at[0] * nn[0] + at[1] * nn[1] + at[2] * nn[2]);
+          }
+          J[6] = F[6];
+          J[7] = jds * da;                                  // uniform depth-scale mode of the source: sum_k d r / d theta_k = JD d_src
+          J[14] = F[7];
+          J[15] = r == 2 ? ch.JDT2 * db : 0.0;              // ... of the target
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) scr[lane * kDwLd + cc] = sw * J[cc];
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) scr[lane * kDwLd + cc] = 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double a0 = scr[(4 * j + mk) * kDwLd + mc];
+          tile = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, tile, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(&Es[dir * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)], tile[q]);
+  }
+  __syncthreads();
+  // rows = modes of fa, columns = modes of fb: dir 0 (source = fa) the quadrant [0:8, 8:16], dir 1 (source = fb) [8:16, 0:8]
+  const int edge = itemEdge[item];
+  if (tid < kCBB && edge >= 0) {
+    const int i = tid >> 3, j = tid & 7;
+    atomicAdd(&edgeOut[static_cast<size_t>(edge) * kCBB + tid], Es[i * 16 + 8 + j] + Es[256 + (8 + i) * 16 + j]);
+  }
+}
+
 }  // namespace cvd

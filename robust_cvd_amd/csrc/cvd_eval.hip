@@ -84,7 +84,7 @@ double evalCost(Ctx& c, const double* x) {
 void enqueueStats(Ctx& c) {
   cvd_handle* h = c.h;
   const int G = static_cast<int>(std::min<size_t>(128, (c.n + 511) / 512));
-  h->dStatPart.ensure(6 * 128);
+  h->dStatPart.ensure(7 * 128);
   hipLaunchKernelGGL(k_step_stats, dim3(G), dim3(256), 0, h->stream, c.n, h->dDx.p, h->dG.p, h->dR.p, h->dLam.p,
                      h->dX.p, h->dHd.p, h->dScal.p, h->dStatPart.p, h->dCounters.p + 2);
   HIP_CHECK(hipGetLastError());

@@ -220,6 +220,7 @@ enum : int { S_RZ = 0, S_RZOLD = 1, S_BETA = 2, S_PQ = 3, S_ALPHA = 4, S_RR = 5,
              // the host may enqueue iterations ahead of the convergence test without changing the result.
              S_DONE = 15, S_TARGET = 16, S_ITERS = 17,
              S_RZPART = 18,  // block-Jacobi part of r^T z while the coarse level (cvd_coarse.h) is pending
+             S_NACTIVE = 19, // number of active unknowns (k_step_stats)
              S_COUNT = 20 };
 
 // Sum of a short global array (F per-frame partials, L2-resident) by every workgroup that needs the scalar:
@@ -2693,51 +2694,56 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
   TAIL_STAMP(4);
 }
 
-// Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|.
+// Step statistics (one block): d.g, d.r, d.(lam d), |d|^2, |x|^2 (active unknowns), max |g|, and the number of active unknowns
+// (entries of diag(H) that are not zero: what the host used to count from a downloaded copy at the start of every solve).
 inline __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ dx,
                                                     const double* __restrict__ g, const double* __restrict__ r,
                                                     const double* __restrict__ lam, const double* __restrict__ x,
                                                     const double* __restrict__ hdiagActive, double* __restrict__ scal,
                                                     double* __restrict__ part, unsigned int* __restrict__ counter) {
   // gridDim.x workgroups stride over the vector; the last one to arrive folds the per-workgroup partials
-  __shared__ double red[6][4];
+  constexpr int NQ = 7;   // sums 0..4 and 6, maximum 5
+  __shared__ double red[NQ][4];
   __shared__ int flag;
   const int G = gridDim.x;
-  double a[6] = {0, 0, 0, 0, 0, 0};
+  double a[NQ] = {0, 0, 0, 0, 0, 0, 0};
   for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(G) * 256) {
     const double d = dx[i];
     a[0] += d * g[i];
     a[1] += d * r[i];
     a[2] += d * lam[i] * d;
     a[3] += d * d;
-    if (hdiagActive[i] != 0.0) a[4] += x[i] * x[i];
+    if (hdiagActive[i] != 0.0) { a[4] += x[i] * x[i]; a[6] += 1.0; }
     a[5] = fmax(a[5], fabs(g[i]));
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) a[k] = waveSum(a[k]);
+  for (int k = 0; k < NQ; ++k)
+    if (k != 5) a[k] = waveSum(a[k]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) a[5] = fmax(a[5], __shfl_xor(a[5], off, 64));
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 6] = a[k];
+    for (int k = 0; k < NQ; ++k) red[k][threadIdx.x >> 6] = a[k];
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < NQ) {
     const int k = threadIdx.x;
-    part[k * G + blockIdx.x] = (k < 5) ? (red[k][0] + red[k][1]) + (red[k][2] + red[k][3])
-                                       : fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
+    part[k * G + blockIdx.x] = (k != 5) ? (red[k][0] + red[k][1]) + (red[k][2] + red[k][3])
+                                        : fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
   }
   if (!lastBlockArrives(counter, G, &flag)) return;
-  double t[6] = {0, 0, 0, 0, 0, 0};
+  double t[NQ] = {0, 0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < G; b += 256) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) t[k] += part[k * G + b];
+    for (int k = 0; k < NQ; ++k)
+      if (k != 5) t[k] += part[k * G + b];
     t[5] = fmax(t[5], part[5 * G + b]);
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) t[k] = waveSum(t[k]);
+  for (int k = 0; k < NQ; ++k)
+    if (k != 5) t[k] = waveSum(t[k]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t[5] = fmax(t[5], __shfl_xor(t[5], off, 64));
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 6] = t[k];
+    for (int k = 0; k < NQ; ++k) red[k][threadIdx.x >> 6] = t[k];
   __syncthreads();
   if (threadIdx.x == 0) {
     scal[S_DG] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -2746,6 +2752,7 @@ inline __global__ __launch_bounds__(256) void k_step_stats(size_t n, const doubl
     scal[S_DD] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
     scal[S_XX] = red[4][0] + red[4][1] + red[4][2] + red[4][3];
     scal[S_GMAX] = fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
+    scal[S_NACTIVE] = red[6][0] + red[6][1] + red[6][2] + red[6][3];
   }
 }
 

@@ -187,7 +187,13 @@ void launchCoarseSetup(Ctx& c, const double* x, int side) {
     } else if (c.nItems > 0) {
       const bool fast = !h->forceGeneric && c.KS == 0 && fastLoss(c.L) &&
                         c.L.intrOpt != CVD_INTR_SHARED;  // (scope of the fast kernels)
-      if (fast) {
+      // (bilinear one-parameter grids, every pair kept, list mode: the 16 projected columns are one MFMA tile wide -- cvd_dense_walk.h)
+      const bool gram = fast && !h->dense && c.KD == 4 && c.L.N == 1 && !C.sparsified && CVD_DETERMINISTIC == 0;
+      if (gram) {
+        const size_t ldsG = (2 * B + 512 + 4 * 64 * kDwLd) * 8;
+        allowLds(k_coarse_edges_mfma, ldsG);
+        hipLaunchKernelGGL(k_coarse_edges_mfma, dim3(c.nItems), dim3(256), ldsG, s, c.L, c.T, c.it, x, fcBuf, C.itemEdgeDev.p, C.edges.p);
+      } else if (fast) {
         CVD_DISPATCH_KD(c.KD, {
           if (h->dense) {
             allowLds((k_coarse_edges_fast<KD, true>), ldsE);

@@ -345,28 +345,15 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
 
   double tEval = 0.0, tLin = 0.0;
   double te = nowSeconds();
-  double xCost = evalFull(c, h->dX.p);
+  // first evaluation: cost, |g|_max, |x| and the number of active unknowns arrive with ONE read-back (until round 5: the cost, then the
+  // statistics, then a downloaded copy of diag(H) counted on the host -- three round trips of 25 - 55 us at the start of every solve)
+  double xCost = evalFull(c, h->dX.p, true, false);
   tEval += nowSeconds() - te;
   sum.initial_cost = xCost;
   phase("first eval");
-
-  auto stats = [&]() {
-    enqueueStats(c);
-    readScalars(c);
-  };
-  HIP_CHECK(hipMemsetAsync(h->dLam.p, 0, c.n * sizeof(double), s));
-  stats();
   double gmax = h->hScal[S_GMAX];
   double xNorm = std::sqrt(h->hScal[S_XX]);
-  {
-    // number of active unknowns
-    std::vector<double> hd(c.n);
-    h->dHd.download(hd.data(), c.n, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-    int na = 0;
-    for (double v : hd) na += (v != 0.0);
-    sum.num_parameters = na;
-  }
+  sum.num_parameters = static_cast<int>(h->hScal[S_NACTIVE] + 0.5);
   phase("stats");
 
   double radius = Ceres::initial_radius;
