@@ -90,11 +90,12 @@ __device__ __forceinline__ bool dinvGridBarrier(unsigned int* counter, unsigned 
 // Bit 30 of *fail = barrier timeout.
 // panel: 2 x nT x 256 doubles, pinv: 2 x 256 doubles, barrier: three zeroed words (arrivals, abandon flag, bad pivots);
 // *fail zeroed by the host.  gridDim.x = nS (nS + 1) / 2.
+// (body: `bid` of `nGroupsArg` workgroups invert ONE matrix; the kernels below run it for one matrix or -- round 6 -- for two
+// independent matrices in one launch, blockIdx.y = matrix, each with its own panel / barrier words)
 template <int TPW>
-inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n, int S, int nS, const double* __restrict__ A,
-                                                                           double* __restrict__ out, int* __restrict__ fail,
-                                                                           double* __restrict__ panel, double* __restrict__ pinv,
-                                                                           unsigned int* __restrict__ barrier, int* __restrict__ outValid) {
+__device__ __forceinline__ void dinvBody(int n, int S, int nS, const double* __restrict__ A, double* __restrict__ out, int* __restrict__ fail,
+                                         double* __restrict__ panel, double* __restrict__ pinv, unsigned int* __restrict__ barrier,
+                                         int* __restrict__ outValid, int bid, unsigned int nGroupsArg) {
   extern __shared__ __attribute__((aligned(16))) double dinvSmem[];
   __shared__ int barrierOk;
   // S^2 <= 8 TPW tiles per workgroup => (2 S + 1) x 256 panel elements over 512 threads
@@ -104,10 +105,10 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, r0 = lane >> 4;
   // super-tile (SI >= SJ) of this workgroup
-  int SI = static_cast<int>((sqrtf(8.f * static_cast<float>(blockIdx.x) + 1.f) - 1.f) * 0.5f);
-  while ((SI + 1) * (SI + 2) / 2 <= static_cast<int>(blockIdx.x)) ++SI;
-  while (SI * (SI + 1) / 2 > static_cast<int>(blockIdx.x)) --SI;
-  const int SJ = static_cast<int>(blockIdx.x) - SI * (SI + 1) / 2;
+  int SI = static_cast<int>((sqrtf(8.f * static_cast<float>(bid) + 1.f) - 1.f) * 0.5f);
+  while ((SI + 1) * (SI + 2) / 2 <= bid) ++SI;
+  while (SI * (SI + 1) / 2 > bid) --SI;
+  const int SJ = bid - SI * (SI + 1) / 2;
   const int rowBase = SI * S, colBase = SJ * S;
   double* arow = dinvSmem;                      // [S] A(rowBase + m, k)
   double* acol = arow + S * kInvTile;           // [S] A(colBase + m, k)
@@ -229,7 +230,7 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   }
   publish(0);
   CVD_DINV_T(0);
-  const unsigned int nGroups = gridDim.x;
+  const unsigned int nGroups = nGroupsArg;
   bool alive = true;
   for (int k = 0; k < nT; ++k) {
     if (!dinvGridBarrier(barrier, static_cast<unsigned int>(k + 1) * nGroups, fail, &barrierOk)) { alive = false; break; }
@@ -332,10 +333,10 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   // (every pivot was inverted before the last barrier: the count is final)
   const unsigned int nBad = __hip_atomic_load(barrier + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (nBad != 0u) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *outValid == 0) atomicOr(fail, 1);
+    if (bid == 0 && threadIdx.x == 0 && *outValid == 0) atomicOr(fail, 1);
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *outValid = 1;
+  if (bid == 0 && threadIdx.x == 0) *outValid = 1;
 
   // A^-1 = -G: the tile as it lies and its mirror image (transposed through the private LDS tile); a diagonal tile is
   // averaged with its own transpose (its two halves were updated independently and differ in the last bits), so that the
@@ -361,9 +362,38 @@ inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n
   }
 #ifdef CVD_DINV_PROFILE
   CVD_DINV_T(6);
-  if (lane == 0 && blockIdx.x < 256)
-    for (int q = 0; q < 8; ++q) g_dinvProf[(blockIdx.x * kDinvNW + w) * 8 + q] = prof[q];
+  if (lane == 0 && bid < 256)
+    for (int q = 0; q < 8; ++q) g_dinvProf[(bid * kDinvNW + w) * 8 + q] = prof[q];
 #endif
+}
+
+template <int TPW>
+inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse(int n, int S, int nS, const double* __restrict__ A,
+                                                                           double* __restrict__ out, int* __restrict__ fail,
+                                                                           double* __restrict__ panel, double* __restrict__ pinv,
+                                                                           unsigned int* __restrict__ barrier, int* __restrict__ outValid) {
+  dinvBody<TPW>(n, S, nS, A, out, fail, panel, pinv, barrier, outValid, static_cast<int>(blockIdx.x), gridDim.x);
+}
+
+// Two independent matrices in one launch (the two temporal levels of the preconditioner: 312 and 495 unknowns at 300 frames, 123 + 160 us
+// one after the other).  Their pivot chains are sequential in themselves and independent of each other: side by side they take the
+// longer one's time.  Every workgroup of BOTH must be resident (the launcher checks the sum against the device).
+struct DinvJob {
+  int n, S, nS, groups;
+  const double* A;
+  double* out;
+  int* fail;
+  double* panel;
+  double* pinv;
+  unsigned int* barrier;
+  int* outValid;
+};
+template <int TPW>
+inline __global__ __launch_bounds__(kDinvNW * 64) void k_dense_spd_inverse_pair(DinvJob j0, DinvJob j1) {
+  const DinvJob& J = blockIdx.y ? j1 : j0;
+  if (static_cast<int>(blockIdx.x) >= J.groups) return;   // (workgroup-uniform; the job's barrier counts J.groups arrivals)
+  dinvBody<TPW>(J.n, J.S, J.nS, J.A, J.out, J.fail, J.panel, J.pinv, J.barrier, J.outValid, static_cast<int>(blockIdx.x),
+                static_cast<unsigned int>(J.groups));
 }
 
 #undef DINV_LI

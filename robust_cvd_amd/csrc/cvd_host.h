@@ -335,6 +335,8 @@ struct cvd_handle_t {
     DevBuf<unsigned char> modeActive;
     DevBuf<int> fail;
     DevBuf<unsigned int> barrier;  // grid barrier words of k_coarse_factor_mw / k_dense_spd_inverse
+    bool ptInvPending = false;     // the temporal pose level's inverse waits for the depth-grid level's (one launch for both)
+    int* ptInvFail = nullptr;
     // second set of the factor's outputs: a rebuild runs on a side stream while the PCG of the same LM iteration
     // still uses the previous factor (launchCoarseSetup / the LM loop)
     DevBuf<double> Wb2;
@@ -643,6 +645,16 @@ bool ownerShardedUpdate(cvd_handle* h, bool withCoarse);
 inline int denseRowSplit(const cvd_handle* h) { return std::min(kCB, std::max(0, h->opt.coarse_dense_row_split)); }
 void launchDenseSpdInverse(cvd_handle* h, int n, const double* A, double* out, int* fail, hipStream_t s, int* outValid,
                            DevBuf<double>* panelBuf = nullptr, DevBuf<unsigned int>* barrierBuf = nullptr);
+struct DinvRequest {
+  int n = 0;
+  const double* A = nullptr;
+  double* out = nullptr;
+  int* fail = nullptr;
+  int* outValid = nullptr;
+  DevBuf<double>* panelBuf = nullptr;
+  DevBuf<unsigned int>* barrierBuf = nullptr;
+};
+void launchDenseSpdInversePair(cvd_handle* h, const DinvRequest& a, const DinvRequest& b, hipStream_t s);
 CoarseView coarseView(cvd_handle* h, bool on, bool walk);
 void prepareMatvec(Ctx& c, const double* x);
 // tailFused: only the partial products are launched; the caller follows with launchPcgTail (finish + update in one launch)
@@ -665,7 +677,7 @@ const TlStep* temporalStepDev(cvd_handle* h);       // its device copy for the k
 // temporal pose level (coarse_level 3)
 void poseTemporalPlan(cvd_handle* h);                                   // node-pair lists for the compiled table's edge graph
 void poseTemporalPrepare(Ctx& c);                                       // buffers + descriptors of this solve
-void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut);      // from the coarse level's diag / edge blocks: matrix + inverse
+void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut, bool deferInverse = false);      // from the coarse level's diag / edge blocks: matrix + inverse
 void launchPoseTemporalInit(Ctx& c, double tol2);                       // first residual: t, c, closes the PCG scalars
 const TlStep* poseTemporalStepDev(cvd_handle* h);                       // nullptr unless this solve uses the level
 void coarseDebug(cvd_handle* h, int32_t* num_unknowns, double* a_c, double* a_c_inverse, int32_t* failed);

@@ -316,6 +316,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
+  h->coarse.ptInvPending = false;   // (a request left behind by a solve that threw)
   h->temporal.on = temporalScope(c);
   if (h->temporal.on) h->temporal.on = temporalPrepare(c);
   if (h->coarseOn && h->coarse.temporalPose) poseTemporalPrepare(c);

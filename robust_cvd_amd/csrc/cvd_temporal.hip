@@ -275,7 +275,16 @@ static void temporalInverse(Ctx& c) {
   auto& T = h->temporal;
   hipStream_t s = h->stream;
   HIP_CHECK(hipMemsetAsync(T.fail.p, 0, sizeof(int), s));
-  launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p, &T.invPanel, &T.invBarrier);
+  if (h->coarse.ptInvPending) {
+    auto& C = h->coarse;
+    C.ptInvPending = false;
+    DinvRequest a, b;
+    a.n = C.ptN; a.A = C.ptMat.p; a.out = C.ptInv.p; a.fail = C.ptInvFail; a.outValid = C.denseValid.p;
+    b.n = T.NT; b.A = T.A.p; b.out = T.Ainv.p; b.fail = T.fail.p; b.outValid = T.valid.p; b.panelBuf = &T.invPanel; b.barrierBuf = &T.invBarrier;
+    launchDenseSpdInversePair(h, a, b, s);
+  } else {
+    launchDenseSpdInverse(h, T.NT, T.A.p, T.Ainv.p, T.fail.p, s, T.valid.p, &T.invPanel, &T.invBarrier);
+  }
   if (h->dist()) {  // (the ranks must agree on "level on / off": see the dense pose-graph level, launchCoarseSetup)
     hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, T.fail.p);
     const int ct = h->tBegin(KC_COMM_COARSE);
@@ -387,7 +396,7 @@ void poseTemporalPrepare(Ctx& c) {
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
-void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut) {
+void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut, bool deferInverse) {
   cvd_handle* h = c.h;
   auto& C = h->coarse;
   HIP_CHECK(hipMemsetAsync(C.ptMat.p, 0, static_cast<size_t>(C.ptN) * C.ptN * sizeof(double), s));
@@ -395,6 +404,11 @@ void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut) {
                      C.ptList.p, C.diag.p, C.edges.p, C.edgeFa.p, C.edgeFb.p, C.modeActive.p, C.ptMat.p);
   hipLaunchKernelGGL(k_tl_shift_diag, dim3((C.ptN + 255) / 256), dim3(256), 0, s, C.ptN, C.ptN, C.ptMat.p, h->opt.coarse_dense_shift);
   HIP_CHECK(hipGetLastError());
+  if (deferInverse && s == h->stream) {   // (the depth-grid level's inverse follows on this stream: temporalInverse launches both)
+    C.ptInvPending = true;
+    C.ptInvFail = failOut;
+    return;
+  }
   launchDenseSpdInverse(h, C.ptN, C.ptMat.p, C.ptInv.p, failOut, s, C.denseValid.p);
 }
 
