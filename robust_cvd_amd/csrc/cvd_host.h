@@ -435,7 +435,8 @@ struct cvd_handle_t {
   // ---- timing helpers --------------------------------------------------------------------------------
   int tBegin(int kc) {
     if (kc >= KC_COUNT ? timing == 0 : !(timing & (1 << kc))) return -1;
-    if (timingStride > 1 && (timingCounterKc[kc]++ % timingStride) != 0) return -1;  // uniform sample of the class' launches
+    // (uniform sample of the class' launches; the dense mode's walks, a handful of long launches per solve, are all timed)
+    if (timingStride > 1 && kc < KC_DENSE_WALK && (timingCounterKc[kc]++ % timingStride) != 0) return -1;
     if (evUsed == evPool.size()) {
       hipEvent_t a, b;
       HIP_CHECK(hipEventCreate(&a));

@@ -20,6 +20,13 @@ rm -rf $OUT/pmc_sq
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL --kernel-include-regex "k_dense_walk|k_dense_gg" --output-format csv -d $OUT/pmc_sq_b -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_sq_b.log 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc_sq_b $OUT/pmc_SQ_dense_b.csv > /dev/null 2>&1
 rm -rf $OUT/pmc_sq_b
+# HBM traffic of the walk (separate passes per counter: MI355X_MICROARCH.md; FETCH_SIZE is doubled when read against a byte count)
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CNT --kernel-include-regex "k_dense_walk|k_dense_gg" --output-format csv -d $OUT/pmc_$CNT -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_$CNT.log 2>&1
+  python $R/tools/pmc_summary.py $OUT/pmc_$CNT $OUT/pmc_${CNT}_dense.csv > /dev/null 2>&1
+  rm -rf $OUT/pmc_$CNT
+done
 head -14 $OUT/kernel_durations_dense.txt | cut -c1-180
 cat $OUT/pmc_SQ_dense.csv
 cat $OUT/pmc_SQ_dense_b.csv
+cat $OUT/pmc_FETCH_SIZE_dense.csv $OUT/pmc_WRITE_SIZE_dense.csv

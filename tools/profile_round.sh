@@ -2,7 +2,7 @@
 # Collects the round's committed evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC traffic passes, SQ counters,
 # LM timeline, workgroup stamps of the hot product.
 # usage (through gpurun): bash tools/profile_round.sh <tag>       (then copy the summaries from gpurun_out/<tag> into profiles/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,6 +19,7 @@ CMD_MAIN="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary
 $B --steps 20 --warmup 3 --time-all-kernels > $OUT/bench_allkernels.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 20 --warmup 3 --no-kernel-timing > $OUT/trace.log 2>&1
 python $R/tools/lm_timeline.py $OUT/trace > $OUT/lm_timeline.txt 2>&1
+python $R/tools/solve_timeline.py $OUT/trace 3 > $OUT/solve_timeline.txt 2>&1
 # SQ counters of the PCG kernels (wave cycles: parked / issue-stalled / active; VALU and LDS activity)
 K="k_matvec_pairs_fast|k_pcg_tail|k_assemble_fast"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq_a -- $B --steps 4 --warmup 1 --pcg-lockstep > $OUT/pmc_sq_a.log 2>&1
@@ -26,12 +27,12 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
 python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_huber.json 2>> $OUT/bench.err
 python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300.json 2>> $OUT/bench.err
-CMD_DENSE="python bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense -- python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/trace_dense.log 2>&1
-python $R/tools/kernel_durations.py $OUT/trace_dense $TAG "$CMD_DENSE" > $OUT/kernel_durations_dense.txt 2>&1
-rm -rf $OUT/trace_dense
+# dense mode: kernel trace, SQ counters and HBM traffic of the one-walk assembly (tools/dense_profile.sh writes into the same directory)
+bash $R/tools/dense_profile.sh $TAG 300 > $OUT/dense_profile.log 2>&1
 # what one rank of an N-rank run computes per PCG iteration (pair-sharded, phantom communicator)
 timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
+timeout 400 python $R/tools/shard_sim.py 1 2 4 8 --dense 2>/dev/null | grep "^world" >> $OUT/shard_sim.log
+timeout 400 python $R/tools/shard_sim.py 1 2 4 8 --config4 2>/dev/null | grep "^world" >> $OUT/shard_sim.log
 # where the workgroups of the hot product spend their life (stamp variant of the library, built before the call)
 [ -f $R/robust_cvd_amd/lib/libcvd_hip_mvprof.so ] && timeout 200 python $R/tools/mv_profile.py 2>/dev/null | grep -v "$F" > $OUT/mv_profile.log
 # the two-launch tail for comparison (cvd_solver_options::pcg_fused_tail = 0)

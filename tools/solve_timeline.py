@@ -13,8 +13,13 @@ for r in csv.DictReader(open(fn)):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvd::", "")
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
-# a solve starts with the first k_frame_consts after a gap > 150 us that is followed by an assembly (first evaluation)
-starts = [i for i in range(1, len(rows)) if rows[i][2].startswith("k_frame_consts") and rows[i][0] - rows[i - 1][1] > 150e3]
+# a timed solve starts with an assembly (the first evaluation) that follows host-to-device uploads of the start state and no candidate-cost pass
+asm = [i for i, r in enumerate(rows) if r[2].startswith(("k_assemble_fast", "k_dense_walk")) and (r[1] - r[0]) / 1e3 > 250]
+starts = []
+for i in asm:
+    back = [rows[j][2] for j in range(max(0, i - 12), i)]
+    if sum(1 for b in back if "copyBuffer" in b) >= 2 and not any(b.startswith("k_cost_items") for b in back):
+        starts.append(max(0, i - 14))
 if len(starts) < which + 1:
     print("not enough solves in the trace:", len(starts))
     sys.exit(0)
