@@ -38,7 +38,13 @@
 namespace cvd {
 
 constexpr int kDwThreads = CVD_DETERMINISTIC ? 64 : 512;
-constexpr int kDwLd = 17;            // row stride (doubles) of the per-wave MFMA staging tile [64 constraints][16 columns]
+constexpr int kDwLd = 17;            // row stride (doubles) of a 16-column MFMA staging tile [64 constraints][16 columns] (k_coarse_edges_mfma)
+constexpr int kDwLdF = 10;           // ... of the walk's 9-feature tile (conflict-free: 20 i mod 64 is injective over a 16-lane group); the
+                                     // lanes of the seven unused columns read a zero word
+constexpr int kDwBlk = 8;            // pixels of a lane's run that are loaded together (one 64 B line of flow)
+constexpr int kDwIoStride = 9;       // per-run stride of the wave's input tiles [64 runs][8 pixels] (9 is odd: conflict-free by lane)
+// input tiles of a wave: flow (float2, reused for the grid x grid scalars: double) | source depth | target depth | mask
+constexpr int kDwIoBytes = 64 * kDwIoStride * (8 + 4 + 4 + 1);
 // (dwRecordDoubles, DenseRecords: cvd_kernels.h, beside the frame-major kernel that folds the records)
 constexpr int kDwCols = 15;          // side-block columns of a record
 
@@ -61,12 +67,17 @@ inline DenseLaneMap denseLaneMap(int W, int H) {
   return m;
 }
 // first pixel of the lane's run in unit u (row-major index within the image) and the run's length (0: the lane idles)
-__device__ __forceinline__ int denseLaneRun(const DenseLaneMap& m, int W, int H, int lane, int u, int& len) {
+__device__ __forceinline__ int denseLaneRunRC(const DenseLaneMap& m, int W, int H, int lane, int u, int& len, int& row, int& col) {
   const int rg = lane / m.lanesPerRow, cb = lane - rg * m.lanesPerRow;
-  const int row = rg * m.bandH + u, col = cb * m.run;
+  row = rg * m.bandH + u;
+  col = cb * m.run;
   const int rowEnd = (rg + 1) * m.bandH < H ? (rg + 1) * m.bandH : H;
   len = (rg < m.rowGroups && row < rowEnd) ? (col + m.run <= W ? m.run : W - col) : 0;
   return row * W + col;
+}
+__device__ __forceinline__ int denseLaneRun(const DenseLaneMap& m, int W, int H, int lane, int u, int& len) {
+  int row, col;
+  return denseLaneRunRC(m, W, H, lane, u, len, row, col);
 }
 
 // Work list: one record per directed pair.
@@ -117,29 +128,27 @@ __device__ __forceinline__ void dwGather(const Layout& L, float lx, float ly, Dw
   t.i0 = ix + iy * L.gx;
 }
 
-// The walk's loads run two pixels ahead: mask byte and flow vector of pixel t + 2 are requested while the two depths of pixel
-// t + 1 -- whose target address follows from its flow vector -- are, and pixel t is worked on with everything in registers.
-// (RecordStream<true> keeps one pixel's mask and flow in flight and takes the depth round trip, an L2 / HBM latency, in every
-// trip: waves parked 32 % of their cycles at two waves per SIMD.)  A masked-out or out-of-bounds candidate is encoded as d.x = 0.
-__device__ __forceinline__ float2 denseDepthsAhead(const Table& T, int ix, int iy, bool ok, unsigned int m, float2 f, int fa, int fb) {
-  float2 d = make_float2(0.f, 0.f);
-  if (!ok || !m) return d;
-  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-  if (!(isfinite(fx1) && isfinite(fy1))) return d;
-  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return d;
+// The pixel whose source depth a constraint at pixel (ix, iy) reads (the reference's Observation constructor truncates the float
+// location times the raster size, lib/PoseOptimizer.cpp:104-116: not always (ix, iy) itself), and the target's for flow f; -1: no candidate.
+__device__ __forceinline__ int denseSourceDepthIndex(const Table& T, int ix, int iy) {
   const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
-  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
   int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
   int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
+  ax = min(max(ax, 0), T.W - 1);
+  ay = min(max(ay, 0), T.H - 1);
+  return ay * T.W + ax;
+}
+__device__ __forceinline__ int denseTargetDepthIndex(const Table& T, int ix, int iy, float2 f) {
+  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
+  if (!(isfinite(fx1) && isfinite(fy1))) return -1;
+  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
+  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return -1;
+  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
   int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
   int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
-  ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
-  bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
-  const size_t fsz = static_cast<size_t>(T.W) * T.H;
-  d.x = T.depth[fa * fsz + static_cast<size_t>(ay) * T.W + ax];
-  d.y = T.depth[fb * fsz + static_cast<size_t>(by) * T.W + bx];
-  return d;
+  bx = min(max(bx, 0), T.W - 1);
+  by = min(max(by, 0), T.H - 1);
+  return by * T.W + bx;
 }
 
 // Constants of the directed pair, wave-uniform (SGPRs: a VALU instruction takes one scalar operand).
@@ -288,7 +297,8 @@ __device__ unsigned long long g_dwProf[4096 * 8];
 constexpr int kDwFeatS = kDwFeat, kDwFeatT = 6;
 __host__ __device__ inline int dwAccDoubles(int G) { return 256 + (kDwFeatS + kDwFeatT + 10) * G + 8; }
 __host__ __device__ inline size_t dwLdsBytes(int G, int B, int threads) {
-  return (static_cast<size_t>(dwAccDoubles(G)) + 2 * B + static_cast<size_t>(threads / 64) * 64 * kDwLd) * 8;
+  return (static_cast<size_t>(dwAccDoubles(G)) + 2 * B + 2 + static_cast<size_t>(threads / 64) * 64 * kDwLdF) * 8 +
+         static_cast<size_t>(threads / 64) * ((kDwIoBytes + 15) / 16 * 16);
 }
 
 #ifndef DW_WAVES
@@ -312,7 +322,15 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
   double* bandT = bandS + 5 * G;          // [5][G], then the cost
   double* xs = acc + accN;
   double* xt = xs + B;
-  double* scr = xt + B + wave * (64 * kDwLd);
+  double* zeroWord = xt + B;                                   // what the lanes of the unused MFMA columns read
+  double* scr = zeroWord + 2 + wave * (64 * kDwLdF);
+  // the wave's input tiles [64 runs][8 pixels] (stride 9): one 64 B line of flow per run and block, loaded by eight adjacent lanes
+  unsigned char* ioBase = reinterpret_cast<unsigned char*>(zeroWord + 2 + NW * (64 * kDwLdF)) + wave * ((kDwIoBytes + 15) / 16 * 16);
+  float2* ioF = reinterpret_cast<float2*>(ioBase);             // flow; after a pixel's trip: its grid x grid scalar (double)
+  double* ioG = reinterpret_cast<double*>(ioBase);
+  float* ioDa = reinterpret_cast<float*>(ioBase + 64 * kDwIoStride * 8);
+  float* ioDb = ioDa + 64 * kDwIoStride;
+  unsigned char* ioM = reinterpret_cast<unsigned char*>(ioDb + 64 * kDwIoStride);
   const int rec = blockIdx.x;
   const int p = wl.pair[rec];
   const int fs = T.pairA[p], ft = T.pairB[p];
@@ -322,8 +340,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
     xs[i] = x[static_cast<size_t>(fs) * B + i];
     xt[i] = x[static_cast<size_t>(ft) * B + i];
   }
-#pragma unroll
-  for (int c = kDwFeat; c < 16; ++c) scr[lane * kDwLd + c] = 0.0;   // (the unused columns of the staging tile: never written again)
+  if (tid < 2) zeroWord[tid] = 0.0;
   __syncthreads();
   DW_STAMP(1);
   // (wave-uniform read-only global data at an address that depends on blockIdx only: scalar loads, as in the hot product)
@@ -346,21 +363,13 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
   double cost = 0.0;
   const int mk = lane >> 4, mc = lane & 15;  // MFMA operand element [k = lane >> 4][column = lane & 15]
   const DenseLaneMap map = wl.map;
+  const size_t npxImg = static_cast<size_t>(T.W) * T.H;
+  const float* depthS = T.depth + static_cast<size_t>(fs) * npxImg;
+  const float* depthT = T.depth + static_cast<size_t>(ft) * npxImg;
+  const int mfmaRead = mc < kDwFeat ? mk * kDwLdF + mc : -1;   // (columns 9..15 of the Gram tile's operand are zero)
   for (int u = wave; u < (havePixels ? map.bandH : 0); u += NW) {
-    int len;
-    const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
-    const int iStop = iFirst + len;
-    const long long cFirst = pixBase + iFirst;
-    const int iy = iFirst / T.W, ix0 = iFirst - iy * T.W;
-    // loads in flight: (mask, flow) of pixel t + 1, the depths of pixel t
-    unsigned int mNext = 0u;
-    float2 fCur = make_float2(0.f, 0.f), fNext = make_float2(0.f, 0.f), dCur;
-    {
-      unsigned int m0 = 0u;
-      if (len > 0) { m0 = (T.fmask + pixBase)[iFirst]; fCur = (T.flow + pixBase)[iFirst]; }
-      if (len > 1) { mNext = (T.fmask + pixBase)[iFirst + 1]; fNext = (T.flow + pixBase)[iFirst + 1]; }
-      dCur = denseDepthsAhead(T, ix0, iy, len > 0, m0, fCur, fs, ft);
-    }
+    int len, iy, ix0;
+    const int iFirst = denseLaneRunRC(map, T.W, T.H, lane, u, len, iy, ix0);
     // source-side sums of the lane's run (one image row: one cell row, one pair of vertical tap weights)
     double AS[2][kDwFeatS], BS[3];
 #pragma unroll
@@ -371,8 +380,51 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
     // (one trip past the run: the flush of the last cell's sums has ONE copy, at the top of the trip)
 #pragma unroll 1
     for (int t = 0; t <= map.run; ++t) {
+      const int tb = t & (kDwBlk - 1);
+      if (tb == 0 && t < map.run) {
+        // ---- the next eight pixels of all 64 runs of the wave, by line: eight adjacent lanes load one run's 64 B of flow, its 32 B
+        // of source depth, its 8 mask bytes into the wave's input tiles; then every lane fetches the target depths of its own eight
+        // pixels, whose addresses follow from the flow.  (A lane that walked its own run alone touched every line in eight trips,
+        // 20 k cycles apart: 18 GB fetched per launch against 2.6 GB of images, 7.7 GB written against 1.2.)
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q) {
+          const int run = (lane >> 3) + 8 * q, px = lane & 7;
+          const int firstR = __shfl(iFirst, run), lenR = __shfl(len, run), rowR = __shfl(iy, run), colR = __shfl(ix0, run);
+          float2 f = make_float2(0.f, 0.f);
+          float da = 0.f;
+          unsigned char m = 0;
+          if (t + px < lenR) {
+            const long long c = pixBase + firstR + t + px;
+            f = T.flow[c];
+            m = T.fmask[c];
+            da = depthS[denseSourceDepthIndex(T, colR + t + px, rowR)];
+          }
+          ioF[run * kDwIoStride + px] = f;
+          ioDa[run * kDwIoStride + px] = da;
+          ioM[run * kDwIoStride + px] = m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < kDwBlk; h += 4) {
+          float dbv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int px = h + k;
+            dbv[k] = 0.f;
+            if (t + px < len && ioM[lane * kDwIoStride + px]) {
+              const int at = denseTargetDepthIndex(T, ix0 + t + px, iy, ioF[lane * kDwIoStride + px]);
+              if (at >= 0) dbv[k] = depthT[at];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ioDb[lane * kDwIoStride + h + k] = dbv[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
       const int i = iFirst + t;
-      const bool inRun = i < iStop;
+      const bool inRun = t < len;
       // the source end point's cell follows from the pixel alone (the float arithmetic of denseConstraintFromFlow)
       DwTaps ts;
       ts.i0 = -2; ts.rx = 0.0; ts.ry = 0.0;
@@ -381,7 +433,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         dwGather(L, __fadd_rn(-1.f, __fmul_rn(2.f, lx0)), __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect)), ts);
       }
       if (curI0 >= 0 && ts.i0 != curI0) {
-        // ---- flush the sums of the cell the lane has left: 4 taps x 12 features, 10 vertex pairs
+        // ---- flush the sums of the cell the lane has left: 4 taps x 9 features, 10 vertex pairs
         const double wy0 = 1.0 - curRy, wy1 = curRy;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -407,18 +459,31 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         BS[0] = BS[1] = BS[2] = 0.0;
         curI0 = -1;
       }
-      // pixel t: flow and depths are here; request the depths of t + 1 and (mask, flow) of t + 2
-      const float2 fl = fCur, d = dCur;
-      {
-        const unsigned int m1 = mNext;
-        fCur = fNext;
-        if (i + 2 < iStop) { mNext = (T.fmask + pixBase)[i + 2]; fNext = (T.flow + pixBase)[i + 2]; }
-        dCur = denseDepthsAhead(T, ix0 + t + 1, iy, i + 1 < iStop, m1, fCur, fs, ft);
-      }
+      if (t == map.run) break;   // (the extra trip only flushes)
+      // pixel t: flow, mask and both depths from the wave's input tiles
+      const float2 fl = ioF[lane * kDwIoStride + tb];
+      const float2 d = make_float2(ioDa[lane * kDwIoStride + tb], ioDb[lane * kDwIoStride + tb]);
       float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool valid = inRun && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f && denseNdcFromFlow(T, ix0 + t, iy, fl, nd);
+      const bool valid = inRun && ioM[lane * kDwIoStride + tb] != 0 && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f &&
+                         denseNdcFromFlow(T, ix0 + t, iy, fl, nd);
+      // (this block's scalars go out together, by line, when its last pixel is done)
+      const bool lastOfBlock = tb == kDwBlk - 1 || t == map.run - 1;
+      auto storeScalars = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int t0 = t - tb;
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q) {
+          const int run = (lane >> 3) + 8 * q, px = lane & 7;
+          const int firstR = __shfl(iFirst, run), lenR = __shfl(len, run);
+          if (t0 + px < lenR) ggOut[pixBase + firstR + t0 + px] = ioG[run * kDwIoStride + px];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
       if (__builtin_amdgcn_readfirstlane(__ballot(valid) == 0ull ? 1 : 0)) {
-        if (inRun) ggOut[cFirst + t] = 0.0;
+        ioG[lane * kDwIoStride + tb] = 0.0;
+        if (lastOfBlock) storeScalars();
         continue;  // (wave-uniform)
       }
       DwState ch;
@@ -440,7 +505,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         const double k2 = P.Rt[2] * ch.Rca[0] + P.Rt[5] * ch.Rca[1] + P.Rt[8] * ch.Rca[2];
         const double wj0 = ch.w * (ch.m00 * k0 + ch.m02 * k2), wj1 = ch.w * (ch.m11 * k1 + ch.m12 * k2), wj2 = ch.w * ch.m22 * k2;
         const double wt = ch.w * ch.JDT2;   // rho' d r_2 / d D_t
-        ggOut[cFirst + t] = wj2 * ch.JDT2 * da * db;
+        ioG[lane * kDwIoStride + tb] = wj2 * ch.JDT2 * da * db;
         {  // ---- source side: features of mu = sum_r wj_r M_r into the run's sums
           const double mu0 = wj0 * ch.m00, mu1 = wj1 * ch.m11, mu2 = wj0 * ch.m02 + wj1 * ch.m12 + wj2 * ch.m22;
           double ft12[kDwFeatS], sSS;   // sSS = sum_r rho' (d r_r / d D_s)^2
@@ -483,8 +548,8 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
           atomicAdd(&bandT[1 * G + j0 + gx], b2 * fb[3]);
           atomicAdd(&bandT[0 * G + j0 + gx + 1], b3 * fb[3]);
         }
-      } else if (inRun) {
-        ggOut[cFirst + t] = 0.0;
+      } else {
+        ioG[lane * kDwIoStride + tb] = 0.0;
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- the three residual rows sqrt(rho') x features through the wave's staging tile into the Gram tile.  A REAL loop: unrolled,
@@ -499,18 +564,20 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
           double F[kDwFeat], jds;
           dwFeatures(ch, P, y, mu0, mu1, mu2, j13, rr, F, jds);
 #pragma unroll
-          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLd + c] = sw * F[c];
+          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLdF + c] = sw * F[c];
         } else {
 #pragma unroll
-          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLd + c] = 0.0;
+          for (int c = 0; c < kDwFeat; ++c) scr[lane * kDwLdF + c] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        const double* rd = mfmaRead >= 0 ? scr + mfmaRead : zeroWord;
+        const int rstep = mfmaRead >= 0 ? 4 * kDwLdF : 0;
 #pragma unroll
         for (int j = 0; j < 16; j += 2) {
-          const double a0 = scr[(4 * j + mk) * kDwLd + mc];
-          const double a1 = scr[(4 * j + 4 + mk) * kDwLd + mc];
+          const double a0 = rd[j * rstep];
+          const double a1 = rd[(j + 1) * rstep];
           tile0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, tile0, 0, 0, 0);
           tile0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, tile0, 0, 0, 0);
         }
@@ -518,6 +585,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (lastOfBlock) storeScalars();
     }
   }
   DW_STAMP(2);
