@@ -177,13 +177,14 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t
  * list the optimizer is handed the flow and mask images of every directed pair -- flow[P][H][W][2] f32 in pixels,
  * mask[P][H][W] u8 (non-zero = valid), at the size given to cvd_set_video -- and its kernels read flow / mask / depth
  * directly (17 B per pixel pair); nothing is sampled or tabulated.  Every constraint is static.  Replaces the constraint
- * list (cvd_set_pair_constraints switches back).  Supported for the default residual configuration (cvd_last_error says
- * which otherwise). */
+ * list (cvd_set_pair_constraints switches back).  A solve outside the scope of the image-reading kernels (see
+ * cvd_dense_mode_supported) writes the list the images stand for on the device (44 B per constraint) and runs on the list kernels. */
 int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* flow, const uint8_t* mask);
 /* 1 when a problem with these parameters / transform descriptors lies within the scope of the dense mode (identity spatial
  * transform, a reprojection loss, Scale value transform, Global or bilinear grid, per-frame or fixed intrinsics, no
- * smoothness triplets, frame block <= 256); 0: hand the constraints over as a list (cvd_set_pair_constraints) --
- * a dense-mode solve outside the scope fails instead of falling back.  problem: 0 = poseOptimization, 1 = normalizeDepth.
+ * smoothness triplets, frame block <= 256): its kernels read the images directly.  0: a dense-mode solve still runs, on the
+ * constraint list materialised on the device (pixel order, 6.4 GB for 144 M constraints); a caller that holds the list
+ * anyway may as well hand it over (cvd_set_pair_constraints).  problem: 0 = poseOptimization, 1 = normalizeDepth.
  * What lib_python's FlowConstraintsCollection asks before it keeps a matchSeparation = 0 collection as images. */
 int32_t cvd_dense_mode_supported(const cvd_opt_params* params, const cvd_xform_desc* depth, const cvd_xform_desc* spatial,
                                  int32_t have_triplets, int32_t world_size, int32_t problem);

@@ -14,6 +14,7 @@ from .binding import Binding
 from .ctypes_types import OptParams, SolveSummary, XformDesc  # noqa: F401 (re-exported)
 
 _lib = None
+_variant = None
 
 
 class SolverOptions(C.Structure):
@@ -64,7 +65,7 @@ def load_library(variant=None):
     """dlopen the in-tree libcvd_hip.so. Raises ImportError (never falls back) when it is not built.  Nothing is read from the
     environment.  `variant` (development tools only, before anything else loaded the library): a profile build
     lib/libcvd_hip_<variant>.so made by robust_cvd_amd.build.build_variant; the chosen path is reported on stderr."""
-    global _lib
+    global _lib, _variant
     if _lib is not None and variant:
         raise RuntimeError("load_library(variant=...) must be the first load of the library in the process")
     if _lib is None:
@@ -87,7 +88,13 @@ def load_library(variant=None):
             raise ImportError(f"{path} was built with ABI revision {lib.cvd_abi_revision()}, this binding is written against "
                               f"{ABI_REVISION} (include/cvd_hip.h: CVD_ABI_REVISION): rebuild the library")
         _lib = lib
+        _variant = variant
     return _lib
+
+
+def loaded_variant():
+    """None for the product library, else the development variant this process loaded (`det`: the bit-reproducible build)."""
+    return _variant
 
 
 EXPORTED_SYMBOLS = [

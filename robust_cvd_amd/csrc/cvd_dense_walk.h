@@ -724,6 +724,22 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
         fN[q] = make_float2(0.f, 0.f);
         if (q < len) { gN[q] = gg[cb + iFirst + q]; fN[q] = T.flow[cb + iFirst + q]; }
       }
+      // The 4 x 4 tap products are summed in registers while BOTH end points stay in their cells (a lane's run is one cell wide and
+      // the flow is smooth: a few flushes per run instead of 16 atomics per pixel -- the kernel was stalled on the LDS queue).
+      double acc[KD][KD];
+      int curR = -1, curC = -1;   // first vertex of the row / column cell the sums belong to
+      auto flush = [&]() {
+        if (curR < 0) return;
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          const int ir = curR + (k & 1) + (k >> 1) * L.gx;
+#pragma unroll
+          for (int l = 0; l < KD; ++l) {
+            const int jc = curC + (l & 1) + (l >> 1) * L.gx - v0;
+            if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], acc[k][l]);
+          }
+        }
+      };
       for (int t0 = 0; t0 < len; t0 += kBatch) {
         double gC[kBatch];
         float2 fC[kBatch];
@@ -736,29 +752,35 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
         }
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
-        const int t = t0 + q;
-        const double g = gC[q];
-        const float2 f = fC[q];
-        if (g == 0.0) continue;
-        float4 nd;
-        if (!denseNdcFromFlow(T, ix0 + t, iy, f, nd)) continue;
-        FastTaps<KD> ts, tt;
-        fastGather<KD>(L, nd.x, nd.y, ts);
-        fastGather<KD>(L, nd.z, nd.w, tt);
-        const FastTaps<KD>& tr = dir ? tt : ts;   // rows = frame a's vertices
-        const FastTaps<KD>& tc = dir ? ts : tt;   // columns = frame b's
+          const int t = t0 + q;
+          const double g = gC[q];
+          const float2 f = fC[q];
+          if (g == 0.0) continue;
+          float4 nd;
+          if (!denseNdcFromFlow(T, ix0 + t, iy, f, nd)) continue;
+          FastTaps<KD> ts, tt;
+          fastGather<KD>(L, nd.x, nd.y, ts);
+          fastGather<KD>(L, nd.z, nd.w, tt);
+          const FastTaps<KD>& tr = dir ? tt : ts;   // rows = frame a's vertices
+          const FastTaps<KD>& tc = dir ? ts : tt;   // columns = frame b's
+          if (tr.I(0) != curR || tc.I(0) != curC) {
+            flush();
+            curR = tr.I(0);
+            curC = tc.I(0);
 #pragma unroll
-        for (int k = 0; k < KD; ++k) {
-          const int ir = tr.I(k);
-          const double fr = g * tr.Wt(k);
+            for (int k = 0; k < KD; ++k)
 #pragma unroll
-          for (int l = 0; l < KD; ++l) {
-            const int jc = tc.I(l) - v0;
-            if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], fr * tc.Wt(l));
+              for (int l = 0; l < KD; ++l) acc[k][l] = 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const double fr = g * tr.Wt(k);
+#pragma unroll
+            for (int l = 0; l < KD; ++l) acc[k][l] += fr * tc.Wt(l);
           }
         }
-        }
       }
+      flush();
     }
   }
   __syncthreads();

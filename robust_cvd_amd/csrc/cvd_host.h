@@ -323,6 +323,7 @@ struct cvd_handle_t {
     DevBuf<int> ptA, ptB, ptPtr, ptList;
     DevBuf<double> ptMat, ptInv, ptR, ptT, ptDot, ptRec;
     DevBuf<TlStep> ptStepDev;   // [0]: per iteration (restricted products = Z^T q), [1]: first residual (= Z^T r)
+    std::vector<unsigned char> ptStepHost;   // what ptStepDev holds (a solve re-uploads the two records only when they changed)
     DevBuf<unsigned int> ptCounter;
     // dense variant (cvd_coarse.h "DENSE coarse level"): A_c^-1 as a full f64 matrix, built in line by k_dense_spd_inverse
     bool denseMode = false;
@@ -349,6 +350,7 @@ struct cvd_handle_t {
     bool on = false;        // this solve uses the level
     bool built = false;     // A_T^-1 of this solve exists
     int S = 0, Sx = 0, Sy = 0, nn = 0, step = 0, NT = 0, width = 0, nGroups = 0, nBlocks = 0;
+    std::vector<unsigned char> stepHost;               // what stepDev holds
     int tabGx = 0, tabGy = 0, tabSx = 0, tabSy = 0;   // what the spatial tables were built for
     int grpF = 0, grpStep = 0;                        // ... the groups / block lists
     std::vector<int> grpFa, grpFb;

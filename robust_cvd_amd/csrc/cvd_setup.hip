@@ -1245,7 +1245,7 @@ void ensureBuffers(Ctx& c) {
     h->dCounters.ensure(8);
     HIP_CHECK(hipMemsetAsync(h->dCounters.p, 0, 8 * sizeof(unsigned int), h->stream));
   }
-  if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), S_COUNT * sizeof(double)));
+  if (!h->hScal) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hScal), (S_COUNT + 1) * sizeof(double)));  // (+ 1: the end-of-solve status word)
   if (!h->hPcg) {
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->hPcg), 16 * sizeof(double)));
     for (auto& e : h->pcgEvent) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -316,11 +316,13 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   h->coarseOn = h->opt.coarse_level != 0 && h->coarse.valid && c.L.includeStatic && h->coarse.nEdges > 0 && !h->forceGeneric &&
                 kind == PK_POSE_STEP;  // (normalizeDepth's problems have no pose unknowns: the block-Jacobi level alone)
   ensureBuffers(c);
+  phase("buffers");
   h->coarse.ptInvPending = false;   // (a request left behind by a solve that threw)
   h->temporal.on = temporalScope(c);
   if (h->temporal.on) h->temporal.on = temporalPrepare(c);
+  phase("level 3 tables");
   if (h->coarseOn && h->coarse.temporalPose) poseTemporalPrepare(c);
-  phase("buffers");
+  phase("level 2 tables");
   buildMask(h, c.L, p, kind, range);
   phase("mask");
   uploadState(h, c.L, h->dX);
@@ -645,16 +647,16 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
     gradPending = false;
   }
   phase("LM loop");
-  if (h->coarseOn && h->coarse.denseMode && h->coarse.fail.p != nullptr && !h->dist()) {
-    // a barrier timeout of the dense coarse inverse (bit 30) only costs PCG iterations -- but it should never pass unnoticed
-    int failWord = 0;
-    HIP_CHECK(hipMemcpyAsync(&failWord, h->coarse.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (failWord & 0x40000000)
-      fprintf(stderr, "[cvd] warning: the dense coarse inverse timed out at its grid barrier (device shared with other work?); "
-                      "the coarse level was off for the last LM iteration(s)\n");
-  }
+  // a barrier timeout of the dense coarse inverse (bit 30) only costs PCG iterations -- but it should never pass unnoticed: its
+  // status word travels with the state (one host wait for both; a round trip of its own cost ~25 us per solve)
+  int* failWord = reinterpret_cast<int*>(h->hScal + S_COUNT);
+  *failWord = 0;
+  if (h->coarseOn && h->coarse.denseMode && h->coarse.fail.p != nullptr && !h->dist())
+    HIP_CHECK(hipMemcpyAsync(failWord, h->coarse.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
   downloadState(h, c.L, h->dX);
+  if (*failWord & 0x40000000)
+    fprintf(stderr, "[cvd] warning: the dense coarse inverse timed out at its grid barrier (device shared with other work?); "
+                    "the coarse level was off for the last LM iteration(s)\n");
   phase("download");
   h->tCollect();
   sum.num_iterations = iteration;

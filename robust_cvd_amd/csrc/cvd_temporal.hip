@@ -295,8 +295,12 @@ static void temporalInverse(Ctx& c) {
     T.built = true;
     const TlStep ts = temporalStep(h);
     T.stepDev.ensure(1);
-    HIP_CHECK(hipMemcpyAsync(T.stepDev.p, &ts, sizeof(TlStep), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));  // (once per solve; `ts` is a local)
+    // (a solve of the same problem finds its record on the device: no upload, and no host wait behind the inverse just enqueued)
+    if (T.stepHost.size() != sizeof(TlStep) || std::memcmp(T.stepHost.data(), &ts, sizeof(TlStep)) != 0) {
+      HIP_CHECK(hipMemcpyAsync(T.stepDev.p, &ts, sizeof(TlStep), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));  // (`ts` is a local)
+      T.stepHost.assign(reinterpret_cast<const unsigned char*>(&ts), reinterpret_cast<const unsigned char*>(&ts) + sizeof(TlStep));
+    }
   }
 }
 
@@ -392,8 +396,16 @@ void poseTemporalPrepare(Ctx& c) {
   st[1] = st[0];
   st[1].sq = C.rc.p;
   C.ptStepDev.ensure(2);
-  HIP_CHECK(hipMemcpyAsync(C.ptStepDev.p, st, sizeof(st), hipMemcpyHostToDevice, s));
+  // (padding bytes of the records are not compared: built from zeroed storage)
+  unsigned char img[sizeof(st)];
+  std::memset(img, 0, sizeof(img));
+  TlStep* rec = reinterpret_cast<TlStep*>(img);
+  rec[0] = st[0];
+  rec[1] = st[1];
+  if (C.ptStepHost.size() == sizeof(img) && std::memcmp(C.ptStepHost.data(), img, sizeof(img)) == 0) return;
+  HIP_CHECK(hipMemcpyAsync(C.ptStepDev.p, img, sizeof(img), hipMemcpyHostToDevice, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  C.ptStepHost.assign(img, img + sizeof(img));
 }
 
 void launchPoseTemporalBuild(Ctx& c, hipStream_t s, int* failOut, bool deferInverse) {

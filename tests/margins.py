@@ -22,9 +22,22 @@ def _log(name, value, limit, kind="tolerance"):
         f.write(json.dumps({"test": test, "name": name, "value": float(value), "limit": float(limit), "kind": kind}) + "\n")
 
 
+def deterministic_build():
+    """The suite runs against lib/libcvd_hip_det.so (pytest --lib-variant det): every accumulation in index order, a solve repeats
+    bit for bit, so comparisons of two paths hold their TIGHT limits there (the relaxed limits of the product build --
+    atomics in arrival order -- would let a real divergence at the 1e-5 level pass)."""
+    from robust_cvd_amd import api
+    return api.loaded_variant() == "det"
+
+
+def limit(product, det):
+    """The limit of an assertion on the product build / on the deterministic build."""
+    return det if deterministic_build() else product
+
+
 def below(name, value, limit, info=None, kind="tolerance"):
     """value < limit: logged with its margin.  kind "tolerance": the 1/3 policy applies; "ratio": a ratio of two iteration counts
-    (>= 10 % between the measured value and the limit)."""
+    (>= 5 % between the measured value and the limit: the limit must still catch a lost benefit)."""
     _log(name, value, limit, kind)
     assert value < limit, (name, value, limit, info)
 
@@ -37,6 +50,9 @@ def close_count(name, a, b, rel=0.1, slack=2):
 
 
 def same_count(name, a, b, slack=1):
-    """LM-iteration counts of two solver paths: equal up to one iteration (a stopping test decided in the last digits)."""
+    """LM-iteration counts of two solver paths: equal up to one iteration (a stopping test decided in the last digits); equal on
+    the deterministic build."""
+    if deterministic_build():
+        slack = 0
     _log(name, abs(a - b), slack + 1, "count")
     assert abs(a - b) <= slack, (name, a, b)

@@ -898,12 +898,13 @@ def test_fused_pcg_tail_matches_the_two_launch_path(Solver, case):
     # differ by an iteration here and there -- not systematically)
     # (... and a count that differs by one can move a rebuild of the coarse level by an LM iteration: 10 % on the total)
     margins.close_count("PCG iterations fused vs two-launch", sum(a[3]), sum(b[3]), rel=0.15, slack=3)
-    margins.below("final cost fused vs two-launch", abs(a[0]["final_cost"] - b[0]["final_cost"]) / abs(b[0]["final_cost"]), 1e-8)
+    # (limits: product build / deterministic build, `pytest --lib-variant det` -- margins.limit)
+    margins.below("final cost fused vs two-launch", abs(a[0]["final_cost"] - b[0]["final_cost"]) / abs(b[0]["final_cost"]), margins.limit(1e-8, 1e-9))
     perr, rerr = synth.relative_pose_error(a[1]["position"], a[1]["orientation"], b[1]["position"], b[1]["orientation"])
     # (two eta = 1e-3 solves whose products round differently end ~1e-6 apart)
-    margins.below("position fused vs two-launch", perr, 3e-5)
+    margins.below("position fused vs two-launch", perr, margins.limit(3e-5, 1e-5))
     margins.below("rotation fused vs two-launch", rerr, 2e-4)   # (metric floor ~5e-5: arccos of float-quaternion matrices)
-    margins.below("depth parameters fused vs two-launch", rel(a[2], b[2]), 3e-5)
+    margins.below("depth parameters fused vs two-launch", rel(a[2], b[2]), margins.limit(3e-5, 1e-5))
 
 
 def test_a_stalled_fused_tail_falls_back_to_the_two_launches(Solver, capfd):
@@ -932,9 +933,9 @@ def test_a_stalled_fused_tail_falls_back_to_the_two_launches(Solver, capfd):
     assert a[3]["tail_disabled"] and not a[3]["fused_tail"] and not b[3]["tail_disabled"]
     assert a[0]["termination"] == 0 and b[0]["termination"] == 0
     margins.same_count("LM iterations stalled-and-recovered vs two-launch", a[0]["num_iterations"], b[0]["num_iterations"])
-    margins.below("final cost stalled-and-recovered vs two-launch", abs(a[0]["final_cost"] - b[0]["final_cost"]) / abs(b[0]["final_cost"]), 1e-8)
+    margins.below("final cost stalled-and-recovered vs two-launch", abs(a[0]["final_cost"] - b[0]["final_cost"]) / abs(b[0]["final_cost"]), margins.limit(1e-8, 1e-9))
     perr, rerr = synth.relative_pose_error(a[1]["position"], a[1]["orientation"], b[1]["position"], b[1]["orientation"])
-    margins.below("position stalled-and-recovered vs two-launch", perr, 3e-5)
+    margins.below("position stalled-and-recovered vs two-launch", perr, margins.limit(3e-5, 1e-5))
     margins.below("rotation stalled-and-recovered vs two-launch", rerr, 2e-4)
 
 

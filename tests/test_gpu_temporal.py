@@ -131,9 +131,10 @@ def test_level_saves_iterations_on_the_benchmarked_problem(Solver):
     margins.same_count("LM iterations with / without the level", out[0][0]["num_iterations"], out[1][0]["num_iterations"])
     # measured over the whole pipeline: 1046 -> 932 with the temporal pose level (the default for this pair graph), 1093 -> 888 with
     # the exact dense one; 50 -> 34 per LM iteration at the final level (profiles/r04_*)
-    # (>= 10 % margin on an iteration-count comparison: measured ratio 0.85 - 0.89, asserted < 1: the level must not COST iterations)
-    margins.below("PCG iterations with / without the level", out[1][0]["total_linear_iterations"] / out[0][0]["total_linear_iterations"], 1.0,
-                  kind="ratio")
+    # (measured ratio 0.85 - 0.89 on the product build; a regression that removes most of the level's benefit must fail: < 0.95,
+    # and < 0.93 on the deterministic build, where the counts repeat)
+    margins.below("PCG iterations with / without the level", out[1][0]["total_linear_iterations"] / out[0][0]["total_linear_iterations"],
+                  margins.limit(0.95, 0.93), kind="ratio")
 
 
 @pytest.mark.parametrize("intr", ["per_frame", "fixed"])
