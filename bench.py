@@ -530,8 +530,9 @@ def main():
                                      "38.2 ms; round 6: one walk, ~780 VALU flop per constraint + the Gram tile on the matrix pipe"},
                 **({"walk": {"avg_ms": m["ktimes"]["dense_walk"]["avg_ms"], "launches": m["ktimes"]["dense_walk"]["launches"]},
                     "grid_x_grid": {"avg_ms": m["ktimes"]["dense_gg"]["avg_ms"], "launches": m["ktimes"]["dense_gg"]["launches"],
-                                    "GB/s": 16.0 * slots * 2 / max(m["ktimes"]["dense_gg"]["avg_ms"], 1e-9) * 1e-6,
-                                    "note": "8 B scalar + 8 B flow per pixel slot, read once per column panel (two panels at 17 x 10)"},
+                                    "GB/s": 16.0 * slots / max(m["ktimes"]["dense_gg"]["avg_ms"], 1e-9) * 1e-6,
+                                    "note": "8 B scalar + 8 B flow per pixel slot, read once: panels of SOURCE vertices, one launch per "
+                                            "direction (the pixels of the one cell row two panels share are read twice: + 1/9 at 17 x 10)"},
                     "product": {"kernel": "k_cross_matvec", "avg_ms": m["ktimes"]["matvec_pairs"]["avg_ms"],
                                 "GB/s": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6,
                                 "frac_hbm": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS}}

@@ -21,7 +21,7 @@
 //                      The workgroup's sums are written as one compact RECORD per directed pair (256 + 40 G doubles).
 //   k_assemble_fast<.., FOLD>   per frame: sums its records into H_ff / g / cost (a gather: no atomics), then regularisers etc. as before
 //   k_dense_fold_cross per undirected pair: pose rows / columns of X_ab from the two directions' records
-//   k_dense_gg         per (undirected pair, column panel): grid x grid of X_ab from the per-pixel scalars and the flow (taps only:
+//   k_dense_gg         per (undirected pair, panel of source vertices, direction): grid x grid of X_ab from the per-pixel scalars and the flow (taps only:
 //                      no Jacobian chain, no depth reads)
 //
 // Record of a directed pair s -> t (doubles; G = vertices of the depth grid, one value parameter per vertex):
@@ -686,35 +686,62 @@ inline __global__ __launch_bounds__(256) void k_dense_fold_cross(Layout L, Cross
   }
 }
 
-// Grid x grid part of X_ab: sum over the pixels of both directions of gg fac-free tap products,
+// Grid x grid part of X_ab: sum over the pixels of both directions of tap products,
 //   X[7 + v_a][7 + v_b] += gg * w_a[k] * w_b[l]        (gg = rho' JD_s,2 JD_t,2 d_s d_t of k_dense_walk; 0 = no constraint)
-// One workgroup per (pair, panel of columns); lane = run of pixels as in the walk.
+// G^2 doubles do not fit the LDS: the block is built in panels of SOURCE vertices -- rows of X for direction a -> b, columns for
+// b -> a, one launch per direction (the second adds).  A pixel's source taps follow from its position alone, so a panel reads only the
+// image rows whose cell row touches it: every pixel is visited once (the rows of the one cell row two panels share: twice), where
+// panels of target vertices -- rounds 6a -- walked all pixels of both directions for every panel.  One workgroup per (pair, panel);
+// lane = run of pixels as in the walk, over the panel's rows.
 constexpr int kGgThreads = CVD_DETERMINISTIC ? 64 : 1024;
 template <int KD>
 inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table T, CrossPairs cp, const int* __restrict__ xDir,
-                                                        const double* __restrict__ gg, int panelW, DenseLaneMap map,
-                                                        double* __restrict__ X) {
+                                                        const double* __restrict__ gg, int panelW, int dir, double* __restrict__ X) {
   static_assert(KD == 4, "bilinear depth grids");
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int yRange[2];
   const int B = L.B, G = L.nD;
   const int pair = blockIdx.x, panel = blockIdx.y;
   const int v0 = panel * panelW, v1 = (v0 + panelW < G) ? v0 + panelW : G, pw = v1 - v0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kGgThreads / 64;
-  double* GG = sm;
-  for (int i = tid; i < G * panelW; i += kGgThreads) GG[i] = 0.0;
+  double* GG = sm;   // [source vertex - v0][target vertex]
+  for (int i = tid; i < G * pw; i += kGgThreads) GG[i] = 0.0;
+  if (tid == 0) { yRange[0] = T.H; yRange[1] = -1; }
   __syncthreads();
-  for (int dir = 0; dir < 2; ++dir) {
-    const int p = xDir[pair * 2 + dir];
-    if (p < 0) continue;
-    const long long cb = T.pairOff[p];
-    if (T.pairOff[p + 1] <= cb) continue;
+  const int p = xDir[pair * 2 + dir];
+  const long long cb = p >= 0 ? T.pairOff[p] : 0;
+  const bool havePixels = p >= 0 && T.pairOff[p + 1] > cb;
+  if (!havePixels && dir != 0) return;   // (uniform; the first direction's launch writes the block even when it is zero)
+  if (havePixels) {
+    // the image rows whose source cell row has a vertex in [v0, v1) (cell row cy: vertices [cy gx, (cy + 2) gx))
+    const int cyLo = (v0 + L.gx) / L.gx - 2, cyHi = (v1 - 1) / L.gx;
+    for (int y = tid; y < T.H; y += kGgThreads) {
+      const float ly0 = __fmul_rn(static_cast<float>(y), T.sy);
+      const float ny = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
+      int cy;
+      double ry;
+      gridCellFast(ny, 0.5 * static_cast<double>(L.gy - 1), L.maxcy, cy, ry);
+      if (cy >= cyLo && cy <= cyHi) {
+        atomicMin(&yRange[0], y);
+        atomicMax(&yRange[1], y);
+      }
+    }
+  }
+  __syncthreads();
+  const int yFirst = yRange[0], Hs = yRange[1] - yRange[0] + 1;
+  if (havePixels && Hs > 0) {
+    DenseLaneMap map;   // (denseLaneMap of the panel's rows)
+    map.run = (T.W + 15) / 16;
+    map.lanesPerRow = (T.W + map.run - 1) / map.run;
+    map.rowGroups = 64 / map.lanesPerRow < Hs ? 64 / map.lanesPerRow : Hs;
+    map.bandH = (Hs + map.rowGroups - 1) / map.rowGroups;
     for (int u = wave; u < map.bandH; u += NW) {
-      int len;
-      const int iFirst = denseLaneRun(map, T.W, T.H, lane, u, len);
-      const int iy = iFirst / T.W, ix0 = iFirst - iy * T.W;
-      // (gg and flow of the lane's next FOUR pixels in flight: the trip is short -- taps and 16 atomics -- and the kernel waits on
-      // its loads otherwise)
+      int len, row, ix0;
+      (void)denseLaneRunRC(map, T.W, Hs, lane, u, len, row, ix0);
+      const int iy = yFirst + row;
+      const long long cFirst = cb + static_cast<long long>(iy) * T.W + ix0;
+      // (gg and flow of the lane's next FOUR pixels in flight: the trip is short and the kernel waits on its loads otherwise)
       constexpr int kBatch = 4;
       double gN[kBatch];
       float2 fN[kBatch];
@@ -722,22 +749,20 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
       for (int q = 0; q < kBatch; ++q) {
         gN[q] = 0.0;
         fN[q] = make_float2(0.f, 0.f);
-        if (q < len) { gN[q] = gg[cb + iFirst + q]; fN[q] = T.flow[cb + iFirst + q]; }
+        if (q < len) { gN[q] = gg[cFirst + q]; fN[q] = T.flow[cFirst + q]; }
       }
       // The 4 x 4 tap products are summed in registers while BOTH end points stay in their cells (a lane's run is one cell wide and
-      // the flow is smooth: a few flushes per run instead of 16 atomics per pixel -- the kernel was stalled on the LDS queue).
+      // the flow is smooth: a few flushes per run instead of 16 atomics per pixel).
       double acc[KD][KD];
-      int curR = -1, curC = -1;   // first vertex of the row / column cell the sums belong to
+      int curS = -1, curT = -1;   // first vertex of the source / target cell the sums belong to
       auto flush = [&]() {
-        if (curR < 0) return;
+        if (curS < 0) return;
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
-          const int ir = curR + (k & 1) + (k >> 1) * L.gx;
+          const int is = curS + (k & 1) + (k >> 1) * L.gx - v0;
+          if (is < 0 || is >= pw) continue;
 #pragma unroll
-          for (int l = 0; l < KD; ++l) {
-            const int jc = curC + (l & 1) + (l >> 1) * L.gx - v0;
-            if (jc >= 0 && jc < pw) atomicAdd(&GG[ir * panelW + jc], acc[k][l]);
-          }
+          for (int l = 0; l < KD; ++l) atomicAdd(&GG[is * G + curT + (l & 1) + (l >> 1) * L.gx], acc[k][l]);
         }
       };
       for (int t0 = 0; t0 < len; t0 += kBatch) {
@@ -748,7 +773,7 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
           gC[q] = gN[q];
           fC[q] = fN[q];
           gN[q] = 0.0;
-          if (t0 + kBatch + q < len) { gN[q] = gg[cb + iFirst + t0 + kBatch + q]; fN[q] = T.flow[cb + iFirst + t0 + kBatch + q]; }
+          if (t0 + kBatch + q < len) { gN[q] = gg[cFirst + t0 + kBatch + q]; fN[q] = T.flow[cFirst + t0 + kBatch + q]; }
         }
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
@@ -761,12 +786,10 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
           FastTaps<KD> ts, tt;
           fastGather<KD>(L, nd.x, nd.y, ts);
           fastGather<KD>(L, nd.z, nd.w, tt);
-          const FastTaps<KD>& tr = dir ? tt : ts;   // rows = frame a's vertices
-          const FastTaps<KD>& tc = dir ? ts : tt;   // columns = frame b's
-          if (tr.I(0) != curR || tc.I(0) != curC) {
+          if (ts.I(0) != curS || tt.I(0) != curT) {
             flush();
-            curR = tr.I(0);
-            curC = tc.I(0);
+            curS = ts.I(0);
+            curT = tt.I(0);
 #pragma unroll
             for (int k = 0; k < KD; ++k)
 #pragma unroll
@@ -774,9 +797,9 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
           }
 #pragma unroll
           for (int k = 0; k < KD; ++k) {
-            const double fr = g * tr.Wt(k);
+            const double fr = g * ts.Wt(k);
 #pragma unroll
-            for (int l = 0; l < KD; ++l) acc[k][l] += fr * tc.Wt(l);
+            for (int l = 0; l < KD; ++l) acc[k][l] += fr * tt.Wt(l);
           }
         }
       }
@@ -785,9 +808,16 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
   }
   __syncthreads();
   double* Xp = X + static_cast<size_t>(pair) * B * B;
-  for (int i = tid; i < G * pw; i += kGgThreads) {
-    const int r = i / pw, cidx = i - r * pw;
-    Xp[static_cast<size_t>(7 + r) * B + 7 + v0 + cidx] = GG[r * panelW + cidx];
+  if (dir == 0) {   // rows = frame a's vertices = this direction's sources
+    for (int i = tid; i < pw * G; i += kGgThreads) {
+      const int is = i / G, it = i - is * G;
+      Xp[static_cast<size_t>(7 + v0 + is) * B + 7 + it] = GG[i];
+    }
+  } else {          // columns = frame b's vertices = this direction's sources; added to what the first launch wrote
+    for (int i = tid; i < pw * G; i += kGgThreads) {
+      const int it = i / pw, is = i - it * pw;
+      Xp[static_cast<size_t>(7 + it) * B + 7 + v0 + is] += GG[is * G + it];
+    }
   }
 }
 

@@ -142,8 +142,9 @@ void launchCrossAssemble(Ctx& c, const double* x) {
   const size_t ldsGrid = static_cast<size_t>(panelW) * G * 8;
   allowLds((k_dense_gg<4>), ldsGrid);
   const int slot = h->tBegin(KC_DENSE_GG);
-  hipLaunchKernelGGL((k_dense_gg<4>), dim3(nP, nPanels), dim3(kGgThreads), ldsGrid, h->stream, c.L, c.T, crossPairs(h), h->dXDir.p,
-                     h->dDwGg.p, panelW, denseLaneMap(h->W, h->H), h->dXBlocks.p);
+  for (int dir = 0; dir < 2; ++dir)   // (a -> b: panels of rows, written; b -> a: panels of columns, added)
+    hipLaunchKernelGGL((k_dense_gg<4>), dim3(nP, nPanels), dim3(kGgThreads), ldsGrid, h->stream, c.L, c.T, crossPairs(h), h->dXDir.p,
+                       h->dDwGg.p, panelW, dir, h->dXBlocks.p);
   h->tEnd(slot);
   HIP_CHECK(hipGetLastError());
 }

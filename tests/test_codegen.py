@@ -24,7 +24,7 @@ SOURCE = f'''
 #include "{CSRC}/cvd_dense_walk.h"
 namespace cvd {{
 template __global__ void k_dense_walk<4>(Layout, Table, DenseWalkList, const double*, const FrameConst*, double*, double*);
-template __global__ void k_dense_gg<4>(Layout, Table, CrossPairs, const int*, const double*, int, DenseLaneMap, double*);
+template __global__ void k_dense_gg<4>(Layout, Table, CrossPairs, const int*, const double*, int, int, double*);
 template __global__ void k_cost_items_fast<4>(Layout, Table, Items, const double*, const FrameConst*, double*);
 template __global__ void k_coarse_edges_fast<4>(Layout, Table, Items, const double*, const FrameConst*, const int*, double*, double*);
 template __global__ void k_matvec_pairs_fast<4, 128>(Layout, Table, Items, const double*, const FrameConst*, const double*,
