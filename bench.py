@@ -58,12 +58,12 @@ CONFIGS = {
 }
 
 
-def kernel_sources_digest():
-    """SHA-256 over the headers that define the hot kernel (k_matvec_pairs_fast and the device functions it inlines): ties a
-    committed PMC measurement to the kernel it measured."""
+def kernel_sources_digest(dense=False):
+    """SHA-256 over the headers that define the hot kernel (k_matvec_pairs_fast and the device functions it inlines; dense: + the
+    dense mode's walk): ties a committed PMC measurement to the kernel it measured."""
     h = hashlib.sha256()
     d = os.path.join(_ROOT, "robust_cvd_amd", "csrc")
-    for fn in ("cvd_device.h", "cvd_kernels.h"):
+    for fn in ("cvd_device.h", "cvd_kernels.h") + (("cvd_dense_walk.h",) if dense else ()):
         with open(os.path.join(d, fn), "rb") as f:
             h.update(fn.encode())
             h.update(f.read())
@@ -460,15 +460,16 @@ def main():
         # process): only when profiles/pmc_matvec_pairs.json was produced from the kernel sources benchmarked here and
         # on this workload; FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE (tools/pmc_to_json.py)
         traffic, traffic_note = None, "no PMC file"
+        pmc_name = "profiles/pmc_dense_walk.json" if (args.dense and dense_explicit) else "profiles/pmc_matvec_pairs.json"
         try:
-            with open(os.path.join(_ROOT, "profiles", "pmc_matvec_pairs.json")) as fpm:
+            with open(os.path.join(_ROOT, pmc_name)) as fpm:
                 pmc = json.load(fpm)
-            if pmc.get("kernel_sources_sha256") != kernel_sources_digest():
-                traffic_note = "profiles/pmc_matvec_pairs.json is stale (kernel sources changed since it was measured)"
+            if pmc.get("kernel_sources_sha256") != kernel_sources_digest(dense=pmc_name.endswith("pmc_dense_walk.json")):
+                traffic_note = f"{pmc_name} is stale (kernel sources changed since it was measured)"
             elif world != 1 or pmc.get("constraints") != int(n_active):
-                traffic_note = "profiles/pmc_matvec_pairs.json was measured on another workload"
+                traffic_note = f"{pmc_name} was measured on another workload"
             else:
-                traffic, traffic_note = pmc["traffic_bytes_per_launch"], "profiles/pmc_matvec_pairs.json (same kernel sources, same workload)"
+                traffic, traffic_note = pmc["traffic_bytes_per_launch"], f"{pmc_name} (same kernel sources, same workload)"
         except Exception:
             pass
         out = {

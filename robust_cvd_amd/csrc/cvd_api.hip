@@ -161,6 +161,11 @@ cvd_handle* cvd_create(int32_t device) {
     }
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseIn, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->evCoarseDone, hipEventDisableTiming));
+    // ... and the stream of the frames' block inverses while the levels are built in line (a latency-bound sweep, one workgroup per
+    // frame, that leaves most of every CU idle: cvd_solve.hip)
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->evInvIn, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->evInvDone, hipEventDisableTiming));
     cvd_solver_options_default(&h->opt);
     cvd_debug_options_default(&h->dbg);
     // device code of every translation unit now, not inside the first solve (first handle of the process: ~0.1 s)

@@ -252,6 +252,8 @@ struct cvd_handle_t {
   DevBuf<double> dInvScratch;
   DevBuf<int> dInvInfo;
   hipEvent_t evCoarseIn = nullptr, evCoarseDone = nullptr;
+  hipStream_t stream3 = nullptr;                       // the frames' block inverses BESIDE an in-line build of the levels (cvd_solve.hip)
+  hipEvent_t evInvIn = nullptr, evInvDone = nullptr;
   DevBuf<FrameConst> dFc2;                             // its own frame constants (the main stream rewrites dFc)
   DevBuf<long long> dItemRange;
   // explicit cross blocks of the dense mode (cvd_cross.h): undirected pairs, their rows, the blocks
@@ -426,6 +428,9 @@ struct cvd_handle_t {
     if (temporal.evDone) (void)hipEventDestroy(temporal.evDone);
     if (evCoarseIn) (void)hipEventDestroy(evCoarseIn);
     if (evCoarseDone) (void)hipEventDestroy(evCoarseDone);
+    if (evInvIn) (void)hipEventDestroy(evInvIn);
+    if (evInvDone) (void)hipEventDestroy(evInvDone);
+    if (stream3) (void)hipStreamDestroy(stream3);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -666,8 +671,9 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
 bool pcgTailScope(Ctx& c, bool coarse, int nThreads, size_t& lds, int& ldsFinish, int& ldsScratch);
 void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, int useBeta, const double* lam, double* q,
                    bool withCoarse, int nThreads, size_t lds, int ldsFinish, int ldsScratch, double tol2);
-void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv, int* dFail, int variant);
-void launchBlockInverse(Ctx& c);
+void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv, int* dFail, int variant,
+                           hipStream_t onStream = nullptr);
+void launchBlockInverse(Ctx& c, hipStream_t onStream = nullptr);   // (onStream: one GPU, B <= 256 only)
 void launchCoarseSetup(Ctx& c, const double* x, int side = 0);
 // third level (cvd_temporal.hip)
 bool temporalScope(const Ctx& c);

@@ -9,10 +9,11 @@ namespace cvd {
 //   variant 1: scalar register-resident sweep (4x4 / 6x6 tiles); variant 2: LDS Cholesky (set_generic_kernels).
 // The three are kept because they pin each other (tests/test_gpu_block_inverse.py).
 void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, const double* dLam, float* dMinv,
-                                  int* dFail, int variant) {
-  hipStream_t s = h->stream;
+                                  int* dFail, int variant, hipStream_t onStream) {
+  hipStream_t s = onStream ? onStream : h->stream;
   const int B = L.B;
   if (B > 256) {
+    if (onStream) throw std::logic_error("launchBlockInverseRaw: the rocSOLVER route runs on the solver's stream");
     // beyond the register-resident kernels (their tile sets end at B = 256): rocSOLVER's strided-batched Cholesky
     // factorisation + inverse of all frames' H_ff + diag(lam), mirrored into the f32 blocks (cvd_coarse.h: k_blocks_*).
     // Reached by two-parameter value transforms on large grids (ScaleShift at 17x10: B = 347); off the tuned path.
@@ -86,13 +87,14 @@ void launchBlockInverseRaw(cvd_handle* h, const Layout& L, const double* dH, con
   HIP_CHECK(hipGetLastError());
 }
 
-void launchBlockInverse(Ctx& c) {
+void launchBlockInverse(Ctx& c, hipStream_t onStream) {
   cvd_handle* h = c.h;
   const int variant = h->forceGeneric ? 2 : (h->opt.block_inverse_variant == 1 ? 1 : 0);
   if (!h->dist()) {
-    launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, variant);
+    launchBlockInverseRaw(h, c.L, h->dH.p, h->dLam.p, h->dMinv.p, h->dFail.p, variant, onStream);
     return;
   }
+  if (onStream) throw std::logic_error("launchBlockInverse: a pair-sharded run keeps everything on the solver's stream");
   // sharded mode: every rank inverts the blocks of ITS frames (it alone holds their reduced H_ff) and the f32 inverses
   // are all-gathered: 4 B^2 bytes per frame on the wire instead of replicated inverse work on every rank
   const size_t B = c.L.B;

@@ -276,8 +276,10 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
   struct PendingGuard {
     cvd_handle* h;
     bool pending = false;
+    bool inverseAside = false;   // the block inverses were forked to their own stream and the solve left before the join
     ~PendingGuard() {
       if (pending) (void)hipStreamWaitEvent(h->stream, h->evCoarseDone, 0);
+      if (inverseAside) (void)hipStreamWaitEvent(h->stream, h->evInvDone, 0);
       if (h->temporal.sidePending) {  // (the third level's assembly was forked and the solve left before its join)
         (void)hipStreamWaitEvent(h->stream, h->temporal.evDone, 0);
         h->temporal.sidePending = false;
@@ -431,7 +433,20 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
       // visibly sensitive to rounding noise along the weak gauge directions.)
       const bool willRefresh = !coarsePending &&
                                (!h->coarseOn || h->opt.coarse_level == 2 || coarseAge < 0 || cgExcess >= kCoarseRebuildIters);
-      {
+      // This iteration builds the levels in line (the first iteration of a solve, or a rebuild while the iterates still move): the
+      // frames' block inverses -- one workgroup per frame, a latency-bound sweep of 0.12 - 0.17 ms that leaves most of every CU
+      // idle, and that only the PCG reads -- run on a stream of their own BESIDE the build instead of in front of it.
+      // (a rebuild on the side stream, for the NEXT iteration: only in the slowly changing regime, see below)
+      const bool asyncRebuild = lastRelChange < asyncMaxChange && !h->coarse.denseMode && h->opt.coarse_level != 2 && !h->dist();
+      const bool inlineRebuild = h->coarseOn && willRefresh && !asyncRebuild;
+      const bool inverseAside = inlineRebuild && !h->dist() && h->stream3 != nullptr && c.L.B <= 256;
+      if (inverseAside) {
+        HIP_CHECK(hipEventRecord(h->evInvIn, s));
+        HIP_CHECK(hipStreamWaitEvent(h->stream3, h->evInvIn, 0));
+        launchBlockInverse(c, h->stream3);
+        HIP_CHECK(hipEventRecord(h->evInvDone, h->stream3));
+        pendingGuard.inverseAside = true;
+      } else {
         const int slot = h->tBegin(KC_INVERSE);
         launchBlockInverse(c);
         h->tEnd(slot);
@@ -450,7 +465,7 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
           // the iterates still move a lot a factor that is one iteration late costs more PCG iterations than the
           // overlap saves, and there the rebuild stays in line.)
           // (the dense level's inverse is one persistent kernel that wants every CU: always in line)
-          if (lastRelChange < asyncMaxChange && !h->coarse.denseMode && h->opt.coarse_level != 2 && !h->dist()) {
+          if (asyncRebuild) {
             h->dFc2.ensure(c.L.F);
             //  the third level is "rebuilt together with the pose-graph level": also when that rebuild runs on the side
             // stream -- at this linearisation point, for THIS iteration's PCG (it is small: two launches and a 0.1 ms inverse).
@@ -481,6 +496,10 @@ void solve(cvd_handle* h, const cvd_opt_params& p, double depthDeformReg, Proble
             // (third level: same linearisation point and damping; its assembly runs beside the pose-graph level's build)
             if (h->temporal.on) launchTemporalSetup(c, h->dX.p, 0);
             launchCoarseSetup(c, h->dX.p);
+            if (inverseAside) {  // (joined before the temporal levels' persistent inverse pair: that kernel keeps the device to itself)
+              HIP_CHECK(hipStreamWaitEvent(s, h->evInvDone, 0));
+              pendingGuard.inverseAside = false;
+            }
             if (h->temporal.on) launchTemporalSetup(c, h->dX.p, 1);
             if (measure) {
               HIP_CHECK(hipEventRecord(h->evRebuild[1], s));

@@ -22,8 +22,22 @@ def test_pmc_traffic_file_was_measured_on_these_kernel_sources():
                     "roofline.traffic = null until `bash tools/pmc_refresh.sh` has run on the GPU box)")
 
 
+def test_dense_traffic_file_was_measured_on_these_kernel_sources():
+    """The same for `bench.py --dense`: profiles/pmc_dense_walk.json (tools/dense_profile.sh) carries the hash of the headers that
+    define k_dense_walk."""
+    import bench
+    import pytest
+    path = os.path.join(ROOT, "profiles", "pmc_dense_walk.json")
+    with open(path) as f:
+        pmc = json.load(f)
+    assert pmc["kernel"].startswith("k_dense_walk") and pmc["traffic_bytes_per_launch"] > 0
+    if pmc["kernel_sources_sha256"] != bench.kernel_sources_digest(dense=True):
+        pytest.skip("profiles/pmc_dense_walk.json is stale: the kernel headers changed since it was measured (the dense bench line "
+                    "reports roofline.traffic = null until `bash tools/dense_profile.sh` has run on the GPU box)")
+
+
 def test_committed_bench_lines_follow_the_contract():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[234]*_bench.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23456]*_bench.json")))
     assert lines, "no bench line under profiles/"
     d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

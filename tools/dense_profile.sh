@@ -24,8 +24,11 @@ rm -rf $OUT/pmc_sq_b
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --kernel-include-regex "k_dense_walk|k_dense_gg" --output-format csv -d $OUT/pmc_$CNT -- python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/pmc_$CNT.log 2>&1
   python $R/tools/pmc_summary.py $OUT/pmc_$CNT $OUT/pmc_${CNT}_dense.csv > /dev/null 2>&1
-  rm -rf $OUT/pmc_$CNT
 done
+# -> profiles/pmc_dense_walk.json: what `bench.py --dense` reports as roofline.traffic (tied to the kernel sources by hash)
+python $R/bench.py --dense --frames $FR --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_dense_cfg.json 2>> $OUT/bench.err   # (workload description)
+python $R/tools/pmc_to_json.py $OUT $TAG dense > $OUT/pmc_dense_walk.json 2> $OUT/pmc_to_json_dense.err && cp $OUT/pmc_dense_walk.json $R/profiles/pmc_dense_walk.json
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 head -14 $OUT/kernel_durations_dense.txt | cut -c1-180
 cat $OUT/pmc_SQ_dense.csv
 cat $OUT/pmc_SQ_dense_b.csv

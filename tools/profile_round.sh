@@ -26,9 +26,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 # BASELINE configs[4] (1000 frames 640x384, 16x12 grid), Cauchy and Huber; dense mode (configs[2] video, 300 frames)
 python $R/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_cauchy.json 2>> $OUT/bench.err
 python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_config4_huber.json 2>> $OUT/bench.err
-python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300.json 2>> $OUT/bench.err
-# dense mode: kernel trace, SQ counters and HBM traffic of the one-walk assembly (tools/dense_profile.sh writes into the same directory)
+# dense mode: kernel trace, SQ counters and HBM traffic of the one-walk assembly (tools/dense_profile.sh writes into the same directory
+# and profiles/pmc_dense_walk.json, which the dense bench line below reads for roofline.traffic)
 bash $R/tools/dense_profile.sh $TAG 300 > $OUT/dense_profile.log 2>&1
+python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300.json 2>> $OUT/bench.err
 # what one rank of an N-rank run computes per PCG iteration (pair-sharded, phantom communicator)
 timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
 timeout 400 python $R/tools/shard_sim.py 1 2 4 8 --dense 2>/dev/null | grep "^world" >> $OUT/shard_sim.log
