@@ -11,10 +11,12 @@ cmdline = sys.argv[3] if len(sys.argv) > 3 else "(command line not recorded)"
 fn = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)
 bygrid = collections.defaultdict(list)
+when = collections.defaultdict(list)
 for r in csv.DictReader(open(fn)):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvd::", "")
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     d[name].append(dur)
+    when[name].append((int(r["Start_Timestamp"]), dur))
     grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
     lds = r.get("LDS_Block_Size") or r.get("LDS_Block_Size_v") or ""
     if lds and int(lds) > 65536:   # (the dense mode's walks launch one grid at every coarse-to-fine level: their LDS size tells the levels apart)
@@ -34,3 +36,9 @@ for name, _ in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:5]:
         med = statistics.median(v)
         w = [x for x in v if x > med / 2]
         print(f"{name:34s} grid {grid:>18s} launches {len(v):5d}  total {sum(v) / 1e3:8.3f} ms  median {med:8.1f} us  working mean {sum(w) / len(w):8.1f} us")
+print("# ... and their LAST six working launches in time order (the end of the trace is the timed region: the final coarse-to-fine level,")
+print("#     which is what bench.py's HIP events time; a dense-mode kernel runs at every level of the pipeline with the same grid)")
+for name, _ in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:5]:
+    med = statistics.median(d[name])
+    last = [x for _, x in sorted(when[name]) if x > med / 2][-6:]
+    print(f"{name:34s} " + "  ".join(f"{x:9.1f}" for x in last) + f"  us   mean {sum(last) / len(last):9.1f} us")

@@ -40,7 +40,7 @@ for name, x in (("prologue (loads, p, E)", us(a[:, 1] - a[:, 0])), ("loop, slowe
                 ("total", us(a[:, 3] - a[:, 0]))):
     print(f"{name:26s} min {x.min():6.2f}  median {np.median(x):6.2f}  mean {x.mean():6.2f}  max {x.max():6.2f}")
 tot = us(a[:, 3] - a[:, 0])
-print("sum of workgroup lifetimes / (256 CUs x 3 slots) = %.1f us" % (tot.sum() / 768))
+print("sum of workgroup lifetimes / (256 CUs x 4 slots: four waves per SIMD since round 5) = %.1f us" % (tot.sum() / 1024))
 # occupancy over time: how many workgroups are alive
 ts = np.linspace(0, us(end.max() - t0), 30)
 alive = [(int(((st <= t) & (us(end - t0) > t)).sum())) for t in ts]
