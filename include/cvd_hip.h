@@ -182,7 +182,7 @@ int32_t cvd_set_pair_constraints(cvd_handle* h, int32_t num_pairs, const int32_t
 int32_t cvd_set_pair_flows(cvd_handle* h, int32_t num_pairs, const int32_t* pair_frames, const float* flow, const uint8_t* mask);
 /* 1 when a problem with these parameters / transform descriptors lies within the scope of the dense mode (identity spatial
  * transform, a reprojection loss, Scale value transform, Global or bilinear grid, per-frame or fixed intrinsics, no
- * smoothness triplets, frame block <= 256): its kernels read the images directly.  0: a dense-mode solve still runs, on the
+ * smoothness triplets, frame block <= 199 -- a frame's packed triangle in LDS --): its kernels read the images directly.  0: a dense-mode solve still runs, on the
  * constraint list materialised on the device (pixel order, 6.4 GB for 144 M constraints); a caller that holds the list
  * anyway may as well hand it over (cvd_set_pair_constraints).  problem: 0 = poseOptimization, 1 = normalizeDepth.
  * What lib_python's FlowConstraintsCollection asks before it keeps a matchSeparation = 0 collection as images. */

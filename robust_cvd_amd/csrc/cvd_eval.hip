@@ -190,6 +190,7 @@ double evalFull(Ctx& c, const double* x, bool withStats, bool noReadBack) {
     else { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(false, true); else CVD_LAUNCH_ASM(false, false); }
 #undef CVD_LAUNCH_ASM
   } else {
+    if (h->dense && c.L.includeStatic) throw std::logic_error("dense mode: the generic assembly has no images to read (DenseListScope should have taken this solve)");
     const AsmPanels panels = makePanels(static_cast<int>(B), (kMaxLds - ldsRest) / 8, panelCap);
     const size_t lds = static_cast<size_t>(panelCap) * 8 + ldsRest;
     CVD_DISPATCH(c.KD, c.KS, {

@@ -615,6 +615,7 @@ bool fastLoss(const Layout& L);
 Table makeTable(cvd_handle* h);
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip);
 bool denseFastScope(const cvd_handle* h, const Layout& L, int KS, bool trip);
+bool denseFastBlockFits(long long B);   // (the frame's packed triangle in LDS: B <= 199)
 // RAII: a solve whose configuration lies outside the dense fast scope runs on the device-materialised list (cvd_dense_walk.h)
 struct DenseListScope {
   cvd_handle* h;

@@ -353,6 +353,7 @@ Table makeTable(cvd_handle* h) {
 // Scope of the dense mode as a function of the CALLER's parameters (cvd_dense_mode_supported: lib_python asks before it hands
 // a matchSeparation = 0 collection over as images instead of a list) -- the same conditions checkDenseScope
 // enforces at solve time, for every step of the schedule the parameters describe.
+bool denseFastBlockFits(long long B);
 bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const cvd_xform_desc& sd, bool haveTriplets, int world,
                         bool normalize) {
   (void)world;  // (pair-sharded runs hand every rank the flow images of ITS pairs: same scope)
@@ -368,16 +369,24 @@ bool denseModeSupported(const cvd_opt_params& p, const cvd_xform_desc& dd, const
   if (dd.depth_type == CVD_DEPTH_IDENTITY) return false;
   if (dd.value_xform != CVD_VALUE_SCALE) return false;
   if (dd.depth_type == CVD_DEPTH_GRID && (dd.cubic_interpolation || dd.grid_size[2] > 1)) return false;
-  // the largest frame block of the schedule must stay within the fast kernels' 256 unknowns
+  // the largest frame block of the schedule must stay within what the image-reading kernels hold in LDS (199 unknowns)
   long long g = dd.depth_type == CVD_DEPTH_GRID ? static_cast<long long>(dd.grid_size[0]) * dd.grid_size[1] : 1;
   if (p.coarse_to_fine && p.num_steps > 1) g = std::max(g, static_cast<long long>(p.ctf_long) * p.ctf_short);
-  return 7 + g <= 256;
+  return denseFastBlockFits(7 + g);
+}
+// The image-reading kernels keep a frame's packed lower triangle in LDS (k_assemble_fast; the fold of the walk's records): B <= 199 at
+// 160 KB.  Beyond that a dense-mode solve takes the list route like every other configuration outside their scope -- the generic
+// list kernels walk the triangle in panels.  (Until round 6 such a solve -- e.g. a 19 x 13 grid, B = 254 -- reached the generic
+// kernels WITHOUT a list: a memory fault, found by tests/test_gpu_dense_mode.py's grid19x13 case.)
+bool denseFastBlockFits(long long B) {
+  return B >= 1 && B <= 256 && (static_cast<size_t>(B) * (B + 1) / 2 + 2 * B + 4 * 36) * 8 <= kMaxLds;
 }
 
 // Dense mode: the specialised kernels (pixel walk, image-reading product / cost) cover the default residual configuration of the
 // reference pipeline; every other configuration runs on the list the images stand for, materialised on the device (DenseListScope).
 bool denseFastScope(const cvd_handle* h, const Layout& L, int KS, bool trip) {
-  return !(KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || L.cubic);
+  return !(KS != 0 || !fastLoss(L) || L.N != 1 || trip || L.intrOpt == CVD_INTR_SHARED || h->forceGeneric || L.cubic ||
+           !denseFastBlockFits(L.B));
 }
 void checkDenseScope(cvd_handle* h, const Layout& L, int KS, bool trip) {
   if (!h->dense) return;
