@@ -134,6 +134,60 @@ def test_dense_one_directional_pairs_and_odd_raster(Solver, product):
     assert rel(a["gradient"], b["gradient"]) < TOL and rel(a["hdiag"], b["hdiag"]) < TOL and rel(a["hfull"], b["hfull"]) < TOL
 
 
+@pytest.mark.parametrize("raster", [(20, 12, True), (20, 12, False), (9, 5, True), (130, 3, True)])
+def test_dense_ragged_inputs_small_rasters_holes_and_invalid_values(Solver, raster):
+    """Edge cases of the image-reading kernels: rasters narrower than one run per lane / shorter than the four row groups of a wave /
+    a single strip (20 x 12, 9 x 5, 130 x 3), a pair whose mask is empty, a pair whose flow points out of the image everywhere, NaN and
+    infinite flow vectors, zero / negative / NaN depth pixels (the reference skips the whole constraint, lib/PoseOptimizer.cpp:1190-1193),
+    a frame no pair touches.  Cost, gradient, diag(H) and the full Hessian (products column by column) against the oracle's list."""
+    W, H, nan_depth = raster
+    v = synth.make_video(6, W, H, seed=67)
+    flow, mask = synth.make_dense_flows(v)
+    rng = np.random.default_rng(11)
+    keep = np.flatnonzero((v.pairs[:, 0] != 5) & (v.pairs[:, 1] != 5))       # frame 5: no constraints at all
+    v.pairs, flow, mask = v.pairs[keep], flow[keep].copy(), mask[keep].copy()
+    mask[0] = 0                                                                # an empty pair
+    flow[1] = 4.0 * max(W, H)                                                  # every target out of bounds
+    bad = rng.random(flow.shape[:3]) < 0.03
+    flow[..., 0][bad] = np.nan
+    bad = rng.random(flow.shape[:3]) < 0.02
+    flow[..., 1][bad] = np.inf
+    depth = v.depth.copy()
+    hole = rng.random(depth.shape)
+    depth[hole < 0.03] = 0.0
+    depth[(hole >= 0.03) & (hole < 0.05)] = -1.0
+    depth[(hole >= 0.05) & (hole < 0.07)] = np.nan if nan_depth else 0.0
+    v.depth = depth
+    # (the scale regulariser takes the median of ALL source depths with std::nth_element, lib/PoseOptimizer.cpp:1371-1375: undefined
+    # with NaN in the image -- switched off there; zeros and negatives alone leave it defined: the case without NaN keeps it on)
+    off, loc = synth.dense_constraints_from_flows(v, flow, mask)
+    hip, orc = Solver(0), Oracle()
+    for s in (hip, orc):
+        s.set_video(v.num_frames, v.width, v.height, v.aspect, v.inv_aspect)
+        s.set_depth_all(v.depth)
+        s.reset_poses()
+    hip.set_pair_flows(v.pairs, flow, mask)
+    orc.set_pair_constraints(v.pairs, off, loc, None)
+    pose = np.zeros((v.num_frames, 7))
+    pose[:, :6] = rng.normal(0, 0.02, (v.num_frames, 6))
+    pose[:, 6] = 0.2
+    p = OptParams.defaults()
+    p.num_threads = 4
+    if nan_depth:
+        p.scale_reg = 0.0
+    res = {}
+    for k, s in (("hip", hip), ("oracle", orc)):
+        s.reset_depth_xforms(XformDesc.grid_depth(4, 3))
+        s.reset_spatial_xforms(XformDesc.spatial())
+        th = s.get_xform_params()
+        s.set_xform_params(th * (1.0 + 0.05 * np.random.default_rng(9).standard_normal(th.shape)))
+        res[k] = s.evaluate(p, 0.1, pose, want_gradient=True, want_hdiag=True, want_hfull=True)
+    a, b = res["hip"], res["oracle"]
+    assert a["num_residual_blocks"] == b["num_residual_blocks"] and b["num_residual_blocks"] > 0
+    assert abs(a["cost"] - b["cost"]) <= TOL * abs(b["cost"]), (a["cost"], b["cost"])
+    assert rel(a["gradient"], b["gradient"]) < TOL and rel(a["hdiag"], b["hdiag"]) < TOL and rel(a["hfull"], b["hfull"]) < TOL
+
+
 def test_dense_mode_and_the_equivalent_list_agree_on_the_device(Solver):
     """The same constraints as images (dense kernels) and as a list (table kernels): identical problem, two code paths."""
     v, hip, _, n = _setup(Solver, seed=63)
