@@ -171,12 +171,13 @@ def test_two_ranks_with_triplets_and_three_ranks():
     assert np.array_equal(ranks3[0][2], ranks3[2][2])
 
 
-@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free"])
+@pytest.mark.parametrize("product", ["explicit_blocks", "matrix_free", "list_route"])
 def test_two_ranks_dense_mode(product):
     """Dense mode (flow / mask images of every pair instead of a constraint list) sharded over two ranks: every rank holds the
     images of ITS pairs; the explicit cross blocks X_ab live on the pair's rank, the reduced H_ff (which carries the
     frame-diagonal part of the product in this mode) on the frame's owner; coarse edge blocks from the local cross blocks are
-    all-reduced.  Against the single-rank dense solve."""
+    all-reduced.  Against the single-rank dense solve.  list_route: Shared intrinsics -- outside the image-reading kernels' scope --,
+    every rank materialises the list of ITS pairs on the device (DenseListScope) and the sharded list kernels run."""
     from robust_cvd_amd import api
     v = synth.make_video(7, 96, 56, seed=55)
     flow, mask = synth.make_dense_flows(v)
@@ -199,6 +200,8 @@ def test_two_ranks_dense_mode(product):
         s.reset_spatial_xforms(XformDesc.spatial())
         p = OptParams.defaults()
         p.ctf_long, p.ctf_short = 6, 4
+        if product == "list_route":
+            p.intr_opt = 1   # IntrinsicsOptimization.Shared
         s.normalize_depth(p)
         ev = s.evaluate(p, 0.1, want_gradient=True, want_hdiag=True)
         s.pose_optimization(p)
