@@ -2172,13 +2172,19 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   const bool fusedY = !init && cs.Wb != nullptr;
   const bool fusedDense = !init && ds.Ainv != nullptr;  // (the grid then has F extra workgroups)
   const int nWaves = nThreads >> 6;
-  const bool denseWg = static_cast<int>(blockIdx.x) >= nF;
-  const int f = denseWg ? L.F + (static_cast<int>(blockIdx.x) - nF) : f0 + static_cast<int>(blockIdx.x);
+  // Logical workgroup index: [0, nF) the frames, then the levels' workgroups.  A launch of its own (not the fused tail, whose
+  // workgroups are all resident) dispatches the LEVELS' workgroups first: theirs is the longest dependent chain of the launch, and
+  // behind a thousand frame workgroups -- four rounds of the device at configs[4] -- it started when everything else was done.
+  const int nExtraWg = static_cast<int>(gridDim.x) - nF;
+  const int bid = FUSED ? static_cast<int>(blockIdx.x)
+                        : (static_cast<int>(blockIdx.x) < nExtraWg ? nF + static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) - nExtraWg);
+  const bool denseWg = bid >= nF;
+  const int f = denseWg ? L.F + (bid - nF) : f0 + bid;
   // (third level: its S workgroups follow the dense level's)
   const int nDenseWg = (fusedDense && ds.rowSplit > 0) ? (nF + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0;
   // (... and the kCB of the temporal pose level, coarse_level 3, follow those: same rows routine, its own descriptor)
   const bool tlOn = !init && tsp != nullptr, tpOn = !init && tpp != nullptr;
-  const bool tlWg = (tlOn || tpOn) && static_cast<int>(blockIdx.x) >= nF + nDenseWg;
+  const bool tlWg = (tlOn || tpOn) && bid >= nF + nDenseWg;
   const int tid = threadIdx.x;
   const size_t base = static_cast<size_t>(f) * B;
   // (pqReduced: the fused exchange of the pair-sharded mode left the all-reduced p.q there; S_RZ is rewritten only by the
@@ -2259,7 +2265,7 @@ __device__ __forceinline__ void cgUpdateBody(const Layout& L, int init, const do
   };
   if (f >= L.F) {
     if (tlWg) {  // third level's workgroup (one coarse hat) or the temporal pose level's (one mode)
-      const int k = static_cast<int>(blockIdx.x) - nF - nDenseWg, nTl = tlOn ? tsp->S * tsp->parts : 0;
+      const int k = bid - nF - nDenseWg, nTl = tlOn ? tsp->S * tsp->parts : 0;
       if (!tlLevelRows<FUSED>(k < nTl ? tsp : tpp, k < nTl ? k : k - nTl, L.F, alpha, 0, sDone, scal, sm, mid)) return;
     } else {
     // ---- dense-level workgroup: rows [0, rowSplit) of kDenseFramesPerGroup frames, one frame after the other (F + F / 2
