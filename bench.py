@@ -534,9 +534,10 @@ def main():
                                     "GB/s": 16.0 * slots / max(m["ktimes"]["dense_gg"]["avg_ms"], 1e-9) * 1e-6,
                                     "note": "8 B scalar + 8 B flow per pixel slot, read once: panels of SOURCE vertices, one launch per "
                                             "direction (the pixels of the one cell row two panels share are read twice: + 1/9 at 17 x 10)"},
+                    # (one block per undirected pair + -- one GPU -- the frames' own blocks H_ff, streamed by the same kernel since round 6)
                     "product": {"kernel": "k_cross_matvec", "avg_ms": m["ktimes"]["matvec_pairs"]["avg_ms"],
-                                "GB/s": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6,
-                                "frac_hbm": len(und) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS}}
+                                "GB/s": (len(und) + (frames if world == 1 else 0)) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6,
+                                "frac_hbm": (len(und) + (frames if world == 1 else 0)) * (B * B * 8.0 + (2 * 3 + 2) * B * 8.0) / max(m["ktimes"]["matvec_pairs"]["avg_ms"], 1e-9) * 1e-6 / HBM_PEAK_GBS}}
                    if dense_explicit else {}),
             }} if args.dense else {}),
             **({"rccl": {"ranks": world, "frames_owned_per_rank": -(-frames // world),

@@ -34,7 +34,11 @@ constexpr int kCrossThreads = 512;
 // q rows of one undirected pair from its block: y_a = X p_b, y_b = X^T p_a with p = (z + Z c + beta p_old) * mask (the
 // search direction, formed here exactly as the matrix-free product forms it).  Each wave streams its rows once, fully
 // coalesced: a row's dot product with p_b gives y_a[row], the same loads scaled by p_a[row] accumulate y_b per column.
+// Workgroups beyond the pairs (diagSlot != nullptr: one per frame) stream the frame's own block: y_f = H_ff p_f into a row of its own.
+// (Until round 6 the finish half of the PCG tail formed H_ff p_f -- 75 MB of the same streaming, but inside a latency chain of one
+// workgroup per frame in front of a grid barrier: the dense mode's tail took 58 us against the list mode's 28.)
 inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L, CrossPairs cp, const double* __restrict__ X,
+                                                                const double* __restrict__ Hd, const int* __restrict__ diagSlot,
                                                                 const double* __restrict__ mask, const double* __restrict__ z,
                                                                 const double* __restrict__ pOld, const double* __restrict__ scal,
                                                                 int useBeta, double* __restrict__ qPart, CoarseView V) {
@@ -49,7 +53,8 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L,
   double* ybw = ya + B;          // NW x B partial column sums
   double* cl = ybw + NW * B;     // 2 x kCB coarse corrections
   double* tls = cl + 2 * kCB;    // third level (CoarseView::tl): the two frames' coefficients, 2 x tlS
-  const int fa = cp.fa[pair], fb = cp.fb[pair];
+  const bool diag = pair >= cp.count;   // (uniform)
+  const int fa = diag ? pair - cp.count : cp.fa[pair], fb = diag ? fa : cp.fb[pair];
   const double beta = useBeta ? scal[S_BETA] : 0.0;
   const bool tlOn = V.tl != nullptr;
   if (tid < 2 * kCB) cl[tid] = (V.cF != nullptr) ? V.cF[(tid < kCB ? fa : fb) * kCB + (tid & (kCB - 1))] : 0.0;
@@ -73,7 +78,7 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L,
     pb[i] = (z[ib] + cb2 + (useBeta ? beta * pOld[ib] : 0.0)) * mask[ib];
   }
   __syncthreads();
-  const double* Xp = X + static_cast<size_t>(pair) * B * B;
+  const double* Xp = diag ? Hd + static_cast<size_t>(fa) * B * B : X + static_cast<size_t>(pair) * B * B;
   constexpr int NC = 4;  // column chunks of 64 per lane: B <= 256
   double cb[NC] = {0.0, 0.0, 0.0, 0.0};
   double pbv[NC];
@@ -108,6 +113,11 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L,
   for (int k = 0; k < NC; ++k)
     if (lane + 64 * k < B) ybw[wave * B + lane + 64 * k] = cb[k];
   __syncthreads();
+  if (diag) {   // (symmetric block: the row products are the whole answer)
+    double* outD = qPart + static_cast<size_t>(diagSlot[fa]) * B;
+    for (int i = tid; i < B; i += kCrossThreads) outD[i] = ya[i];
+    return;
+  }
   double* outA = qPart + static_cast<size_t>(cp.slot[pair * 2]) * B;
   double* outB = qPart + static_cast<size_t>(cp.slot[pair * 2 + 1]) * B;
   for (int i = tid; i < B; i += kCrossThreads) {

@@ -258,7 +258,9 @@ struct cvd_handle_t {
   DevBuf<long long> dItemRange;
   // explicit cross blocks of the dense mode (cvd_cross.h): undirected pairs, their rows, the blocks
   std::vector<int> xFa, xFb;
-  DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff, dXPairEdge;
+  DevBuf<int> dXFa, dXFb, dXSlot, dXFiOff, dXPairEdge, dXDiagSlot;
+  bool xDiagRows = false;           // the product kernel writes H_ff p_f into a row of the frame's range (one GPU)
+  int xRows = 0;                    // rows of the partial-product buffer in the explicit-block mode
   DevBuf<long long> dXRange;
   DevBuf<double> dXBlocks;
   // one-walk assembly of the dense mode (cvd_dense_walk.h): records of the directed pairs, per-pixel grid x grid scalars

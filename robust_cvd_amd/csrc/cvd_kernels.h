@@ -2694,6 +2694,7 @@ struct TailUpdate {
   DenseStep ds;
   const TlStep* ts;        // third level (device copy of its descriptor), nullptr: off
   const TlStep* tp;        // temporal pose level (coarse_level 3), nullptr: off
+  int diagInProduct;       // explicit cross blocks: H_ff p_f is one of the frame's partial rows (k_cross_matvec), not the finish half's work
 };
 
 template <int KD>
@@ -2719,7 +2720,7 @@ inline __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))
     if (f < L.F) {
       TailCarry carry{0.0, 0.0};
       if (!matvecFinishBody<KD, true>(L, x, mask, lam, median, inRange, rangeFlags, fiOff, fiList, qPart, U.z, pOld, pNew, scal,
-                                      nullptr, useBeta, q, fdot, 0, nRows, rc, V, qc, ccOff, Hdiag, nullptr, 0, L.F,
+                                      nullptr, useBeta, q, fdot, 0, nRows, rc, V, qc, ccOff, Hdiag, nullptr, 0, U.diagInProduct ? 0 : L.F,
                                       sm + U.ldsFinish, carry, U.ts, sm + L.B))  // (restriction products: the update half's partial-sum region)
         return false;
       pv = carry.pv;

@@ -75,13 +75,15 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
     hipEvent_t evStart, evStop;
     (void)h->tReserve(KC_MATVEC_PAIRS, evStart, evStop);
     const size_t ldsX = (3 * B + (kCrossThreads / 64) * B + 2 * kCB + 2 * kTlMaxS) * 8;
-    const unsigned nP = static_cast<unsigned>(h->xFa.size());
+    // (+ one workgroup per frame for its own block H_ff: see k_cross_matvec)
+    const unsigned nP = static_cast<unsigned>(h->xFa.size()) + (h->xDiagRows ? static_cast<unsigned>(c.L.F) : 0u);
+    const int* diagSlot = h->xDiagRows ? h->dXDiagSlot.p : nullptr;
     if (evStart)
       hipExtLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, evStart, evStop, 0, c.L, crossPairs(h),
-                            h->dXBlocks.p, h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+                            h->dXBlocks.p, h->dH.p, diagSlot, h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
     else
-      hipLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, c.L, crossPairs(h), h->dXBlocks.p, h->dMask.p, z,
-                         pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
+      hipLaunchKernelGGL(k_cross_matvec, dim3(nP), dim3(kCrossThreads), ldsX, s, c.L, crossPairs(h), h->dXBlocks.p, h->dH.p, diagSlot,
+                         h->dMask.p, z, pOld, h->dScal.p, useBeta, h->dQPart.p, cF);
     HIP_CHECK(hipGetLastError());
   } else if (c.L.includeStatic && c.nItems > 0) {
     const size_t lds = 6 * B * 8 + 2 * sizeof(FrameConst) + (18 + 4 * 24 + 8 + 2 * kCB) * 8;
@@ -197,7 +199,7 @@ void launchMatvec(Ctx& c, const double* x, const double* z, const double* pOld, 
                          h->regCache, cF,
                          fusedX ? (denseFused ? qcX : nullptr) : (((fusedCoarse || denseFused) && !h->dist()) ? h->coarse.qc.p : nullptr), cc,
                          c.cross ? h->dH.p : nullptr, fusedX ? pqX : nullptr, h->dist() ? h->ownFirst() : 0,
-                         h->dist() ? h->ownCount() : c.L.F, ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
+                         h->dist() ? h->ownCount() : ((c.cross && h->xDiagRows) ? 0 : c.L.F), ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr));
     });
     HIP_CHECK(hipGetLastError());
     if (fusedX && ownerShardedUpdate(h, withCoarse)) {
@@ -291,7 +293,8 @@ void launchPcgTail(Ctx& c, const double* x, const double* pOld, double* pNew, in
   const TailUpdate U{h->dMinv.p, h->dDx.p, h->dR.p, h->dZ.p, fd + F, fd + 2 * F, tol2, h->coarse.modeActive.p, h->hPcg,
                      h->dCounters.p + 1, h->dTailBar.p, h->dFdot.p + 4 * static_cast<size_t>(F) + 32, ldsFinish, ldsScratch, ds,
                      ts.Ainv != nullptr ? temporalStepDev(h) : static_cast<const TlStep*>(nullptr),
-                     poseT ? poseTemporalStepDev(h) : static_cast<const TlStep*>(nullptr)};
+                     poseT ? poseTemporalStepDev(h) : static_cast<const TlStep*>(nullptr),
+                     (c.cross && h->xDiagRows) ? 1 : 0};
   const int grid = F + (withCoarse && !poseT && split > 0 ? (F + kDenseFramesPerGroup - 1) / kDenseFramesPerGroup : 0) +
                    (ts.Ainv != nullptr ? ts.S * ts.parts : 0) + (poseT ? kCB * tlParts(h->coarse.ptNn) : 0);
   const int slot = h->tBegin(KC_CG_UPDATE);  // (timed under the update class: the finish class stays empty on this path)

@@ -903,12 +903,18 @@ void compileTable(cvd_handle* h, const std::vector<int>& range, bool withTriplet
       h->dDwRecOff.upload(recOff.data(), recOff.size(), s);
       h->dXDir.upload(xDir.data(), xDir.size(), s);
     }
-    std::vector<int> xFiOff(h->F + 1, 0), xSlot(std::max<size_t>(1, h->xFa.size() * 2), 0);
+    std::vector<int> xFiOff(h->F + 1, 0), xSlot(std::max<size_t>(1, h->xFa.size() * 2), 0), xDiagSlot(std::max(1, h->F), 0);
+    // (one GPU: a frame's own block H_ff is one more row of its range, produced by the product kernel -- k_cross_matvec; a
+    // pair-sharded run keeps H_ff p_f in the finish half of the frame's owner)
+    h->xDiagRows = !h->dist();
     int row = 0;
     for (int f = 0; f < h->F; ++f) {
       for (int code : frameRows[f]) xSlot[code] = row++;
+      if (h->xDiagRows) xDiagSlot[f] = row++;
       xFiOff[f + 1] = row;
     }
+    h->xRows = row;
+    h->dXDiagSlot.upload(xDiagSlot.data(), xDiagSlot.size(), s);
     h->dXFa.upload(h->xFa.data(), h->xFa.size(), s);
     h->dXFb.upload(h->xFb.data(), h->xFb.size(), s);
     h->dXRange.upload(xRange.data(), xRange.size(), s);
@@ -1242,7 +1248,7 @@ void ensureBuffers(Ctx& c) {
       HIP_CHECK(hipMemsetAsync(h->dHd.p, 0, nPad * sizeof(double), h->stream));
     }
   }
-  h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(std::max(h->qRows, c.nItems * 2)) * B));
+  h->dQPart.ensure(std::max<size_t>(1, static_cast<size_t>(std::max(std::max(h->qRows, c.nItems * 2), c.cross ? h->xRows : 0)) * B));
   h->dFdot.ensure(static_cast<size_t>(c.L.F) * 4 + 64);  // (+64: the published p.q sum of k_pcg_tail, in a line of its own)
   h->dCostItem.ensure(std::max(1, c.nItems));
   h->dCostFrame.ensure(c.L.F);
