@@ -163,13 +163,13 @@ __device__ __forceinline__ void dwChain(const Layout& L, const DwPairConst& P, c
                                         const double* __restrict__ xt, const float4& nd, double da, double db, const DwTaps& ts,
                                         const DwTaps& tt, DwState& o) {
   constexpr double eps = 1e-6;
-  const int gx = L.gx;
+  const int gx = L.gx, gMax = L.nD - 1;
   // (the same tap order and summation order as fastGather / the other fast kernels)
   double Da = 0.0, Db = 0.0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    Da += da * xs[7 + ts.i0 + (k & 1) + (k >> 1) * gx] * ts.Wt(k);
-    Db += db * xt[7 + tt.i0 + (k & 1) + (k >> 1) * gx] * tt.Wt(k);
+    Da += da * xs[7 + min(ts.i0 + (k & 1) + (k >> 1) * gx, gMax)] * ts.Wt(k);   // (clamped: the 1 x 1 grid of a Global transform)
+    Db += db * xt[7 + min(tt.i0 + (k & 1) + (k >> 1) * gx, gMax)] * tt.Wt(k);
   }
   o.Da = Da;
   const double pax = static_cast<double>(nd.x), pay = static_cast<double>(nd.y);
@@ -311,6 +311,9 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
   static_assert(KD == 4, "bilinear depth grids (the explicit-block scope of the dense mode)");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int B = L.B, G = L.nD, gx = L.gx;
+  // A Global depth transform (one value parameter per frame) is walked as a 1 x 1 grid: dwGather returns vertex 0 with weight one
+  // and three taps of weight exactly zero that do not exist -- nothing is accumulated for them and the chain's gathers clamp their index.
+  const int nTap = G == 1 ? 1 : 4;
   const int accN = dwAccDoubles(G);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,6 +440,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         const double wy0 = 1.0 - curRy, wy1 = curRy;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (k >= nTap) continue;   // (uniform: a Global transform is ONE vertex, its cell's other three taps do not exist)
           double* col = MS + curI0 + (k & 1) + (k >> 1) * gx;
           const double wy = (k >> 1) ? wy1 : wy0;
 #pragma unroll
@@ -445,15 +449,17 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
         // vertex pairs of the cell, lower vertex first: offsets {0, 1, gx - 1, gx, gx + 1} -> band index {0, 1, 2, 3, 4}
         const double y00 = wy0 * wy0, y01 = wy0 * wy1, y11 = wy1 * wy1;
         atomicAdd(&bandS[0 * G + curI0], BS[0] * y00);
-        atomicAdd(&bandS[1 * G + curI0], BS[1] * y00);
-        atomicAdd(&bandS[3 * G + curI0], BS[0] * y01);
-        atomicAdd(&bandS[4 * G + curI0], BS[1] * y01);
-        atomicAdd(&bandS[0 * G + curI0 + 1], BS[2] * y00);
-        atomicAdd(&bandS[2 * G + curI0 + 1], BS[1] * y01);
-        atomicAdd(&bandS[3 * G + curI0 + 1], BS[2] * y01);
-        atomicAdd(&bandS[0 * G + curI0 + gx], BS[0] * y11);
-        atomicAdd(&bandS[1 * G + curI0 + gx], BS[1] * y11);
-        atomicAdd(&bandS[0 * G + curI0 + gx + 1], BS[2] * y11);
+        if (nTap == 4) {
+          atomicAdd(&bandS[1 * G + curI0], BS[1] * y00);
+          atomicAdd(&bandS[3 * G + curI0], BS[0] * y01);
+          atomicAdd(&bandS[4 * G + curI0], BS[1] * y01);
+          atomicAdd(&bandS[0 * G + curI0 + 1], BS[2] * y00);
+          atomicAdd(&bandS[2 * G + curI0 + 1], BS[1] * y01);
+          atomicAdd(&bandS[3 * G + curI0 + 1], BS[2] * y01);
+          atomicAdd(&bandS[0 * G + curI0 + gx], BS[0] * y11);
+          atomicAdd(&bandS[1 * G + curI0 + gx], BS[1] * y11);
+          atomicAdd(&bandS[0 * G + curI0 + gx + 1], BS[2] * y11);
+        }
 #pragma unroll
         for (int f = 0; f < kDwFeatS; ++f) { AS[0][f] = 0.0; AS[1][f] = 0.0; }
         BS[0] = BS[1] = BS[2] = 0.0;
@@ -530,6 +536,7 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
           for (int k = 0; k < 4; ++k) fb[k] = tt.Wt(k) * db;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
+            if (k >= nTap) continue;
             double* col = MT + tt.i0 + (k & 1) + (k >> 1) * gx;
 #pragma unroll
             for (int f = 0; f < kDwFeatT; ++f) atomicAdd(&col[f * G], mt[f] * fb[k]);
@@ -538,15 +545,17 @@ inline __global__ __launch_bounds__(kDwThreads) __attribute__((amdgpu_waves_per_
           const int j0 = tt.i0;
           const double b0 = sTT * fb[0], b1 = sTT * fb[1], b2 = sTT * fb[2], b3 = sTT * fb[3];
           atomicAdd(&bandT[0 * G + j0], b0 * fb[0]);
-          atomicAdd(&bandT[1 * G + j0], b0 * fb[1]);
-          atomicAdd(&bandT[3 * G + j0], b0 * fb[2]);
-          atomicAdd(&bandT[4 * G + j0], b0 * fb[3]);
-          atomicAdd(&bandT[0 * G + j0 + 1], b1 * fb[1]);
-          atomicAdd(&bandT[2 * G + j0 + 1], b1 * fb[2]);
-          atomicAdd(&bandT[3 * G + j0 + 1], b1 * fb[3]);
-          atomicAdd(&bandT[0 * G + j0 + gx], b2 * fb[2]);
-          atomicAdd(&bandT[1 * G + j0 + gx], b2 * fb[3]);
-          atomicAdd(&bandT[0 * G + j0 + gx + 1], b3 * fb[3]);
+          if (nTap == 4) {
+            atomicAdd(&bandT[1 * G + j0], b0 * fb[1]);
+            atomicAdd(&bandT[3 * G + j0], b0 * fb[2]);
+            atomicAdd(&bandT[4 * G + j0], b0 * fb[3]);
+            atomicAdd(&bandT[0 * G + j0 + 1], b1 * fb[1]);
+            atomicAdd(&bandT[2 * G + j0 + 1], b1 * fb[2]);
+            atomicAdd(&bandT[3 * G + j0 + 1], b1 * fb[3]);
+            atomicAdd(&bandT[0 * G + j0 + gx], b2 * fb[2]);
+            atomicAdd(&bandT[1 * G + j0 + gx], b2 * fb[3]);
+            atomicAdd(&bandT[0 * G + j0 + gx + 1], b3 * fb[3]);
+          }
         }
       } else {
         ioG[lane * kDwIoStride + tb] = 0.0;
@@ -762,7 +771,10 @@ inline __global__ __launch_bounds__(kGgThreads) void k_dense_gg(Layout L, Table 
           const int is = curS + (k & 1) + (k >> 1) * L.gx - v0;
           if (is < 0 || is >= pw) continue;
 #pragma unroll
-          for (int l = 0; l < KD; ++l) atomicAdd(&GG[is * G + curT + (l & 1) + (l >> 1) * L.gx], acc[k][l]);
+          for (int l = 0; l < KD; ++l) {
+            const int it = curT + (l & 1) + (l >> 1) * L.gx;
+            if (it < G) atomicAdd(&GG[is * G + it], acc[k][l]);   // (a Global transform's 1 x 1 grid: only tap 0 exists)
+          }
         }
       };
       for (int t0 = 0; t0 < len; t0 += kBatch) {

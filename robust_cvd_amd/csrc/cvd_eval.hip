@@ -97,7 +97,7 @@ void enqueueStats(Ctx& c) {
 bool crossScope(cvd_handle* h, const Ctx& c) {
   const bool off = h->opt.dense_matrix_free != 0;  // comparison variant
   return h->dense && !off && !h->forceGeneric && c.L.includeStatic && !h->xFa.empty() && c.KS == 0 && fastLoss(c.L) &&
-         c.L.N == 1 && c.L.nD > 0 && c.KD == 4 && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
+         c.L.N == 1 && c.L.nD > 0 && (c.KD == 4 || (c.KD == 1 && c.L.nD == 1)) && c.L.intrOpt != CVD_INTR_SHARED && !c.trip && !(c.L.positionRegSqrt > 0.0) &&
          c.L.B <= 256 && (static_cast<size_t>(c.L.B) * (c.L.B + 1) / 2 + 2 * c.L.B + 4 * 36) * 8 <= kMaxLds &&  // (the fold's packed block)
          dwLdsBytes(c.L.nD, c.L.B, kDwThreads) <= kMaxLds;
 }
@@ -181,11 +181,21 @@ double evalFull(Ctx& c, const double* x, bool withStats, bool noReadBack) {
 #endif
     if (c.cross) {
       // explicit-block scope of the dense mode: one walk over the pixels, then a per-frame fold of the pairs' records
+      // (a Global transform -- the first level of the default schedule -- is walked as a 1 x 1 grid; its fold and regularisers
+      // are the one-tap instantiation's.  Until round 6 that level ran matrix-free: 1.6 ms per PCG product over the 144 M pixels
+      // for an 8 x 8 block per pair, more than half of the dense pipeline's time.)
       launchDenseWalk(c, x);
-      allowLds((k_assemble_fast<4, true, false, true>), ldsFast);
-      hipLaunchKernelGGL((k_assemble_fast<4, true, false, true>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
-                         h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p, h->dCostFrame.p,
-                         h->dFocal.p, h->dFocal.p + c.L.F, denseRecords(h));
+      if (c.KD == 1) {
+        allowLds((k_assemble_fast<1, true, false, true>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<1, true, false, true>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p, h->dCostFrame.p,
+                           h->dFocal.p, h->dFocal.p + c.L.F, denseRecords(h));
+      } else {
+        allowLds((k_assemble_fast<4, true, false, true>), ldsFast);
+        hipLaunchKernelGGL((k_assemble_fast<4, true, false, true>), dim3(c.L.F), dim3(kAsmThreads), ldsFast, s, c.L, c.T, x, h->dFc.p,
+                           h->dMask.p, h->dMedian.p, h->dRegOwner.p, h->dInRange.p, work, h->dG.p, h->dH.p, h->dCostFrame.p,
+                           h->dFocal.p, h->dFocal.p + c.L.F, denseRecords(h));
+      }
     } else if (h->dense) { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(true, true); else CVD_LAUNCH_ASM(true, false); }
     else { if (stage && CVD_ASM_STAGE) CVD_LAUNCH_ASM(false, true); else CVD_LAUNCH_ASM(false, false); }
 #undef CVD_LAUNCH_ASM
