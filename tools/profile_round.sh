@@ -30,6 +30,7 @@ python $R/bench.py --config 4 --robust huber --steps 10 --warmup 2 --no-cpu-base
 # and profiles/pmc_dense_walk.json, which the dense bench line below reads for roofline.traffic)
 bash $R/tools/dense_profile.sh $TAG 300 > $OUT/dense_profile.log 2>&1
 python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --time-all-kernels > $OUT/bench_dense_300.json 2>> $OUT/bench.err
+python $R/bench.py --dense --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_dense_300_plain.json 2>> $OUT/bench.err   # (only the hot kernel timed: the line's value without the event pairs around every class)
 # what one rank of an N-rank run computes per PCG iteration (pair-sharded, phantom communicator)
 timeout 300 python $R/tools/shard_sim.py 1 2 4 8 2>/dev/null | grep "^world" > $OUT/shard_sim.log
 timeout 400 python $R/tools/shard_sim.py 1 2 4 8 --dense 2>/dev/null | grep "^world" >> $OUT/shard_sim.log
