@@ -100,7 +100,7 @@ inline __global__ __launch_bounds__(kCrossThreads) void k_cross_matvec(Layout L,
     for (int k = 0; k < NC; ++k) {
       d0 += xv0[k] * pbv[k];
       d1 += xv1[k] * pbv[k];
-      cb[k] += xv0[k] * a0 + xv1[k] * a1;
+      if (!diag) cb[k] += xv0[k] * a0 + xv1[k] * a1;   // (uniform; a frame's own block is symmetric: its row products are everything)
     }
     d0 = waveSum(d0);
     d1 = waveSum(d1);

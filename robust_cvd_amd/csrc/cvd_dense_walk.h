@@ -87,20 +87,12 @@ struct DenseWalkList {
   DenseLaneMap map;
 };
 
-// ndc of both end points of a dense-mode constraint from its flow vector, WITHOUT the depth fetch (k_dense_gg: taps only).  The same
-// float arithmetic as denseConstraintFromFlow; false: target out of bounds.
+// ndc of both end points of a dense-mode constraint from its flow vector, WITHOUT the depth fetch (k_dense_gg: taps only); false:
+// no candidate.  (densePixelGeometry, cvd_kernels.h: the one statement of this arithmetic.)
 __device__ __forceinline__ bool denseNdcFromFlow(const Table& T, int ix, int iy, float2 f, float4& n) {
-  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-  if (!(isfinite(fx1) && isfinite(fy1))) return false;
-  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
-  const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
-  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
-  n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
-  n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
-  n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
-  n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
-  return true;
+  float4 loc;
+  int ai, bi;
+  return densePixelGeometry(T, ix, iy, f, loc, n, ai, bi);
 }
 
 // One constraint s -> t.  What stays in registers between its phases is the minimum the Jacobian can be re-expanded from:
@@ -131,24 +123,12 @@ __device__ __forceinline__ void dwGather(const Layout& L, float lx, float ly, Dw
 // The pixel whose source depth a constraint at pixel (ix, iy) reads (the reference's Observation constructor truncates the float
 // location times the raster size, lib/PoseOptimizer.cpp:104-116: not always (ix, iy) itself), and the target's for flow f; -1: no candidate.
 __device__ __forceinline__ int denseSourceDepthIndex(const Table& T, int ix, int iy) {
-  const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
-  int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
-  int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
-  ax = min(max(ax, 0), T.W - 1);
-  ay = min(max(ay, 0), T.H - 1);
-  return ay * T.W + ax;
+  return densePixelOfLoc(T, __fmul_rn(static_cast<float>(ix), T.sx), __fmul_rn(static_cast<float>(iy), T.sy));
 }
 __device__ __forceinline__ int denseTargetDepthIndex(const Table& T, int ix, int iy, float2 f) {
-  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-  if (!(isfinite(fx1) && isfinite(fy1))) return -1;
-  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return -1;
-  const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
-  int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
-  int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
-  bx = min(max(bx, 0), T.W - 1);
-  by = min(max(by, 0), T.H - 1);
-  return by * T.W + bx;
+  float4 loc, n;
+  int ai, bi;
+  return densePixelGeometry(T, ix, iy, f, loc, n, ai, bi) ? bi : -1;
 }
 
 // Constants of the directed pair, wave-uniform (SGPRs: a VALU instruction takes one scalar operand).
@@ -844,12 +824,9 @@ constexpr int kDlChunk = 4096;   // pixels per workgroup
 __device__ __forceinline__ bool denseCandidate(const Table& T, int pix, unsigned int m, float2 f, float4& loc) {
   if (!m) return false;
   const int iy = pix / T.W, ix = pix - iy * T.W;
-  const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-  if (!(isfinite(fx1) && isfinite(fy1))) return false;
-  const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-  if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
-  loc = make_float4(__fmul_rn(static_cast<float>(ix), T.sx), __fmul_rn(static_cast<float>(iy), T.sy), __fmul_rn(fx1, T.sx), __fmul_rn(fy1, T.sy));
-  return true;
+  float4 n;
+  int ai, bi;
+  return densePixelGeometry(T, ix, iy, f, loc, n, ai, bi);
 }
 // pass 1: candidates per (pair, chunk); pass 2 (offsets != nullptr): write them at the chunk's offset in pixel order
 inline __global__ __launch_bounds__(256) void k_dense_list(Table T, int chunksPerPair, int* __restrict__ counts,

@@ -37,34 +37,52 @@ struct Table {
   float sx, sy, invAspect;      // loc = pixel * (1 / W, invAspect / H), float as in the reference (:371)
 };
 
-// Dense mode, the part of a constraint that follows its mask byte and flow vector `f` (both of which the kernels request
-// one trip ahead, RecordStream): bounds test of the rounded target, scaling, Observation constructor incl. the two depths.
-__device__ __forceinline__ bool denseConstraintFromFlow(const Table& T, long long c, long long pixBase, int fa, int fb, float2 f,
-                                                        float4& n, float2& d) {
-  const int pix = static_cast<int>(c - pixBase);
-  const int iy = pix / T.W, ix = pix - iy * T.W;
+// Dense mode: everything about a pixel's constraint that follows from its position and flow vector `f` -- ONE statement of the
+// reference's float arithmetic for every kernel that reads the images (product, cost, walk, grid x grid, list materialisation):
+// candidate test of FlowConstraintsCollection::compute (lib/FlowConstraints.cpp:436-460: target int(x + flow + 0.5) in bounds),
+// constraint scaling (:371), the Observation constructor's pixel-edge NDC and truncating depth fetch (lib/PoseOptimizer.cpp:104-116).
+// loc = (source x, y, target x, y) in [0, 1] x [0, invAspect]; n = ndc of both end points; ai / bi = the pixels whose source depths
+// the two observations read (not always the constraint's own pixel: the fetch truncates loc * raster).  false: no candidate.
+__device__ __forceinline__ int densePixelOfLoc(const Table& T, float lx, float ly) {
+  int px = static_cast<int>(__fmul_rn(lx, static_cast<float>(T.W)));
+  int py = static_cast<int>(__fmul_rn(__fdiv_rn(ly, T.invAspect), static_cast<float>(T.H)));
+  px = min(max(px, 0), T.W - 1);
+  py = min(max(py, 0), T.H - 1);
+  return py * T.W + px;
+}
+__device__ __forceinline__ bool densePixelGeometry(const Table& T, int ix, int iy, float2 f, float4& loc, float4& n, int& ai, int& bi) {
   const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
   if (!(isfinite(fx1) && isfinite(fy1))) return false;
   const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
   if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
   const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
   const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
+  loc = make_float4(lx0, ly0, lx1, ly1);
   n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
   n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
   n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
   n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
-  int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
-  int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
-  int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
-  int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
-  ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
-  bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
-  const size_t fs = static_cast<size_t>(T.W) * T.H;
-  const float da = T.depth[fa * fs + static_cast<size_t>(ay) * T.W + ax];
-  const float db = T.depth[fb * fs + static_cast<size_t>(by) * T.W + bx];
-  if (!(isfinite(da) && da > 0.f && isfinite(db) && db > 0.f)) return false;
-  d = make_float2(da, db);
+  ai = densePixelOfLoc(T, lx0, ly0);
+  bi = densePixelOfLoc(T, lx1, ly1);
   return true;
+}
+// ... + the two depths, REQUESTED only (a kernel that runs its loads ahead tests the values when it uses them)
+__device__ __forceinline__ bool denseConstraintRequest(const Table& T, int pix, int fa, int fb, float2 f, float4& n, float2& d) {
+  const int iy = pix / T.W, ix = pix - iy * T.W;
+  float4 loc;
+  int ai, bi;
+  d = make_float2(0.f, 0.f);
+  if (!densePixelGeometry(T, ix, iy, f, loc, n, ai, bi)) return false;
+  const size_t fs = static_cast<size_t>(T.W) * T.H;
+  d.x = T.depth[fa * fs + ai];
+  d.y = T.depth[fb * fs + bi];
+  return true;
+}
+__device__ __forceinline__ bool denseDepthsValid(float2 d) { return isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f; }
+// ... and tested (lib/PoseOptimizer.cpp:1190-1193: an invalid depth skips the whole constraint)
+__device__ __forceinline__ bool denseConstraintFromFlow(const Table& T, long long c, long long pixBase, int fa, int fb, float2 f,
+                                                        float4& n, float2& d) {
+  return denseConstraintRequest(T, static_cast<int>(c - pixBase), fa, fb, f, n, d) && denseDepthsValid(d);
 }
 
 // One constraint of the pair-major / frame-major fast kernels: (ndc of both end points, the two source depths); false =
@@ -143,30 +161,8 @@ struct DenseStreamAhead {
   float4 ndCur;        // pixel i: candidate, ndc, depths (requested; validity is tested when they are used)
   float2 dCur;
   bool candCur;
-  // candidate test + ndc + the REQUEST of the two depths (denseConstraintFromFlow without its test of the depth values)
   __device__ __forceinline__ bool request(const Table& T, int pix, int fa, int fb, float2 f, float4& n, float2& d) const {
-    d = make_float2(0.f, 0.f);
-    const int iy = pix / T.W, ix = pix - iy * T.W;
-    const float fx1 = __fadd_rn(static_cast<float>(ix), f.x), fy1 = __fadd_rn(static_cast<float>(iy), f.y);
-    if (!(isfinite(fx1) && isfinite(fy1))) return false;
-    const int ix1 = static_cast<int>(__fadd_rn(fx1, 0.5f)), iy1 = static_cast<int>(__fadd_rn(fy1, 0.5f));
-    if (ix1 < 0 || ix1 >= T.W || iy1 < 0 || iy1 >= T.H) return false;
-    const float lx0 = __fmul_rn(static_cast<float>(ix), T.sx), ly0 = __fmul_rn(static_cast<float>(iy), T.sy);
-    const float lx1 = __fmul_rn(fx1, T.sx), ly1 = __fmul_rn(fy1, T.sy);
-    n.x = __fadd_rn(-1.f, __fmul_rn(2.f, lx0));
-    n.y = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly0), T.invAspect));
-    n.z = __fadd_rn(-1.f, __fmul_rn(2.f, lx1));
-    n.w = __fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, ly1), T.invAspect));
-    int ax = static_cast<int>(__fmul_rn(lx0, static_cast<float>(T.W)));
-    int ay = static_cast<int>(__fmul_rn(__fdiv_rn(ly0, T.invAspect), static_cast<float>(T.H)));
-    int bx = static_cast<int>(__fmul_rn(lx1, static_cast<float>(T.W)));
-    int by = static_cast<int>(__fmul_rn(__fdiv_rn(ly1, T.invAspect), static_cast<float>(T.H)));
-    ax = min(max(ax, 0), T.W - 1); ay = min(max(ay, 0), T.H - 1);
-    bx = min(max(bx, 0), T.W - 1); by = min(max(by, 0), T.H - 1);
-    const size_t fs = static_cast<size_t>(T.W) * T.H;
-    d.x = T.depth[fa * fs + static_cast<size_t>(ay) * T.W + ax];
-    d.y = T.depth[fb * fs + static_cast<size_t>(by) * T.W + bx];
-    return true;
+    return denseConstraintRequest(T, pix, fa, fb, f, n, d);
   }
   __device__ __forceinline__ void prime(const Table& T, long long base, int i, int step, int n, long long pixBase, int fa, int fb) {
     unsigned int m0 = 0u;
@@ -188,7 +184,7 @@ struct DenseStreamAhead {
     mNext = 0u;
     if (i + 2 * step < n) { mNext = (T.fmask + base)[i + 2 * step]; fNext = (T.flow + base)[i + 2 * step]; }
     candCur = m1 != 0u && request(T, static_cast<int>(base - pixBase) + i + step, fa, fb, f1, ndCur, dCur);
-    return cand && isfinite(d.x) && d.x > 0.f && isfinite(d.y) && d.y > 0.f;
+    return cand && denseDepthsValid(d);
   }
 };
 
