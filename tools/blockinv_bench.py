@@ -1,10 +1,14 @@
 """How the per-frame block inverse (k_block_inverse_mfma) scales with the number of frames at B = 177: one workgroup per frame, 256 CUs.
 usage (GPU box): rocprofv3 --kernel-trace --stats -d out -- python tools/blockinv_bench.py   (kernel durations in the trace)
 or: python tools/blockinv_bench.py  (wall clock around the debug entry point: includes the transfers -- differences only)"""
-import sys, time
+import os
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from robust_cvd_amd import api
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from robust_cvd_amd import api  # noqa: E402
 
 B = 177
 rng = np.random.default_rng(0)
